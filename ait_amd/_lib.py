@@ -1,0 +1,67 @@
+"""ctypes binding of libait_hip.so (include/ait_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a tensor is not on a
+GPU, the call raises.  PyTorch is used only for device memory and streams.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libait_hip.so")
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/ait_hip.h one to one
+SIGNATURES = {
+    "ait_abi_version": (_i, []),
+    "ait_strerror": (ctypes.c_char_p, [_i]),
+    "ait_roi_align_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "ait_roi_align_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "ait_nms_workspace_bytes": (_sz, [_i]),
+    "ait_nms": (_i, [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class AitHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AitHipError(
+                "libait_hip.so is missing (%s): run `python -m ait_amd.build` -- there is no "
+                "CPU fallback for the hot path" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise AitHipError("%s failed: %s (%d)" % (what, lib().ait_strerror(rc).decode(), rc))
+
+
+def dev_ptr(t: torch.Tensor, dtype=torch.float32):
+    """data_ptr of a contiguous GPU tensor of the given dtype (else raise)."""
+    if not t.is_cuda:
+        raise AitHipError("tensor must live on a GPU (got %s): the hot path has no CPU fallback"
+                          % t.device)
+    if t.dtype != dtype:
+        raise AitHipError("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise AitHipError("tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def cur_stream(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,81 @@
+/* include/ait_hip.h -- C ABI of libait_hip.so, the MI355X (gfx950) implementation of AIT's
+ * proposal-query matching hot path.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers + sizes; every pointer is DEVICE memory unless it says host.
+ *   - the caller owns every buffer including workspaces; nothing is allocated inside.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call only
+ *     enqueues work on that stream and returns -- no host synchronisation.
+ *   - returns AIT_OK (0) or a negative AIT_E* code; no C++ exception crosses the boundary.
+ *   - re-entrant; no global mutable state; safe to call concurrently on different devices
+ *     (the kernels run on the device that is current for the calling thread).
+ *   - tensors are fp32, contiguous, row-major / NCHW unless stated.
+ *
+ * Each function names the reference interface it replaces (paths relative to the reference
+ * repository root).
+ */
+#ifndef AIT_HIP_H_
+#define AIT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIT_OK 0
+#define AIT_EINVAL (-1)   /* bad argument (NULL pointer, non-positive size, unsupported shape) */
+#define AIT_EWORKSPACE (-2) /* workspace too small */
+#define AIT_ELAUNCH (-3)  /* hipLaunchKernel / hipMemsetAsync reported an error */
+#define AIT_EUNSUPPORTED (-4)
+
+/* ABI version; bumped on any signature change. */
+int ait_abi_version(void);
+const char* ait_strerror(int code);
+
+/* ---------------------------------------------------------------------------------------
+ * RoIAlign.  Replaces model._C.roi_align_forward / roi_align_backward
+ *   (lib/model/csrc/vision.cpp:9-10, lib/model/csrc/ROIAlign.h:11-45; kernels
+ *    lib/model/csrc/cuda/ROIAlign_cuda.cu:65-122,178-254; CPU semantics
+ *    lib/model/csrc/cpu/ROIAlign_cpu.cpp:113-219).
+ *   feat      [B,C,H,W]
+ *   rois      [n_rois,5] = (batch_index, x1, y1, x2, y2) in image pixels
+ *   out       [n_rois,C,PH,PW]
+ *   grad_in   [B,C,H,W], zero-filled by the call before the scatter (the reference
+ *             allocates a zero tensor, ROIAlign_cuda.cu:316)
+ * sampling_ratio <= 0 selects the adaptive grid ceil(roi/P) (ROIAlign_cpu.cpp:161-165).
+ * RoIs whose batch index is outside [0,B) produce zeros / contribute nothing.
+ * ------------------------------------------------------------------------------------- */
+int ait_roi_align_fwd(const float* feat, const float* rois, int n_rois, int B, int C, int H,
+                      int W, int PH, int PW, float spatial_scale, int sampling_ratio,
+                      float* out, void* stream);
+int ait_roi_align_bwd(const float* grad_out, const float* rois, int n_rois, int B, int C,
+                      int H, int W, int PH, int PW, float spatial_scale, int sampling_ratio,
+                      float* grad_in, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * NMS.  Replaces model._C.nms (lib/model/csrc/vision.cpp:8, lib/model/csrc/nms.h:10-28)
+ * with the CPU reference's semantics (lib/model/csrc/cpu/nms_cpu.cpp:5-65): +1 pixel
+ * convention, a box is suppressed when IoU >= thr, survivors are reported as ORIGINAL
+ * indices in ascending order.
+ *   boxes     [n,4] (x1,y1,x2,y2)
+ *   order     [n] int64 permutation sorting the boxes by descending score, or NULL when the
+ *             boxes are already sorted (the only way rpn/proposal_layer.py:153 calls it)
+ *   keep      [n] int64, first *n_keep entries valid
+ *   n_keep    [1] int32 (device)
+ *   max_keep  > 0: stop after that many survivors IN SCORE ORDER have been found
+ *             (proposal_layer.py:156-157 keeps only the first post_nms_topN); only legal
+ *             with order == NULL, where score order == index order.  <= 0: no limit.
+ * Everything (IoU bitmask, greedy scan, compaction) runs on the device; unlike
+ * lib/model/csrc/cuda/nms.cu:99-123 there is no device->host copy and no host scan.
+ * ------------------------------------------------------------------------------------- */
+size_t ait_nms_workspace_bytes(int n);
+int ait_nms(const float* boxes, const int64_t* order, int n, float thr, int max_keep,
+            void* workspace, size_t workspace_bytes, int64_t* keep, int32_t* n_keep,
+            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIT_HIP_H_ */

@@ -1,0 +1,36 @@
+"""The C-ABI library builds for gfx950 on a GPU-less host, loads, and exports exactly the
+symbols include/ait_hip.h declares (no compute calls here)."""
+import os
+import re
+
+from ait_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "ait_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ait_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    path = build.build()
+    assert os.path.exists(path)
+    L = _lib.lib()
+    names = _declared()
+    assert names, "no declarations parsed from include/ait_hip.h"
+    for n in names:
+        assert hasattr(L, n), "libait_hip.so does not export %s" % n
+    assert sorted(_lib.SIGNATURES) == names, (sorted(_lib.SIGNATURES), names)
+    assert L.ait_abi_version() >= 1
+    assert L.ait_strerror(0) == b"ok"
+    assert L.ait_nms_workspace_bytes(12000) >= 12000 * 188 * 8
+
+
+def test_code_object_is_gfx950():
+    import subprocess
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", build.LIB],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    blob = open(build.LIB, "rb").read()
+    assert b"gfx950" in blob or "gfx950" in out

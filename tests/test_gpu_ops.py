@@ -1,0 +1,110 @@
+"""GPU parity tests for the HIP RoIAlign / NMS kernels, called through the C ABI, against the
+CPU oracle (oracle/native.c) and the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, native
+from oracle.digest import seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_roi_align_fwd_golden(golden):
+    from ait_amd.roi_layers import ROIAlign
+    g = golden("g4_roi_align")
+    feat, rois = cases.roi_align_case()
+    y = ROIAlign((7, 7), 1.0 / 16.0, 0)(_dev(feat), _dev(rois)).cpu().numpy()
+    # identical fp32 operation sequence (no FMA contraction) -> expected bit-exact; the stated
+    # tolerance for the contract is 1e-6 relative
+    np.testing.assert_allclose(y, g["y"], rtol=1e-6, atol=1e-7)
+    y2 = ROIAlign((7, 7), 1.0 / 16.0, 2)(_dev(feat), _dev(rois)).cpu().numpy()
+    np.testing.assert_allclose(y2, g["y_sr2"], rtol=1e-6, atol=1e-7)
+    feat_r = seeded(402, (2, 8, cases.FEAT_H, cases.FEAT_W))
+    rois_r = cases.random_rois(403, 64, 2)
+    y3 = ROIAlign((7, 7), 1.0 / 16.0, 0)(_dev(feat_r), _dev(rois_r)).cpu().numpy()
+    np.testing.assert_allclose(y3, g["y_rand"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("C,n", [(1024, 300), (40, 17), (3, 1)])
+def test_roi_align_fwd_bwd_vs_oracle(C, n):
+    from ait_amd.roi_layers import roi_align
+    feat = seeded(7, (2, C, cases.FEAT_H, cases.FEAT_W))
+    rois = cases.random_rois(8, n, 2)
+    x = _dev(feat).requires_grad_(True)
+    y = roi_align(x, _dev(rois), (7, 7), 1.0 / 16.0, 0)
+    want = native.roi_align_fwd(feat, rois)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+    g = seeded(9, tuple(y.shape))
+    y.backward(_dev(g))
+    gwant = native.roi_align_bwd(g, rois, feat.shape)
+    # atomics: order-dependent last-ulp differences; sums of up to ~n*gh*gw terms
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gwant, rtol=1e-4, atol=1e-4)
+
+
+def test_roi_align_empty_and_bad_batch_index():
+    from ait_amd.roi_layers import roi_align
+    feat = _dev(seeded(1, (1, 8, 10, 12)))
+    y = roi_align(feat, torch.zeros((0, 5), device="cuda"), (7, 7), 1.0 / 16.0, 0)
+    assert tuple(y.shape) == (0, 8, 7, 7)
+    rois = torch.tensor([[3, 0, 0, 50, 50]], dtype=torch.float32, device="cuda")
+    assert float(roi_align(feat, rois, (7, 7), 1.0 / 16.0, 0).abs().sum()) == 0.0
+
+
+def test_roi_align_requires_gpu_tensor():
+    from ait_amd import _lib
+    from ait_amd.roi_layers import roi_align
+    with pytest.raises(_lib.AitHipError):
+        roi_align(torch.zeros(1, 1, 4, 4), torch.zeros(1, 5), (7, 7), 1.0, 0)
+
+
+@pytest.mark.parametrize("n", cases.NMS_SIZES)
+@pytest.mark.parametrize("thr", cases.NMS_THRESHOLDS)
+def test_nms_bit_exact_vs_golden(golden, n, thr):
+    from ait_amd.roi_layers import nms, nms_sorted
+    g = golden("g5_nms")
+    box, sc = cases.nms_boxes(500 + n, n)
+    want = g["keep_n%d_t%02d" % (n, int(thr * 10))]
+    keep = nms(_dev(box), _dev(sc), thr)
+    assert keep.dtype == torch.int64
+    assert np.array_equal(keep.cpu().numpy(), want)
+    # pre-sorted entry point with early exit after post_nms_topN survivors
+    for topn in (0, 300, 2000):
+        k, cnt = nms_sorted(_dev(box), thr, topn)
+        cnt = int(cnt.item())
+        ref = want if topn == 0 else want[:topn]
+        assert cnt == len(ref)
+        assert np.array_equal(k[:cnt].cpu().numpy(), ref)
+
+
+def test_nms_ties_and_unsorted_scores(golden):
+    from ait_amd.roi_layers import nms
+    g = golden("g5_nms")
+    box, sc = cases.nms_tie_case()
+    for thr in (0.7, 0.5, 0.3):
+        assert np.array_equal(nms(_dev(box), _dev(sc), thr).cpu().numpy(),
+                              g["keep_tie_t%02d" % int(thr * 10)])
+    box2, sc2 = cases.nms_boxes(777, 2000, integer=True)
+    assert np.array_equal(nms(_dev(box2), _dev(sc2), 0.7).cpu().numpy(), g["keep_int2000_t07"])
+    # scores in arbitrary order: survivors still reported as ascending original indices
+    rs = np.random.RandomState(3)
+    perm = rs.permutation(len(sc2))
+    got = nms(_dev(box2[perm]), _dev(sc2[perm]), 0.7).cpu().numpy()
+    want = native.nms(box2[perm], sc2[perm], 0.7)
+    assert np.array_equal(got, want)
+    assert nms(torch.zeros((0, 4), device="cuda"), torch.zeros((0,), device="cuda"), 0.7).numel() == 0
+
+
+def test_nms_idempotent_at_full_size():
+    """Size-independent property at the TRAIN pre-NMS size: NMS of the survivors keeps all."""
+    from ait_amd.roi_layers import nms
+    box, sc = cases.nms_boxes(4242, 12000)
+    b, s = _dev(box), _dev(sc)
+    keep = nms(b, s, 0.7)
+    again = nms(b[keep], s[keep], 0.7)
+    assert again.numel() == keep.numel()
+    assert np.array_equal(again.cpu().numpy(), np.arange(keep.numel()))

@@ -23,6 +23,7 @@ class _ROIAlign(Function):
         if roi.dim() != 2 or roi.size(1) != 5:
             raise ValueError("rois must be [K,5] (batch_index, x1, y1, x2, y2)")
         B, C, H, W = input.shape
+        _lib.dev_ptr(input)  # raises unless this is a GPU fp32 tensor: no CPU fallback
         out = torch.empty((roi.size(0), C, ph, pw), dtype=input.dtype, device=input.device)
         with torch.cuda.device(input.device):
             rc = _lib.lib().ait_roi_align_fwd(
@@ -72,6 +73,7 @@ def nms_sorted(dets, threshold, max_keep=0):
     rpn/proposal_layer.py:153 passes).  Returns (keep[int64, n], n_keep[int32 device scalar]):
     no host synchronisation; keep[:n_keep] are the survivors in ascending index order."""
     dets = dets.contiguous().float()
+    _lib.dev_ptr(dets)
     n = dets.size(0)
     keep = torch.empty((max(n, 1),), dtype=torch.int64, device=dets.device)
     n_keep = torch.zeros((1,), dtype=torch.int32, device=dets.device)
@@ -92,6 +94,7 @@ def nms(dets, scores, threshold):
     if dets.numel() == 0:
         return torch.empty((0,), dtype=torch.int64, device=dets.device)
     dets = dets.contiguous().float()
+    _lib.dev_ptr(dets)
     n = dets.size(0)
     order = torch.sort(scores.float(), 0, descending=True, stable=True)[1].contiguous()
     keep = torch.empty((n,), dtype=torch.int64, device=dets.device)

@@ -75,6 +75,39 @@ int ait_nms(const float* boxes, const int64_t* order, int n, float thr, int max_
             void* workspace, size_t workspace_bytes, int64_t* keep, int32_t* n_keep,
             void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32
+ * accumulate).  Replaces the ATen matmul / addmm / 1x1-conv calls behind
+ *   nn.Linear w_qs/w_ks/w_vs/fc      lib/model/system/SubLayers.py:51-58,77-79,97
+ *   nn.Linear w_1/w_2                lib/model/system/SubLayers.py:172-173,181
+ *   conv2d_1x1 enc_emb/dec_emb/dec_trans  lib/model/system/Models.py:188-193,207-209,246-247,278
+ * and their autograd backward products.
+ *
+ *   C (op)= alpha * opA(A) . opB(B) [+ bias] [+ residual], optional ReLU
+ *   trans_a == 0: A is [M,K] row-major (lda >= K);  trans_a != 0: A is [K,M] (lda >= M)
+ *   trans_b == 0: B is [K,N] row-major (ldb >= N);  trans_b != 0: B is [N,K] (ldb >= K)
+ *                 (trans_b != 0 is the nn.Linear layout: y = x W^T)
+ *   bias     [N], or [M] with AIT_GEMM_BIAS_ROW; may be NULL
+ *   residual same addressing as C; may be NULL
+ *   c_colblk == 0: C(i,j) at C[i*ldc + j].
+ *   c_colblk  > 0: C(i,j) at C[(j / c_colblk) * c_batch_stride + i*ldc + (j % c_colblk)]
+ *                  (writes a [channel, token] product straight into an NCHW tensor:
+ *                   dec_trans, Models.py:276-278)
+ *   flags    AIT_GEMM_RELU | AIT_GEMM_ACCUMULATE (C += ...) | AIT_GEMM_ATOMIC | AIT_GEMM_BIAS_ROW
+ *   split_k  > 1 splits the reduction over gridDim.z; requires AIT_GEMM_ATOMIC (partial tiles
+ *            are combined with fp32 atomics into C, which the caller has zeroed or wants
+ *            accumulated into) and no bias / residual / ReLU.
+ * Requirements: lda, ldb, K multiples of 4; A, B 16-byte aligned (else AIT_EUNSUPPORTED).
+ * ------------------------------------------------------------------------------------- */
+#define AIT_GEMM_RELU 1
+#define AIT_GEMM_ACCUMULATE 2
+#define AIT_GEMM_ATOMIC 4
+#define AIT_GEMM_BIAS_ROW 8
+int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
+                 int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
+                 const float* residual, int flags, int split_k, int c_colblk,
+                 long long c_batch_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

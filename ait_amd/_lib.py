@@ -21,7 +21,11 @@ SIGNATURES = {
     "ait_roi_align_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "ait_nms_workspace_bytes": (_sz, [_i]),
     "ait_nms": (_i, [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
+    "ait_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
+                          _i, ctypes.c_longlong, _vp]),
 }
+
+GEMM_RELU, GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_BIAS_ROW = 1, 2, 4, 8
 
 _lib = None
 

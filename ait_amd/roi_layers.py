@@ -96,7 +96,7 @@ def nms(dets, scores, threshold):
     dets = dets.contiguous().float()
     _lib.dev_ptr(dets)
     n = dets.size(0)
-    order = torch.sort(scores.float(), 0, descending=True, stable=True)[1].contiguous()
+    order = torch.sort(scores.float(), dim=0, descending=True, stable=True)[1].contiguous()
     keep = torch.empty((n,), dtype=torch.int64, device=dets.device)
     n_keep = torch.zeros((1,), dtype=torch.int32, device=dets.device)
     L = _lib.lib()

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libait_hip.so")
 
 _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_ll, _ull = ctypes.c_longlong, ctypes.c_ulonglong
 
 # name -> (restype, argtypes); mirrors include/ait_hip.h one to one
 SIGNATURES = {
@@ -23,9 +24,18 @@ SIGNATURES = {
     "ait_nms": (_i, [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
     "ait_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
                           _i, ctypes.c_longlong, _vp]),
+    "ait_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp, _vp, _vp]),
+    "ait_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _ull, _vp, _vp,
+                        _vp, _vp, _vp]),
+    "ait_sh_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ait_sh_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "ait_attn_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp,
+                          _vp]),
+    "ait_attn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _ull, _vp, _i,
+                          _vp, _i, _vp, _i, _vp]),
 }
 
-GEMM_RELU, GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_BIAS_ROW = 1, 2, 4, 8
+GEMM_RELU, GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_BIAS_ROW, GEMM_MASK_POS = 1, 2, 4, 8, 16
 
 _lib = None
 

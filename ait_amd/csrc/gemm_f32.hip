@@ -183,6 +183,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(const GemmArgs g)
   const bool accum = (g.flags & AIT_GEMM_ACCUMULATE) != 0;
   const bool relu = (g.flags & AIT_GEMM_RELU) != 0;
   const bool bias_row = (g.flags & AIT_GEMM_BIAS_ROW) != 0;
+  const bool mask_pos = (g.flags & AIT_GEMM_MASK_POS) != 0;
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -206,7 +207,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(const GemmArgs g)
           continue;
         }
         v += bias_row ? (g.bias ? g.bias[row] : 0.f) : bcol;
-        if (g.residual) v += g.residual[off];
+        if (mask_pos) {
+          if (!(g.residual[off] > 0.f)) v = 0.f;  // ReLU backward: gate by the saved activation
+        } else if (g.residual) {
+          v += g.residual[off];
+        }
         if (accum) v += g.C[off];
         if (relu) v = fmaxf(v, 0.f);
         g.C[off] = v;
@@ -242,6 +247,7 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   if (split_k > 1 && !(flags & AIT_GEMM_ATOMIC)) return AIT_EINVAL;
   if ((flags & AIT_GEMM_ATOMIC) && (bias || residual || (flags & AIT_GEMM_RELU)))
     return AIT_EINVAL;
+  if ((flags & AIT_GEMM_MASK_POS) && !residual) return AIT_EINVAL;
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.residual = residual;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;

@@ -1,0 +1,383 @@
+// ait_amd/csrc/rowwise.hip -- the HBM-bound row kernels of the AIT path for gfx950:
+//   * ait_ln_fwd / ait_ln_bwd   y = LayerNorm_eps( dropout(a[src_row] + pos[t]) + residual )
+//       covers the encoder / decoder prologue (lib/model/system/Models.py:98-99,155-156, with the
+//       zero padding of :269-270 and the repeat over proposals of :250 folded into the row map)
+//       and the post-attention / post-FFN "dropout, += residual, LayerNorm" tails
+//       (lib/model/system/SubLayers.py:97-100,182-185).
+//   * ait_sh_fwd / ait_sh_bwd   selective heads (SHBlock, SubLayers.py:22-39) + the head sum
+//       of MultiHeadAttention.forward (SubLayers.py:92).
+//
+// Wave64 design: one wavefront per 512-float row (8 floats per lane = two 16-B loads), wave
+// reductions by DPP/shuffle butterflies, no LDS on the forward path; everything is sized so a
+// row is read once and written once.  Dropout is a stateless counter-based hash of
+// (seed, element index), recomputed (not stored) in the backward pass.
+#include "common.h"
+
+namespace {
+
+constexpr int kD = 512;      // d_model of the AIT path (channels / 2)
+constexpr int kVec = 8;      // floats per lane
+constexpr int kRowsPerBlock = 4;
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+// keep-probability 1-p decision for element `idx` of dropout site `seed`
+__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx,
+                                            float p, float inv_keep) {
+  unsigned h = mix32((unsigned)idx ^ mix32((unsigned)(idx >> 32) + (unsigned)seed) ^
+                     (unsigned)(seed >> 32) * 0x9e3779b9u);
+  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.f;
+}
+
+struct RowMap {
+  int seq_len, src_rows, rep;
+};
+// out row r=(q,t) -> source row of `a`, or -1 for a zero (padding) row
+__device__ __forceinline__ long long src_row(const RowMap m, long long r) {
+  const long long q = r / m.seq_len;
+  const int t = (int)(r - q * m.seq_len);
+  if (t >= m.src_rows) return -1;
+  return (q / m.rep) * m.src_rows + t;
+}
+
+__device__ __forceinline__ void load8(const float* __restrict__ p, float (&v)[kVec]) {
+  const float4 a = reinterpret_cast<const float4*>(p)[0];
+  const float4 b = reinterpret_cast<const float4*>(p)[1];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8(float* __restrict__ p, const float (&v)[kVec]) {
+  reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// z = dropout(a + pos) + residual for this lane's 8 columns of out row r
+__device__ __forceinline__ void form_z(const float* __restrict__ a, const float* __restrict__ pos,
+                                       const float* __restrict__ res, const RowMap m, long long r,
+                                       int c0, float p, float inv_keep, unsigned long long seed,
+                                       float (&z)[kVec], float (&ds)[kVec]) {
+  const long long sr = src_row(m, r);
+  if (sr >= 0) load8(a + sr * kD + c0, z);
+  else {
+#pragma unroll
+    for (int i = 0; i < kVec; i++) z[i] = 0.f;
+  }
+  if (pos) {
+    float pv[kVec];
+    load8(pos + (size_t)(r % m.seq_len) * kD + c0, pv);
+#pragma unroll
+    for (int i = 0; i < kVec; i++) z[i] += pv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < kVec; i++) {
+    ds[i] = (p > 0.f) ? drop_scale(seed, (unsigned long long)r * kD + c0 + i, p, inv_keep) : 1.f;
+    z[i] *= ds[i];
+  }
+  if (res) {
+    float rv[kVec];
+    load8(res + (size_t)r * kD + c0, rv);
+#pragma unroll
+    for (int i = 0; i < kVec; i++) z[i] += rv[i];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void ln_fwd_kernel(
+    const float* __restrict__ a, const float* __restrict__ pos, const float* __restrict__ res,
+    const float* __restrict__ gamma, const float* __restrict__ beta, long long rows, RowMap m,
+    float eps, float p, unsigned long long seed, float* __restrict__ y, float* __restrict__ mean,
+    float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = lane * kVec;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float g[kVec], b[kVec];
+  load8(gamma + c0, g);
+  load8(beta + c0, b);
+  for (long long r = (long long)blockIdx.x * kRowsPerBlock + wave; r < rows;
+       r += (long long)gridDim.x * kRowsPerBlock) {
+    float z[kVec], ds[kVec];
+    form_z(a, pos, res, m, r, c0, p, inv_keep, seed, z, ds);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kVec; i++) s += z[i];
+    const float mu = wave_sum(s) * (1.f / kD);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kVec; i++) {
+      const float d = z[i] - mu;
+      q += d * d;
+    }
+    const float var = wave_sum(q) * (1.f / kD);  // biased, like nn.LayerNorm
+    const float rs = 1.f / sqrtf(var + eps);
+    float o[kVec];
+#pragma unroll
+    for (int i = 0; i < kVec; i++) o[i] = (z[i] - mu) * rs * g[i] + b[i];
+    store8(y + (size_t)r * kD + c0, o);
+    if (lane == 0) {
+      if (mean) mean[r] = mu;
+      if (rstd) rstd[r] = rs;
+    }
+  }
+}
+
+// dgamma/dbeta: per-lane partials over the rows of this block, summed across the 4 waves in
+// LDS, then ONE atomic per column per block.
+__global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ a, const float* __restrict__ pos,
+    const float* __restrict__ res, const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ rstd, long long rows, RowMap m, float p, unsigned long long seed,
+    float* __restrict__ da, float* __restrict__ dres, float* __restrict__ dgamma,
+    float* __restrict__ dbeta) {
+  __shared__ float red[2][kRowsPerBlock][kD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = lane * kVec;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  float g[kVec], dg[kVec], db[kVec];
+  load8(gamma + c0, g);
+#pragma unroll
+  for (int i = 0; i < kVec; i++) dg[i] = db[i] = 0.f;
+  for (long long r = (long long)blockIdx.x * kRowsPerBlock + wave; r < rows;
+       r += (long long)gridDim.x * kRowsPerBlock) {
+    float z[kVec], ds[kVec], d[kVec];
+    form_z(a, pos, res, m, r, c0, p, inv_keep, seed, z, ds);
+    load8(dy + (size_t)r * kD + c0, d);
+    const float mu = mean[r], rs = rstd[r];
+    float s1 = 0.f, s2 = 0.f, xh[kVec], wd[kVec];
+#pragma unroll
+    for (int i = 0; i < kVec; i++) {
+      xh[i] = (z[i] - mu) * rs;
+      wd[i] = d[i] * g[i];
+      s1 += wd[i];
+      s2 += wd[i] * xh[i];
+      dg[i] += d[i] * xh[i];
+      db[i] += d[i];
+    }
+    s1 = wave_sum(s1) * (1.f / kD);
+    s2 = wave_sum(s2) * (1.f / kD);
+    float dz[kVec];
+#pragma unroll
+    for (int i = 0; i < kVec; i++) dz[i] = (wd[i] - s1 - xh[i] * s2) * rs;
+    if (dres) store8(dres + (size_t)r * kD + c0, dz);
+    if (da) {
+      long long orow = r;
+      if (m.rep == 1) orow = src_row(m, r);  // source indexing; padded rows have no source
+      if (orow >= 0) {
+#pragma unroll
+        for (int i = 0; i < kVec; i++) dz[i] *= ds[i];
+        store8(da + (size_t)orow * kD + c0, dz);
+      }
+    }
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int i = 0; i < kVec; i++) {
+      red[0][wave][c0 + i] = dg[i];
+      red[1][wave][c0 + i] = db[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < kD; c += kThreads) {
+      float sg = 0.f, sb = 0.f;
+#pragma unroll
+      for (int w = 0; w < kRowsPerBlock; w++) {
+        sg += red[0][w][c];
+        sb += red[1][w][c];
+      }
+      unsafeAtomicAdd(dgamma + c, sg);
+      unsafeAtomicAdd(dbeta + c, sb);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Selective heads.  O [n_seq, 8, 64, 64] (head, token, channel).  One 256-thread workgroup per
+// sequence; thread = (token group tq = tid>>6 of 16 tokens, channel c = tid&63), so every global
+// access is a coalesced 256-B row of 64 channels.
+// ---------------------------------------------------------------------------------------------
+constexpr int kH = 8, kT = 64, kC = 64;
+
+__global__ __launch_bounds__(kThreads) void sh_fwd_kernel(
+    const float* __restrict__ O, const float* __restrict__ sk_w, const float* __restrict__ sk_b,
+    float* __restrict__ u, float* __restrict__ gate_out, float* __restrict__ s_out) {
+  __shared__ float part[4][kC];
+  __shared__ float s[kC];
+  __shared__ float gate[kH * kC];
+  const int n = blockIdx.x, tid = threadIdx.x, c = tid & 63, tq = tid >> 6;
+  const float* __restrict__ On = O + (size_t)n * kH * kT * kC;
+  float acc = 0.f;
+  for (int h = 0; h < kH; h++)
+    for (int t = tq * 16; t < tq * 16 + 16; t++) acc += On[(h * kT + t) * kC + c];
+  part[tq][c] = acc;
+  __syncthreads();
+  if (tid < kC) {
+    const float v = (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) * (1.f / kT);
+    s[tid] = v;
+    if (s_out) s_out[(size_t)n * kC + tid] = v;
+  }
+  __syncthreads();
+  for (int j = tid; j < kH * kC; j += kThreads) {  // g = sk_w s + sk_b
+    const float4* __restrict__ w = reinterpret_cast<const float4*>(sk_w + (size_t)j * kC);
+    float d = sk_b[j];
+#pragma unroll
+    for (int q = 0; q < kC / 4; q++) {
+      const float4 wv = w[q];
+      d += wv.x * s[4 * q] + wv.y * s[4 * q + 1] + wv.z * s[4 * q + 2] + wv.w * s[4 * q + 3];
+    }
+    gate[j] = d;
+  }
+  __syncthreads();
+  if (tid < kC) {  // softmax over the 8 heads, per channel
+    float mx = gate[tid];
+#pragma unroll
+    for (int h = 1; h < kH; h++) mx = fmaxf(mx, gate[h * kC + tid]);
+    float e[kH], sum = 0.f;
+#pragma unroll
+    for (int h = 0; h < kH; h++) {
+      e[h] = expf(gate[h * kC + tid] - mx);
+      sum += e[h];
+    }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int h = 0; h < kH; h++) gate[h * kC + tid] = e[h] * inv;
+  }
+  __syncthreads();
+  if (gate_out)
+    for (int j = tid; j < kH * kC; j += kThreads) gate_out[(size_t)n * kH * kC + j] = gate[j];
+  float gl[kH];
+#pragma unroll
+  for (int h = 0; h < kH; h++) gl[h] = gate[h * kC + c];
+  float* __restrict__ un = u + (size_t)n * kT * kC;
+  for (int t = tq * 16; t < tq * 16 + 16; t++) {
+    float v = 0.f;
+#pragma unroll
+    for (int h = 0; h < kH; h++) v += On[(h * kT + t) * kC + c] * gl[h];
+    un[t * kC + c] = v;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void sh_bwd_kernel(
+    const float* __restrict__ du, const float* __restrict__ O, const float* __restrict__ gate_in,
+    const float* __restrict__ sk_w, float* __restrict__ dO, float* __restrict__ dg_out) {
+  __shared__ float part[4][kH * kC];
+  __shared__ float dg[kH * kC];
+  __shared__ float dsv[kC];
+  const int n = blockIdx.x, tid = threadIdx.x, c = tid & 63, tq = tid >> 6;
+  const float* __restrict__ On = O + (size_t)n * kH * kT * kC;
+  const float* __restrict__ dun = du + (size_t)n * kT * kC;
+  float gl[kH], dgate[kH];
+#pragma unroll
+  for (int h = 0; h < kH; h++) {
+    gl[h] = gate_in[(size_t)n * kH * kC + h * kC + c];
+    dgate[h] = 0.f;
+  }
+  for (int t = tq * 16; t < tq * 16 + 16; t++) {
+    const float d = dun[t * kC + c];
+#pragma unroll
+    for (int h = 0; h < kH; h++) dgate[h] += d * On[(h * kT + t) * kC + c];
+  }
+#pragma unroll
+  for (int h = 0; h < kH; h++) part[tq][h * kC + c] = dgate[h];
+  __syncthreads();
+  if (tid < kC) {  // softmax backward over heads
+    float dgt[kH], dot = 0.f;
+#pragma unroll
+    for (int h = 0; h < kH; h++) {
+      const int j = h * kC + tid;
+      dgt[h] = part[0][j] + part[1][j] + part[2][j] + part[3][j];
+      dot += dgt[h] * gl[h];  // tq == 0 for these threads, so gl[] is this channel's gate
+    }
+#pragma unroll
+    for (int h = 0; h < kH; h++) {
+      const float v = gl[h] * (dgt[h] - dot);
+      dg[h * kC + tid] = v;
+      dg_out[(size_t)n * kH * kC + h * kC + tid] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < kC) {  // ds = sk_w^T dg, already divided by T (s is a mean over tokens)
+    float d = 0.f;
+    for (int j = 0; j < kH * kC; j++) d += sk_w[(size_t)j * kC + tid] * dg[j];
+    dsv[tid] = d * (1.f / kT);
+  }
+  __syncthreads();
+  const float dsc = dsv[c];
+  float* __restrict__ dOn = dO + (size_t)n * kH * kT * kC;
+  for (int t = tq * 16; t < tq * 16 + 16; t++) {
+    const float d = dun[t * kC + c];
+#pragma unroll
+    for (int h = 0; h < kH; h++) dOn[(h * kT + t) * kC + c] = d * gl[h] + dsc;
+  }
+}
+
+inline unsigned ln_grid(long long rows) {
+  long long b = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+  return (unsigned)(b < 4096 ? (b > 0 ? b : 1) : 4096);
+}
+
+}  // namespace
+
+AIT_API int ait_ln_fwd(const float* a, const float* pos, const float* residual,
+                       const float* gamma, const float* beta, long long rows, int d, int seq_len,
+                       int src_rows_per_seq, int rep, float eps, float p_drop,
+                       unsigned long long seed, float* y, float* mean, float* rstd,
+                       void* stream) {
+  if (rows < 0 || seq_len <= 0 || src_rows_per_seq <= 0 || src_rows_per_seq > seq_len ||
+      rep < 1 || p_drop < 0.f || p_drop >= 1.f)
+    return AIT_EINVAL;
+  if (d != kD) return AIT_EUNSUPPORTED;
+  if (rows == 0) return AIT_OK;
+  if (!a || !gamma || !beta || !y) return AIT_EINVAL;
+  RowMap m{seq_len, src_rows_per_seq, rep};
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(rows)), dim3(kThreads), 0, ait_stream(stream), a,
+                     pos, residual, gamma, beta, rows, m, eps, p_drop, seed, y, mean, rstd);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_ln_bwd(const float* dy, const float* a, const float* pos, const float* residual,
+                       const float* gamma, const float* mean, const float* rstd, long long rows,
+                       int d, int seq_len, int src_rows_per_seq, int rep, float p_drop,
+                       unsigned long long seed, float* da, float* dres, float* dgamma,
+                       float* dbeta, void* stream) {
+  if (rows < 0 || seq_len <= 0 || src_rows_per_seq <= 0 || src_rows_per_seq > seq_len ||
+      rep < 1 || p_drop < 0.f || p_drop >= 1.f)
+    return AIT_EINVAL;
+  if (d != kD) return AIT_EUNSUPPORTED;
+  if (rows == 0) return AIT_OK;
+  if (!dy || !a || !gamma || !mean || !rstd) return AIT_EINVAL;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return AIT_EINVAL;
+  RowMap m{seq_len, src_rows_per_seq, rep};
+  // fewer, fatter blocks: each block issues 2*512 atomics for the affine gradients
+  long long b = (rows + 63) / 64;
+  unsigned grid = (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(kThreads), 0, ait_stream(stream), dy, a, pos,
+                     residual, gamma, mean, rstd, rows, m, p_drop, seed, da, dres, dgamma, dbeta);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_sh_fwd(const float* O, const float* sk_w, const float* sk_b, int n_seq, int H,
+                       int T, int dv, float* u, float* gate, float* s, void* stream) {
+  if (n_seq < 0) return AIT_EINVAL;
+  if (H != kH || T != kT || dv != kC) return AIT_EUNSUPPORTED;
+  if (n_seq == 0) return AIT_OK;
+  if (!O || !sk_w || !sk_b || !u) return AIT_EINVAL;
+  hipLaunchKernelGGL(sh_fwd_kernel, dim3(n_seq), dim3(kThreads), 0, ait_stream(stream), O, sk_w,
+                     sk_b, u, gate, s);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_sh_bwd(const float* du, const float* O, const float* gate, const float* sk_w,
+                       int n_seq, int H, int T, int dv, float* dO, float* dg, void* stream) {
+  if (n_seq < 0) return AIT_EINVAL;
+  if (H != kH || T != kT || dv != kC) return AIT_EUNSUPPORTED;
+  if (n_seq == 0) return AIT_OK;
+  if (!du || !O || !gate || !sk_w || !dO || !dg) return AIT_EINVAL;
+  hipLaunchKernelGGL(sh_bwd_kernel, dim3(n_seq), dim3(kThreads), 0, ait_stream(stream), du, O, gate,
+                     sk_w, dO, dg);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}

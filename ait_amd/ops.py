@@ -41,3 +41,107 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, 
             _lib.cur_stream(a.device))
     _lib.check(rc, "ait_gemm_f32")
     return out
+
+
+def gemm_relu_bwd(dy, w, act, out=None):
+    """dh = (dy @ w) masked by act > 0   (dy [M,N], w [N,K] row-major, act [M,K])."""
+    M, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        rc = _lib.lib().ait_gemm_f32(0, 0, M, K, N, 1.0, _lib.dev_ptr(dy), dy.stride(0),
+                                     _lib.dev_ptr(w), w.stride(0), _lib.dev_ptr(out), out.stride(0),
+                                     None, _lib.dev_ptr(act), _lib.GEMM_MASK_POS, 1, 0, 0,
+                                     _lib.cur_stream(dy.device))
+    _lib.check(rc, "ait_gemm_f32(mask)")
+    return out
+
+
+D_MODEL = 512
+
+
+def ln_fwd(a, pos, residual, gamma, beta, rows, seq_len, src_rows, rep, eps, p, seed,
+           save_stats=True):
+    y = torch.empty((rows, D_MODEL), dtype=torch.float32, device=a.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=a.device) if save_stats else None
+    rstd = torch.empty((rows,), dtype=torch.float32, device=a.device) if save_stats else None
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().ait_ln_fwd(_p(a), _p(pos), _p(residual), _p(gamma), _p(beta), rows, D_MODEL,
+                                   seq_len, src_rows, rep, float(eps), float(p), int(seed), _p(y),
+                                   _p(mean), _p(rstd), _lib.cur_stream(a.device))
+    _lib.check(rc, "ait_ln_fwd")
+    return y, mean, rstd
+
+
+def ln_bwd(dy, a, pos, residual, gamma, mean, rstd, rows, seq_len, src_rows, rep, p, seed,
+           need_da=True, need_dres=True):
+    dev = dy.device
+    da = None
+    if need_da:
+        n_src = a.shape[0] if rep == 1 else rows
+        da = torch.empty((n_src, D_MODEL), dtype=torch.float32, device=dev)
+    dres = torch.empty((rows, D_MODEL), dtype=torch.float32, device=dev) if need_dres else None
+    dgb = torch.zeros((2, D_MODEL), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ait_ln_bwd(_p(dy), _p(a), _p(pos), _p(residual), _p(gamma), _p(mean),
+                                   _p(rstd), rows, D_MODEL, seq_len, src_rows, rep, float(p),
+                                   int(seed), _p(da), _p(dres), _p(dgb[0]), _p(dgb[1]),
+                                   _lib.cur_stream(dev))
+    _lib.check(rc, "ait_ln_bwd")
+    return da, dres, dgb[0], dgb[1]
+
+
+def sh_fwd(O, sk_w, sk_b):
+    n, H, T, dv = O.shape
+    u = torch.empty((n, T, dv), dtype=torch.float32, device=O.device)
+    gate = torch.empty((n, H * dv), dtype=torch.float32, device=O.device)
+    s = torch.empty((n, dv), dtype=torch.float32, device=O.device)
+    with torch.cuda.device(O.device):
+        rc = _lib.lib().ait_sh_fwd(_p(O), _p(sk_w), _p(sk_b), n, H, T, dv, _p(u), _p(gate), _p(s),
+                                   _lib.cur_stream(O.device))
+    _lib.check(rc, "ait_sh_fwd")
+    return u, gate, s
+
+
+def sh_bwd(du, O, gate, sk_w):
+    n, H, T, dv = O.shape
+    dO = torch.empty_like(O)
+    dg = torch.empty((n, H * dv), dtype=torch.float32, device=O.device)
+    with torch.cuda.device(O.device):
+        rc = _lib.lib().ait_sh_bwd(_p(du), _p(O), _p(gate), _p(sk_w), n, H, T, dv, _p(dO), _p(dg),
+                                   _lib.cur_stream(O.device))
+    _lib.check(rc, "ait_sh_bwd")
+    return dO, dg
+
+
+def _col(t, off):
+    """device pointer of column `off` of a 2-D row-major tensor"""
+    _lib.dev_ptr(t)
+    return ctypes.c_void_p(t.data_ptr() + 4 * off)
+
+
+def attn_fwd(q, qoff, k, koff, v, voff, n_seq, H, T, d, mask_mode, n_valid, scale, p, seed,
+             save_p=True):
+    dev = q.device
+    O = torch.empty((n_seq, H, T, d), dtype=torch.float32, device=dev)
+    P = torch.empty((n_seq, H, T, T), dtype=torch.float32, device=dev) if save_p else None
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ait_attn_fwd(_col(q, qoff), q.stride(0), _col(k, koff), k.stride(0),
+                                     _col(v, voff), v.stride(0), n_seq, H, T, d, mask_mode,
+                                     n_valid, float(scale), float(p), int(seed), _p(P), _p(O),
+                                     _lib.cur_stream(dev))
+    _lib.check(rc, "ait_attn_fwd")
+    return O, P
+
+
+def attn_bwd(q, qoff, k, koff, v, voff, P, dO, n_seq, H, T, d, scale, p, seed, dq, dqoff, dk,
+             dkoff, dv, dvoff):
+    dev = q.device
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ait_attn_bwd(_col(q, qoff), q.stride(0), _col(k, koff), k.stride(0),
+                                     _col(v, voff), v.stride(0), _p(P), _p(dO), n_seq, H, T, d,
+                                     float(scale), float(p), int(seed), _col(dq, dqoff),
+                                     dq.stride(0), _col(dk, dkoff), dk.stride(0),
+                                     _col(dv, dvoff), dv.stride(0), _lib.cur_stream(dev))
+    _lib.check(rc, "ait_attn_bwd")

@@ -1,0 +1,534 @@
+"""Host-side mirror of the reference's `lib/model/system` package (the live AIT module) on top
+of libait_hip.so.
+
+Same class names, constructor arguments, parameter names/shapes (so a reference checkpoint loads
+with load_state_dict) and call signatures:
+
+    Transformer(d_k=64, d_v=64, d_model=512, d_word_vec=512, d_inner=2048, n_position=64,
+                n_layers=1, n_head=8, dropout=0.1)(x_props=..., x_query=...)
+        lib/model/system/Models.py:174-280
+    Encoder / Decoder / PositionalEncoding           lib/model/system/Models.py:26-172
+    EncoderLayer / DecoderLayer                      lib/model/system/Layers.py:10-56
+    MultiHeadAttention / SHBlock / PositionwiseFeedForward   lib/model/system/SubLayers.py
+    ScaledDotProductAttention                        lib/model/system/Modules.py
+
+Everything numeric runs in hand-written HIP kernels through the C ABI (fp32 MFMA GEMMs, fused
+dropout+residual+LayerNorm rows, per-(sequence, head) attention tiles, selective heads); torch
+supplies device memory, streams and the autograd tape between the fused blocks.  There is no CPU
+path: tensors must be on a GPU or the call raises.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+LN_EPS = 1e-6
+SEQ = 64          # tokens per sequence on the AIT path (8x8 query cells)
+
+
+def _new_seed():
+    """64-bit dropout seed drawn from torch's CPU generator (reproducible under manual_seed)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+# ------------------------------------------------------------------------------------------
+# masks: the AIT path only ever uses these two predicates
+# ------------------------------------------------------------------------------------------
+class KeyPadMask:
+    """Keys >= n_valid are masked (the reference's src_mask, Models.py:258-260)."""
+
+    def __init__(self, n_valid):
+        self.n_valid = int(n_valid)
+
+
+class CausalMask:
+    """key <= query (the reference's trg_mask, Models.py:262-263)."""
+
+
+def _mask_code(mask):
+    if mask is None:
+        return 0, 0
+    if isinstance(mask, KeyPadMask):
+        return 1, mask.n_valid
+    if isinstance(mask, CausalMask):
+        return 2, 0
+    return None
+
+
+# ------------------------------------------------------------------------------------------
+# autograd functions over the C ABI
+# ------------------------------------------------------------------------------------------
+def _split_k(M_out, N_out):
+    tiles = ((M_out + 127) // 128) * ((N_out + 127) // 128)
+    return max(1, min(64, 1024 // tiles))
+
+
+def _wgrad(dy, x):
+    """dW[N,K] = dy[M,N]^T x[M,K] (reduction over tokens, split-K)."""
+    return ops.gemm(dy, x, trans_a=True, trans_b=False, split_k=_split_k(dy.shape[1], x.shape[1]))
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b on the matrix cores (nn.Linear / 1x1 conv)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return ops.gemm(x, w, bias=b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.gemm(dy, w, trans_b=False) if ctx.needs_input_grad[0] else None
+        dw = _wgrad(dy, x) if ctx.needs_input_grad[1] else None
+        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+class _FFN(torch.autograd.Function):
+    """f = relu(x W1^T + b1) W2^T + b2   (SubLayers.py:181)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        h = ops.gemm(x, w1, bias=b1, relu=True)
+        f = ops.gemm(h, w2, bias=b2)
+        ctx.save_for_backward(x, w1, w2, h)
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        x, w1, w2, h = ctx.saved_tensors
+        df = df.contiguous()
+        dw2 = _wgrad(df, h)
+        db2 = df.sum(0)
+        dh = ops.gemm_relu_bwd(df, w2, h)          # (df W2) gated by h > 0
+        dw1 = _wgrad(dh, x)
+        db1 = dh.sum(0)
+        dx = ops.gemm(dh, w1, trans_b=False)
+        return dx, dw1, db1, dw2, db2
+
+
+class _DropResLN(torch.autograd.Function):
+    """y = LayerNorm(dropout(a[src] + pos) + residual) (one kernel, one pass)."""
+
+    @staticmethod
+    def forward(ctx, a, pos, residual, gamma, beta, rows, seq_len, src_rows, rep, p, seed):
+        y, mean, rstd = ops.ln_fwd(a, pos, residual, gamma, beta, rows, seq_len, src_rows, rep,
+                                   LN_EPS, p, seed)
+        ctx.save_for_backward(a, pos, residual, gamma, mean, rstd)
+        ctx.cfg = (rows, seq_len, src_rows, rep, p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, pos, residual, gamma, mean, rstd = ctx.saved_tensors
+        rows, seq_len, src_rows, rep, p, seed = ctx.cfg
+        need_res = residual is not None and ctx.needs_input_grad[2]
+        da, dres, dg, db = ops.ln_bwd(dy.contiguous(), a, pos, residual, gamma, mean, rstd, rows,
+                                      seq_len, src_rows, rep, p, seed,
+                                      need_da=ctx.needs_input_grad[0], need_dres=need_res)
+        if da is not None and rep > 1:   # the query sequence was repeated over the proposals
+            da = da.view(-1, rep, src_rows, ops.D_MODEL).sum(1).reshape(-1, ops.D_MODEL)
+        return da, None, dres, dg, db, None, None, None, None, None, None
+
+
+class _AttnSelf(torch.autograd.Function):
+    """qkv [M,3*H*d] (Q | K | V column blocks) -> O [n,H,T,d]."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_seq, H, d, mask_mode, n_valid, scale, p, seed):
+        hd = H * d
+        O, P = ops.attn_fwd(qkv, 0, qkv, hd, qkv, 2 * hd, n_seq, H, SEQ, d, mask_mode, n_valid,
+                            scale, p, seed)
+        ctx.save_for_backward(qkv, P)
+        ctx.cfg = (n_seq, H, d, scale, p, seed)
+        ctx.mark_non_differentiable(P)
+        return O, P
+
+    @staticmethod
+    def backward(ctx, dO, _dP):
+        qkv, P = ctx.saved_tensors
+        n_seq, H, d, scale, p, seed = ctx.cfg
+        hd = H * d
+        dqkv = torch.empty_like(qkv)
+        ops.attn_bwd(qkv, 0, qkv, hd, qkv, 2 * hd, P, dO.contiguous(), n_seq, H, SEQ, d, scale, p,
+                     seed, dqkv, 0, dqkv, hd, dqkv, 2 * hd)
+        return dqkv, None, None, None, None, None, None, None, None
+
+
+class _AttnCross(torch.autograd.Function):
+    """q [M,H*d], kv [M,2*H*d] (K | V column blocks) -> O [n,H,T,d]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, n_seq, H, d, mask_mode, n_valid, scale, p, seed):
+        hd = H * d
+        O, P = ops.attn_fwd(q, 0, kv, 0, kv, hd, n_seq, H, SEQ, d, mask_mode, n_valid, scale, p, seed)
+        ctx.save_for_backward(q, kv, P)
+        ctx.cfg = (n_seq, H, d, scale, p, seed)
+        ctx.mark_non_differentiable(P)
+        return O, P
+
+    @staticmethod
+    def backward(ctx, dO, _dP):
+        q, kv, P = ctx.saved_tensors
+        n_seq, H, d, scale, p, seed = ctx.cfg
+        hd = H * d
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        ops.attn_bwd(q, 0, kv, 0, kv, hd, P, dO.contiguous(), n_seq, H, SEQ, d, scale, p, seed,
+                     dq, 0, dkv, 0, dkv, hd)
+        return dq, dkv, None, None, None, None, None, None, None, None
+
+
+class _SelectiveHeads(torch.autograd.Function):
+    """O [n,H,T,dv] -> sum_h O_h * softmax_h(sk(mean_t sum_h O_h))  [n,T,dv]."""
+
+    @staticmethod
+    def forward(ctx, O, sk_w, sk_b):
+        u, gate, s = ops.sh_fwd(O, sk_w, sk_b)
+        ctx.save_for_backward(O, sk_w, gate, s)
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        O, sk_w, gate, s = ctx.saved_tensors
+        dO, dg = ops.sh_bwd(du.contiguous(), O, gate, sk_w)
+        dw = ops.gemm(dg, s, trans_a=True, trans_b=False)       # [H*dv, dv] = dg^T s
+        return dO, dw, dg.sum(0)
+
+
+class _ToNCHW(torch.autograd.Function):
+    """y[p, ch, t] = sum_k x[p*T + t, k] W[ch, k] + b[ch]: the dec_trans 1x1 conv written straight
+    into NCHW by the GEMM epilogue (Models.py:276-278)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, n_seq, T):
+        ch = w.shape[0]
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (n_seq, T)
+        return ops.gemm(w, x, bias=b, bias_row=True, c_colblk=T, c_batch_stride=ch * T,
+                        out_shape=(n_seq, ch, T))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        n_seq, T = ctx.cfg
+        ch = w.shape[0]
+        dyt = dy.reshape(n_seq, ch, T).transpose(1, 2).reshape(n_seq * T, ch)   # [M, ch]
+        dx = ops.gemm(dyt, w, trans_b=False)
+        dw = _wgrad(dyt, x)
+        return dx, dw, dyt.sum(0), None, None
+
+
+# ------------------------------------------------------------------------------------------
+# modules (names and parameters as in the reference)
+# ------------------------------------------------------------------------------------------
+class ScaledDotProductAttention(nn.Module):
+    """Generic-shape attention (Modules.py:6-29).  The AIT fast path never instantiates the score
+    matrix through this module; it is kept for the image-level co-attention (len_q != 64)."""
+
+    def __init__(self, temperature, attn_dropout=0.1, dist='softmax'):
+        super().__init__()
+        self.dist = dist
+        self.temperature = temperature
+        self.attn_dropout = attn_dropout
+        self.dropout = nn.Dropout(attn_dropout)
+
+    def forward(self, q, k, v, mask=None):
+        attn = torch.matmul(q / self.temperature, k.transpose(2, 3))
+        if mask is not None:
+            attn = attn.masked_fill(mask == 0, -1e9)
+        if self.dist == 'softmax':
+            attn = self.dropout(torch.softmax(attn, dim=-1))
+        elif self.dist == 'division':
+            attn = self.dropout(attn / attn.size(-1))
+        return torch.matmul(attn, v), attn
+
+
+class SHBlock(nn.Module):
+    def __init__(self, n_head, d_v):
+        super().__init__()
+        self.sk = nn.Linear(d_v, d_v * n_head)
+        self.n_head, self.d_v = n_head, d_v
+
+    def forward(self, x):
+        """x [bs, n_head, T, d_v] -> same shape (SubLayers.py:22-39); generic-shape path."""
+        bs, n_head, T, C = x.size()
+        s = x.sum(dim=1).mean(dim=1)
+        v = torch.softmax(self.sk(s).view(bs, n_head, C), dim=1).unsqueeze(2)
+        return x * v
+
+
+def _dense_mask(mask, bs, lq, lk, device):
+    if mask is None or torch.is_tensor(mask):
+        return mask
+    if isinstance(mask, KeyPadMask):
+        m = torch.zeros((bs, 1, lk), dtype=torch.uint8, device=device)
+        m[:, :, :mask.n_valid] = 1
+        return m
+    return torch.tril(torch.ones((lq, lk), dtype=torch.uint8, device=device)).unsqueeze(0)
+
+
+class MultiHeadAttention(nn.Module):
+    """SubLayers.py:41-102.  `mask` may be None, a KeyPadMask / CausalMask marker (fast HIP path),
+    or a dense uint8 tensor as in the reference (generic path)."""
+
+    def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1, dist='softmax'):
+        super().__init__()
+        self.n_head, self.d_k, self.d_v, self.d_model = n_head, d_k, d_v, d_model
+        self.w_qs = nn.Linear(d_model, n_head * d_k, bias=False)
+        self.w_ks = nn.Linear(d_model, n_head * d_k, bias=False)
+        self.w_vs = nn.Linear(d_model, n_head * d_v, bias=False)
+        if n_head > 1:
+            self.sh = SHBlock(n_head=n_head, d_v=d_v)
+            self.fc = nn.Linear(d_v, d_model, bias=False)
+        else:
+            self.fc = nn.Linear(n_head * d_v, d_model, bias=False)
+        self.attention = ScaledDotProductAttention(temperature=d_k ** 0.5, dist=dist)
+        self.dist = dist
+        self.dropout = nn.Dropout(dropout)
+        self.p = dropout
+        self.layer_norm = nn.LayerNorm(d_model, eps=LN_EPS)
+
+    def _fast(self, q, k, v, mask):
+        return (self.n_head == 8 and self.d_k == 64 and self.d_v == 64 and self.dist == 'softmax'
+                and self.d_model == ops.D_MODEL and q.size(1) == SEQ and k.size(1) == SEQ
+                and (k is v) and _mask_code(mask) is not None and q.size(0) == k.size(0))
+
+    def forward(self, q, k, v, mask=None):
+        if self._fast(q, k, v, mask):
+            return self._forward_hip(q, k, mask)
+        return self._forward_generic(q, k, v, mask)
+
+    def _forward_hip(self, x_q, x_kv, mask):
+        n_seq = x_q.size(0)
+        H, d = self.n_head, self.d_k
+        mode, n_valid = _mask_code(mask)
+        p = self.p if self.training else 0.0
+        xq = x_q.reshape(n_seq * SEQ, self.d_model)
+        if x_kv is x_q:
+            w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
+            qkv = _Linear.apply(xq, w, None)
+            O, attn = _AttnSelf.apply(qkv, n_seq, H, d, mode, n_valid, 1.0 / self.d_k ** 0.5, p,
+                                      _new_seed())
+        else:
+            xkv = x_kv.reshape(n_seq * SEQ, self.d_model)
+            qp = _Linear.apply(xq, self.w_qs.weight, None)
+            kv = _Linear.apply(xkv, torch.cat([self.w_ks.weight, self.w_vs.weight], 0), None)
+            O, attn = _AttnCross.apply(qp, kv, n_seq, H, d, mode, n_valid, 1.0 / self.d_k ** 0.5,
+                                       p, _new_seed())
+        u = _SelectiveHeads.apply(O, self.sh.sk.weight, self.sh.sk.bias)      # [n, T, dv]
+        f = _Linear.apply(u.view(n_seq * SEQ, d), self.fc.weight, None)
+        y = _DropResLN.apply(f, None, xq, self.layer_norm.weight, self.layer_norm.bias,
+                             n_seq * SEQ, SEQ, SEQ, 1, p, _new_seed())
+        return y.view(n_seq, SEQ, self.d_model), attn
+
+    def _forward_generic(self, q, k, v, mask):
+        d_k, d_v, n_head = self.d_k, self.d_v, self.n_head
+        sz_b, len_q, len_k = q.size(0), q.size(1), k.size(1)
+        residual = q
+        qp = _Linear.apply(q.reshape(-1, self.d_model), self.w_qs.weight, None)
+        kp = _Linear.apply(k.reshape(-1, self.d_model), self.w_ks.weight, None)
+        vp = _Linear.apply(v.reshape(-1, self.d_model), self.w_vs.weight, None)
+        qh = qp.view(sz_b, len_q, n_head, d_k).transpose(1, 2)
+        kh = kp.view(sz_b, len_k, n_head, d_k).transpose(1, 2)
+        vh = vp.view(sz_b, len_k, n_head, d_v).transpose(1, 2)
+        mask = _dense_mask(mask, sz_b, len_q, len_k, q.device)
+        if mask is not None:
+            mask = mask.unsqueeze(1)
+        o, attn = self.attention(qh, kh, vh, mask=mask)
+        if n_head > 1:
+            o = self.sh(o).sum(dim=1, keepdim=True)
+        o = o.transpose(1, 2).contiguous().view(sz_b * len_q, -1)
+        o = self.dropout(_Linear.apply(o, self.fc.weight, None)).view(sz_b, len_q, -1)
+        return self.layer_norm(o + residual), attn
+
+
+class PositionwiseFeedForward(nn.Module):
+    """SubLayers.py:167-187."""
+
+    def __init__(self, d_in, d_hid, dropout=0.1):
+        super().__init__()
+        self.w_1 = nn.Linear(d_in, d_hid)
+        self.w_2 = nn.Linear(d_hid, d_in)
+        self.layer_norm = nn.LayerNorm(d_in, eps=LN_EPS)
+        self.dropout = nn.Dropout(dropout)
+        self.p = dropout
+        self.d_in = d_in
+
+    def forward(self, x):
+        shape = x.shape
+        x2 = x.reshape(-1, self.d_in)
+        f = _FFN.apply(x2, self.w_1.weight, self.w_1.bias, self.w_2.weight, self.w_2.bias)
+        if self.d_in == ops.D_MODEL:
+            rows = x2.shape[0]
+            p = self.p if self.training else 0.0
+            y = _DropResLN.apply(f, None, x2, self.layer_norm.weight, self.layer_norm.bias, rows,
+                                 SEQ, SEQ, 1, p, _new_seed())
+        else:
+            y = self.layer_norm(self.dropout(f) + x2)
+        return y.view(shape)
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, d_model, d_inner, n_head, d_k, d_v, dropout=0.1):
+        super().__init__()
+        self.slf_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
+        self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
+
+    def forward(self, enc_input, slf_attn_mask=None):
+        enc_output, enc_slf_attn = self.slf_attn(enc_input, enc_input, enc_input, mask=slf_attn_mask)
+        return self.pos_ffn(enc_output), enc_slf_attn
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, d_model, d_inner, n_head, d_k, d_v, dropout=0.1):
+        super().__init__()
+        self.slf_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
+        self.enc_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
+        self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, dropout=dropout)
+
+    def forward(self, dec_input, enc_output, slf_attn_mask=None, dec_enc_attn_mask=None):
+        dec_output, dec_slf_attn = self.slf_attn(dec_input, dec_input, dec_input, mask=slf_attn_mask)
+        dec_output, dec_enc_attn = self.enc_attn(dec_output, enc_output, enc_output,
+                                                 mask=dec_enc_attn_mask)
+        return self.pos_ffn(dec_output), dec_slf_attn, dec_enc_attn
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoid table built in float64 then cast, as Models.py:33-45 (buffer, not a parameter)."""
+
+    def __init__(self, d_hid, n_position=200):
+        super().__init__()
+        pos = np.arange(n_position, dtype=np.float64)[:, None]
+        j = np.arange(d_hid)
+        angle = pos / np.power(10000.0, 2.0 * (j // 2) / d_hid)[None, :]
+        angle[:, 0::2] = np.sin(angle[:, 0::2])
+        angle[:, 1::2] = np.cos(angle[:, 1::2])
+        self.register_buffer('pos_table', torch.from_numpy(angle.astype(np.float32)).unsqueeze(0))
+
+    def forward(self, x):
+        return x + self.pos_table[:, :x.size(1)].clone().detach()
+
+
+class _Coder(nn.Module):
+    def __init__(self, layer_cls, d_word_vec, n_layers, n_head, d_k, d_v, d_model, d_inner,
+                 dropout, n_position):
+        super().__init__()
+        self.position_enc = PositionalEncoding(d_word_vec, n_position=n_position)
+        self.dropout = nn.Dropout(p=dropout)
+        self.p = dropout
+        self.layer_stack = nn.ModuleList([
+            layer_cls(d_model, d_inner, n_head, d_k, d_v, dropout=dropout) for _ in range(n_layers)])
+        self.layer_norm = nn.LayerNorm(d_model, eps=LN_EPS)
+
+    def prologue(self, tokens, n_seq, src_rows, rep):
+        """LayerNorm(dropout(pad/repeat(tokens) + pos_table)) -> [n_seq, 64, d]."""
+        p = self.p if self.training else 0.0
+        y = _DropResLN.apply(tokens, self.position_enc.pos_table[0, :SEQ].contiguous(), None,
+                             self.layer_norm.weight, self.layer_norm.bias, n_seq * SEQ, SEQ,
+                             src_rows, rep, p, _new_seed())
+        return y.view(n_seq, SEQ, -1)
+
+
+class Encoder(_Coder):
+    """Models.py:54-111."""
+
+    def __init__(self, d_word_vec, n_layers, n_head, d_k, d_v, d_model, d_inner, pad_idx=1,
+                 dropout=0.1, n_position=200):
+        super().__init__(EncoderLayer, d_word_vec, n_layers, n_head, d_k, d_v, d_model, d_inner,
+                         dropout, n_position)
+
+    def forward(self, src_seq, src_mask, return_attns=False):
+        """src_seq [bs, 64, d] already padded (reference calling convention)."""
+        n = src_seq.size(0)
+        x = self.prologue(src_seq.reshape(n * SEQ, -1), n, SEQ, 1)
+        return self.run_layers(x, src_mask, return_attns)
+
+    def run_layers(self, x, src_mask, return_attns=False):
+        attns = []
+        for layer in self.layer_stack:
+            x, a = layer(x, slf_attn_mask=src_mask)
+            attns += [a] if return_attns else []
+        return (x, attns) if return_attns else (x,)
+
+
+class Decoder(_Coder):
+    """Models.py:114-172."""
+
+    def __init__(self, d_word_vec, n_layers, n_head, d_k, d_v, d_model, d_inner, pad_idx=1,
+                 n_position=200, dropout=0.1):
+        super().__init__(DecoderLayer, d_word_vec, n_layers, n_head, d_k, d_v, d_model, d_inner,
+                         dropout, n_position)
+
+    def forward(self, trg_seq, trg_mask, enc_output, src_mask, return_attns=False):
+        n = trg_seq.size(0)
+        x = self.prologue(trg_seq.reshape(n * SEQ, -1), n, SEQ, 1)
+        return self.run_layers(x, trg_mask, enc_output, src_mask, return_attns)
+
+    def run_layers(self, x, trg_mask, enc_output, src_mask, return_attns=False):
+        a1, a2 = [], []
+        for layer in self.layer_stack:
+            x, s, c = layer(x, enc_output, slf_attn_mask=trg_mask, dec_enc_attn_mask=src_mask)
+            a1 += [s] if return_attns else []
+            a2 += [c] if return_attns else []
+        return (x, a1, a2) if return_attns else (x,)
+
+
+def conv2d_1x1(in_ch, out_ch, stride=1, groups=1, dilation=1, bias=True):
+    """lib/model/modules/cells.py:22-24."""
+    return nn.Conv2d(in_ch, out_ch, kernel_size=1, stride=stride, bias=bias)
+
+
+class Transformer(nn.Module):
+    """Adaptive Image Transformer (Models.py:174-280): proposal features x query feature ->
+    query-conditioned proposal features [bs*P, 2d, hq, wq]."""
+
+    def __init__(self, src_pad_idx=1, trg_pad_idx=1, d_word_vec=512, d_model=512, d_inner=2048,
+                 n_layers=6, n_head=8, d_k=64, d_v=64, dropout=0.1, n_position=200,
+                 trg_emb_prj_weight_sharing=True, emb_src_trg_weight_sharing=True):
+        super().__init__()
+        assert d_model == d_word_vec, \
+            'To facilitate the residual connections, the dimensions of all module outputs shall be the same.'
+        if d_model != ops.D_MODEL or n_head != 8 or d_k != 64 or d_v != 64 or n_position < SEQ:
+            raise NotImplementedError(
+                "the HIP path is built for the AIT configuration d_model=512, 8 heads of 64 "
+                "(faster_rcnn_sys_transformer_sk_dilat.py:148-158)")
+        self.src_pad_idx, self.trg_pad_idx = src_pad_idx, trg_pad_idx
+        self.channels = d_word_vec
+        self.enc_emb = nn.Sequential(conv2d_1x1(d_word_vec * 2, d_word_vec, bias=True))
+        self.dec_emb = nn.Sequential(conv2d_1x1(d_word_vec * 2, d_word_vec, bias=True))
+        self.encoder = Encoder(n_position=n_position, d_word_vec=d_word_vec, d_model=d_model,
+                               d_inner=d_inner, n_layers=n_layers, n_head=n_head, d_k=d_k, d_v=d_v,
+                               pad_idx=src_pad_idx, dropout=dropout)
+        self.decoder = Decoder(n_position=n_position, d_word_vec=d_word_vec, d_model=d_model,
+                               d_inner=d_inner, n_layers=n_layers, n_head=n_head, d_k=d_k, d_v=d_v,
+                               pad_idx=trg_pad_idx, dropout=dropout)
+        self.dec_trans = nn.Sequential(conv2d_1x1(d_word_vec, d_word_vec * 2, bias=True))
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, x_props, x_query):
+        bp, c2, hp, wp = x_props.size()
+        bs, _, hq, wq = x_query.size()
+        n_s, n_t = hp * wp, hq * wq
+        if n_t != SEQ or n_s > SEQ or bp % bs:
+            raise NotImplementedError("AIT HIP path: query must be 8x8 cells, proposals <= 64 cells")
+        P = bp // bs
+        d = self.channels
+        # NCHW -> token-major rows for the embedding GEMMs
+        xp = x_props.reshape(bp, c2, n_s).transpose(1, 2).reshape(bp * n_s, c2)
+        xq = x_query.reshape(bs, c2, n_t).transpose(1, 2).reshape(bs * n_t, c2)
+        emb_p = _Linear.apply(xp, self.enc_emb[0].weight.view(d, c2), self.enc_emb[0].bias)
+        emb_q = _Linear.apply(xq, self.dec_emb[0].weight.view(d, c2), self.dec_emb[0].bias)
+        src_mask, trg_mask = KeyPadMask(n_s), CausalMask()
+        enc = self.encoder.prologue(emb_p, bp, n_s, 1)              # zero-pads 49 -> 64 rows
+        enc, *_ = self.encoder.run_layers(enc, src_mask)
+        dec = self.decoder.prologue(emb_q, bp, n_t, P)              # repeats the query over P
+        dec, *_ = self.decoder.run_layers(dec, trg_mask, enc, src_mask)
+        out = _ToNCHW.apply(dec.reshape(bp * n_t, d), self.dec_trans[0].weight.view(c2, d),
+                            self.dec_trans[0].bias, bp, n_t)
+        return out.view(bp, c2, hq, wq)

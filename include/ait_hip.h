@@ -94,6 +94,7 @@ int ait_nms(const float* boxes, const int64_t* order, int n, float thr, int max_
  *                  (writes a [channel, token] product straight into an NCHW tensor:
  *                   dec_trans, Models.py:276-278)
  *   flags    AIT_GEMM_RELU | AIT_GEMM_ACCUMULATE (C += ...) | AIT_GEMM_ATOMIC | AIT_GEMM_BIAS_ROW
+ *            | AIT_GEMM_MASK_POS
  *   split_k  > 1 splits the reduction over gridDim.z; requires AIT_GEMM_ATOMIC (partial tiles
  *            are combined with fp32 atomics into C, which the caller has zeroed or wants
  *            accumulated into) and no bias / residual / ReLU.
@@ -103,10 +104,77 @@ int ait_nms(const float* boxes, const int64_t* order, int n, float thr, int max_
 #define AIT_GEMM_ACCUMULATE 2
 #define AIT_GEMM_ATOMIC 4
 #define AIT_GEMM_BIAS_ROW 8
+#define AIT_GEMM_MASK_POS 16 /* C = (residual > 0) ? value : 0  (ReLU backward; `residual` holds
+                                the saved forward activation and is NOT added) */
 int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
                  int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
                  const float* residual, int flags, int split_k, int c_colblk,
                  long long c_batch_stride, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Row kernels (d_model = 512 only; other widths return AIT_EUNSUPPORTED).
+ *
+ * ait_ln_fwd:   y[r] = LayerNorm_eps( dropout(a[src(r)] + pos[t]) + residual[r] ) * gamma + beta
+ *   Replaces, in one pass over HBM:
+ *     encoder/decoder prologue  dropout(position_enc(x)); layer_norm   lib/model/system/Models.py:98-99,155-156
+ *       incl. the zero padding 49->64 (:269-270) and the repeat of the query over proposals (:250)
+ *     "dropout(fc(q)); q += residual; layer_norm(q)"                  lib/model/system/SubLayers.py:97-100
+ *     "dropout(w_2(...)); x += residual; layer_norm(x)"               lib/model/system/SubLayers.py:182-185
+ *   Output row r = (q, t) with q = r / seq_len, t = r % seq_len.  Its source row in `a` is
+ *   (q / rep) * src_rows_per_seq + t when t < src_rows_per_seq, else a zero row
+ *   (identity map: seq_len = src_rows_per_seq, rep = 1).  pos [seq_len, d] and residual
+ *   [rows, d] may be NULL.  mean / rstd [rows] are saved for the backward (may be NULL).
+ *   Dropout: stateless hash of (seed, r*d + c); p_drop = 0 disables it.
+ * ait_ln_bwd:   recomputes z from (a, pos, residual, seed); writes
+ *   da   = dropout-mask * dz.  rep == 1: indexed by SOURCE row (padding rows dropped);
+ *          rep  > 1: indexed by output row (the caller sums over the rep copies).  May be NULL.
+ *   dres = dz [rows, d], may be NULL.
+ *   dgamma, dbeta [d]: ACCUMULATED with atomics (caller zeroes or carries a running sum); both
+ *          NULL or both non-NULL.
+ * ------------------------------------------------------------------------------------- */
+int ait_ln_fwd(const float* a, const float* pos, const float* residual, const float* gamma,
+               const float* beta, long long rows, int d, int seq_len, int src_rows_per_seq,
+               int rep, float eps, float p_drop, unsigned long long seed, float* y, float* mean,
+               float* rstd, void* stream);
+int ait_ln_bwd(const float* dy, const float* a, const float* pos, const float* residual,
+               const float* gamma, const float* mean, const float* rstd, long long rows, int d,
+               int seq_len, int src_rows_per_seq, int rep, float p_drop, unsigned long long seed,
+               float* da, float* dres, float* dgamma, float* dbeta, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Selective heads + head sum (H = 8, T = 64, dv = 64 only).
+ * Replaces SHBlock.forward (lib/model/system/SubLayers.py:22-39) and q.sum(dim=1) (:92).
+ *   O     [n_seq, H, T, dv]  per-head attention outputs
+ *   sk_w  [H*dv, dv], sk_b [H*dv]   (state_dict: *.sh.sk.weight / *.sh.sk.bias)
+ *   u     [n_seq, T, dv] = sum_h O_h * softmax_h(sk(mean_t sum_h O_h))
+ *   gate  [n_seq, H*dv]  the head softmax (saved for backward), s [n_seq, dv] the pooled vector
+ * Backward: dO [n_seq,H,T,dv]; dg [n_seq, H*dv] = gradient at the sk() output, from which the
+ * caller forms d sk_w = dg^T s (one GEMM) and d sk_b = column sums.
+ * ------------------------------------------------------------------------------------- */
+int ait_sh_fwd(const float* O, const float* sk_w, const float* sk_b, int n_seq, int H, int T,
+               int dv, float* u, float* gate, float* s, void* stream);
+int ait_sh_bwd(const float* du, const float* O, const float* gate, const float* sk_w, int n_seq,
+               int H, int T, int dv, float* dO, float* dg, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Scaled dot-product attention per (sequence, head) (T = 64, d = 64 only).
+ * Replaces ScaledDotProductAttention.forward (lib/model/system/Modules.py:16-29) and the
+ * head split / transpose around it (lib/model/system/SubLayers.py:77-90).
+ *   q,k,v  row (n*T + t) of a [n_seq*T, ld*] matrix; head h occupies columns [h*d, (h+1)*d)
+ *   mask_mode 0: none; 1: keys >= n_valid_keys masked (src_mask, Models.py:258-260);
+ *             2: causal, key <= query (trg_mask, Models.py:262-263)
+ *   scale  1/temperature (= 1/8)
+ *   P      [n_seq, H, T, T] softmax probabilities BEFORE dropout (saved for backward; NULL to skip)
+ *   O      [n_seq, H, T, d]  = dropout(P) V
+ * Backward writes dq/dk/dv with the same row/column addressing as q/k/v.
+ * ------------------------------------------------------------------------------------- */
+int ait_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                 int n_seq, int H, int T, int d, int mask_mode, int n_valid_keys, float scale,
+                 float p_drop, unsigned long long seed, float* P, float* O, void* stream);
+int ait_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                 const float* P, const float* dO, int n_seq, int H, int T, int d, float scale,
+                 float p_drop, unsigned long long seed, float* dq, int lddq, float* dk, int lddk,
+                 float* dv, int lddv, void* stream);
 
 #ifdef __cplusplus
 }

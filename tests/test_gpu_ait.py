@@ -1,0 +1,222 @@
+"""GPU parity of the HIP AIT path (ait_amd.system, through the C ABI) against the CPU oracle and
+the golden vectors recorded from the reference.
+
+Tolerance (fp32, north_star): |err| <= ATOL + 1e-4*|ref| elementwise on activations; gradients
+use a wider absolute floor because they are sums over up to bp*64 rows."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ait_ref
+from oracle.digest import compare, seeded
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 2e-5
+GRTOL, GATOL = 1e-4, 2e-4
+
+
+def _check(prefix, t, g, rtol=RTOL, atol=ATOL):
+    ok, msg = compare(prefix, t, g, rtol, atol)
+    assert ok, msg
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _load(module, sd, pre):
+    module.load_state_dict({k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)})
+    return module.cuda()
+
+
+@pytest.mark.parametrize("mname", ["none", "pad49", "causal", "cross_pad49"])
+def test_multi_head_attention_vs_reference_golden(golden, mname):
+    from ait_amd.system import CausalMask, KeyPadMask, MultiHeadAttention
+    g = golden("g2_sublayers")
+    pre = "encoder.layer_stack.0.slf_attn."
+    sd = ait_ref.make_ait_state_dict(seed=2)
+    mha = _load(MultiHeadAttention(8, 512, 64, 64, dropout=0.1), sd, pre).eval()
+    m = {"none": None, "pad49": KeyPadMask(49), "causal": CausalMask(), "cross_pad49": KeyPadMask(49)}[mname]
+    xq = _dev(seeded(221, (2, 64, 512))).requires_grad_(True)
+    wrt = [xq]
+    if mname.startswith("cross"):
+        xk = _dev(seeded(222, (2, 64, 512))).requires_grad_(True)
+        wrt.append(xk)
+        y, attn = mha(xq, xk, xk, mask=m)
+    else:
+        y, attn = mha(xq, xq, xq, mask=m)
+    assert tuple(attn.shape) == (2, 8, 64, 64)
+    cot = _dev(seeded(223, tuple(y.shape)))
+    params = dict(mha.named_parameters())
+    gs = torch.autograd.grad(y, wrt + list(params.values()), cot)
+    _check("mha_%s/y" % mname, y, g)
+    _check("mha_%s/gx" % mname, gs[0], g, GRTOL, GATOL)
+    if mname.startswith("cross"):
+        _check("mha_%s/gkv" % mname, gs[1], g, GRTOL, GATOL)
+    for (pn, _), gr in zip(params.items(), gs[len(wrt):]):
+        _check("mha_%s/g_%s" % (mname, pn), gr, g, GRTOL, GATOL)
+
+
+def test_attention_probabilities_match_sdpa_golden(golden):
+    """The fused tile kernel's softmax output (returned as `attn`) vs the reference's
+    ScaledDotProductAttention under each mask, with the projections set to identity."""
+    from ait_amd import ops
+    g = golden("g2_sublayers")
+    for mname, mode, nv in (("none", 0, 0), ("pad49", 1, 49), ("causal", 2, 0)):
+        q, k, v = (seeded(s, (2, 8, 64, 64)) for s in (211, 212, 213))
+        # [b,H,T,d] -> token-major [b*T, H*d]
+        pack = lambda a: _dev(np.ascontiguousarray(a.transpose(0, 2, 1, 3).reshape(2 * 64, 512)))
+        qkv = torch.cat([pack(q), pack(k), pack(v)], 1).contiguous()
+        O, P = ops.attn_fwd(qkv, 0, qkv, 512, qkv, 1024, 2, 8, 64, 64, mode, nv, 0.125, 0.0, 0)
+        _check("sdpa_%s/o" % mname, O, g)
+        _check("sdpa_%s/attn" % mname, P, g)
+        dO = _dev(seeded(214, (2, 8, 64, 64)))
+        dqkv = torch.empty_like(qkv)
+        ops.attn_bwd(qkv, 0, qkv, 512, qkv, 1024, P, dO, 2, 8, 64, 64, 0.125, 0.0, 0,
+                     dqkv, 0, dqkv, 512, dqkv, 1024)
+        unpack = lambda t: t.view(2, 64, 8, 64).permute(0, 2, 1, 3)
+        _check("sdpa_%s/gq" % mname, unpack(dqkv[:, :512]), g, GRTOL, GATOL)
+        _check("sdpa_%s/gk" % mname, unpack(dqkv[:, 512:1024]), g, GRTOL, GATOL)
+        _check("sdpa_%s/gv" % mname, unpack(dqkv[:, 1024:]), g, GRTOL, GATOL)
+
+
+def test_selective_heads_vs_reference_golden(golden):
+    from ait_amd.system import _SelectiveHeads
+    g = golden("g2_sublayers")
+    sd = ait_ref.make_ait_state_dict(seed=2)
+    pre = "encoder.layer_stack.0.slf_attn."
+    w = sd[pre + "sh.sk.weight"].cuda().requires_grad_(True)
+    b = sd[pre + "sh.sk.bias"].cuda().requires_grad_(True)
+    x = _dev(seeded(201, (2, 8, 64, 64))).requires_grad_(True)
+    u = _SelectiveHeads.apply(x, w, b)
+    # the golden is SHBlock's output BEFORE the head sum; compare the sum and push the same
+    # cotangent through (d/dx of sum_h is a broadcast)
+    want = torch.from_numpy(g["shblock/y/sample"]) if "shblock/y/full" not in g.files else None
+    ref = ait_ref.selective_heads(x.detach().cpu(), w.detach().cpu(), b.detach().cpu()).sum(1)
+    assert torch.allclose(u.detach().cpu(), ref, rtol=RTOL, atol=ATOL)
+    cot = seeded(202, (2, 8, 64, 64))
+    # gradient check against the golden: feed SHBlock-level cotangent summed... the golden's
+    # cotangent is per-head, so compare via the oracle instead (pinned by test_oracle_ait)
+    xo = x.detach().cpu().requires_grad_(True)
+    wo, bo = w.detach().cpu().requires_grad_(True), b.detach().cpu().requires_grad_(True)
+    cu = torch.from_numpy(seeded(203, (2, 64, 64)))
+    go = torch.autograd.grad(ait_ref.selective_heads(xo, wo, bo).sum(1), [xo, wo, bo], cu)
+    gg = torch.autograd.grad(u, [x, w, b], cu.cuda())
+    for a, r in zip(gg, go):
+        assert torch.allclose(a.cpu(), r, rtol=GRTOL, atol=GATOL)
+    del want, cot
+
+
+def test_feed_forward_vs_reference_golden(golden):
+    from ait_amd.system import PositionwiseFeedForward
+    g = golden("g2_sublayers")
+    pre = "encoder.layer_stack.0.pos_ffn."
+    ffn = _load(PositionwiseFeedForward(512, 2048, dropout=0.1), ait_ref.make_ait_state_dict(seed=2), pre).eval()
+    x = _dev(seeded(231, (2, 64, 512))).requires_grad_(True)
+    y = ffn(x)
+    cot = _dev(seeded(232, tuple(y.shape)))
+    params = dict(ffn.named_parameters())
+    gs = torch.autograd.grad(y, [x] + list(params.values()), cot)
+    _check("ffn/y", y, g)
+    _check("ffn/gx", gs[0], g, GRTOL, GATOL)
+    for (pn, _), gr in zip(params.items(), gs[1:]):
+        _check("ffn/g_" + pn, gr, g, GRTOL, GATOL)
+
+
+def _transformer(seed):
+    from ait_amd.system import Transformer
+    t = Transformer(d_k=64, d_v=64, d_model=512, d_word_vec=512, d_inner=2048, n_position=64,
+                    n_layers=1, n_head=8, dropout=0.1)
+    t.load_state_dict(ait_ref.make_ait_state_dict(seed=seed), strict=True)
+    return t.cuda()
+
+
+def test_state_dict_contract():
+    """46 parameters / 8,338,944 elements / 2 buffers with the reference's names."""
+    t = _transformer(3)
+    names = [n for n, _ in t.named_parameters()]
+    assert len(names) == 46 and sum(p.numel() for p in t.parameters()) == 8338944
+    assert sorted(ait_ref.ait_param_shapes()) == sorted(names)
+    assert sorted(n for n, _ in t.named_buffers()) == ["decoder.position_enc.pos_table",
+                                                       "encoder.position_enc.pos_table"]
+
+
+def test_transformer_vs_reference_golden(golden):
+    g = golden("g3_transformer")
+    t = _transformer(3).eval()
+    xp = _dev(seeded(301, (6, 1024, 7, 7))).requires_grad_(True)
+    xq = _dev(seeded(302, (2, 1024, 8, 8))).requires_grad_(True)
+    y = t(x_props=xp, x_query=xq)
+    assert tuple(y.shape) == (6, 1024, 8, 8)
+    cot = _dev(seeded(303, tuple(y.shape)))
+    params = dict(t.named_parameters())
+    gs = torch.autograd.grad(y, [xp, xq] + list(params.values()), cot)
+    _check("t23/y", y, g)
+    _check("t23/g_x_props", gs[0], g, GRTOL, GATOL)
+    _check("t23/g_x_query", gs[1], g, GRTOL, GATOL)
+    for (pn, _), gr in zip(params.items(), gs[2:]):
+        _check("t23/g_" + pn, gr, g, GRTOL, 5e-4)
+
+
+def test_transformer_cfg1_and_oracle(golden):
+    """BASELINE cfg1 shape (1 pair, 128 proposals): golden digest + full-tensor oracle compare."""
+    g = golden("g3_transformer")
+    t = _transformer(3).eval()
+    xp, xq = seeded(311, (128, 1024, 7, 7)), seeded(312, (1, 1024, 8, 8))
+    with torch.no_grad():
+        y = t(x_props=_dev(xp), x_query=_dev(xq))
+    _check("t1_128/y", y, g)
+    with torch.no_grad():
+        ref = ait_ref.transformer_forward(ait_ref.make_ait_state_dict(seed=3), torch.from_numpy(xp),
+                                          torch.from_numpy(xq))
+    err = (y.cpu() - ref).abs()
+    assert bool((err <= ATOL + RTOL * ref.abs()).all()), float(err.max())
+
+
+def test_layernorm_row_maps_and_dropout_statistics():
+    from ait_amd import ops
+    torch.manual_seed(0)
+    bp, P = 6, 3
+    gamma = torch.rand(512, device="cuda") + 0.5
+    beta = torch.randn(512, device="cuda")
+    pos = torch.randn(64, 512, device="cuda")
+    # encoder map: 49 source rows per sequence zero-padded to 64
+    a = torch.randn(bp * 49, 512, device="cuda")
+    y, mean, rstd = ops.ln_fwd(a, pos, None, gamma, beta, bp * 64, 64, 49, 1, 1e-6, 0.0, 0)
+    z = torch.zeros(bp, 64, 512, device="cuda")
+    z[:, :49] = a.view(bp, 49, 512)
+    want = torch.nn.functional.layer_norm(z + pos, (512,), gamma, beta, 1e-6)
+    assert torch.allclose(y.view(bp, 64, 512), want, rtol=1e-5, atol=1e-5)
+    # decoder map: each of bs sequences repeated over P proposals
+    aq = torch.randn((bp // P) * 64, 512, device="cuda")
+    y2, _, _ = ops.ln_fwd(aq, pos, None, gamma, beta, bp * 64, 64, 64, P, 1e-6, 0.0, 0)
+    want2 = torch.nn.functional.layer_norm(
+        aq.view(bp // P, 1, 64, 512).expand(-1, P, -1, -1).reshape(bp, 64, 512) + pos, (512,), gamma, beta, 1e-6)
+    assert torch.allclose(y2.view(bp, 64, 512), want2, rtol=1e-5, atol=1e-5)
+    # dropout: keep fraction ~ 1-p, survivors scaled by 1/(1-p), same mask in fwd and bwd
+    ones = torch.ones(4096 * 64 // 64, 512, device="cuda")
+    rows = ones.shape[0]
+    g1, b0 = torch.ones(512, device="cuda"), torch.zeros(512, device="cuda")
+    res = torch.zeros_like(ones)
+    # LN of a 0/1.11 pattern is awkward to invert; check the mask through the backward instead
+    y3, m3, r3 = ops.ln_fwd(ones, None, res, g1, b0, rows, 64, 64, 1, 1e-6, 0.1, 1234)
+    da, dres, _, _ = ops.ln_bwd(torch.randn_like(ones), ones, None, res, g1, m3, r3, rows, 64, 64, 1, 0.1, 1234)
+    kept = (da != 0).float().mean().item()
+    assert abs(kept - 0.9) < 0.01
+    ratio = (da[da != 0] / dres[da != 0])
+    assert torch.allclose(ratio, torch.full_like(ratio, 1 / 0.9), rtol=1e-5)
+
+
+def test_train_mode_dropout_runs_and_is_seeded():
+    t = _transformer(3).train()
+    xp = _dev(seeded(301, (6, 1024, 7, 7)))
+    xq = _dev(seeded(302, (2, 1024, 8, 8)))
+    torch.manual_seed(7)
+    y1 = t(x_props=xp, x_query=xq)
+    torch.manual_seed(7)
+    y2 = t(x_props=xp, x_query=xq)
+    y3 = t(x_props=xp, x_query=xq)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    y1.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in t.parameters())

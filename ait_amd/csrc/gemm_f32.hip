@@ -240,8 +240,10 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   if (M < 0 || N < 0 || K < 0) return AIT_EINVAL;
   if (M == 0 || N == 0) return AIT_OK;
   if (!A || !B || !C) return AIT_EINVAL;
+  // float4 staging: row pitches and bases 16-B aligned; K % 4 only matters for an operand whose
+  // reduction dimension is the contiguous one
   if ((lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
-      (reinterpret_cast<uintptr_t>(B) & 15) || (K & 3))
+      (reinterpret_cast<uintptr_t>(B) & 15) || ((K & 3) && (!trans_a || trans_b)))
     return AIT_EUNSUPPORTED;
   if (split_k < 1) split_k = 1;
   if (split_k > 1 && !(flags & AIT_GEMM_ATOMIC)) return AIT_EINVAL;

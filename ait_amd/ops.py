@@ -18,7 +18,11 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, 
     a: [M,K] (or [K,M] if trans_a);  b: [N,K] if trans_b (nn.Linear weight layout) else [K,N].
     2-D, last dim contiguous; row pitch taken from stride(0).
     """
-    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    assert a.dim() == 2 and b.dim() == 2
+    if a.stride(1) != 1 or a.stride(0) % 4 or a.stride(0) < a.shape[1]:
+        a = a.contiguous()
+    if b.stride(1) != 1 or b.stride(0) % 4 or b.stride(0) < b.shape[1]:
+        b = b.contiguous()
     M, K = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
     N = b.shape[0] if trans_b else b.shape[1]
     Kb = b.shape[1] if trans_b else b.shape[0]

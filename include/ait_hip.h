@@ -98,7 +98,9 @@ int ait_nms(const float* boxes, const int64_t* order, int n, float thr, int max_
  *   split_k  > 1 splits the reduction over gridDim.z; requires AIT_GEMM_ATOMIC (partial tiles
  *            are combined with fp32 atomics into C, which the caller has zeroed or wants
  *            accumulated into) and no bias / residual / ReLU.
- * Requirements: lda, ldb, K multiples of 4; A, B 16-byte aligned (else AIT_EUNSUPPORTED).
+ * Requirements: lda, ldb multiples of 4; A, B 16-byte aligned; K a multiple of 4 unless both
+ * operands have the reduction dimension outermost (trans_a != 0 and trans_b == 0)
+ * (else AIT_EUNSUPPORTED).
  * ------------------------------------------------------------------------------------- */
 #define AIT_GEMM_RELU 1
 #define AIT_GEMM_ACCUMULATE 2

@@ -11,7 +11,7 @@ Groups:
   g1  PositionalEncoding table                         (system/Models.py:26-51)
   g2  SHBlock / ScaledDotProductAttention / MultiHeadAttention{none,pad49,causal} /
       PositionwiseFeedForward at bp=2, outputs + input/weight grads (system/SubLayers.py)
-  g3  Transformer (bs,P)=(2,3) output + grads wrt inputs and all 46 params; (1,128) digest
+  g3  Transformer (2,3) and (1,128) outputs; (1,2) output + grads wrt inputs and all 46 params
   g4  model._C.roi_align_forward (csrc/cpu/ROIAlign_cpu.cpp)
   g5  model._C.nms kept indices (csrc/cpu/nms_cpu.cpp), incl. exact ovr == thr ties
   g6  generate_anchors tables + shifted-grid checksum (rpn/generate_anchors.py)
@@ -131,21 +131,48 @@ def _ref_transformer(sd):
 
 
 def g3():
+    """Forward at (bs,P)=(2,3) and cfg1 (1,128); forward+backward at (1,2).
+
+    ReLU makes the gradient discontinuous where a hidden pre-activation crosses zero, and with
+    ~1e5..1e6 hidden activations per call one of them is routinely within fp32 rounding noise
+    (~3e-7) of zero: its sign, and with it ~1e-3 of the gradient norm, then depends on the
+    summation order of whoever computes it (observed: the reference itself at 1 vs 8 CPU
+    threads).  The backward fixture therefore searches for an input seed whose smallest
+    |pre-activation| in the REFERENCE's own fp32 forward is >= 5e-6, so that every correct
+    implementation sees the same ReLU mask."""
     out = {}
     sd = ait_ref.make_ait_state_dict(seed=3)
     t = _ref_transformer(sd)
-    bs, P = 2, 3
-    xp = torch.from_numpy(seeded(301, (bs * P, 1024, 7, 7))).requires_grad_(True)
-    xq = torch.from_numpy(seeded(302, (bs, 1024, 8, 8))).requires_grad_(True)
-    y = t(x_props=xp, x_query=xq)
+    with torch.no_grad():
+        y = t(x_props=torch.from_numpy(seeded(301, (6, 1024, 7, 7))),
+              x_query=torch.from_numpy(seeded(302, (2, 1024, 8, 8))))
+    pack("t23/y", y, out)
+    pre_min = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: pre_min.append(float(o.abs().min())))
+             for m in (t.encoder.layer_stack[0].pos_ffn.w_1, t.decoder.layer_stack[0].pos_ffn.w_1)]
+    bs, P = 1, 2
+    for seed in range(3200, 3400):
+        del pre_min[:]
+        xp = torch.from_numpy(seeded(seed, (bs * P, 1024, 7, 7))).requires_grad_(True)
+        xq = torch.from_numpy(seeded(seed + 1000, (bs, 1024, 8, 8))).requires_grad_(True)
+        y = t(x_props=xp, x_query=xq)
+        if min(pre_min) >= 5e-6:
+            break
+    else:
+        raise RuntimeError("no seed with a safe ReLU margin found")
+    for h in hooks:
+        h.remove()
+    print("g3 backward fixture: seed", seed, "min |pre-activation|", min(pre_min))
+    out["t12/seed"] = np.asarray(seed)
+    out["t12/relu_margin"] = np.asarray(min(pre_min))
     cot = torch.from_numpy(seeded(303, tuple(y.shape)))
     params = dict(t.named_parameters())
     gs = _grads(y, [xp, xq] + list(params.values()), cot)
-    pack("t23/y", y, out)
-    pack("t23/g_x_props", gs[0], out)
-    pack("t23/g_x_query", gs[1], out)
+    pack("t12/y", y, out)
+    pack("t12/g_x_props", gs[0], out)
+    pack("t12/g_x_query", gs[1], out)
     for (pn, _), g in zip(params.items(), gs[2:]):
-        pack("t23/g_" + pn, g, out)
+        pack("t12/g_" + pn, g, out)
     # cfg1 shape (1,128), forward only
     with torch.no_grad():
         y = t(x_props=torch.from_numpy(seeded(311, (128, 1024, 7, 7))),

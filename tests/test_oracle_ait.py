@@ -104,19 +104,27 @@ def test_transformer_forward_and_grads(golden):
     g = golden("g3_transformer")
     sd = {k: (v.clone().requires_grad_(True) if "pos_table" not in k else v)
           for k, v in ait_ref.make_ait_state_dict(seed=3).items()}
-    xp = torch.from_numpy(seeded(301, (6, 1024, 7, 7))).requires_grad_(True)
-    xq = torch.from_numpy(seeded(302, (2, 1024, 8, 8))).requires_grad_(True)
+    with torch.no_grad():
+        y23 = ait_ref.transformer_forward(sd, torch.from_numpy(seeded(301, (6, 1024, 7, 7))),
+                                          torch.from_numpy(seeded(302, (2, 1024, 8, 8))))
+    assert tuple(y23.shape) == (6, 1024, 8, 8)            # adaptive_image_transformer.py:35
+    _check("t23/y", y23, g)
+    # backward fixture at (bs,P)=(1,2): seed chosen by gen_golden so that no ReLU pre-activation
+    # is within rounding noise of zero (see oracle/gen_golden.py g3)
+    seed = int(g["t12/seed"])
+    assert float(g["t12/relu_margin"]) >= 5e-6
+    xp = torch.from_numpy(seeded(seed, (2, 1024, 7, 7))).requires_grad_(True)
+    xq = torch.from_numpy(seeded(seed + 1000, (1, 1024, 8, 8))).requires_grad_(True)
     y = ait_ref.transformer_forward(sd, xp, xq)
-    assert tuple(y.shape) == (6, 1024, 8, 8)            # adaptive_image_transformer.py:35
     cot = torch.from_numpy(seeded(303, tuple(y.shape)))
     names = [k for k in sd if "pos_table" not in k]
     assert len(names) == 46 and sum(sd[n].numel() for n in names) == 8338944
     gs = torch.autograd.grad(y, [xp, xq] + [sd[n] for n in names], cot)
-    _check("t23/y", y, g)
-    _check("t23/g_x_props", gs[0], g, GRTOL, GATOL)
-    _check("t23/g_x_query", gs[1], g, GRTOL, GATOL)
+    _check("t12/y", y, g)
+    _check("t12/g_x_props", gs[0], g, GRTOL, GATOL)
+    _check("t12/g_x_query", gs[1], g, GRTOL, GATOL)
     for n, gr in zip(names, gs[2:]):
-        _check("t23/g_" + n, gr, g, GRTOL, 5e-4)
+        _check("t12/g_" + n, gr, g, GRTOL, GATOL)
 
 
 def test_transformer_cfg1_shape(golden):

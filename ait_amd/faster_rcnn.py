@@ -1,0 +1,323 @@
+"""Detector assembly around the AIT hot path: host-side mirror of
+
+  lib/model/faster_rcnn/faster_rcnn_sys_transformer_sk_dilat.py   (_fasterRCNN, CoAttentionModule)
+  lib/model/faster_rcnn/resnet_sys_transformer_sk_dilat.py        (ResNet, RCNNBackbone, resnet)
+  lib/model/modules/blocks_sys_transformer_sk_dilat.py:915-997    (SKBlock, SKNet)
+
+with the reference's constructor/forward signatures, 10-tuple return value and state_dict key
+names (a reference checkpoint loads with load_state_dict).  The hot path inside -- RoIAlign,
+the AIT Transformer, NMS -- runs in libait_hip.so; the ResNet convolutions stay on
+PyTorch-ROCm (MIOpen), as SURVEY.md section 2 scopes them.
+
+    model = resnet(classes, 50, pretrained=False, class_agnostic=True, num_K=3)
+    model.create_architecture()
+    rois, cls_prob, bbox_pred, rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, margin_loss, \
+        RCNN_loss_bbox, rois_label, c_att = model(image, query, img_info, gt_boxes, num_boxes)
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import cfg
+from .roi_layers import ROIAlign
+from .rpn import _ProposalTargetLayer, _RPN, _smooth_l1_loss
+from .system import MultiHeadAttention, Transformer, conv2d_1x1
+
+
+# ------------------------------------------------------------------------------------------
+# channel block between AIT and layer4
+# ------------------------------------------------------------------------------------------
+class SKBlock(nn.Module):
+    """Selective-kernel block as the reference actually computes it: two grouped conv branches
+    (1x1 and 3x3, 8 groups, ReLU); the branch-attention weights `a` are computed and then NOT
+    used -- the output is sum_branches f*f (blocks_sys_transformer_sk_dilat.py:974-981)."""
+
+    def __init__(self, channels, reduction=16):
+        super().__init__()
+        kernels = [1, 3]
+        self.n_state = len(kernels)
+        self.convs = nn.ModuleList([nn.Sequential(
+            nn.Conv2d(channels, channels, kernel_size=k, stride=1, padding=k // 2, groups=8),
+            nn.ReLU(inplace=True)) for k in kernels])
+        self.gap = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(channels, channels // reduction)
+        self.sk = nn.Linear(channels // reduction, channels * self.n_state)
+        self.softmax = nn.Softmax(dim=1)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv1d, nn.Conv2d)):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        out = None
+        for branch in self.convs:
+            f = branch(x)
+            out = f * f if out is None else out + f * f
+        return out
+
+
+class SKNet(nn.Module):
+    def __init__(self, channels, reduction=16):
+        super().__init__()
+        self.sk_props = SKBlock(channels, reduction)
+        self.sk_query = SKBlock(channels, reduction)
+
+    def forward(self, x_props, x_query):
+        return self.sk_props(x_props), self.sk_query(x_query)
+
+
+# ------------------------------------------------------------------------------------------
+# image-level co-attention (VOC variant): two MultiHeadAttention blocks with len_q = H_i*W_i
+# ------------------------------------------------------------------------------------------
+class CoAttentionModule(nn.Module):
+    def __init__(self, d_word_vec, d_model, d_inner, n_head, d_k, d_v, dropout=0.1):
+        super().__init__()
+        self.d_model, self.d_word_vec = d_model, d_word_vec
+        self.img_emb = nn.Sequential(conv2d_1x1(d_word_vec, d_model, bias=True))
+        self.qry_emb = nn.Sequential(conv2d_1x1(d_word_vec, d_model, bias=True))
+        self.i2q_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
+        self.q2i_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout=dropout)
+        self.img_trans = nn.Sequential(nn.Linear(d_model, d_word_vec, bias=True))
+        self.qry_trans = nn.Sequential(nn.Linear(d_model, d_word_vec, bias=True))
+
+    def forward(self, x_img, x_qry):
+        bs, _, h_i, w_i = x_img.size()
+        _, _, h_q, w_q = x_qry.size()
+        img = self.img_emb(x_img).flatten(2).transpose(1, 2)          # [bs, HW, 512]
+        qry = self.qry_emb(x_qry).flatten(2).transpose(1, 2)          # [bs, 64, 512]
+        enc_img, _ = self.q2i_attn(q=img, k=qry, v=qry, mask=None)
+        enc_qry, _ = self.i2q_attn(q=qry, k=img, v=img, mask=None)
+        non_img = self.img_trans(enc_img).transpose(1, 2).reshape(bs, self.d_word_vec, h_i, w_i)
+        non_qry = self.qry_trans(enc_qry).transpose(1, 2).reshape(bs, self.d_word_vec, h_q, w_q)
+        return non_img, non_qry
+
+
+# ------------------------------------------------------------------------------------------
+# ResNet backbone (stride on the first 1x1 of a bottleneck, ceil-mode max-pool without padding)
+# ------------------------------------------------------------------------------------------
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, stride=stride, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        out = out + (x if self.downsample is None else self.downsample(x))
+        return self.relu(out)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=1000):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=0, ceil_mode=True)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AvgPool2d(7)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2. / n))
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+
+def resnet50():
+    return ResNet(Bottleneck, [3, 4, 6, 3])
+
+
+def resnet101():
+    return ResNet(Bottleneck, [3, 4, 23, 3])
+
+
+class RCNNBackbone(nn.Module):
+    """C4 trunk shared by the target image and the query patch (siamese).  Keeps the whole
+    ResNet as `.backbone` (so the checkpoint keys RCNN_base.backbone.* exist, including the never
+    used fc) and aliases stem / layer1-3 exactly like the reference."""
+
+    def __init__(self, cfg_, backbone, **kwargs):
+        super().__init__()
+        self.backbone = backbone
+        self.channels = kwargs.get('channels', 2048)
+        self.with_contextual_relation = kwargs.get('with_contextual_relation', False)
+        if self.with_contextual_relation:
+            raise NotImplementedError("the contextual-relation (GRU) branch is dead in the reference")
+        self.stem = nn.Sequential(backbone.conv1, backbone.bn1, backbone.relu, backbone.maxpool)
+        for p in self.stem[0].parameters():
+            p.requires_grad = False
+        for p in self.stem[1].parameters():
+            p.requires_grad = False
+        self.layer1 = backbone.layer1
+        self.layer2 = backbone.layer2
+        self.layer3 = backbone.layer3
+
+    def forward(self, x):
+        return self.layer3(self.layer2(self.layer1(self.stem(x)))), None
+
+
+# ------------------------------------------------------------------------------------------
+# the detector
+# ------------------------------------------------------------------------------------------
+class _fasterRCNN(nn.Module):
+    def __init__(self, classes, class_agnostic, num_K):
+        super().__init__()
+        self.classes = classes
+        self.n_classes = len(classes)
+        self.class_agnostic = class_agnostic
+        self.channels = self.dout_base_model
+        self.num_K = num_K
+        C = self.channels
+        self.coattention = CoAttentionModule(d_k=64, d_v=64, d_word_vec=C, d_model=C // 2,
+                                             d_inner=C * 2, n_head=8, dropout=0.1)
+        self.RCNN_rpn = _RPN(C)
+        self.RCNN_proposal_target = _ProposalTargetLayer(self.n_classes)
+        if cfg.POOLING_MODE != 'align':
+            raise NotImplementedError("only POOLING_MODE 'align' is built (every shipped yml uses it)")
+        self.RCNN_roi_align = ROIAlign((cfg.POOLING_SIZE, cfg.POOLING_SIZE), 1.0 / 16.0, 0)
+        self.sk = SKNet(channels=C)
+        self.transformer = Transformer(d_k=64, d_v=64, d_model=C // 2, d_word_vec=C // 2,
+                                       d_inner=C * 2, n_position=8 * 8, n_layers=1, n_head=8,
+                                       dropout=0.1)
+        self.triplet_loss = torch.nn.MarginRankingLoss(margin=cfg.TRAIN.MARGIN)
+
+    def forward(self, image, query, img_info, gt_boxes, num_boxes):
+        bs = image.size(0)
+        img_info, gt_boxes, num_boxes = img_info.data, gt_boxes.data, num_boxes.data
+
+        image_feat, _ = self.RCNN_base(image)                 # [bs, 1024, H_i, W_i]
+        query_feat, _ = self.RCNN_base(query)                 # [bs, 1024, 8, 8]
+        non_img, non_qry = self.coattention(x_img=image_feat, x_qry=query_feat)
+
+        rois, rpn_loss_cls, rpn_loss_bbox = self.RCNN_rpn(non_img, img_info, gt_boxes, num_boxes)
+        if self.training:
+            rois, rois_label, rois_target, rois_inside_ws, rois_outside_ws = \
+                self.RCNN_proposal_target(rois, gt_boxes, num_boxes)
+            rois_label = rois_label.view(-1).long()
+            rois_target = rois_target.view(-1, rois_target.size(2))
+            rois_inside_ws = rois_inside_ws.view(-1, rois_inside_ws.size(2))
+            rois_outside_ws = rois_outside_ws.view(-1, rois_outside_ws.size(2))
+        else:
+            rois_label = None
+            rpn_loss_cls = margin_loss = rpn_loss_bbox = 0
+        num_props = rois.size(1)
+
+        props_feat = self.RCNN_roi_align(non_img, rois.view(-1, 5))          # [bs*P, 1024, 7, 7]
+        props_feat = self.transformer(x_props=props_feat, x_query=non_qry)   # [bs*P, 1024, 8, 8]
+        props_feat, query_feat = self.sk(x_props=props_feat, x_query=non_qry)
+        c_att = None
+        props_feat = self._head_to_tail(props_feat)                          # [bs*P, 2048]
+        query_feat = self._head_to_tail(query_feat)                          # [bs, 2048]
+
+        bbox_pred = self.RCNN_bbox_pred(props_feat)
+        stack_feat = torch.cat((props_feat.view(bs, num_props, -1),
+                                query_feat.unsqueeze(1).expand(-1, num_props, -1)), dim=2).reshape(-1, 4096)
+        score = self.RCNN_cls_score(stack_feat)                              # similarity logits
+        score_prob = F.softmax(score, 1)[:, 1]
+
+        RCNN_loss_cls = 0
+        RCNN_loss_bbox = 0
+        if self.training:
+            score_label = rois_label.view(bs, -1).float()
+            gt_map = (score_label.unsqueeze(1) - score_label.unsqueeze(-1)).abs()
+            sp = score_prob.view(bs, -1)
+            pr_map = (sp.unsqueeze(1) - sp.unsqueeze(-1)).abs()
+            target = -((gt_map - 1) ** 2) + gt_map
+            RCNN_loss_cls = F.cross_entropy(score, rois_label)
+            margin_loss = 3 * self.triplet_loss(pr_map, gt_map, target)
+            RCNN_loss_bbox = _smooth_l1_loss(bbox_pred, rois_target, rois_inside_ws, rois_outside_ws)
+
+        cls_prob = score_prob.view(bs, num_props, -1)
+        bbox_pred = bbox_pred.view(bs, num_props, -1)
+        return rois, cls_prob, bbox_pred, rpn_loss_cls, rpn_loss_bbox, RCNN_loss_cls, margin_loss, \
+            RCNN_loss_bbox, rois_label, c_att
+
+    def _init_weights(self):
+        def normal_init(m, mean, stddev, truncated=False):
+            if truncated:
+                m.weight.data.normal_().fmod_(2).mul_(stddev).add_(mean)
+            else:
+                m.weight.data.normal_(mean, stddev)
+                m.bias.data.zero_()
+        t = cfg.TRAIN.TRUNCATED
+        normal_init(self.RCNN_rpn.RPN_Conv, 0, 0.01, t)
+        normal_init(self.RCNN_rpn.RPN_cls_score, 0, 0.01, t)
+        normal_init(self.RCNN_rpn.RPN_bbox_pred, 0, 0.01, t)
+        normal_init(self.RCNN_cls_score[0], 0, 0.01, t)
+        normal_init(self.RCNN_cls_score[1], 0, 0.01, t)
+        normal_init(self.RCNN_bbox_pred, 0, 0.001, t)
+
+    def create_architecture(self):
+        self._init_modules()
+        self._init_weights()
+
+
+class resnet(_fasterRCNN):
+    def __init__(self, classes, num_layers=101, pretrained=False, class_agnostic=False, num_K=3):
+        self.dout_base_model = 1024
+        self.pretrained = pretrained
+        self.class_agnostic = class_agnostic
+        self.num_layers = num_layers
+        _fasterRCNN.__init__(self, classes, class_agnostic, num_K)
+
+    def _init_modules(self):
+        net = resnet50() if self.num_layers == 50 else resnet101()
+        if self.pretrained:
+            raise NotImplementedError("ImageNet weights are loaded with load_state_dict by the driver")
+        self.RCNN_base = RCNNBackbone(cfg, backbone=net)
+        self.RCNN_top = nn.Sequential(net.layer4)
+        self.RCNN_cls_score = nn.Sequential(nn.Linear(2048 * 2, 8), nn.Linear(8, 2))
+        self.RCNN_bbox_pred = nn.Linear(2048, 4 if self.class_agnostic else 4 * self.n_classes)
+
+        def set_bn_fix(m):
+            if m.__class__.__name__.find('BatchNorm') != -1:
+                for p in m.parameters():
+                    p.requires_grad = False
+        self.RCNN_base.apply(set_bn_fix)
+        self.RCNN_top.apply(set_bn_fix)
+
+    def train(self, mode=True):
+        nn.Module.train(self, mode)
+        if mode:
+            self.RCNN_base.stem.eval()
+
+            def set_bn_eval(m):
+                if m.__class__.__name__.find('BatchNorm') != -1:
+                    m.eval()
+            self.RCNN_base.apply(set_bn_eval)
+            self.RCNN_top.apply(set_bn_eval)
+        return self
+
+    def _head_to_tail(self, pool5):
+        return self.RCNN_top(pool5).mean(3).mean(2)

@@ -1,0 +1,374 @@
+"""Proposal machinery around the hot path: host-side mirror of the reference's lib/model/rpn
+package (same class names, constructor arguments, forward signatures and outputs).
+
+  generate_anchors          rpn/generate_anchors.py:45-105
+  bbox_transform_inv / clip_boxes / bbox_transform_batch / bbox_overlaps_batch
+                            rpn/bbox_transform.py:77-103,125-133,38-75,168-257
+  _ProposalLayer            rpn/proposal_layer.py:28-166   (NMS = libait_hip.so, no host sync)
+  _AnchorTargetLayer        rpn/anchor_target_layer.py:27-199
+  _ProposalTargetLayer      rpn/proposal_target_layer_cascade.py:17-220
+  _RPN                      rpn/rpn.py:18-128
+  _smooth_l1_loss           lib/model/utils/net_utils.py:75-89
+
+MI355X notes: box decode / clip / IoU are small batched tensor ops on the device; NMS is the
+on-device HIP kernel with early exit at post_nms_topN (the reference's GPU path copies an
+N x N/64 bitmask to the host and scans it there); the two samplers keep the reference's exact
+NumPy global-RNG call sequence (index parity) but move ONE small tensor per layer to the host
+instead of synchronising per image.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import cfg
+from .roi_layers import nms_sorted
+
+
+# ------------------------------------------------------------------------------------------
+# anchors
+# ------------------------------------------------------------------------------------------
+def _centered(ws, hs, cx, cy):
+    ws, hs = np.asarray(ws, np.float64)[:, None], np.asarray(hs, np.float64)[:, None]
+    return np.hstack((cx - 0.5 * (ws - 1), cy - 0.5 * (hs - 1), cx + 0.5 * (ws - 1), cy + 0.5 * (hs - 1)))
+
+
+def generate_anchors(base_size=16, ratios=(0.5, 1, 2), scales=2 ** np.arange(3, 6)):
+    """Anchor windows (x1,y1,x2,y2) around a (0,0,base-1,base-1) cell: for every aspect ratio
+    (area preserved, sides rounded), every scale.  Row order = ratio-major, scale-minor."""
+    ratios, scales = np.asarray(ratios, np.float64), np.asarray(scales, np.float64)
+    ctr = 0.5 * (base_size - 1)
+    area = float(base_size * base_size)
+    ws = np.round(np.sqrt(area / ratios))
+    hs = np.round(ws * ratios)
+    return np.vstack([_centered(w * scales, h * scales, ctr, ctr) for w, h in zip(ws, hs)])
+
+
+class _AnchorGrid:
+    """Anchors shifted over an H x W feature map (stride 16), cached per (H, W, device)."""
+
+    def __init__(self, feat_stride, scales, ratios):
+        self.stride = feat_stride
+        self.base = torch.from_numpy(generate_anchors(scales=np.array(scales), ratios=np.array(ratios))).float()
+        self._cache = {}
+
+    @property
+    def A(self):
+        return self.base.size(0)
+
+    def get(self, H, W, device):
+        key = (H, W, str(device))
+        if key not in self._cache:
+            sx = torch.arange(W, dtype=torch.float32) * self.stride
+            sy = torch.arange(H, dtype=torch.float32) * self.stride
+            shifts = torch.stack([sx.repeat(H), sy.repeat_interleave(W), sx.repeat(H), sy.repeat_interleave(W)], 1)
+            self._cache[key] = (self.base.view(1, -1, 4) + shifts.view(-1, 1, 4)).view(-1, 4).to(device)
+        return self._cache[key]
+
+
+# ------------------------------------------------------------------------------------------
+# box arithmetic (+1 pixel convention throughout)
+# ------------------------------------------------------------------------------------------
+def bbox_transform_inv(boxes, deltas, batch_size=None):
+    """boxes [b,N,4] (or [N,4] broadcast), deltas [b,N,4] -> decoded boxes [b,N,4]."""
+    w = boxes[..., 2] - boxes[..., 0] + 1.0
+    h = boxes[..., 3] - boxes[..., 1] + 1.0
+    cx = boxes[..., 0] + 0.5 * w
+    cy = boxes[..., 1] + 0.5 * h
+    pcx = deltas[..., 0] * w + cx
+    pcy = deltas[..., 1] * h + cy
+    pw = torch.exp(deltas[..., 2]) * w
+    ph = torch.exp(deltas[..., 3]) * h
+    return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), -1)
+
+
+def clip_boxes(boxes, im_shape, batch_size=None):
+    """Clamp [b,N,4] boxes to [0, W-1] x [0, H-1] with im_shape[b] = (H, W, scale)."""
+    hi = torch.stack((im_shape[:, 1], im_shape[:, 0], im_shape[:, 1], im_shape[:, 0]), 1) - 1
+    hi = hi.to(boxes.dtype).unsqueeze(1)
+    return torch.minimum(boxes.clamp(min=0), hi)
+
+
+def bbox_transform_batch(ex_rois, gt_rois):
+    """Regression targets of gt w.r.t. ex; ex [N,4] or [b,N,4], gt [b,N,4]."""
+    if ex_rois.dim() == 2:
+        ex_rois = ex_rois.unsqueeze(0)
+    ew = ex_rois[..., 2] - ex_rois[..., 0] + 1.0
+    eh = ex_rois[..., 3] - ex_rois[..., 1] + 1.0
+    ecx = ex_rois[..., 0] + 0.5 * ew
+    ecy = ex_rois[..., 1] + 0.5 * eh
+    gw = gt_rois[..., 2] - gt_rois[..., 0] + 1.0
+    gh = gt_rois[..., 3] - gt_rois[..., 1] + 1.0
+    gcx = gt_rois[..., 0] + 0.5 * gw
+    gcy = gt_rois[..., 1] + 0.5 * gh
+    return torch.stack(((gcx - ecx) / ew, (gcy - ecy) / eh, torch.log(gw / ew), torch.log(gh / eh)), 2)
+
+
+def bbox_overlaps_batch(anchors, gt_boxes):
+    """IoU [b,N,K] of anchors ([N,4], [b,N,4] or [b,N,5] with a leading batch column) against
+    gt_boxes [b,K,>=4].  Zero-area gt columns -> 0, zero-area anchor rows -> -1."""
+    b = gt_boxes.size(0)
+    if anchors.dim() == 2:
+        anchors = anchors.unsqueeze(0).expand(b, -1, 4)
+    elif anchors.size(2) == 5:
+        anchors = anchors[:, :, 1:5]
+    gt = gt_boxes[:, :, :4]
+    gw = gt[:, :, 2] - gt[:, :, 0] + 1
+    gh = gt[:, :, 3] - gt[:, :, 1] + 1
+    aw = anchors[:, :, 2] - anchors[:, :, 0] + 1
+    ah = anchors[:, :, 3] - anchors[:, :, 1] + 1
+    g_area = (gw * gh).unsqueeze(1)
+    a_area = (aw * ah).unsqueeze(2)
+    A, G = anchors.unsqueeze(2), gt.unsqueeze(1)
+    iw = (torch.min(A[..., 2], G[..., 2]) - torch.max(A[..., 0], G[..., 0]) + 1).clamp(min=0)
+    ih = (torch.min(A[..., 3], G[..., 3]) - torch.max(A[..., 1], G[..., 1]) + 1).clamp(min=0)
+    inter = iw * ih
+    ov = inter / (a_area + g_area - inter)
+    ov = ov.masked_fill(((gw == 1) & (gh == 1)).unsqueeze(1), 0)
+    ov = ov.masked_fill(((aw == 1) & (ah == 1)).unsqueeze(2), -1)
+    return ov
+
+
+def _smooth_l1_loss(bbox_pred, bbox_targets, bbox_inside_weights, bbox_outside_weights, sigma=1.0,
+                    dim=[1]):
+    s2 = sigma ** 2
+    d = bbox_inside_weights * (bbox_pred - bbox_targets)
+    ad = d.abs()
+    quad = (ad < 1.0 / s2).detach().float()
+    loss = bbox_outside_weights * (d * d * (s2 / 2.0) * quad + (ad - 0.5 / s2) * (1.0 - quad))
+    for i in sorted(dim, reverse=True):
+        loss = loss.sum(i)
+    return loss.mean()
+
+
+# ------------------------------------------------------------------------------------------
+# proposal layer
+# ------------------------------------------------------------------------------------------
+class _ProposalLayer(nn.Module):
+    """(rpn_cls_prob, rpn_bbox_pred, im_info, 'TRAIN'|'TEST') -> rois [b, post_nms_topN, 5]
+    = (batch index, x1, y1, x2, y2), zero rows after the last survivor."""
+
+    def __init__(self, feat_stride, scales, ratios):
+        super().__init__()
+        self._grid = _AnchorGrid(feat_stride, scales, ratios)
+        self._num_anchors = self._grid.A
+
+    def forward(self, input):
+        probs, deltas, im_info, cfg_key = input
+        A = self._num_anchors
+        pre_n = cfg[cfg_key].RPN_PRE_NMS_TOP_N
+        post_n = cfg[cfg_key].RPN_POST_NMS_TOP_N
+        thr = cfg[cfg_key].RPN_NMS_THRESH
+        b, _, H, W = deltas.shape
+        scores = probs[:, A:].permute(0, 2, 3, 1).reshape(b, -1)        # fg probabilities
+        deltas = deltas.permute(0, 2, 3, 1).reshape(b, -1, 4)
+        anchors = self._grid.get(H, W, deltas.device)
+        boxes = clip_boxes(bbox_transform_inv(anchors.unsqueeze(0), deltas), im_info)
+        order = torch.sort(scores, 1, True)[1]
+        if 0 < pre_n < scores.numel():          # (the reference compares with numel of the batch)
+            order = order[:, :pre_n]
+        out = scores.new_zeros(b, post_n, 5)
+        slot = torch.arange(post_n, device=scores.device)
+        for i in range(b):
+            cand = boxes[i].index_select(0, order[i]).contiguous()
+            keep, n_keep = nms_sorted(cand, thr, post_n)
+            idx = keep[:post_n].clamp_(0, cand.size(0) - 1)
+            if idx.numel() < post_n:
+                idx = F.pad(idx, (0, post_n - idx.numel()))
+            sel = cand.index_select(0, idx)
+            out[i, :, 1:] = torch.where((slot < n_keep).unsqueeze(1), sel, torch.zeros_like(sel))
+            out[i, :, 0] = i
+        return out
+
+
+# ------------------------------------------------------------------------------------------
+# RPN training targets
+# ------------------------------------------------------------------------------------------
+class _AnchorTargetLayer(nn.Module):
+    """(rpn_cls_score, gt_boxes, im_info, num_boxes) -> [labels [b,1,A*H,W], bbox_targets
+    [b,4A,H,W], inside weights, outside weights]."""
+
+    def __init__(self, feat_stride, scales, ratios):
+        super().__init__()
+        self._grid = _AnchorGrid(feat_stride, scales, ratios)
+        self._num_anchors = self._grid.A
+        self._allowed_border = 0
+
+    def forward(self, input):
+        rpn_cls_score, gt_boxes, im_info, num_boxes = input
+        H, W = rpn_cls_score.size(2), rpn_cls_score.size(3)
+        b = gt_boxes.size(0)
+        A = self._num_anchors
+        dev = gt_boxes.device
+        all_anchors = self._grid.get(H, W, dev)
+        total = all_anchors.size(0)
+        bd = self._allowed_border
+        im_w, im_h = int(im_info[0][1]), int(im_info[0][0])
+        inside = ((all_anchors[:, 0] >= -bd) & (all_anchors[:, 1] >= -bd) &
+                  (all_anchors[:, 2] < im_w + bd) & (all_anchors[:, 3] < im_h + bd))
+        inds_inside = torch.nonzero(inside).view(-1)
+        anchors = all_anchors[inds_inside]
+        n_in = anchors.size(0)
+
+        overlaps = bbox_overlaps_batch(anchors, gt_boxes)                 # [b, n_in, G]
+        max_ov, argmax_ov = overlaps.max(2)
+        gt_max = overlaps.max(1)[0]
+        labels = gt_boxes.new_full((b, n_in), -1)
+        if not cfg.TRAIN.RPN_CLOBBER_POSITIVES:
+            labels[max_ov < cfg.TRAIN.RPN_NEGATIVE_OVERLAP] = 0
+        gt_max = torch.where(gt_max == 0, torch.full_like(gt_max, 1e-5), gt_max)
+        is_best = (overlaps == gt_max.unsqueeze(1)).sum(2) > 0
+        labels[is_best] = 1
+        labels[max_ov >= cfg.TRAIN.RPN_POSITIVE_OVERLAP] = 1
+        if cfg.TRAIN.RPN_CLOBBER_POSITIVES:
+            labels[max_ov < cfg.TRAIN.RPN_NEGATIVE_OVERLAP] = 0
+
+        # ---- subsampling on the host: one D2H + one H2D, reference RNG call order ----------
+        num_fg = int(cfg.TRAIN.RPN_FG_FRACTION * cfg.TRAIN.RPN_BATCHSIZE)
+        lab = labels.cpu().numpy()
+        sum_bg = (lab == 0).sum(1)
+        for i in range(b):
+            fg = np.nonzero(lab[i] == 1)[0]
+            if fg.size > num_fg:
+                perm = np.random.permutation(fg.size)
+                lab[i, fg[perm[:fg.size - num_fg]]] = -1
+            num_bg = cfg.TRAIN.RPN_BATCHSIZE - int((lab[i] == 1).sum())
+            if sum_bg[i] > num_bg:
+                bg = np.nonzero(lab[i] == 0)[0]
+                perm = np.random.permutation(bg.size)
+                lab[i, bg[perm[:bg.size - num_bg]]] = -1
+        # uniform example weighting; like the reference, the count comes from the LAST image
+        assert cfg.TRAIN.RPN_POSITIVE_WEIGHT < 0
+        num_examples = int((lab[b - 1] >= 0).sum())
+        labels = torch.from_numpy(lab).to(dev)
+
+        gt_for_anchor = torch.gather(gt_boxes[:, :, :4], 1, argmax_ov.unsqueeze(2).expand(-1, -1, 4))
+        targets = bbox_transform_batch(anchors, gt_for_anchor)            # [b, n_in, 4]
+        inside_w = (labels == 1).to(gt_boxes.dtype) * cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0]
+        outside_w = (labels >= 0).to(gt_boxes.dtype) * (1.0 / num_examples)
+
+        def unmap(x, fill):
+            full = x.new_full((b, total) + tuple(x.shape[2:]), fill)
+            full[:, inds_inside] = x
+            return full
+
+        labels = unmap(labels, -1).view(b, H, W, A).permute(0, 3, 1, 2).reshape(b, 1, A * H, W)
+        targets = unmap(targets, 0).view(b, H, W, A * 4).permute(0, 3, 1, 2).contiguous()
+
+        def spread(wt):
+            return unmap(wt, 0).unsqueeze(2).expand(b, total, 4).reshape(b, H, W, 4 * A) \
+                .permute(0, 3, 1, 2).contiguous()
+
+        return [labels, targets, spread(inside_w), spread(outside_w)]
+
+
+class _ProposalTargetLayer(nn.Module):
+    """(all_rois [b,R,5], gt_boxes [b,G,5], num_boxes) -> rois [b,P,5], labels [b,P],
+    bbox_targets [b,P,4], inside weights, outside weights with P = cfg.TRAIN.BATCH_SIZE."""
+
+    def __init__(self, nclasses):
+        super().__init__()
+        self._num_classes = nclasses
+
+    def forward(self, all_rois, gt_boxes, num_boxes):
+        dev, dt = gt_boxes.device, gt_boxes.dtype
+        b = gt_boxes.size(0)
+        gt_as_rois = torch.zeros_like(gt_boxes)
+        gt_as_rois[:, :, 1:5] = gt_boxes[:, :, :4]
+        all_rois = torch.cat([all_rois, gt_as_rois], 1)
+        P = int(cfg.TRAIN.BATCH_SIZE)
+        fg_per_image = int(np.round(cfg.TRAIN.FG_FRACTION * P)) or 1
+
+        overlaps = bbox_overlaps_batch(all_rois, gt_boxes)
+        max_ov, assign = overlaps.max(2)
+        labels = torch.gather(gt_boxes[:, :, 4], 1, assign)
+
+        mo = max_ov.cpu().numpy()                       # the one D2H of this layer
+        keep = np.zeros((b, P), np.int64)
+        n_fg = np.zeros((b,), np.int64)
+        for i in range(b):
+            fg = np.nonzero(mo[i] >= cfg.TRAIN.FG_THRESH)[0]
+            bg = np.nonzero((mo[i] < cfg.TRAIN.BG_THRESH_HI) & (mo[i] >= cfg.TRAIN.BG_THRESH_LO))[0]
+            if fg.size > 0 and bg.size > 0:
+                k = min(fg_per_image, fg.size)
+                fg = fg[np.random.permutation(fg.size)[:k]]
+                bg = bg[np.floor(np.random.rand(P - k) * bg.size).astype(np.int64)]
+            elif fg.size > 0:
+                fg = fg[np.floor(np.random.rand(P) * fg.size).astype(np.int64)]
+                bg, k = fg[:0], P
+            elif bg.size > 0:
+                bg = bg[np.floor(np.random.rand(P) * bg.size).astype(np.int64)]
+                fg, k = bg[:0], 0
+            else:
+                raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
+            keep[i] = np.concatenate([fg, bg])
+            n_fg[i] = k
+        keep_t = torch.from_numpy(keep).to(dev)
+        is_fg = torch.arange(P, device=dev).unsqueeze(0) < torch.from_numpy(n_fg).to(dev).unsqueeze(1)
+
+        labels_b = torch.gather(labels, 1, keep_t) * is_fg.to(dt)
+        rois_b = torch.gather(all_rois, 1, keep_t.unsqueeze(2).expand(-1, -1, 5)).clone()
+        rois_b[:, :, 0] = torch.arange(b, device=dev, dtype=dt).unsqueeze(1)
+        gt_idx = torch.gather(assign, 1, keep_t)
+        gt_b = torch.gather(gt_boxes, 1, gt_idx.unsqueeze(2).expand(-1, -1, gt_boxes.size(2)))
+
+        targets = bbox_transform_batch(rois_b[:, :, 1:5], gt_b[:, :, :4])
+        if cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED:
+            means = torch.tensor(cfg.TRAIN.BBOX_NORMALIZE_MEANS, device=dev, dtype=dt)
+            stds = torch.tensor(cfg.TRAIN.BBOX_NORMALIZE_STDS, device=dev, dtype=dt)
+            targets = (targets - means) / stds
+        pos = (labels_b > 0).unsqueeze(2).to(dt)
+        # an image whose sampled labels sum to zero gets no regression targets at all
+        pos = pos * (labels_b.sum(1) != 0).view(b, 1, 1).to(dt)
+        bbox_targets = targets * pos
+        inside_w = pos * torch.tensor(cfg.TRAIN.BBOX_INSIDE_WEIGHTS, device=dev, dtype=dt)
+        outside_w = (inside_w > 0).to(dt)
+        return rois_b, labels_b, bbox_targets, inside_w, outside_w
+
+
+class _RPN(nn.Module):
+    """Region proposal network head: 3x3 conv -> {2A objectness, 4A box deltas}."""
+
+    def __init__(self, din):
+        super().__init__()
+        self.din = din
+        self.anchor_scales = cfg.ANCHOR_SCALES
+        self.anchor_ratios = cfg.ANCHOR_RATIOS
+        self.feat_stride = cfg.FEAT_STRIDE[0]
+        A = len(self.anchor_scales) * len(self.anchor_ratios)
+        self.RPN_Conv = nn.Conv2d(self.din, 512, 3, 1, 1, bias=True)
+        self.nc_score_out = A * 2
+        self.RPN_cls_score = nn.Conv2d(512, self.nc_score_out, 1, 1, 0)
+        self.nc_bbox_out = A * 4
+        self.RPN_bbox_pred = nn.Conv2d(512, self.nc_bbox_out, 1, 1, 0)
+        self.RPN_proposal = _ProposalLayer(self.feat_stride, self.anchor_scales, self.anchor_ratios)
+        self.RPN_anchor_target = _AnchorTargetLayer(self.feat_stride, self.anchor_scales, self.anchor_ratios)
+        self.rpn_loss_cls = 0
+        self.rpn_loss_box = 0
+
+    @staticmethod
+    def reshape(x, d):
+        s = x.size()
+        return x.contiguous().view(s[0], int(d), int(float(s[1] * s[2]) / float(d)), s[3])
+
+    def forward(self, base_feat, im_info, gt_boxes, num_boxes):
+        b = base_feat.size(0)
+        conv = F.relu(self.RPN_Conv(base_feat), inplace=True)
+        cls_score = self.RPN_cls_score(conv)
+        score_2 = self.reshape(cls_score, 2)
+        cls_prob = self.reshape(F.softmax(score_2, 1), self.nc_score_out)
+        bbox_pred = self.RPN_bbox_pred(conv)
+        rois = self.RPN_proposal((cls_prob.data, bbox_pred.data, im_info,
+                                  'TRAIN' if self.training else 'TEST'))
+        self.rpn_loss_cls = 0
+        self.rpn_loss_box = 0
+        if self.training:
+            assert gt_boxes is not None
+            labels, targets, w_in, w_out = self.RPN_anchor_target((cls_score.data, gt_boxes, im_info, num_boxes))
+            logits = score_2.permute(0, 2, 3, 1).reshape(-1, 2)
+            labels = labels.view(-1)
+            keep = torch.nonzero(labels != -1).view(-1)
+            self.rpn_loss_cls = F.cross_entropy(logits.index_select(0, keep),
+                                                labels.index_select(0, keep).long())
+            self.rpn_loss_box = _smooth_l1_loss(bbox_pred, targets, w_in, w_out, sigma=3, dim=[1, 2, 3])
+        return rois, self.rpn_loss_cls, self.rpn_loss_box

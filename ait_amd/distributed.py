@@ -1,0 +1,64 @@
+"""Data-parallel plumbing for the AIT path on one MI355X node: one process per GPU, RCCL
+(`backend="nccl"` on ROCm) over xGMI.
+
+The (target, query) pairs of a batch are independent, so the only exchange per
+step is the gradient all-reduce; it is bucketed (~25 MB) and overlapped with backward by
+torch's DistributedDataParallel reducer.  The reference's single-process nn.DataParallel
+(trainval_net_voc.py:321-326: per-step parameter broadcast + gather through device 0) is not
+reproduced.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend=None):
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def wrap(model, local_rank, bucket_mb=25):
+    """DDP with a static graph: parameters that never receive a gradient (the never-used
+    RCNN_base.backbone.fc and the SKBlock fc/sk that the reference computes but does not use)
+    are found on the first iteration and dropped from the reduction."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return model
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    ids = [local_rank] if next(model.parameters()).is_cuda else None
+    return DDP(model, device_ids=ids, bucket_cap_mb=bucket_mb, gradient_as_bucket_view=True,
+               static_graph=True)
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def shard_slice(n_items, rank, world):
+    """Contiguous even split of n_items work units (pairs) over ranks."""
+    per = n_items // world
+    extra = n_items % world
+    start = rank * per + min(rank, extra)
+    return start, start + per + (1 if rank < extra else 0)

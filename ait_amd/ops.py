@@ -10,6 +10,24 @@ def _p(t, dtype=torch.float32):
     return None if t is None else _lib.dev_ptr(t, dtype)
 
 
+# When set to a list, every GEMM launch appends (flops, start_event, end_event) recorded on the
+# launch stream (bench.py's live roofline measurement).
+GEMM_PROFILE = None
+
+
+def _profiled(fn, flops, device):
+    if GEMM_PROFILE is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream(device)
+    e0.record(st)
+    rc = fn()
+    e1.record(st)
+    GEMM_PROFILE.append((flops, e0, e1))
+    return rc
+
+
 def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, relu=False,
          accumulate=False, alpha=1.0, split_k=1, bias_row=False, c_colblk=0, c_batch_stride=0,
          out_shape=None):
@@ -38,11 +56,11 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, 
         | (_lib.GEMM_ACCUMULATE if accumulate and split_k == 1 else 0) \
         | (_lib.GEMM_ATOMIC if split_k > 1 else 0) | (_lib.GEMM_BIAS_ROW if bias_row else 0)
     with torch.cuda.device(a.device):
-        rc = _lib.lib().ait_gemm_f32(
+        rc = _profiled(lambda: _lib.lib().ait_gemm_f32(
             int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.dev_ptr(a), a.stride(0),
             _lib.dev_ptr(b), b.stride(0), ctypes.c_void_p(out.data_ptr()), ldc, _p(bias),
             _p(residual), flags, int(split_k), int(c_colblk), int(c_batch_stride),
-            _lib.cur_stream(a.device))
+            _lib.cur_stream(a.device)), 2.0 * M * N * K, a.device)
     _lib.check(rc, "ait_gemm_f32")
     return out
 
@@ -54,10 +72,10 @@ def gemm_relu_bwd(dy, w, act, out=None):
     if out is None:
         out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
     with torch.cuda.device(dy.device):
-        rc = _lib.lib().ait_gemm_f32(0, 0, M, K, N, 1.0, _lib.dev_ptr(dy), dy.stride(0),
-                                     _lib.dev_ptr(w), w.stride(0), _lib.dev_ptr(out), out.stride(0),
-                                     None, _lib.dev_ptr(act), _lib.GEMM_MASK_POS, 1, 0, 0,
-                                     _lib.cur_stream(dy.device))
+        rc = _profiled(lambda: _lib.lib().ait_gemm_f32(
+            0, 0, M, K, N, 1.0, _lib.dev_ptr(dy), dy.stride(0), _lib.dev_ptr(w), w.stride(0),
+            _lib.dev_ptr(out), out.stride(0), None, _lib.dev_ptr(act), _lib.GEMM_MASK_POS, 1, 0, 0,
+            _lib.cur_stream(dy.device)), 2.0 * M * N * K, dy.device)
     _lib.check(rc, "ait_gemm_f32(mask)")
     return out
 

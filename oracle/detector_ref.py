@@ -1,0 +1,534 @@
+"""oracle/detector_ref.py -- TEST INFRASTRUCTURE ONLY (never imported by ait_amd/).
+
+CPU restatement, functional over a state_dict, of the whole `_fasterRCNN.forward` of the VOC
+variant, i.e. the caller of the hot path and the similarity logits that the parity contract is
+stated on.  Used as the checker in tests/ and __graft_entry__.smoke(), and timed as the
+`cpu_baseline` ("port") by bench.py -- the reference itself cannot run backward on the CPU
+(lib/model/csrc/ROIAlign.h:44).
+
+Follows (paths relative to /root/reference):
+  trunk / layer4 head      lib/model/faster_rcnn/resnet_sys_transformer_sk_dilat.py:72-172,227-356,482-491
+  co-attention             lib/model/faster_rcnn/faster_rcnn_sys_transformer_sk_dilat.py:31-102
+  RPN head                 lib/model/rpn/rpn.py:65-128
+  anchors                  lib/model/rpn/generate_anchors.py:45-105
+  proposal layer           lib/model/rpn/proposal_layer.py:51-166
+  anchor target layer      lib/model/rpn/anchor_target_layer.py:50-199
+  proposal target layer    lib/model/rpn/proposal_target_layer_cascade.py:33-220
+  box arithmetic           lib/model/rpn/bbox_transform.py
+  SKBlock (with its f*f quirk)   lib/model/modules/blocks_sys_transformer_sk_dilat.py:915-997
+  forward + heads + losses lib/model/faster_rcnn/faster_rcnn_sys_transformer_sk_dilat.py:173-328
+  smooth L1                lib/model/utils/net_utils.py:75-89
+RoIAlign / NMS come from oracle/native.c, the AIT transformer from oracle/ait_ref.py.
+
+Pinned against tests/golden/g6..g10 (oracle/gen_golden_detector.py runs the imported reference
+on the same seeded inputs / weights).
+"""
+import math
+import time
+import zlib
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ait_ref, native
+
+
+# ------------------------------------------------------------------------------------------
+# configuration (the keys of lib/model/utils/config.py the path reads, after cfgs/res50.yml)
+# ------------------------------------------------------------------------------------------
+def default_config():
+    return dict(
+        ANCHOR_SCALES=[8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], FEAT_STRIDE=16, POOLING_SIZE=7,
+        TRAIN=dict(RPN_PRE_NMS_TOP_N=12000, RPN_POST_NMS_TOP_N=2000, RPN_NMS_THRESH=0.7,
+                   RPN_POSITIVE_OVERLAP=0.7, RPN_NEGATIVE_OVERLAP=0.3, RPN_CLOBBER_POSITIVES=False,
+                   RPN_FG_FRACTION=0.5, RPN_BATCHSIZE=256, RPN_BBOX_INSIDE_WEIGHTS=(1., 1., 1., 1.),
+                   BATCH_SIZE=128, FG_FRACTION=0.25, FG_THRESH=0.5, BG_THRESH_HI=0.5,
+                   BG_THRESH_LO=0.0, BBOX_NORMALIZE_MEANS=(0., 0., 0., 0.),
+                   BBOX_NORMALIZE_STDS=(0.1, 0.1, 0.2, 0.2), BBOX_INSIDE_WEIGHTS=(1., 1., 1., 1.),
+                   MARGIN=-0.3),
+        TEST=dict(RPN_PRE_NMS_TOP_N=6000, RPN_POST_NMS_TOP_N=300, RPN_NMS_THRESH=0.7),
+    )
+
+
+# ------------------------------------------------------------------------------------------
+# anchors and box arithmetic
+# ------------------------------------------------------------------------------------------
+def generate_anchors(base_size=16, ratios=(0.5, 1, 2), scales=(8, 16, 32)):
+    out = []
+    ctr = (base_size - 1) * 0.5
+    for r in ratios:
+        w = np.round(np.sqrt(base_size * base_size / r))
+        h = np.round(w * r)
+        for s in scales:
+            ws, hs = w * s, h * s
+            out.append([ctr - 0.5 * (ws - 1), ctr - 0.5 * (hs - 1), ctr + 0.5 * (ws - 1), ctr + 0.5 * (hs - 1)])
+    return np.array(out, dtype=np.float64)
+
+
+def anchor_grid(H, W, stride, scales, ratios):
+    base = torch.from_numpy(generate_anchors(scales=scales, ratios=ratios)).float()
+    ys, xs = np.meshgrid(np.arange(H) * stride, np.arange(W) * stride, indexing="ij")
+    shifts = torch.from_numpy(np.stack([xs.ravel(), ys.ravel(), xs.ravel(), ys.ravel()], 1)).float()
+    return (base.view(1, -1, 4) + shifts.view(-1, 1, 4)).reshape(-1, 4)
+
+
+def decode_boxes(anchors, deltas):
+    w = anchors[..., 2] - anchors[..., 0] + 1.0
+    h = anchors[..., 3] - anchors[..., 1] + 1.0
+    cx = anchors[..., 0] + 0.5 * w
+    cy = anchors[..., 1] + 0.5 * h
+    pcx = deltas[..., 0] * w + cx
+    pcy = deltas[..., 1] * h + cy
+    pw = torch.exp(deltas[..., 2]) * w
+    ph = torch.exp(deltas[..., 3]) * h
+    return torch.stack([pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph], -1)
+
+
+def encode_boxes(ex, gt):
+    ew = ex[..., 2] - ex[..., 0] + 1.0
+    eh = ex[..., 3] - ex[..., 1] + 1.0
+    ecx = ex[..., 0] + 0.5 * ew
+    ecy = ex[..., 1] + 0.5 * eh
+    gw = gt[..., 2] - gt[..., 0] + 1.0
+    gh = gt[..., 3] - gt[..., 1] + 1.0
+    gcx = gt[..., 0] + 0.5 * gw
+    gcy = gt[..., 1] + 0.5 * gh
+    return torch.stack([(gcx - ecx) / ew, (gcy - ecy) / eh, torch.log(gw / ew), torch.log(gh / eh)], -1)
+
+
+def iou_batch(boxes, gt):
+    """boxes [b,N,4], gt [b,K,4] -> [b,N,K] with the reference's zero-area conventions."""
+    bw = boxes[..., 2] - boxes[..., 0] + 1
+    bh = boxes[..., 3] - boxes[..., 1] + 1
+    gw = gt[..., 2] - gt[..., 0] + 1
+    gh = gt[..., 3] - gt[..., 1] + 1
+    B, G = boxes[:, :, None, :], gt[:, None, :, :]
+    iw = (torch.minimum(B[..., 2], G[..., 2]) - torch.maximum(B[..., 0], G[..., 0]) + 1).clamp(min=0)
+    ih = (torch.minimum(B[..., 3], G[..., 3]) - torch.maximum(B[..., 1], G[..., 1]) + 1).clamp(min=0)
+    inter = iw * ih
+    ov = inter / ((bw * bh)[:, :, None] + (gw * gh)[:, None, :] - inter)
+    ov = ov.masked_fill(((gw == 1) & (gh == 1))[:, None, :], 0)
+    ov = ov.masked_fill(((bw == 1) & (bh == 1))[:, :, None], -1)
+    return ov
+
+
+def smooth_l1(pred, target, w_in, w_out, sigma=1.0, dims=(1,)):
+    s2 = sigma ** 2
+    d = w_in * (pred - target)
+    ad = d.abs()
+    near = (ad < 1.0 / s2).float()
+    loss = w_out * (d * d * (s2 / 2.0) * near + (ad - 0.5 / s2) * (1.0 - near))
+    for i in sorted(dims, reverse=True):
+        loss = loss.sum(i)
+    return loss.mean()
+
+
+# ------------------------------------------------------------------------------------------
+# RoIAlign with autograd (forward / backward = oracle/native.c)
+# ------------------------------------------------------------------------------------------
+class _RoIAlignCPU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, pooled, scale):
+        ctx.save_for_backward(rois)
+        ctx.meta = (tuple(feat.shape), pooled, scale)
+        return torch.from_numpy(native.roi_align_fwd(feat.detach().numpy(), rois.numpy(), (pooled, pooled), scale, 0))
+
+    @staticmethod
+    def backward(ctx, g):
+        (rois,) = ctx.saved_tensors
+        shape, pooled, scale = ctx.meta
+        return torch.from_numpy(native.roi_align_bwd(g.contiguous().numpy(), rois.numpy(), shape, scale, 0)), None, None, None
+
+
+# ------------------------------------------------------------------------------------------
+# backbone
+# ------------------------------------------------------------------------------------------
+def _bn(x, sd, p):
+    return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"],
+                        sd[p + "bias"], False, 0.0, 1e-5)
+
+
+def _bottleneck(x, sd, p, stride):
+    out = F.relu(_bn(F.conv2d(x, sd[p + "conv1.weight"], stride=stride), sd, p + "bn1."))
+    out = F.relu(_bn(F.conv2d(out, sd[p + "conv2.weight"], padding=1), sd, p + "bn2."))
+    out = _bn(F.conv2d(out, sd[p + "conv3.weight"]), sd, p + "bn3.")
+    if (p + "downsample.0.weight") in sd:
+        x = _bn(F.conv2d(x, sd[p + "downsample.0.weight"], stride=stride), sd, p + "downsample.1.")
+    return F.relu(out + x)
+
+
+def _stage(x, sd, p, stride):
+    i = 0
+    while (p + "%d.conv1.weight" % i) in sd:
+        x = _bottleneck(x, sd, p + "%d." % i, stride if i == 0 else 1)
+        i += 1
+    return x
+
+
+def trunk(x, sd, pre="RCNN_base.backbone."):
+    x = F.relu(_bn(F.conv2d(x, sd[pre + "conv1.weight"], stride=2, padding=3), sd, pre + "bn1."))
+    x = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
+    x = _stage(x, sd, pre + "layer1.", 1)
+    x = _stage(x, sd, pre + "layer2.", 2)
+    return _stage(x, sd, pre + "layer3.", 2)
+
+
+def head_to_tail(x, sd, pre="RCNN_top.0."):
+    return _stage(x, sd, pre, 2).mean(3).mean(2)
+
+
+def coattention(sd, x_img, x_qry, pre="coattention."):
+    bs, C, hi, wi = x_img.shape
+    hq, wq = x_qry.shape[2:]
+    img = F.conv2d(x_img, sd[pre + "img_emb.0.weight"], sd[pre + "img_emb.0.bias"]).flatten(2).transpose(1, 2)
+    qry = F.conv2d(x_qry, sd[pre + "qry_emb.0.weight"], sd[pre + "qry_emb.0.bias"]).flatten(2).transpose(1, 2)
+    e_img, _ = ait_ref.multi_head_attention(sd, pre + "q2i_attn.", img, qry, qry, None)
+    e_qry, _ = ait_ref.multi_head_attention(sd, pre + "i2q_attn.", qry, img, img, None)
+    non_img = F.linear(e_img, sd[pre + "img_trans.0.weight"], sd[pre + "img_trans.0.bias"])
+    non_qry = F.linear(e_qry, sd[pre + "qry_trans.0.weight"], sd[pre + "qry_trans.0.bias"])
+    return (non_img.transpose(1, 2).reshape(bs, C, hi, wi), non_qry.transpose(1, 2).reshape(bs, C, hq, wq))
+
+
+def sk_block(sd, pre, x):
+    f0 = F.relu(F.conv2d(x, sd[pre + "convs.0.0.weight"], sd[pre + "convs.0.0.bias"], groups=8))
+    f1 = F.relu(F.conv2d(x, sd[pre + "convs.1.0.weight"], sd[pre + "convs.1.0.bias"], padding=1, groups=8))
+    return f0 * f0 + f1 * f1          # the attention weights are computed but unused upstream
+
+
+# ------------------------------------------------------------------------------------------
+# RPN
+# ------------------------------------------------------------------------------------------
+def proposal_layer(cfgd, key, cls_prob, bbox_pred, im_info):
+    c = cfgd[key]
+    A = len(cfgd["ANCHOR_SCALES"]) * len(cfgd["ANCHOR_RATIOS"])
+    b, _, H, W = bbox_pred.shape
+    scores = cls_prob[:, A:].permute(0, 2, 3, 1).reshape(b, -1)
+    deltas = bbox_pred.permute(0, 2, 3, 1).reshape(b, -1, 4)
+    anchors = anchor_grid(H, W, cfgd["FEAT_STRIDE"], cfgd["ANCHOR_SCALES"], cfgd["ANCHOR_RATIOS"])
+    boxes = decode_boxes(anchors.unsqueeze(0), deltas)
+    for i in range(b):
+        boxes[i, :, 0::2].clamp_(0, float(im_info[i, 1]) - 1)
+        boxes[i, :, 1::2].clamp_(0, float(im_info[i, 0]) - 1)
+    order = torch.sort(scores, 1, True)[1]
+    post = c["RPN_POST_NMS_TOP_N"]
+    out = torch.zeros(b, post, 5)
+    for i in range(b):
+        o = order[i]
+        if 0 < c["RPN_PRE_NMS_TOP_N"] < scores.numel():
+            o = o[:c["RPN_PRE_NMS_TOP_N"]]
+        cand = boxes[i][o]
+        keep = native.nms(cand.numpy(), scores[i][o].numpy(), c["RPN_NMS_THRESH"])[:post]
+        out[i, :, 0] = i
+        out[i, :len(keep), 1:] = cand[torch.from_numpy(keep)]
+    return out
+
+
+def anchor_target_layer(cfgd, cls_score, gt_boxes, im_info):
+    t = cfgd["TRAIN"]
+    b = gt_boxes.shape[0]
+    H, W = cls_score.shape[2:]
+    A = len(cfgd["ANCHOR_SCALES"]) * len(cfgd["ANCHOR_RATIOS"])
+    allanc = anchor_grid(H, W, cfgd["FEAT_STRIDE"], cfgd["ANCHOR_SCALES"], cfgd["ANCHOR_RATIOS"])
+    total = allanc.shape[0]
+    inside = torch.nonzero((allanc[:, 0] >= 0) & (allanc[:, 1] >= 0) & (allanc[:, 2] < int(im_info[0][1])) &
+                           (allanc[:, 3] < int(im_info[0][0]))).view(-1)
+    anc = allanc[inside]
+    ov = iou_batch(anc.unsqueeze(0).expand(b, -1, 4), gt_boxes[:, :, :4])
+    max_ov, arg = ov.max(2)
+    gt_max = ov.max(1)[0]
+    labels = torch.full((b, anc.shape[0]), -1.0)
+    labels[max_ov < t["RPN_NEGATIVE_OVERLAP"]] = 0
+    gt_max[gt_max == 0] = 1e-5
+    labels[(ov == gt_max[:, None, :]).sum(2) > 0] = 1
+    labels[max_ov >= t["RPN_POSITIVE_OVERLAP"]] = 1
+    num_fg = int(t["RPN_FG_FRACTION"] * t["RPN_BATCHSIZE"])
+    sum_fg = (labels == 1).sum(1)
+    sum_bg = (labels == 0).sum(1)
+    for i in range(b):
+        if sum_fg[i] > num_fg:
+            fg = torch.nonzero(labels[i] == 1).view(-1)
+            perm = torch.from_numpy(np.random.permutation(fg.numel())).long()
+            labels[i][fg[perm[:fg.numel() - num_fg]]] = -1
+        num_bg = t["RPN_BATCHSIZE"] - int((labels[i] == 1).sum())
+        if sum_bg[i] > num_bg:
+            bg = torch.nonzero(labels[i] == 0).view(-1)
+            perm = torch.from_numpy(np.random.permutation(bg.numel())).long()
+            labels[i][bg[perm[:bg.numel() - num_bg]]] = -1
+    n_ex = int((labels[b - 1] >= 0).sum())          # the reference's leaked loop variable
+    targets = encode_boxes(anc.unsqueeze(0), torch.gather(gt_boxes[:, :, :4], 1, arg[:, :, None].expand(-1, -1, 4)))
+    w_in = (labels == 1).float() * t["RPN_BBOX_INSIDE_WEIGHTS"][0]
+    w_out = (labels >= 0).float() / n_ex
+
+    def unmap(x, fill):
+        full = torch.full((b, total) + tuple(x.shape[2:]), float(fill))
+        full[:, inside] = x
+        return full
+    labels = unmap(labels, -1).view(b, H, W, A).permute(0, 3, 1, 2).reshape(b, 1, A * H, W)
+    targets = unmap(targets, 0).view(b, H, W, A * 4).permute(0, 3, 1, 2)
+    w_in = unmap(w_in, 0)[:, :, None].expand(b, total, 4).reshape(b, H, W, 4 * A).permute(0, 3, 1, 2)
+    w_out = unmap(w_out, 0)[:, :, None].expand(b, total, 4).reshape(b, H, W, 4 * A).permute(0, 3, 1, 2)
+    return labels, targets, w_in, w_out
+
+
+def rpn_forward(sd, cfgd, feat, im_info, gt_boxes, training, pre="RCNN_rpn."):
+    b = feat.shape[0]
+    A = len(cfgd["ANCHOR_SCALES"]) * len(cfgd["ANCHOR_RATIOS"])
+    conv = F.relu(F.conv2d(feat, sd[pre + "RPN_Conv.weight"], sd[pre + "RPN_Conv.bias"], padding=1))
+    cls_score = F.conv2d(conv, sd[pre + "RPN_cls_score.weight"], sd[pre + "RPN_cls_score.bias"])
+    H, W = cls_score.shape[2:]
+    score2 = cls_score.reshape(b, 2, A * H, W)
+    cls_prob = F.softmax(score2, 1).reshape(b, 2 * A, H, W)
+    bbox_pred = F.conv2d(conv, sd[pre + "RPN_bbox_pred.weight"], sd[pre + "RPN_bbox_pred.bias"])
+    rois = proposal_layer(cfgd, "TRAIN" if training else "TEST", cls_prob.detach(), bbox_pred.detach(), im_info)
+    loss_cls = loss_box = 0
+    if training:
+        labels, targets, w_in, w_out = anchor_target_layer(cfgd, cls_score.detach(), gt_boxes, im_info)
+        logits = score2.permute(0, 2, 3, 1).reshape(-1, 2)
+        lab = labels.reshape(-1)
+        keep = torch.nonzero(lab != -1).view(-1)
+        loss_cls = F.cross_entropy(logits[keep], lab[keep].long())
+        loss_box = smooth_l1(bbox_pred, targets, w_in, w_out, sigma=3, dims=(1, 2, 3))
+    return rois, loss_cls, loss_box, dict(cls_prob=cls_prob, bbox_pred=bbox_pred)
+
+
+def proposal_target_layer(cfgd, all_rois, gt_boxes):
+    t = cfgd["TRAIN"]
+    b = gt_boxes.shape[0]
+    gt_rois = torch.zeros_like(gt_boxes)
+    gt_rois[:, :, 1:5] = gt_boxes[:, :, :4]
+    all_rois = torch.cat([all_rois, gt_rois], 1)
+    P = int(t["BATCH_SIZE"])
+    fg_per = int(np.round(t["FG_FRACTION"] * P)) or 1
+    ov = iou_batch(all_rois[:, :, 1:5], gt_boxes[:, :, :4])
+    max_ov, assign = ov.max(2)
+    labels = torch.gather(gt_boxes[:, :, 4], 1, assign)
+    lab_b = torch.zeros(b, P)
+    rois_b = torch.zeros(b, P, 5)
+    gt_b = torch.zeros(b, P, 5)
+    for i in range(b):
+        fg = torch.nonzero(max_ov[i] >= t["FG_THRESH"]).view(-1)
+        bg = torch.nonzero((max_ov[i] < t["BG_THRESH_HI"]) & (max_ov[i] >= t["BG_THRESH_LO"])).view(-1)
+        nf, nb_ = fg.numel(), bg.numel()
+        if nf > 0 and nb_ > 0:
+            k = min(fg_per, nf)
+            fg = fg[torch.from_numpy(np.random.permutation(nf)).long()[:k]]
+            bg = bg[torch.from_numpy(np.floor(np.random.rand(P - k) * nb_)).long()]
+        elif nf > 0:
+            fg = fg[torch.from_numpy(np.floor(np.random.rand(P) * nf)).long()]
+            bg, k = fg[:0], P
+        elif nb_ > 0:
+            bg = bg[torch.from_numpy(np.floor(np.random.rand(P) * nb_)).long()]
+            fg, k = bg[:0], 0
+        else:
+            raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
+        keep = torch.cat([fg, bg])
+        lab_b[i] = labels[i][keep]
+        lab_b[i, k:] = 0
+        rois_b[i] = all_rois[i][keep]
+        rois_b[i, :, 0] = i
+        gt_b[i] = gt_boxes[i][assign[i][keep]]
+    targets = encode_boxes(rois_b[:, :, 1:5], gt_b[:, :, :4])
+    targets = (targets - torch.tensor(t["BBOX_NORMALIZE_MEANS"])) / torch.tensor(t["BBOX_NORMALIZE_STDS"])
+    pos = ((lab_b > 0) & (lab_b.sum(1, keepdim=True) != 0)).float()[:, :, None]
+    w_in = pos * torch.tensor(t["BBOX_INSIDE_WEIGHTS"])
+    return rois_b, lab_b, targets * pos, w_in, (w_in > 0).float()
+
+
+# ------------------------------------------------------------------------------------------
+# the detector forward
+# ------------------------------------------------------------------------------------------
+def detector_forward(sd, cfgd, image, query, im_info, gt_boxes, num_boxes, training, rois_override=None):
+    bs = image.shape[0]
+    image_feat = trunk(image, sd)
+    query_feat = trunk(query, sd)
+    non_img, non_qry = coattention(sd, image_feat, query_feat)
+    rois, rpn_loss_cls, rpn_loss_bbox, rpn_aux = rpn_forward(sd, cfgd, non_img, im_info, gt_boxes, training)
+    rois_label = None
+    if training:
+        rois, lab, rois_target, w_in, w_out = proposal_target_layer(cfgd, rois, gt_boxes)
+        rois_label = lab.view(-1).long()
+        rois_target, w_in, w_out = rois_target.view(-1, 4), w_in.view(-1, 4), w_out.view(-1, 4)
+    else:
+        rpn_loss_cls = rpn_loss_bbox = 0
+    if rois_override is not None:
+        rois = rois_override
+    P = rois.shape[1]
+    props = _RoIAlignCPU.apply(non_img, rois.reshape(-1, 5).contiguous(), cfgd["POOLING_SIZE"], 1.0 / 16.0)
+    ait_out = ait_ref.transformer_forward(sd, props, non_qry, pre="transformer.")
+    f_props = sk_block(sd, "sk.sk_props.", ait_out)
+    f_query = sk_block(sd, "sk.sk_query.", non_qry)
+    v_props = head_to_tail(f_props, sd)
+    v_query = head_to_tail(f_query, sd)
+    bbox_pred = F.linear(v_props, sd["RCNN_bbox_pred.weight"], sd["RCNN_bbox_pred.bias"])
+    stack = torch.cat([v_props.view(bs, P, -1), v_query[:, None, :].expand(-1, P, -1)], 2).reshape(-1, 4096)
+    score = F.linear(F.linear(stack, sd["RCNN_cls_score.0.weight"], sd["RCNN_cls_score.0.bias"]),
+                     sd["RCNN_cls_score.1.weight"], sd["RCNN_cls_score.1.bias"])
+    prob = F.softmax(score, 1)[:, 1]
+    loss_cls = loss_box = margin = 0
+    if training:
+        sl = rois_label.view(bs, -1).float()
+        gt_map = (sl[:, None, :] - sl[:, :, None]).abs()
+        sp = prob.view(bs, -1)
+        pr_map = (sp[:, None, :] - sp[:, :, None]).abs()
+        target = -((gt_map - 1) ** 2) + gt_map
+        loss_cls = F.cross_entropy(score, rois_label)
+        margin = 3 * F.margin_ranking_loss(pr_map, gt_map, target, margin=cfgd["TRAIN"]["MARGIN"])
+        loss_box = smooth_l1(bbox_pred, rois_target, w_in, w_out)
+    out = (rois, prob.view(bs, P, -1), bbox_pred.view(bs, P, -1), rpn_loss_cls, rpn_loss_bbox, loss_cls,
+           margin, loss_box, rois_label, None)
+    aux = dict(score=score, image_feat=image_feat, query_feat=query_feat, non_img=non_img, non_qry=non_qry,
+               props=props, ait_out=ait_out, **rpn_aux)
+    return out, aux
+
+
+# ------------------------------------------------------------------------------------------
+# deterministic detector weights: f(seed, name, shape) on MT19937
+# ------------------------------------------------------------------------------------------
+def make_detector_state_dict(seed, shapes):
+    """shapes: {state_dict key: shape}, e.g. from the product model's state_dict().  The
+    distributions follow the reference's initialisers (He-normal convs resnet :139-145, N(0,.01)
+    RPN / cls heads and N(0,.001) box head faster_rcnn_*:342-347, xavier inside AIT); batch-norm
+    statistics are made non-trivial but tame so 16 residual blocks keep O(1) activations."""
+    sd = {}
+    for name, shape in shapes.items():
+        shape = tuple(shape)
+        rs = np.random.RandomState((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 32))
+        leaf = name.split(".")[-1]
+        if name.startswith("transformer."):
+            sub = name[len("transformer."):]
+            if "pos_table" in sub:
+                v = ait_ref.pos_table(shape[1], shape[2]).numpy()
+            else:
+                v = ait_ref.make_tensor(seed, sub, shape).numpy()
+        elif leaf == "num_batches_tracked":
+            v = np.zeros(shape, np.int64)
+        elif leaf == "running_mean":
+            v = rs.uniform(-0.1, 0.1, shape)
+        elif leaf == "running_var":
+            v = rs.uniform(0.8, 1.2, shape)
+        elif ".bn" in name or "downsample.1" in name:
+            if leaf == "weight":
+                v = rs.uniform(0.2, 0.4, shape) if ".bn3." in name else rs.uniform(0.8, 1.2, shape)
+            else:
+                v = rs.uniform(-0.05, 0.05, shape)
+        elif "layer_norm" in name:
+            v = 1.0 + rs.uniform(-0.1, 0.1, shape) if leaf == "weight" else rs.uniform(-0.1, 0.1, shape)
+        elif name.startswith("RCNN_rpn.") or name.startswith("RCNN_cls_score."):
+            v = rs.normal(0, 0.01, shape) if leaf == "weight" else np.zeros(shape)
+        elif name.startswith("RCNN_bbox_pred."):
+            v = rs.normal(0, 0.001, shape) if leaf == "weight" else np.zeros(shape)
+        elif len(shape) == 4:                                  # convolutions
+            fan_out = shape[0] * shape[2] * shape[3]
+            v = rs.normal(0, math.sqrt(2.0 / fan_out), shape)
+        elif len(shape) == 2:                                  # linear layers (co-attention, SK)
+            a = math.sqrt(6.0 / (shape[0] + shape[1]))
+            v = rs.uniform(-a, a, shape)
+        else:
+            v = rs.uniform(-0.05, 0.05, shape)
+        sd[name] = torch.from_numpy(np.asarray(v)).to(torch.int64 if leaf == "num_batches_tracked" else torch.float32)
+    return sd
+
+
+def synth_inputs(bs, seed, im_hw=(600, 1000), q=128, max_gt=20, n_gt=3):
+    rs = np.random.RandomState(seed)
+    im = torch.from_numpy(rs.standard_normal((bs, 3) + tuple(im_hw)).astype(np.float32))
+    qr = torch.from_numpy(rs.standard_normal((bs, 3, q, q)).astype(np.float32))
+    info = torch.tensor([[im_hw[0], im_hw[1], 1.0]] * bs)
+    gt = torch.zeros(bs, max_gt, 5)
+    for b in range(bs):
+        for k in range(n_gt):
+            w, h = rs.uniform(64, 400, 2)
+            x1, y1 = rs.uniform(0, im_hw[1] - w), rs.uniform(0, im_hw[0] - h)
+            gt[b, k] = torch.tensor([x1, y1, x1 + w, y1 + h, 1.0])
+    return im, qr, info, gt, torch.full((bs,), n_gt)
+
+
+def reference_shapes(n_layers=50, A=9):
+    """state_dict shapes of the VOC-variant detector without instantiating the product."""
+    s = {}
+
+    def bn(p, c):
+        s[p + "weight"] = (c,); s[p + "bias"] = (c,); s[p + "running_mean"] = (c,)
+        s[p + "running_var"] = (c,); s[p + "num_batches_tracked"] = ()
+    blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[n_layers]
+    pre = "RCNN_base.backbone."
+    s[pre + "conv1.weight"] = (64, 3, 7, 7)
+    bn(pre + "bn1.", 64)
+    inpl = 64
+    for li, (planes, n) in enumerate(zip((64, 128, 256, 512), blocks), 1):
+        for i in range(n):
+            p = pre + "layer%d.%d." % (li, i)
+            s[p + "conv1.weight"] = (planes, inpl, 1, 1); bn(p + "bn1.", planes)
+            s[p + "conv2.weight"] = (planes, planes, 3, 3); bn(p + "bn2.", planes)
+            s[p + "conv3.weight"] = (planes * 4, planes, 1, 1); bn(p + "bn3.", planes * 4)
+            if i == 0:
+                s[p + "downsample.0.weight"] = (planes * 4, inpl, 1, 1); bn(p + "downsample.1.", planes * 4)
+            inpl = planes * 4
+    s[pre + "fc.weight"] = (1000, 2048); s[pre + "fc.bias"] = (1000,)
+    for k in list(s):
+        sub = k[len(pre):]
+        if sub.startswith("layer4."):
+            s["RCNN_top.0." + sub[len("layer4."):]] = s[k]
+    for sub, shp in ait_ref.ait_param_shapes().items():
+        s["transformer." + sub] = shp
+    s["transformer.encoder.position_enc.pos_table"] = (1, 64, 512)
+    s["transformer.decoder.position_enc.pos_table"] = (1, 64, 512)
+    c = "coattention."
+    for e in ("img_emb", "qry_emb"):
+        s[c + e + ".0.weight"] = (512, 1024, 1, 1); s[c + e + ".0.bias"] = (512,)
+    for a in ("i2q_attn.", "q2i_attn."):
+        for w in ("w_qs", "w_ks", "w_vs"):
+            s[c + a + w + ".weight"] = (512, 512)
+        s[c + a + "sh.sk.weight"] = (512, 64); s[c + a + "sh.sk.bias"] = (512,)
+        s[c + a + "fc.weight"] = (512, 64)
+        s[c + a + "layer_norm.weight"] = (512,); s[c + a + "layer_norm.bias"] = (512,)
+    for e in ("img_trans", "qry_trans"):
+        s[c + e + ".0.weight"] = (1024, 512); s[c + e + ".0.bias"] = (1024,)
+    for b in ("sk.sk_props.", "sk.sk_query."):
+        s[b + "convs.0.0.weight"] = (1024, 128, 1, 1); s[b + "convs.0.0.bias"] = (1024,)
+        s[b + "convs.1.0.weight"] = (1024, 128, 3, 3); s[b + "convs.1.0.bias"] = (1024,)
+        s[b + "fc.weight"] = (64, 1024); s[b + "fc.bias"] = (64,)
+        s[b + "sk.weight"] = (2048, 64); s[b + "sk.bias"] = (2048,)
+    r = "RCNN_rpn."
+    s[r + "RPN_Conv.weight"] = (512, 1024, 3, 3); s[r + "RPN_Conv.bias"] = (512,)
+    s[r + "RPN_cls_score.weight"] = (2 * A, 512, 1, 1); s[r + "RPN_cls_score.bias"] = (2 * A,)
+    s[r + "RPN_bbox_pred.weight"] = (4 * A, 512, 1, 1); s[r + "RPN_bbox_pred.bias"] = (4 * A,)
+    s["RCNN_cls_score.0.weight"] = (8, 4096); s["RCNN_cls_score.0.bias"] = (8,)
+    s["RCNN_cls_score.1.weight"] = (2, 8); s["RCNN_cls_score.1.bias"] = (2,)
+    s["RCNN_bbox_pred.weight"] = (4, 2048); s["RCNN_bbox_pred.bias"] = (4,)
+    return s
+
+
+def time_train_step(P=300, cores=1, seconds_budget=25.0, seed=5):
+    """cpu_baseline leg of bench.py: forward + backward of ONE (target, query) pair per
+    iteration (600x1000 target, 128x128 query, P proposals) until the budget is spent."""
+    cfgd = default_config()
+    cfgd["TRAIN"]["BATCH_SIZE"] = P
+    sd = make_detector_state_dict(seed, reference_shapes())
+    frozen = ("RCNN_base.backbone.conv1.", "RCNN_base.backbone.bn1.", "running_", "num_batches", "pos_table")
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and not any(f in k for f in frozen) and ".bn" not in k \
+                and "downsample.1" not in k:
+            v.requires_grad_(True)
+    np.random.seed(3)
+    times = []
+    t_start = time.perf_counter()
+    it = 0
+    while True:
+        im, qr, info, gt, nb = synth_inputs(1, 100 + it)
+        t0 = time.perf_counter()
+        out, _ = detector_forward(sd, cfgd, im, qr, info, gt, nb, True)
+        loss = out[3] + out[4] + out[5] + out[6] + out[7]
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        for v in sd.values():
+            v.grad = None
+        it += 1
+        if time.perf_counter() - t_start > seconds_budget or it >= 8:
+            break
+    best = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    return {"value": 1.0 / best, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d single-pair train iterations (fwd+bwd, 600x1000 target, P=%d) of "
+                      "oracle/detector_ref.py with torch.set_num_threads(%d); RoIAlign/NMS from "
+                      "oracle/native.c run single-threaded; median of all but the first" % (it, P, cores)}

@@ -84,3 +84,25 @@ def nms_tie_case():
 
 NMS_SIZES = (1, 64, 65, 1000, 6000, 12000)
 NMS_THRESHOLDS = (0.7, 0.3)
+
+
+def rpn_case(A=9, b=2):
+    """seeded RPN outputs at the 38x63 feature size"""
+    H, W = FEAT_H, FEAT_W
+    rs = np.random.RandomState(701)
+    fg = rs.uniform(0.0, 1.0, (b, A, H, W)).astype(np.float32)
+    prob = np.concatenate([1 - fg, fg], 1)
+    deltas = (rs.standard_normal((b, 4 * A, H, W)) * 0.25).astype(np.float32)
+    im_info = np.array([[600, 1000, 1.0]] * b, np.float32)
+    return prob, deltas, im_info
+
+
+def gt_case(b=2, G=20, n=3, seed=702):
+    rs = np.random.RandomState(seed)
+    gt = np.zeros((b, G, 5), np.float32)
+    for i in range(b):
+        for k in range(n):
+            w, h = rs.uniform(64, 400, 2)
+            x1, y1 = rs.uniform(0, 1000 - w), rs.uniform(0, 600 - h)
+            gt[i, k] = (x1, y1, x1 + w, y1 + h, 1.0)
+    return gt

@@ -1,0 +1,84 @@
+"""The N>1 path on CPU: two gloo ranks exercise ait_amd.distributed (init from the
+torch.distributed.run environment, DDP wrap with static graph + a never-used parameter, pair
+sharding, max-over-ranks timing) with a stand-in module (the HIP ops need a GPU)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys, torch, torch.nn as nn
+    sys.path.insert(0, %r)
+    from ait_amd import distributed as D
+    rank, local_rank, world = D.init()
+    assert world == 2 and rank == int(os.environ["RANK"])
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(8, 8); self.b = nn.Linear(8, 1)
+            self.unused = nn.Linear(8, 8)        # like RCNN_base.backbone.fc: never gets a grad
+        def forward(self, x):
+            return self.b(torch.relu(self.a(x)))
+    torch.manual_seed(0)
+    net = Net()
+    ddp = D.wrap(net, local_rank)
+    lo, hi = D.shard_slice(6, rank, world)
+    assert (lo, hi) == ((0, 3) if rank == 0 else (3, 6))
+    torch.manual_seed(100)
+    x = torch.randn(6, 8)[lo:hi]
+    for _ in range(3):                          # static_graph needs >1 iteration to settle
+        net.zero_grad()
+        ddp(x).sum().backward()
+    g = net.a.weight.grad.clone()
+    ref = [torch.zeros_like(g) for _ in range(world)]
+    torch.distributed.all_gather(ref, g)
+    assert torch.allclose(ref[0], ref[1]), "gradients were not all-reduced"
+    assert net.unused.weight.grad is None
+    # equals the mean over ranks of the local gradients
+    net2 = Net(); net2.load_state_dict(net.state_dict())
+    full = torch.randn(6, 8, generator=torch.Generator().manual_seed(100))
+    torch.manual_seed(100); full = torch.randn(6, 8)
+    net2(full).sum().backward()
+    assert torch.allclose(g, net2.a.weight.grad / world, atol=1e-6)
+    t = D.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    assert t == 2.0
+    D.barrier()
+    print("rank", rank, "ok")
+""")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_data_parallel(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+        assert "rank %d ok" % r in o
+
+
+def test_shard_slice_covers_everything():
+    from ait_amd.distributed import shard_slice
+    for n in (0, 1, 7, 64):
+        for w in (1, 2, 3, 8):
+            spans = [shard_slice(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

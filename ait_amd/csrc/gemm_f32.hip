@@ -55,6 +55,7 @@ struct GemmArgs {
   float alpha;
   int flags;
   int k_per_split;
+  int splits;
 };
 
 // Stage one BK x 128 slab of an operand into registers.
@@ -120,16 +121,32 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(const GemmArgs g)
   float* As = lds;                           // [2][BK][LDS_PITCH]
   float* Bs = lds + 2 * BK * LDS_PITCH;      // [2][BK][LDS_PITCH]
 
-  // ---- XCD-aware tile assignment -------------------------------------------------------
+  // ---- XCD-aware work assignment (blocks b and b+8 share an XCD / L2) ----------------------
   const int tiles_n = (g.N + BN - 1) / BN;
   const int tiles_m = (g.M + BM - 1) / BM;
   const int bid = blockIdx.x;
   const int xcd = bid % AIT_NXCD, j = bid / AIT_NXCD;
-  const int tm = (j / tiles_n) * AIT_NXCD + xcd;
-  const int tn = j % tiles_n;
+  int tm, tn, split;
+  if (g.splits == 1) {
+    // the N-tiles of one M-panel run back to back on ONE XCD: its A panel stays in that L2
+    tm = (j / tiles_n) * AIT_NXCD + xcd;
+    tn = j % tiles_n;
+    split = 0;
+  } else {
+    // split-K (weight gradients): every XCD owns splits/8 K-ranges and runs ALL output tiles of
+    // them concurrently, so each byte of A and B crosses the fabric once and the 16-row slabs
+    // that the co-running tiles walk in step are served from that XCD's L2
+    const int tiles = tiles_m * tiles_n;
+    const int per_xcd = (g.splits + AIT_NXCD - 1) / AIT_NXCD;
+    split = xcd * per_xcd + j / tiles;
+    const int t = j % tiles;
+    tm = t / tiles_n;
+    tn = t % tiles_n;
+    if (split >= g.splits) return;
+  }
   if (tm >= tiles_m) return;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = blockIdx.z * g.k_per_split;
+  const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   if (kbeg >= kend) return;
 
@@ -220,13 +237,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(const GemmArgs g)
 }
 
 template <bool AK, bool BK_>
-int launch(const GemmArgs& g, int splits, hipStream_t s) {
+int launch(const GemmArgs& g, hipStream_t s) {
   const int tiles_n = (g.N + BN - 1) / BN;
   const int tiles_m = (g.M + BM - 1) / BM;
-  const int tm_pad = (tiles_m + AIT_NXCD - 1) / AIT_NXCD * AIT_NXCD;
-  dim3 grid((unsigned)(tm_pad * tiles_n), 1, (unsigned)splits);
+  unsigned blocks;
+  if (g.splits == 1) {
+    const int tm_pad = (tiles_m + AIT_NXCD - 1) / AIT_NXCD * AIT_NXCD;
+    blocks = (unsigned)(tm_pad * tiles_n);
+  } else {
+    const int per_xcd = (g.splits + AIT_NXCD - 1) / AIT_NXCD;
+    blocks = (unsigned)(per_xcd * AIT_NXCD * tiles_m * tiles_n);
+  }
   const size_t lds = sizeof(float) * 4 * BK * LDS_PITCH;
-  hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), grid, dim3(kThreads), lds, s, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_>), dim3(blocks), dim3(kThreads), lds, s, g);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }
@@ -257,13 +280,13 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   int kps = (K + split_k - 1) / split_k;
   kps = (kps + BK - 1) / BK * BK;
   g.k_per_split = kps;
-  const int splits = (K + kps - 1) / kps;
+  g.splits = (K + kps - 1) / kps;
   hipStream_t s = ait_stream(stream);
   // operand "K-contiguous" means the reduction dimension is the fast one in memory:
   //   A: !trans_a  (A is [M,K]);   B: trans_b (B is [N,K])
   const bool ak = !trans_a, bk = trans_b != 0;
-  if (ak && bk) return launch<true, true>(g, splits, s);
-  if (ak && !bk) return launch<true, false>(g, splits, s);
-  if (!ak && bk) return launch<false, true>(g, splits, s);
-  return launch<false, false>(g, splits, s);
+  if (ak && bk) return launch<true, true>(g, s);
+  if (ak && !bk) return launch<true, false>(g, s);
+  if (!ak && bk) return launch<false, true>(g, s);
+  return launch<false, false>(g, s);
 }

@@ -60,8 +60,10 @@ def _mask_code(mask):
 # autograd functions over the C ABI
 # ------------------------------------------------------------------------------------------
 def _split_k(M_out, N_out):
+    """K-splits for a weight gradient: a multiple of 8 (each XCD owns whole K-ranges) sized so
+    that tiles x splits ~ 1024 workgroups (4 per CU, all resident at once)."""
     tiles = ((M_out + 127) // 128) * ((N_out + 127) // 128)
-    return max(1, min(64, 1024 // tiles))
+    return max(8, min(64, (1024 // tiles + 7) // 8 * 8))
 
 
 def _wgrad(dy, x):

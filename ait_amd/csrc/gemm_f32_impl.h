@@ -1,0 +1,314 @@
+// ait_amd/csrc/gemm_f32_impl.h -- the fp32 MFMA GEMM kernel, templated on its tile configuration.
+// See gemm_f32.hip for the design notes.  Included by gemm_f32.hip (product instantiations) and by
+// scripts/tune_gemm.hip (the tuning harness).
+#pragma once
+#include "common.h"
+
+namespace ait_gemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;      // [N] (or [M] with AIT_GEMM_BIAS_ROW)
+  const float* residual;  // same addressing as C
+  int M, N, K;
+  int lda, ldb, ldc;
+  int c_colblk;           // 0: plain row-major C.  >0: C(i,j) at (j/colblk)*c_batch + i*ldc + j%colblk
+  long long c_batch;
+  float alpha;
+  int flags;
+  int k_per_split;
+  int splits;
+};
+
+// Tile configuration: BM x BN output tile, K-slabs of BK, WM x WN wavefronts each owning
+// (BM/WM/32) x (BN/WN/32) MFMA tiles of 32x32.
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_>
+struct Cfg {
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_;
+  static constexpr int NT = 64 * WM * WN;          // threads
+  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static constexpr int PA = BM + 4, PB = BN + 4;   // LDS pitches (floats), 16-B aligned rows
+  static constexpr int VA = BM * BK / 4 / NT;      // float4 per thread per A slab
+  static constexpr int VB = BN * BK / 4 / NT;
+  static constexpr size_t LDS = sizeof(float) * 2 * BK * (PA + PB);
+  static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile / wave mismatch");
+  static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "slab / thread mismatch");
+};
+
+// Stage one BK x ROWS slab of an operand into registers.
+//   KCONTIG = true : element (r, k) at p[r*ld + k]   (reduction dim contiguous)
+//   KCONTIG = false: element (r, k) at p[k*ld + r]
+// Rows >= R and k >= Kend read as zero.  ld % 4 == 0 and 16-B aligned bases are required.
+template <bool KCONTIG, int ROWS, int BK, int NT, int NV>
+__device__ __forceinline__ void load_slab(const float* __restrict__ p, int ld, int r0, int R,
+                                          int k0, int Kend, float4 (&v)[NV]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const int e = t + i * NT;
+    if (KCONTIG) {
+      const int r = r0 + e / (BK / 4), k = k0 + (e % (BK / 4)) * 4;
+      if (r < R && k < Kend)
+        v[i] = *reinterpret_cast<const float4*>(p + (size_t)r * ld + k);
+      else
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const int k = k0 + e / (ROWS / 4), r = r0 + (e % (ROWS / 4)) * 4;
+      if (k < Kend && r + 3 < R) {
+        v[i] = *reinterpret_cast<const float4*>(p + (size_t)k * ld + r);
+      } else if (k < Kend && r < R) {  // ragged right edge
+        const float* q = p + (size_t)k * ld + r;
+        v[i].x = q[0];
+        v[i].y = (r + 1 < R) ? q[1] : 0.f;
+        v[i].z = (r + 2 < R) ? q[2] : 0.f;
+        v[i].w = 0.f;
+      } else {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+}
+
+template <bool KCONTIG, int ROWS, int BK, int NT, int NV, int PITCH>
+__device__ __forceinline__ void store_slab(float* __restrict__ s, const float4 (&v)[NV]) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const int e = t + i * NT;
+    if (KCONTIG) {
+      const int r = e / (BK / 4), k = (e % (BK / 4)) * 4;
+      s[(k + 0) * PITCH + r] = v[i].x;
+      s[(k + 1) * PITCH + r] = v[i].y;
+      s[(k + 2) * PITCH + r] = v[i].z;
+      s[(k + 3) * PITCH + r] = v[i].w;
+    } else {
+      const int k = e / (ROWS / 4), r = (e % (ROWS / 4)) * 4;
+      *reinterpret_cast<float4*>(s + k * PITCH + r) = v[i];
+    }
+  }
+}
+
+// AK / BKC: true when that operand is stored with the reduction dimension contiguous.
+//   forward  y = x W^T   : A = x [M,K] (AK), B = W [N,K] (BKC)
+//   dgrad    dx = dy W   : A = dy [M,K'] (AK), B = W [K',N] (!BKC)
+//   wgrad    dW = dy^T x : A = dy [K',M] (!AK), B = x [K',N] (!BKC)
+// EPI selects the epilogue at compile time (a run-time flag test per element makes hipcc branch
+// around every load/store and wait vmcnt(0) each time):
+//   EPI_STORE  C = alpha*acc (+bias) (relu)            -- no loads at all
+//   EPI_ATOMIC C += alpha*acc with fp32 atomics        -- split-K partial tiles
+//   EPI_AUX    the forms that read memory: +residual, ReLU-backward gate, accumulate into C
+enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_AUX = 2 };
+
+template <class C, bool AK, bool BKC, int EPI>
+__global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs g) {
+  constexpr int BM = C::BM, BN = C::BN, BK = C::BK;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* As = lds;                       // [2][BK][PA]
+  float* Bs = lds + 2 * BK * C::PA;      // [2][BK][PB]
+
+  // ---- XCD-aware work assignment (blocks b and b+8 share an XCD / L2) ----------------------
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int bid = blockIdx.x;
+  const int xcd = bid % AIT_NXCD, j = bid / AIT_NXCD;
+  int tm, tn, split;
+  if (g.splits == 1) {
+    // the N-tiles of one M-panel run back to back on ONE XCD: its A panel stays in that L2
+    tm = (j / tiles_n) * AIT_NXCD + xcd;
+    tn = j % tiles_n;
+    split = 0;
+  } else {
+    // split-K (weight gradients): every XCD owns splits/8 K-ranges and runs ALL output tiles of
+    // them concurrently, so each byte of A and B crosses the fabric once and the 16-row slabs
+    // that the co-running tiles walk in step are served from that XCD's L2
+    const int tiles = tiles_m * tiles_n;
+    const int per_xcd = (g.splits + AIT_NXCD - 1) / AIT_NXCD;
+    split = xcd * per_xcd + j / tiles;
+    const int t = j % tiles;
+    tm = t / tiles_n;
+    tn = t % tiles_n;
+    if (split >= g.splits) return;
+  }
+  if (tm >= tiles_m) return;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  if (kbeg >= kend) return;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave / C::WN) * (C::TM * 32), wn = (wave % C::WN) * (C::TN * 32);
+  const int li = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[C::TM][C::TN];
+#pragma unroll
+  for (int a = 0; a < C::TM; a++)
+#pragma unroll
+    for (int b = 0; b < C::TN; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  float4 ra[C::VA], rb[C::VB];
+  load_slab<AK, BM, BK, C::NT, C::VA>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
+  load_slab<BKC, BN, BK, C::NT, C::VB>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
+  store_slab<AK, BM, BK, C::NT, C::VA, C::PA>(As, ra);
+  store_slab<BKC, BN, BK, C::NT, C::VB, C::PB>(Bs, rb);
+  __syncthreads();
+
+  int cur = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more) {
+      load_slab<AK, BM, BK, C::NT, C::VA>(g.A, g.lda, m0, g.M, k0 + BK, kend, ra);
+      load_slab<BKC, BN, BK, C::NT, C::VB>(g.B, g.ldb, n0, g.N, k0 + BK, kend, rb);
+    }
+    const float* as = As + cur * BK * C::PA + wm + li;
+    const float* bs = Bs + cur * BK * C::PB + wn + li;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float av[C::TM], bv[C::TN];
+#pragma unroll
+      for (int a = 0; a < C::TM; a++) av[a] = as[(kk + lk) * C::PA + a * 32];
+#pragma unroll
+      for (int b = 0; b < C::TN; b++) bv[b] = bs[(kk + lk) * C::PB + b * 32];
+#pragma unroll
+      for (int a = 0; a < C::TM; a++)
+#pragma unroll
+        for (int b = 0; b < C::TN; b++)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    if (more) {
+      store_slab<AK, BM, BK, C::NT, C::VA, C::PA>(As + (cur ^ 1) * BK * C::PA, ra);
+      store_slab<BKC, BN, BK, C::NT, C::VB, C::PB>(Bs + (cur ^ 1) * BK * C::PB, rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool relu = (g.flags & AIT_GEMM_RELU) != 0;
+  const bool bias_row = (g.flags & AIT_GEMM_BIAS_ROW) != 0;
+#pragma unroll
+  for (int a = 0; a < C::TM; a++)
+#pragma unroll
+    for (int b = 0; b < C::TN; b++) {
+      const int col = n0 + wn + b * 32 + li;
+      const bool col_ok = col < g.N;
+      const int colc = col_ok ? col : 0;
+      size_t cbase;
+      if (g.c_colblk > 0)
+        cbase = (size_t)(colc / g.c_colblk) * g.c_batch + (colc % g.c_colblk);
+      else
+        cbase = colc;
+      const int rbase = m0 + wm + a * 32 + 4 * lk;
+      if (EPI == EPI_ATOMIC) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (col_ok && row < g.M) unsafeAtomicAdd(g.C + cbase + (size_t)row * g.ldc, g.alpha * acc[a][b][r]);
+        }
+      } else {
+        float v[16];
+        const float bcol = (g.bias && !bias_row) ? g.bias[colc] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          v[r] = g.alpha * acc[a][b][r] + (bias_row ? (g.bias ? g.bias[min(row, g.M - 1)] : 0.f) : bcol);
+        }
+        if (EPI == EPI_AUX) {
+          const bool mask_pos = (g.flags & AIT_GEMM_MASK_POS) != 0;
+          const bool accum = (g.flags & AIT_GEMM_ACCUMULATE) != 0;
+          float x[16], y[16];
+          // all loads first (clamped addresses, unconditional), then the arithmetic
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
+            const size_t off = cbase + (size_t)row * g.ldc;
+            x[r] = g.residual ? g.residual[off] : 0.f;
+            y[r] = accum ? g.C[off] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            if (mask_pos) v[r] = x[r] > 0.f ? v[r] : 0.f;  // ReLU backward: gate by the saved activation
+            else v[r] += x[r];
+            v[r] += y[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (relu) v[r] = fmaxf(v[r], 0.f);
+          if (col_ok && row < g.M) g.C[cbase + (size_t)row * g.ldc] = v[r];
+        }
+      }
+    }
+}
+
+template <class C, bool AK, bool BKC, int EPI>
+int launch(const GemmArgs& g, hipStream_t s) {
+  const int tiles_n = (g.N + C::BN - 1) / C::BN;
+  const int tiles_m = (g.M + C::BM - 1) / C::BM;
+  unsigned blocks;
+  if (g.splits == 1) {
+    const int tm_pad = (tiles_m + AIT_NXCD - 1) / AIT_NXCD * AIT_NXCD;
+    blocks = (unsigned)(tm_pad * tiles_n);
+  } else {
+    const int per_xcd = (g.splits + AIT_NXCD - 1) / AIT_NXCD;
+    blocks = (unsigned)(per_xcd * AIT_NXCD * tiles_m * tiles_n);
+  }
+  auto kern = gemm_f32_kernel<C, AK, BKC, EPI>;
+  if (C::LDS > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(C::NT), C::LDS, s, g);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+template <class C, int EPI>
+int dispatch_layout(const GemmArgs& g, bool ak, bool bk, hipStream_t s) {
+  if (ak && bk) return launch<C, true, true, EPI>(g, s);
+  if (ak && !bk) return launch<C, true, false, EPI>(g, s);
+  if (!ak && bk) return launch<C, false, true, EPI>(g, s);
+  return launch<C, false, false, EPI>(g, s);
+}
+
+template <class C>
+int dispatch(const GemmArgs& g, bool ak, bool bk, hipStream_t s) {
+  if (g.flags & AIT_GEMM_ATOMIC) return dispatch_layout<C, EPI_ATOMIC>(g, ak, bk, s);
+  if (g.residual || (g.flags & (AIT_GEMM_ACCUMULATE | AIT_GEMM_MASK_POS)))
+    return dispatch_layout<C, EPI_AUX>(g, ak, bk, s);
+  return dispatch_layout<C, EPI_STORE>(g, ak, bk, s);
+}
+
+// Validate arguments and fill GemmArgs (shared by the product entry point and the tuner).
+inline int make_args(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
+                     int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
+                     const float* residual, int flags, int split_k, int c_colblk,
+                     long long c_batch_stride, int BK, GemmArgs& g) {
+  if (M < 0 || N < 0 || K < 0) return AIT_EINVAL;
+  if (!A || !B || !C) return AIT_EINVAL;
+  // float4 staging: row pitches and bases 16-B aligned; K % 4 only matters for an operand whose
+  // reduction dimension is the contiguous one
+  if ((lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
+      (reinterpret_cast<uintptr_t>(B) & 15) || ((K & 3) && (!trans_a || trans_b)))
+    return AIT_EUNSUPPORTED;
+  if (split_k < 1) split_k = 1;
+  if (split_k > 1 && !(flags & AIT_GEMM_ATOMIC)) return AIT_EINVAL;
+  if ((flags & AIT_GEMM_ATOMIC) && (bias || residual || (flags & AIT_GEMM_RELU)))
+    return AIT_EINVAL;
+  if ((flags & AIT_GEMM_MASK_POS) && !residual) return AIT_EINVAL;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.residual = residual;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.c_colblk = c_colblk; g.c_batch = c_batch_stride; g.alpha = alpha; g.flags = flags;
+  int kps = (K + split_k - 1) / split_k;
+  kps = (kps + BK - 1) / BK * BK;
+  g.k_per_split = kps;
+  g.splits = (K + kps - 1) / kps;
+  return AIT_OK;
+}
+
+}  // namespace ait_gemm

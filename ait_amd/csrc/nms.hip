@@ -47,6 +47,8 @@ __global__ __launch_bounds__(kTile) void nms_mask_kernel(const float4* __restric
                                                          unsigned long long* __restrict__ mask) {
   const int rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb) return;  // lower triangle is never read
+  boxes += (size_t)blockIdx.z * n;            // batched call: one image per grid z-slice
+  mask += (size_t)blockIdx.z * n * nb;
   __shared__ float4 cbox[kTile];
   __shared__ float carea[kTile];
   const int lane = threadIdx.x;
@@ -79,8 +81,12 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 // order != NULL; otherwise survivors are written straight to keep[] in ascending order.
 __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(
     const unsigned long long* __restrict__ mask, int n, int nb, int max_keep,
-    unsigned char* __restrict__ alive, long long* __restrict__ keep, int* __restrict__ n_keep) {
+    unsigned char* __restrict__ alive, long long* __restrict__ keep, int* __restrict__ n_keep,
+    long long keep_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long removed[];
+  mask += (size_t)blockIdx.x * n * nb;        // batched call: one workgroup per image
+  keep += (size_t)blockIdx.x * keep_stride;
+  n_keep += blockIdx.x;
   __shared__ unsigned long long kept_bits;
   __shared__ int kept_total;
   const int tid = threadIdx.x;
@@ -215,12 +221,55 @@ AIT_API int ait_nms(const float* boxes, const int64_t* order, int n, float thr, 
   AIT_CHECK_LAUNCH();
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(kScanThreads), (size_t)nb * 8, s, mask, n,
                      nb, max_keep, order ? alive : nullptr,
-                     reinterpret_cast<long long*>(keep), n_keep);
+                     reinterpret_cast<long long*>(keep), n_keep, 0ll);
   AIT_CHECK_LAUNCH();
   if (order) {
     hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(kScanThreads), 0, s, alive, order, n,
                        flag, reinterpret_cast<long long*>(keep));
     AIT_CHECK_LAUNCH();
   }
+  return AIT_OK;
+}
+
+AIT_API size_t ait_nms_batched_workspace_bytes(int batch, int n) {
+  if (n <= 0 || batch <= 0) return 0;
+  const size_t nb = (size_t)(n + kTile - 1) / kTile;
+  return (size_t)batch * align_up((size_t)n * nb * 8, 256);
+}
+
+AIT_API int ait_nms_batched(const float* boxes, int batch, int n, float thr, int max_keep,
+                            void* workspace, size_t workspace_bytes, int64_t* keep,
+                            long long keep_stride, int32_t* n_keep, void* stream) {
+  if (n < 0 || batch < 0 || !n_keep) return AIT_EINVAL;
+  hipStream_t s = ait_stream(stream);
+  if (batch == 0) return AIT_OK;
+  if (n == 0) {
+    if (hipMemsetAsync(n_keep, 0, sizeof(int32_t) * batch, s) != hipSuccess) return AIT_ELAUNCH;
+    return AIT_OK;
+  }
+  if (!boxes || !keep || !workspace) return AIT_EINVAL;
+  if (workspace_bytes < ait_nms_batched_workspace_bytes(batch, n)) return AIT_EWORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(boxes) & 15) != 0) return AIT_EINVAL;
+  const int nb = (n + kTile - 1) / kTile;
+  if ((size_t)nb * 8 > 60 * 1024) return AIT_EUNSUPPORTED;
+  if (((size_t)n * nb * 8) % 256 != 0) {
+    // per-image mask slabs must be contiguous for the z-sliced kernels: fall back to a loop
+    const size_t per = ait_nms_workspace_bytes(n);
+    if (workspace_bytes < per) return AIT_EWORKSPACE;
+    for (int b = 0; b < batch; b++) {
+      int rc = ait_nms(boxes + (size_t)b * n * 4, nullptr, n, thr, max_keep, workspace, per,
+                       keep + (size_t)b * keep_stride, n_keep + b, stream);
+      if (rc != AIT_OK) return rc;
+    }
+    return AIT_OK;
+  }
+  auto* mask = reinterpret_cast<unsigned long long*>(workspace);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb, batch), dim3(kTile), 0, s,
+                     reinterpret_cast<const float4*>(boxes), nullptr, n, thr, nb, mask);
+  AIT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(kScanThreads), (size_t)nb * 8, s, mask, n,
+                     nb, max_keep, nullptr, reinterpret_cast<long long*>(keep), n_keep,
+                     keep_stride);
+  AIT_CHECK_LAUNCH();
   return AIT_OK;
 }

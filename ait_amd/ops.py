@@ -15,7 +15,7 @@ def _p(t, dtype=torch.float32):
 GEMM_PROFILE = None
 
 
-def _profiled(fn, flops, device):
+def _profiled(fn, flops, device, tag=None):
     if GEMM_PROFILE is None:
         return fn()
     e0 = torch.cuda.Event(enable_timing=True)
@@ -24,7 +24,7 @@ def _profiled(fn, flops, device):
     e0.record(st)
     rc = fn()
     e1.record(st)
-    GEMM_PROFILE.append((flops, e0, e1))
+    GEMM_PROFILE.append((flops, e0, e1) if tag is None else (flops, e0, e1, tag))
     return rc
 
 
@@ -60,7 +60,8 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, 
             int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.dev_ptr(a), a.stride(0),
             _lib.dev_ptr(b), b.stride(0), ctypes.c_void_p(out.data_ptr()), ldc, _p(bias),
             _p(residual), flags, int(split_k), int(c_colblk), int(c_batch_stride),
-            _lib.cur_stream(a.device)), 2.0 * M * N * K, a.device)
+            _lib.cur_stream(a.device)), 2.0 * M * N * K, a.device,
+            (M, N, K, int(trans_a), int(trans_b), int(split_k), int(c_colblk)))
     _lib.check(rc, "ait_gemm_f32")
     return out
 
@@ -75,7 +76,7 @@ def gemm_relu_bwd(dy, w, act, out=None):
         rc = _profiled(lambda: _lib.lib().ait_gemm_f32(
             0, 0, M, K, N, 1.0, _lib.dev_ptr(dy), dy.stride(0), _lib.dev_ptr(w), w.stride(0),
             _lib.dev_ptr(out), out.stride(0), None, _lib.dev_ptr(act), _lib.GEMM_MASK_POS, 1, 0, 0,
-            _lib.cur_stream(dy.device)), 2.0 * M * N * K, dy.device)
+            _lib.cur_stream(dy.device)), 2.0 * M * N * K, dy.device, (M, K, N, 0, 0, 1, -1))
     _lib.check(rc, "ait_gemm_f32(mask)")
     return out
 

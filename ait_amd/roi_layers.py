@@ -89,6 +89,26 @@ def nms_sorted(dets, threshold, max_keep=0):
     return keep, n_keep
 
 
+def nms_sorted_batched(dets, threshold, max_keep=0):
+    """dets [b, n, 4], each image's boxes sorted by descending score.  Returns
+    (keep [b, n] int64, n_keep [b] int32); one launch pair for the whole batch, no host sync."""
+    dets = dets.contiguous().float()
+    _lib.dev_ptr(dets)
+    b, n = dets.size(0), dets.size(1)
+    keep = torch.empty((b, max(n, 1)), dtype=torch.int64, device=dets.device)
+    n_keep = torch.zeros((b,), dtype=torch.int32, device=dets.device)
+    L = _lib.lib()
+    ws_bytes = max(L.ait_nms_batched_workspace_bytes(b, n), L.ait_nms_workspace_bytes(n))
+    ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dets.device)
+    with torch.cuda.device(dets.device):
+        rc = L.ait_nms_batched(_lib.dev_ptr(dets) if n else None, b, n, float(threshold),
+                               int(max_keep), _lib.dev_ptr(ws, torch.uint8), ws_bytes,
+                               _lib.dev_ptr(keep, torch.int64), keep.stride(0),
+                               _lib.dev_ptr(n_keep, torch.int32), _lib.cur_stream(dets.device))
+    _lib.check(rc, "ait_nms_batched")
+    return keep, n_keep
+
+
 def nms(dets, scores, threshold):
     """Drop-in for model._C.nms: int64 indices of kept boxes, ascending (nms_cpu.cpp:64)."""
     if dets.numel() == 0:

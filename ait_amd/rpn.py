@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .config import cfg
-from .roi_layers import nms_sorted
+from .roi_layers import nms_sorted_batched
 
 
 # ------------------------------------------------------------------------------------------
@@ -167,17 +167,17 @@ class _ProposalLayer(nn.Module):
         order = torch.sort(scores, 1, True)[1]
         if 0 < pre_n < scores.numel():          # (the reference compares with numel of the batch)
             order = order[:, :pre_n]
+        cand = torch.gather(boxes, 1, order.unsqueeze(2).expand(-1, -1, 4)).contiguous()   # [b, n, 4]
+        n = cand.size(1)
+        keep, n_keep = nms_sorted_batched(cand, thr, post_n)          # one launch pair, no sync
+        idx = keep[:, :post_n].clamp_(0, n - 1)
+        if idx.size(1) < post_n:
+            idx = F.pad(idx, (0, post_n - idx.size(1)))
+        sel = torch.gather(cand, 1, idx.unsqueeze(2).expand(-1, -1, 4))
+        live = torch.arange(post_n, device=scores.device).unsqueeze(0) < n_keep.unsqueeze(1)
         out = scores.new_zeros(b, post_n, 5)
-        slot = torch.arange(post_n, device=scores.device)
-        for i in range(b):
-            cand = boxes[i].index_select(0, order[i]).contiguous()
-            keep, n_keep = nms_sorted(cand, thr, post_n)
-            idx = keep[:post_n].clamp_(0, cand.size(0) - 1)
-            if idx.numel() < post_n:
-                idx = F.pad(idx, (0, post_n - idx.numel()))
-            sel = cand.index_select(0, idx)
-            out[i, :, 1:] = torch.where((slot < n_keep).unsqueeze(1), sel, torch.zeros_like(sel))
-            out[i, :, 0] = i
+        out[:, :, 1:] = torch.where(live.unsqueeze(2), sel, torch.zeros_like(sel))
+        out[:, :, 0] = torch.arange(b, device=scores.device, dtype=scores.dtype).unsqueeze(1)
         return out
 
 

@@ -130,8 +130,8 @@ def main():
 
     if rank != 0:
         return
-    flops = sum(f for f, _, _ in prof)
-    gemm_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in prof)
+    flops = sum(p[0] for p in prof)
+    gemm_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
     achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     pairs = world * args.bs * args.steps
     line = {
@@ -151,6 +151,17 @@ def main():
                      "gemm_ms_per_step": gemm_ms / max(1, args.steps),
                      "gemm_gflop_per_step": flops / max(1, args.steps) / 1e9},
     }
+    if os.environ.get("AIT_BENCH_GEMM_TABLE"):
+        import collections
+        tab = collections.OrderedDict()
+        for p in prof:
+            t = tab.setdefault(p[3], [0.0, 0])
+            t[0] += p[1].elapsed_time(p[2])
+            t[1] += 1
+        for k, (ms, n) in sorted(tab.items(), key=lambda kv: -kv[1][0]):
+            fl = 2.0 * k[0] * k[1] * k[2]
+            print("gemm M=%6d N=%5d K=%6d ta=%d tb=%d sk=%2d colblk=%3d : %2d/step %8.1f us  %6.1f TF/s  %5.2f ms/step"
+                  % (k + (n // args.steps, 1e3 * ms / n, fl / (ms / n) / 1e9, ms / args.steps)), file=sys.stderr)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.proposals)
     print(json.dumps(line), flush=True)

@@ -74,6 +74,14 @@ size_t ait_nms_workspace_bytes(int n);
 int ait_nms(const float* boxes, const int64_t* order, int n, float thr, int max_keep,
             void* workspace, size_t workspace_bytes, int64_t* keep, int32_t* n_keep,
             void* stream);
+/* Batched form for the proposal layer (rpn/proposal_layer.py:134-164 loops over the images of a
+ * batch): `batch` independent problems of n pre-sorted boxes each, boxes [batch,n,4]; image b's
+ * survivors go to keep + b*keep_stride, its count to n_keep[b].  One launch pair for the whole
+ * batch: the greedy scans of the images run concurrently on different CUs. */
+size_t ait_nms_batched_workspace_bytes(int batch, int n);
+int ait_nms_batched(const float* boxes, int batch, int n, float thr, int max_keep,
+                    void* workspace, size_t workspace_bytes, int64_t* keep,
+                    long long keep_stride, int32_t* n_keep, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32

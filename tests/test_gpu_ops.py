@@ -108,3 +108,20 @@ def test_nms_idempotent_at_full_size():
     again = nms(b[keep], s[keep], 0.7)
     assert again.numel() == keep.numel()
     assert np.array_equal(again.cpu().numpy(), np.arange(keep.numel()))
+
+
+def test_nms_batched_matches_per_image(golden):
+    from ait_amd.roi_layers import nms_sorted_batched
+    g = golden("g5_nms")
+    for n in (65, 1000, 6000):
+        boxes = np.stack([cases.nms_boxes(500 + n, n)[0], cases.nms_boxes(900 + n, n)[0],
+                          cases.nms_boxes(500 + n, n)[0]])
+        for topn in (0, 300):
+            keep, cnt = nms_sorted_batched(_dev(boxes), 0.7, topn)
+            want0 = g["keep_n%d_t07" % n]
+            want1 = native.nms(boxes[1], cases.nms_boxes(900 + n, n)[1], 0.7)
+            for b, want in ((0, want0), (1, want1), (2, want0)):
+                ref = want if topn == 0 else want[:topn]
+                c = int(cnt[b].item())
+                assert c == len(ref)
+                assert np.array_equal(keep[b, :c].cpu().numpy(), ref)

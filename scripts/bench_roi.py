@@ -1,0 +1,26 @@
+"""RoIAlign fwd/bwd micro-benchmark on the bench shapes (GPU box)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from ait_amd.roi_layers import roi_align
+from oracle import cases
+bs, P, C = 4, 300, 1024
+feat = torch.randn(bs, C, 38, 63, device="cuda", requires_grad=True)
+rois = torch.from_numpy(cases.random_rois(5, bs * P, bs, min_side=32, max_side=480)).cuda()
+def timeit(fn, n=20, w=5):
+    for _ in range(w): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+y = roi_align(feat, rois, (7, 7), 1 / 16., 0)
+g = torch.randn_like(y)
+fwd = timeit(lambda: roi_align(feat.detach(), rois, (7, 7), 1 / 16., 0))
+def fb():
+    feat.grad = None
+    roi_align(feat, rois, (7, 7), 1 / 16., 0).backward(g)
+both = timeit(fb)
+fb_bytes = bs * C * 38 * 63 * 4 + bs * P * C * 49 * 4
+print("roi_align fwd %.3f ms (%.2f TB/s algorithmic)  bwd %.3f ms (%.2f TB/s)" % (fwd, fb_bytes / fwd / 1e9, both - fwd, fb_bytes / (both - fwd) / 1e9))

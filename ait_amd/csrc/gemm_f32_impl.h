@@ -26,9 +26,9 @@ struct GemmArgs {
 
 // Tile configuration: BM x BN output tile, K-slabs of BK, WM x WN wavefronts each owning
 // (BM/WM/32) x (BN/WN/32) MFMA tiles of 32x32.
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int OPT_ = 0>
 struct Cfg {
-  static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_;
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_, OPT = OPT_;
   static constexpr int NT = 64 * WM * WN;          // threads
   static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static constexpr int PA = BM + 4, PB = BN + 4;   // LDS pitches (floats), 16-B aligned rows
@@ -159,6 +159,17 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
   __syncthreads();
 
   int cur = 0;
+  // operands of the first k-step of the current slab (OPT bit 1: fetched before the barrier that
+  // precedes the slab, so the MFMAs restart without an LDS round trip after it)
+  float av[C::TM], bv[C::TN];
+  {
+    const float* as = As + wm + li;
+    const float* bs = Bs + wn + li;
+#pragma unroll
+    for (int a = 0; a < C::TM; a++) av[a] = as[lk * C::PA + a * 32];
+#pragma unroll
+    for (int b = 0; b < C::TN; b++) bv[b] = bs[lk * C::PB + b * 32];
+  }
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
     if (more) {
@@ -167,25 +178,43 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
     }
     const float* as = As + cur * BK * C::PA + wm + li;
     const float* bs = Bs + cur * BK * C::PB + wn + li;
+    if (C::OPT & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      float av[C::TM], bv[C::TN];
+      float an[C::TM], bn[C::TN];
+      if (kk + 2 < BK) {   // software-pipelined operand fetch: next k-step's reads fly under these MFMAs
 #pragma unroll
-      for (int a = 0; a < C::TM; a++) av[a] = as[(kk + lk) * C::PA + a * 32];
+        for (int a = 0; a < C::TM; a++) an[a] = as[(kk + 2 + lk) * C::PA + a * 32];
 #pragma unroll
-      for (int b = 0; b < C::TN; b++) bv[b] = bs[(kk + lk) * C::PB + b * 32];
+        for (int b = 0; b < C::TN; b++) bn[b] = bs[(kk + 2 + lk) * C::PB + b * 32];
+      }
 #pragma unroll
       for (int a = 0; a < C::TM; a++)
 #pragma unroll
         for (int b = 0; b < C::TN; b++)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+      if (kk + 2 < BK) {
+#pragma unroll
+        for (int a = 0; a < C::TM; a++) av[a] = an[a];
+#pragma unroll
+        for (int b = 0; b < C::TN; b++) bv[b] = bn[b];
+      }
     }
+    if (C::OPT & 1) __builtin_amdgcn_s_setprio(0);
     if (more) {
       store_slab<AK, BM, BK, C::NT, C::VA, C::PA>(As + (cur ^ 1) * BK * C::PA, ra);
       store_slab<BKC, BN, BK, C::NT, C::VB, C::PB>(Bs + (cur ^ 1) * BK * C::PB, rb);
     }
     __syncthreads();
     cur ^= 1;
+    if (more) {
+      const float* as2 = As + cur * BK * C::PA + wm + li;
+      const float* bs2 = Bs + cur * BK * C::PB + wn + li;
+#pragma unroll
+      for (int a = 0; a < C::TM; a++) av[a] = as2[lk * C::PA + a * 32];
+#pragma unroll
+      for (int b = 0; b < C::TN; b++) bv[b] = bs2[lk * C::PB + b * 32];
+    }
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

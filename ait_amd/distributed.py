@@ -26,7 +26,9 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # AIT_DIST_BACKEND=gloo lets two ranks share ONE GPU (RCCL refuses duplicate devices):
+            # used to exercise the N>1 path on a single-GPU box
+            backend = os.environ.get("AIT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
@@ -38,7 +40,7 @@ def wrap(model, local_rank, bucket_mb=25):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
-    ids = [local_rank] if next(model.parameters()).is_cuda else None
+    ids = [next(model.parameters()).device.index] if next(model.parameters()).is_cuda else None
     return DDP(model, device_ids=ids, bucket_cap_mb=bucket_mb, gradient_as_bucket_view=True,
                static_graph=True)
 

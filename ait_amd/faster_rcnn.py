@@ -94,6 +94,64 @@ class CoAttentionModule(nn.Module):
         return non_img, non_qry
 
 
+class CoAttention(nn.Module):
+    """Non-local image <-> query co-attention of the COCO variant
+    (lib/model/modules/blocks_coatt_transformer_sk.py:17-122, 'division' normalisation,
+    GroupNorm(32) on both output projections, zero-initialised GroupNorm affine)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.in_ch = kwargs.get('in_ch', 1024)
+        self.c_hidden = kwargs.get('c_hidden', 512)
+        self.with_residual = kwargs.get('with_residual', True)
+        self.normlization = kwargs.get('normlization', 'division')
+        self.emb = conv2d_1x1(self.in_ch, self.c_hidden)
+        self.rho = conv2d_1x1(self.in_ch, self.c_hidden)
+        self.phi = conv2d_1x1(self.in_ch, self.c_hidden)
+        self.omega = nn.Sequential(conv2d_1x1(self.c_hidden, self.in_ch), nn.GroupNorm(32, self.in_ch))
+        self.theta = nn.Sequential(conv2d_1x1(self.c_hidden, self.in_ch), nn.GroupNorm(32, self.in_ch))
+        if self.normlization == 'softmax':
+            self.softmax = nn.Softmax(dim=2)
+        for m in self.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 0)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x_img, x_qry):
+        bz, _, h_i, w_i = x_img.shape
+        _, _, h_q, w_q = x_qry.shape
+        ch = self.c_hidden
+        emb_img = self.emb(x_img).view(bz, ch, -1).transpose(1, 2)        # [bz, N_i, ch]
+        emb_qry = self.emb(x_qry).view(bz, ch, -1).transpose(1, 2)        # [bz, N_q, ch]
+        rho_qry = self.rho(x_qry).view(bz, ch, -1).transpose(1, 2)        # [bz, N_q, ch]
+        phi_img = self.phi(x_img).view(bz, ch, -1)                        # [bz, ch, N_i]
+        rel = torch.matmul(rho_qry, phi_img)                              # [bz, N_q, N_i]
+        n_q, n_i = rel.size(1), rel.size(2)
+        q2i, i2q = rel, rel.transpose(1, 2)
+        if self.normlization == 'softmax':
+            q2i, i2q = self.softmax(q2i), self.softmax(i2q.contiguous())
+        else:
+            q2i, i2q = q2i / n_i, i2q / n_q
+        non_img = self.theta(torch.matmul(i2q, emb_qry).transpose(1, 2).reshape(bz, ch, h_i, w_i))
+        non_qry = self.omega(torch.matmul(q2i, emb_img).transpose(1, 2).reshape(bz, ch, h_q, w_q))
+        if self.with_residual:
+            non_img, non_qry = non_img + x_img, non_qry + x_qry
+        return non_img, non_qry
+
+
+class CoAttentionModuleCOCO(nn.Module):
+    """faster_rcnn_coatt_transformer_sk.py:104-158: thin wrapper (keeps the checkpoint key
+    prefix coattention_module.coattention.*)."""
+
+    def __init__(self, inplanes):
+        super().__init__()
+        self.coattention = CoAttention(in_ch=inplanes, c_hidden=max(1, inplanes // 2),
+                                       with_residual=True, normlization='division')
+
+    def forward(self, x_img, x_qry):
+        return self.coattention(x_img, x_qry)
+
+
 # ------------------------------------------------------------------------------------------
 # ResNet backbone (stride on the first 1x1 of a bottleneck, ceil-mode max-pool without padding)
 # ------------------------------------------------------------------------------------------
@@ -191,6 +249,11 @@ class RCNNBackbone(nn.Module):
 # the detector
 # ------------------------------------------------------------------------------------------
 class _fasterRCNN(nn.Module):
+    # 'voc' = faster_rcnn_sys_transformer_sk_dilat.py (MultiHeadAttention co-attention),
+    # 'coco' = faster_rcnn_coatt_transformer_sk.py (non-local co-attention); everything after the
+    # co-attention is identical in the two reference files
+    variant = 'voc'
+
     def __init__(self, classes, class_agnostic, num_K):
         super().__init__()
         self.classes = classes
@@ -199,8 +262,11 @@ class _fasterRCNN(nn.Module):
         self.channels = self.dout_base_model
         self.num_K = num_K
         C = self.channels
-        self.coattention = CoAttentionModule(d_k=64, d_v=64, d_word_vec=C, d_model=C // 2,
-                                             d_inner=C * 2, n_head=8, dropout=0.1)
+        if self.variant == 'coco':
+            self.coattention_module = CoAttentionModuleCOCO(C)
+        else:
+            self.coattention = CoAttentionModule(d_k=64, d_v=64, d_word_vec=C, d_model=C // 2,
+                                                 d_inner=C * 2, n_head=8, dropout=0.1)
         self.RCNN_rpn = _RPN(C)
         self.RCNN_proposal_target = _ProposalTargetLayer(self.n_classes)
         if cfg.POOLING_MODE != 'align':
@@ -218,7 +284,10 @@ class _fasterRCNN(nn.Module):
 
         image_feat, _ = self.RCNN_base(image)                 # [bs, 1024, H_i, W_i]
         query_feat, _ = self.RCNN_base(query)                 # [bs, 1024, 8, 8]
-        non_img, non_qry = self.coattention(x_img=image_feat, x_qry=query_feat)
+        if self.variant == 'coco':
+            non_img, non_qry = self.coattention_module(image_feat, query_feat)
+        else:
+            non_img, non_qry = self.coattention(x_img=image_feat, x_qry=query_feat)
 
         rois, rpn_loss_cls, rpn_loss_bbox = self.RCNN_rpn(non_img, img_info, gt_boxes, num_boxes)
         if self.training:
@@ -321,3 +390,10 @@ class resnet(_fasterRCNN):
 
     def _head_to_tail(self, pool5):
         return self.RCNN_top(pool5).mean(3).mean(2)
+
+
+class resnet_coco(resnet):
+    """The COCO-variant detector (lib/model/faster_rcnn/resnet_coatt_transformer_sk.py `resnet`,
+    driven by trainval_net_coco.py:34 / test_net_coco.py:33).  Use with
+    cfg_from_list(['ANCHOR_SCALES', [4, 8, 16, 32], 'MAX_NUM_GT_BOXES', 50])."""
+    variant = 'coco'

@@ -168,8 +168,8 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "ResNet50 VOC seen-classes, 300 proposals, bs=4 per GPU, "
-                               "fwd+bwd+SGD step (BASELINE.json configs[1])",
+        "config": {"workload": "ResNet50 VOC seen-classes, %d proposals, bs=%d per GPU, "
+                               "fwd+bwd+SGD step (BASELINE.json configs[1])" % (args.proposals, args.bs),
                    "pairs_per_gpu": args.bs, "global_batch": world * args.bs,
                    "proposals": args.proposals, "target": "600x1000", "query": "128x128",
                    "parallelism": "dp%d" % world},

@@ -190,6 +190,30 @@ def coattention(sd, x_img, x_qry, pre="coattention."):
     return (non_img.transpose(1, 2).reshape(bs, C, hi, wi), non_qry.transpose(1, 2).reshape(bs, C, hq, wq))
 
 
+def coattention_nonlocal(sd, x_img, x_qry, pre="coattention_module.coattention."):
+    """COCO variant: lib/model/modules/blocks_coatt_transformer_sk.py:60-122 ('division')."""
+    bz, C, hi, wi = x_img.shape
+    hq, wq = x_qry.shape[2:]
+
+    def c1(x, name):
+        return F.conv2d(x, sd[pre + name + ".weight"], sd[pre + name + ".bias"])
+    emb_img = c1(x_img, "emb").flatten(2).transpose(1, 2)
+    emb_qry = c1(x_qry, "emb").flatten(2).transpose(1, 2)
+    rho_qry = c1(x_qry, "rho").flatten(2).transpose(1, 2)
+    phi_img = c1(x_img, "phi").flatten(2)
+    rel = torch.matmul(rho_qry, phi_img)
+    q2i = rel / rel.shape[2]
+    i2q = rel.transpose(1, 2) / rel.shape[1]
+    ch = emb_img.shape[2]
+
+    def proj(x, name):
+        y = F.conv2d(x, sd[pre + name + ".0.weight"], sd[pre + name + ".0.bias"])
+        return F.group_norm(y, 32, sd[pre + name + ".1.weight"], sd[pre + name + ".1.bias"], 1e-5)
+    non_img = proj(torch.matmul(i2q, emb_qry).transpose(1, 2).reshape(bz, ch, hi, wi), "theta") + x_img
+    non_qry = proj(torch.matmul(q2i, emb_img).transpose(1, 2).reshape(bz, ch, hq, wq), "omega") + x_qry
+    return non_img, non_qry
+
+
 def sk_block(sd, pre, x):
     f0 = F.relu(F.conv2d(x, sd[pre + "convs.0.0.weight"], sd[pre + "convs.0.0.bias"], groups=8))
     f1 = F.relu(F.conv2d(x, sd[pre + "convs.1.0.weight"], sd[pre + "convs.1.0.bias"], padding=1, groups=8))
@@ -342,7 +366,10 @@ def detector_forward(sd, cfgd, image, query, im_info, gt_boxes, num_boxes, train
     bs = image.shape[0]
     image_feat = trunk(image, sd)
     query_feat = trunk(query, sd)
-    non_img, non_qry = coattention(sd, image_feat, query_feat)
+    if "coattention_module.coattention.emb.weight" in sd:      # COCO variant
+        non_img, non_qry = coattention_nonlocal(sd, image_feat, query_feat)
+    else:
+        non_img, non_qry = coattention(sd, image_feat, query_feat)
     rois, rpn_loss_cls, rpn_loss_bbox, rpn_aux = rpn_forward(sd, cfgd, non_img, im_info, gt_boxes, training)
     rois_label = None
     if training:
@@ -412,6 +439,9 @@ def make_detector_state_dict(seed, shapes):
                 v = rs.uniform(0.2, 0.4, shape) if ".bn3." in name else rs.uniform(0.8, 1.2, shape)
             else:
                 v = rs.uniform(-0.05, 0.05, shape)
+        elif name.startswith("coattention_module.") and len(shape) == 1 and ".1." in name:
+            # GroupNorm affine (zero-initialised upstream; non-zero here so the branch is exercised)
+            v = rs.uniform(0.3, 0.6, shape) if leaf == "weight" else rs.uniform(-0.05, 0.05, shape)
         elif "layer_norm" in name:
             v = 1.0 + rs.uniform(-0.1, 0.1, shape) if leaf == "weight" else rs.uniform(-0.1, 0.1, shape)
         elif name.startswith("RCNN_rpn.") or name.startswith("RCNN_cls_score."):
@@ -444,8 +474,8 @@ def synth_inputs(bs, seed, im_hw=(600, 1000), q=128, max_gt=20, n_gt=3):
     return im, qr, info, gt, torch.full((bs,), n_gt)
 
 
-def reference_shapes(n_layers=50, A=9):
-    """state_dict shapes of the VOC-variant detector without instantiating the product."""
+def reference_shapes(n_layers=50, A=9, variant="voc"):
+    """state_dict shapes of the detector (VOC or COCO variant) without instantiating the product."""
     s = {}
 
     def bn(p, c):
@@ -474,16 +504,23 @@ def reference_shapes(n_layers=50, A=9):
         s["transformer." + sub] = shp
     s["transformer.encoder.position_enc.pos_table"] = (1, 64, 512)
     s["transformer.decoder.position_enc.pos_table"] = (1, 64, 512)
+    if variant == "coco":
+        c = "coattention_module.coattention."
+        for e in ("emb", "rho", "phi"):
+            s[c + e + ".weight"] = (512, 1024, 1, 1); s[c + e + ".bias"] = (512,)
+        for e in ("omega", "theta"):
+            s[c + e + ".0.weight"] = (1024, 512, 1, 1); s[c + e + ".0.bias"] = (1024,)
+            s[c + e + ".1.weight"] = (1024,); s[c + e + ".1.bias"] = (1024,)
     c = "coattention."
-    for e in ("img_emb", "qry_emb"):
+    for e in (() if variant == "coco" else ("img_emb", "qry_emb")):
         s[c + e + ".0.weight"] = (512, 1024, 1, 1); s[c + e + ".0.bias"] = (512,)
-    for a in ("i2q_attn.", "q2i_attn."):
+    for a in (() if variant == "coco" else ("i2q_attn.", "q2i_attn.")):
         for w in ("w_qs", "w_ks", "w_vs"):
             s[c + a + w + ".weight"] = (512, 512)
         s[c + a + "sh.sk.weight"] = (512, 64); s[c + a + "sh.sk.bias"] = (512,)
         s[c + a + "fc.weight"] = (512, 64)
         s[c + a + "layer_norm.weight"] = (512,); s[c + a + "layer_norm.bias"] = (512,)
-    for e in ("img_trans", "qry_trans"):
+    for e in (() if variant == "coco" else ("img_trans", "qry_trans")):
         s[c + e + ".0.weight"] = (1024, 512); s[c + e + ".0.bias"] = (1024,)
     for b in ("sk.sk_props.", "sk.sk_query."):
         s[b + "convs.0.0.weight"] = (1024, 128, 1, 1); s[b + "convs.0.0.bias"] = (1024,)

@@ -156,4 +156,55 @@ def g10():
     _save("g10_detector_train", out)
 
 
-GROUPS = {"g7": g7, "g8": g8, "g9": g9, "g10": g10}
+def g11():
+    """COCO variant (faster_rcnn_coatt_transformer_sk.py): non-local co-attention, A = 12 anchors,
+    50 GT slots; eval forward (1 pair, 128 proposals) and one train forward (P = 128)."""
+    cfg = _cfg()
+    import sys
+    import model.roi_layers  # noqa: F401
+    ra = sys.modules['model.roi_layers.roi_align']
+    if not isinstance(ra._C, _ContiguousOps):
+        ra._C = _ContiguousOps(ra._C)
+    saved = (list(cfg.ANCHOR_SCALES), cfg.MAX_NUM_GT_BOXES)
+    cfg.ANCHOR_SCALES = [4, 8, 16, 32]
+    cfg.MAX_NUM_GT_BOXES = 50
+    from model.faster_rcnn.resnet_coatt_transformer_sk import resnet
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = resnet(('__background__', 'fg'), 50, pretrained=False, class_agnostic=True, num_K=3)
+        m.create_architecture()
+    sd = detector_ref.make_detector_state_dict(11, detector_ref.reference_shapes(A=12, variant="coco"))
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k.startswith(("RCNN_base.stem.", "RCNN_base.layer")) for k in res.missing_keys), res.missing_keys
+    out = {}
+    m.eval()
+    cfg.TEST.RPN_POST_NMS_TOP_N = 128
+    im, qr, info, gt, nb = detector_ref.synth_inputs(1, 1101, max_gt=50)
+    feats = {}
+    h = [m.RCNN_cls_score.register_forward_hook(lambda mod, i, o: feats.__setitem__("score", o)),
+         m.coattention_module.register_forward_hook(lambda mod, i, o: feats.__setitem__("co", o))]
+    with torch.no_grad():
+        rois, cls_prob, bbox_pred, *_ = m(im, qr, info, gt, nb)
+    for x in h:
+        x.remove()
+    cfg.TEST.RPN_POST_NMS_TOP_N = 300
+    out.update({"rois": rois.numpy(), "cls_prob": cls_prob.numpy(), "bbox_pred": bbox_pred.numpy(),
+                "score": feats["score"].numpy()})
+    pack("non_img", feats["co"][0], out)
+    pack("non_qry", feats["co"][1], out)
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    cfg.TRAIN.BATCH_SIZE = 128
+    np.random.seed(3)
+    with torch.no_grad():
+        res = m(im, qr, info, gt, nb)
+    out["train_rois"] = res[0].numpy()
+    out["train_labels"] = res[8].numpy()
+    out["train_losses"] = np.array([float(x) for x in res[3:8]], np.float64)
+    cfg.ANCHOR_SCALES, cfg.MAX_NUM_GT_BOXES = saved
+    _save("g11_detector_coco", out)
+
+
+GROUPS = {"g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}

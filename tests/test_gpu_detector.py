@@ -179,3 +179,43 @@ def test_detector_train_step_gradients_vs_oracle(model):
         got, want = params[k].grad.cpu(), sd[k].grad
         rel = float((got - want).norm() / (want.norm() + 1e-12))
         assert rel < 5e-3, (k, rel)
+
+
+def test_detector_coco_variant(golden):
+    """COCO variant (faster_rcnn_coatt_transformer_sk.py): non-local co-attention, A = 12."""
+    from ait_amd import config
+    from ait_amd.faster_rcnn import resnet_coco
+    g = golden("g11_detector_coco")
+    saved = (config.cfg.ANCHOR_SCALES, config.cfg.MAX_NUM_GT_BOXES)
+    config.cfg_from_list(['ANCHOR_SCALES', [4, 8, 16, 32], 'MAX_NUM_GT_BOXES', 50])
+    try:
+        m = resnet_coco(('__background__', 'fg'), 50, pretrained=False, class_agnostic=True, num_K=3)
+        m.create_architecture()
+        res = m.load_state_dict(D.make_detector_state_dict(11, D.reference_shapes(A=12, variant="coco")), strict=False)
+        assert not res.unexpected_keys
+        assert all(k.startswith(("RCNN_base.stem.", "RCNN_base.layer")) for k in res.missing_keys)
+        m = m.cuda().eval()
+        config.cfg.TEST.RPN_POST_NMS_TOP_N = 128
+        ins = [t.cuda() for t in D.synth_inputs(1, 1101, max_gt=50)]
+        feats = {}
+        h = m.RCNN_cls_score.register_forward_hook(lambda mod, i, o: feats.__setitem__("score", o))
+        with torch.no_grad():
+            out = m(*ins)
+        h.remove()
+        same = np.abs(out[0].cpu().numpy() - g["rois"]).max(-1)[0] <= 2e-3
+        assert same.mean() >= 0.98
+        np.testing.assert_allclose(feats["score"].cpu().numpy()[same], g["score"][same], rtol=1e-4, atol=2e-6)
+        # training forward: sampled RoIs / labels / losses
+        m.train()
+        for mod in m.modules():
+            if hasattr(mod, "p") and isinstance(mod.p, float):
+                mod.p = 0.0
+        config.cfg.TRAIN.BATCH_SIZE = 128
+        np.random.seed(3)
+        with torch.no_grad():
+            out = m(*ins)
+        if _rows_match(out[0].cpu().numpy(), g["train_rois"]) == 1.0:
+            assert np.array_equal(out[8].cpu().numpy(), g["train_labels"])
+            np.testing.assert_allclose(np.array([float(x) for x in out[3:8]]), g["train_losses"], rtol=2e-4, atol=2e-6)
+    finally:
+        config.cfg.ANCHOR_SCALES, config.cfg.MAX_NUM_GT_BOXES = saved

@@ -99,3 +99,27 @@ def test_detector_train_forward_losses(golden, det_sd, P):
     losses = np.array([float(x) for x in out[3:8]])
     np.testing.assert_allclose(losses, g["P%d_losses" % P], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(out[1].numpy(), g["P%d_cls_prob" % P], rtol=1e-4, atol=1e-6)
+
+
+def test_detector_coco_variant(golden):
+    """COCO variant (non-local co-attention, 12 anchors, 50 GT slots): eval logits + train losses."""
+    g = golden("g11_detector_coco")
+    sd = D.make_detector_state_dict(11, D.reference_shapes(A=12, variant="coco"))
+    cfgd = D.default_config()
+    cfgd["ANCHOR_SCALES"] = [4, 8, 16, 32]
+    cfgd["TEST"]["RPN_POST_NMS_TOP_N"] = 128
+    im, qr, info, gt, nb = D.synth_inputs(1, 1101, max_gt=50)
+    with torch.no_grad():
+        out, aux = D.detector_forward(sd, cfgd, im, qr, info, gt, nb, False)
+    for name in ("non_img", "non_qry"):
+        ok, msg = compare(name, aux[name], g, 1e-4, 2e-5)
+        assert ok, msg
+    np.testing.assert_allclose(out[0].numpy(), g["rois"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(aux["score"].numpy(), g["score"], rtol=1e-4, atol=1e-6)
+    cfgd["TRAIN"]["BATCH_SIZE"] = 128
+    np.random.seed(3)
+    with torch.no_grad():
+        out, _ = D.detector_forward(sd, cfgd, im, qr, info, gt, nb, True)
+    np.testing.assert_allclose(out[0].numpy(), g["train_rois"], rtol=0, atol=1e-3)
+    assert np.array_equal(out[8].numpy(), g["train_labels"])
+    np.testing.assert_allclose(np.array([float(x) for x in out[3:8]]), g["train_losses"], rtol=1e-4, atol=1e-6)

@@ -118,8 +118,9 @@ def main():
     args = ap.parse_args()
 
     from ait_amd import distributed as D
-    from ait_amd import _lib, ops
+    from ait_amd import _lib, ops, tuning
     rank, local_rank, world = D.init()
+    tuned = tuning.use_tuned_miopen_db(rank)      # MIOpen solver picks for the torch-side convs
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
@@ -172,7 +173,7 @@ def main():
                                "fwd+bwd+SGD step (BASELINE.json configs[1])" % (args.proposals, args.bs),
                    "pairs_per_gpu": args.bs, "global_batch": world * args.bs,
                    "proposals": args.proposals, "target": "600x1000", "query": "128x128",
-                   "parallelism": "dp%d" % world},
+                   "parallelism": "dp%d" % world, "miopen_find_db": bool(tuned)},
         "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
                      "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32_MFMA_TFLOPS,

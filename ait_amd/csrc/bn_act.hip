@@ -1,0 +1,128 @@
+// ait_amd/csrc/bn_act.hip -- frozen batch-norm + residual + ReLU in one pass (and its backward).
+//
+// Every BatchNorm of the detector is frozen and runs in eval mode during training
+// (lib/model/faster_rcnn/resnet_sys_transformer_sk_dilat.py:435-441,457-480), i.e. it is the
+// per-channel affine map y = x*scale[c] + shift[c] with scale = gamma/sqrt(var+eps),
+// shift = beta - mean*scale.  The bottleneck tail "bn3(conv3) ; out += residual ; relu"
+// (:99-111) and "bn ; relu" (:88-96) are HBM-bound elementwise chains that the reference runs as
+// 2-3 separate passes; here each is ONE read-modify-write pass (16 B per lane), forward and
+// backward (dx = dy * [y>0] * scale[c], dres = dy * [y>0]).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void bn_act_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ res, int relu, long long total, int C, int HW, float* __restrict__ y) {
+  const long long stride = (long long)gridDim.x * kThreads * 4;
+  for (long long i = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4; i < total; i += stride) {
+    float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (VEC) {
+      const float4 a = *reinterpret_cast<const float4*>(x + i);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+      if (res) {
+        const float4 b = *reinterpret_cast<const float4*>(res + i);
+        r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w;
+      }
+      const int c = (int)((i / HW) % C);
+      const float s = scale[c], t = shift[c];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        v[k] = v[k] * s + t + r[k];
+        if (relu) v[k] = fmaxf(v[k], 0.f);
+      }
+      *reinterpret_cast<float4*>(y + i) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const long long j = i + k;
+        if (j >= total) break;
+        const int c = (int)((j / HW) % C);
+        float o = x[j] * scale[c] + shift[c] + (res ? res[j] : 0.f);
+        if (relu) o = fmaxf(o, 0.f);
+        y[j] = o;
+      }
+    }
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void bn_act_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ scale,
+    int relu, long long total, int C, int HW, float* __restrict__ dx, float* __restrict__ dres) {
+  const long long stride = (long long)gridDim.x * kThreads * 4;
+  for (long long i = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4; i < total; i += stride) {
+    if (VEC) {
+      const float4 g4 = *reinterpret_cast<const float4*>(dy + i);
+      float g[4] = {g4.x, g4.y, g4.z, g4.w};
+      if (relu) {
+        const float4 o = *reinterpret_cast<const float4*>(y + i);
+        g[0] = o.x > 0.f ? g[0] : 0.f;
+        g[1] = o.y > 0.f ? g[1] : 0.f;
+        g[2] = o.z > 0.f ? g[2] : 0.f;
+        g[3] = o.w > 0.f ? g[3] : 0.f;
+      }
+      if (dres) *reinterpret_cast<float4*>(dres + i) = make_float4(g[0], g[1], g[2], g[3]);
+      const float s = scale[(int)((i / HW) % C)];
+      *reinterpret_cast<float4*>(dx + i) = make_float4(g[0] * s, g[1] * s, g[2] * s, g[3] * s);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const long long j = i + k;
+        if (j >= total) break;
+        float g = dy[j];
+        if (relu && !(y[j] > 0.f)) g = 0.f;
+        if (dres) dres[j] = g;
+        dx[j] = g * scale[(int)((j / HW) % C)];
+      }
+    }
+  }
+}
+
+inline unsigned grid_for(long long total) {
+  long long b = (total / 4 + kThreads - 1) / kThreads;
+  return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+AIT_API int ait_bn_act_fwd(const float* x, const float* scale, const float* shift,
+                           const float* residual, int relu, long long n, int C, int HW, float* y,
+                           void* stream) {
+  if (n < 0 || C <= 0 || HW <= 0) return AIT_EINVAL;
+  const long long total = n * C * HW;
+  if (total == 0) return AIT_OK;
+  if (!x || !scale || !shift || !y) return AIT_EINVAL;
+  const bool vec = (HW % 4 == 0) && aligned16(x) && aligned16(y) && (!residual || aligned16(residual));
+  if (vec)
+    hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(grid_for(total)), dim3(kThreads), 0,
+                       ait_stream(stream), x, scale, shift, residual, relu, total, C, HW, y);
+  else
+    hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(grid_for(total)), dim3(kThreads), 0,
+                       ait_stream(stream), x, scale, shift, residual, relu, total, C, HW, y);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_bn_act_bwd(const float* dy, const float* y, const float* scale, int relu,
+                           long long n, int C, int HW, float* dx, float* dres, void* stream) {
+  if (n < 0 || C <= 0 || HW <= 0) return AIT_EINVAL;
+  const long long total = n * C * HW;
+  if (total == 0) return AIT_OK;
+  if (!dy || !scale || !dx || (relu && !y)) return AIT_EINVAL;
+  const bool vec = (HW % 4 == 0) && aligned16(dy) && aligned16(dx) && (!relu || aligned16(y)) &&
+                   (!dres || aligned16(dres));
+  if (vec)
+    hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(grid_for(total)), dim3(kThreads), 0,
+                       ait_stream(stream), dy, y, scale, relu, total, C, HW, dx, dres);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(grid_for(total)), dim3(kThreads), 0,
+                       ait_stream(stream), dy, y, scale, relu, total, C, HW, dx, dres);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}

@@ -41,8 +41,9 @@ def wrap(model, local_rank, bucket_mb=25):
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [next(model.parameters()).device.index] if next(model.parameters()).is_cuda else None
+    # buffers (frozen BatchNorm statistics, positional tables) never change: no per-step broadcast
     return DDP(model, device_ids=ids, bucket_cap_mb=bucket_mb, gradient_as_bucket_view=True,
-               static_graph=True)
+               static_graph=True, broadcast_buffers=False)
 
 
 def barrier():

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .config import cfg
 from .roi_layers import ROIAlign
 from .rpn import _ProposalTargetLayer, _RPN, _smooth_l1_loss
@@ -153,6 +154,50 @@ class CoAttentionModuleCOCO(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------
+# frozen BatchNorm (+ residual) (+ ReLU) as one HIP pass
+# ------------------------------------------------------------------------------------------
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, relu):
+        y = ops.bn_act_fwd(x, scale, shift, residual, relu)
+        ctx.save_for_backward(y if relu else None, scale)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, scale = ctx.saved_tensors
+        dx, dres = ops.bn_act_bwd(dy.contiguous(), y, scale, ctx.relu,
+                                  ctx.has_res and ctx.needs_input_grad[3])
+        return dx, None, None, dres, None
+
+
+def bn_act(x, bn, residual=None, relu=True):
+    """relu(bn(x) + residual) for a FROZEN BatchNorm2d in eval mode (the only state the reference
+    ever runs its BatchNorms in); anything else goes through torch."""
+    frozen = (not bn.training) and not bn.weight.requires_grad and not bn.bias.requires_grad
+    if not (frozen and x.is_cuda and x.dtype == torch.float32):
+        y = bn(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr(), bn.running_mean.data_ptr())
+    cache = getattr(bn, "_ait_affine", None)
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+            shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+        cache = (key, scale, shift)
+        bn._ait_affine = cache
+    x = x.contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+    return _BnAct.apply(x, cache[1], cache[2], residual, relu)
+
+
+# ------------------------------------------------------------------------------------------
 # ResNet backbone (stride on the first 1x1 of a bottleneck, ceil-mode max-pool without padding)
 # ------------------------------------------------------------------------------------------
 class Bottleneck(nn.Module):
@@ -171,11 +216,13 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        out = out + (x if self.downsample is None else self.downsample(x))
-        return self.relu(out)
+        out = bn_act(self.conv1(x), self.bn1)
+        out = bn_act(self.conv2(out), self.bn2)
+        if self.downsample is None:
+            identity = x
+        else:
+            identity = bn_act(self.downsample[0](x), self.downsample[1], relu=False)
+        return bn_act(self.conv3(out), self.bn3, residual=identity)
 
 
 class ResNet(nn.Module):
@@ -242,7 +289,8 @@ class RCNNBackbone(nn.Module):
         self.layer3 = backbone.layer3
 
     def forward(self, x):
-        return self.layer3(self.layer2(self.layer1(self.stem(x)))), None
+        x = self.stem[3](bn_act(self.stem[0](x), self.stem[1]))        # conv1, bn1+relu, maxpool
+        return self.layer3(self.layer2(self.layer1(x))), None
 
 
 # ------------------------------------------------------------------------------------------

@@ -168,3 +168,26 @@ def attn_bwd(q, qoff, k, koff, v, voff, P, dO, n_seq, H, T, d, scale, p, seed, d
                                      dq.stride(0), _col(dk, dkoff), dk.stride(0),
                                      _col(dv, dvoff), dv.stride(0), _lib.cur_stream(dev))
     _lib.check(rc, "ait_attn_bwd")
+
+
+def bn_act_fwd(x, scale, shift, residual, relu):
+    n, C = x.shape[0], x.shape[1]
+    HW = x.numel() // max(1, n * C)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().ait_bn_act_fwd(_p(x), _p(scale), _p(shift), _p(residual), int(relu), n, C, HW,
+                                       _p(y), _lib.cur_stream(x.device))
+    _lib.check(rc, "ait_bn_act_fwd")
+    return y
+
+
+def bn_act_bwd(dy, y, scale, relu, need_dres):
+    n, C = dy.shape[0], dy.shape[1]
+    HW = dy.numel() // max(1, n * C)
+    dx = torch.empty_like(dy)
+    dres = torch.empty_like(dy) if need_dres else None
+    with torch.cuda.device(dy.device):
+        rc = _lib.lib().ait_bn_act_bwd(_p(dy), _p(y), _p(scale), int(relu), n, C, HW, _p(dx), _p(dres),
+                                       _lib.cur_stream(dy.device))
+    _lib.check(rc, "ait_bn_act_bwd")
+    return dx, dres

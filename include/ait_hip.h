@@ -186,6 +186,21 @@ int ait_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* 
                  float p_drop, unsigned long long seed, float* dq, int lddq, float* dk, int lddk,
                  float* dv, int lddv, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Frozen batch-norm + residual + ReLU, one pass (NCHW fp32, x [n,C,HW]).
+ * Replaces the eval-mode BatchNorm2d / "out += residual" / ReLU chains of the ResNet bottlenecks
+ * (lib/model/faster_rcnn/resnet_sys_transformer_sk_dilat.py:85-111; every BatchNorm is frozen and
+ * kept in eval mode during training, :435-441,457-480):
+ *   y  = [relu]( x*scale[c] + shift[c] [+ residual] )      scale = gamma/sqrt(var+eps),
+ *                                                          shift = beta - mean*scale
+ *   dx = dy*[y>0]*scale[c],  dres = dy*[y>0]               (the BN parameters get no gradient)
+ * residual / dres may be NULL.
+ * ------------------------------------------------------------------------------------- */
+int ait_bn_act_fwd(const float* x, const float* scale, const float* shift, const float* residual,
+                   int relu, long long n, int C, int HW, float* y, void* stream);
+int ait_bn_act_bwd(const float* dy, const float* y, const float* scale, int relu, long long n,
+                   int C, int HW, float* dx, float* dres, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

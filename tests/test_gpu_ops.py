@@ -125,3 +125,30 @@ def test_nms_batched_matches_per_image(golden):
                 c = int(cnt[b].item())
                 assert c == len(ref)
                 assert np.array_equal(keep[b, :c].cpu().numpy(), ref)
+
+
+def test_frozen_bn_residual_relu_matches_torch():
+    """ait_bn_act_fwd/bwd vs eval-mode BatchNorm2d + add + ReLU in torch (fp32 tolerance 1e-5)."""
+    from ait_amd.faster_rcnn import bn_act
+    torch.manual_seed(0)
+    for shape in ((3, 16, 4, 4), (2, 8, 75, 125), (1, 5, 7, 9)):     # HW % 4 == 0 and != 0
+        bn = torch.nn.BatchNorm2d(shape[1]).cuda().eval()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+            bn.running_mean.uniform_(-0.5, 0.5); bn.running_var.uniform_(0.5, 1.5)
+        for p in bn.parameters():
+            p.requires_grad = False
+        for use_res in (False, True):
+            for relu in (True, False):
+                x = torch.randn(shape, device="cuda", requires_grad=True)
+                r = torch.randn(shape, device="cuda", requires_grad=True) if use_res else None
+                y = bn_act(x, bn, residual=r, relu=relu)
+                ref = bn(x) + (r if use_res else 0)
+                ref = torch.relu(ref) if relu else ref
+                assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6)
+                g = torch.randn(shape, device="cuda")
+                wrt = [x] + ([r] if use_res else [])
+                got = torch.autograd.grad(y, wrt, g)
+                want = torch.autograd.grad(ref, wrt, g)
+                for a, b in zip(got, want):
+                    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)

@@ -39,8 +39,11 @@ using namespace ait_gemm;
 // Two product tiles (scripts/tune_gemm.py, MI355X): 256x128 with 8 waves is the fastest of the
 // eight configurations tried on every large AIT shape (110-123 TFLOP/s vs 102-118 for 128x128;
 // 256x256 and BK=32 lose occupancy and are slower); 128x128 serves outputs with few rows.
-using Tile256 = Cfg<256, 128, 16, 4, 2, 2>;
-using Tile128 = Cfg<128, 128, 16, 2, 2, 2>;
+// OPT 2 = operand reads pinned above the MFMAs (+1..7 %), OPT 4 = three-slab LDS ring that lets
+// the MFMA stream run across the per-slab barrier (+1..3 % more on the 256x128 tile, a loss on
+// 128x128 split-K shapes).
+using Tile256 = Cfg<256, 128, 16, 4, 2, 2, 6>;
+using Tile128 = Cfg<128, 128, 16, 2, 2, 2, 2>;
 }  // namespace
 
 AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha,

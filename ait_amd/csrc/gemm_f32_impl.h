@@ -34,7 +34,8 @@ struct Cfg {
   static constexpr int PA = BM + 4, PB = BN + 4;   // LDS pitches (floats), 16-B aligned rows
   static constexpr int VA = BM * BK / 4 / NT;      // float4 per thread per A slab
   static constexpr int VB = BN * BK / 4 / NT;
-  static constexpr size_t LDS = sizeof(float) * 2 * BK * (PA + PB);
+  static constexpr int NBUF = (OPT_ & 4) ? 3 : 2;   // OPT bit 2: three-slab LDS ring
+  static constexpr size_t LDS = sizeof(float) * NBUF * BK * (PA + PB);
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile / wave mismatch");
   static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "slab / thread mismatch");
 };
@@ -107,8 +108,8 @@ template <class C, bool AK, bool BKC, int EPI>
 __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs g) {
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* As = lds;                       // [2][BK][PA]
-  float* Bs = lds + 2 * BK * C::PA;      // [2][BK][PB]
+  float* As = lds;                              // [NBUF][BK][PA]
+  float* Bs = lds + C::NBUF * BK * C::PA;       // [NBUF][BK][PB]
 
   // ---- XCD-aware work assignment (blocks b and b+8 share an XCD / L2) ----------------------
   const int tiles_n = (g.N + BN - 1) / BN;
@@ -117,9 +118,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
   const int xcd = bid % AIT_NXCD, j = bid / AIT_NXCD;
   int tm, tn, split;
   if (g.splits == 1) {
-    // the N-tiles of one M-panel run back to back on ONE XCD: its A panel stays in that L2
-    tm = (j / tiles_n) * AIT_NXCD + xcd;
-    tn = j % tiles_n;
+    // every XCD gets one contiguous chunk of the row-major tile list, so the N-tiles of an
+    // M-panel run back to back on ONE XCD (its A panel stays in that L2) and all 8 XCDs are busy
+    // whatever tiles_m is (bijective: ids past the end simply exit)
+    const int total = tiles_m * tiles_n;
+    const int chunk = (total + AIT_NXCD - 1) / AIT_NXCD;
+    const int id = xcd * chunk + j;
+    if (j >= chunk || id >= total) return;
+    tm = id / tiles_n;
+    tn = id % tiles_n;
     split = 0;
   } else {
     // split-K (weight gradients): every XCD owns splits/8 K-ranges and runs ALL output tiles of
@@ -152,6 +159,76 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
   float4 ra[C::VA], rb[C::VB];
+  float av[C::TM], bv[C::TN];
+  if constexpr (C::NBUF == 3) {
+    // ---- three-slab ring: slab k+2 is fetched from global while slab k is multiplied; slab k+1 is
+    // already complete in LDS, so the first operands of slab k+1 are read BEFORE the barrier that
+    // ends slab k and the MFMA stream runs across the barrier without an LDS round trip.
+    load_slab<AK, BM, BK, C::NT, C::VA>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
+    load_slab<BKC, BN, BK, C::NT, C::VB>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
+    store_slab<AK, BM, BK, C::NT, C::VA, C::PA>(As, ra);
+    store_slab<BKC, BN, BK, C::NT, C::VB, C::PB>(Bs, rb);
+    load_slab<AK, BM, BK, C::NT, C::VA>(g.A, g.lda, m0, g.M, kbeg + BK, kend, ra);   // zeros past kend
+    load_slab<BKC, BN, BK, C::NT, C::VB>(g.B, g.ldb, n0, g.N, kbeg + BK, kend, rb);
+    store_slab<AK, BM, BK, C::NT, C::VA, C::PA>(As + BK * C::PA, ra);
+    store_slab<BKC, BN, BK, C::NT, C::VB, C::PB>(Bs + BK * C::PB, rb);
+    __syncthreads();
+    {
+      const float* as = As + wm + li;
+      const float* bs = Bs + wn + li;
+#pragma unroll
+      for (int a = 0; a < C::TM; a++) av[a] = as[lk * C::PA + a * 32];
+#pragma unroll
+      for (int b = 0; b < C::TN; b++) bv[b] = bs[lk * C::PB + b * 32];
+    }
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      const bool more2 = k0 + 2 * BK < kend;
+      if (more2) {
+        load_slab<AK, BM, BK, C::NT, C::VA>(g.A, g.lda, m0, g.M, k0 + 2 * BK, kend, ra);
+        load_slab<BKC, BN, BK, C::NT, C::VB>(g.B, g.ldb, n0, g.N, k0 + 2 * BK, kend, rb);
+      }
+      const int nxt = (cur == 2) ? 0 : cur + 1;
+      const int nxt2 = (nxt == 2) ? 0 : nxt + 1;
+      const float* as = As + cur * BK * C::PA + wm + li;
+      const float* bs = Bs + cur * BK * C::PB + wn + li;
+      const float* asn = As + nxt * BK * C::PA + wm + li;
+      const float* bsn = Bs + nxt * BK * C::PB + wn + li;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        float an[C::TM], bn[C::TN];
+        if (kk + 2 < BK) {
+#pragma unroll
+          for (int a = 0; a < C::TM; a++) an[a] = as[(kk + 2 + lk) * C::PA + a * 32];
+#pragma unroll
+          for (int b = 0; b < C::TN; b++) bn[b] = bs[(kk + 2 + lk) * C::PB + b * 32];
+        } else {   // last k-step of the slab: first operands of the NEXT slab (complete since the last barrier)
+#pragma unroll
+          for (int a = 0; a < C::TM; a++) an[a] = asn[lk * C::PA + a * 32];
+#pragma unroll
+          for (int b = 0; b < C::TN; b++) bn[b] = bsn[lk * C::PB + b * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < C::TM; a++)
+#pragma unroll
+          for (int b = 0; b < C::TN; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < C::TM; a++) av[a] = an[a];
+#pragma unroll
+        for (int b = 0; b < C::TN; b++) bv[b] = bn[b];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more2) {
+        store_slab<AK, BM, BK, C::NT, C::VA, C::PA>(As + nxt2 * BK * C::PA, ra);
+        store_slab<BKC, BN, BK, C::NT, C::VB, C::PB>(Bs + nxt2 * BK * C::PB, rb);
+      }
+      __syncthreads();
+      cur = nxt;
+    }
+  } else {
   load_slab<AK, BM, BK, C::NT, C::VA>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
   load_slab<BKC, BN, BK, C::NT, C::VB>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
   store_slab<AK, BM, BK, C::NT, C::VA, C::PA>(As, ra);
@@ -161,7 +238,6 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
   int cur = 0;
   // operands of the first k-step of the current slab (OPT bit 1: fetched before the barrier that
   // precedes the slab, so the MFMAs restart without an LDS round trip after it)
-  float av[C::TM], bv[C::TN];
   {
     const float* as = As + wm + li;
     const float* bs = Bs + wn + li;
@@ -188,6 +264,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
 #pragma unroll
         for (int b = 0; b < C::TN; b++) bn[b] = bs[(kk + 2 + lk) * C::PB + b * 32];
       }
+      // keep the reads ABOVE the MFMAs (hipcc otherwise sinks them below, re-serialising the
+      // LDS round trip with the matrix pipe: read -> wait -> 4 MFMA -> read -> wait ...)
+      if (C::OPT & 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < C::TM; a++)
 #pragma unroll
@@ -215,6 +294,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
 #pragma unroll
       for (int b = 0; b < C::TN; b++) bv[b] = bs2[lk * C::PB + b * 32];
     }
+  }
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -282,8 +362,8 @@ int launch(const GemmArgs& g, hipStream_t s) {
   const int tiles_m = (g.M + C::BM - 1) / C::BM;
   unsigned blocks;
   if (g.splits == 1) {
-    const int tm_pad = (tiles_m + AIT_NXCD - 1) / AIT_NXCD * AIT_NXCD;
-    blocks = (unsigned)(tm_pad * tiles_n);
+    const int chunk = (tiles_m * tiles_n + AIT_NXCD - 1) / AIT_NXCD;
+    blocks = (unsigned)(chunk * AIT_NXCD);
   } else {
     const int per_xcd = (g.splits + AIT_NXCD - 1) / AIT_NXCD;
     blocks = (unsigned)(per_xcd * AIT_NXCD * tiles_m * tiles_n);

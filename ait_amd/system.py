@@ -59,16 +59,29 @@ def _mask_code(mask):
 # ------------------------------------------------------------------------------------------
 # autograd functions over the C ABI
 # ------------------------------------------------------------------------------------------
-def _split_k(M_out, N_out):
-    """K-splits for a weight gradient: a multiple of 8 (each XCD owns whole K-ranges) sized so
-    that tiles x splits ~ 1024 workgroups (4 per CU, all resident at once)."""
-    tiles = ((M_out + 127) // 128) * ((N_out + 127) // 128)
-    return max(8, min(64, (1024 // tiles + 7) // 8 * 8))
+def _split_k(M_out, N_out, K):
+    """K-splits for a weight gradient [M_out, N_out] = sum over K tokens.  Multiples of 8 (each XCD
+    owns whole K-ranges); chosen so that tiles x splits fills the 512 resident workgroup slots of
+    the 256x128 kernel (2 per CU) in whole rounds, with at least 256 tokens per split."""
+    if M_out >= 512:
+        tiles, slots = ((M_out + 255) // 256) * ((N_out + 127) // 128), 512
+    else:
+        tiles, slots = ((M_out + 127) // 128) * ((N_out + 127) // 128), 1024
+    best, best_eff = 8, -1.0
+    for s in range(8, 65, 8):
+        if K // s < 256 and s > 8:
+            break
+        rounds = tiles * s / slots
+        eff = rounds / max(1.0, float(-(-tiles * s // slots)))
+        if eff > best_eff + 1e-9:
+            best, best_eff = s, eff
+    return best
 
 
 def _wgrad(dy, x):
     """dW[N,K] = dy[M,N]^T x[M,K] (reduction over tokens, split-K)."""
-    return ops.gemm(dy, x, trans_a=True, trans_b=False, split_k=_split_k(dy.shape[1], x.shape[1]))
+    return ops.gemm(dy, x, trans_a=True, trans_b=False,
+                    split_k=_split_k(dy.shape[1], x.shape[1], dy.shape[0]))
 
 
 class _Linear(torch.autograd.Function):

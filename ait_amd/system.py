@@ -68,7 +68,7 @@ def _split_k(M_out, N_out, K):
     else:
         tiles, slots = ((M_out + 127) // 128) * ((N_out + 127) // 128), 1024
     best, best_eff = 8, -1.0
-    for s in range(8, 65, 8):
+    for s in range(8, 129 if tiles <= 4 else 65, 8):
         if K // s < 256 and s > 8:
             break
         rounds = tiles * s / slots
@@ -210,7 +210,8 @@ class _SelectiveHeads(torch.autograd.Function):
     def backward(ctx, du):
         O, sk_w, gate, s = ctx.saved_tensors
         dO, dg = ops.sh_bwd(du.contiguous(), O, gate, sk_w)
-        dw = ops.gemm(dg, s, trans_a=True, trans_b=False)       # [H*dv, dv] = dg^T s
+        dw = ops.gemm(dg, s, trans_a=True, trans_b=False,
+                      split_k=8 if dg.shape[0] >= 512 else 1)       # [H*dv, dv] = dg^T s
         return dO, dw, dg.sum(0)
 
 

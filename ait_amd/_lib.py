@@ -33,9 +33,9 @@ SIGNATURES = {
                         _vp, _vp, _vp]),
     "ait_sh_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ait_sh_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "ait_attn_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp,
+    "ait_attn_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp,
                           _vp]),
-    "ait_attn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _f, _ull, _vp, _i,
+    "ait_attn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _i,
                           _vp, _i, _vp, _i, _vp]),
 }
 

@@ -52,6 +52,13 @@ __device__ __forceinline__ void g2l(const float* __restrict__ g, int ld, float* 
   for (int r = 0; r < T; r++) s[r * PITCH + lane] = g[(size_t)r * ld + lane];
 }
 
+// same, for a K/V panel that only has `rows` (<= 64) rows per sequence: the rest reads as zero
+__device__ __forceinline__ void g2l_rows(const float* __restrict__ g, int ld, float* __restrict__ s,
+                                         int lane, int rows) {
+#pragma unroll 8
+  for (int r = 0; r < T; r++) s[r * PITCH + lane] = r < rows ? g[(size_t)r * ld + lane] : 0.f;
+}
+
 // acc[a][b] += sum_k L(i,k) * R(k,j) for a 64x64x64 product out of two LDS panels.
 //   LT = false: L(i,k) = Ls[i][k]      LT = true: L(i,k) = Ls[k][i]   (left operand transposed)
 //   RT = false: R(k,j) = Rs[k][j]      RT = true: R(k,j) = Rs[j][k]   (right operand transposed)
@@ -132,6 +139,18 @@ __device__ __forceinline__ void acc_to_global(const f32x16 (&acc)[2][2], float* 
       for (int r = 0; r < 16; r++)
         g[(size_t)acc_row(a, r, lane) * ld + acc_col(b, lane)] = acc[a][b][r] * mul;
 }
+__device__ __forceinline__ void acc_to_global_rows(const f32x16 (&acc)[2][2], float* __restrict__ g,
+                                                   int ld, int lane, int rows) {
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = acc_row(a, r, lane);
+        if (row < rows) g[(size_t)row * ld + acc_col(b, lane)] = acc[a][b][r];
+      }
+}
 __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[2][2], float* __restrict__ s,
                                            int lane) {
 #pragma unroll
@@ -147,6 +166,7 @@ struct AttnArgs {
   int ldq, ldk, ldv;
   int n_seq, H;
   int mask_mode, n_valid;
+  int kv_rows;   // rows per sequence in the K / V tensors (64, or fewer when the memory is unpadded)
   float scale, p;
   unsigned long long seed;
 };
@@ -161,14 +181,14 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnArgs g, fl
   float* s0 = lds + wave * 2 * kPanel;
   float* s1 = s0 + kPanel;
   g2l(g.q + ((size_t)n * T) * g.ldq + h * D, g.ldq, s0, lane);
-  g2l(g.k + ((size_t)n * T) * g.ldk + h * D, g.ldk, s1, lane);
+  g2l_rows(g.k + ((size_t)n * g.kv_rows) * g.ldk + h * D, g.ldk, s1, lane, g.kv_rows);
   f32x16 acc[2][2];
   zero(acc);
   mm64<false, true>(s0, s1, acc, lane);  // S = Q K^T
   // ---- scale, mask, softmax over keys (columns) ----------------------------------------
-  const int mode = g.mask_mode, nv = g.n_valid;
+  const int mode = g.mask_mode, nv = g.n_valid, kvr = g.kv_rows;
   for_acc(acc, lane, [&](float x, int row, int col) {
-    const bool dead = (mode == 1 && col >= nv) || (mode == 2 && col > row);
+    const bool dead = col >= kvr || (mode == 1 && col >= nv) || (mode == 2 && col > row);
     return dead ? -1e9f : x * g.scale;
   });
 #pragma unroll
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnArgs g, fl
     });
   }
   acc_to_lds(acc, s0, lane);  // P_drop over the Q panel (this wave's reads of it are done)
-  g2l(g.v + ((size_t)n * T) * g.ldv + h * D, g.ldv, s1, lane);
+  g2l_rows(g.v + ((size_t)n * g.kv_rows) * g.ldv + h * D, g.ldv, s1, lane, g.kv_rows);
   zero(acc);
   mm64<false, false>(s0, s1, acc, lane);  // O = P V
   acc_to_global(acc, O + (size_t)unit * T * D, D, lane, 1.f);
@@ -243,9 +263,9 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kernel(const AttnBwdArgs g)
   f32x16 acc[2][2];
   zero(acc);
   mm64<true, false>(s0, s1, acc, lane);  // dV = Pd^T dO
-  acc_to_global(acc, g.dv + ((size_t)n * T) * g.lddv + h * D, g.lddv, lane, 1.f);
+  acc_to_global_rows(acc, g.dv + ((size_t)n * g.f.kv_rows) * g.lddv + h * D, g.lddv, lane, g.f.kv_rows);
   // dPd = dO V^T
-  g2l(g.f.v + ((size_t)n * T) * g.f.ldv + h * D, g.f.ldv, s0, lane);
+  g2l_rows(g.f.v + ((size_t)n * g.f.kv_rows) * g.f.ldv + h * D, g.f.ldv, s0, lane, g.f.kv_rows);
   zero(acc);
   mm64<false, true>(s1, s0, acc, lane);
   // dS = P * (dP - rowsum(dP * P)) with dP = dPd * mask/(1-p);  then the 1/sqrt(dk) scale
@@ -264,14 +284,14 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kernel(const AttnBwdArgs g)
       acc[a][1][r] = prob[a][1][r] * (d1 - dot) * g.f.scale;
     }
   acc_to_lds(acc, s0, lane);  // dS (already scaled)
-  g2l(g.f.k + ((size_t)n * T) * g.f.ldk + h * D, g.f.ldk, s1, lane);
+  g2l_rows(g.f.k + ((size_t)n * g.f.kv_rows) * g.f.ldk + h * D, g.f.ldk, s1, lane, g.f.kv_rows);
   zero(acc);
   mm64<false, false>(s0, s1, acc, lane);  // dQ = dS K
   acc_to_global(acc, g.dq + ((size_t)n * T) * g.lddq + h * D, g.lddq, lane, 1.f);
   g2l(g.f.q + ((size_t)n * T) * g.f.ldq + h * D, g.f.ldq, s1, lane);
   zero(acc);
   mm64<true, false>(s0, s1, acc, lane);  // dK = dS^T Q
-  acc_to_global(acc, g.dk + ((size_t)n * T) * g.lddk + h * D, g.lddk, lane, 1.f);
+  acc_to_global_rows(acc, g.dk + ((size_t)n * g.f.kv_rows) * g.lddk + h * D, g.lddk, lane, g.f.kv_rows);
 }
 
 constexpr size_t kLds = 0;  // panels are static LDS (66.5 KB per workgroup)
@@ -284,14 +304,15 @@ inline bool bad(int n_seq, int H, int Tt, int d, int mask_mode, int n_valid, flo
 }  // namespace
 
 AIT_API int ait_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                         int n_seq, int H, int Tt, int d, int mask_mode, int n_valid_keys,
+                         int n_seq, int H, int Tt, int d, int kv_rows, int mask_mode, int n_valid_keys,
                          float scale, float p_drop, unsigned long long seed, float* P, float* O,
                          void* stream) {
   if (bad(n_seq, H, Tt, d, mask_mode, n_valid_keys, p_drop)) return AIT_EINVAL;
   if (Tt != T || d != D) return AIT_EUNSUPPORTED;
   if (n_seq == 0) return AIT_OK;
   if (!q || !k || !v || !O) return AIT_EINVAL;
-  AttnArgs a{q, k, v, ldq, ldk, ldv, n_seq, H, mask_mode, n_valid_keys, scale, p_drop, seed};
+  if (kv_rows <= 0 || kv_rows > T) return AIT_EINVAL;
+  AttnArgs a{q, k, v, ldq, ldk, ldv, n_seq, H, mask_mode, n_valid_keys, kv_rows, scale, p_drop, seed};
   const long long units = (long long)n_seq * H;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)((units + kWaves - 1) / kWaves)),
                      dim3(kThreads), kLds, ait_stream(stream), a, P, O);
@@ -300,7 +321,7 @@ AIT_API int ait_attn_fwd(const float* q, int ldq, const float* k, int ldk, const
 }
 
 AIT_API int ait_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                         const float* P, const float* dO, int n_seq, int H, int Tt, int d,
+                         const float* P, const float* dO, int n_seq, int H, int Tt, int d, int kv_rows,
                          float scale, float p_drop, unsigned long long seed, float* dq, int lddq,
                          float* dk, int lddk, float* dv, int lddv, void* stream) {
   if (bad(n_seq, H, Tt, d, 0, 0, p_drop)) return AIT_EINVAL;
@@ -308,7 +329,8 @@ AIT_API int ait_attn_bwd(const float* q, int ldq, const float* k, int ldk, const
   if (n_seq == 0) return AIT_OK;
   if (!q || !k || !v || !P || !dO || !dq || !dk || !dv) return AIT_EINVAL;
   AttnBwdArgs b;
-  b.f = AttnArgs{q, k, v, ldq, ldk, ldv, n_seq, H, 0, 0, scale, p_drop, seed};
+  if (kv_rows <= 0 || kv_rows > T) return AIT_EINVAL;
+  b.f = AttnArgs{q, k, v, ldq, ldk, ldv, n_seq, H, 0, 0, kv_rows, scale, p_drop, seed};
   b.P = P; b.dO = dO; b.dq = dq; b.dk = dk; b.dv = dv;
   b.lddq = lddq; b.lddk = lddk; b.lddv = lddv;
   const long long units = (long long)n_seq * H;

@@ -145,13 +145,14 @@ def _col(t, off):
 
 
 def attn_fwd(q, qoff, k, koff, v, voff, n_seq, H, T, d, mask_mode, n_valid, scale, p, seed,
-             save_p=True):
+             save_p=True, kv_rows=None):
+    kv_rows = T if kv_rows is None else kv_rows
     dev = q.device
     O = torch.empty((n_seq, H, T, d), dtype=torch.float32, device=dev)
     P = torch.empty((n_seq, H, T, T), dtype=torch.float32, device=dev) if save_p else None
     with torch.cuda.device(dev):
         rc = _lib.lib().ait_attn_fwd(_col(q, qoff), q.stride(0), _col(k, koff), k.stride(0),
-                                     _col(v, voff), v.stride(0), n_seq, H, T, d, mask_mode,
+                                     _col(v, voff), v.stride(0), n_seq, H, T, d, int(kv_rows), mask_mode,
                                      n_valid, float(scale), float(p), int(seed), _p(P), _p(O),
                                      _lib.cur_stream(dev))
     _lib.check(rc, "ait_attn_fwd")
@@ -159,12 +160,13 @@ def attn_fwd(q, qoff, k, koff, v, voff, n_seq, H, T, d, mask_mode, n_valid, scal
 
 
 def attn_bwd(q, qoff, k, koff, v, voff, P, dO, n_seq, H, T, d, scale, p, seed, dq, dqoff, dk,
-             dkoff, dv, dvoff):
+             dkoff, dv, dvoff, kv_rows=None):
     dev = q.device
+    kv_rows = T if kv_rows is None else kv_rows
     with torch.cuda.device(dev):
         rc = _lib.lib().ait_attn_bwd(_col(q, qoff), q.stride(0), _col(k, koff), k.stride(0),
                                      _col(v, voff), v.stride(0), _p(P), _p(dO), n_seq, H, T, d,
-                                     float(scale), float(p), int(seed), _col(dq, dqoff),
+                                     int(kv_rows), float(scale), float(p), int(seed), _col(dq, dqoff),
                                      dq.stride(0), _col(dk, dkoff), dk.stride(0),
                                      _col(dv, dvoff), dv.stride(0), _lib.cur_stream(dev))
     _lib.check(rc, "ait_attn_bwd")

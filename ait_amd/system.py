@@ -17,6 +17,8 @@ dropout+residual+LayerNorm rows, per-(sequence, head) attention tiles, selective
 supplies device memory, streams and the autograd tape between the fused blocks.  There is no CPU
 path: tensors must be on a GPU or the call raises.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -180,20 +182,22 @@ class _AttnCross(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, kv, n_seq, H, d, mask_mode, n_valid, scale, p, seed):
         hd = H * d
-        O, P = ops.attn_fwd(q, 0, kv, 0, kv, hd, n_seq, H, SEQ, d, mask_mode, n_valid, scale, p, seed)
+        kv_rows = kv.shape[0] // n_seq          # 64, or the unpadded memory length (49)
+        O, P = ops.attn_fwd(q, 0, kv, 0, kv, hd, n_seq, H, SEQ, d, mask_mode, n_valid, scale, p, seed,
+                            kv_rows=kv_rows)
         ctx.save_for_backward(q, kv, P)
-        ctx.cfg = (n_seq, H, d, scale, p, seed)
+        ctx.cfg = (n_seq, H, d, scale, p, seed, kv_rows)
         ctx.mark_non_differentiable(P)
         return O, P
 
     @staticmethod
     def backward(ctx, dO, _dP):
         q, kv, P = ctx.saved_tensors
-        n_seq, H, d, scale, p, seed = ctx.cfg
+        n_seq, H, d, scale, p, seed, kv_rows = ctx.cfg
         hd = H * d
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         ops.attn_bwd(q, 0, kv, 0, kv, hd, P, dO.contiguous(), n_seq, H, SEQ, d, scale, p, seed,
-                     dq, 0, dkv, 0, dkv, hd)
+                     dq, 0, dkv, 0, dkv, hd, kv_rows=kv_rows)
         return dq, dkv, None, None, None, None, None, None, None, None
 
 
@@ -309,9 +313,12 @@ class MultiHeadAttention(nn.Module):
         self.layer_norm = nn.LayerNorm(d_model, eps=LN_EPS)
 
     def _fast(self, q, k, v, mask):
-        return (self.n_head == 8 and self.d_k == 64 and self.d_v == 64 and self.dist == 'softmax'
-                and self.d_model == ops.D_MODEL and q.size(1) == SEQ and k.size(1) == SEQ
-                and (k is v) and _mask_code(mask) is not None and q.size(0) == k.size(0))
+        if not (self.n_head == 8 and self.d_k == 64 and self.d_v == 64 and self.dist == 'softmax'
+                and self.d_model == ops.D_MODEL and q.size(1) == SEQ and (k is v)
+                and _mask_code(mask) is not None and q.size(0) == k.size(0)):
+            return False
+        # self-attention: 64 keys; cross-attention: a memory of up to 64 tokens, passed unpadded
+        return k.size(1) == SEQ or (k is not q and 0 < k.size(1) < SEQ)
 
     def forward(self, q, k, v, mask=None):
         if self._fast(q, k, v, mask):
@@ -330,7 +337,7 @@ class MultiHeadAttention(nn.Module):
             O, attn = _AttnSelf.apply(qkv, n_seq, H, d, mode, n_valid, 1.0 / self.d_k ** 0.5, p,
                                       _new_seed())
         else:
-            xkv = x_kv.reshape(n_seq * SEQ, self.d_model)
+            xkv = x_kv.reshape(n_seq * x_kv.size(1), self.d_model)
             qp = _Linear.apply(xq, self.w_qs.weight, None)
             kv = _Linear.apply(xkv, torch.cat([self.w_ks.weight, self.w_vs.weight], 0), None)
             O, attn = _AttnCross.apply(qp, kv, n_seq, H, d, mode, n_valid, 1.0 / self.d_k ** 0.5,
@@ -463,10 +470,21 @@ class Encoder(_Coder):
         x = self.prologue(src_seq.reshape(n * SEQ, -1), n, SEQ, 1)
         return self.run_layers(x, src_mask, return_attns)
 
-    def run_layers(self, x, src_mask, return_attns=False):
+    def run_layers(self, x, src_mask, return_attns=False, n_valid=None):
+        """n_valid (tokens that are real, not zero padding): after the LAST layer's attention
+        only the first n_valid rows of each sequence are ever read again (the padded rows are
+        masked as keys in the decoder's cross-attention), so that layer's feed-forward and
+        LayerNorm run on the compacted rows and the memory is returned unpadded
+        [bs, n_valid, d].  Skipped work: 23 % of the encoder feed-forward and of the
+        cross-attention K/V projection (SURVEY.md 8d reports it separately)."""
         attns = []
-        for layer in self.layer_stack:
-            x, a = layer(x, slf_attn_mask=src_mask)
+        last = len(self.layer_stack) - 1
+        for i, layer in enumerate(self.layer_stack):
+            if n_valid is not None and n_valid < x.size(1) and i == last:
+                x, a = layer.slf_attn(x, x, x, mask=src_mask)
+                x = layer.pos_ffn(x[:, :n_valid].contiguous())
+            else:
+                x, a = layer(x, slf_attn_mask=src_mask)
             attns += [a] if return_attns else []
         return (x, attns) if return_attns else (x,)
 
@@ -542,9 +560,13 @@ class Transformer(nn.Module):
         emb_q = _Linear.apply(xq, self.dec_emb[0].weight.view(d, c2), self.dec_emb[0].bias)
         src_mask, trg_mask = KeyPadMask(n_s), CausalMask()
         enc = self.encoder.prologue(emb_p, bp, n_s, 1)              # zero-pads 49 -> 64 rows
-        enc, *_ = self.encoder.run_layers(enc, src_mask)
+        if os.environ.get("AIT_COMPACT_MEMORY", "1") == "0":     # A/B switch: padded memory, as the reference
+            n_s_eff = SEQ
+        else:
+            n_s_eff = n_s
+        enc, *_ = self.encoder.run_layers(enc, src_mask, n_valid=n_s_eff)  # memory [bp, 49, d]
         dec = self.decoder.prologue(emb_q, bp, n_t, P)              # repeats the query over P
-        dec, *_ = self.decoder.run_layers(dec, trg_mask, enc, src_mask)
+        dec, *_ = self.decoder.run_layers(dec, trg_mask, enc, None if n_s_eff < SEQ else src_mask)
         out = _ToNCHW.apply(dec.reshape(bp * n_t, d), self.dec_trans[0].weight.view(c2, d),
                             self.dec_trans[0].bias, bp, n_t)
         return out.view(bp, c2, hq, wq)

@@ -170,7 +170,10 @@ int ait_sh_bwd(const float* du, const float* O, const float* gate, const float* 
  * Scaled dot-product attention per (sequence, head) (T = 64, d = 64 only).
  * Replaces ScaledDotProductAttention.forward (lib/model/system/Modules.py:16-29) and the
  * head split / transpose around it (lib/model/system/SubLayers.py:77-90).
- *   q,k,v  row (n*T + t) of a [n_seq*T, ld*] matrix; head h occupies columns [h*d, (h+1)*d)
+ *   q      row (n*T + t) of a [n_seq*T, ldq] matrix; head h occupies columns [h*d, (h+1)*d)
+ *   k,v    row (n*kv_rows + t) of [n_seq*kv_rows, ld*] matrices, kv_rows <= T: a memory of fewer
+ *          than T tokens is passed UNPADDED (the 49-token proposal memory of the decoder's
+ *          cross-attention); keys >= kv_rows do not exist (probability exactly 0)
  *   mask_mode 0: none; 1: keys >= n_valid_keys masked (src_mask, Models.py:258-260);
  *             2: causal, key <= query (trg_mask, Models.py:262-263)
  *   scale  1/temperature (= 1/8)
@@ -179,10 +182,10 @@ int ait_sh_bwd(const float* du, const float* O, const float* gate, const float* 
  * Backward writes dq/dk/dv with the same row/column addressing as q/k/v.
  * ------------------------------------------------------------------------------------- */
 int ait_attn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                 int n_seq, int H, int T, int d, int mask_mode, int n_valid_keys, float scale,
+                 int n_seq, int H, int T, int d, int kv_rows, int mask_mode, int n_valid_keys, float scale,
                  float p_drop, unsigned long long seed, float* P, float* O, void* stream);
 int ait_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                 const float* P, const float* dO, int n_seq, int H, int T, int d, float scale,
+                 const float* P, const float* dO, int n_seq, int H, int T, int d, int kv_rows, float scale,
                  float p_drop, unsigned long long seed, float* dq, int lddq, float* dk, int lddk,
                  float* dv, int lddv, void* stream);
 

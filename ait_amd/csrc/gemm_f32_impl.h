@@ -219,9 +219,19 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
         for (int a = 0; a < C::TM; a++) av[a] = an[a];
 #pragma unroll
         for (int b = 0; b < C::TN; b++) bv[b] = bn[b];
+        if ((C::OPT & 8) && kk == BK / 2) {
+          // OPT bit 3: the slab fetched at the top of this iteration is written to the ring in
+          // the MIDDLE of the MFMA stream (its loads have long landed), not in front of the barrier
+          __builtin_amdgcn_sched_barrier(0);
+          if (more2) {
+            store_slab<AK, BM, BK, C::NT, C::VA, C::PA>(As + nxt2 * BK * C::PA, ra);
+            store_slab<BKC, BN, BK, C::NT, C::VB, C::PB>(Bs + nxt2 * BK * C::PB, rb);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (more2) {
+      if (!(C::OPT & 8) && more2) {
         store_slab<AK, BM, BK, C::NT, C::VA, C::PA>(As + nxt2 * BK * C::PA, ra);
         store_slab<BKC, BN, BK, C::NT, C::VB, C::PB>(Bs + nxt2 * BK * C::PB, rb);
       }

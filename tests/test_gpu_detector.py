@@ -219,3 +219,24 @@ def test_detector_coco_variant(golden):
             np.testing.assert_allclose(np.array([float(x) for x in out[3:8]]), g["train_losses"], rtol=2e-4, atol=2e-6)
     finally:
         config.cfg.ANCHOR_SCALES, config.cfg.MAX_NUM_GT_BOXES = saved
+
+
+def test_resnet101_variant_runs():
+    """BASELINE cfg5 backbone (ResNet101, cfgs/res101.yml) in fp32: builds with the reference's
+    key set and trains one small step (the bf16 arithmetic of cfg5 is a later round)."""
+    from ait_amd import config
+    from ait_amd.faster_rcnn import resnet
+    m = resnet(('__background__', 'fg'), 101, pretrained=False, class_agnostic=True, num_K=3)
+    m.create_architecture()
+    keys = set(m.state_dict())
+    assert set(D.reference_shapes(n_layers=101)) <= keys
+    assert "RCNN_base.backbone.layer3.22.conv3.weight" in keys
+    m = m.cuda().train()
+    config.cfg.TRAIN.BATCH_SIZE = 32
+    np.random.seed(3)
+    ins = [t.cuda() for t in D.synth_inputs(1, 7, im_hw=(320, 480))]
+    out = m(*ins)
+    loss = out[3] + out[4] + out[5] + out[6] + out[7]
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert tuple(out[0].shape) == (1, 32, 5)

@@ -26,6 +26,8 @@ SIGNATURES = {
     "ait_nms_batched": (_i, [_vp, _i, _i, _f, _i, _vp, _sz, _vp, _ll, _vp, _vp]),
     "ait_bn_act_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp, _vp]),
     "ait_bn_act_bwd": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _vp, _vp, _vp]),
+    "ait_sk_sqsum_fwd": (_i, [_vp, _vp, _ll, _vp, _vp]),
+    "ait_sk_sqsum_bwd": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _vp]),
     "ait_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
                           _i, ctypes.c_longlong, _vp]),
     "ait_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp, _vp, _vp]),

@@ -126,3 +126,69 @@ AIT_API int ait_bn_act_bwd(const float* dy, const float* y, const float* scale, 
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// SKBlock tail: out = relu(a)^2 + relu(b)^2  (lib/model/modules/blocks_sys_transformer_sk_dilat.py
+// :966-981 as actually executed: two conv+ReLU branches, `v = f * f`, sum over the branches; the
+// branch-attention weights are computed upstream but never used).  One pass instead of five.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(kThreads) void sk_sqsum_fwd_kernel(const float4* __restrict__ a,
+                                                                const float4* __restrict__ b,
+                                                                long long n4, float4* __restrict__ y) {
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+    const float4 x = a[i], z = b[i];
+    float4 o;
+    float p, q;
+    p = fmaxf(x.x, 0.f); q = fmaxf(z.x, 0.f); o.x = p * p + q * q;
+    p = fmaxf(x.y, 0.f); q = fmaxf(z.y, 0.f); o.y = p * p + q * q;
+    p = fmaxf(x.z, 0.f); q = fmaxf(z.z, 0.f); o.z = p * p + q * q;
+    p = fmaxf(x.w, 0.f); q = fmaxf(z.w, 0.f); o.w = p * p + q * q;
+    y[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void sk_sqsum_bwd_kernel(
+    const float4* __restrict__ dy, const float4* __restrict__ a, const float4* __restrict__ b,
+    long long n4, float4* __restrict__ da, float4* __restrict__ db) {
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += stride) {
+    const float4 g = dy[i], x = a[i], z = b[i];
+    // d/da relu(a)^2 = 2*relu(a)
+    da[i] = make_float4(2.f * fmaxf(x.x, 0.f) * g.x, 2.f * fmaxf(x.y, 0.f) * g.y,
+                        2.f * fmaxf(x.z, 0.f) * g.z, 2.f * fmaxf(x.w, 0.f) * g.w);
+    db[i] = make_float4(2.f * fmaxf(z.x, 0.f) * g.x, 2.f * fmaxf(z.y, 0.f) * g.y,
+                        2.f * fmaxf(z.z, 0.f) * g.z, 2.f * fmaxf(z.w, 0.f) * g.w);
+  }
+}
+
+}  // namespace
+
+AIT_API int ait_sk_sqsum_fwd(const float* a, const float* b, long long n, float* y, void* stream) {
+  if (n < 0) return AIT_EINVAL;
+  if (n == 0) return AIT_OK;
+  if (!a || !b || !y) return AIT_EINVAL;
+  if ((n & 3) || !aligned16(a) || !aligned16(b) || !aligned16(y)) return AIT_EUNSUPPORTED;
+  hipLaunchKernelGGL(sk_sqsum_fwd_kernel, dim3(grid_for(n)), dim3(kThreads), 0, ait_stream(stream),
+                     reinterpret_cast<const float4*>(a), reinterpret_cast<const float4*>(b), n / 4,
+                     reinterpret_cast<float4*>(y));
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_sk_sqsum_bwd(const float* dy, const float* a, const float* b, long long n, float* da,
+                             float* db, void* stream) {
+  if (n < 0) return AIT_EINVAL;
+  if (n == 0) return AIT_OK;
+  if (!dy || !a || !b || !da || !db) return AIT_EINVAL;
+  if ((n & 3) || !aligned16(dy) || !aligned16(a) || !aligned16(b) || !aligned16(da) || !aligned16(db))
+    return AIT_EUNSUPPORTED;
+  hipLaunchKernelGGL(sk_sqsum_bwd_kernel, dim3(grid_for(n)), dim3(kThreads), 0, ait_stream(stream),
+                     reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(a),
+                     reinterpret_cast<const float4*>(b), n / 4, reinterpret_cast<float4*>(da),
+                     reinterpret_cast<float4*>(db));
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}

@@ -30,6 +30,20 @@ from .system import MultiHeadAttention, Transformer, conv2d_1x1
 # ------------------------------------------------------------------------------------------
 # channel block between AIT and layer4
 # ------------------------------------------------------------------------------------------
+class _SkSqSum(torch.autograd.Function):
+    """relu(a)^2 + relu(b)^2 (the SKBlock tail as the reference executes it)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return ops.sk_sqsum_fwd(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b = ctx.saved_tensors
+        return ops.sk_sqsum_bwd(dy.contiguous(), a, b)
+
+
 class SKBlock(nn.Module):
     """Selective-kernel block as the reference actually computes it: two grouped conv branches
     (1x1 and 3x3, 8 groups, ReLU); the branch-attention weights `a` are computed and then NOT
@@ -52,6 +66,9 @@ class SKBlock(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and self.n_state == 2 and x.numel() % 4 == 0:
+            # convolutions on MIOpen, then ReLU / square / branch sum in one fused HIP pass
+            return _SkSqSum.apply(self.convs[0][0](x).contiguous(), self.convs[1][0](x).contiguous())
         out = None
         for branch in self.convs:
             f = branch(x)

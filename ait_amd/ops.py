@@ -193,3 +193,20 @@ def bn_act_bwd(dy, y, scale, relu, need_dres):
                                        _lib.cur_stream(dy.device))
     _lib.check(rc, "ait_bn_act_bwd")
     return dx, dres
+
+
+def sk_sqsum_fwd(a, b):
+    y = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().ait_sk_sqsum_fwd(_p(a), _p(b), a.numel(), _p(y), _lib.cur_stream(a.device))
+    _lib.check(rc, "ait_sk_sqsum_fwd")
+    return y
+
+
+def sk_sqsum_bwd(dy, a, b):
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().ait_sk_sqsum_bwd(_p(dy), _p(a), _p(b), a.numel(), _p(da), _p(db),
+                                         _lib.cur_stream(a.device))
+    _lib.check(rc, "ait_sk_sqsum_bwd")
+    return da, db

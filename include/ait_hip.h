@@ -204,6 +204,13 @@ int ait_bn_act_fwd(const float* x, const float* scale, const float* shift, const
 int ait_bn_act_bwd(const float* dy, const float* y, const float* scale, int relu, long long n,
                    int C, int HW, float* dx, float* dres, void* stream);
 
+/* SKBlock tail as the reference executes it (blocks_sys_transformer_sk_dilat.py:966-981: two
+ * conv+ReLU branches, `v = f * f`, summed): y = relu(a)^2 + relu(b)^2 over n fp32 elements
+ * (n % 4 == 0, 16-byte aligned), and da = 2*relu(a)*dy, db = 2*relu(b)*dy. */
+int ait_sk_sqsum_fwd(const float* a, const float* b, long long n, float* y, void* stream);
+int ait_sk_sqsum_bwd(const float* dy, const float* a, const float* b, long long n, float* da,
+                     float* db, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

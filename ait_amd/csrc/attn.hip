@@ -55,8 +55,13 @@ __device__ __forceinline__ void g2l(const float* __restrict__ g, int ld, float* 
 // same, for a K/V panel that only has `rows` (<= 64) rows per sequence: the rest reads as zero
 __device__ __forceinline__ void g2l_rows(const float* __restrict__ g, int ld, float* __restrict__ s,
                                          int lane, int rows) {
+  // loads stay unconditional (clamped row) so the compiler keeps them batched; a per-row branch
+  // around the load serialises 64 global round trips
 #pragma unroll 8
-  for (int r = 0; r < T; r++) s[r * PITCH + lane] = r < rows ? g[(size_t)r * ld + lane] : 0.f;
+  for (int r = 0; r < T; r++) {
+    const float v = g[(size_t)min(r, rows - 1) * ld + lane];
+    s[r * PITCH + lane] = r < rows ? v : 0.f;
+  }
 }
 
 // acc[a][b] += sum_k L(i,k) * R(k,j) for a 64x64x64 product out of two LDS panels.

@@ -569,3 +569,27 @@ def time_train_step(P=300, cores=1, seconds_budget=25.0, seed=5):
             "sample": "%d single-pair train iterations (fwd+bwd, 600x1000 target, P=%d) of "
                       "oracle/detector_ref.py with torch.set_num_threads(%d); RoIAlign/NMS from "
                       "oracle/native.c run single-threaded; median of all but the first" % (it, P, cores)}
+
+
+def postprocess_detections(cfgd, rois, cls_prob, bbox_pred, im_info, im_scale, nms_thr=0.3, thresh=0.0,
+                           max_per_image=100):
+    """test_net_coco.py:381-449 restated on the CPU (class-agnostic, one image)."""
+    t = cfgd["TRAIN"]
+    deltas = bbox_pred.view(-1, 4) * torch.tensor(t["BBOX_NORMALIZE_STDS"]) + torch.tensor(t["BBOX_NORMALIZE_MEANS"])
+    pred = decode_boxes(rois[0, :, 1:5], deltas)
+    pred[:, 0::2].clamp_(0, float(im_info[0, 1]) - 1)
+    pred[:, 1::2].clamp_(0, float(im_info[0, 0]) - 1)
+    pred = pred / im_scale
+    scores = cls_prob.reshape(-1)
+    inds = torch.nonzero(scores > thresh).view(-1)
+    if inds.numel() == 0:
+        return torch.zeros(0, 5)
+    s, b = scores[inds], pred[inds]
+    order = torch.sort(s, 0, True)[1]
+    dets = torch.cat([b, s[:, None]], 1)[order]
+    keep = native.nms(b[order].numpy(), s[order].numpy(), nms_thr)
+    dets = dets[torch.from_numpy(keep)]
+    if max_per_image > 0 and dets.shape[0] > max_per_image:
+        kth = np.sort(dets[:, 4].numpy())[-max_per_image]
+        dets = dets[dets[:, 4] >= float(kth)]
+    return dets

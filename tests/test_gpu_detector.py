@@ -240,3 +240,18 @@ def test_resnet101_variant_runs():
     loss.backward()
     assert torch.isfinite(loss)
     assert tuple(out[0].shape) == (1, 32, 5)
+
+
+def test_eval_postprocessing_vs_oracle(golden):
+    """test_net_*.py post-processing (de-normalise, decode, clip, threshold, sort, second NMS at
+    cfg.TEST.NMS, top-100) on the reference's own eval outputs (golden g9)."""
+    from ait_amd.postprocess import detections
+    g = golden("g9_detector_eval")
+    info = torch.tensor([[600.0, 1000.0, 1.0]])
+    rois, prob, bbox = (torch.from_numpy(g[k]) for k in ("rois", "cls_prob", "bbox_pred"))
+    # make the regression non-trivial (the random-weight golden has ~1e-3 deltas)
+    bbox = bbox * 300.0
+    want = D.postprocess_detections(D.default_config(), rois, prob, bbox, info, 1.6).numpy()
+    got = detections(rois.cuda(), prob.cuda(), bbox.cuda(), info.cuda(), 1.6).cpu().numpy()
+    assert got.shape == want.shape and got.shape[0] <= 100 + 5
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-3)

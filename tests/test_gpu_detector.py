@@ -249,8 +249,11 @@ def test_eval_postprocessing_vs_oracle(golden):
     g = golden("g9_detector_eval")
     info = torch.tensor([[600.0, 1000.0, 1.0]])
     rois, prob, bbox = (torch.from_numpy(g[k]) for k in ("rois", "cls_prob", "bbox_pred"))
-    # make the regression non-trivial (the random-weight golden has ~1e-3 deltas)
+    # make the regression non-trivial (the random-weight golden has ~1e-3 deltas) and the scores
+    # distinct (random weights give probabilities tied to ~1e-7, whose sort order is arbitrary)
     bbox = bbox * 300.0
+    n = prob.numel()
+    prob = torch.from_numpy(np.random.RandomState(5).permutation(n).astype(np.float32) / n * 0.9 + 0.05).view_as(prob)
     want = D.postprocess_detections(D.default_config(), rois, prob, bbox, info, 1.6).numpy()
     got = detections(rois.cuda(), prob.cuda(), bbox.cuda(), info.cuda(), 1.6).cpu().numpy()
     assert got.shape == want.shape and got.shape[0] <= 100 + 5

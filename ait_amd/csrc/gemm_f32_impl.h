@@ -97,13 +97,76 @@ __device__ __forceinline__ void store_slab(float* __restrict__ s, const float4 (
 //   forward  y = x W^T   : A = x [M,K] (AK), B = W [N,K] (BKC)
 //   dgrad    dx = dy W   : A = dy [M,K'] (AK), B = W [K',N] (!BKC)
 //   wgrad    dW = dy^T x : A = dy [K',M] (!AK), B = x [K',N] (!BKC)
+enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_AUX = 2 };
+
+// C/D layout of the 32x32 MFMA (any input dtype): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int TM, int TN, int EPI>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& g, int m0, int n0,
+                                         int wm, int wn, int li, int lk) {
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const bool relu = (g.flags & AIT_GEMM_RELU) != 0;
+  const bool bias_row = (g.flags & AIT_GEMM_BIAS_ROW) != 0;
+#pragma unroll
+  for (int a = 0; a < TM; a++)
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
+      const int col = n0 + wn + b * 32 + li;
+      const bool col_ok = col < g.N;
+      const int colc = col_ok ? col : 0;
+      size_t cbase;
+      if (g.c_colblk > 0)
+        cbase = (size_t)(colc / g.c_colblk) * g.c_batch + (colc % g.c_colblk);
+      else
+        cbase = colc;
+      const int rbase = m0 + wm + a * 32 + 4 * lk;
+      if (EPI == EPI_ATOMIC) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (col_ok && row < g.M) unsafeAtomicAdd(g.C + cbase + (size_t)row * g.ldc, g.alpha * acc[a][b][r]);
+        }
+      } else {
+        float v[16];
+        const float bcol = (g.bias && !bias_row) ? g.bias[colc] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          v[r] = g.alpha * acc[a][b][r] + (bias_row ? (g.bias ? g.bias[min(row, g.M - 1)] : 0.f) : bcol);
+        }
+        if (EPI == EPI_AUX) {
+          const bool mask_pos = (g.flags & AIT_GEMM_MASK_POS) != 0;
+          const bool accum = (g.flags & AIT_GEMM_ACCUMULATE) != 0;
+          float x[16], y[16];
+          // all loads first (clamped addresses, unconditional), then the arithmetic
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
+            const size_t off = cbase + (size_t)row * g.ldc;
+            x[r] = g.residual ? g.residual[off] : 0.f;
+            y[r] = accum ? g.C[off] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            if (mask_pos) v[r] = x[r] > 0.f ? v[r] : 0.f;  // ReLU backward: gate by the saved activation
+            else v[r] += x[r];
+            v[r] += y[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (relu) v[r] = fmaxf(v[r], 0.f);
+          if (col_ok && row < g.M) g.C[cbase + (size_t)row * g.ldc] = v[r];
+        }
+      }
+    }
+}
+
 // EPI selects the epilogue at compile time (a run-time flag test per element makes hipcc branch
 // around every load/store and wait vmcnt(0) each time):
 //   EPI_STORE  C = alpha*acc (+bias) (relu)            -- no loads at all
 //   EPI_ATOMIC C += alpha*acc with fp32 atomics        -- split-K partial tiles
 //   EPI_AUX    the forms that read memory: +residual, ReLU-backward gate, accumulate into C
-enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_AUX = 2 };
-
 template <class C, bool AK, bool BKC, int EPI>
 __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs g) {
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK;
@@ -307,63 +370,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
   }
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const bool relu = (g.flags & AIT_GEMM_RELU) != 0;
-  const bool bias_row = (g.flags & AIT_GEMM_BIAS_ROW) != 0;
-#pragma unroll
-  for (int a = 0; a < C::TM; a++)
-#pragma unroll
-    for (int b = 0; b < C::TN; b++) {
-      const int col = n0 + wn + b * 32 + li;
-      const bool col_ok = col < g.N;
-      const int colc = col_ok ? col : 0;
-      size_t cbase;
-      if (g.c_colblk > 0)
-        cbase = (size_t)(colc / g.c_colblk) * g.c_batch + (colc % g.c_colblk);
-      else
-        cbase = colc;
-      const int rbase = m0 + wm + a * 32 + 4 * lk;
-      if (EPI == EPI_ATOMIC) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (col_ok && row < g.M) unsafeAtomicAdd(g.C + cbase + (size_t)row * g.ldc, g.alpha * acc[a][b][r]);
-        }
-      } else {
-        float v[16];
-        const float bcol = (g.bias && !bias_row) ? g.bias[colc] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          v[r] = g.alpha * acc[a][b][r] + (bias_row ? (g.bias ? g.bias[min(row, g.M - 1)] : 0.f) : bcol);
-        }
-        if (EPI == EPI_AUX) {
-          const bool mask_pos = (g.flags & AIT_GEMM_MASK_POS) != 0;
-          const bool accum = (g.flags & AIT_GEMM_ACCUMULATE) != 0;
-          float x[16], y[16];
-          // all loads first (clamped addresses, unconditional), then the arithmetic
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
-            const size_t off = cbase + (size_t)row * g.ldc;
-            x[r] = g.residual ? g.residual[off] : 0.f;
-            y[r] = accum ? g.C[off] : 0.f;
-          }
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            if (mask_pos) v[r] = x[r] > 0.f ? v[r] : 0.f;  // ReLU backward: gate by the saved activation
-            else v[r] += x[r];
-            v[r] += y[r];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (relu) v[r] = fmaxf(v[r], 0.f);
-          if (col_ok && row < g.M) g.C[cbase + (size_t)row * g.ldc] = v[r];
-        }
-      }
-    }
+  epilogue<C::TM, C::TN, EPI>(acc, g, m0, n0, wm, wn, li, lk);
 }
 
 template <class C, bool AK, bool BKC, int EPI>

@@ -10,6 +10,23 @@ def _p(t, dtype=torch.float32):
     return None if t is None else _lib.dev_ptr(t, dtype)
 
 
+# "f32": exact fp32 products on v_mfma_f32_32x32x2_f32 (default, the parity / headline path).
+# "bf16": operands rounded to bf16 on the fly, v_mfma_f32_32x32x16_bf16 (BASELINE cfg 5 arithmetic).
+MATMUL_DTYPE = "f32"
+
+
+def set_matmul_dtype(dtype):
+    global MATMUL_DTYPE
+    if dtype not in ("f32", "bf16"):
+        raise ValueError(dtype)
+    MATMUL_DTYPE = dtype
+
+
+def _gemm_fn():
+    L = _lib.lib()
+    return L.ait_gemm_bf16 if MATMUL_DTYPE == "bf16" else L.ait_gemm_f32
+
+
 # When set to a list, every GEMM launch appends (flops, start_event, end_event) recorded on the
 # launch stream (bench.py's live roofline measurement).
 GEMM_PROFILE = None
@@ -56,7 +73,7 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, 
         | (_lib.GEMM_ACCUMULATE if accumulate and split_k == 1 else 0) \
         | (_lib.GEMM_ATOMIC if split_k > 1 else 0) | (_lib.GEMM_BIAS_ROW if bias_row else 0)
     with torch.cuda.device(a.device):
-        rc = _profiled(lambda: _lib.lib().ait_gemm_f32(
+        rc = _profiled(lambda: _gemm_fn()(
             int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.dev_ptr(a), a.stride(0),
             _lib.dev_ptr(b), b.stride(0), ctypes.c_void_p(out.data_ptr()), ldc, _p(bias),
             _p(residual), flags, int(split_k), int(c_colblk), int(c_batch_stride),
@@ -73,7 +90,7 @@ def gemm_relu_bwd(dy, w, act, out=None):
     if out is None:
         out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
     with torch.cuda.device(dy.device):
-        rc = _profiled(lambda: _lib.lib().ait_gemm_f32(
+        rc = _profiled(lambda: _gemm_fn()(
             0, 0, M, K, N, 1.0, _lib.dev_ptr(dy), dy.stride(0), _lib.dev_ptr(w), w.stride(0),
             _lib.dev_ptr(out), out.stride(0), None, _lib.dev_ptr(act), _lib.GEMM_MASK_POS, 1, 0, 0,
             _lib.cur_stream(dy.device)), 2.0 * M * N * K, dy.device, (M, K, N, 0, 0, 1, -1))

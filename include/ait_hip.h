@@ -121,6 +121,14 @@ int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, con
                  const float* residual, int flags, int split_k, int c_colblk,
                  long long c_batch_stride, void* stream);
 
+/* bf16 matrix-core variant (BASELINE cfg 5): identical interface, layouts and epilogues; A and B
+ * stay fp32 in memory, are rounded to bf16 (RNE) while being staged into LDS, multiplied on
+ * v_mfma_f32_32x32x16_bf16 and accumulated in fp32.  Not used for the fp32 headline metric. */
+int ait_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
+                  int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
+                  const float* residual, int flags, int split_k, int c_colblk,
+                  long long c_batch_stride, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Row kernels (d_model = 512 only; other widths return AIT_EUNSUPPORTED).
  *

@@ -24,6 +24,7 @@ def timeit(fn, n=10, w=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 M = 76800
+dt = "bf16" if "bf16" in sys.argv else "f32"
 shapes = [("qkv NT", M, 1536, 512, 0, 1, 1), ("ffn2 NT", M, 512, 2048, 0, 1, 1), ("ffn1 NT", M, 2048, 512, 0, 1, 1),
           ("dgrad NN", M, 512, 2048, 0, 0, 1), ("dgrad NN", M, 2048, 512, 0, 0, 1),
           ("wgrad TN", 512, 2048, M, 1, 0, 16), ("wgrad TN", 2048, 512, M, 1, 0, 16), ("wgrad TN", 1536, 512, M, 1, 0, 24)]

@@ -69,3 +69,46 @@ def test_gemm_rejects_unaligned():
     b = torch.randn(8, 6, device="cuda")
     with pytest.raises(_lib.AitHipError):
         ops.gemm(a, b)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (512, 512, 512), (300, 200, 64), (7350, 512, 1024), (64, 64, 2048),
+                                   (130, 4, 20)])
+def test_gemm_bf16_layouts(ta, tb, M, N, K):
+    """bf16 matrix-core variant: equals an fp64 product of the bf16-ROUNDED operands up to fp32
+    accumulation error, and the fp32 product within bf16 input rounding (2^-8 relative per operand)."""
+    from ait_amd import ops
+    torch.manual_seed(M + N + K)
+    if (ta and M % 4) or (not tb and N % 4):
+        pytest.skip("leading dimension must be a multiple of 4")
+    a = torch.randn((K, M) if ta else (M, K), device="cuda")
+    b = torch.randn((N, K) if tb else (K, N), device="cuda")
+    ops.set_matmul_dtype("bf16")
+    try:
+        c = ops.gemm(a, b, trans_a=ta, trans_b=tb)
+    finally:
+        ops.set_matmul_dtype("f32")
+    ar, br = a.bfloat16().double(), b.bfloat16().double()
+    want = (ar.t() if ta else ar) @ (br.t() if tb else br)
+    bound = 4e-7 * (ar.abs().t() if ta else ar.abs()) @ (br.abs().t() if tb else br.abs()) + 1e-5
+    assert bool(((c.double() - want).abs() <= bound).all())
+    full = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    assert float((c.double() - full).norm() / full.norm()) < 6e-3
+
+
+def test_gemm_bf16_epilogues_and_splitk():
+    from ait_amd import ops
+    torch.manual_seed(1)
+    ops.set_matmul_dtype("bf16")
+    try:
+        M, N, K = 512, 256, 128
+        a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+        bias, res = torch.randn(N, device="cuda"), torch.randn(M, N, device="cuda")
+        ref = a.bfloat16().double() @ w.bfloat16().double().t()
+        got = ops.gemm(a, w, bias=bias, residual=res, relu=True)
+        assert torch.allclose(got.double(), torch.relu(ref + bias.double() + res.double()), rtol=1e-5, atol=1e-4)
+        dy, x = torch.randn(4096, N, device="cuda"), torch.randn(4096, K, device="cuda")
+        dw = ops.gemm(dy, x, trans_a=True, trans_b=False, split_k=8)
+        assert torch.allclose(dw.double(), dy.bfloat16().double().t() @ x.bfloat16().double(), rtol=1e-5, atol=2e-3)
+    finally:
+        ops.set_matmul_dtype("f32")

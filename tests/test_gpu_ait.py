@@ -241,3 +241,30 @@ def test_train_mode_dropout_runs_and_is_seeded():
     assert torch.equal(y1, y2) and not torch.equal(y1, y3)
     y1.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in t.parameters())
+
+
+def test_transformer_bf16_matmul_mode_vs_fp32_oracle():
+    """BASELINE cfg 5 arithmetic: AIT GEMM operands rounded to bf16 (fp32 accumulate, fp32
+    LayerNorm / softmax / attention tiles).  Stated tolerance against the fp32 oracle: relative
+    L2 error <= 1e-2 on the output and <= 5e-2 on the input gradients (bf16 has 8 significand
+    bits; measured on MI355X: 3.4e-3 / 3.2e-2 / 2.2e-2)."""
+    from ait_amd import ops
+    sd = ait_ref.make_ait_state_dict(seed=3)
+    t = _transformer(3).eval()
+    xp0, xq0, cot0 = seeded(301, (6, 1024, 7, 7)), seeded(302, (2, 1024, 8, 8)), seeded(303, (6, 1024, 8, 8))
+    a = torch.from_numpy(xp0).requires_grad_(True)
+    b = torch.from_numpy(xq0).requires_grad_(True)
+    ref = ait_ref.transformer_forward(sd, a, b)
+    ga, gb = torch.autograd.grad(ref, [a, b], torch.from_numpy(cot0))
+    ops.set_matmul_dtype("bf16")
+    try:
+        A, B = _dev(xp0).requires_grad_(True), _dev(xq0).requires_grad_(True)
+        y = t(x_props=A, x_query=B)
+        GA, GB = torch.autograd.grad(y, [A, B], _dev(cot0))
+    finally:
+        ops.set_matmul_dtype("f32")
+    rel = lambda got, want: float((got.detach().cpu() - want.detach()).norm() / want.detach().norm())
+    errs = (rel(y, ref), rel(GA, ga), rel(GB, gb))
+    print("bf16-mode relative L2 errors (y, d x_props, d x_query):", errs)
+    assert errs[0] < 1e-2 and errs[1] < 5e-2 and errs[2] < 5e-2, errs
+    assert errs[0] > 1e-5          # the switch really changed the arithmetic

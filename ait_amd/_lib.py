@@ -32,6 +32,8 @@ SIGNATURES = {
                           _i, ctypes.c_longlong, _vp]),
     "ait_gemm_bf16": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
                            _i, ctypes.c_longlong, _vp]),
+    "ait_gemm_bf16x3": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
+                             _i, ctypes.c_longlong, _vp]),
     "ait_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp, _vp, _vp]),
     "ait_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _ull, _vp, _vp,
                         _vp, _vp, _vp]),

@@ -20,11 +20,23 @@ using namespace ait_gemm;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 256, BN = 128, BK = 32, WM = 4, WN = 2;
-constexpr int NT = 64 * WM * WN;            // 512 threads
-constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+constexpr int BK = 32;
 constexpr int ROWB = BK * 2;                // bytes per LDS row
-constexpr size_t LDS_BYTES = 2 * (BM + BN) * ROWB;
+
+// SPLIT = false: plain bf16 operands (cfg-5 arithmetic).
+// SPLIT = true : "bf16x3" -- every fp32 operand x is staged as hi = bf16(x) and lo = bf16(x - hi)
+//   and each product is formed as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the bf16 matrix cores with
+//   fp32 accumulation: the dropped lo*lo term and the residuals are <= ~3*2^-18 relative per
+//   product, i.e. fp32-class accuracy at 3/16 of the fp32 MFMA cost.  EXPERIMENTAL, opt-in.
+template <int BM_, int BN_, int WM_, int WN_, bool SPLIT_>
+struct BCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr bool SPLIT = SPLIT_;
+  static constexpr int NT = 64 * WM * WN;
+  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static constexpr int PARTS = SPLIT ? 2 : 1;
+  static constexpr size_t LDS_BYTES = (size_t)2 * PARTS * (BM + BN) * ROWB;
+};
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset of a 16-B chunk
   return row * ROWB + ((chunk ^ ((row >> 2) & 3)) << 4);
@@ -32,7 +44,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset of
 
 // ---- staging: global fp32 -> registers (raw) -> bf16 -> LDS -----------------------------------
 // KCONTIG: item = (row, chunk of 8 k): 2 float4.   !KCONTIG: item = (4 rows, 4 k): 4 float4.
-template <bool KCONTIG, int ROWS>
+template <bool KCONTIG, int ROWS, int NT, bool SPLIT>
 struct Stage {
   static constexpr int ITEMS = KCONTIG ? ROWS * 4 : (ROWS / 4) * 8;
   static constexpr int PER = (ITEMS + NT - 1) / NT;
@@ -76,38 +88,54 @@ struct Stage {
     }
   }
 
-  __device__ __forceinline__ void store(char* __restrict__ lds) const {
+  static __device__ __forceinline__ __bf16 lo_part(float x, __bf16 hi) { return (__bf16)(x - (float)hi); }
+
+  // hi image at `lds`, lo image (SPLIT only) `lo_off` bytes further
+  __device__ __forceinline__ void store(char* __restrict__ lds, int lo_off) const {
 #pragma unroll
     for (int i = 0; i < PER; i++) {
       const int e = threadIdx.x + i * NT;
       if (e >= ITEMS) continue;
       if (KCONTIG) {
         const int row = e >> 2, c = e & 3;
-        bf16x8 o;
-        o[0] = (__bf16)v[i][0].x; o[1] = (__bf16)v[i][0].y; o[2] = (__bf16)v[i][0].z; o[3] = (__bf16)v[i][0].w;
-        o[4] = (__bf16)v[i][1].x; o[5] = (__bf16)v[i][1].y; o[6] = (__bf16)v[i][1].z; o[7] = (__bf16)v[i][1].w;
+        const float f[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
+        bf16x8 o, l;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          o[q] = (__bf16)f[q];
+          if (SPLIT) l[q] = lo_part(f[q], o[q]);
+        }
         *reinterpret_cast<bf16x8*>(lds + lds_off(row, c)) = o;
+        if (SPLIT) *reinterpret_cast<bf16x8*>(lds + lo_off + lds_off(row, c)) = l;
       } else {
         const int rq = e % (ROWS / 4), c8 = e / (ROWS / 4);
         const float* f = reinterpret_cast<const float*>(&v[i][0]);   // f[q*4 + j] = (k = c8*4+q, row rq*4+j)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          bf16x4 o;
-          o[0] = (__bf16)f[0 * 4 + j]; o[1] = (__bf16)f[1 * 4 + j];
-          o[2] = (__bf16)f[2 * 4 + j]; o[3] = (__bf16)f[3 * 4 + j];
+          bf16x4 o, l;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            o[q] = (__bf16)f[q * 4 + j];
+            if (SPLIT) l[q] = lo_part(f[q * 4 + j], o[q]);
+          }
           const int row = rq * 4 + j;
-          *reinterpret_cast<bf16x4*>(lds + lds_off(row, c8 >> 1) + (c8 & 1) * 8) = o;
+          const int off = lds_off(row, c8 >> 1) + (c8 & 1) * 8;
+          *reinterpret_cast<bf16x4*>(lds + off) = o;
+          if (SPLIT) *reinterpret_cast<bf16x4*>(lds + lo_off + off) = l;
         }
       }
     }
   }
 };
 
-template <bool AK, bool BKC, int EPI>
-__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
+template <class C, bool AK, bool BKC, int EPI>
+__global__ __launch_bounds__(C::NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
+  constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, WN = C::WN;
+  constexpr int A_IMG = BM * ROWB, B_IMG = BN * ROWB;            // bytes of one (hi or lo) image
+  constexpr int A_BUF = A_IMG * C::PARTS, B_BUF = B_IMG * C::PARTS;
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* As = lds;                          // [2][BM][64 B]
-  char* Bs = lds + 2 * BM * ROWB;          // [2][BN][64 B]
+  char* As = lds;                          // [2 buffers][hi | lo][BM][64 B]
+  char* Bs = lds + 2 * A_BUF;              // [2 buffers][hi | lo][BN][64 B]
 
   const int tiles_n = (g.N + BN - 1) / BN;
   const int tiles_m = (g.M + BM - 1) / BM;
@@ -148,12 +176,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-  Stage<AK, BM> sa;
-  Stage<BKC, BN> sb;
+  Stage<AK, BM, C::NT, C::SPLIT> sa;
+  Stage<BKC, BN, C::NT, C::SPLIT> sb;
   sa.load(g.A, g.lda, m0, g.M, kbeg, kend);
   sb.load(g.B, g.ldb, n0, g.N, kbeg, kend);
-  sa.store(As);
-  sb.store(Bs);
+  sa.store(As, A_IMG);
+  sb.store(Bs, B_IMG);
   __syncthreads();
 
   int cur = 0;
@@ -163,26 +191,37 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
       sa.load(g.A, g.lda, m0, g.M, k0 + BK, kend);
       sb.load(g.B, g.ldb, n0, g.N, k0 + BK, kend);
     }
-    const char* as = As + cur * BM * ROWB;
-    const char* bs = Bs + cur * BN * ROWB;
+    const char* as = As + cur * A_BUF;
+    const char* bs = Bs + cur * B_BUF;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
-      bf16x8 av[TM], bv[TN];
+      bf16x8 av[TM], bv[TN], al[TM], bl[TN];
+#pragma unroll
+      for (int a = 0; a < TM; a++) {
+        const int off = lds_off(wm + a * 32 + li, ks * 2 + lk);
+        av[a] = *reinterpret_cast<const bf16x8*>(as + off);
+        if (C::SPLIT) al[a] = *reinterpret_cast<const bf16x8*>(as + A_IMG + off);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; b++) {
+        const int off = lds_off(wn + b * 32 + li, ks * 2 + lk);
+        bv[b] = *reinterpret_cast<const bf16x8*>(bs + off);
+        if (C::SPLIT) bl[b] = *reinterpret_cast<const bf16x8*>(bs + B_IMG + off);
+      }
 #pragma unroll
       for (int a = 0; a < TM; a++)
-        av[a] = *reinterpret_cast<const bf16x8*>(as + lds_off(wm + a * 32 + li, ks * 2 + lk));
 #pragma unroll
-      for (int b = 0; b < TN; b++)
-        bv[b] = *reinterpret_cast<const bf16x8*>(bs + lds_off(wn + b * 32 + li, ks * 2 + lk));
-#pragma unroll
-      for (int a = 0; a < TM; a++)
-#pragma unroll
-        for (int b = 0; b < TN; b++)
+        for (int b = 0; b < TN; b++) {
+          if (C::SPLIT) {   // small cross terms first, the dominant hi*hi term last
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bv[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bl[b], acc[a][b], 0, 0, 0);
+          }
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
     }
     if (more) {
-      sa.store(As + (cur ^ 1) * BM * ROWB);
-      sb.store(Bs + (cur ^ 1) * BN * ROWB);
+      sa.store(As + (cur ^ 1) * A_BUF, A_IMG);
+      sb.store(Bs + (cur ^ 1) * B_BUF, B_IMG);
     }
     __syncthreads();
     cur ^= 1;
@@ -190,10 +229,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
   epilogue<TM, TN, EPI>(acc, g, m0, n0, wm, wn, li, lk);
 }
 
-template <bool AK, bool BKC, int EPI>
+template <class C, bool AK, bool BKC, int EPI>
 int launch_bf16(const GemmArgs& g, hipStream_t s) {
-  const int tiles_n = (g.N + BN - 1) / BN;
-  const int tiles_m = (g.M + BM - 1) / BM;
+  const int tiles_n = (g.N + C::BN - 1) / C::BN;
+  const int tiles_m = (g.M + C::BM - 1) / C::BM;
   unsigned blocks;
   if (g.splits == 1) {
     blocks = (unsigned)((tiles_m * tiles_n + AIT_NXCD - 1) / AIT_NXCD * AIT_NXCD);
@@ -201,17 +240,46 @@ int launch_bf16(const GemmArgs& g, hipStream_t s) {
     const int per_xcd = (g.splits + AIT_NXCD - 1) / AIT_NXCD;
     blocks = (unsigned)(per_xcd * AIT_NXCD * tiles_m * tiles_n);
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<AK, BKC, EPI>), dim3(blocks), dim3(NT), LDS_BYTES, s, g);
+  auto kern = gemm_bf16_kernel<C, AK, BKC, EPI>;
+  if (C::LDS_BYTES > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(C::NT), C::LDS_BYTES, s, g);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }
 
-template <int EPI>
+template <class C, int EPI>
+int dispatch_layout_bf16(const GemmArgs& g, bool ak, bool bk, hipStream_t s) {
+  if (ak && bk) return launch_bf16<C, true, true, EPI>(g, s);
+  if (ak && !bk) return launch_bf16<C, true, false, EPI>(g, s);
+  if (!ak && bk) return launch_bf16<C, false, true, EPI>(g, s);
+  return launch_bf16<C, false, false, EPI>(g, s);
+}
+
+template <class C>
 int dispatch_bf16(const GemmArgs& g, bool ak, bool bk, hipStream_t s) {
-  if (ak && bk) return launch_bf16<true, true, EPI>(g, s);
-  if (ak && !bk) return launch_bf16<true, false, EPI>(g, s);
-  if (!ak && bk) return launch_bf16<false, true, EPI>(g, s);
-  return launch_bf16<false, false, EPI>(g, s);
+  if (g.flags & AIT_GEMM_ATOMIC) return dispatch_layout_bf16<C, EPI_ATOMIC>(g, ak, bk, s);
+  if (g.residual || (g.flags & (AIT_GEMM_ACCUMULATE | AIT_GEMM_MASK_POS)))
+    return dispatch_layout_bf16<C, EPI_AUX>(g, ak, bk, s);
+  return dispatch_layout_bf16<C, EPI_STORE>(g, ak, bk, s);
+}
+
+using Bf16Tile = BCfg<256, 128, 4, 2, false>;
+using SplitTile = BCfg<128, 128, 2, 2, true>;     // hi+lo images: 64 KB of LDS per workgroup
+
+int run_gemm(bool split3, int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
+             int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
+             const float* residual, int flags, int split_k, int c_colblk, long long c_batch_stride,
+             void* stream) {
+  if (M == 0 || N == 0) return (M < 0 || N < 0 || K < 0) ? AIT_EINVAL : AIT_OK;
+  GemmArgs g;
+  const int rc = make_args(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
+                           flags, split_k, c_colblk, c_batch_stride, BK, g);
+  if (rc != AIT_OK) return rc;
+  hipStream_t s = ait_stream(stream);
+  if (split3) return dispatch_bf16<SplitTile>(g, !trans_a, trans_b != 0, s);
+  return dispatch_bf16<Bf16Tile>(g, !trans_a, trans_b != 0, s);
 }
 
 }  // namespace
@@ -220,15 +288,14 @@ AIT_API int ait_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, float a
                           const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                           const float* bias, const float* residual, int flags, int split_k,
                           int c_colblk, long long c_batch_stride, void* stream) {
-  if (M == 0 || N == 0) return (M < 0 || N < 0 || K < 0) ? AIT_EINVAL : AIT_OK;
-  GemmArgs g;
-  const int rc = make_args(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
-                           flags, split_k, c_colblk, c_batch_stride, BK, g);
-  if (rc != AIT_OK) return rc;
-  hipStream_t s = ait_stream(stream);
-  const bool ak = !trans_a, bk = trans_b != 0;
-  if (g.flags & AIT_GEMM_ATOMIC) return dispatch_bf16<EPI_ATOMIC>(g, ak, bk, s);
-  if (g.residual || (g.flags & (AIT_GEMM_ACCUMULATE | AIT_GEMM_MASK_POS)))
-    return dispatch_bf16<EPI_AUX>(g, ak, bk, s);
-  return dispatch_bf16<EPI_STORE>(g, ak, bk, s);
+  return run_gemm(false, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
+                  flags, split_k, c_colblk, c_batch_stride, stream);
+}
+
+AIT_API int ait_gemm_bf16x3(int trans_a, int trans_b, int M, int N, int K, float alpha,
+                            const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                            const float* bias, const float* residual, int flags, int split_k,
+                            int c_colblk, long long c_batch_stride, void* stream) {
+  return run_gemm(true, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
+                  flags, split_k, c_colblk, c_batch_stride, stream);
 }

@@ -12,19 +12,20 @@ def _p(t, dtype=torch.float32):
 
 # "f32": exact fp32 products on v_mfma_f32_32x32x2_f32 (default, the parity / headline path).
 # "bf16": operands rounded to bf16 on the fly, v_mfma_f32_32x32x16_bf16 (BASELINE cfg 5 arithmetic).
+# "bf16x3": experimental split-bf16 emulation of fp32 products (3 bf16 MFMAs per product).
 MATMUL_DTYPE = "f32"
 
 
 def set_matmul_dtype(dtype):
     global MATMUL_DTYPE
-    if dtype not in ("f32", "bf16"):
+    if dtype not in ("f32", "bf16", "bf16x3"):
         raise ValueError(dtype)
     MATMUL_DTYPE = dtype
 
 
 def _gemm_fn():
     L = _lib.lib()
-    return L.ait_gemm_bf16 if MATMUL_DTYPE == "bf16" else L.ait_gemm_f32
+    return {"f32": L.ait_gemm_f32, "bf16": L.ait_gemm_bf16, "bf16x3": L.ait_gemm_bf16x3}[MATMUL_DTYPE]
 
 
 # When set to a list, every GEMM launch appends (flops, start_event, end_event) recorded on the

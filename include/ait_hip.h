@@ -129,6 +129,16 @@ int ait_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, float alpha, co
                   const float* residual, int flags, int split_k, int c_colblk,
                   long long c_batch_stride, void* stream);
 
+/* EXPERIMENTAL "bf16x3" variant: every fp32 operand is split into hi = bf16(x), lo = bf16(x - hi)
+ * and each product is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the bf16 matrix cores with fp32
+ * accumulation (<= ~3*2^-18 relative per product): fp32-class accuracy at 3/16 of the fp32 MFMA
+ * cost.  Opt-in only (ait_amd.ops.set_matmul_dtype("bf16x3")); the default and the headline
+ * metric use the exact ait_gemm_f32. */
+int ait_gemm_bf16x3(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
+                    int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
+                    const float* residual, int flags, int split_k, int c_colblk,
+                    long long c_batch_stride, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Row kernels (d_model = 512 only; other widths return AIT_EUNSUPPORTED).
  *

@@ -24,6 +24,8 @@ def timeit(fn, n=20, w=5):
 bp = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1200
 if "bf16" in sys.argv:
     ops.set_matmul_dtype("bf16")
+if "bf16x3" in sys.argv:
+    ops.set_matmul_dtype("bf16x3")
 M = bp * 64
 shapes = [("qkv   NT", M, 1536, 512, False, True), ("proj  NT", M, 512, 512, False, True),
           ("ffn1  NT", M, 2048, 512, False, True), ("ffn2  NT", M, 512, 2048, False, True),

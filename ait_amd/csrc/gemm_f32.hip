@@ -44,6 +44,11 @@ using namespace ait_gemm;
 // 128x128 split-K shapes).
 using Tile256 = Cfg<256, 128, 16, 4, 2, 2, 6>;
 using Tile128 = Cfg<128, 128, 16, 2, 2, 2, 2>;
+// Narrow outputs (the 64-wide SHBlock / fc products): 256x64, same 64x64 per-wave shape, no dead
+// half tile.  Few-tile problems (the bs*64-row query side): 64x64 tiles, 4x the workgroups and a
+// quarter of the serial K loop per workgroup -- those launches are latency, not throughput.
+using TileN64 = Cfg<256, 64, 16, 4, 1, 2, 2>;
+using Tile64 = Cfg<64, 64, 16, 2, 2, 2, 2>;
 }  // namespace
 
 AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha,
@@ -58,6 +63,9 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   // operand "K-contiguous" means the reduction dimension is the fast one in memory:
   //   A: !trans_a  (A is [M,K]);   B: trans_b (B is [N,K])
   const long long tiles256 = (long long)((M + 255) / 256) * ((N + 127) / 128) * g.splits;
+  if (N <= 64 && (long long)((M + 255) / 256) * g.splits >= 128) return dispatch<TileN64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   if (M >= 512 && tiles256 >= 512) return dispatch<Tile256>(g, !trans_a, trans_b != 0, ait_stream(stream));
+  const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * g.splits;
+  if (tiles128 < 128) return dispatch<Tile64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   return dispatch<Tile128>(g, !trans_a, trans_b != 0, ait_stream(stream));
 }

@@ -13,7 +13,9 @@ def _ref(a, b, ta, tb):
 
 @pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 512, 512), (300, 200, 64), (58800 // 8, 512, 1024),
-                                   (64, 64, 2048), (1, 1, 4), (130, 4, 20)])
+                                   (64, 64, 2048), (1, 1, 4), (130, 4, 20),
+                                   (40000, 64, 128),     # 256x64 tile (narrow outputs)
+                                   (33000, 512, 64)])    # 256x128 tile
 def test_gemm_layouts(ta, tb, M, N, K):
     from ait_amd import ops
     torch.manual_seed(M * 7 + N * 3 + K)
@@ -52,6 +54,10 @@ def test_gemm_epilogues():
     x = torch.randn(Mtok, K, device="cuda")
     dw = ops.gemm(dy, x, trans_a=True, trans_b=False, split_k=8)
     assert torch.allclose(dw.double(), dy.double().t() @ x.double(), rtol=1e-5, atol=2e-3)
+    # the same on the 256x64 tile: SHBlock / fc weight gradient, 64 columns, 128 K-splits
+    dy64, x64 = torch.randn(40000, 512, device="cuda"), torch.randn(40000, 64, device="cuda")
+    dw64 = ops.gemm(dy64, x64, trans_a=True, trans_b=False, split_k=128)
+    assert torch.allclose(dw64.double(), dy64.double().t() @ x64.double(), rtol=1e-5, atol=5e-3)
     # column-blocked C: [channel, token] product written into NCHW [p, ch, 64]
     P, CH = 5, 96
     dec = torch.randn(P * 64, K, device="cuda")

@@ -15,6 +15,7 @@ PyTorch-ROCm (MIOpen), as SURVEY.md section 2 scopes them.
         RCNN_loss_bbox, rois_label, c_att = model(image, query, img_info, gt_boxes, num_boxes)
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -30,6 +31,9 @@ from .system import MultiHeadAttention, Transformer, conv2d_1x1
 # ------------------------------------------------------------------------------------------
 # channel block between AIT and layer4
 # ------------------------------------------------------------------------------------------
+_SK_FULL = os.environ.get("AIT_SK_FULL", "0") == "1"
+
+
 class _SkSqSum(torch.autograd.Function):
     """relu(a)^2 + relu(b)^2 (the SKBlock tail as the reference executes it)."""
 
@@ -65,13 +69,22 @@ class SKBlock(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
                 nn.init.constant_(m.bias, 0)
 
-    def forward(self, x):
+    def _branch(self, i, x, stride):
+        conv = self.convs[i][0]
+        if stride == 1:
+            return conv(x)
+        return F.conv2d(x, conv.weight, conv.bias, stride, conv.padding, conv.dilation, conv.groups)
+
+    def forward(self, x, stride=1):
+        """stride = 2 evaluates the block only at the even output positions (see
+        _fasterRCNN.forward: the only consumer, layer4's stride-2 1x1 convolutions, never reads the
+        others); the values at those positions are the same convolution sums."""
         if x.is_cuda and x.dtype == torch.float32 and self.n_state == 2 and x.numel() % 4 == 0:
             # convolutions on MIOpen, then ReLU / square / branch sum in one fused HIP pass
-            return _SkSqSum.apply(self.convs[0][0](x).contiguous(), self.convs[1][0](x).contiguous())
+            return _SkSqSum.apply(self._branch(0, x, stride).contiguous(), self._branch(1, x, stride).contiguous())
         out = None
-        for branch in self.convs:
-            f = branch(x)
+        for i in range(self.n_state):
+            f = F.relu(self._branch(i, x, stride))
             out = f * f if out is None else out + f * f
         return out
 
@@ -82,8 +95,8 @@ class SKNet(nn.Module):
         self.sk_props = SKBlock(channels, reduction)
         self.sk_query = SKBlock(channels, reduction)
 
-    def forward(self, x_props, x_query):
-        return self.sk_props(x_props), self.sk_query(x_query)
+    def forward(self, x_props, x_query, stride=1):
+        return self.sk_props(x_props, stride), self.sk_query(x_query, stride)
 
 
 # ------------------------------------------------------------------------------------------
@@ -232,11 +245,18 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
-        out = bn_act(self.conv1(x), self.bn1)
+    def forward(self, x, subsampled=False):
+        """subsampled=True: `x` already holds only the positions this block's stride-s 1x1
+        convolutions read (x[:, :, ::s, ::s]), so they run at stride 1."""
+        if subsampled:
+            out = bn_act(F.conv2d(x, self.conv1.weight), self.bn1)
+        else:
+            out = bn_act(self.conv1(x), self.bn1)
         out = bn_act(self.conv2(out), self.bn2)
         if self.downsample is None:
             identity = x
+        elif subsampled:
+            identity = bn_act(F.conv2d(x, self.downsample[0].weight), self.downsample[1], relu=False)
         else:
             identity = bn_act(self.downsample[0](x), self.downsample[1], relu=False)
         return bn_act(self.conv3(out), self.bn3, residual=identity)
@@ -369,10 +389,17 @@ class _fasterRCNN(nn.Module):
 
         props_feat = self.RCNN_roi_align(non_img, rois.view(-1, 5))          # [bs*P, 1024, 7, 7]
         props_feat = self.transformer(x_props=props_feat, x_query=non_qry)   # [bs*P, 1024, 8, 8]
-        props_feat, query_feat = self.sk(x_props=props_feat, x_query=non_qry)
+        # layer4 opens with stride-2 1x1 convolutions (Bottleneck.conv1 / downsample,
+        # resnet_sys_transformer_sk_dilat.py:78,482-490): of the SK block's 8x8 output only the 16
+        # even positions are ever read.  SK is position-wise after its convolutions, so it is
+        # evaluated at those positions only (stride 2) and layer4 takes the result at stride 1:
+        # same sums, same gradients (the dead positions receive exactly zero gradient in the
+        # reference), 3/4 of the SK work not done.  AIT_SK_FULL=1 keeps the dead positions.
+        sk_stride = 1 if _SK_FULL else self._top_stride()
+        props_feat, query_feat = self.sk(x_props=props_feat, x_query=non_qry, stride=sk_stride)
         c_att = None
-        props_feat = self._head_to_tail(props_feat)                          # [bs*P, 2048]
-        query_feat = self._head_to_tail(query_feat)                          # [bs, 2048]
+        props_feat = self._head_to_tail(props_feat, subsampled=sk_stride != 1)   # [bs*P, 2048]
+        query_feat = self._head_to_tail(query_feat, subsampled=sk_stride != 1)   # [bs, 2048]
 
         bbox_pred = self.RCNN_bbox_pred(props_feat)
         stack_feat = torch.cat((props_feat.view(bs, num_props, -1),
@@ -453,8 +480,20 @@ class resnet(_fasterRCNN):
             self.RCNN_top.apply(set_bn_eval)
         return self
 
-    def _head_to_tail(self, pool5):
-        return self.RCNN_top(pool5).mean(3).mean(2)
+    def _top_stride(self):
+        b0 = self.RCNN_top[0][0]
+        ok = isinstance(b0, Bottleneck) and b0.conv1.kernel_size == (1, 1) and b0.downsample is not None \
+            and b0.downsample[0].kernel_size == (1, 1) and b0.downsample[0].stride == b0.conv1.stride \
+            and b0.conv1.stride[0] == b0.conv1.stride[1] == 2
+        return 2 if ok else 1
+
+    def _head_to_tail(self, pool5, subsampled=False):
+        if not subsampled:
+            return self.RCNN_top(pool5).mean(3).mean(2)
+        x = pool5
+        for i, blk in enumerate(self.RCNN_top[0]):
+            x = blk(x, subsampled=(i == 0))
+        return x.mean(3).mean(2)
 
 
 class resnet_coco(resnet):

@@ -245,21 +245,54 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x, subsampled=False):
+    def forward(self, x, subsampled=False, out_stride=1):
         """subsampled=True: `x` already holds only the positions this block's stride-s 1x1
-        convolutions read (x[:, :, ::s, ::s]), so they run at stride 1."""
+        convolutions read (x[:, :, ::s, ::s]), so they run at stride 1.
+        out_stride=s: the caller guarantees that this block's output is read ONLY by stride-s 1x1
+        convolutions (the first block of the next stage); the block then produces just those
+        positions -- conv2 runs at stride s (same 3x3 sums at the kept positions), conv3, the
+        frozen BN, the residual and the ReLU are position-wise."""
         if subsampled:
             out = bn_act(F.conv2d(x, self.conv1.weight), self.bn1)
         else:
             out = bn_act(self.conv1(x), self.bn1)
-        out = bn_act(self.conv2(out), self.bn2)
+        if out_stride == 1:
+            out = bn_act(self.conv2(out), self.bn2)
+        else:
+            out = bn_act(F.conv2d(out, self.conv2.weight, None, out_stride, self.conv2.padding), self.bn2)
         if self.downsample is None:
-            identity = x
+            identity = x if out_stride == 1 else x[:, :, ::out_stride, ::out_stride].contiguous()
+        elif out_stride != 1:
+            raise ValueError("out_stride needs an identity shortcut")
         elif subsampled:
             identity = bn_act(F.conv2d(x, self.downsample[0].weight), self.downsample[1], relu=False)
         else:
             identity = bn_act(self.downsample[0](x), self.downsample[1], relu=False)
         return bn_act(self.conv3(out), self.bn3, residual=identity)
+
+
+def _opens_with_stride2_1x1(stage):
+    b0 = stage[0]
+    return isinstance(b0, Bottleneck) and b0.conv1.kernel_size == (1, 1) and b0.downsample is not None \
+        and b0.downsample[0].kernel_size == (1, 1) and b0.downsample[0].stride == b0.conv1.stride \
+        and b0.conv1.stride == (2, 2)
+
+
+def run_stages(stages, x):
+    """layer_k(...layer_1(x)) for consecutive ResNet stages.  Where stage k+1 opens with stride-2
+    1x1 convolutions (Bottleneck.conv1 / downsample, resnet_sys_transformer_sk_dilat.py:78), three
+    quarters of stage k's last block output is never read: that block then computes only the
+    positions that are (see Bottleneck.forward).  Same values and gradients as the plain
+    composition; AIT_SK_FULL=1 restores it."""
+    subsampled = False
+    for k, stage in enumerate(stages):
+        nxt = stages[k + 1] if k + 1 < len(stages) else None
+        skip = (not _SK_FULL) and nxt is not None and _opens_with_stride2_1x1(nxt) \
+            and isinstance(stage[-1], Bottleneck) and stage[-1].downsample is None and len(stage) > 1
+        for i, blk in enumerate(stage):
+            x = blk(x, subsampled=(subsampled and i == 0), out_stride=2 if (skip and i == len(stage) - 1) else 1)
+        subsampled = skip
+    return x
 
 
 class ResNet(nn.Module):
@@ -327,7 +360,7 @@ class RCNNBackbone(nn.Module):
 
     def forward(self, x):
         x = self.stem[3](bn_act(self.stem[0](x), self.stem[1]))        # conv1, bn1+relu, maxpool
-        return self.layer3(self.layer2(self.layer1(x))), None
+        return run_stages([self.layer1, self.layer2, self.layer3], x), None
 
 
 # ------------------------------------------------------------------------------------------
@@ -481,11 +514,7 @@ class resnet(_fasterRCNN):
         return self
 
     def _top_stride(self):
-        b0 = self.RCNN_top[0][0]
-        ok = isinstance(b0, Bottleneck) and b0.conv1.kernel_size == (1, 1) and b0.downsample is not None \
-            and b0.downsample[0].kernel_size == (1, 1) and b0.downsample[0].stride == b0.conv1.stride \
-            and b0.conv1.stride[0] == b0.conv1.stride[1] == 2
-        return 2 if ok else 1
+        return 2 if _opens_with_stride2_1x1(self.RCNN_top[0]) else 1
 
     def _head_to_tail(self, pool5, subsampled=False):
         if not subsampled:

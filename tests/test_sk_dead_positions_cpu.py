@@ -30,3 +30,23 @@ def test_stride2_sk_equals_full_sk_through_layer4():
         assert (a is None) == (b is None)
         if a is not None:
             assert (a - b).abs().max() <= 1e-11 * max(1.0, float(a.abs().max()))
+
+
+def test_backbone_stage_boundaries_skip_dead_positions_exactly():
+    """run_stages: the last block of layer1 / layer2 computes only what layer2[0] / layer3[0] read."""
+    from ait_amd import faster_rcnn as fr
+    torch.manual_seed(1)
+    net = fr.resnet50().double().eval()
+    for p in net.parameters():
+        p.requires_grad_(True)
+    x = torch.randn(2, 64, 19, 31, dtype=torch.float64, requires_grad=True)      # odd sizes on purpose
+    stages = [net.layer1, net.layer2, net.layer3]
+    params = [p for st in stages for p in st.parameters() if p.dim() == 4]
+    y_ref = net.layer3(net.layer2(net.layer1(x)))
+    cot = torch.randn_like(y_ref)
+    g_ref = torch.autograd.grad(y_ref, [x] + params, cot)
+    y = fr.run_stages(stages, x)
+    g = torch.autograd.grad(y, [x] + params, cot)
+    assert y.shape == y_ref.shape and (y - y_ref).abs().max() < 1e-12 * y_ref.abs().max()
+    for a, b in zip(g, g_ref):
+        assert (a - b).abs().max() <= 1e-11 * max(1.0, float(b.abs().max()))

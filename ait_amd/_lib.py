@@ -75,14 +75,17 @@ def check(rc: int, what: str):
         raise AitHipError("%s failed: %s (%d)" % (what, lib().ait_strerror(rc).decode(), rc))
 
 
-def dev_ptr(t: torch.Tensor, dtype=torch.float32):
-    """data_ptr of a contiguous GPU tensor of the given dtype (else raise)."""
+def dev_ptr(t: torch.Tensor, dtype=torch.float32, dense_any_format=False):
+    """data_ptr of a contiguous GPU tensor of the given dtype (else raise).  dense_any_format
+    also accepts a channels-last-contiguous 4-d tensor (elementwise kernels that take the memory
+    order from their (n, C, HW) arguments)."""
     if not t.is_cuda:
         raise AitHipError("tensor must live on a GPU (got %s): the hot path has no CPU fallback"
                           % t.device)
     if t.dtype != dtype:
         raise AitHipError("expected %s, got %s" % (dtype, t.dtype))
-    if not t.is_contiguous():
+    if not t.is_contiguous() and not (dense_any_format and t.dim() == 4
+                                      and t.is_contiguous(memory_format=torch.channels_last)):
         raise AitHipError("tensor must be contiguous")
     return ctypes.c_void_p(t.data_ptr())
 

@@ -13,25 +13,37 @@ namespace {
 
 constexpr int kThreads = 256;
 
-template <bool VEC>
+// MODE 0: scalar (any shape); 1: NCHW planes with HW % 4 == 0 (a float4 shares one channel);
+// 2: channels-last rows (HW == 1, C % 4 == 0: a float4 covers four consecutive channels)
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void bn_act_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ res, int relu, long long total, int C, int HW, float* __restrict__ y) {
   const long long stride = (long long)gridDim.x * kThreads * 4;
   for (long long i = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4; i < total; i += stride) {
     float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
-    if (VEC) {
+    if (MODE != 0) {
       const float4 a = *reinterpret_cast<const float4*>(x + i);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
       if (res) {
         const float4 b = *reinterpret_cast<const float4*>(res + i);
         r[0] = b.x; r[1] = b.y; r[2] = b.z; r[3] = b.w;
       }
-      const int c = (int)((i / HW) % C);
-      const float s = scale[c], t = shift[c];
+      float s[4], t[4];
+      if (MODE == 1) {
+        const int c = (int)((i / HW) % C);
+        s[0] = s[1] = s[2] = s[3] = scale[c];
+        t[0] = t[1] = t[2] = t[3] = shift[c];
+      } else {
+        const int c = (int)(i % C);
+        const float4 s4 = *reinterpret_cast<const float4*>(scale + c);
+        const float4 t4 = *reinterpret_cast<const float4*>(shift + c);
+        s[0] = s4.x; s[1] = s4.y; s[2] = s4.z; s[3] = s4.w;
+        t[0] = t4.x; t[1] = t4.y; t[2] = t4.z; t[3] = t4.w;
+      }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        v[k] = v[k] * s + t + r[k];
+        v[k] = v[k] * s[k] + t[k] + r[k];
         if (relu) v[k] = fmaxf(v[k], 0.f);
       }
       *reinterpret_cast<float4*>(y + i) = make_float4(v[0], v[1], v[2], v[3]);
@@ -49,13 +61,13 @@ __global__ __launch_bounds__(kThreads) void bn_act_fwd_kernel(
   }
 }
 
-template <bool VEC>
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void bn_act_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ scale,
     int relu, long long total, int C, int HW, float* __restrict__ dx, float* __restrict__ dres) {
   const long long stride = (long long)gridDim.x * kThreads * 4;
   for (long long i = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4; i < total; i += stride) {
-    if (VEC) {
+    if (MODE != 0) {
       const float4 g4 = *reinterpret_cast<const float4*>(dy + i);
       float g[4] = {g4.x, g4.y, g4.z, g4.w};
       if (relu) {
@@ -66,8 +78,13 @@ __global__ __launch_bounds__(kThreads) void bn_act_bwd_kernel(
         g[3] = o.w > 0.f ? g[3] : 0.f;
       }
       if (dres) *reinterpret_cast<float4*>(dres + i) = make_float4(g[0], g[1], g[2], g[3]);
-      const float s = scale[(int)((i / HW) % C)];
-      *reinterpret_cast<float4*>(dx + i) = make_float4(g[0] * s, g[1] * s, g[2] * s, g[3] * s);
+      if (MODE == 1) {
+        const float s = scale[(int)((i / HW) % C)];
+        *reinterpret_cast<float4*>(dx + i) = make_float4(g[0] * s, g[1] * s, g[2] * s, g[3] * s);
+      } else {
+        const float4 s4 = *reinterpret_cast<const float4*>(scale + (int)(i % C));
+        *reinterpret_cast<float4*>(dx + i) = make_float4(g[0] * s4.x, g[1] * s4.y, g[2] * s4.z, g[3] * s4.w);
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -98,12 +115,15 @@ AIT_API int ait_bn_act_fwd(const float* x, const float* scale, const float* shif
   const long long total = n * C * HW;
   if (total == 0) return AIT_OK;
   if (!x || !scale || !shift || !y) return AIT_EINVAL;
-  const bool vec = (HW % 4 == 0) && aligned16(x) && aligned16(y) && (!residual || aligned16(residual));
-  if (vec)
-    hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(grid_for(total)), dim3(kThreads), 0,
+  const bool al = aligned16(x) && aligned16(y) && (!residual || aligned16(residual));
+  if (al && HW % 4 == 0)
+    hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(grid_for(total)), dim3(kThreads), 0,
+                       ait_stream(stream), x, scale, shift, residual, relu, total, C, HW, y);
+  else if (al && HW == 1 && C % 4 == 0 && aligned16(scale) && aligned16(shift))
+    hipLaunchKernelGGL(bn_act_fwd_kernel<2>, dim3(grid_for(total)), dim3(kThreads), 0,
                        ait_stream(stream), x, scale, shift, residual, relu, total, C, HW, y);
   else
-    hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(grid_for(total)), dim3(kThreads), 0,
+    hipLaunchKernelGGL(bn_act_fwd_kernel<0>, dim3(grid_for(total)), dim3(kThreads), 0,
                        ait_stream(stream), x, scale, shift, residual, relu, total, C, HW, y);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
@@ -115,13 +135,15 @@ AIT_API int ait_bn_act_bwd(const float* dy, const float* y, const float* scale, 
   const long long total = n * C * HW;
   if (total == 0) return AIT_OK;
   if (!dy || !scale || !dx || (relu && !y)) return AIT_EINVAL;
-  const bool vec = (HW % 4 == 0) && aligned16(dy) && aligned16(dx) && (!relu || aligned16(y)) &&
-                   (!dres || aligned16(dres));
-  if (vec)
-    hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3(grid_for(total)), dim3(kThreads), 0,
+  const bool al = aligned16(dy) && aligned16(dx) && (!relu || aligned16(y)) && (!dres || aligned16(dres));
+  if (al && HW % 4 == 0)
+    hipLaunchKernelGGL(bn_act_bwd_kernel<1>, dim3(grid_for(total)), dim3(kThreads), 0,
+                       ait_stream(stream), dy, y, scale, relu, total, C, HW, dx, dres);
+  else if (al && HW == 1 && C % 4 == 0 && aligned16(scale))
+    hipLaunchKernelGGL(bn_act_bwd_kernel<2>, dim3(grid_for(total)), dim3(kThreads), 0,
                        ait_stream(stream), dy, y, scale, relu, total, C, HW, dx, dres);
   else
-    hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3(grid_for(total)), dim3(kThreads), 0,
+    hipLaunchKernelGGL(bn_act_bwd_kernel<0>, dim3(grid_for(total)), dim3(kThreads), 0,
                        ait_stream(stream), dy, y, scale, relu, total, C, HW, dx, dres);
   AIT_CHECK_LAUNCH();
   return AIT_OK;

@@ -190,24 +190,43 @@ def attn_bwd(q, qoff, k, koff, v, voff, P, dO, n_seq, H, T, d, scale, p, seed, d
     _lib.check(rc, "ait_attn_bwd")
 
 
-def bn_act_fwd(x, scale, shift, residual, relu):
+def _bn_dims(x):
+    """(n, C, HW) as the kernel sees the memory: NCHW planes, or -- for a channels-last tensor --
+    n*H*W rows of C channels (HW = 1)."""
     n, C = x.shape[0], x.shape[1]
-    HW = x.numel() // max(1, n * C)
+    if x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):
+        return x.numel() // max(1, C), C, 1
+    return n, C, x.numel() // max(1, n * C)
+
+
+def _pd(t):
+    return None if t is None else _lib.dev_ptr(t, torch.float32, dense_any_format=True)
+
+
+def _same_format(x, *others):
+    for t in others:
+        if t is not None and (t.shape != x.shape or t.stride() != x.stride()):
+            raise _lib.AitHipError("bn_act operands must share shape and memory format")
+
+
+def bn_act_fwd(x, scale, shift, residual, relu):
+    n, C, HW = _bn_dims(x)
     y = torch.empty_like(x)
+    _same_format(x, residual, y)
     with torch.cuda.device(x.device):
-        rc = _lib.lib().ait_bn_act_fwd(_p(x), _p(scale), _p(shift), _p(residual), int(relu), n, C, HW,
-                                       _p(y), _lib.cur_stream(x.device))
+        rc = _lib.lib().ait_bn_act_fwd(_pd(x), _p(scale), _p(shift), _pd(residual), int(relu), n, C, HW,
+                                       _pd(y), _lib.cur_stream(x.device))
     _lib.check(rc, "ait_bn_act_fwd")
     return y
 
 
 def bn_act_bwd(dy, y, scale, relu, need_dres):
-    n, C = dy.shape[0], dy.shape[1]
-    HW = dy.numel() // max(1, n * C)
+    n, C, HW = _bn_dims(dy)
     dx = torch.empty_like(dy)
     dres = torch.empty_like(dy) if need_dres else None
+    _same_format(dy, y, dx, dres)
     with torch.cuda.device(dy.device):
-        rc = _lib.lib().ait_bn_act_bwd(_p(dy), _p(y), _p(scale), int(relu), n, C, HW, _p(dx), _p(dres),
+        rc = _lib.lib().ait_bn_act_bwd(_pd(dy), _pd(y), _p(scale), int(relu), n, C, HW, _pd(dx), _pd(dres),
                                        _lib.cur_stream(dy.device))
     _lib.check(rc, "ait_bn_act_bwd")
     return dx, dres
@@ -215,16 +234,18 @@ def bn_act_bwd(dy, y, scale, relu, need_dres):
 
 def sk_sqsum_fwd(a, b):
     y = torch.empty_like(a)
+    _same_format(a, b, y)
     with torch.cuda.device(a.device):
-        rc = _lib.lib().ait_sk_sqsum_fwd(_p(a), _p(b), a.numel(), _p(y), _lib.cur_stream(a.device))
+        rc = _lib.lib().ait_sk_sqsum_fwd(_pd(a), _pd(b), a.numel(), _pd(y), _lib.cur_stream(a.device))
     _lib.check(rc, "ait_sk_sqsum_fwd")
     return y
 
 
 def sk_sqsum_bwd(dy, a, b):
     da, db = torch.empty_like(a), torch.empty_like(b)
+    _same_format(a, b, dy, da, db)
     with torch.cuda.device(a.device):
-        rc = _lib.lib().ait_sk_sqsum_bwd(_p(dy), _p(a), _p(b), a.numel(), _p(da), _p(db),
+        rc = _lib.lib().ait_sk_sqsum_bwd(_pd(dy), _pd(a), _pd(b), a.numel(), _pd(da), _pd(db),
                                          _lib.cur_stream(a.device))
     _lib.check(rc, "ait_sk_sqsum_bwd")
     return da, db

@@ -541,6 +541,7 @@ class Transformer(nn.Module):
                                d_inner=d_inner, n_layers=n_layers, n_head=n_head, d_k=d_k, d_v=d_v,
                                pad_idx=trg_pad_idx, dropout=dropout)
         self.dec_trans = nn.Sequential(conv2d_1x1(d_word_vec, d_word_vec * 2, bias=True))
+        self.channels_last_out = False
         for p in self.parameters():
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
@@ -567,6 +568,12 @@ class Transformer(nn.Module):
         enc, *_ = self.encoder.run_layers(enc, src_mask, n_valid=n_s_eff)  # memory [bp, 49, d]
         dec = self.decoder.prologue(emb_q, bp, n_t, P)              # repeats the query over P
         dec, *_ = self.decoder.run_layers(dec, trg_mask, enc, None if n_s_eff < SEQ else src_mask)
+        if self.channels_last_out:
+            # same [bp, 2d, hq, wq] tensor in channels-last memory: the plain token-major GEMM
+            # output, for a consumer (SK block, layer4) that runs NHWC kernels
+            out = _Linear.apply(dec.reshape(bp * n_t, d), self.dec_trans[0].weight.view(c2, d),
+                                self.dec_trans[0].bias)
+            return out.view(bp, hq, wq, c2).permute(0, 3, 1, 2)
         out = _ToNCHW.apply(dec.reshape(bp * n_t, d), self.dec_trans[0].weight.view(c2, d),
                             self.dec_trans[0].bias, bp, n_t)
         return out.view(bp, c2, hq, wq)

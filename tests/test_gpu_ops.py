@@ -131,7 +131,10 @@ def test_frozen_bn_residual_relu_matches_torch():
     """ait_bn_act_fwd/bwd vs eval-mode BatchNorm2d + add + ReLU in torch (fp32 tolerance 1e-5)."""
     from ait_amd.faster_rcnn import bn_act
     torch.manual_seed(0)
-    for shape in ((3, 16, 4, 4), (2, 8, 75, 125), (1, 5, 7, 9)):     # HW % 4 == 0 and != 0
+    # HW % 4 == 0 and != 0, then the same in channels-last memory (C % 4 == 0 and != 0)
+    for shape, fmt in (((3, 16, 4, 4), torch.contiguous_format), ((2, 8, 75, 125), torch.contiguous_format),
+                       ((1, 5, 7, 9), torch.contiguous_format), ((3, 16, 4, 4), torch.channels_last),
+                       ((2, 6, 5, 3), torch.channels_last)):
         bn = torch.nn.BatchNorm2d(shape[1]).cuda().eval()
         with torch.no_grad():
             bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
@@ -140,9 +143,10 @@ def test_frozen_bn_residual_relu_matches_torch():
             p.requires_grad = False
         for use_res in (False, True):
             for relu in (True, False):
-                x = torch.randn(shape, device="cuda", requires_grad=True)
+                x = torch.randn(shape, device="cuda").contiguous(memory_format=fmt).requires_grad_(True)
                 r = torch.randn(shape, device="cuda", requires_grad=True) if use_res else None
                 y = bn_act(x, bn, residual=r, relu=relu)
+                assert y.is_contiguous(memory_format=fmt)
                 ref = bn(x) + (r if use_res else 0)
                 ref = torch.relu(ref) if relu else ref
                 assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6)

@@ -278,7 +278,8 @@ class Bottleneck(nn.Module):
         else:
             out = bn_act(F.conv2d(out, self.conv2.weight, None, out_stride, self.conv2.padding), self.bn2)
         if self.downsample is None:
-            identity = x if out_stride == 1 else x[:, :, ::out_stride, ::out_stride].contiguous()
+            identity = x if out_stride == 1 else \
+                x[:, :, ::out_stride, ::out_stride].contiguous(memory_format=_fmt(x))
         elif out_stride != 1:
             raise ValueError("out_stride needs an identity shortcut")
         elif subsampled:

@@ -20,6 +20,9 @@ SIGNATURES = {
     "ait_strerror": (ctypes.c_char_p, [_i]),
     "ait_roi_align_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "ait_roi_align_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    "ait_roi_align_nhwc_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ait_roi_align_nhwc_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
+    "ait_roi_align_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
     "ait_nms_workspace_bytes": (_sz, [_i]),
     "ait_nms": (_i, [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
     "ait_nms_batched_workspace_bytes": (_sz, [_i, _i]),

@@ -26,6 +26,7 @@ COMMON = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-I", INCLUDE,
 EXACT = ["-ffp-contract=off"]
 PER_FILE = {
     "roi_align.hip": EXACT,
+    "roi_align_nhwc.hip": EXACT,
     "nms.hip": EXACT,
     "boxes.hip": EXACT,
 }

@@ -1,0 +1,353 @@
+// ait_amd/csrc/roi_align_nhwc.hip -- RoIAlign on channels-last features, token-major output.
+//
+// Same operator as roi_align.hip (lib/model/csrc/cpu/ROIAlign_cpu.cpp:17-219, cuda/ROIAlign_cuda.cu
+// :15-254: scale, PHxPW bins, adaptive ceil(roi/P) sampling grid, no coordinate rounding,
+// out-of-range samples = 0, average), for the memory layout the neighbours of the operator use on
+// MI355X: the feature map arrives as [B, H, W, C] (channels-last; the image-level co-attention
+// emits token rows) and the pooled result is written as [n_rois, PH*PW, C] -- exactly the token
+// rows the AIT's embedding GEMM reads (Models.py:252-256 transposes NCHW into that form; here
+// nothing is transposed).
+//
+// In this layout the operator is a sparse-times-dense product with SCALAR weights per (bin, cell):
+//     out[r, ph, pw, :] = sum_Y sum_X  Wy[r][ph][Y] * Wx[r][pw][X] * F[b_r, Y, X, :]
+// because bilinear interpolation and the sample average are separable per axis.  Wy / Wx are the
+// per-axis interpolation matrices (1/count folded into Wy); a small pre-pass writes them, with the
+// band of non-zero entries of every row, into a caller-owned workspace.  Every feature access is a
+// coalesced C-vector (16 B per lane), weights are wave-uniform.
+//   forward : one workgroup per (roi, ph); each lane owns 4 channels and the PW accumulators of
+//             its bin row; cells at bin borders are re-read from L1.
+//   backward: one workgroup per feature cell (b, Y, X) GATHERS from the RoIs that cover it, in RoI
+//             order -- every cell is written exactly once: no atomics, no zero-fill, bitwise
+//             reproducible (the reference's atomicAdd scatter, ROIAlign_cuda.cu:222-249, is not).
+// Summation order differs from the reference's per-sample order, so results agree to fp32
+// rounding (tests: 1e-5 relative), not bit for bit; the bit-exact NCHW kernels stay the default of
+// the stand-alone operator.
+#include "common.h"
+
+namespace {
+
+constexpr int kPW = 7;          // pooled width/height this file is specialised for (cfg.POOLING_SIZE)
+constexpr int kThreads = 256;
+
+struct Geom {
+  int b, gh, gw;
+  float y0, x0, bh, bw, inv_count;
+};
+
+__device__ __forceinline__ Geom roi_geom(const float* __restrict__ r, float scale, int PH, int PW, int sr) {
+  Geom g;
+  g.b = (int)r[0];
+  const float sw = r[1] * scale, sh = r[2] * scale, ew = r[3] * scale, eh = r[4] * scale;
+  float rw = ew - sw, rh = eh - sh;
+  if (rw < 1.f) rw = 1.f;
+  if (rh < 1.f) rh = 1.f;
+  g.y0 = sh;
+  g.x0 = sw;
+  g.bh = rh / (float)PH;
+  g.bw = rw / (float)PW;
+  g.gh = sr > 0 ? sr : (int)ceilf(rh / (float)PH);
+  g.gw = sr > 0 ? sr : (int)ceilf(rw / (float)PW);
+  g.inv_count = 1.f / (float)(g.gh * g.gw > 0 ? g.gh * g.gw : 1);
+  return g;
+}
+
+// One row of a per-axis interpolation matrix: w[0..L) = sum over the `grid` samples of bin p of the
+// two-tap linear weights (ROIAlign_cpu.cpp:36-95 along one axis).  Returns the non-zero band.
+__device__ __forceinline__ void axis_row(float start, int p, float bin, int grid, int L, float mul,
+                                         float* __restrict__ w, int& lo_out, int& hi_out) {
+  int blo = L, bhi = -1;
+  for (int i = 0; i < grid; i++) {
+    float v = start + (float)p * bin + ((float)i + .5f) * bin / (float)grid;
+    if (v < -1.0f || v > (float)L) continue;
+    if (v <= 0.f) v = 0.f;
+    int lo = (int)v, hi;
+    if (lo >= L - 1) {
+      hi = lo = L - 1;
+      v = (float)lo;
+    } else {
+      hi = lo + 1;
+    }
+    const float wl = v - (float)lo;
+    w[lo] += 1.f - wl;
+    w[hi] += wl;
+    blo = min(blo, lo);
+    bhi = max(bhi, hi);
+  }
+  for (int i = blo; i <= bhi; i++) w[i] *= mul;
+  lo_out = blo;
+  hi_out = bhi;
+}
+
+// workspace layout: floats [n_rois][PH*H + PW*W]  then ints [n_rois][2*PH + 2*PW + 4]
+//   ints: band_y[ph] = (lo, hi), band_x[pw] = (lo, hi), then ymin, ymax, xmin, xmax  (hi < lo: empty)
+__host__ __device__ inline size_t tab_floats(int H, int W, int PH, int PW) { return (size_t)PH * H + (size_t)PW * W; }
+__host__ __device__ inline size_t tab_ints(int PH, int PW) { return 2 * (size_t)PH + 2 * (size_t)PW + 4; }
+
+__global__ __launch_bounds__(64) void roi_tables_kernel(const float* __restrict__ rois, int n_rois, int B,
+                                                        int H, int W, int PH, int PW, float scale, int sr,
+                                                        float* __restrict__ wf, int* __restrict__ wi) {
+  const int n = blockIdx.x;
+  const Geom g = roi_geom(rois + 5 * n, scale, PH, PW, sr);
+  float* __restrict__ wy = wf + (size_t)n * tab_floats(H, W, PH, PW);
+  float* __restrict__ wx = wy + (size_t)PH * H;
+  int* __restrict__ ti = wi + (size_t)n * tab_ints(PH, PW);
+  for (int i = threadIdx.x; i < PH * H + PW * W; i += 64) wy[i] = 0.f;
+  __syncthreads();
+  const bool ok = g.b >= 0 && g.b < B;
+  const int t = threadIdx.x;
+  if (t < PH) {
+    int lo = H, hi = -1;
+    if (ok) axis_row(g.y0, t, g.bh, g.gh, H, g.inv_count, wy + (size_t)t * H, lo, hi);
+    ti[2 * t] = lo;
+    ti[2 * t + 1] = hi;
+  } else if (t >= 32 && t < 32 + PW) {
+    const int p = t - 32;
+    int lo = W, hi = -1;
+    if (ok) axis_row(g.x0, p, g.bw, g.gw, W, 1.f, wx + (size_t)p * W, lo, hi);
+    ti[2 * PH + 2 * p] = lo;
+    ti[2 * PH + 2 * p + 1] = hi;
+  }
+  __syncthreads();
+  if (t == 0) {
+    int ymin = H, ymax = -1, xmin = W, xmax = -1;
+    for (int p = 0; p < PH; p++) {
+      if (ti[2 * p + 1] >= ti[2 * p]) {
+        ymin = min(ymin, ti[2 * p]);
+        ymax = max(ymax, ti[2 * p + 1]);
+      }
+    }
+    for (int p = 0; p < PW; p++) {
+      if (ti[2 * PH + 2 * p + 1] >= ti[2 * PH + 2 * p]) {
+        xmin = min(xmin, ti[2 * PH + 2 * p]);
+        xmax = max(xmax, ti[2 * PH + 2 * p + 1]);
+      }
+    }
+    if (xmax < xmin || ymax < ymin) {   // no valid sample on one axis: the RoI touches nothing
+      ymin = H; ymax = -1; xmin = W; xmax = -1;
+    }
+    int* lim = ti + 2 * PH + 2 * PW;
+    lim[0] = ymin; lim[1] = ymax; lim[2] = xmin; lim[3] = xmax;
+  }
+}
+
+__device__ __forceinline__ float4 fma4(float w, float4 f, float4 a) {
+  a.x = fmaf(w, f.x, a.x);
+  a.y = fmaf(w, f.y, a.y);
+  a.z = fmaf(w, f.z, a.z);
+  a.w = fmaf(w, f.w, a.w);
+  return a;
+}
+
+// XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so give every XCD a contiguous
+// chunk of the work list (the PH rows of one RoI / neighbouring cells share their inputs in one L2).
+__device__ __forceinline__ long long xcd_chunk_id(long long total) {
+  const long long chunk = (total + AIT_NXCD - 1) / AIT_NXCD;
+  const long long id = (long long)(blockIdx.x % AIT_NXCD) * chunk + blockIdx.x / AIT_NXCD;
+  return (blockIdx.x / AIT_NXCD) < chunk && id < total ? id : -1;
+}
+
+__global__ __launch_bounds__(kThreads) void roi_align_nhwc_fwd_kernel(
+    const float* __restrict__ feat, const float* __restrict__ rois, int n_rois, int B, int C, int H, int W,
+    int PH, const float* __restrict__ wf, const int* __restrict__ wi, float* __restrict__ out) {
+  constexpr int PW = kPW;
+  const long long id = xcd_chunk_id((long long)n_rois * PH);
+  if (id < 0) return;
+  const int n = (int)(id / PH), ph = (int)(id % PH);
+  const int C4 = C >> 2;
+  float4* __restrict__ o = reinterpret_cast<float4*>(out) + ((size_t)n * PH + ph) * PW * C4;
+  const int* __restrict__ ti = wi + (size_t)n * tab_ints(PH, PW);
+  const int* lim = ti + 2 * PH + 2 * PW;
+  const int ylo = ti[2 * ph], yhi = ti[2 * ph + 1];
+  const int xmin = lim[2], xmax = lim[3];
+  const int b = (int)rois[5 * n];
+  if (yhi < ylo || xmax < xmin || b < 0 || b >= B) {
+    for (int i = threadIdx.x; i < PW * C4; i += kThreads) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // wy[H] | wx[PW][W]
+  float* s_wy = sm;
+  float* s_wx = sm + H;
+  const float* __restrict__ gwy = wf + (size_t)n * tab_floats(H, W, PH, PW) + (size_t)ph * H;
+  const float* __restrict__ gwx = wf + (size_t)n * tab_floats(H, W, PH, PW) + (size_t)PH * H;
+  for (int i = threadIdx.x; i < H; i += kThreads) s_wy[i] = gwy[i];
+  for (int i = threadIdx.x; i < PW * W; i += kThreads) s_wx[i] = gwx[i];
+  int bx_lo[PW], bx_hi[PW];
+#pragma unroll
+  for (int p = 0; p < PW; p++) {
+    bx_lo[p] = ti[2 * PH + 2 * p];
+    bx_hi[p] = ti[2 * PH + 2 * p + 1];
+  }
+  __syncthreads();
+  const float4* __restrict__ f0 = reinterpret_cast<const float4*>(feat) + (size_t)b * H * W * C4;
+  for (int c4 = threadIdx.x; c4 < C4; c4 += kThreads) {
+    float4 acc[PW];
+#pragma unroll
+    for (int p = 0; p < PW; p++) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int y = ylo; y <= yhi; y++) {
+      const float wyv = s_wy[y];
+      if (wyv == 0.f) continue;
+      const float4* __restrict__ frow = f0 + (size_t)y * W * C4 + c4;
+#pragma unroll
+      for (int p = 0; p < PW; p++) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int x = bx_lo[p]; x <= bx_hi[p]; x++) t = fma4(s_wx[p * W + x], frow[(size_t)x * C4], t);
+        acc[p] = fma4(wyv, t, acc[p]);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PW; p++) o[(size_t)p * C4 + c4] = acc[p];
+  }
+}
+
+// Backward: workgroup = one feature cell.  The RoIs are scanned in chunks of 256 (one per lane);
+// the covering ones are compacted IN ROI ORDER into LDS together with their 2*PW weights for this
+// cell, then every lane accumulates its 4 channels over that list.
+__global__ __launch_bounds__(kThreads) void roi_align_nhwc_bwd_kernel(
+    const float* __restrict__ gout, const float* __restrict__ rois, int n_rois, int B, int C, int H, int W,
+    int PH, const float* __restrict__ wf, const int* __restrict__ wi, float* __restrict__ gin) {
+  constexpr int PW = kPW;
+  const long long id = xcd_chunk_id((long long)B * H * W);
+  if (id < 0) return;
+  const int b = (int)(id / ((long long)H * W));
+  const int yx = (int)(id % ((long long)H * W));
+  const int y = yx / W, x = yx % W;
+  const int C4 = C >> 2;
+  __shared__ int s_roi[kThreads];
+  __shared__ float s_w[kThreads][2 * PW];
+  __shared__ int s_cnt[kThreads / 64 + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NACC = 4;                       // channel groups per lane: C <= 4 * 4 * 256
+  float4 acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; k++) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t tf = tab_floats(H, W, PH, PW);
+  const size_t tint = tab_ints(PH, PW);
+  for (int base = 0; base < n_rois; base += kThreads) {
+    const int r = base + threadIdx.x;
+    bool cov = false;
+    if (r < n_rois && (int)rois[5 * r] == b) {
+      const int* lim = wi + (size_t)r * tint + 2 * PH + 2 * PW;
+      cov = y >= lim[0] && y <= lim[1] && x >= lim[2] && x <= lim[3];
+    }
+    const unsigned long long m = __ballot(cov);
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kThreads / 64; w++) {
+      if (w < wave) off += s_cnt[w];
+      total += s_cnt[w];
+    }
+    if (cov) {
+      const int slot = off + __popcll(m & ((1ull << lane) - 1ull));
+      s_roi[slot] = r;
+      const float* __restrict__ t = wf + (size_t)r * tf;
+#pragma unroll
+      for (int p = 0; p < PW; p++) {
+        s_w[slot][p] = p < PH ? t[(size_t)p * H + y] : 0.f;
+        s_w[slot][PW + p] = t[(size_t)PH * H + (size_t)p * W + x];
+      }
+    }
+    __syncthreads();
+    for (int i = 0; i < total; i++) {
+      const int rr = s_roi[i];
+      const float4* __restrict__ g = reinterpret_cast<const float4*>(gout) + (size_t)rr * PH * PW * C4;
+#pragma unroll
+      for (int p = 0; p < PW; p++) {
+        const float wyv = s_w[i][p];
+        if (p >= PH || wyv == 0.f) continue;
+#pragma unroll
+        for (int q = 0; q < PW; q++) {
+          const float wv = wyv * s_w[i][PW + q];
+          if (wv == 0.f) continue;
+          const float4* __restrict__ gp = g + ((size_t)p * PW + q) * C4;
+#pragma unroll
+          for (int k = 0; k < NACC; k++) {
+            const int c4 = threadIdx.x + k * kThreads;
+            if (c4 < C4) acc[k] = fma4(wv, gp[c4], acc[k]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float4* __restrict__ o = reinterpret_cast<float4*>(gin) + ((size_t)b * H * W + yx) * C4;
+#pragma unroll
+  for (int k = 0; k < NACC; k++) {
+    const int c4 = threadIdx.x + k * kThreads;
+    if (c4 < C4) o[c4] = acc[k];
+  }
+}
+
+inline bool bad(int n_rois, int B, int C, int H, int W, int PH, int PW) {
+  return n_rois < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0;
+}
+
+inline bool unsupported(int C, int PH, int PW) {
+  return PW != kPW || PH > kPW || (C & 3) || C > 4 * 4 * kThreads;
+}
+
+int make_tables(const float* rois, int n_rois, int B, int H, int W, int PH, int PW, float scale, int sr,
+                void* ws, size_t ws_bytes, float*& wf, int*& wi, hipStream_t s) {
+  const size_t need = (size_t)n_rois * (tab_floats(H, W, PH, PW) * sizeof(float) + tab_ints(PH, PW) * sizeof(int));
+  if (!ws || ws_bytes < need) return AIT_EWORKSPACE;
+  wf = static_cast<float*>(ws);
+  wi = reinterpret_cast<int*>(wf + (size_t)n_rois * tab_floats(H, W, PH, PW));
+  hipLaunchKernelGGL(roi_tables_kernel, dim3(n_rois), dim3(64), 0, s, rois, n_rois, B, H, W, PH, PW, scale, sr,
+                     wf, wi);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+inline unsigned chunked_grid(long long total) {
+  return (unsigned)((total + AIT_NXCD - 1) / AIT_NXCD * AIT_NXCD);
+}
+
+}  // namespace
+
+AIT_API size_t ait_roi_align_nhwc_workspace_bytes(int n_rois, int H, int W, int PH, int PW) {
+  if (n_rois <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0) return 0;
+  return (size_t)n_rois * (tab_floats(H, W, PH, PW) * sizeof(float) + tab_ints(PH, PW) * sizeof(int));
+}
+
+AIT_API int ait_roi_align_nhwc_fwd(const float* feat, const float* rois, int n_rois, int B, int C, int H,
+                                   int W, int PH, int PW, float spatial_scale, int sampling_ratio,
+                                   void* workspace, size_t workspace_bytes, float* out, void* stream) {
+  if (bad(n_rois, B, C, H, W, PH, PW)) return AIT_EINVAL;
+  if (unsupported(C, PH, PW)) return AIT_EUNSUPPORTED;
+  if (n_rois == 0) return AIT_OK;
+  if (!feat || !rois || !out) return AIT_EINVAL;
+  hipStream_t s = ait_stream(stream);
+  float* wf;
+  int* wi;
+  const int rc = make_tables(rois, n_rois, B, H, W, PH, PW, spatial_scale, sampling_ratio, workspace,
+                             workspace_bytes, wf, wi, s);
+  if (rc != AIT_OK) return rc;
+  const size_t lds = sizeof(float) * ((size_t)H + (size_t)PW * W);
+  if (lds > 60 * 1024) return AIT_EUNSUPPORTED;
+  hipLaunchKernelGGL(roi_align_nhwc_fwd_kernel, dim3(chunked_grid((long long)n_rois * PH)), dim3(kThreads),
+                     lds, s, feat, rois, n_rois, B, C, H, W, PH, wf, wi, out);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_roi_align_nhwc_bwd(const float* grad_out, const float* rois, int n_rois, int B, int C,
+                                   int H, int W, int PH, int PW, float spatial_scale, int sampling_ratio,
+                                   void* workspace, size_t workspace_bytes, float* grad_in, void* stream) {
+  if (bad(n_rois, B, C, H, W, PH, PW)) return AIT_EINVAL;
+  if (unsupported(C, PH, PW)) return AIT_EUNSUPPORTED;
+  if (!grad_in) return AIT_EINVAL;
+  hipStream_t s = ait_stream(stream);
+  if (n_rois == 0)
+    return hipMemsetAsync(grad_in, 0, sizeof(float) * (size_t)B * H * W * C, s) == hipSuccess ? AIT_OK : AIT_ELAUNCH;
+  if (!grad_out || !rois) return AIT_EINVAL;
+  float* wf;
+  int* wi;
+  const int rc = make_tables(rois, n_rois, B, H, W, PH, PW, spatial_scale, sampling_ratio, workspace,
+                             workspace_bytes, wf, wi, s);
+  if (rc != AIT_OK) return rc;
+  hipLaunchKernelGGL(roi_align_nhwc_bwd_kernel, dim3(chunked_grid((long long)B * H * W)), dim3(kThreads), 0, s,
+                     grad_out, rois, n_rois, B, C, H, W, PH, wf, wi, grad_in);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}

@@ -39,6 +39,9 @@ _SK_FULL = os.environ.get("AIT_SK_FULL", "0") == "1"
 _TOP_NHWC = os.environ.get("AIT_TOP_NHWC", "1") == "1"
 # The C4 trunk likewise (82.5 -> 80.5 ms/step); its output is handed on in NCHW.  AIT_BASE_NHWC=0 keeps NCHW.
 _BASE_NHWC = os.environ.get("AIT_BASE_NHWC", "1") == "1"
+# RoIAlign on channels-last features writing the token rows the AIT embedding reads (no NCHW <->
+# token transposes of the 235 MB pooled tensor, coalesced C-vector taps).  AIT_ROI_NHWC=0: NCHW.
+_ROI_NHWC = os.environ.get("AIT_ROI_NHWC", "1") == "1"
 
 
 def _fmt(x):
@@ -409,7 +412,8 @@ class _fasterRCNN(nn.Module):
         self.RCNN_proposal_target = _ProposalTargetLayer(self.n_classes)
         if cfg.POOLING_MODE != 'align':
             raise NotImplementedError("only POOLING_MODE 'align' is built (every shipped yml uses it)")
-        self.RCNN_roi_align = ROIAlign((cfg.POOLING_SIZE, cfg.POOLING_SIZE), 1.0 / 16.0, 0)
+        self.RCNN_roi_align = ROIAlign((cfg.POOLING_SIZE, cfg.POOLING_SIZE), 1.0 / 16.0, 0,
+                                       channels_last=_ROI_NHWC)
         self.sk = SKNet(channels=C)
         self.transformer = Transformer(d_k=64, d_v=64, d_model=C // 2, d_word_vec=C // 2,
                                        d_inner=C * 2, n_position=8 * 8, n_layers=1, n_head=8,

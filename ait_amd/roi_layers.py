@@ -10,6 +10,7 @@ from torch import nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
+import ctypes
 
 from . import _lib
 
@@ -53,14 +54,77 @@ class _ROIAlign(Function):
 roi_align = _ROIAlign.apply
 
 
+def _nhwc_workspace(n_rois, H, W, ph, pw, device):
+    nbytes = _lib.lib().ait_roi_align_nhwc_workspace_bytes(n_rois, H, W, ph, pw)
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device), int(nbytes)
+
+
+class _ROIAlignChannelsLast(Function):
+    """Same operator, same logical shapes ([B,C,H,W] in, [K,C,ph,pw] out), but computed on
+    channels-last memory by ait_roi_align_nhwc_*: the input is taken as [B,H,W,C] and the result IS
+    the token-major [K, ph*pw, C] matrix (returned as its [K,C,ph,pw] view), so a channels-last
+    producer and a token-major consumer meet without a transpose."""
+
+    @staticmethod
+    def forward(ctx, input, roi, output_size, spatial_scale, sampling_ratio):
+        ph, pw = _pair(output_size)
+        roi = roi.contiguous().float()
+        if roi.dim() != 2 or roi.size(1) != 5:
+            raise ValueError("rois must be [K,5] (batch_index, x1, y1, x2, y2)")
+        _lib.dev_ptr(roi)
+        B, C, H, W = input.shape
+        x = input.contiguous(memory_format=torch.channels_last)
+        K = roi.size(0)
+        out = torch.empty((K, ph, pw, C), dtype=torch.float32, device=input.device)
+        ws, nbytes = _nhwc_workspace(K, H, W, ph, pw, input.device)
+        with torch.cuda.device(input.device):
+            rc = _lib.lib().ait_roi_align_nhwc_fwd(
+                _lib.dev_ptr(x, torch.float32, True), _lib.dev_ptr(roi), K, B, C, H, W, ph, pw,
+                float(spatial_scale), int(sampling_ratio), ctypes.c_void_p(ws.data_ptr()), nbytes,
+                _lib.dev_ptr(out), _lib.cur_stream(input.device))
+        _lib.check(rc, "ait_roi_align_nhwc_fwd")
+        ctx.save_for_backward(roi)
+        ctx.geom = (B, C, H, W, ph, pw, float(spatial_scale), int(sampling_ratio))
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (roi,) = ctx.saved_tensors
+        B, C, H, W, ph, pw, scale, sr = ctx.geom
+        g = grad_output.permute(0, 2, 3, 1).contiguous()          # [K, ph, pw, C]; free for a token-major grad
+        K = roi.size(0)
+        grad_input = torch.empty((B, H, W, C), dtype=torch.float32, device=g.device)
+        ws, nbytes = _nhwc_workspace(K, H, W, ph, pw, g.device)
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().ait_roi_align_nhwc_bwd(
+                _lib.dev_ptr(g), _lib.dev_ptr(roi), K, B, C, H, W, ph, pw, scale, sr,
+                ctypes.c_void_p(ws.data_ptr()), nbytes, _lib.dev_ptr(grad_input), _lib.cur_stream(g.device))
+        _lib.check(rc, "ait_roi_align_nhwc_bwd")
+        return grad_input.permute(0, 3, 1, 2), None, None, None, None
+
+
+def roi_align_channels_last_supported(C, output_size):
+    ph, pw = _pair(output_size)
+    return pw == 7 and ph <= 7 and C % 4 == 0 and C <= 4096
+
+
 class ROIAlign(nn.Module):
-    def __init__(self, output_size, spatial_scale, sampling_ratio):
+    """roi_layers/roi_align.py:49-67.  channels_last=True selects the channels-last / token-major
+    kernels (same values up to fp32 summation order; see include/ait_hip.h); the default is the
+    bit-exact NCHW operator."""
+
+    def __init__(self, output_size, spatial_scale, sampling_ratio, channels_last=False):
         super().__init__()
         self.output_size = output_size
         self.spatial_scale = spatial_scale
         self.sampling_ratio = sampling_ratio
+        self.channels_last = channels_last
 
     def forward(self, input, rois):
+        if self.channels_last and input.is_cuda and roi_align_channels_last_supported(input.size(1), self.output_size):
+            return _ROIAlignChannelsLast.apply(input, rois, self.output_size, self.spatial_scale,
+                                               self.sampling_ratio)
         return roi_align(input, rois, self.output_size, self.spatial_scale, self.sampling_ratio)
 
     def __repr__(self):

@@ -54,6 +54,24 @@ int ait_roi_align_bwd(const float* grad_out, const float* rois, int n_rois, int 
                       int H, int W, int PH, int PW, float spatial_scale, int sampling_ratio,
                       float* grad_in, void* stream);
 
+/* The same operator on CHANNELS-LAST features with a token-major result, for callers that keep
+ * those layouts (ait_amd.faster_rcnn: the co-attention emits token rows, the AIT embedding reads
+ * token rows -- the NCHW<->token transposes of Models.py:252-256 disappear):
+ *   feat [B,H,W,C], out / grad_out [n_rois, PH*PW, C], grad_in [B,H,W,C];  PW == 7, PH <= 7,
+ *   C % 4 == 0 and C <= 4096 (else AIT_EUNSUPPORTED: use the NCHW entry points).
+ * workspace: ait_roi_align_nhwc_workspace_bytes(...) bytes, caller-owned, scratch (per-RoI
+ * per-axis interpolation matrices; rebuilt by every call, nothing is kept between calls).
+ * The result equals the NCHW operator's up to fp32 summation order (separable weights instead of
+ * per-sample sums); the backward gathers per feature cell in RoI order: no atomics, no zero-fill,
+ * bitwise reproducible. */
+size_t ait_roi_align_nhwc_workspace_bytes(int n_rois, int H, int W, int PH, int PW);
+int ait_roi_align_nhwc_fwd(const float* feat, const float* rois, int n_rois, int B, int C, int H,
+                           int W, int PH, int PW, float spatial_scale, int sampling_ratio,
+                           void* workspace, size_t workspace_bytes, float* out, void* stream);
+int ait_roi_align_nhwc_bwd(const float* grad_out, const float* rois, int n_rois, int B, int C,
+                           int H, int W, int PH, int PW, float spatial_scale, int sampling_ratio,
+                           void* workspace, size_t workspace_bytes, float* grad_in, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * NMS.  Replaces model._C.nms (lib/model/csrc/vision.cpp:8, lib/model/csrc/nms.h:10-28)
  * with the CPU reference's semantics (lib/model/csrc/cpu/nms_cpu.cpp:5-65): +1 pixel

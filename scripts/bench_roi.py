@@ -24,3 +24,17 @@ def fb():
 both = timeit(fb)
 fb_bytes = bs * C * 38 * 63 * 4 + bs * P * C * 49 * 4
 print("roi_align fwd %.3f ms (%.2f TB/s algorithmic)  bwd %.3f ms (%.2f TB/s)" % (fwd, fb_bytes / fwd / 1e9, both - fwd, fb_bytes / (both - fwd) / 1e9))
+
+# channels-last / token-major kernels (ait_roi_align_nhwc_*)
+from ait_amd.roi_layers import ROIAlign
+op = ROIAlign((7, 7), 1 / 16., 0, channels_last=True)
+fcl = feat.detach().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+y2 = op(fcl, rois)
+g2 = torch.randn_like(y2)          # channels-last grad, like the one the AIT hands back
+fwd2 = timeit(lambda: op(fcl.detach(), rois))
+def fb2():
+    fcl.grad = None
+    op(fcl, rois).backward(g2)
+both2 = timeit(fb2)
+print("channels-last fwd %.3f ms (%.2f TB/s algorithmic)  bwd %.3f ms (%.2f TB/s)" % (fwd2, fb_bytes / fwd2 / 1e9, both2 - fwd2, fb_bytes / (both2 - fwd2) / 1e9))
+print("max |nhwc - nchw| fwd: %.3e" % float((y2 - y).abs().max()))

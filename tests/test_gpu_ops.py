@@ -46,6 +46,51 @@ def test_roi_align_fwd_bwd_vs_oracle(C, n):
     np.testing.assert_allclose(x.grad.cpu().numpy(), gwant, rtol=1e-4, atol=1e-4)
 
 
+def test_roi_align_channels_last_golden_and_oracle(golden):
+    """ait_roi_align_nhwc_fwd/bwd (channels-last features, token-major result, separable weights):
+    the same operator up to fp32 summation order -- 1e-5 relative against the reference's golden
+    vectors (edge cases: inside, touching borders, < 1 px, whole image, out of range) and against
+    the oracle at C = 1024; the result's memory is the [K, 49, C] token matrix."""
+    from ait_amd.roi_layers import ROIAlign
+    g = golden("g4_roi_align")
+    feat, rois = cases.roi_align_case()
+    op = ROIAlign((7, 7), 1.0 / 16.0, 0, channels_last=True)
+    if feat.shape[1] % 4 == 0:
+        y = op(_dev(feat), _dev(rois))
+        assert y.permute(0, 2, 3, 1).is_contiguous()
+        np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=1e-5, atol=1e-6)
+        y2 = ROIAlign((7, 7), 1.0 / 16.0, 2, channels_last=True)(_dev(feat), _dev(rois)).cpu().numpy()
+        np.testing.assert_allclose(y2, g["y_sr2"], rtol=1e-5, atol=1e-6)
+    feat_r = seeded(402, (2, 8, cases.FEAT_H, cases.FEAT_W))
+    rois_r = cases.random_rois(403, 64, 2)
+    y3 = op(_dev(feat_r), _dev(rois_r)).cpu().numpy()
+    np.testing.assert_allclose(y3, g["y_rand"], rtol=1e-5, atol=1e-6)
+    for C, n in ((1024, 300), (40, 17), (2052, 5)):
+        feat = seeded(7, (2, C, cases.FEAT_H, cases.FEAT_W))
+        rois = cases.random_rois(8, n, 2)
+        x = _dev(feat).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = op(x, _dev(rois))
+        want = native.roi_align_fwd(feat, rois)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+        gr = seeded(9, tuple(y.shape))
+        y.backward(_dev(gr))
+        gwant = native.roi_align_bwd(gr, rois, feat.shape)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), gwant, rtol=1e-4, atol=1e-4)
+        # the gather backward is bitwise reproducible
+        x2 = _dev(feat).requires_grad_(True)
+        op(x2, _dev(rois)).backward(_dev(gr))
+        assert torch.equal(x.grad, x2.grad)
+    small = _dev(seeded(1, (1, 8, 10, 12)))
+    empty = op(small, torch.zeros((0, 5), device="cuda"))
+    assert tuple(empty.shape) == (0, 8, 7, 7)
+    # a batch index outside [0, B): zeros out, no gradient in (as the NCHW operator)
+    xs = small.clone().requires_grad_(True)
+    yb = op(xs, torch.tensor([[3, 0, 0, 50, 50]], dtype=torch.float32, device="cuda"))
+    assert float(yb.abs().sum()) == 0.0
+    yb.backward(torch.ones_like(yb))
+    assert float(xs.grad.abs().sum()) == 0.0
+
+
 def test_roi_align_empty_and_bad_batch_index():
     from ait_amd.roi_layers import roi_align
     feat = _dev(seeded(1, (1, 8, 10, 12)))

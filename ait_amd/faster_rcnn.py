@@ -500,6 +500,13 @@ class _fasterRCNN(nn.Module):
     def create_architecture(self):
         self._init_modules()
         self._init_weights()
+        # convolution weights live in the memory format their activations use, so that MIOpen's
+        # NHWC kernels need no per-call weight re-layout (values, shapes, state_dict unchanged)
+        if _BASE_NHWC:
+            self.RCNN_base.to(memory_format=torch.channels_last)
+        if _TOP_NHWC:
+            self.RCNN_top.to(memory_format=torch.channels_last)
+            self.sk.to(memory_format=torch.channels_last)
 
 
 class resnet(_fasterRCNN):
@@ -549,6 +556,10 @@ class resnet(_fasterRCNN):
             x = x.contiguous(memory_format=torch.channels_last)
         for i, blk in enumerate(self.RCNN_top[0]):
             x = blk(x, subsampled=(i == 0))
+        if _fmt(x) == torch.channels_last:
+            # mean(3).mean(2) of the reference as ONE reduction over the 16 positions of a
+            # channels-last row block (equal group sizes: the same mean, one rounding fewer)
+            return x.permute(0, 2, 3, 1).reshape(x.size(0), -1, x.size(1)).mean(1)
         return x.mean(3).mean(2)
 
 

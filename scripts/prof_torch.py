@@ -23,14 +23,15 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     for _ in range(2): step()
     torch.cuda.synchronize()
 ka = prof.key_averages(group_by_input_shape=True)
-rows = sorted(ka, key=lambda e: -e.self_device_time_total)
-print("== by op + shapes (self device time per step, ms)")
-for e in rows[:70]:
-    print("%8.3f  x%-4d %-38s %s" % (e.self_device_time_total / 2e3, e.count // 2, e.key[:38], str(e.input_shapes)[:110]))
-ks = prof.key_averages(group_by_stack_n=6)
-print("== by stack, elementwise only")
-want = ("aten::add", "aten::copy_", "aten::mul", "aten::sum", "aten::add_", "aten::mul_", "aten::div", "aten::sub", "aten::clone", "aten::contiguous", "aten::cat", "aten::fill_", "aten::zero_")
-rows = sorted((e for e in ks if e.key in want), key=lambda e: -e.self_device_time_total)
-for e in rows[:45]:
-    st = [s for s in e.stack if "ait_amd" in s or "bench" in s or "autograd" in s][:3]
-    print("%8.3f  x%-4d %-14s %s" % (e.self_device_time_total / 2e3, e.count // 2, e.key, " <- ".join(s.split("/")[-1][:60] for s in st)))
+want = ("aten::add", "aten::copy_", "aten::mul", "aten::sum", "aten::add_", "aten::mul_", "aten::div", "aten::sub",
+        "aten::fill_", "aten::zero_", "aten::mean", "aten::cat", "aten::max", "aten::index", "aten::where",
+        "aten::masked_fill_", "aten::_softmax", "aten::clamp", "aten::exp", "aten::sort", "aten::gather",
+        "aten::native_layer_norm", "aten::native_dropout", "aten::bmm", "aten::mm", "aten::addmm",
+        "aten::max_pool2d_with_indices", "aten::max_pool2d_with_indices_backward", "aten::_foreach_add_",
+        "aten::_foreach_mul_", "aten::threshold_backward", "aten::relu", "aten::sigmoid")
+rows = sorted((e for e in ka if e.key.startswith("aten::") and e.self_device_time_total > 0
+               and "convolution" not in e.key), key=lambda e: -e.self_device_time_total)
+tot = sum(e.self_device_time_total for e in rows) / 2e3
+print("== torch ops excluding convolutions: %.2f ms/step" % tot)
+for e in rows[:60]:
+    print("%7.3f ms  x%-3d %-34s %s" % (e.self_device_time_total / 2e3, e.count // 2, e.key[:34], str(e.input_shapes)[:120]))

@@ -25,7 +25,7 @@ from . import ops
 from .config import cfg
 from .roi_layers import ROIAlign
 from .rpn import _ProposalTargetLayer, _RPN, _smooth_l1_loss
-from .system import MultiHeadAttention, Transformer, conv2d_1x1
+from .system import MultiHeadAttention, Transformer, _split_k, conv2d_1x1
 
 
 # ------------------------------------------------------------------------------------------
@@ -222,15 +222,13 @@ class _BnAct(torch.autograd.Function):
         return dx, None, None, dres, None
 
 
-def bn_act(x, bn, residual=None, relu=True):
-    """relu(bn(x) + residual) for a FROZEN BatchNorm2d in eval mode (the only state the reference
-    ever runs its BatchNorms in); anything else goes through torch."""
-    frozen = (not bn.training) and not bn.weight.requires_grad and not bn.bias.requires_grad
-    if not (frozen and x.is_cuda and x.dtype == torch.float32):
-        y = bn(x)
-        if residual is not None:
-            y = y + residual
-        return F.relu(y) if relu else y
+def _bn_frozen(bn):
+    return (not bn.training) and not bn.weight.requires_grad and not bn.bias.requires_grad
+
+
+def _bn_affine(bn):
+    """(scale, shift) of a frozen eval-mode BatchNorm2d: y = x*scale[c] + shift[c]; cached until a
+    buffer or parameter of the module changes."""
     key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
            bn.weight.data_ptr(), bn.running_mean.data_ptr())
     cache = getattr(bn, "_ait_affine", None)
@@ -238,13 +236,97 @@ def bn_act(x, bn, residual=None, relu=True):
         with torch.no_grad():
             scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
             shift = (bn.bias - bn.running_mean * scale).float().contiguous()
-        cache = (key, scale, shift)
+        cache = (key, scale, shift, torch.ones_like(scale))
         bn._ait_affine = cache
+    return cache[1], cache[2], cache[3]
+
+
+def bn_act(x, bn, residual=None, relu=True):
+    """relu(bn(x) + residual) for a FROZEN BatchNorm2d in eval mode (the only state the reference
+    ever runs its BatchNorms in); anything else goes through torch."""
+    if not (_bn_frozen(bn) and x.is_cuda and x.dtype == torch.float32):
+        y = bn(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+    scale, shift, _ = _bn_affine(bn)
     fmt = _fmt(x)
     x = x.contiguous(memory_format=fmt)
     if residual is not None:
         residual = residual.contiguous(memory_format=fmt)
-    return _BnAct.apply(x, cache[1], cache[2], residual, relu)
+    return _BnAct.apply(x, scale, shift, residual, relu)
+
+
+# ------------------------------------------------------------------------------------------
+# 1x1 convolution + frozen BN (+ residual) (+ ReLU) on channels-last activations = ONE GEMM
+# ------------------------------------------------------------------------------------------
+class _Conv1x1BnAct(torch.autograd.Function):
+    """A stride-1 1x1 convolution over a channels-last tensor is the token-major product
+    [N*H*W, Cin] x [Cout, Cin]^T; the frozen BatchNorm's scale is folded into the weight rows and
+    its shift, the residual and the ReLU ride in the GEMM epilogue (ait_gemm_f32).  Backward: one
+    masking pass (dz = dy * [y > 0], which is also the residual's gradient), then the two products
+    dx = dz W' and dW = scale * (dz^T x)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, ones, residual, relu):
+        n, cin, h, w = x.shape
+        cout = weight.shape[0]
+        xm = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)                  # view of channels-last x
+        w2 = weight.reshape(cout, cin) * scale[:, None]
+        rm = None if residual is None else residual.permute(0, 2, 3, 1).reshape(n * h * w, cout)
+        ym = ops.gemm(xm, w2, bias=shift, residual=rm, relu=relu, exact=True)
+        y = ym.view(n, h, w, cout).permute(0, 3, 1, 2)
+        ctx.save_for_backward(xm, w2, scale, ones, y if relu else None)
+        ctx.relu, ctx.has_res, ctx.wshape = relu, residual is not None, weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, w2, scale, ones, y = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        if ctx.relu:
+            dz, _ = ops.bn_act_bwd(dy, y, ones, True, False)               # dy * [y > 0]
+        else:
+            dz = dy
+        n, cout, h, w = dz.shape
+        dzm = dz.permute(0, 2, 3, 1).reshape(n * h * w, cout)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dzm, w2, trans_b=False, exact=True)
+            dx = dx.view(n, h, w, -1).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm(dzm, xm, trans_a=True, trans_b=False, exact=True,
+                          split_k=_split_k(cout, xm.shape[1], xm.shape[0]))
+            dw = (dw * scale[:, None]).view(ctx.wshape)
+        dres = dz if ctx.has_res and ctx.needs_input_grad[5] else None
+        return dx, dw, None, None, None, dres, None
+
+
+# OFF by default: measured on MI355X, MIOpen's NHWC implicit-GEMM assembly kernels beat
+# ait_gemm_f32 on these shapes even with the BN/ReLU pass fused away (bs=4, P=300: 75.9 ms/step
+# without, 78.2 with layer4 only, 81.2 with layer3+4, 82.9 with every 1x1).  Kept as an opt-in
+# (AIT_CONV1X1_GEMM=1, AIT_CONV1X1_MIN_C=<min channels>) and as the parity-tested reference point
+# for the next attempt (tests/test_gpu_ops.py).
+_CONV1X1_GEMM = os.environ.get("AIT_CONV1X1_GEMM", "0") == "1"
+_CONV1X1_MIN_C = int(os.environ.get("AIT_CONV1X1_MIN_C", "512"))
+
+
+def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, stride1=False):
+    """relu(bn(conv(x)) + residual) for a bias-free 1x1 convolution.  `stride1`: run the
+    convolution at stride 1 whatever conv.stride says (the input is already subsampled).
+    Channels-last fp32 GPU activations with a frozen BN take the single-GEMM path above; everything
+    else is conv (MIOpen) + bn_act."""
+    stride = (1, 1) if stride1 else conv.stride
+    if (_CONV1X1_GEMM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _bn_frozen(bn)
+            and conv.kernel_size == (1, 1) and stride == (1, 1) and conv.groups == 1 and conv.bias is None
+            and conv.padding == (0, 0) and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0
+            and min(conv.in_channels, conv.out_channels) >= _CONV1X1_MIN_C
+            and x.is_contiguous(memory_format=torch.channels_last)
+            and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
+        scale, shift, ones = _bn_affine(bn)
+        return _Conv1x1BnAct.apply(x, conv.weight, scale, shift, ones, residual, relu)
+    y = F.conv2d(x, conv.weight, None, stride) if stride1 else conv(x)
+    return bn_act(y, bn, residual=residual, relu=relu)
 
 
 # ------------------------------------------------------------------------------------------
@@ -272,10 +354,7 @@ class Bottleneck(nn.Module):
         convolutions (the first block of the next stage); the block then produces just those
         positions -- conv2 runs at stride s (same 3x3 sums at the kept positions), conv3, the
         frozen BN, the residual and the ReLU are position-wise."""
-        if subsampled:
-            out = bn_act(F.conv2d(x, self.conv1.weight), self.bn1)
-        else:
-            out = bn_act(self.conv1(x), self.bn1)
+        out = conv1x1_bn_act(x, self.conv1, self.bn1, stride1=subsampled)
         if out_stride == 1:
             out = bn_act(self.conv2(out), self.bn2)
         else:
@@ -285,11 +364,9 @@ class Bottleneck(nn.Module):
                 x[:, :, ::out_stride, ::out_stride].contiguous(memory_format=_fmt(x))
         elif out_stride != 1:
             raise ValueError("out_stride needs an identity shortcut")
-        elif subsampled:
-            identity = bn_act(F.conv2d(x, self.downsample[0].weight), self.downsample[1], relu=False)
         else:
-            identity = bn_act(self.downsample[0](x), self.downsample[1], relu=False)
-        return bn_act(self.conv3(out), self.bn3, residual=identity)
+            identity = conv1x1_bn_act(x, self.downsample[0], self.downsample[1], relu=False, stride1=subsampled)
+        return conv1x1_bn_act(out, self.conv3, self.bn3, residual=identity)
 
 
 def _opens_with_stride2_1x1(stage):

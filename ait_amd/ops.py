@@ -23,8 +23,10 @@ def set_matmul_dtype(dtype):
     MATMUL_DTYPE = dtype
 
 
-def _gemm_fn():
+def _gemm_fn(exact=False):
     L = _lib.lib()
+    if exact:
+        return L.ait_gemm_f32
     return {"f32": L.ait_gemm_f32, "bf16": L.ait_gemm_bf16, "bf16x3": L.ait_gemm_bf16x3}[MATMUL_DTYPE]
 
 
@@ -48,11 +50,12 @@ def _profiled(fn, flops, device, tag=None):
 
 def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, relu=False,
          accumulate=False, alpha=1.0, split_k=1, bias_row=False, c_colblk=0, c_batch_stride=0,
-         out_shape=None):
+         out_shape=None, exact=False):
     """out (op)= alpha * op(a) @ op(b) (+bias)(+residual)(relu) on the fp32 matrix cores.
 
     a: [M,K] (or [K,M] if trans_a);  b: [N,K] if trans_b (nn.Linear weight layout) else [K,N].
-    2-D, last dim contiguous; row pitch taken from stride(0).
+    2-D, last dim contiguous; row pitch taken from stride(0).  exact=True pins the launch to the
+    fp32 kernel whatever set_matmul_dtype says (the convolution-side products).
     """
     assert a.dim() == 2 and b.dim() == 2
     if a.stride(1) != 1 or a.stride(0) % 4 or a.stride(0) < a.shape[1]:
@@ -74,7 +77,7 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, 
         | (_lib.GEMM_ACCUMULATE if accumulate and split_k == 1 else 0) \
         | (_lib.GEMM_ATOMIC if split_k > 1 else 0) | (_lib.GEMM_BIAS_ROW if bias_row else 0)
     with torch.cuda.device(a.device):
-        rc = _profiled(lambda: _gemm_fn()(
+        rc = _profiled(lambda: _gemm_fn(exact)(
             int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.dev_ptr(a), a.stride(0),
             _lib.dev_ptr(b), b.stride(0), ctypes.c_void_p(out.data_ptr()), ldc, _p(bias),
             _p(residual), flags, int(split_k), int(c_colblk), int(c_batch_stride),

@@ -201,3 +201,39 @@ def test_frozen_bn_residual_relu_matches_torch():
                 want = torch.autograd.grad(ref, wrt, g)
                 for a, b in zip(got, want):
                     assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_conv1x1_bn_act_gemm_path_matches_torch(monkeypatch):
+    """1x1 conv + frozen BN (+ residual) (+ ReLU) on channels-last activations as ONE ait_gemm_f32
+    launch (scale folded into the weight rows, shift / residual / ReLU in the epilogue) against
+    conv2d + eval BatchNorm + add + relu in torch: forward and all gradients, 1e-5 relative."""
+    from ait_amd import faster_rcnn as fr
+    monkeypatch.setattr(fr, "_CONV1X1_GEMM", True)          # opt-in path (off by default: slower than MIOpen)
+    monkeypatch.setattr(fr, "_CONV1X1_MIN_C", 0)
+    torch.manual_seed(3)
+    for (n, cin, cout, h, w) in ((3, 64, 256, 9, 7), (2, 256, 64, 5, 6), (1200, 512, 2048, 4, 4)):
+        conv = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
+        bn = torch.nn.BatchNorm2d(cout).cuda().eval()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+            bn.running_mean.uniform_(-0.5, 0.5); bn.running_var.uniform_(0.5, 1.5)
+        for p in bn.parameters():
+            p.requires_grad = False
+        for use_res in (False, True):
+            for relu in (True, False):
+                x = torch.randn(n, cin, h, w, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                r = torch.randn(n, cout, h, w, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True) \
+                    if use_res else None
+                y = fr.conv1x1_bn_act(x, conv, bn, residual=r, relu=relu)
+                assert y.grad_fn.__class__.__name__.startswith("_Conv1x1BnAct")
+                ref = bn(conv(x)) + (r if use_res else 0)
+                ref = torch.relu(ref) if relu else ref
+                scale = float(ref.abs().max())
+                assert float((y - ref).abs().max()) <= 1e-5 * scale
+                g = torch.randn_like(ref)
+                wrt = [x, conv.weight] + ([r] if use_res else [])
+                got = torch.autograd.grad(y, wrt, g)
+                want = torch.autograd.grad(ref, wrt, g)
+                for a, b in zip(got, want):
+                    assert a.shape == b.shape
+                    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6

@@ -45,24 +45,37 @@ __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned lo
   return u >= p ? inv_keep : 0.f;
 }
 
-// global [64 rows, pitch ld] (64 contiguous floats per row) -> LDS panel [64][65]
-__device__ __forceinline__ void g2l(const float* __restrict__ g, int ld, float* __restrict__ s,
-                                    int lane) {
-#pragma unroll 8
-  for (int r = 0; r < T; r++) s[r * PITCH + lane] = g[(size_t)r * ld + lane];
-}
-
-// same, for a K/V panel that only has `rows` (<= 64) rows per sequence: the rest reads as zero
-__device__ __forceinline__ void g2l_rows(const float* __restrict__ g, int ld, float* __restrict__ s,
-                                         int lane, int rows) {
-  // loads stay unconditional (clamped row) so the compiler keeps them batched; a per-row branch
-  // around the load serialises 64 global round trips
-#pragma unroll 8
-  for (int r = 0; r < T; r++) {
-    const float v = g[(size_t)min(r, rows - 1) * ld + lane];
-    s[r * PITCH + lane] = r < rows ? v : 0.f;
+// One 64x64 operand panel on its way global -> registers -> LDS [64][65].  All 16 loads of a lane
+// (16 B each: lane = (row & 3, 16-B column chunk), 4 rows per wave-wide load) are issued back to
+// back, so a panel costs ONE memory round trip, and they can be issued long before the panel is
+// needed (the caller runs the previous product in between).  The LDS writes are four ds_write_b32
+// per chunk; with the odd pitch, (row & 3) + 4*chunk + j covers all 64 banks exactly once.
+struct Stage {
+  float4 v[16];
+  // rows >= `rows` (K / V panels of an unpadded memory) read as zero; their loads are clamped to
+  // the last valid row so that nothing is branched around
+  __device__ __forceinline__ void load(const float* __restrict__ g, int ld, int lane, int rows = T) {
+    const int c = (lane & 15) * 4, r0 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int r = min(i * 4 + r0, rows - 1);
+      v[i] = *reinterpret_cast<const float4*>(g + (size_t)r * ld + c);
+    }
   }
-}
+  __device__ __forceinline__ void store(float* __restrict__ s, int lane, int rows = T) const {
+    const int c = (lane & 15) * 4, r0 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int r = i * 4 + r0;
+      const bool live = r < rows;
+      float* __restrict__ d = s + r * PITCH + c;
+      d[0] = live ? v[i].x : 0.f;
+      d[1] = live ? v[i].y : 0.f;
+      d[2] = live ? v[i].z : 0.f;
+      d[3] = live ? v[i].w : 0.f;
+    }
+  }
+};
 
 // acc[a][b] += sum_k L(i,k) * R(k,j) for a 64x64x64 product out of two LDS panels.
 //   LT = false: L(i,k) = Ls[i][k]      LT = true: L(i,k) = Ls[k][i]   (left operand transposed)
@@ -185,8 +198,12 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnArgs g, fl
   const int n = (int)(unit / g.H), h = (int)(unit % g.H);
   float* s0 = lds + wave * 2 * kPanel;
   float* s1 = s0 + kPanel;
-  g2l(g.q + ((size_t)n * T) * g.ldq + h * D, g.ldq, s0, lane);
-  g2l_rows(g.k + ((size_t)n * g.kv_rows) * g.ldk + h * D, g.ldk, s1, lane, g.kv_rows);
+  Stage sq, sk, sv;
+  sq.load(g.q + ((size_t)n * T) * g.ldq + h * D, g.ldq, lane);
+  sk.load(g.k + ((size_t)n * g.kv_rows) * g.ldk + h * D, g.ldk, lane, g.kv_rows);
+  sv.load(g.v + ((size_t)n * g.kv_rows) * g.ldv + h * D, g.ldv, lane, g.kv_rows);   // in flight under S and the softmax
+  sq.store(s0, lane);
+  sk.store(s1, lane, g.kv_rows);
   f32x16 acc[2][2];
   zero(acc);
   mm64<false, true>(s0, s1, acc, lane);  // S = Q K^T
@@ -215,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnArgs g, fl
     });
   }
   acc_to_lds(acc, s0, lane);  // P_drop over the Q panel (this wave's reads of it are done)
-  g2l_rows(g.v + ((size_t)n * g.kv_rows) * g.ldv + h * D, g.ldv, s1, lane, g.kv_rows);
+  sv.store(s1, lane, g.kv_rows);
   zero(acc);
   mm64<false, false>(s0, s1, acc, lane);  // O = P V
   acc_to_global(acc, O + (size_t)unit * T * D, D, lane, 1.f);
@@ -264,13 +281,17 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kernel(const AttnBwdArgs g)
         }
     acc_to_lds(pd, s0, lane);
   }
-  g2l(g.dO + (size_t)unit * T * D, D, s1, lane);
+  Stage st, nx;      // current / next operand panel: the next one's loads fly under the current product
+  st.load(g.dO + (size_t)unit * T * D, D, lane);
+  nx.load(g.f.v + ((size_t)n * g.f.kv_rows) * g.f.ldv + h * D, g.f.ldv, lane, g.f.kv_rows);
+  st.store(s1, lane);
   f32x16 acc[2][2];
   zero(acc);
   mm64<true, false>(s0, s1, acc, lane);  // dV = Pd^T dO
   acc_to_global_rows(acc, g.dv + ((size_t)n * g.f.kv_rows) * g.lddv + h * D, g.lddv, lane, g.f.kv_rows);
   // dPd = dO V^T
-  g2l_rows(g.f.v + ((size_t)n * g.f.kv_rows) * g.f.ldv + h * D, g.f.ldv, s0, lane, g.f.kv_rows);
+  nx.store(s0, lane, g.f.kv_rows);
+  st.load(g.f.k + ((size_t)n * g.f.kv_rows) * g.f.ldk + h * D, g.f.ldk, lane, g.f.kv_rows);
   zero(acc);
   mm64<false, true>(s1, s0, acc, lane);
   // dS = P * (dP - rowsum(dP * P)) with dP = dPd * mask/(1-p);  then the 1/sqrt(dk) scale
@@ -289,11 +310,12 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kernel(const AttnBwdArgs g)
       acc[a][1][r] = prob[a][1][r] * (d1 - dot) * g.f.scale;
     }
   acc_to_lds(acc, s0, lane);  // dS (already scaled)
-  g2l_rows(g.f.k + ((size_t)n * g.f.kv_rows) * g.f.ldk + h * D, g.f.ldk, s1, lane, g.f.kv_rows);
+  st.store(s1, lane, g.f.kv_rows);
+  nx.load(g.f.q + ((size_t)n * T) * g.f.ldq + h * D, g.f.ldq, lane);
   zero(acc);
   mm64<false, false>(s0, s1, acc, lane);  // dQ = dS K
   acc_to_global(acc, g.dq + ((size_t)n * T) * g.lddq + h * D, g.lddq, lane, 1.f);
-  g2l(g.f.q + ((size_t)n * T) * g.f.ldq + h * D, g.f.ldq, s1, lane);
+  nx.store(s1, lane);
   zero(acc);
   mm64<true, false>(s0, s1, acc, lane);  // dK = dS^T Q
   acc_to_global_rows(acc, g.dk + ((size_t)n * g.f.kv_rows) * g.lddk + h * D, g.lddk, lane, g.f.kv_rows);

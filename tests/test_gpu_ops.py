@@ -234,6 +234,8 @@ def test_conv1x1_bn_act_gemm_path_matches_torch(monkeypatch):
                 wrt = [x, conv.weight] + ([r] if use_res else [])
                 got = torch.autograd.grad(y, wrt, g)
                 want = torch.autograd.grad(ref, wrt, g)
+                # relative L2: with ~4e7 outputs a ReLU whose pre-activation sits within rounding
+                # of zero flips its mask bit between the two summation orders (one element of dy)
                 for a, b in zip(got, want):
                     assert a.shape == b.shape
-                    assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6
+                    assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-6

@@ -93,6 +93,42 @@ __device__ __forceinline__ void store_slab(float* __restrict__ s, const float4 (
   }
 }
 
+// ---- OPT bit 4: "row image" for operands whose reduction dimension is contiguous in memory ------
+// Instead of transposing such an operand into the K-major slab (4 x ds_write_b32 per float4, one
+// ds_read_b32 per MFMA operand), its slab is kept as it arrives: [row][BK = 16 floats] = 64-B rows
+// of four 16-B chunks, chunk index XOR ((row >> 2) & 3) (conflict-free ds_write_b128 AND
+// ds_read_b128, same geometry as gemm_bf16.hip).  A lane then fetches FOUR k-steps of one operand
+// tile with one ds_read_b128.  This needs the k order of a slab to be: lane half lk works through
+// k = 8*lk + s for MFMA step s = 0..7 (any order is legal as long as A and B agree; a K-major
+// operand simply reads row 8*lk + s).
+__device__ __forceinline__ int rowimg_off(int row, int chunk) {     // float offset of a 16-B chunk
+  return row * 16 + ((chunk ^ ((row >> 2) & 3)) << 2);
+}
+
+template <int ROWS, int NT, int NV>
+__device__ __forceinline__ void store_rowimg(float* __restrict__ s, const float4 (&v)[NV]) {
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const int e = threadIdx.x + i * NT;
+    *reinterpret_cast<float4*>(s + rowimg_off(e >> 2, e & 3)) = v[i];
+  }
+}
+
+// operands of k-step group g (4 MFMA steps) of one slab for TILES 32-row tiles starting at row0
+template <bool ROWIMG, int TILES, int PITCH>
+__device__ __forceinline__ void fetch_group(const float* __restrict__ slab, int row0, int li, int lk, int g,
+                                            float4 (&x)[TILES]) {
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    if (ROWIMG) {
+      x[t] = *reinterpret_cast<const float4*>(slab + rowimg_off(row0 + t * 32 + li, 2 * lk + g));
+    } else {
+      const float* p = slab + (8 * lk + 4 * g) * PITCH + row0 + t * 32 + li;
+      x[t] = make_float4(p[0], p[PITCH], p[2 * PITCH], p[3 * PITCH]);
+    }
+  }
+}
+
 // AK / BKC: true when that operand is stored with the reduction dimension contiguous.
 //   forward  y = x W^T   : A = x [M,K] (AK), B = W [N,K] (BKC)
 //   dgrad    dx = dy W   : A = dy [M,K'] (AK), B = W [K',N] (!BKC)
@@ -223,7 +259,68 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
 
   float4 ra[C::VA], rb[C::VB];
   float av[C::TM], bv[C::TN];
-  if constexpr (C::NBUF == 3) {
+  if constexpr (C::NBUF == 3 && (C::OPT & 16) != 0 && (AK || BKC)) {
+    // ---- three-slab ring with row images for the K-contiguous operand(s) and operands fetched per
+    // group of four k-steps (see rowimg_off).  Requires BK == 16.
+    static_assert(BK == 16, "row image needs 16-float slabs");
+    constexpr int SA = BK * C::PA, SB = BK * C::PB;      // slab strides (the row image is smaller)
+    auto put = [&](int slot) {
+      if (AK) store_rowimg<BM, C::NT, C::VA>(As + slot * SA, ra);
+      else store_slab<false, BM, BK, C::NT, C::VA, C::PA>(As + slot * SA, ra);
+      if (BKC) store_rowimg<BN, C::NT, C::VB>(Bs + slot * SB, rb);
+      else store_slab<false, BN, BK, C::NT, C::VB, C::PB>(Bs + slot * SB, rb);
+    };
+    load_slab<AK, BM, BK, C::NT, C::VA>(g.A, g.lda, m0, g.M, kbeg, kend, ra);
+    load_slab<BKC, BN, BK, C::NT, C::VB>(g.B, g.ldb, n0, g.N, kbeg, kend, rb);
+    put(0);
+    load_slab<AK, BM, BK, C::NT, C::VA>(g.A, g.lda, m0, g.M, kbeg + BK, kend, ra);   // zeros past kend
+    load_slab<BKC, BN, BK, C::NT, C::VB>(g.B, g.ldb, n0, g.N, kbeg + BK, kend, rb);
+    put(1);
+    __syncthreads();
+    float4 xa[C::TM], xb[C::TN], na[C::TM], nb[C::TN];
+    fetch_group<AK, C::TM, C::PA>(As, wm, li, lk, 0, xa);
+    fetch_group<BKC, C::TN, C::PB>(Bs, wn, li, lk, 0, xb);
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      const bool more2 = k0 + 2 * BK < kend;
+      if (more2) {
+        load_slab<AK, BM, BK, C::NT, C::VA>(g.A, g.lda, m0, g.M, k0 + 2 * BK, kend, ra);
+        load_slab<BKC, BN, BK, C::NT, C::VB>(g.B, g.ldb, n0, g.N, k0 + 2 * BK, kend, rb);
+      }
+      const int nxt = (cur == 2) ? 0 : cur + 1;
+      const int nxt2 = (nxt == 2) ? 0 : nxt + 1;
+#pragma unroll
+      for (int grp = 0; grp < 2; grp++) {
+        // next group's operands: second half of this slab, then the first half of the NEXT slab
+        // (complete in LDS since the last barrier), so the MFMA stream runs across the barrier
+        const float* an_ = As + (grp == 0 ? cur : nxt) * SA;
+        const float* bn_ = Bs + (grp == 0 ? cur : nxt) * SB;
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_group<AK, C::TM, C::PA>(an_, wm, li, lk, grp == 0 ? 1 : 0, na);
+        fetch_group<BKC, C::TN, C::PB>(bn_, wn, li, lk, grp == 0 ? 1 : 0, nb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+          for (int a = 0; a < C::TM; a++)
+#pragma unroll
+            for (int b = 0; b < C::TN; b++) {
+              const float fa = j == 0 ? xa[a].x : j == 1 ? xa[a].y : j == 2 ? xa[a].z : xa[a].w;
+              const float fb = j == 0 ? xb[b].x : j == 1 ? xb[b].y : j == 2 ? xb[b].z : xb[b].w;
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[a][b], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < C::TM; a++) xa[a] = na[a];
+#pragma unroll
+        for (int b = 0; b < C::TN; b++) xb[b] = nb[b];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more2) put(nxt2);
+      __syncthreads();
+      cur = nxt;
+    }
+  } else if constexpr (C::NBUF == 3) {
     // ---- three-slab ring: slab k+2 is fetched from global while slab k is multiplied; slab k+1 is
     // already complete in LDS, so the first operands of slab k+1 are read BEFORE the barrier that
     // ends slab k and the MFMA stream runs across the barrier without an LDS round trip.

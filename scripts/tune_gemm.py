@@ -14,7 +14,8 @@ L = ctypes.CDLL(so)
 vp, i = ctypes.c_void_p, ctypes.c_int
 L.tune_gemm.argtypes = [i, i, i, i, i, i, vp, i, vp, i, vp, i, i, i, vp]
 names = {0: "128x128x16 4w", 1: "256x128x16 8w", 2: "256x128x16 8w schedbar", 3: "128x128x16 4w schedbar",
-         4: "256x128x16 8w 3buf", 5: "256x128x16 8w 3buf midstore", 6: "256x128x16 3buf midstore prio", 7: "256x128x32 3buf midstore"}
+         4: "256x128x16 8w 3buf", 5: "256x128x16 8w 3buf midstore", 6: "256x128x16 3buf midstore prio", 7: "256x128x32 3buf midstore",
+         8: "256x128x16 3buf row-image"}
 def timeit(fn, n=10, w=3):
     for _ in range(w): fn()
     torch.cuda.synchronize()

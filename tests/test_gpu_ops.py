@@ -211,7 +211,9 @@ def test_conv1x1_bn_act_gemm_path_matches_torch(monkeypatch):
     monkeypatch.setattr(fr, "_CONV1X1_GEMM", True)          # opt-in path (off by default: slower than MIOpen)
     monkeypatch.setattr(fr, "_CONV1X1_MIN_C", 0)
     torch.manual_seed(3)
-    for (n, cin, cout, h, w) in ((3, 64, 256, 9, 7), (2, 256, 64, 5, 6), (1200, 512, 2048, 4, 4)):
+    # (gradients are compared on sizes where no ReLU pre-activation sits within rounding of zero:
+    # at [1200,2048,4,4] = 4e7 outputs one always does, and its mask bit moves 2e-4 of the norm)
+    for (n, cin, cout, h, w) in ((3, 64, 256, 9, 7), (2, 256, 64, 5, 6), (48, 512, 2048, 4, 4)):
         conv = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
         bn = torch.nn.BatchNorm2d(cout).cuda().eval()
         with torch.no_grad():
@@ -234,8 +236,6 @@ def test_conv1x1_bn_act_gemm_path_matches_torch(monkeypatch):
                 wrt = [x, conv.weight] + ([r] if use_res else [])
                 got = torch.autograd.grad(y, wrt, g)
                 want = torch.autograd.grad(ref, wrt, g)
-                # relative L2: with ~4e7 outputs a ReLU whose pre-activation sits within rounding
-                # of zero flips its mask bit between the two summation orders (one element of dy)
                 for a, b in zip(got, want):
                     assert a.shape == b.shape
                     assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-6

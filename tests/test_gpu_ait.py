@@ -308,3 +308,35 @@ def test_transformer_bf16x3_mode_meets_the_fp32_tolerance():
     bad = int((d > 1e-4 * n).sum())
     print("tokens over 1e-4:", bad, "of", d.numel(), "median", float((d / n).median()))
     assert float((d / n).median()) < 2e-5 and errs["bf16x3"][1] < 5e-3, (bad, errs)
+
+
+def test_transformer_full_size_is_batch_invariant_and_linear_in_the_cotangent():
+    """BASELINE cfg2 size (4 pairs x 300 proposals = 1200 sequences) -- beyond what the CPU oracle
+    finishes in seconds, so checked through size-independent properties: every proposal's output
+    depends only on its own features and its pair's query (a slice of the full batch equals the
+    small batch the oracle tests pin), the channels-last output mode holds the same values, and the
+    backward is linear in the cotangent."""
+    t = _transformer(3).eval()
+    bs, P = 4, 300
+    xp = _dev(seeded(321, (bs * P, 1024, 7, 7)))
+    xq = _dev(seeded(322, (bs, 1024, 8, 8)))
+    with torch.no_grad():
+        y = t(x_props=xp, x_query=xq)
+        pick = torch.tensor([P + 7, P + 8, P + 250], device="cuda")          # three proposals of pair 1
+        y_small = t(x_props=xp[pick], x_query=xq[1:2])
+        t.channels_last_out = True
+        y_cl = t(x_props=xp, x_query=xq)
+        t.channels_last_out = False
+    assert tuple(y.shape) == (bs * P, 1024, 8, 8) and bool(torch.isfinite(y).all())
+    scale = float(y.abs().max())
+    assert float((y[pick] - y_small).abs().max()) <= 2e-5 * scale
+    assert y_cl.permute(0, 2, 3, 1).is_contiguous() and float((y_cl - y).abs().max()) <= 2e-5 * scale
+    a = xp.clone().requires_grad_(True)
+    b = xq.clone().requires_grad_(True)
+    out = t(x_props=a, x_query=b)
+    g = _dev(seeded(323, tuple(out.shape)))
+    g1 = torch.autograd.grad(out, [a, b], g, retain_graph=True)
+    g2 = torch.autograd.grad(out, [a, b], -2.0 * g)
+    for u, v in zip(g1, g2):
+        assert bool(torch.isfinite(u).all())
+        assert float((v + 2.0 * u).norm()) <= 1e-5 * float(u.norm())

@@ -258,3 +258,47 @@ def test_eval_postprocessing_vs_oracle(golden):
     got = detections(rois.cuda(), prob.cuda(), bbox.cuda(), info.cuda(), 1.6).cpu().numpy()
     assert got.shape == want.shape and got.shape[0] <= 100 + 5
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-3)
+
+
+def test_detector_full_size_step_matches_reference_work_and_is_reproducible(model):
+    """BASELINE cfg2 size (4 pairs, 600x1000, 300 proposals), training mode.  Size-independent
+    properties: (1) the default fast path (dead SK / trunk positions skipped, channels-last stages,
+    channels-last RoIAlign) and the path that does all of the reference's work in NCHW activations agree on every
+    loss and on the similarity probabilities; (2) the same seeds reproduce the same step."""
+    import ait_amd.faster_rcnn as fr
+    from ait_amd.config import cfg
+    from ait_amd.roi_layers import ROIAlign
+    cfg.TRAIN.BATCH_SIZE = 300
+    model.train()
+    for m in model.modules():                                        # dropout off: compare arithmetic, not masks
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    ins = [t.cuda() for t in D.synth_inputs(4, 77)]
+
+    def run():
+        np.random.seed(3)
+        torch.manual_seed(5)
+        with torch.no_grad():
+            out = model(*ins)
+        return torch.stack([out[3], out[4], out[5], out[6], out[7]]).double().cpu(), out[1].double().cpu(), out[0].cpu()
+
+    saved = (fr._SK_FULL, fr._TOP_NHWC, fr._BASE_NHWC, model.RCNN_roi_align.channels_last, model.transformer.channels_last_out)
+    try:
+        losses, prob, rois = run()
+        losses2, prob2, rois2 = run()
+        fr._SK_FULL, fr._TOP_NHWC, fr._BASE_NHWC = True, False, False
+        model.RCNN_roi_align.channels_last = False
+        model.transformer.channels_last_out = False
+        losses_ref, prob_ref, rois_ref = run()
+    finally:
+        fr._SK_FULL, fr._TOP_NHWC, fr._BASE_NHWC = saved[:3]
+        model.RCNN_roi_align.channels_last, model.transformer.channels_last_out = saved[3], saved[4]
+        model.train()
+    assert bool(torch.isfinite(losses).all())
+    # MIOpen's split-K convolution kernels accumulate with atomics: two runs differ in the last bits
+    assert float(((rois - rois2).abs().amax(-1) <= 2e-3).float().mean()) >= 0.98
+    assert float((losses - losses2).abs().max()) <= 2e-4 * float(losses.abs().max()) + 1e-6
+    same = (rois - rois_ref).abs().amax(-1) <= 2e-3                    # proposals can swap at near-tied scores
+    assert float(same.float().mean()) >= 0.98
+    assert float((losses - losses_ref).abs().max()) <= 2e-4 * float(losses_ref.abs().max()) + 1e-6
+    assert float((prob - prob_ref)[same].abs().max()) <= 1e-4

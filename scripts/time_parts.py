@@ -19,10 +19,12 @@ def fb(mod, x, fwd_only=False):
         y = y[0] if isinstance(y, tuple) else y
         if not fwd_only: y.sum().backward()
     return f
-x = torch.randn(1200, 1024, 8, 8, device=dev, requires_grad=True)
-print("RCNN_top(layer4) fwd      %.2f ms" % timeit(fb(m.RCNN_top, x, True)))
-print("RCNN_top(layer4) fwd+bwd  %.2f ms" % timeit(fb(m.RCNN_top, x)))
-print("sk_props fwd+bwd          %.2f ms" % timeit(fb(m.sk.sk_props, x)))
+x = torch.randn(1200, 1024, 8, 8, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+x4 = torch.randn(1200, 1024, 4, 4, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+m.train()
+print("layer4 (subsampled input, as the detector runs it) fwd      %.2f ms" % timeit(fb(lambda t: m._head_to_tail(t, subsampled=True), x4, True)))
+print("layer4 (subsampled input, as the detector runs it) fwd+bwd  %.2f ms" % timeit(fb(lambda t: m._head_to_tail(t, subsampled=True), x4)))
+print("sk_props stride 2 fwd+bwd                                   %.2f ms" % timeit(fb(lambda t: m.sk.sk_props(t, 2), x)))
 im = torch.randn(4, 3, 600, 1000, device=dev)
 print("backbone(image) fwd       %.2f ms" % timeit(fb(m.RCNN_base, im, True)))
 print("backbone(image) fwd+bwd   %.2f ms" % timeit(fb(m.RCNN_base, im)))

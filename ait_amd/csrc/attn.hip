@@ -10,10 +10,11 @@
 // tiles (64 accumulator VGPRs), so the whole softmax lives in registers and the probabilities
 // never round-trip through HBM inside the kernel.  Four units per 256-thread workgroup.
 //
-// Operands are staged through a wave-private LDS area of two 64x65 fp32 panels (odd pitch:
+// Operands are staged through a wave-private 64x65 fp32 LDS panel (odd pitch:
 // both access patterns the MFMA needs -- "rows down the lanes" for X as a left operand / X^T as
 // a right operand, and "columns along the lanes" for the other two cases -- are conflict-free
-// ds_read_b32).  2 x 16.6 KB per wave, 66.5 KB per workgroup -> 2 workgroups (8 waves) per CU.
+// ds_read_b32); the other operand of every product lives in registers (see OpRegs).  16.6 KB per
+// wave, 66.5 KB per workgroup -> 2 workgroups (8 waves, 2 per SIMD) per CU.
 // Global loads/stores are whole 256-B head rows (64 floats), coalesced.
 //
 // Masks are the two compile-time predicates of the reference: key padding
@@ -59,7 +60,7 @@ struct Stage {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int r = min(i * 4 + r0, rows - 1);
-      v[i] = *reinterpret_cast<const float4*>(g + (size_t)r * ld + c);
+      v[i] = *reinterpret_cast<const float4*>(g + (r * ld + c));      // 32-bit offset off a wave-uniform base
     }
   }
   __device__ __forceinline__ void store(float* __restrict__ s, int lane, int rows = T) const {
@@ -109,6 +110,85 @@ __device__ __forceinline__ void mm64(const float* __restrict__ Ls, const float* 
   }
 }
 
+// ---- register-resident operands -----------------------------------------------------------------
+// The MFMA wants, per k-step j (k = 2j + lk):  A operand  lane(li,lk) = L(li + 32a, k),
+//                                              B operand  lane(li,lk) = R(k, li + 32b).
+// A B operand that is row-major in memory (R(k,j) = X[k][j]) can be loaded straight from global
+// into registers -- lane li reads 32 consecutive floats of row k, whole 128-B segments -- so it
+// never needs an LDS panel.  An A operand "rows down the lanes" is not coalescable from global;
+// it is staged once through the wave's panel and then lifted into registers, which frees the
+// panel for the other operand.  Either way a wave needs ONE 64x65 panel instead of two, i.e.
+// 66.5 KB per workgroup and two workgroups (2 waves per SIMD) per CU.
+struct OpRegs {
+  float v[2][32];   // [tile][k-step]
+};
+
+// B(k, j) = g[k*ld + j] for k < rows, else 0
+__device__ __forceinline__ void breg_load(OpRegs& b, const float* __restrict__ g, int ld, int lane,
+                                          int rows = T) {
+  const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 32; j++) {
+    const int k = 2 * j + lk;
+    const int off = min(k, rows - 1) * ld + li;          // 32-bit offset off a wave-uniform base
+    const float x0 = g[off], x1 = g[off + 32];
+    b.v[0][j] = k < rows ? x0 : 0.f;
+    b.v[1][j] = k < rows ? x1 : 0.f;
+  }
+}
+
+// A(i, k) = Ls[i][k] lifted out of an LDS panel
+__device__ __forceinline__ void areg_from_lds(OpRegs& a, const float* __restrict__ Ls, int lane) {
+  const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 32; j++) {
+    a.v[0][j] = Ls[li * PITCH + 2 * j + lk];
+    a.v[1][j] = Ls[(li + 32) * PITCH + 2 * j + lk];
+  }
+}
+
+// acc += A(regs) * R   with R(k, j) = Rs[j][k]   (right operand transposed, from the panel)
+__device__ __forceinline__ void mm_areg_bldsT(const OpRegs& a, const float* __restrict__ Rs,
+                                              f32x16 (&acc)[2][2], int lane) {
+  const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 32; j++) {
+    // fence every 8 k-steps: the loop must be fully unrolled (static register indices), but the
+    // scheduler must not lift all 64 panel reads above the first MFMA (64 more live registers)
+    if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    const int kk = 2 * j + lk;
+    const float b0 = Rs[li * PITCH + kk], b1 = Rs[(li + 32) * PITCH + kk];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[0][j], b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[0][j], b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[1][j], b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[1][j], b1, acc[1][1], 0, 0, 0);
+  }
+}
+
+// acc += L * B(regs)   with L(i,k) = Ls[i][k] (LT = false) or Ls[k][i] (LT = true) from the panel
+template <bool LT>
+__device__ __forceinline__ void mm_alds_breg(const float* __restrict__ Ls, const OpRegs& b,
+                                             f32x16 (&acc)[2][2], int lane) {
+  const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 32; j++) {
+    if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    const int kk = 2 * j + lk;
+    float a0, a1;
+    if (LT) {
+      a0 = Ls[kk * PITCH + li];
+      a1 = Ls[kk * PITCH + li + 32];
+    } else {
+      a0 = Ls[li * PITCH + kk];
+      a1 = Ls[(li + 32) * PITCH + kk];
+    }
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.v[0][j], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b.v[1][j], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.v[0][j], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b.v[1][j], acc[1][1], 0, 0, 0);
+  }
+}
+
 __device__ __forceinline__ void zero(f32x16 (&acc)[2][2]) {
 #pragma unroll
   for (int a = 0; a < 2; a++)
@@ -155,7 +235,7 @@ __device__ __forceinline__ void acc_to_global(const f32x16 (&acc)[2][2], float* 
     for (int b = 0; b < 2; b++)
 #pragma unroll
       for (int r = 0; r < 16; r++)
-        g[(size_t)acc_row(a, r, lane) * ld + acc_col(b, lane)] = acc[a][b][r] * mul;
+        g[acc_row(a, r, lane) * ld + acc_col(b, lane)] = acc[a][b][r] * mul;
 }
 __device__ __forceinline__ void acc_to_global_rows(const f32x16 (&acc)[2][2], float* __restrict__ g,
                                                    int ld, int lane, int rows) {
@@ -166,7 +246,7 @@ __device__ __forceinline__ void acc_to_global_rows(const f32x16 (&acc)[2][2], fl
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int row = acc_row(a, r, lane);
-        if (row < rows) g[(size_t)row * ld + acc_col(b, lane)] = acc[a][b][r];
+        if (row < rows) g[row * ld + acc_col(b, lane)] = acc[a][b][r];
       }
 }
 __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[2][2], float* __restrict__ s,
@@ -189,24 +269,30 @@ struct AttnArgs {
   unsigned long long seed;
 };
 
-__global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnArgs g, float* __restrict__ P,
-                                                            float* __restrict__ O) {
-  __shared__ __attribute__((aligned(16))) float lds[kWaves * 2 * kPanel];
+__global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const AttnArgs g, float* __restrict__ P,
+                                                               float* __restrict__ O) {
+  __shared__ __attribute__((aligned(16))) float lds[kWaves * kPanel];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long unit = (long long)blockIdx.x * kWaves + wave;  // (sequence, head)
   if (unit >= (long long)g.n_seq * g.H) return;
   const int n = (int)(unit / g.H), h = (int)(unit % g.H);
-  float* s0 = lds + wave * 2 * kPanel;
-  float* s1 = s0 + kPanel;
-  Stage sq, sk, sv;
-  sq.load(g.q + ((size_t)n * T) * g.ldq + h * D, g.ldq, lane);
-  sk.load(g.k + ((size_t)n * g.kv_rows) * g.ldk + h * D, g.ldk, lane, g.kv_rows);
-  sv.load(g.v + ((size_t)n * g.kv_rows) * g.ldv + h * D, g.ldv, lane, g.kv_rows);   // in flight under S and the softmax
-  sq.store(s0, lane);
-  sk.store(s1, lane, g.kv_rows);
+  float* s0 = lds + wave * kPanel;
+  OpRegs op;
+  {
+    Stage sq, sk;
+    sq.load(g.q + ((size_t)n * T) * g.ldq + h * D, g.ldq, lane);
+    sk.load(g.k + ((size_t)n * g.kv_rows) * g.ldk + h * D, g.ldk, lane, g.kv_rows);
+    sq.store(s0, lane);
+    areg_from_lds(op, s0, lane);          // Q as the left operand, in registers
+    sk.store(s0, lane, g.kv_rows);        // the panel now holds K
+  }
+  __builtin_amdgcn_sched_barrier(0);
   f32x16 acc[2][2];
   zero(acc);
-  mm64<false, true>(s0, s1, acc, lane);  // S = Q K^T
+  mm_areg_bldsT(op, s0, acc, lane);       // S = Q K^T
+  __builtin_amdgcn_sched_barrier(0);
+  // V goes straight from global into registers (row-major right operand); in flight under the softmax
+  breg_load(op, g.v + ((size_t)n * g.kv_rows) * g.ldv + h * D, g.ldv, lane, g.kv_rows);
   // ---- scale, mask, softmax over keys (columns) ----------------------------------------
   const int mode = g.mask_mode, nv = g.n_valid, kvr = g.kv_rows;
   for_acc(acc, lane, [&](float x, int row, int col) {
@@ -231,10 +317,9 @@ __global__ __launch_bounds__(kThreads) void attn_fwd_kernel(const AttnArgs g, fl
       return x * drop_scale(g.seed, pbase + (size_t)row * T + col, g.p, inv_keep);
     });
   }
-  acc_to_lds(acc, s0, lane);  // P_drop over the Q panel (this wave's reads of it are done)
-  sv.store(s1, lane, g.kv_rows);
+  acc_to_lds(acc, s0, lane);  // P_drop over the K panel (this wave's reads of it are done)
   zero(acc);
-  mm64<false, false>(s0, s1, acc, lane);  // O = P V
+  mm_alds_breg<false>(s0, op, acc, lane);  // O = P V
   acc_to_global(acc, O + (size_t)unit * T * D, D, lane, 1.f);
 }
 
@@ -245,26 +330,26 @@ struct AttnBwdArgs {
   int lddq, lddk, lddv;
 };
 
-__global__ __launch_bounds__(kThreads) void attn_bwd_kernel(const AttnBwdArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[kWaves * 2 * kPanel];
+__global__ __launch_bounds__(kThreads, 2) void attn_bwd_kernel(const AttnBwdArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[kWaves * kPanel];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long unit = (long long)blockIdx.x * kWaves + wave;
   if (unit >= (long long)g.f.n_seq * g.f.H) return;
   const int n = (int)(unit / g.f.H), h = (int)(unit % g.f.H);
-  float* s0 = lds + wave * 2 * kPanel;
-  float* s1 = s0 + kPanel;
+  float* s0 = lds + wave * kPanel;
   const size_t pbase = (size_t)unit * T * T;
   const float p = g.f.p, inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  // P (pre-dropout) in accumulator layout, straight from HBM (128-B row segments)
-  f32x16 prob[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; a++)
-#pragma unroll
-    for (int b = 0; b < 2; b++)
-#pragma unroll
-      for (int r = 0; r < 16; r++)
-        prob[a][b][r] = g.P[pbase + (size_t)acc_row(a, r, lane) * T + acc_col(b, lane)];
-  // s0 <- dropout(P), s1 <- dO
+  const float* __restrict__ dO = g.dO + (size_t)unit * T * D;
+  const float* __restrict__ Vg = g.f.v + ((size_t)n * g.f.kv_rows) * g.f.ldv + h * D;
+  const float* __restrict__ Kg = g.f.k + ((size_t)n * g.f.kv_rows) * g.f.ldk + h * D;
+  const float* __restrict__ Qg = g.f.q + ((size_t)n * T) * g.f.ldq + h * D;
+  const float* __restrict__ Pu = g.P + pbase;
+  OpRegs op;
+  f32x16 acc[2][2];
+  // ---- dV = dropout(P)^T dO :  panel <- dropout(P), dO as the register right operand -------------
+  // P (pre-dropout) comes in accumulator layout straight from HBM (128-B row segments); it is read a
+  // second time for dS (still in L2) rather than held in 64 registers across two products.
+  breg_load(op, dO, D, lane);
   {
     f32x16 pd[2][2];
 #pragma unroll
@@ -273,51 +358,55 @@ __global__ __launch_bounds__(kThreads) void attn_bwd_kernel(const AttnBwdArgs g)
       for (int b = 0; b < 2; b++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          float sc = p > 0.f ? drop_scale(g.f.seed,
-                                          pbase + (size_t)acc_row(a, r, lane) * T + acc_col(b, lane),
-                                          p, inv_keep)
-                             : 1.f;
-          pd[a][b][r] = prob[a][b][r] * sc;
+          const int row = acc_row(a, r, lane), col = acc_col(b, lane);
+          // branch-free: at p = 0 the hash test u >= p always passes and inv_keep is 1
+          pd[a][b][r] = Pu[row * T + col] * drop_scale(g.f.seed, pbase + (size_t)row * T + col, p, inv_keep);
         }
     acc_to_lds(pd, s0, lane);
   }
-  Stage st, nx;      // current / next operand panel: the next one's loads fly under the current product
-  st.load(g.dO + (size_t)unit * T * D, D, lane);
-  nx.load(g.f.v + ((size_t)n * g.f.kv_rows) * g.f.ldv + h * D, g.f.ldv, lane, g.f.kv_rows);
-  st.store(s1, lane);
-  f32x16 acc[2][2];
+  __builtin_amdgcn_sched_barrier(0);   // phase fence: keeps later loads from being hoisted above
   zero(acc);
-  mm64<true, false>(s0, s1, acc, lane);  // dV = Pd^T dO
+  mm_alds_breg<true>(s0, op, acc, lane);
   acc_to_global_rows(acc, g.dv + ((size_t)n * g.f.kv_rows) * g.lddv + h * D, g.lddv, lane, g.f.kv_rows);
-  // dPd = dO V^T
-  nx.store(s0, lane, g.f.kv_rows);
-  st.load(g.f.k + ((size_t)n * g.f.kv_rows) * g.f.ldk + h * D, g.f.ldk, lane, g.f.kv_rows);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- dPd = dO V^T :  dO through the panel into registers (left operand), then the panel holds V
+  {
+    Stage st;
+    st.load(dO, D, lane);
+    st.store(s0, lane);
+    areg_from_lds(op, s0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    st.load(Vg, g.f.ldv, lane, g.f.kv_rows);
+    st.store(s0, lane, g.f.kv_rows);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   zero(acc);
-  mm64<false, true>(s1, s0, acc, lane);
-  // dS = P * (dP - rowsum(dP * P)) with dP = dPd * mask/(1-p);  then the 1/sqrt(dk) scale
+  mm_areg_bldsT(op, s0, acc, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- dS = P * (dP - rowsum(dP * P)) with dP = dPd * mask/(1-p);  then the 1/sqrt(dk) scale ------
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      float d0 = acc[a][0][r], d1 = acc[a][1][r];
-      if (p > 0.f) {
-        const int row = acc_row(a, r, lane);
-        d0 *= drop_scale(g.f.seed, pbase + (size_t)row * T + acc_col(0, lane), p, inv_keep);
-        d1 *= drop_scale(g.f.seed, pbase + (size_t)row * T + acc_col(1, lane), p, inv_keep);
-      }
-      const float dot = half_sum(d0 * prob[a][0][r] + d1 * prob[a][1][r]);
-      acc[a][0][r] = prob[a][0][r] * (d0 - dot) * g.f.scale;
-      acc[a][1][r] = prob[a][1][r] * (d1 - dot) * g.f.scale;
+      if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // four rows' shuffle chains at a time
+      const int row = acc_row(a, r, lane);
+      const float p0 = Pu[row * T + acc_col(0, lane)], p1 = Pu[row * T + acc_col(1, lane)];
+      const float d0 = acc[a][0][r] * drop_scale(g.f.seed, pbase + (size_t)row * T + acc_col(0, lane), p, inv_keep);
+      const float d1 = acc[a][1][r] * drop_scale(g.f.seed, pbase + (size_t)row * T + acc_col(1, lane), p, inv_keep);
+      const float dot = half_sum(d0 * p0 + d1 * p1);
+      acc[a][0][r] = p0 * (d0 - dot) * g.f.scale;
+      acc[a][1][r] = p1 * (d1 - dot) * g.f.scale;
     }
-  acc_to_lds(acc, s0, lane);  // dS (already scaled)
-  st.store(s1, lane, g.f.kv_rows);
-  nx.load(g.f.q + ((size_t)n * T) * g.f.ldq + h * D, g.f.ldq, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  breg_load(op, Kg, g.f.ldk, lane, g.f.kv_rows);
+  acc_to_lds(acc, s0, lane);  // dS (already scaled) over the V panel
   zero(acc);
-  mm64<false, false>(s0, s1, acc, lane);  // dQ = dS K
+  mm_alds_breg<false>(s0, op, acc, lane);  // dQ = dS K
+  __builtin_amdgcn_sched_barrier(0);
+  breg_load(op, Qg, g.f.ldq, lane);
   acc_to_global(acc, g.dq + ((size_t)n * T) * g.lddq + h * D, g.lddq, lane, 1.f);
-  nx.store(s1, lane);
   zero(acc);
-  mm64<true, false>(s0, s1, acc, lane);  // dK = dS^T Q
+  mm_alds_breg<true>(s0, op, acc, lane);   // dK = dS^T Q
   acc_to_global_rows(acc, g.dk + ((size_t)n * g.f.kv_rows) * g.lddk + h * D, g.lddk, lane, g.f.kv_rows);
 }
 

@@ -24,6 +24,9 @@ extern "C" __attribute__((visibility("default"))) int tune_gemm(
     case 4: return run<Cfg<256, 128, 16, 4, 2, 2, 6>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
     case 5: return run<Cfg<256, 128, 16, 4, 2, 2, 14>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
     case 6: return run<Cfg<256, 128, 16, 4, 2, 2, 15>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
+    case 9: return run<Cfg<256, 128, 16, 2, 2, 2, 6>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
+    case 10: return run<Cfg<128, 256, 16, 2, 2, 2, 6>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
+    case 11: return run<Cfg<256, 128, 16, 2, 2, 2, 22>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
     case 8: return run<Cfg<256, 128, 16, 4, 2, 2, 22>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
     case 7: return run<Cfg<256, 128, 32, 4, 2, 2, 14>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
     default: return -1;

@@ -79,6 +79,17 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 
 // Dynamic LDS: removed[nb] (u64).  alive[n] (u8, by sorted position) is written when
 // order != NULL; otherwise survivors are written straight to keep[] in ascending order.
+//
+// Per 64-row block rb the only truly serial work is the intra-block greedy chain; everything that
+// touches memory is taken off that path:
+//   * wave 0 owns the chain.  One iteration ahead it prefetches, per lane (= row of the NEXT block),
+//     that row's diagonal word and its word for the block after it ("critical column").  The chain
+//     runs on scalar registers (readlane); when row i survives, its critical word is OR-ed in the
+//     same scalar loop, so removed[rb+1] is complete the moment the chain ends -- no load in between.
+//   * waves 1..7 meanwhile OR the PREVIOUS block's surviving rows into the words w >= rb+1 that are
+//     not needed before the next iteration (coalesced row segments, four independent loads in
+//     flight per thread, 64-bit LDS atomic OR), hidden behind the chain.
+// One barrier per block.  Stops early once max_keep survivors are found.
 __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(
     const unsigned long long* __restrict__ mask, int n, int nb, int max_keep,
     unsigned char* __restrict__ alive, long long* __restrict__ keep, int* __restrict__ n_keep,
@@ -87,28 +98,40 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(
   mask += (size_t)blockIdx.x * n * nb;        // batched call: one workgroup per image
   keep += (size_t)blockIdx.x * keep_stride;
   n_keep += blockIdx.x;
-  __shared__ unsigned long long kept_bits;
+  __shared__ unsigned long long kept_bits[2];
+  __shared__ int kept_rows[2][kTile];    // the surviving rows of the current / previous block, in order
   __shared__ int kept_total;
   const int tid = threadIdx.x;
   for (int i = tid; i < nb; i += kScanThreads) removed[i] = 0ull;
   if (tid == 0) kept_total = 0;
   __syncthreads();
-  unsigned long long diag = 0ull;
-  if (tid < kTile && tid < n) diag = mask[(size_t)tid * nb + 0];
+  unsigned long long diag = 0ull, crit = 0ull;
+  if (tid < kTile && tid < n) {
+    diag = mask[(size_t)tid * nb + 0];
+    if (nb > 1) crit = mask[(size_t)tid * nb + 1];
+  }
   for (int rb = 0; rb < nb; rb++) {
     const int base = rb * kTile;
     const int cnt = min(kTile, n - base);
+    const int cur = rb & 1;
     if (tid < kTile) {  // wave 0: intra-block greedy chain, all in scalar registers
       unsigned long long word = removed[rb];
       if (cnt < kTile) word |= ~0ull << cnt;
-      unsigned long long next_diag = 0ull;
-      if (rb + 1 < nb && base + kTile + tid < n)
-        next_diag = mask[(size_t)(base + kTile + tid) * nb + rb + 1];  // prefetch
+      unsigned long long next_diag = 0ull, next_crit = 0ull;
+      if (rb + 1 < nb && base + kTile + tid < n) {   // prefetch for the next block
+        const unsigned long long* __restrict__ r = mask + (size_t)(base + kTile + tid) * nb + rb + 1;
+        next_diag = r[0];
+        if (rb + 2 < nb) next_crit = r[1];
+      }
+      unsigned long long cw = 0ull;      // what this block's survivors suppress in block rb + 1
       for (int i = 0; i < cnt; i++) {
-        unsigned long long d = readlane64(diag, i);
-        if (!((word >> i) & 1ull)) word |= d;
+        if (!((word >> i) & 1ull)) {       // uniform branch: row i survives
+          word |= readlane64(diag, i);
+          cw |= readlane64(crit, i);
+        }
       }
       diag = next_diag;
+      crit = next_crit;
       unsigned long long k = ~word;  // survivors of this block
       int total = kept_total;
       if (max_keep > 0 && total + __popcll(k) > max_keep) {
@@ -122,6 +145,7 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(
         }
         k = kk;
       }
+      if ((k >> tid) & 1ull) kept_rows[cur][__popcll(k & ((1ull << tid) - 1ull))] = tid;
       if (alive) {
         if (tid < cnt) alive[base + tid] = (unsigned char)((k >> tid) & 1ull);
       } else if ((k >> tid) & 1ull) {
@@ -129,29 +153,39 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(
         keep[total + rank] = base + tid;
       }
       if (tid == 0) {
-        kept_bits = k;
+        kept_bits[cur] = k;
         kept_total = total + __popcll(k);
+        if (rb + 1 < nb && cw) atomicOr(&removed[rb + 1], cw);
+      }
+    } else if (rb > 0) {
+      // waves 1..7: the previous block's survivors -> removed[w] for w >= rb + 1 (its word for block
+      // rb itself was the critical column wave 0 handled one iteration ago).  Thread = (row group g
+      // of 7, word lane): a word lane walks the column words (coalesced 512-B row segments per wave),
+      // a row group takes every 7th surviving row, four per step with independent loads in flight.
+      const int prev = cur ^ 1;
+      const int kc = __popcll(kept_bits[prev]);
+      const int t = tid - kTile, g = t >> 6, wl = t & 63;
+      constexpr int G = kScanThreads / kTile - 1;
+      const unsigned long long* __restrict__ mrow = mask + (size_t)(base - kTile) * nb;
+      for (int w = rb + 1 + wl; w < nb; w += kTile) {
+        unsigned long long acc = 0ull;
+        for (int j = g; j < kc; j += 4 * G) {
+          const int r0 = kept_rows[prev][j];
+          const int r1 = kept_rows[prev][min(j + G, kc - 1)], r2 = kept_rows[prev][min(j + 2 * G, kc - 1)],
+                    r3 = kept_rows[prev][min(j + 3 * G, kc - 1)];   // clamped duplicates OR harmlessly
+          const unsigned long long a0 = mrow[(size_t)r0 * nb + w], a1 = mrow[(size_t)r1 * nb + w],
+                                   a2 = mrow[(size_t)r2 * nb + w], a3 = mrow[(size_t)r3 * nb + w];
+          acc |= a0 | a1 | a2 | a3;
+        }
+        if (acc) atomicOr(&removed[w], acc);
       }
     }
     __syncthreads();
-    const unsigned long long k = kept_bits;
-    const bool done = max_keep > 0 && kept_total >= max_keep;
-    if (done) {
+    if (max_keep > 0 && kept_total >= max_keep) {
       if (alive)
         for (int i = base + cnt + tid; i < n; i += kScanThreads) alive[i] = 0;
       break;
     }
-    // OR the kept rows' words into the running vector: independent, coalesced loads
-    for (int w = rb + 1 + tid; w < nb; w += kScanThreads) {
-      unsigned long long acc = 0ull, kk = k;
-      while (kk) {
-        int i = __ffsll((long long)kk) - 1;
-        kk &= kk - 1ull;
-        acc |= mask[(size_t)(base + i) * nb + w];
-      }
-      if (acc) removed[w] |= acc;
-    }
-    __syncthreads();
   }
   if (tid == 0) *n_keep = kept_total;
 }

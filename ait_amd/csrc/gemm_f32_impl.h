@@ -129,6 +129,47 @@ __device__ __forceinline__ void fetch_group(const float* __restrict__ slab, int 
   }
 }
 
+// ---- OPT bit 8 (256): slabs go global -> LDS directly (gfx950 global_load_lds_dwordx4) ------------
+// One wave-wide instruction moves 64 x 16 B = 1 KB: every lane supplies its own global address, the
+// data lands at (wave-uniform LDS base) + lane * 16 B.  No staging registers, no ds_write, no
+// VGPR write-back traffic next to the MFMA results.  LDS images (unpadded, 1 KB granules):
+//   reduction dim contiguous in memory: the row image of rowimg_off() -- granule q = rows
+//       16q..16q+15; lane L fills slot (row 16q + L/4, position L%4) and therefore FETCHES the chunk
+//       that the swizzle assigns to that slot;
+//   reduction dim outermost: K-major [16][ROWS], granule q = 256 consecutive elements of it.
+// Out-of-range rows are clamped to the last valid row (their products are never stored); the
+// caller guarantees whole slabs (K range a multiple of 16) and ROWS-dim % 4 == 0 for K-outer.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <bool KCONTIG, int ROWS, int NWAVES>
+__device__ __forceinline__ void dlds_load(const float* __restrict__ p, int ld, int r0, int R, int k0,
+                                          float* __restrict__ slab, int wave, int lane) {
+  constexpr int GRAN = ROWS * 16 / 256;          // 1-KB granules per slab
+#pragma unroll
+  for (int q0 = 0; q0 < GRAN; q0 += NWAVES) {
+    const int q = q0 + wave;                     // wave-uniform
+    if (GRAN % NWAVES != 0 && q >= GRAN) break;
+    const float* src;
+    if (KCONTIG) {
+      const int row = q * 16 + (lane >> 2), pos = lane & 3;
+      const int chunk = pos ^ ((row >> 2) & 3);
+      src = p + (size_t)min(r0 + row, R - 1) * ld + k0 + chunk * 4;
+    } else {
+      const int e = q * 256 + lane * 4;          // element of the [16][ROWS] image
+      const int k = e / ROWS, r = e % ROWS;
+      src = p + (size_t)(k0 + k) * ld + min(r0 + r, R - 4);
+    }
+    // Issued as inline assembly on purpose: through the builtin the compiler treats the transfer
+    // as a store to LDS that may alias every later ds_read and puts s_waitcnt vmcnt(0) in front of
+    // the next operand fetch, i.e. it serialises the slab's memory latency with the MFMA stream.
+    // Ordering is explicit here instead: a slot is requested only after the barrier that retired
+    // its last reader, and awaited (vmcnt(0)) before the barrier that publishes it.
+    const unsigned dst = (unsigned)(size_t)(lds_void*)(slab + q * 256);      // wave-uniform LDS address
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "m0", "memory");
+  }
+}
+
 // AK / BKC: true when that operand is stored with the reduction dimension contiguous.
 //   forward  y = x W^T   : A = x [M,K] (AK), B = W [N,K] (BKC)
 //   dgrad    dx = dy W   : A = dy [M,K'] (AK), B = W [K',N] (!BKC)
@@ -259,7 +300,61 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
 
   float4 ra[C::VA], rb[C::VB];
   float av[C::TM], bv[C::TN];
-  if constexpr (C::NBUF == 3 && (C::OPT & 16) != 0 && (AK || BKC)) {
+  if constexpr (C::NBUF == 3 && (C::OPT & 256) != 0) {
+    // ---- three-slab ring fed by direct-to-LDS loads (see dlds_load); operands fetched per group of
+    // four k-steps.  Slab k+2 is requested at the top of iteration k into the slot that iteration
+    // k-1 finished reading; it is awaited (vmcnt) just before the barrier that ends iteration k.
+    static_assert(BK == 16 && BM % 16 == 0 && BN % 16 == 0, "direct-to-LDS path needs 16-float slabs");
+    constexpr int SA = BM * 16, SB = BN * 16;          // floats per slab image
+    constexpr int NW = C::NT / 64;
+    float* Bd = lds + 3 * SA;
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    auto request = [&](int slot, int k0) {
+      dlds_load<AK, BM, NW>(g.A, g.lda, m0, g.M, k0, As + slot * SA, uw, lane);
+      dlds_load<BKC, BN, NW>(g.B, g.ldb, n0, g.N, k0, Bd + slot * SB, uw, lane);
+    };
+    request(0, kbeg);
+    if (kbeg + BK < kend) request(1, kbeg + BK);
+    __builtin_amdgcn_s_waitcnt(0x0070);                // vmcnt(0) (lgkm/exp untouched)
+    __syncthreads();
+    float4 xa[C::TM], xb[C::TN], na[C::TM], nb[C::TN];
+    fetch_group<AK, C::TM, BM>(As, wm, li, lk, 0, xa);
+    fetch_group<BKC, C::TN, BN>(Bd, wn, li, lk, 0, xb);
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      const int nxt = (cur == 2) ? 0 : cur + 1;
+      const int nxt2 = (nxt == 2) ? 0 : nxt + 1;
+      if (k0 + 2 * BK < kend) request(nxt2, k0 + 2 * BK);
+#pragma unroll
+      for (int grp = 0; grp < 2; grp++) {
+        const float* an_ = As + (grp == 0 ? cur : nxt) * SA;
+        const float* bn_ = Bd + (grp == 0 ? cur : nxt) * SB;
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_group<AK, C::TM, BM>(an_, wm, li, lk, grp == 0 ? 1 : 0, na);
+        fetch_group<BKC, C::TN, BN>(bn_, wn, li, lk, grp == 0 ? 1 : 0, nb);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+          for (int a = 0; a < C::TM; a++)
+#pragma unroll
+            for (int b = 0; b < C::TN; b++) {
+              const float fa = j == 0 ? xa[a].x : j == 1 ? xa[a].y : j == 2 ? xa[a].z : xa[a].w;
+              const float fb = j == 0 ? xb[b].x : j == 1 ? xb[b].y : j == 2 ? xb[b].z : xb[b].w;
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[a][b], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < C::TM; a++) xa[a] = na[a];
+#pragma unroll
+        for (int b = 0; b < C::TN; b++) xb[b] = nb[b];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0x0070);
+      __syncthreads();
+      cur = nxt;
+    }
+  } else if constexpr (C::NBUF == 3 && (C::OPT & 16) != 0 && (AK || BKC)) {
     // ---- three-slab ring with row images for the K-contiguous operand(s) and operands fetched per
     // group of four k-steps (see rowimg_off).  Requires BK == 16.
     static_assert(BK == 16, "row image needs 16-float slabs");
@@ -343,8 +438,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
     }
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      // OPT bits 5/6/7 are TUNER-ONLY ablations (wrong results): 32 = no global loads, 64 = no LDS
+      // stores, 128 = no barrier -- to see which part of the slab hand-over the matrix pipe waits on
       const bool more2 = k0 + 2 * BK < kend;
-      if (more2) {
+      if (more2 && !(C::OPT & 32)) {
         load_slab<AK, BM, BK, C::NT, C::VA>(g.A, g.lda, m0, g.M, k0 + 2 * BK, kend, ra);
         load_slab<BKC, BN, BK, C::NT, C::VB>(g.B, g.ldb, n0, g.N, k0 + 2 * BK, kend, rb);
       }
@@ -391,11 +488,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (!(C::OPT & 8) && more2) {
+      if (!(C::OPT & 8) && more2 && !(C::OPT & 64)) {
         store_slab<AK, BM, BK, C::NT, C::VA, C::PA>(As + nxt2 * BK * C::PA, ra);
         store_slab<BKC, BN, BK, C::NT, C::VB, C::PB>(Bs + nxt2 * BK * C::PB, rb);
       }
-      __syncthreads();
+      if (!(C::OPT & 128)) __syncthreads();
       cur = nxt;
     }
   } else {

@@ -16,7 +16,9 @@ L.tune_gemm.argtypes = [i, i, i, i, i, i, vp, i, vp, i, vp, i, i, i, vp]
 names = {0: "128x128x16 4w", 1: "256x128x16 8w", 2: "256x128x16 8w schedbar", 3: "128x128x16 4w schedbar",
          4: "256x128x16 8w 3buf", 5: "256x128x16 8w 3buf midstore", 6: "256x128x16 3buf midstore prio", 7: "256x128x32 3buf midstore",
          8: "256x128x16 3buf row-image", 9: "256x128x16 4 waves of 128x64, 3buf", 10: "128x256x16 4 waves of 64x128, 3buf",
-         11: "256x128x16 4 waves of 128x64, 3buf row-image"}
+         11: "256x128x16 4 waves of 128x64, 3buf row-image",
+         12: "ABLATION v4 without global loads", 13: "ABLATION v4 without global loads / LDS stores",
+         14: "ABLATION v4 without loads / stores / barrier", 15: "256x128x16 3buf direct-to-LDS"}
 def timeit(fn, n=10, w=3):
     for _ in range(w): fn()
     torch.cuda.synchronize()

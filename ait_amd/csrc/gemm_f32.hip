@@ -43,6 +43,11 @@ using namespace ait_gemm;
 // the MFMA stream run across the per-slab barrier (+1..3 % more on the 256x128 tile, a loss on
 // 128x128 split-K shapes).
 using Tile256 = Cfg<256, 128, 16, 4, 2, 2, 6>;
+// The same tile with its slabs moved global -> LDS directly (global_load_lds_dwordx4, OPT bit 8:
+// no staging registers, no ds_write; K-contiguous operands as swizzled row images read with
+// ds_read_b128).  A/B on MI355X, 60 launches each, repeated: +3..8 % on the NT shapes, 0..+1.5 % NN,
+// +1..7 % TN.  Needs whole slabs (K % 16 == 0) and 4-element granularity of a K-outer operand.
+using Tile256D = Cfg<256, 128, 16, 4, 2, 2, 6 + 256>;
 using Tile128 = Cfg<128, 128, 16, 2, 2, 2, 2>;
 // Narrow outputs (the 64-wide SHBlock / fc products): 256x64, same 64x64 per-wave shape, no dead
 // half tile.  Few-tile problems (the bs*64-row query side): 64x64 tiles, 4x the workgroups and a
@@ -64,7 +69,11 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   //   A: !trans_a  (A is [M,K]);   B: trans_b (B is [N,K])
   const long long tiles256 = (long long)((M + 255) / 256) * ((N + 127) / 128) * g.splits;
   if (N <= 64 && (long long)((M + 255) / 256) * g.splits >= 128) return dispatch<TileN64>(g, !trans_a, trans_b != 0, ait_stream(stream));
-  if (M >= 512 && tiles256 >= 512) return dispatch<Tile256>(g, !trans_a, trans_b != 0, ait_stream(stream));
+  if (M >= 512 && tiles256 >= 512) {
+    const bool direct = (K % 16 == 0) && (!trans_a || (M % 4 == 0 && M >= 4)) && (trans_b || (N % 4 == 0 && N >= 4));
+    if (direct) return dispatch<Tile256D>(g, !trans_a, trans_b != 0, ait_stream(stream));
+    return dispatch<Tile256>(g, !trans_a, trans_b != 0, ait_stream(stream));
+  }
   const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * g.splits;
   if (tiles128 < 128) return dispatch<Tile64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   return dispatch<Tile128>(g, !trans_a, trans_b != 0, ait_stream(stream));

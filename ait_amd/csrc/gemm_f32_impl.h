@@ -350,8 +350,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
         for (int b = 0; b < C::TN; b++) xb[b] = nb[b];
       }
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0x0070);
-      __syncthreads();
+      if (C::OPT & 512) {   // TUNER-ONLY ablation (may read a slab before it has landed): leave this
+                            // iteration's three requests in flight across the barrier
+        asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __syncthreads();
+      }
       cur = nxt;
     }
   } else if constexpr (C::NBUF == 3 && (C::OPT & 16) != 0 && (AK || BKC)) {

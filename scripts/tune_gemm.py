@@ -18,8 +18,9 @@ names = {0: "128x128x16 4w", 1: "256x128x16 8w", 2: "256x128x16 8w schedbar", 3:
          8: "256x128x16 3buf row-image", 9: "256x128x16 4 waves of 128x64, 3buf", 10: "128x256x16 4 waves of 64x128, 3buf",
          11: "256x128x16 4 waves of 128x64, 3buf row-image",
          12: "ABLATION v4 without global loads", 13: "ABLATION v4 without global loads / LDS stores",
-         14: "ABLATION v4 without loads / stores / barrier", 15: "256x128x16 3buf direct-to-LDS"}
-def timeit(fn, n=10, w=3):
+         14: "ABLATION v4 without loads / stores / barrier", 15: "256x128x16 3buf direct-to-LDS",
+         16: "ABLATION v15 with the slab wait relaxed to vmcnt(3)"}
+def timeit(fn, n=int(os.environ.get("TUNE_N", "10")), w=3):
     for _ in range(w): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -15,7 +15,9 @@ def _ref(a, b, ta, tb):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 512, 512), (300, 200, 64), (58800 // 8, 512, 1024),
                                    (64, 64, 2048), (1, 1, 4), (130, 4, 20),
                                    (40000, 64, 128),     # 256x64 tile (narrow outputs)
-                                   (33000, 512, 64)])    # 256x128 tile
+                                   (33000, 512, 64),     # 256x128 tile, slabs direct to LDS (K % 16 == 0)
+                                   (33000, 512, 72),     # 256x128 tile, register-staged slabs (K tail)
+                                   (33002, 520, 64)])    # ragged M / N edges on both
 def test_gemm_layouts(ta, tb, M, N, K):
     from ait_amd import ops
     torch.manual_seed(M * 7 + N * 3 + K)
@@ -27,8 +29,9 @@ def test_gemm_layouts(ta, tb, M, N, K):
     b = torch.randn((N, K) if tb else (K, N), device="cuda")
     c = ops.gemm(a, b, trans_a=ta, trans_b=tb)
     want = _ref(a, b, ta, tb)
-    # exact-fp32 products, fp32 accumulate: error <= ~1e-7 * sum|a||b|
-    bound = 4e-7 * (a.double().abs().t() if ta else a.double().abs()) @ \
+    # exact-fp32 products, fp32 accumulate.  Worst case K * 2^-24 * sum|a||b|; observed maxima over
+    # 30 seeds are 0.33..0.40e-6 * sum|a||b| for every tile / slab path, so 6e-7 is a tight fence
+    bound = 6e-7 * (a.double().abs().t() if ta else a.double().abs()) @ \
         (b.double().abs().t() if tb else b.double().abs()) + 1e-6
     assert bool(((c.double() - want).abs() <= bound).all())
 

@@ -204,6 +204,23 @@ class CoAttentionModuleCOCO(nn.Module):
 # ------------------------------------------------------------------------------------------
 # frozen BatchNorm (+ residual) (+ ReLU) as one HIP pass
 # ------------------------------------------------------------------------------------------
+class _Subsample(torch.autograd.Function):
+    """x[:, :, ::s, ::s] in the memory format of x.  The stock slice backward materialises its
+    zero-filled gradient in NCHW order, which then has to be re-laid-out before it can meet the
+    channels-last gradient of the other consumer of x; this one keeps the format."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.shape, ctx.s, ctx.fmt = x.shape, s, _fmt(x)
+        return x[:, :, ::s, ::s].contiguous(memory_format=ctx.fmt)
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device, memory_format=ctx.fmt).zero_()
+        g[:, :, ::ctx.s, ::ctx.s] = dy
+        return g, None
+
+
 class _BnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, scale, shift, residual, relu):
@@ -360,8 +377,7 @@ class Bottleneck(nn.Module):
         else:
             out = bn_act(F.conv2d(out, self.conv2.weight, None, out_stride, self.conv2.padding), self.bn2)
         if self.downsample is None:
-            identity = x if out_stride == 1 else \
-                x[:, :, ::out_stride, ::out_stride].contiguous(memory_format=_fmt(x))
+            identity = x if out_stride == 1 else _Subsample.apply(x, out_stride)
         elif out_stride != 1:
             raise ValueError("out_stride needs an identity shortcut")
         else:

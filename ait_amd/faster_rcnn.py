@@ -25,7 +25,7 @@ from . import ops
 from .config import cfg
 from .roi_layers import ROIAlign
 from .rpn import _ProposalTargetLayer, _RPN, _smooth_l1_loss
-from .system import MultiHeadAttention, Transformer, _split_k, conv2d_1x1
+from .system import MultiHeadAttention, Transformer, _Linear, _split_k, conv2d_1x1
 
 
 # ------------------------------------------------------------------------------------------
@@ -134,6 +134,20 @@ class CoAttentionModule(nn.Module):
     def forward(self, x_img, x_qry):
         bs, _, h_i, w_i = x_img.size()
         _, _, h_q, w_q = x_qry.size()
+        if x_img.is_cuda and x_img.dtype == torch.float32 and _fmt(x_img) == torch.channels_last:
+            # channels-last features ARE the token rows [bs*HW, C] the attention works on: the 1x1
+            # embeddings run as token-major GEMMs and the result is handed on as a channels-last
+            # view -- no NCHW <-> token transposes on either side (same arithmetic, same values)
+            c = x_img.size(1)
+            tok = x_img.permute(0, 2, 3, 1).reshape(bs * h_i * w_i, c)
+            e = self.img_emb[0]
+            img = _Linear.apply(tok, e.weight.view(e.out_channels, c), e.bias).view(bs, h_i * w_i, -1)
+            qry = self.qry_emb(x_qry).flatten(2).transpose(1, 2)
+            enc_img, _ = self.q2i_attn(q=img, k=qry, v=qry, mask=None)
+            enc_qry, _ = self.i2q_attn(q=qry, k=img, v=img, mask=None)
+            non_img = self.img_trans(enc_img).view(bs, h_i, w_i, self.d_word_vec).permute(0, 3, 1, 2)
+            non_qry = self.qry_trans(enc_qry).transpose(1, 2).reshape(bs, self.d_word_vec, h_q, w_q)
+            return non_img, non_qry
         img = self.img_emb(x_img).flatten(2).transpose(1, 2)          # [bs, HW, 512]
         qry = self.qry_emb(x_qry).flatten(2).transpose(1, 2)          # [bs, 64, 512]
         enc_img, _ = self.q2i_attn(q=img, k=qry, v=qry, mask=None)
@@ -198,7 +212,7 @@ class CoAttentionModuleCOCO(nn.Module):
                                        with_residual=True, normlization='division')
 
     def forward(self, x_img, x_qry):
-        return self.coattention(x_img, x_qry)
+        return self.coattention(x_img.contiguous(), x_qry.contiguous())
 
 
 # ------------------------------------------------------------------------------------------
@@ -476,7 +490,9 @@ class RCNNBackbone(nn.Module):
         if _BASE_NHWC and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
         x = self.stem[3](bn_act(self.stem[0](x), self.stem[1]))        # conv1, bn1+relu, maxpool
-        return run_stages([self.layer1, self.layer2, self.layer3], x).contiguous(), None
+        # (a channels-last trunk hands its feature on channels-last: the co-attention reads token rows,
+        # the RPN convolutions and the RoIAlign used here take either format)
+        return run_stages([self.layer1, self.layer2, self.layer3], x), None
 
 
 # ------------------------------------------------------------------------------------------

@@ -37,6 +37,8 @@ SIGNATURES = {
                            _i, ctypes.c_longlong, _vp]),
     "ait_gemm_bf16x3": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
                              _i, ctypes.c_longlong, _vp]),
+    "ait_transformer_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ait_transformer_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
     "ait_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp, _vp, _vp]),
     "ait_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _ull, _vp, _vp,
                         _vp, _vp, _vp]),
@@ -71,6 +73,25 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
+
+
+class MhaWeights(ctypes.Structure):
+    """ait_mha_weights of include/ait_hip.h."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("w_qkv", "sk_w", "sk_b", "fc_w", "ln_g", "ln_b")]
+
+
+class FfnWeights(ctypes.Structure):
+    """ait_ffn_weights."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("w1", "b1", "w2", "b2", "ln_g", "ln_b")]
+
+
+class TransformerWeights(ctypes.Structure):
+    """ait_transformer_weights."""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "enc_emb_w", "enc_emb_b", "dec_emb_w", "dec_emb_b", "dec_trans_w", "dec_trans_b",
+        "enc_ln_g", "enc_ln_b", "dec_ln_g", "dec_ln_b", "pos_table")] + \
+        [("enc_slf", MhaWeights), ("dec_slf", MhaWeights), ("dec_enc", MhaWeights),
+         ("enc_ffn", FfnWeights), ("dec_ffn", FfnWeights)]
 
 
 def check(rc: int, what: str):

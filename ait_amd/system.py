@@ -17,13 +17,14 @@ dropout+residual+LayerNorm rows, per-(sequence, head) attention tiles, selective
 supplies device memory, streams and the autograd tape between the fused blocks.  There is no CPU
 path: tensors must be on a GPU or the call raises.
 """
+import ctypes
 import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 
 LN_EPS = 1e-6
 SEQ = 64          # tokens per sequence on the AIT path (8x8 query cells)
@@ -546,12 +547,76 @@ class Transformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
+    def _c_weights(self):
+        """ait_transformer_weights (include/ait_hip.h) over this module's parameters; the returned
+        keep-alive list owns the concatenated QKV matrices."""
+        keep = []
+
+        def ptr(t):
+            t = t.detach()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        def mha(m):
+            w = _lib.MhaWeights()
+            w.w_qkv = ptr(torch.cat([m.w_qs.weight, m.w_ks.weight, m.w_vs.weight], 0))
+            w.sk_w, w.sk_b, w.fc_w = ptr(m.sh.sk.weight), ptr(m.sh.sk.bias), ptr(m.fc.weight)
+            w.ln_g, w.ln_b = ptr(m.layer_norm.weight), ptr(m.layer_norm.bias)
+            return w
+
+        def ffn(m):
+            w = _lib.FfnWeights()
+            w.w1, w.b1, w.w2, w.b2 = ptr(m.w_1.weight), ptr(m.w_1.bias), ptr(m.w_2.weight), ptr(m.w_2.bias)
+            w.ln_g, w.ln_b = ptr(m.layer_norm.weight), ptr(m.layer_norm.bias)
+            return w
+
+        W = _lib.TransformerWeights()
+        W.enc_emb_w, W.enc_emb_b = ptr(self.enc_emb[0].weight), ptr(self.enc_emb[0].bias)
+        W.dec_emb_w, W.dec_emb_b = ptr(self.dec_emb[0].weight), ptr(self.dec_emb[0].bias)
+        W.dec_trans_w, W.dec_trans_b = ptr(self.dec_trans[0].weight), ptr(self.dec_trans[0].bias)
+        W.enc_ln_g, W.enc_ln_b = ptr(self.encoder.layer_norm.weight), ptr(self.encoder.layer_norm.bias)
+        W.dec_ln_g, W.dec_ln_b = ptr(self.decoder.layer_norm.weight), ptr(self.decoder.layer_norm.bias)
+        W.pos_table = ptr(self.encoder.position_enc.pos_table[0, :SEQ])
+        enc, dec = self.encoder.layer_stack[0], self.decoder.layer_stack[0]
+        W.enc_slf, W.dec_slf, W.dec_enc = mha(enc.slf_attn), mha(dec.slf_attn), mha(dec.enc_attn)
+        W.enc_ffn, W.dec_ffn = ffn(enc.pos_ffn), ffn(dec.pos_ffn)
+        return W, keep
+
+    def forward_tokens_c(self, xp_tok, xq_tok, bp, bs, n_s):
+        """Inference through the single C entry point ait_transformer_fwd: token-major inputs
+        [bp*n_s, 2d] / [bs*64, 2d] -> [bp*64, 2d].  Same kernels in the same order as forward()."""
+        if len(self.encoder.layer_stack) != 1 or len(self.decoder.layer_stack) != 1:
+            raise NotImplementedError("ait_transformer_fwd is built for n_layers = 1")
+        L = _lib.lib()
+        W, keep = self._c_weights()
+        nbytes = int(L.ait_transformer_workspace_bytes(bp, bs, n_s))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=xp_tok.device)
+        out = torch.empty((bp * SEQ, 2 * self.channels), dtype=torch.float32, device=xp_tok.device)
+        with torch.cuda.device(xp_tok.device):
+            rc = L.ait_transformer_fwd(_lib.dev_ptr(xp_tok), _lib.dev_ptr(xq_tok), bp, bs, n_s,
+                                       ctypes.byref(W), ctypes.c_void_p(ws.data_ptr()), nbytes,
+                                       _lib.dev_ptr(out), _lib.cur_stream(xp_tok.device))
+        _lib.check(rc, "ait_transformer_fwd")
+        del keep
+        return out
+
     def forward(self, x_props, x_query):
         bp, c2, hp, wp = x_props.size()
         bs, _, hq, wq = x_query.size()
         n_s, n_t = hp * wp, hq * wq
         if n_t != SEQ or n_s > SEQ or bp % bs:
             raise NotImplementedError("AIT HIP path: query must be 8x8 cells, proposals <= 64 cells")
+        if (not self.training and not torch.is_grad_enabled() and len(self.encoder.layer_stack) == 1
+                and os.environ.get("AIT_COMPACT_MEMORY", "1") != "0"):
+            # inference: the whole operator is ONE call into the C ABI (ait_transformer_fwd)
+            xp = x_props.reshape(bp, c2, n_s).transpose(1, 2).reshape(bp * n_s, c2).contiguous()
+            xq = x_query.reshape(bs, c2, n_t).transpose(1, 2).reshape(bs * n_t, c2).contiguous()
+            out = self.forward_tokens_c(xp, xq, bp, bs, n_s)
+            if self.channels_last_out:
+                return out.view(bp, hq, wq, c2).permute(0, 3, 1, 2)
+            return out.view(bp, n_t, c2).transpose(1, 2).reshape(bp, c2, hq, wq)
         P = bp // bs
         d = self.channels
         # NCHW -> token-major rows for the embedding GEMMs

@@ -226,6 +226,46 @@ int ait_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* 
                  float* dv, int lddv, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The whole AIT forward as one call: Transformer.forward in eval mode
+ * (lib/model/system/Models.py:231-280, n_layers = 1, d_model = 512, 8 heads of 64, d_inner = 2048:
+ * the configuration of faster_rcnn_sys_transformer_sk_dilat.py:148-158).  Composes the entry
+ * points above exactly as ait_amd/system.py does; see ait_amd/csrc/transformer.hip.
+ *   x_props [bp * n_src, 1024]  proposal tokens (token-major = channels-last [bp, h, w, 1024];
+ *                                n_src = h*w <= 64, 49 for 7x7 RoIAlign bins)
+ *   x_query [bs * 64, 1024]     query tokens; sequence i belongs to pair i / (bp / bs)
+ *   out     [bp * 64, 1024]     token-major (= channels-last [bp, 8, 8, 1024])
+ * Weights: plain pointers into the state_dict tensors; w_qkv is the row concatenation
+ * [w_qs.weight; w_ks.weight; w_vs.weight] ([1536, 512]).  Workspace: caller-owned scratch of
+ * ait_transformer_workspace_bytes(bp, bs, n_src) bytes.  Training (dropout, saved activations)
+ * goes through the autograd wrappers of ait_amd/system.py.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *w_qkv;            /* [1536, 512]  Q | K | V row blocks, no bias */
+  const float *sk_w, *sk_b;      /* SHBlock: sh.sk.weight [512, 64], sh.sk.bias [512] */
+  const float *fc_w;             /* fc.weight [512, 64], no bias */
+  const float *ln_g, *ln_b;      /* layer_norm.weight / bias [512] */
+} ait_mha_weights;
+typedef struct {
+  const float *w1, *b1;          /* w_1.weight [2048, 512], w_1.bias [2048] */
+  const float *w2, *b2;          /* w_2.weight [512, 2048], w_2.bias [512] */
+  const float *ln_g, *ln_b;
+} ait_ffn_weights;
+typedef struct {
+  const float *enc_emb_w, *enc_emb_b;       /* enc_emb.0.weight [512, 1024], bias [512] */
+  const float *dec_emb_w, *dec_emb_b;
+  const float *dec_trans_w, *dec_trans_b;   /* dec_trans.0.weight [1024, 512], bias [1024] */
+  const float *enc_ln_g, *enc_ln_b;         /* encoder.layer_norm */
+  const float *dec_ln_g, *dec_ln_b;         /* decoder.layer_norm */
+  const float *pos_table;                   /* position_enc.pos_table [64, 512] */
+  ait_mha_weights enc_slf, dec_slf, dec_enc;
+  ait_ffn_weights enc_ffn, dec_ffn;
+} ait_transformer_weights;
+size_t ait_transformer_workspace_bytes(int bp, int bs, int n_src);
+int ait_transformer_fwd(const float* x_props, const float* x_query, int bp, int bs, int n_src,
+                        const ait_transformer_weights* w, void* workspace, size_t workspace_bytes,
+                        float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Frozen batch-norm + residual + ReLU, one pass (NCHW fp32, x [n,C,HW]).
  * Replaces the eval-mode BatchNorm2d / "out += residual" / ReLU chains of the ResNet bottlenecks
  * (lib/model/faster_rcnn/resnet_sys_transformer_sk_dilat.py:85-111; every BatchNorm is frozen and

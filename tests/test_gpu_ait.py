@@ -340,3 +340,30 @@ def test_transformer_full_size_is_batch_invariant_and_linear_in_the_cotangent():
     for u, v in zip(g1, g2):
         assert bool(torch.isfinite(u).all())
         assert float((v + 2.0 * u).norm()) <= 1e-5 * float(u.norm())
+
+
+def test_transformer_c_entry_point_equals_the_autograd_composition():
+    """ait_transformer_fwd (the whole AIT forward behind ONE C-ABI call, used by eval-mode inference
+    under torch.no_grad) against the same module run through the Python autograd composition:
+    same kernels in the same order -> the same bits; and both against the fp32 oracle."""
+    t = _transformer(3).eval()
+    xp0, xq0 = seeded(301, (6, 1024, 7, 7)), seeded(302, (2, 1024, 8, 8))
+    xp, xq = _dev(xp0), _dev(xq0)
+    with torch.enable_grad():
+        y_py = t(x_props=xp.clone().requires_grad_(True), x_query=xq).detach()
+    with torch.no_grad():
+        y_c = t(x_props=xp, x_query=xq)
+        t.channels_last_out = True
+        y_c_cl = t(x_props=xp, x_query=xq)
+        t.channels_last_out = False
+    assert torch.equal(y_c, y_py)
+    assert torch.equal(y_c_cl, y_py) and y_c_cl.permute(0, 2, 3, 1).is_contiguous()
+    ref = ait_ref.transformer_forward(ait_ref.make_ait_state_dict(seed=3), torch.from_numpy(xp0), torch.from_numpy(xq0))
+    assert float((y_c.cpu() - ref).norm() / ref.norm()) < 1e-5
+    # a padded (64-token) proposal memory and a wrong pairing are handled / rejected
+    with torch.no_grad():
+        y64 = t(x_props=_dev(seeded(305, (4, 1024, 8, 8))), x_query=xq)
+    assert tuple(y64.shape) == (4, 1024, 8, 8) and bool(torch.isfinite(y64).all())
+    from ait_amd import _lib
+    with pytest.raises(_lib.AitHipError):
+        t.forward_tokens_c(torch.zeros(5 * 49, 1024, device="cuda"), torch.zeros(2 * 64, 1024, device="cuda"), 5, 2, 49)

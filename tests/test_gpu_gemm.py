@@ -149,3 +149,37 @@ def test_gemm_bf16_epilogues_and_splitk():
         assert torch.allclose(dw.double(), dy.bfloat16().double().t() @ x.bfloat16().double(), rtol=1e-5, atol=2e-3)
     finally:
         ops.set_matmul_dtype("f32")
+
+
+def test_gemm_large_tile_direct_to_lds_epilogues():
+    """The 256x128 tile with direct-to-LDS slabs (K % 16 == 0, >= 512 workgroups) under every
+    epilogue the AIT uses: bias + residual + ReLU, accumulate, ReLU-backward gate, column-blocked
+    (NCHW) store, split-K atomics -- against fp64 products."""
+    from ait_amd import ops
+    torch.manual_seed(11)
+    M, N, K = 33000, 512, 256
+    a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+    bias, res = torch.randn(N, device="cuda"), torch.randn(M, N, device="cuda")
+    ref = a.double() @ w.double().t()
+    tol = dict(rtol=1e-5, atol=2e-4)
+    assert torch.allclose(ops.gemm(a, w, bias=bias, residual=res, relu=True).double(),
+                          torch.relu(ref + bias.double() + res.double()), **tol)
+    c = res.clone()
+    ops.gemm(a, w, out=c, accumulate=True, alpha=0.5)
+    assert torch.allclose(c.double(), res.double() + 0.5 * ref, **tol)
+    # dgrad layout (B stored [K, N]) with the ReLU-backward gate
+    wk = torch.randn(K, N, device="cuda")
+    act = torch.randn(M, N, device="cuda")
+    got = ops.gemm_relu_bwd(a, wk, act)
+    assert torch.allclose(got.double(), (a.double() @ wk.double()) * (act > 0), **tol)
+    # weight-gradient layout, split-K atomics: dW[N2, K2] = dy[T, N2]^T x[T, K2]
+    T_, N2, K2 = 65536, 2048, 512
+    dy, x = torch.randn(T_, N2, device="cuda"), torch.randn(T_, K2, device="cuda")
+    dw = ops.gemm(dy, x, trans_a=True, trans_b=False, split_k=16)
+    assert torch.allclose(dw.double(), dy.double().t() @ x.double(), rtol=1e-5, atol=3e-2)
+    # column-blocked C: [channel, token] product written into NCHW [p, ch, 64]
+    P, CH = 520, 1024
+    dec, wt, bch = torch.randn(P * 64, K, device="cuda"), torch.randn(CH, K, device="cuda"), torch.randn(CH, device="cuda")
+    out = ops.gemm(wt, dec, bias=bch, bias_row=True, c_colblk=64, c_batch_stride=CH * 64, out_shape=(P, CH, 64))
+    want = (dec.double() @ wt.double().t() + bch.double()).view(P, 64, CH).transpose(1, 2)
+    assert torch.allclose(out.double(), want, **tol)

@@ -37,6 +37,10 @@ SIGNATURES = {
                            _i, ctypes.c_longlong, _vp]),
     "ait_gemm_bf16x3": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
                              _i, ctypes.c_longlong, _vp]),
+    "ait_mha_block_workspace_bytes": (_sz, [_i, _i]),
+    "ait_mha_block_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
+    "ait_ffn_workspace_bytes": (_sz, [_ll]),
+    "ait_ffn_fwd": (_i, [_vp, _ll, _vp, _vp, _sz, _vp, _vp]),
     "ait_transformer_workspace_bytes": (_sz, [_i, _i, _i]),
     "ait_transformer_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
     "ait_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp, _vp, _vp]),

@@ -94,6 +94,55 @@ int ffn_block(const float* x, long long rows, const ait_ffn_weights& w, float* h
 
 }  // namespace
 
+AIT_API size_t ait_mha_block_workspace_bytes(int n_seq, int kv_rows) {
+  if (n_seq <= 0 || kv_rows <= 0 || kv_rows > T) return 0;
+  const size_t M = (size_t)n_seq * T;
+  // qkv (or q | kv), O, u, gate, s, f
+  return (M * 3 * D + (size_t)n_seq * kv_rows * 2 * D + M * D + M * DK + (size_t)n_seq * D + (size_t)n_seq * DK + M * D) *
+             sizeof(float) + 8 * 256;
+}
+
+AIT_API int ait_mha_block_fwd(const float* xq, const float* xkv, int n_seq, int kv_rows, int mask_mode,
+                              int n_valid_keys, const ait_mha_weights* w, void* workspace, size_t workspace_bytes,
+                              float* y, void* stream) {
+  if (n_seq < 0 || kv_rows <= 0 || kv_rows > T || mask_mode < 0 || mask_mode > 2 || !w) return AIT_EINVAL;
+  if (n_seq == 0) return AIT_OK;
+  if (!xq || !y || !workspace) return AIT_EINVAL;
+  if (!xkv || xkv == xq) {
+    if (kv_rows != T) return AIT_EINVAL;       // self-attention: keys are the 64 query tokens
+    xkv = xq;
+  }
+  if (workspace_bytes < ait_mha_block_workspace_bytes(n_seq, kv_rows)) return AIT_EWORKSPACE;
+  const size_t M = (size_t)n_seq * T;
+  Bump b{static_cast<char*>(workspace), workspace_bytes};
+  float* qkv = b.take(M * 3 * D + (size_t)n_seq * kv_rows * 2 * D);
+  float* O = b.take(M * D);
+  float* u = b.take(M * DK);
+  float* gate = b.take((size_t)n_seq * D);
+  float* sp = b.take((size_t)n_seq * DK);
+  float* f = b.take(M * D);
+  if (!qkv || !O || !u || !gate || !sp || !f) return AIT_EWORKSPACE;
+  return mha_block(xq, xkv, n_seq, kv_rows, mask_mode, n_valid_keys, *w, qkv, O, u, gate, sp, f, y, stream);
+}
+
+AIT_API size_t ait_ffn_workspace_bytes(long long rows) {
+  if (rows <= 0) return 0;
+  return ((size_t)rows * DI + (size_t)rows * D) * sizeof(float) + 4 * 256;
+}
+
+AIT_API int ait_ffn_fwd(const float* x, long long rows, const ait_ffn_weights* w, void* workspace,
+                        size_t workspace_bytes, float* y, void* stream) {
+  if (rows < 0 || rows > 0x7fffffffLL || !w) return AIT_EINVAL;
+  if (rows == 0) return AIT_OK;
+  if (!x || !y || !workspace) return AIT_EINVAL;
+  if (workspace_bytes < ait_ffn_workspace_bytes(rows)) return AIT_EWORKSPACE;
+  Bump b{static_cast<char*>(workspace), workspace_bytes};
+  float* h = b.take((size_t)rows * DI);
+  float* f = b.take((size_t)rows * D);
+  if (!h || !f) return AIT_EWORKSPACE;
+  return ffn_block(x, rows, *w, h, f, y, stream);
+}
+
 AIT_API size_t ait_transformer_workspace_bytes(int bp, int bs, int n_src) {
   if (bp <= 0 || bs <= 0 || n_src <= 0 || n_src > T) return 0;
   return ws_floats(bp, bs, n_src) * sizeof(float) + 32 * 256;

@@ -260,6 +260,19 @@ typedef struct {
   ait_mha_weights enc_slf, dec_slf, dec_enc;
   ait_ffn_weights enc_ffn, dec_ffn;
 } ait_transformer_weights;
+/* The two sub-layer blocks the operator is made of, in eval mode (no dropout):
+ *   ait_mha_block_fwd  y = LayerNorm(fc(selective_heads(attention(x_q W_q, x_kv W_k, x_kv W_v))) + x_q)
+ *                      (MultiHeadAttention.forward, SubLayers.py:68-102).  xq [n_seq*64, 512];
+ *                      xkv NULL (or == xq) for self-attention, else the memory [n_seq*kv_rows, 512]
+ *                      with kv_rows <= 64; mask_mode / n_valid_keys as in ait_attn_fwd.
+ *   ait_ffn_fwd        y = LayerNorm(W2 relu(W1 x + b1) + b2 + x)   (SubLayers.py:177-187), x [rows, 512]. */
+size_t ait_mha_block_workspace_bytes(int n_seq, int kv_rows);
+int ait_mha_block_fwd(const float* xq, const float* xkv, int n_seq, int kv_rows, int mask_mode,
+                      int n_valid_keys, const ait_mha_weights* w, void* workspace, size_t workspace_bytes,
+                      float* y, void* stream);
+size_t ait_ffn_workspace_bytes(long long rows);
+int ait_ffn_fwd(const float* x, long long rows, const ait_ffn_weights* w, void* workspace,
+                size_t workspace_bytes, float* y, void* stream);
 size_t ait_transformer_workspace_bytes(int bp, int bs, int n_src);
 int ait_transformer_fwd(const float* x_props, const float* x_query, int bp, int bs, int n_src,
                         const ait_transformer_weights* w, void* workspace, size_t workspace_bytes,

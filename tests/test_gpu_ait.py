@@ -367,3 +367,47 @@ def test_transformer_c_entry_point_equals_the_autograd_composition():
     from ait_amd import _lib
     with pytest.raises(_lib.AitHipError):
         t.forward_tokens_c(torch.zeros(5 * 49, 1024, device="cuda"), torch.zeros(2 * 64, 1024, device="cuda"), 5, 2, 49)
+
+
+def test_c_sublayer_blocks_match_the_modules():
+    """ait_mha_block_fwd / ait_ffn_fwd (one C call per sub-layer, eval mode) against the Python
+    modules built from the same kernels: self-attention with each mask, cross-attention over an
+    unpadded 49-token memory, and the feed-forward block -- same bits."""
+    import ctypes
+    from ait_amd import _lib
+    from ait_amd.system import CausalMask, KeyPadMask
+    t = _transformer(3).eval()
+    L = _lib.lib()
+    n = 5
+    x = _dev(seeded(401, (n, 64, 512)))
+    mem = _dev(seeded(402, (n, 49, 512)))
+    W, keep = t._c_weights()
+
+    def run_mha(wstruct, xq, xkv, kv_rows, mode, n_valid):
+        nbytes = int(L.ait_mha_block_workspace_bytes(n, kv_rows))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        y = torch.empty(n * 64, 512, device="cuda")
+        rc = L.ait_mha_block_fwd(_lib.dev_ptr(xq), None if xkv is None else _lib.dev_ptr(xkv), n, kv_rows, mode,
+                                 n_valid, ctypes.byref(wstruct), ctypes.c_void_p(ws.data_ptr()), nbytes,
+                                 _lib.dev_ptr(y), _lib.cur_stream(xq.device))
+        _lib.check(rc, "ait_mha_block_fwd")
+        return y.view(n, 64, 512)
+
+    enc, dec = t.encoder.layer_stack[0], t.decoder.layer_stack[0]
+    with torch.no_grad():
+        assert torch.equal(run_mha(W.enc_slf, x, None, 64, 1, 49), enc.slf_attn(x, x, x, mask=KeyPadMask(49))[0])
+        assert torch.equal(run_mha(W.dec_slf, x, None, 64, 2, 0), dec.slf_attn(x, x, x, mask=CausalMask())[0])
+        assert torch.equal(run_mha(W.dec_enc, x, mem, 49, 0, 49), dec.enc_attn(x, mem, mem, mask=None)[0])
+        rows = n * 64
+        nbytes = int(L.ait_ffn_workspace_bytes(rows))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        y = torch.empty(rows, 512, device="cuda")
+        _lib.check(L.ait_ffn_fwd(_lib.dev_ptr(x), rows, ctypes.byref(W.dec_ffn), ctypes.c_void_p(ws.data_ptr()), nbytes,
+                                 _lib.dev_ptr(y), _lib.cur_stream(x.device)), "ait_ffn_fwd")
+        assert torch.equal(y.view(n, 64, 512), dec.pos_ffn(x))
+    # argument checking: a workspace that is too small, an impossible memory length
+    assert L.ait_ffn_fwd(_lib.dev_ptr(x), rows, ctypes.byref(W.dec_ffn), ctypes.c_void_p(ws.data_ptr()), 16,
+                         _lib.dev_ptr(y), None) == -2
+    assert L.ait_mha_block_fwd(_lib.dev_ptr(x), None, n, 49, 0, 0, ctypes.byref(W.enc_slf),
+                               ctypes.c_void_p(ws.data_ptr()), nbytes, _lib.dev_ptr(y), None) == -1
+    del keep

@@ -6,7 +6,8 @@
 // the fp32 operand traffic out of L2/HBM, so the tile is the larger 256x128 and K advances 32
 // per slab.
 //
-// LDS image: row-major [rows][32 bf16] = 64 B per row in 16-B chunks of 8 consecutive k; the
+// LDS image of an operand whose reduction dim is contiguous in memory (for the other kind see
+// Stage::store): row-major [rows][32 bf16] = 64 B per row in 16-B chunks of 8 consecutive k; the
 // bf16 MFMA wants exactly one such chunk per lane (lane l: row l&31, k-chunk l>>5), fetched with
 // one ds_read_b128.  Chunk index XOR ((row>>2)&3) makes that read conflict-free (four rows share
 // a 256-B bank row; the four 16-lane groups of a b128 read then hit four different chunks).
@@ -108,25 +109,43 @@ struct Stage {
         *reinterpret_cast<bf16x8*>(lds + lds_off(row, c)) = o;
         if (SPLIT) *reinterpret_cast<bf16x8*>(lds + lo_off + lds_off(row, c)) = l;
       } else {
+        // K-outer operand: "k-pair-major" image  word[kp][row] = (bf16 k = 2kp, bf16 k = 2kp + 1).
+        // The item's 4 rows x 4 k become two rows of four consecutive words: two conflict-free
+        // ds_write_b128 (consecutive lanes -> consecutive 16 B).  The MFMA side reads its 8
+        // consecutive k of one row as four ds_read_b32 down the kp axis (lanes = consecutive rows).
         const int rq = e % (ROWS / 4), c8 = e / (ROWS / 4);
         const float* f = reinterpret_cast<const float*>(&v[i][0]);   // f[q*4 + j] = (k = c8*4+q, row rq*4+j)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          bf16x4 o, l;
+        for (int h = 0; h < 2; h++) {                                 // kp = c8*2 + h  <-  k = c8*4 + 2h, +1
+          bf16x8 o, l;
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            o[q] = (__bf16)f[q * 4 + j];
-            if (SPLIT) l[q] = lo_part(f[q * 4 + j], o[q]);
+          for (int j = 0; j < 4; j++) {
+            const float x0 = f[(2 * h) * 4 + j], x1 = f[(2 * h + 1) * 4 + j];
+            o[2 * j] = (__bf16)x0;
+            o[2 * j + 1] = (__bf16)x1;
+            if (SPLIT) {
+              l[2 * j] = lo_part(x0, o[2 * j]);
+              l[2 * j + 1] = lo_part(x1, o[2 * j + 1]);
+            }
           }
-          const int row = rq * 4 + j;
-          const int off = lds_off(row, c8 >> 1) + (c8 & 1) * 8;
-          *reinterpret_cast<bf16x4*>(lds + off) = o;
-          if (SPLIT) *reinterpret_cast<bf16x4*>(lds + lo_off + off) = l;
+          const int off = ((c8 * 2 + h) * ROWS + rq * 4) * 4;
+          *reinterpret_cast<bf16x8*>(lds + off) = o;
+          if (SPLIT) *reinterpret_cast<bf16x8*>(lds + lo_off + off) = l;
         }
       }
     }
   }
 };
+
+// one operand tile's 8 consecutive k (k-step ks, lane half lk) for row `row` out of an LDS image
+template <bool KCONTIG, int ROWS>
+__device__ __forceinline__ bf16x8 fetch8(const char* __restrict__ img, int row, int ks, int lk) {
+  if (KCONTIG) return *reinterpret_cast<const bf16x8*>(img + lds_off(row, ks * 2 + lk));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned* __restrict__ w = reinterpret_cast<const unsigned*>(img) + (ks * 8 + lk * 4) * ROWS + row;
+  u32x4 p = {w[0], w[ROWS], w[2 * ROWS], w[3 * ROWS]};
+  return __builtin_bit_cast(bf16x8, p);
+}
 
 template <class C, bool AK, bool BKC, int EPI>
 __global__ __launch_bounds__(C::NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
@@ -198,15 +217,13 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
       bf16x8 av[TM], bv[TN], al[TM], bl[TN];
 #pragma unroll
       for (int a = 0; a < TM; a++) {
-        const int off = lds_off(wm + a * 32 + li, ks * 2 + lk);
-        av[a] = *reinterpret_cast<const bf16x8*>(as + off);
-        if (C::SPLIT) al[a] = *reinterpret_cast<const bf16x8*>(as + A_IMG + off);
+        av[a] = fetch8<AK, BM>(as, wm + a * 32 + li, ks, lk);
+        if (C::SPLIT) al[a] = fetch8<AK, BM>(as + A_IMG, wm + a * 32 + li, ks, lk);
       }
 #pragma unroll
       for (int b = 0; b < TN; b++) {
-        const int off = lds_off(wn + b * 32 + li, ks * 2 + lk);
-        bv[b] = *reinterpret_cast<const bf16x8*>(bs + off);
-        if (C::SPLIT) bl[b] = *reinterpret_cast<const bf16x8*>(bs + B_IMG + off);
+        bv[b] = fetch8<BKC, BN>(bs, wn + b * 32 + li, ks, lk);
+        if (C::SPLIT) bl[b] = fetch8<BKC, BN>(bs + B_IMG, wn + b * 32 + li, ks, lk);
       }
 #pragma unroll
       for (int a = 0; a < TM; a++)

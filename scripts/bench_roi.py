@@ -3,10 +3,12 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ait_amd.roi_layers import roi_align
-from oracle import cases
 bs, P, C = 4, 300, 1024
 feat = torch.randn(bs, C, 38, 63, device="cuda", requires_grad=True)
-rois = torch.from_numpy(cases.random_rois(5, bs * P, bs, min_side=32, max_side=480)).cuda()
+rs = np.random.RandomState(5)
+side_w, side_h = rs.uniform(32, 480, bs * P), rs.uniform(32, 480, bs * P)
+x1, y1 = rs.uniform(0, 1000 - side_w), rs.uniform(0, 600 - side_h)
+rois = torch.from_numpy(np.stack([rs.randint(0, bs, bs * P).astype(np.float64), x1, y1, x1 + side_w, y1 + side_h], 1).astype(np.float32)).cuda()
 def timeit(fn, n=20, w=5):
     for _ in range(w): fn()
     torch.cuda.synchronize()

@@ -8,7 +8,7 @@ import numpy as np, torch
 from ait_amd import ops
 from ait_amd.config import cfg, cfg_from_list
 from ait_amd.faster_rcnn import resnet_coco
-from oracle import detector_ref as D
+import bench
 bs, P = 8, 512
 cfg_from_list(['ANCHOR_SCALES', [4, 8, 16, 32], 'MAX_NUM_GT_BOXES', 50, 'TRAIN.BATCH_SIZE', P])
 ops.set_matmul_dtype(sys.argv[1] if len(sys.argv) > 1 else "bf16")
@@ -16,7 +16,7 @@ torch.manual_seed(0); np.random.seed(3)
 m = resnet_coco(('bg', 'fg'), 101, pretrained=False, class_agnostic=True, num_K=3); m.create_architecture()
 m = m.cuda().train()
 opt = torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=1e-3, momentum=0.9)
-ins = [t.cuda() for t in D.synth_inputs(bs, 5, max_gt=50)] if 'max_gt' in D.synth_inputs.__code__.co_varnames else [t.cuda() for t in D.synth_inputs(bs, 5)]
+ins = bench.synth_batch(bs, 5, torch.device("cuda:0"), max_gt=50)       # MAX_NUM_GT_BOXES = 50
 def step():
     opt.zero_grad(set_to_none=True)
     out = m(*ins)

@@ -309,6 +309,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
     constexpr int NW = C::NT / 64;
     float* Bd = lds + 3 * SA;
     const int uw = __builtin_amdgcn_readfirstlane(wave);
+    if (C::OPT & 1024) {
+      // TUNER experiment: the two workgroups of a CU are identical and start together, i.e. they
+      // reach their per-slab barriers together; delay the second resident workgroup by half a slab
+      if (((blockIdx.x / AIT_NXCD) / 32) & 1) __builtin_amdgcn_s_sleep(64);
+    }
     auto request = [&](int slot, int k0) {
       dlds_load<AK, BM, NW>(g.A, g.lda, m0, g.M, k0, As + slot * SA, uw, lane);
       dlds_load<BKC, BN, NW>(g.B, g.ldb, n0, g.N, k0, Bd + slot * SB, uw, lane);

@@ -48,6 +48,10 @@ using Tile256 = Cfg<256, 128, 16, 4, 2, 2, 6>;
 // ds_read_b128).  A/B on MI355X, 60 launches each, repeated: +3..8 % on the NT shapes, 0..+1.5 % NN,
 // +1..7 % TN.  Needs whole slabs (K % 16 == 0) and 4-element granularity of a K-outer operand.
 using Tile256D = Cfg<256, 128, 16, 4, 2, 2, 6 + 256>;
+// ... and with FOUR waves owning 128x64 each (8 MFMA tiles, 0.75 operand fetches per MFMA instead
+// of 1.0; 2 waves per SIMD): the weight-gradient layout (both operands K-outer, so every fetch is
+// four ds_read_b32) gains 3..8 % (126-129 -> 136 TFLOP/s), the other layouts do not.
+using Tile256D4 = Cfg<256, 128, 16, 2, 2, 2, 6 + 256>;
 using Tile128 = Cfg<128, 128, 16, 2, 2, 2, 2>;
 // Narrow outputs (the 64-wide SHBlock / fc products): 256x64, same 64x64 per-wave shape, no dead
 // half tile.  Few-tile problems (the bs*64-row query side): 64x64 tiles, 4x the workgroups and a
@@ -71,6 +75,7 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   if (N <= 64 && (long long)((M + 255) / 256) * g.splits >= 128) return dispatch<TileN64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   if (M >= 512 && tiles256 >= 512) {
     const bool direct = (K % 16 == 0) && (!trans_a || (M % 4 == 0 && M >= 4)) && (trans_b || (N % 4 == 0 && N >= 4));
+    if (direct && trans_a && !trans_b) return dispatch<Tile256D4>(g, false, false, ait_stream(stream));
     if (direct) return dispatch<Tile256D>(g, !trans_a, trans_b != 0, ait_stream(stream));
     return dispatch<Tile256>(g, !trans_a, trans_b != 0, ait_stream(stream));
   }

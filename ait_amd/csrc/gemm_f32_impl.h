@@ -170,6 +170,49 @@ __device__ __forceinline__ void dlds_load(const float* __restrict__ p, int ld, i
   }
 }
 
+// ---- OPT bit 11 (2048): 32-float slabs, two stages, direct to LDS (experiment) ----------------------
+// K-contiguous operands are then fetched as whole 128-B lines (a 16-float slab touches every
+// line twice, in two consecutive slabs).  Row image: [row][32 floats] = eight 16-B chunks, chunk
+// index XOR (row & 7); lane half lk works through k = 16*lk + s, s = 0..15.
+__device__ __forceinline__ int rowimg32_off(int row, int chunk) { return row * 32 + ((chunk ^ (row & 7)) << 2); }
+
+template <bool KCONTIG, int ROWS, int NWAVES>
+__device__ __forceinline__ void dlds_load32(const float* __restrict__ p, int ld, int r0, int R, int k0,
+                                            float* __restrict__ slab, int wave, int lane) {
+  constexpr int GRAN = ROWS * 32 / 256;
+#pragma unroll
+  for (int q0 = 0; q0 < GRAN; q0 += NWAVES) {
+    const int q = q0 + wave;
+    if (GRAN % NWAVES != 0 && q >= GRAN) break;
+    const float* src;
+    if (KCONTIG) {
+      const int row = q * 8 + (lane >> 3), pos = lane & 7;
+      src = p + (size_t)min(r0 + row, R - 1) * ld + k0 + ((pos ^ (row & 7)) << 2);
+    } else {
+      const int e = q * 256 + lane * 4;
+      const int k = e / ROWS, r = e % ROWS;
+      src = p + (size_t)(k0 + k) * ld + min(r0 + r, R - 4);
+    }
+    const unsigned dst = (unsigned)(size_t)(lds_void*)(slab + q * 256);
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "m0", "memory");
+  }
+}
+
+template <bool ROWIMG, int TILES, int ROWS>
+__device__ __forceinline__ void fetch_group32(const float* __restrict__ slab, int row0, int li, int lk, int g,
+                                              float4 (&x)[TILES]) {
+#pragma unroll
+  for (int t = 0; t < TILES; t++) {
+    const int row = row0 + t * 32 + li;
+    if (ROWIMG) {
+      x[t] = *reinterpret_cast<const float4*>(slab + rowimg32_off(row, 4 * lk + g));
+    } else {
+      const float* p = slab + (16 * lk + 4 * g) * ROWS + row;
+      x[t] = make_float4(p[0], p[ROWS], p[2 * ROWS], p[3 * ROWS]);
+    }
+  }
+}
+
 // AK / BKC: true when that operand is stored with the reduction dimension contiguous.
 //   forward  y = x W^T   : A = x [M,K] (AK), B = W [N,K] (BKC)
 //   dgrad    dx = dy W   : A = dy [M,K'] (AK), B = W [K',N] (!BKC)
@@ -300,7 +343,59 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
 
   float4 ra[C::VA], rb[C::VB];
   float av[C::TM], bv[C::TN];
-  if constexpr (C::NBUF == 3 && (C::OPT & 256) != 0) {
+  if constexpr ((C::OPT & 2048) != 0) {
+    static_assert(BK == 32, "OPT 2048 is the 32-float-slab path");
+    constexpr int SA = BM * 32, SB = BN * 32;
+    constexpr int NW = C::NT / 64;
+    float* Bd = lds + 2 * SA;
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    auto request = [&](int slot, int k0) {
+      dlds_load32<AK, BM, NW>(g.A, g.lda, m0, g.M, k0, As + slot * SA, uw, lane);
+      dlds_load32<BKC, BN, NW>(g.B, g.ldb, n0, g.N, k0, Bd + slot * SB, uw, lane);
+    };
+    request(0, kbeg);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      if (k0 + BK < kend) request(cur ^ 1, k0 + BK);
+      const float* as = As + cur * SA;
+      const float* bs = Bd + cur * SB;
+      float4 xa[C::TM], xb[C::TN], na[C::TM], nb[C::TN];
+      fetch_group32<AK, C::TM, BM>(as, wm, li, lk, 0, xa);
+      fetch_group32<BKC, C::TN, BN>(bs, wn, li, lk, 0, xb);
+#pragma unroll
+      for (int grp = 0; grp < 4; grp++) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp < 3) {
+          fetch_group32<AK, C::TM, BM>(as, wm, li, lk, grp + 1, na);
+          fetch_group32<BKC, C::TN, BN>(bs, wn, li, lk, grp + 1, nb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+          for (int a = 0; a < C::TM; a++)
+#pragma unroll
+            for (int b = 0; b < C::TN; b++) {
+              const float fa = j == 0 ? xa[a].x : j == 1 ? xa[a].y : j == 2 ? xa[a].z : xa[a].w;
+              const float fb = j == 0 ? xb[b].x : j == 1 ? xb[b].y : j == 2 ? xb[b].z : xb[b].w;
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[a][b], 0, 0, 0);
+            }
+        }
+        if (grp < 3) {
+#pragma unroll
+          for (int a = 0; a < C::TM; a++) xa[a] = na[a];
+#pragma unroll
+          for (int b = 0; b < C::TN; b++) xb[b] = nb[b];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0x0070);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else if constexpr (C::NBUF == 3 && (C::OPT & 256) != 0) {
     // ---- three-slab ring fed by direct-to-LDS loads (see dlds_load); operands fetched per group of
     // four k-steps.  Slab k+2 is requested at the top of iteration k into the slot that iteration
     // k-1 finished reading; it is awaited (vmcnt) just before the barrier that ends iteration k.

@@ -24,6 +24,8 @@ extern "C" __attribute__((visibility("default"))) int tune_gemm(
     case 4: return run<Cfg<256, 128, 16, 4, 2, 2, 6>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
     case 5: return run<Cfg<256, 128, 16, 4, 2, 2, 14>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
     case 6: return run<Cfg<256, 128, 16, 4, 2, 2, 15>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
+    case 22: return run<Cfg<128, 128, 32, 2, 2, 2, 2 + 2048>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
+    case 23: return run<Cfg<256, 128, 32, 4, 2, 1, 2 + 2048>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
     case 20: return run<Cfg<256, 128, 16, 2, 2, 2, 6 + 256>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
     case 21: return run<Cfg<256, 256, 16, 2, 4, 1, 6 + 256>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);
     case 19: return run<Cfg<256, 128, 16, 4, 2, 2, 6 + 256 + 1024>>(ta, tb, M, N, K, A, lda, B, ldb, C, ldc, flags, split_k, stream);

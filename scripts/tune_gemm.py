@@ -21,7 +21,8 @@ names = {0: "128x128x16 4w", 1: "256x128x16 8w", 2: "256x128x16 8w schedbar", 3:
          14: "ABLATION v4 without loads / stores / barrier", 15: "256x128x16 3buf direct-to-LDS",
          16: "ABLATION v15 with the slab wait relaxed to vmcnt(3)", 17: "256x256x16 16 waves direct-to-LDS",
          18: "128x128x16 4 waves direct-to-LDS, 3 blocks/CU", 19: "v15 with the second resident workgroup delayed half a slab",
-         20: "256x128x16 direct-to-LDS, 4 waves of 128x64", 21: "256x256x16 direct-to-LDS, 8 waves of 128x64"}
+         20: "256x128x16 direct-to-LDS, 4 waves of 128x64", 21: "256x256x16 direct-to-LDS, 8 waves of 128x64",
+         22: "128x128x32 two-stage direct-to-LDS, 4 waves (the rocBLAS macro tile)", 23: "256x128x32 two-stage direct-to-LDS, 8 waves, 1 block/CU"}
 def timeit(fn, n=int(os.environ.get("TUNE_N", "10")), w=3):
     for _ in range(w): fn()
     torch.cuda.synchronize()

@@ -36,28 +36,22 @@
 
 namespace {
 using namespace ait_gemm;
-// Two product tiles (scripts/tune_gemm.py, MI355X): 256x128 with 8 waves is the fastest of the
-// eight configurations tried on every large AIT shape (110-123 TFLOP/s vs 102-118 for 128x128;
-// 256x256 and BK=32 lose occupancy and are slower); 128x128 serves outputs with few rows.
-// OPT 2 = operand reads pinned above the MFMAs (+1..7 %), OPT 4 = three-slab LDS ring that lets
-// the MFMA stream run across the per-slab barrier (+1..3 % more on the 256x128 tile, a loss on
-// 128x128 split-K shapes).
-using Tile256 = Cfg<256, 128, 16, 4, 2, 2, 6>;
-// The same tile with its slabs moved global -> LDS directly (global_load_lds_dwordx4, OPT bit 8:
-// no staging registers, no ds_write; K-contiguous operands as swizzled row images read with
-// ds_read_b128).  A/B on MI355X, 60 launches each, repeated: +3..8 % on the NT shapes, 0..+1.5 % NN,
-// +1..7 % TN.  Needs whole slabs (K % 16 == 0) and 4-element granularity of a K-outer operand.
-using Tile256D = Cfg<256, 128, 16, 4, 2, 2, 6 + 256>;
-// ... and with FOUR waves owning 128x64 each (8 MFMA tiles, 0.75 operand fetches per MFMA instead
-// of 1.0; 2 waves per SIMD): the weight-gradient layout (both operands K-outer, so every fetch is
-// four ds_read_b32) gains 3..8 % (126-129 -> 136 TFLOP/s), the other layouts do not.
-using Tile256D4 = Cfg<256, 128, 16, 2, 2, 2, 6 + 256>;
-using Tile128 = Cfg<128, 128, 16, 2, 2, 2, 2>;
-// Narrow outputs (the 64-wide SHBlock / fc products): 256x64, same 64x64 per-wave shape, no dead
-// half tile.  Few-tile problems (the bs*64-row query side): 64x64 tiles, 4x the workgroups and a
-// quarter of the serial K loop per workgroup -- those launches are latency, not throughput.
-using TileN64 = Cfg<256, 64, 16, 4, 1, 2, 2>;
-using Tile64 = Cfg<64, 64, 16, 2, 2, 2, 2>;
+// Product tiles (measured on MI355X with scripts/gemm_lab.hip / scripts/tune_gemm.py):
+//   Tile256D   256x128, 8 waves (64x64 each), slabs global -> LDS directly, PERSISTENT (the slab ring
+//              runs across tile boundaries): every large product with K % 16 == 0.
+//   Tile256D4  the same with FOUR waves owning 128x64 each (8 MFMA tiles, 0.75 operand fetches per MFMA
+//              instead of 1.0): the weight-gradient layout, where both operands are K-outer and every
+//              operand fetch is four ds_read_b32.
+//   Tile256    256x128, register-staged three-slab ring: large products whose K is not a multiple of 16.
+//   Tile128    128x128 register-staged double buffer: outputs with few rows.
+//   TileN64    256x64 for the 64-column SHBlock / fc products (no dead half tile).
+//   Tile64     64x64 for few-tile problems (the bs*64-row query side): latency, not throughput.
+using Tile256D = Cfg<256, 128, 16, 4, 2, 4, MODE_DLDS>;   // MINW 4: <= 128 VGPRs, two workgroups per CU
+using Tile256D4 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS>;
+using Tile256 = Cfg<256, 128, 16, 4, 2, 2, MODE_RING>;
+using Tile128 = Cfg<128, 128, 16, 2, 2, 2, MODE_DB>;
+using TileN64 = Cfg<256, 64, 16, 4, 1, 2, MODE_DB>;
+using Tile64 = Cfg<64, 64, 16, 2, 2, 2, MODE_DB>;
 }  // namespace
 
 AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha,
@@ -74,7 +68,7 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   const long long tiles256 = (long long)((M + 255) / 256) * ((N + 127) / 128) * g.splits;
   if (N <= 64 && (long long)((M + 255) / 256) * g.splits >= 128) return dispatch<TileN64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   if (M >= 512 && tiles256 >= 512) {
-    const bool direct = (K % 16 == 0) && (!trans_a || (M % 4 == 0 && M >= 4)) && (trans_b || (N % 4 == 0 && N >= 4));
+    const bool direct = K > 0 && (K % 16 == 0) && (!trans_a || (M % 4 == 0 && M >= 4)) && (trans_b || (N % 4 == 0 && N >= 4));
     if (direct && trans_a && !trans_b) return dispatch<Tile256D4>(g, false, false, ait_stream(stream));
     if (direct) return dispatch<Tile256D>(g, !trans_a, trans_b != 0, ait_stream(stream));
     return dispatch<Tile256>(g, !trans_a, trans_b != 0, ait_stream(stream));

@@ -313,7 +313,7 @@ def rpn_forward(sd, cfgd, feat, im_info, gt_boxes, training, pre="RCNN_rpn."):
         keep = torch.nonzero(lab != -1).view(-1)
         loss_cls = F.cross_entropy(logits[keep], lab[keep].long())
         loss_box = smooth_l1(bbox_pred, targets, w_in, w_out, sigma=3, dims=(1, 2, 3))
-    return rois, loss_cls, loss_box, dict(cls_prob=cls_prob, bbox_pred=bbox_pred)
+    return rois, loss_cls, loss_box, dict(cls_prob=cls_prob, bbox_pred=bbox_pred, rpn_rois=rois.detach())
 
 
 def proposal_target_layer(cfgd, all_rois, gt_boxes):

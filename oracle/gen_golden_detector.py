@@ -207,4 +207,83 @@ def g11():
     _save("g11_detector_coco", out)
 
 
-GROUPS = {"g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
+def g12():
+    """What the reference's proposal layer hands to its NMS and what comes back (proposal_layer.py:
+    134-157): the decoded, clipped, score-sorted candidate boxes of every image and the kept indices
+    (first post_nms_topN, -1 padded).  Recorded by wrapping the module-level `nms` name."""
+    cfg = _cfg()
+    import model.rpn.proposal_layer as PL
+    out = {}
+    prob, deltas, info = rpn_case()
+    layer = PL._ProposalLayer(16, cfg.ANCHOR_SCALES, cfg.ANCHOR_RATIOS)
+    real = PL.nms
+    for key in ("TRAIN", "TEST"):
+        rec = []
+
+        def spy(boxes, scores, thr, _rec=rec):
+            keep = real(boxes, scores, thr)
+            _rec.append((boxes.clone().numpy(), keep.clone().numpy().reshape(-1), float(thr)))
+            return keep
+        PL.nms = spy
+        try:
+            layer((torch.from_numpy(prob), torch.from_numpy(deltas), torch.from_numpy(info), key))
+        finally:
+            PL.nms = real
+        post_n = cfg[key].RPN_POST_NMS_TOP_N
+        out["cand_" + key] = np.stack([r[0] for r in rec]).astype(np.float32)
+        keep = np.full((len(rec), post_n), -1, np.int32)
+        for i, r in enumerate(rec):
+            k = r[1][:post_n]
+            keep[i, :k.size] = k
+        out["keep_" + key] = keep
+        out["nkeep_" + key] = np.array([min(post_n, r[1].size) for r in rec], np.int32)
+        out["thr_" + key] = np.float32(rec[0][2])
+    _save("g12_proposal_nms", out)
+
+
+def g13():
+    """The proposal-layer outputs inside the g10 / g11 training forwards (seeds as there), so that
+    the GPU tests can hand the product's sampler / RoIAlign / AIT / heads the reference's OWN
+    proposals and compare labels and losses unconditionally."""
+    out = {}
+    m, cfg = _ref_model()
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    cfg.TRAIN.BATCH_SIZE = 128
+    np.random.seed(3)
+    ins = detector_ref.synth_inputs(1, 1001)
+    got = {}
+    h = m.RCNN_rpn.RPN_proposal.register_forward_hook(lambda mod, i, o: got.__setitem__("rois", o))
+    with torch.no_grad():
+        m(*ins)
+    h.remove()
+    out["voc_prop_rois"] = got["rois"].numpy()
+    # COCO variant (as g11)
+    import sys
+    saved = (list(cfg.ANCHOR_SCALES), cfg.MAX_NUM_GT_BOXES)
+    cfg.ANCHOR_SCALES = [4, 8, 16, 32]
+    cfg.MAX_NUM_GT_BOXES = 50
+    from model.faster_rcnn.resnet_coatt_transformer_sk import resnet
+    with contextlib.redirect_stdout(io.StringIO()):
+        mc = resnet(('__background__', 'fg'), 50, pretrained=False, class_agnostic=True, num_K=3)
+        mc.create_architecture()
+    sd = detector_ref.make_detector_state_dict(11, detector_ref.reference_shapes(A=12, variant="coco"))
+    mc.load_state_dict(sd, strict=False)
+    mc.train()
+    for mod in mc.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    ins = detector_ref.synth_inputs(1, 1101, max_gt=50)
+    np.random.seed(3)
+    h = mc.RCNN_rpn.RPN_proposal.register_forward_hook(lambda mod, i, o: got.__setitem__("rois", o))
+    with torch.no_grad():
+        mc(*ins)
+    h.remove()
+    out["coco_prop_rois"] = got["rois"].numpy()
+    cfg.ANCHOR_SCALES, cfg.MAX_NUM_GT_BOXES = saved
+    _save("g13_detector_proposals", out)
+
+
+GROUPS = {"g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12, "g13": g13}

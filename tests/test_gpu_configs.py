@@ -1,0 +1,162 @@
+"""BASELINE.json configs[2..4] on one GPU (one rank's share of the data-parallel job): the COCO-variant
+detector at 8 pairs x 300 proposals (cfg3 / cfg4) and ResNet101 + bf16 AIT GEMMs at 8 pairs x 512
+proposals (cfg5).  The reference cannot run these sizes on the CPU in test time, so the checks are the
+size-independent properties the domain offers -- batch invariance of the eval forward, reproducibility
+and finiteness of a training step, agreement of the bf16 mode with the fp32 mode within the stated bf16
+tolerance -- plus, at fixture size, the bf16 logits against the fp32 CPU oracle."""
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detector_ref as D
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def _coco_cfg(P, post_n):
+    from ait_amd import config
+    c = config.cfg
+    saved = (c.ANCHOR_SCALES, c.MAX_NUM_GT_BOXES, c.TRAIN.BATCH_SIZE, c.TEST.RPN_POST_NMS_TOP_N)
+    config.cfg_from_list(['ANCHOR_SCALES', [4, 8, 16, 32], 'MAX_NUM_GT_BOXES', 50, 'TRAIN.BATCH_SIZE', P,
+                          'TEST.RPN_POST_NMS_TOP_N', post_n])
+    try:
+        yield
+    finally:
+        c.ANCHOR_SCALES, c.MAX_NUM_GT_BOXES, c.TRAIN.BATCH_SIZE, c.TEST.RPN_POST_NMS_TOP_N = saved
+
+
+def _coco_model(n_layers, seed=11):
+    from ait_amd.faster_rcnn import resnet_coco
+    m = resnet_coco(('__background__', 'fg'), n_layers, pretrained=False, class_agnostic=True, num_K=3)
+    m.create_architecture()
+    sd = D.make_detector_state_dict(seed, D.reference_shapes(n_layers=n_layers, A=12, variant="coco"))
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    return m.cuda(), sd
+
+
+def _train_step(m, ins, seed=3):
+    m.train()
+    m.zero_grad(set_to_none=True)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    out = m(*ins)
+    loss = out[3] + out[4] + out[5] + out[6] + out[7]
+    loss.backward()
+    losses = torch.stack([out[3], out[4], out[5], out[6], out[7]]).detach().double().cpu()
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    return out, losses, grads
+
+
+def _eval_probs(m, ins):
+    m.eval()
+    with torch.no_grad():
+        out = m(*ins)
+    return out[0].cpu(), out[1].double().cpu()
+
+
+def test_cfg34_coco_variant_8_pairs_300_proposals():
+    """cfg3 / cfg4: one rank's 8 pairs x 300 proposals of the COCO variant (ResNet50)."""
+    with _coco_cfg(300, 300):
+        m, _ = _coco_model(50)
+        ins = [t.cuda() for t in D.synth_inputs(8, 2101, max_gt=50)]
+        # eval forward: a pair's result does not depend on which other pairs share its batch
+        rois8, prob8 = _eval_probs(m, ins)
+        rois3, prob3 = _eval_probs(m, [t[2:5] for t in ins])
+        assert tuple(rois8.shape) == (8, 300, 5)
+        assert torch.equal(rois8[2:5, :, 1:], rois3[:, :, 1:])
+        assert float((prob8[2:5] - prob3).abs().max()) <= 1e-5
+        # training step: finite, gradients on every trained parameter, reproducible under the same seeds
+        for mod in m.modules():
+            if hasattr(mod, "p") and isinstance(mod.p, float):
+                mod.p = 0.0
+        out, l1, g1 = _train_step(m, ins)
+        assert tuple(out[0].shape) == (8, 300, 5) and tuple(out[8].shape) == (8 * 300,)
+        assert bool(torch.isfinite(l1).all())
+        assert all(bool(torch.isfinite(g).all()) for g in g1.values())
+        assert "transformer.enc_emb.0.weight" in g1 and "coattention_module.coattention.emb.weight" in g1
+        gnorm1 = {k: float(v.double().norm()) for k, v in g1.items()}
+        _, l2, g2 = _train_step(m, ins)
+        # (MIOpen's split-K convolution kernels accumulate with atomics: last-bit differences)
+        assert float((l1 - l2).abs().max()) <= 2e-4 * float(l1.abs().max()) + 1e-6
+        for k in ("transformer.enc_emb.0.weight", "RCNN_cls_score.1.weight", "RCNN_rpn.RPN_Conv.weight"):
+            assert abs(float(g2[k].double().norm()) - gnorm1[k]) <= 1e-3 * gnorm1[k] + 1e-9
+
+
+def test_cfg5_resnet101_coco_bf16_8_pairs_512_proposals():
+    """cfg5 (cfgs/res101.yml): ResNet101, COCO variant, 512 proposals, 8 pairs per GPU, bf16 matrix-core
+    GEMMs in the AIT (fp32 accumulate; fp32 elsewhere).  The reference has no bf16 path, so:
+    eval batch invariance, a finite training step with gradients everywhere, and agreement with the
+    SAME step in fp32 mode within the bf16 tolerance (losses 2e-2 relative, gradient norms 5e-2)."""
+    from ait_amd import ops
+    with _coco_cfg(512, 512):
+        m, _ = _coco_model(101)
+        ins = [t.cuda() for t in D.synth_inputs(8, 2201, max_gt=50)]
+        for mod in m.modules():
+            if hasattr(mod, "p") and isinstance(mod.p, float):
+                mod.p = 0.0
+        ops.set_matmul_dtype("bf16")
+        try:
+            rois8, prob8 = _eval_probs(m, ins)
+            rois2, prob2 = _eval_probs(m, [t[5:7] for t in ins])
+            assert tuple(rois8.shape) == (8, 512, 5)
+            assert torch.equal(rois8[5:7, :, 1:], rois2[:, :, 1:])
+            assert float((prob8[5:7] - prob2).abs().max()) <= 1e-5
+            out, lb, gb = _train_step(m, ins)
+            gb = {k: float(v.double().norm()) for k, v in gb.items()}
+        finally:
+            ops.set_matmul_dtype("f32")
+        assert tuple(out[0].shape) == (8, 512, 5)
+        assert bool(torch.isfinite(lb).all()) and all(np.isfinite(v) for v in gb.values())
+        assert "RCNN_base.backbone.layer3.22.conv3.weight" in gb and "transformer.dec_trans.0.weight" in gb
+        _, lf, gf = _train_step(m, ins)
+        gf = {k: float(v.double().norm()) for k, v in gf.items()}
+        rel = ((lb - lf).abs() / (lf.abs() + 1e-3)).max()
+        assert float(rel) <= 2e-2, (lb, lf)
+        assert float((lb - lf).abs().max()) > 0.0          # the switch really changed the arithmetic
+        for k in ("transformer.enc_emb.0.weight", "transformer.dec_trans.0.weight", "RCNN_cls_score.0.weight",
+                  "RCNN_base.backbone.layer3.22.conv3.weight"):
+            assert abs(gb[k] - gf[k]) <= 5e-2 * gf[k] + 1e-9, (k, gb[k], gf[k])
+        assert torch.cuda.max_memory_allocated() < 100 * 2 ** 30
+
+
+def test_cfg5_bf16_logits_vs_fp32_oracle_at_fixture_size():
+    """ResNet101 COCO variant, 1 pair, 320x480 target, 64 proposals, eval: similarity probabilities of
+    the bf16 mode against the fp32 CPU oracle on the oracle's own RoIs.  Stated bf16 tolerance: 2e-2
+    relative L2 on the logits (8 significand bits through 12 GEMMs), 5e-3 absolute on probabilities."""
+    from ait_amd import ops
+    with _coco_cfg(64, 64):
+        m, sd = _coco_model(101)
+        ins = D.synth_inputs(1, 2301, im_hw=(320, 480), max_gt=50)
+        cfgd = D.default_config()
+        cfgd["ANCHOR_SCALES"], cfgd["MAX_NUM_GT_BOXES"] = [4, 8, 16, 32], 50
+        cfgd["TEST"]["RPN_POST_NMS_TOP_N"] = 64
+        with torch.no_grad():
+            want, aux = D.detector_forward(sd, cfgd, *ins, False)
+        fixed = want[0].cuda()
+        feats = {}
+        h = [m.RCNN_rpn.RPN_proposal.register_forward_hook(lambda mod, i, o: fixed),
+             m.RCNN_cls_score.register_forward_hook(lambda mod, i, o: feats.__setitem__("score", o))]
+        m.eval()
+        try:
+            with torch.no_grad():
+                got32 = m(*[t.cuda() for t in ins])
+            s32 = feats["score"].double().cpu()
+            ops.set_matmul_dtype("bf16")
+            with torch.no_grad():
+                got16 = m(*[t.cuda() for t in ins])
+            s16 = feats["score"].double().cpu()
+        finally:
+            ops.set_matmul_dtype("f32")
+            for x in h:
+                x.remove()
+        ref = aux["score"].double()
+        # fp32 mode: the 1e-4 bar of north_star; bf16 mode: the stated bf16 tolerance
+        np.testing.assert_allclose(s32.numpy(), ref.numpy(), rtol=1e-4, atol=2e-6)
+        rel = float((s16 - ref).norm() / ref.norm())
+        assert 1e-6 < rel <= 2e-2, rel
+        assert float((got16[1].double().cpu() - want[1].double()).abs().max()) <= 5e-3
+        assert float((got32[1].double().cpu() - want[1].double()).abs().max()) <= 1e-5

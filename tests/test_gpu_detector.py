@@ -1,5 +1,8 @@
 """GPU parity of the detector assembly (ait_amd.faster_rcnn / ait_amd.rpn over libait_hip.so)
 against the reference's golden vectors g7..g10 and the CPU oracle."""
+import contextlib
+import warnings
+
 import numpy as np
 import pytest
 import torch
@@ -29,7 +32,7 @@ def _rows_match(got, want, atol=2e-3):
 
 
 @pytest.mark.parametrize("key", ["TRAIN", "TEST"])
-def test_proposal_layer_vs_reference_golden(golden, key):
+def test_proposal_layer_vs_reference_golden(golden, key, record_property):
     from ait_amd.rpn import _ProposalLayer
     g = golden("g7_proposal_layer")
     prob, deltas, info = cases.rpn_case()
@@ -37,7 +40,30 @@ def test_proposal_layer_vs_reference_golden(golden, key):
     rois = layer((_dev(prob), _dev(deltas), _dev(info), key)).cpu().numpy()
     want = g["rois_" + key]
     assert rois.shape == want.shape
+    n_diff = int((np.abs(rois - want).max(-1) > 2e-3).sum())
+    record_property("rows_differing_from_reference", n_diff)
+    if n_diff:
+        warnings.warn("proposal layer (%s): %d of %d rows differ from the reference (GPU exp() ulp moved a "
+                      "box across the NMS threshold)" % (key, n_diff, want.shape[0] * want.shape[1]))
     assert _rows_match(rois, want) >= 0.995
+
+
+@pytest.mark.parametrize("key", ["TRAIN", "TEST"])
+def test_nms_on_reference_candidates_index_identity(golden, key):
+    """The boxes the REFERENCE's proposal layer hands to its NMS (decoded, clipped, score-sorted:
+    golden g12, proposal_layer.py:134-153) through ait_nms_batched: kept indices identical, image by
+    image -- index identity through the layer without the GPU-vs-CPU exp() of the decode in between."""
+    from ait_amd.roi_layers import nms_sorted, nms_sorted_batched
+    g = golden("g12_proposal_nms")
+    cand, want, n_want = g["cand_" + key], g["keep_" + key], g["nkeep_" + key]
+    post_n = want.shape[1]
+    keep, cnt = nms_sorted_batched(_dev(cand), float(g["thr_" + key]), post_n)
+    for b in range(cand.shape[0]):
+        c = int(cnt[b].item())
+        assert c == int(n_want[b])
+        assert np.array_equal(keep[b, :c].cpu().numpy(), want[b, :c].astype(np.int64))
+        k1, c1 = nms_sorted(_dev(cand[b]), float(g["thr_" + key]), post_n)      # per-image entry point
+        assert int(c1.item()) == c and np.array_equal(k1[:c].cpu().numpy(), want[b, :c].astype(np.int64))
 
 
 def test_anchor_grid_bit_exact(golden):
@@ -113,32 +139,61 @@ def test_detector_eval_forward_cfg1(golden, model):
     np.testing.assert_allclose(out[2].cpu().numpy()[0][same], g["bbox_pred"][0][same], rtol=1e-3, atol=2e-6)
 
 
+@contextlib.contextmanager
+def _dropout_off(model):
+    """parity is defined at dropout p = 0"""
+    saved = [(m, m.p) for m in model.modules() if hasattr(m, "p") and isinstance(m.p, float)]
+    for m, _ in saved:
+        m.p = 0.0
+    try:
+        yield
+    finally:
+        for m, p in saved:
+            m.p = p
+
+
+@contextlib.contextmanager
+def _reference_proposals(model, rois):
+    """Replace the proposal layer's output by the REFERENCE's own proposals of the same forward
+    (golden g13): everything downstream -- both samplers under the reference's RNG order, RoIAlign,
+    the AIT, SK, layer4, heads, losses -- then runs on exactly the reference's boxes, so labels and
+    losses compare unconditionally (no dependence on a GPU-vs-CPU exp() ulp in the box decode)."""
+    layer = model.RCNN_rpn.RPN_proposal
+    fixed = torch.from_numpy(np.ascontiguousarray(rois)).cuda()
+    h = layer.register_forward_hook(lambda mod, i, o: fixed.to(o.dtype))
+    try:
+        yield
+    finally:
+        h.remove()
+
+
 @pytest.mark.parametrize("P", [128, 300])
-def test_detector_train_forward_losses(golden, model, P):
+def test_detector_train_forward_losses(golden, model, P, record_property):
     from ait_amd.config import cfg
     g = golden("g10_detector_train")
+    props = golden("g13_detector_proposals")["voc_prop_rois"]
     cfg.TRAIN.BATCH_SIZE = P
     model.train()
-    saved = []
-    for mod in model.modules():                      # parity is defined at dropout p = 0
-        if hasattr(mod, "p") and isinstance(mod.p, float):
-            saved.append((mod, mod.p))
-            mod.p = 0.0
-    try:
+    ins = [t.cuda() for t in D.synth_inputs(1, 1001)]
+    with _dropout_off(model):
         np.random.seed(3)
-        im, qr, info, gt, nb = [t.cuda() for t in D.synth_inputs(1, 1001)]
         with torch.no_grad():
-            out = model(im, qr, info, gt, nb)
-    finally:
-        for mod, p in saved:
-            mod.p = p
-    rois = out[0].cpu().numpy()
-    frac = _rows_match(rois, g["P%d_rois" % P])
+            out = model(*ins)
+        np.random.seed(3)
+        with torch.no_grad(), _reference_proposals(model, props):
+            ref_in = model(*ins)
+    # (1) the product's own proposals: the sampled RoI set is the reference's up to boundary cases
+    frac = _rows_match(out[0].cpu().numpy(), g["P%d_rois" % P])
+    record_property("sampled_roi_rows_matching_reference", frac)
     assert frac >= 0.98, frac
-    if frac == 1.0:                                  # identical sampled RoIs -> identical targets
-        assert np.array_equal(out[8].cpu().numpy(), g["P%d_labels" % P])
-        losses = np.array([float(x) for x in out[3:8]])
-        np.testing.assert_allclose(losses, g["P%d_losses" % P], rtol=2e-4, atol=2e-6)
+    # the RPN losses do not depend on the proposals: always comparable
+    np.testing.assert_allclose(np.array([float(out[3]), float(out[4])]), g["P%d_losses" % P][:2], rtol=2e-4, atol=2e-6)
+    # (2) on the reference's proposals: identical sampled RoIs, labels and all five losses -- unconditional
+    np.testing.assert_allclose(ref_in[0].cpu().numpy(), g["P%d_rois" % P], rtol=0, atol=1e-4)
+    assert np.array_equal(ref_in[8].cpu().numpy(), g["P%d_labels" % P])
+    losses = np.array([float(x) for x in ref_in[3:8]])
+    np.testing.assert_allclose(losses, g["P%d_losses" % P], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(ref_in[1].cpu().numpy(), g["P%d_cls_prob" % P], rtol=1e-4, atol=1e-6)
 
 
 def test_detector_train_step_gradients_vs_oracle(model):
@@ -156,22 +211,17 @@ def test_detector_train_step_gradients_vs_oracle(model):
         sd[k].requires_grad_(True)
     ins = D.synth_inputs(1, 1101)
     np.random.seed(3)
-    out, _ = D.detector_forward(sd, cfgd, *ins, True)
+    out, _aux = D.detector_forward(sd, cfgd, *ins, True)
     (out[3] + out[4] + out[5] + out[6] + out[7]).backward()
     model.train()
-    saved = [(m, m.p) for m in model.modules() if hasattr(m, "p") and isinstance(m.p, float)]
-    for m, _ in saved:
-        m.p = 0.0
-    try:
+    # the oracle's own proposals are injected into the product (as _reference_proposals does with the
+    # reference's): the comparison below never depends on a GPU-vs-CPU ulp in the box decode
+    with _dropout_off(model), _reference_proposals(model, _aux["rpn_rois"].numpy()):
         model.zero_grad(set_to_none=True)
         np.random.seed(3)
         res = model(*[t.cuda() for t in ins])
         (res[3] + res[4] + res[5] + res[6] + res[7]).backward()
-    finally:
-        for m, p in saved:
-            m.p = p
-    if _rows_match(res[0].cpu().numpy(), out[0].numpy()) < 1.0:
-        pytest.skip("RoI set differs by a boundary case; gradient comparison not meaningful")
+    np.testing.assert_allclose(res[0].cpu().numpy(), out[0].numpy(), rtol=0, atol=1e-4)
     params = dict(model.named_parameters())
     for i in range(3, 8):
         assert abs(float(res[i]) - float(out[i])) <= 2e-4 * abs(float(out[i])) + 2e-6
@@ -205,18 +255,22 @@ def test_detector_coco_variant(golden):
         same = np.abs(out[0].cpu().numpy() - g["rois"]).max(-1)[0] <= 2e-3
         assert same.mean() >= 0.98
         np.testing.assert_allclose(feats["score"].cpu().numpy()[same], g["score"][same], rtol=1e-4, atol=2e-6)
-        # training forward: sampled RoIs / labels / losses
+        # training forward: sampled RoIs / labels / losses, on the product's own proposals (RoI set
+        # up to boundary cases, RPN losses exact) and on the reference's proposals (everything)
         m.train()
-        for mod in m.modules():
-            if hasattr(mod, "p") and isinstance(mod.p, float):
-                mod.p = 0.0
         config.cfg.TRAIN.BATCH_SIZE = 128
-        np.random.seed(3)
-        with torch.no_grad():
-            out = m(*ins)
-        if _rows_match(out[0].cpu().numpy(), g["train_rois"]) == 1.0:
-            assert np.array_equal(out[8].cpu().numpy(), g["train_labels"])
-            np.testing.assert_allclose(np.array([float(x) for x in out[3:8]]), g["train_losses"], rtol=2e-4, atol=2e-6)
+        with _dropout_off(m):
+            np.random.seed(3)
+            with torch.no_grad():
+                out = m(*ins)
+            np.random.seed(3)
+            with torch.no_grad(), _reference_proposals(m, golden("g13_detector_proposals")["coco_prop_rois"]):
+                ref_in = m(*ins)
+        assert _rows_match(out[0].cpu().numpy(), g["train_rois"]) >= 0.98
+        np.testing.assert_allclose(np.array([float(out[3]), float(out[4])]), g["train_losses"][:2], rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(ref_in[0].cpu().numpy(), g["train_rois"], rtol=0, atol=1e-4)
+        assert np.array_equal(ref_in[8].cpu().numpy(), g["train_labels"])
+        np.testing.assert_allclose(np.array([float(x) for x in ref_in[3:8]]), g["train_losses"], rtol=2e-4, atol=2e-6)
     finally:
         config.cfg.ANCHOR_SCALES, config.cfg.MAX_NUM_GT_BOXES = saved
 

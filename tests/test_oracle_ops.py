@@ -74,3 +74,17 @@ def test_nms_ties_suppress_on_equal(golden):
     assert np.array_equal(native.nms(box2, sc2, 0.7), g["keep_int2000_t07"])
     assert native.nms(np.zeros((0, 4), np.float32), np.zeros((0,), np.float32), 0.7).shape == (0,)
     assert g["keep_empty"].shape == (0,)
+
+
+@pytest.mark.parametrize("key", ["TRAIN", "TEST"])
+def test_nms_on_the_reference_proposal_layer_candidates(golden, key):
+    """golden g12: the boxes the reference's proposal layer hands to its NMS (proposal_layer.py:134-153)
+    and the indices it keeps; the C restatement reproduces them image by image."""
+    g = golden("g12_proposal_nms")
+    cand, want, n_want = g["cand_" + key], g["keep_" + key], g["nkeep_" + key]
+    for b in range(cand.shape[0]):
+        n = cand.shape[1]
+        scores = np.linspace(1.0, 0.0, n, dtype=np.float32)            # already sorted by descending score
+        keep = native.nms(cand[b], scores, float(g["thr_" + key]))[:want.shape[1]]
+        assert keep.size == int(n_want[b])
+        assert np.array_equal(keep, want[b, :keep.size].astype(np.int64))

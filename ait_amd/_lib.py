@@ -18,6 +18,12 @@ _ll, _ull = ctypes.c_longlong, ctypes.c_ulonglong
 SIGNATURES = {
     "ait_abi_version": (_i, []),
     "ait_strerror": (ctypes.c_char_p, [_i]),
+    "ait_probe_create": (_vp, [_i]),
+    "ait_probe_destroy": (None, [_vp]),
+    "ait_probe_attach": (None, [_vp]),
+    "ait_probe_reset": (_i, [_vp]),
+    "ait_probe_count": (_i, [_vp]),
+    "ait_probe_get": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "ait_roi_align_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "ait_roi_align_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "ait_roi_align_nhwc_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
@@ -44,8 +50,25 @@ SIGNATURES = {
     "ait_transformer_workspace_bytes": (_sz, [_i, _i, _i]),
     "ait_transformer_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
     "ait_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp, _vp, _vp]),
-    "ait_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _ull, _vp, _vp,
-                        _vp, _vp, _vp]),
+    "ait_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _ull, _vp, _vp,
+                        _vp, _vp, _vp, _vp]),
+    "ait_colsum_f32": (_i, [_vp, _ll, _i, _ll, _vp, _vp]),
+    "ait_rep_sum_f32": (_i, [_vp, _i, _i, _ll, _vp, _vp]),
+    "ait_dropout_seed": (_ull, [_ull, _i]),
+    "ait_mha_block_saved_bytes": (_sz, [_i, _i]),
+    "ait_mha_block_fwd_train": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _vp]),
+    "ait_mha_block_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "ait_mha_block_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp,
+                               _vp, _vp]),
+    "ait_ffn_saved_bytes": (_sz, [_ll]),
+    "ait_ffn_fwd_train": (_i, [_vp, _ll, _vp, _f, _ull, _vp, _sz, _vp, _vp]),
+    "ait_ffn_bwd_workspace_bytes": (_sz, [_ll]),
+    "ait_ffn_bwd": (_i, [_vp, _vp, _ll, _vp, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "ait_transformer_saved_bytes": (_sz, [_i, _i, _i]),
+    "ait_transformer_fwd_train": (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _vp]),
+    "ait_transformer_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ait_transformer_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp,
+                                 _vp, _vp]),
     "ait_sh_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ait_sh_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ait_attn_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp,
@@ -96,6 +119,68 @@ class TransformerWeights(ctypes.Structure):
         "enc_ln_g", "enc_ln_b", "dec_ln_g", "dec_ln_b", "pos_table")] + \
         [("enc_slf", MhaWeights), ("dec_slf", MhaWeights), ("dec_enc", MhaWeights),
          ("enc_ffn", FfnWeights), ("dec_ffn", FfnWeights)]
+
+
+# the gradient structs have the members of the weight structs (ait_mha_grads / ait_ffn_grads), and
+# ait_transformer_grads those of ait_transformer_weights without pos_table
+MhaGrads, FfnGrads = MhaWeights, FfnWeights
+
+
+class TransformerGrads(ctypes.Structure):
+    """ait_transformer_grads."""
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "enc_emb_w", "enc_emb_b", "dec_emb_w", "dec_emb_b", "dec_trans_w", "dec_trans_b",
+        "enc_ln_g", "enc_ln_b", "dec_ln_g", "dec_ln_b")] + \
+        [("enc_slf", MhaGrads), ("dec_slf", MhaGrads), ("dec_enc", MhaGrads),
+         ("enc_ffn", FfnGrads), ("dec_ffn", FfnGrads)]
+
+
+PROBE_GEMM, PROBE_ROI_FWD, PROBE_ROI_BWD = 1, 2, 3
+
+
+class Probe:
+    """Measurement probe of include/ait_hip.h: while attached (to the calling thread), every GEMM / RoIAlign
+    launch of the library is bracketed by HIP events on its launch stream.
+
+        with Probe(20000) as pr:  ...run...
+        torch.cuda.synchronize(); rows = pr.entries()   # [(kind, work, ms, dims6), ...]
+    """
+
+    def __init__(self, capacity=65536):
+        self._L = lib()
+        self._p = self._L.ait_probe_create(int(capacity))
+        if not self._p:
+            raise AitHipError("ait_probe_create failed")
+
+    def __enter__(self):
+        self._L.ait_probe_reset(self._p)
+        self._L.ait_probe_attach(self._p)
+        return self
+
+    def __exit__(self, *exc):
+        self._L.ait_probe_attach(None)
+        return False
+
+    def entries(self):
+        out = []
+        kind, work, ms = ctypes.c_int(), ctypes.c_double(), ctypes.c_float()
+        dims = (ctypes.c_int * 6)()
+        for i in range(self._L.ait_probe_count(self._p)):
+            rc = self._L.ait_probe_get(self._p, i, ctypes.byref(kind), ctypes.byref(work), ctypes.byref(ms), dims)
+            check(rc, "ait_probe_get (synchronise the stream first)")
+            out.append((kind.value, work.value, ms.value, tuple(dims)))
+        return out
+
+    def close(self):
+        if self._p:
+            self._L.ait_probe_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def check(rc: int, what: str):

@@ -15,6 +15,38 @@
 
 static inline hipStream_t ait_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- measurement probe (include/ait_hip.h "Measurement"): while a probe is attached to the calling
+// thread, the instrumented entry points bracket their launches with a HIP event pair on the launch
+// stream and note the algorithmic work.  Detached (the default): one thread-local pointer test.
+struct AitProbeEntry {
+  int kind;
+  double work;            // flops (AIT_PROBE_GEMM) or algorithmic bytes
+  int dims[6];
+  hipEvent_t e0, e1;
+};
+struct AitProbe {
+  int cap, n;
+  AitProbeEntry* e;
+};
+AitProbe* ait_probe_current();
+struct AitProbeScope {
+  AitProbeEntry* ent = nullptr;
+  hipStream_t s;
+  AitProbeScope(int kind, double work, hipStream_t stream, int d0 = 0, int d1 = 0, int d2 = 0, int d3 = 0, int d4 = 0,
+                int d5 = 0)
+      : s(stream) {
+    AitProbe* p = ait_probe_current();
+    if (!p || p->n >= p->cap) return;
+    ent = &p->e[p->n++];
+    ent->kind = kind; ent->work = work;
+    ent->dims[0] = d0; ent->dims[1] = d1; ent->dims[2] = d2; ent->dims[3] = d3; ent->dims[4] = d4; ent->dims[5] = d5;
+    (void)hipEventRecord(ent->e0, s);
+  }
+  ~AitProbeScope() {
+    if (ent) (void)hipEventRecord(ent->e1, s);
+  }
+};
+
 // MI355X dispatches workgroups round-robin over its 8 XCDs (blocks b and b+8 share an L2).
 // `xcd_major` turns a linear block id into (xcd_slot, index-within-slot) so that all blocks
 // that share one XCD's L2 can be given work that shares operands.  Speed only, never

@@ -259,8 +259,9 @@ int launch_bf16(const GemmArgs& g, hipStream_t s) {
   }
   auto kern = gemm_bf16_kernel<C, AK, BKC, EPI>;
   if (C::LDS_BYTES > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)C::LDS_BYTES) != hipSuccess)
+      return AIT_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(C::NT), C::LDS_BYTES, s, g);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
@@ -277,7 +278,9 @@ int dispatch_layout_bf16(const GemmArgs& g, bool ak, bool bk, hipStream_t s) {
 template <class C>
 int dispatch_bf16(const GemmArgs& g, bool ak, bool bk, hipStream_t s) {
   if (g.flags & AIT_GEMM_ATOMIC) return dispatch_layout_bf16<C, EPI_ATOMIC>(g, ak, bk, s);
-  if (g.residual || (g.flags & (AIT_GEMM_ACCUMULATE | AIT_GEMM_MASK_POS)))
+  const bool row_bias = g.bias && (g.flags & AIT_GEMM_BIAS_ROW);
+  if (g.residual && !(g.flags & AIT_GEMM_ACCUMULATE) && !row_bias) return dispatch_layout_bf16<C, EPI_RES>(g, ak, bk, s);
+  if (g.residual || (g.flags & (AIT_GEMM_ACCUMULATE | AIT_GEMM_MASK_POS)) || row_bias)
     return dispatch_layout_bf16<C, EPI_AUX>(g, ak, bk, s);
   return dispatch_layout_bf16<C, EPI_STORE>(g, ak, bk, s);
 }
@@ -295,6 +298,7 @@ int run_gemm(bool split3, int trans_a, int trans_b, int M, int N, int K, float a
                            flags, split_k, c_colblk, c_batch_stride, BK, g);
   if (rc != AIT_OK) return rc;
   hipStream_t s = ait_stream(stream);
+  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * M * N * K, s, M, N, K, trans_a, trans_b, g.splits);
   if (split3) return dispatch_bf16<SplitTile>(g, !trans_a, trans_b != 0, s);
   return dispatch_bf16<Bf16Tile>(g, !trans_a, trans_b != 0, s);
 }

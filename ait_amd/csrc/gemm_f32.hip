@@ -63,6 +63,7 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   const int rc = make_args(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
                            flags, split_k, c_colblk, c_batch_stride, Tile128::BK, g);
   if (rc != AIT_OK) return rc;
+  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * M * N * K, ait_stream(stream), M, N, K, trans_a, trans_b, g.splits);
   // operand "K-contiguous" means the reduction dimension is the fast one in memory:
   //   A: !trans_a  (A is [M,K]);   B: trans_b (B is [N,K])
   const long long tiles256 = (long long)((M + 255) / 256) * ((N + 127) / 128) * g.splits;

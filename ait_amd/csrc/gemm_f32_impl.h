@@ -41,16 +41,24 @@ enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
 
 // Tile configuration: BM x BN output tile, K-slabs of BK, WM x WN wavefronts each owning
 // (BM/WM/32) x (BN/WN/32) MFMA tiles of 32x32.
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int MODE_ = MODE_DB>
+// MODE_DLDS only: NS_ = slots of the slab ring (3: the slab requested during an iteration is awaited at
+// its end; 4: one more slab stays in flight across the barrier, counted vmcnt), KNOBS_ = scheduling
+// choices that do not change results (measured with scripts/gemm_lab.hip):
+//   KNOB_BURST  the transfers of a slab are issued back to back at the top of the iteration instead of one
+//               behind each of the first MFMA steps
+//   KNOB_PRIO   the second-dispatched half of the workgroup's waves runs at s_setprio 1
+enum { KNOB_BURST = 1, KNOB_PRIO = 2 };
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int MODE_ = MODE_DB, int NS_ = 3, int KNOBS_ = 0>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_, MODE = MODE_;
+  static constexpr int NS = NS_, KNOBS = KNOBS_;
   static constexpr int NT = 64 * WM * WN;          // threads
   static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   static constexpr int PA = BM + 4, PB = BN + 4;   // LDS pitches (floats), 16-B aligned rows
   static constexpr int VA = BM * BK / 4 / NT;      // float4 per thread per A slab
   static constexpr int VB = BN * BK / 4 / NT;
   static constexpr int NBUF = (MODE_ == MODE_DB) ? 2 : 3;
-  static constexpr size_t LDS = (MODE_ == MODE_DLDS) ? sizeof(float) * 3 * BK * (BM + BN)
+  static constexpr size_t LDS = (MODE_ == MODE_DLDS) ? sizeof(float) * NS_ * BK * (BM + BN)
                                                      : sizeof(float) * NBUF * BK * (PA + PB);
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile / wave mismatch");
   static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "slab / thread mismatch");
@@ -162,23 +170,90 @@ __device__ __forceinline__ void fetch_group(const float* __restrict__ slab, int 
 //   forward  y = x W^T   : A = x [M,K] (AK), B = W [N,K] (BKC)
 //   dgrad    dx = dy W   : A = dy [M,K'] (AK), B = W [K',N] (!BKC)
 //   wgrad    dW = dy^T x : A = dy [K',M] (!AK), B = x [K',N] (!BKC)
-enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_AUX = 2 };
+enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_AUX = 2, EPI_RES = 3 };
 
 // C/D layout of the 32x32 MFMA (any input dtype): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // EPI selects the epilogue at compile time (a run-time flag test per element makes hipcc branch
 // around every load/store and wait vmcnt(0) each time):
-//   EPI_STORE  C = alpha*acc (+bias) (relu)            -- no loads at all
+//   EPI_STORE  C = alpha*acc (+bias) (relu)            -- no loads between the stores
 //   EPI_ATOMIC C += alpha*acc with fp32 atomics        -- split-K partial tiles
-//   EPI_AUX    the forms that read memory: +residual, ReLU-backward gate, accumulate into C
+//   EPI_RES / EPI_AUX  the forms that read memory (see below)
 // Addressing: element offsets are 32-bit (make_args rejects outputs of 2^31 elements or more), formed
 // as (uniform base pointer) + (per-lane unsigned offset) so that hipcc emits the saddr + voffset form
 // of the global instructions: one VGPR per address instead of a 64-bit pair per store.
+//
+// The epilogue must not put a LOAD between its stores: vmcnt retires in order, so waiting for a load
+// issued after a store waits for that store's full round trip to memory (~2 us under load), once per
+// group of stores -- measured at ~20 us per 256x128 tile in the first version of this file, where the
+// per-element `bias ? bias[..] : 0` selects compiled to branches around loads.  Hence:
+//   EPI_STORE   takes only the column-bias form (dispatch() sends row biases to EPI_AUX); the TN bias
+//               values of a lane are loaded ONCE, before any store;
+//   EPI_RES     "+ residual" and the ReLU-backward gate (the two forms the training path uses on large
+//               products): software-pipelined, the loads of the next half tile go out before the stores
+//               of the current one;
+//   EPI_AUX     everything else (accumulate into C, row bias, combinations): loads in uniform-branch
+//               blocks before each half tile's stores (small / rare launches).
 template <int TM, int TN, int EPI>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& g, int m0, int n0,
                                          int wm, int wn, int li, int lk) {
   const bool relu = (g.flags & AIT_GEMM_RELU) != 0;
-  const bool bias_row = (g.flags & AIT_GEMM_BIAS_ROW) != 0;
   const unsigned ldc = (unsigned)g.ldc;
+  const bool interior = (m0 + wm + TM * 32 <= g.M) && (n0 + wn + TN * 32 <= g.N);   // wave-uniform
+  // row r of an MFMA tile sits (r&3) + 8*(r>>2) rows below its first row
+#define AIT_ROW(r) (((r) & 3) + 8 * ((r) >> 2))
+  float bcol[TN];
+#pragma unroll
+  for (int b = 0; b < TN; b++) bcol[b] = 0.f;
+  if (EPI != EPI_ATOMIC && g.bias && !(g.flags & AIT_GEMM_BIAS_ROW)) {
+#pragma unroll
+    for (int b = 0; b < TN; b++) bcol[b] = g.bias[min(n0 + wn + b * 32 + li, g.N - 1)];
+  }
+  // column part of the element offset, per tile column b
+  unsigned cb[TN];
+  bool cok[TN];
+#pragma unroll
+  for (int b = 0; b < TN; b++) {
+    const int col = n0 + wn + b * 32 + li;
+    cok[b] = col < g.N;
+    const int colc = cok[b] ? col : 0;
+    cb[b] = g.c_colblk > 0 ? (unsigned)(colc / g.c_colblk) * (unsigned)g.c_batch + (unsigned)(colc % g.c_colblk)
+                           : (unsigned)colc;
+  }
+
+  if (EPI == EPI_RES) {
+    // ---- residual add / ReLU-backward gate, software-pipelined over the 4*TM*TN quarter tiles (4 rows
+    // each): the loads of quarter i+1 are issued BEFORE the stores of quarter i, so the wait for them is
+    // a counted vmcnt that leaves those stores in flight
+    const bool mask_pos = (g.flags & AIT_GEMM_MASK_POS) != 0;
+    constexpr int NQ = 4 * TM * TN;
+    float x[4], xn[4];
+    auto row_of = [&](int i, int q) { return m0 + wm + (i / (4 * TN)) * 32 + 4 * lk + 8 * (i & 3) + q; };
+    auto col_of = [&](int i) { return (i / 4) % TN; };
+#pragma unroll
+    for (int q = 0; q < 4; q++) x[q] = g.residual[cb[col_of(0)] + (unsigned)min(row_of(0, q), g.M - 1) * ldc];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+      const int a = i / (4 * TN), b = col_of(i);
+      if (i + 1 < NQ) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) xn[q] = g.residual[cb[col_of(i + 1)] + (unsigned)min(row_of(i + 1, q), g.M - 1) * ldc];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float v = g.alpha * acc[a][b][4 * (i & 3) + q] + bcol[b];
+        v = mask_pos ? (x[q] > 0.f ? v : 0.f) : v + x[q];
+        if (relu) v = fmaxf(v, 0.f);
+        const int row = row_of(i, q);
+        if (interior || (cok[b] && row < g.M)) g.C[cb[b] + (unsigned)row * ldc] = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; q++) x[q] = xn[q];
+    }
+    return;
+  }
+
 #pragma unroll
   for (int a = 0; a < TM; a++)
 #pragma unroll
@@ -186,63 +261,67 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
       // one MFMA tile at a time (the fence keeps hipcc from interleaving the address arithmetic of all
       // tiles, which does not fit the 128-register budget of the two-workgroups-per-CU kernels)
       __builtin_amdgcn_sched_barrier(0);
-      const int col = n0 + wn + b * 32 + li;
-      const bool col_ok = col < g.N;
-      const int colc = col_ok ? col : 0;
-      unsigned cbase;
-      if (g.c_colblk > 0)
-        cbase = (unsigned)(colc / g.c_colblk) * (unsigned)g.c_batch + (unsigned)(colc % g.c_colblk);
-      else
-        cbase = (unsigned)colc;
       const int rbase = m0 + wm + a * 32 + 4 * lk;
+      const unsigned obase = cb[b] + (unsigned)rbase * ldc;     // element offset of (rbase, col)
       if (EPI == EPI_ATOMIC) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (col_ok && row < g.M) unsafeAtomicAdd(g.C + (cbase + (unsigned)row * ldc), g.alpha * acc[a][b][r]);
+          if (interior || (cok[b] && rbase + AIT_ROW(r) < g.M))
+            unsafeAtomicAdd(g.C + (obase + (unsigned)AIT_ROW(r) * ldc), g.alpha * acc[a][b][r]);
         }
       } else {
-        const float bcol = (g.bias && !bias_row) ? g.bias[colc] : 0.f;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {      // two halves of 8 accumulator registers
+        for (int h = 0; h < 2; h++) {
           float v[8];
 #pragma unroll
-          for (int q = 0; q < 8; q++) {
-            const int r = h * 8 + q;
-            const int row = rbase + (r & 3) + 8 * (r >> 2);
-            v[q] = g.alpha * acc[a][b][r] + (bias_row ? (g.bias ? g.bias[min(row, g.M - 1)] : 0.f) : bcol);
-          }
+          for (int q = 0; q < 8; q++) v[q] = g.alpha * acc[a][b][h * 8 + q] + bcol[b];
           if (EPI == EPI_AUX) {
-            const bool mask_pos = (g.flags & AIT_GEMM_MASK_POS) != 0;
-            const bool accum = (g.flags & AIT_GEMM_ACCUMULATE) != 0;
-            float x[8], y[8];
-            // all loads first (clamped addresses, unconditional), then the arithmetic
+            // the general form (accumulate into C, row bias, any combination): loads in uniform-branch
+            // blocks, then the arithmetic.  (Every such load waits for the stores before it: this path
+            // serves small / rare launches only.)
+            unsigned off[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-              const int r = h * 8 + q;
-              const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
-              const unsigned off = cbase + (unsigned)row * ldc;
-              x[q] = g.residual ? g.residual[off] : 0.f;
-              y[q] = accum ? g.C[off] : 0.f;
+            for (int q = 0; q < 8; q++) off[q] = cb[b] + (unsigned)min(rbase + AIT_ROW(h * 8 + q), g.M - 1) * ldc;
+            if (g.bias && (g.flags & AIT_GEMM_BIAS_ROW)) {
+#pragma unroll
+              for (int q = 0; q < 8; q++) v[q] += g.bias[min(rbase + AIT_ROW(h * 8 + q), g.M - 1)];
             }
+            if (g.residual) {
+              float x[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-              if (mask_pos) v[q] = x[q] > 0.f ? v[q] : 0.f;  // ReLU backward: gate by the saved activation
-              else v[q] += x[q];
-              v[q] += y[q];
+              for (int q = 0; q < 8; q++) x[q] = g.residual[off[q]];
+              if (g.flags & AIT_GEMM_MASK_POS) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = x[q] > 0.f ? v[q] : 0.f;
+              } else {
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] += x[q];
+              }
+            }
+            if (g.flags & AIT_GEMM_ACCUMULATE) {
+              float y[8];
+#pragma unroll
+              for (int q = 0; q < 8; q++) y[q] = g.C[off[q]];
+#pragma unroll
+              for (int q = 0; q < 8; q++) v[q] += y[q];
             }
           }
+          if (relu) {
 #pragma unroll
-          for (int q = 0; q < 8; q++) {
-            const int r = h * 8 + q;
-            const int row = rbase + (r & 3) + 8 * (r >> 2);
-            if (relu) v[q] = fmaxf(v[q], 0.f);
-            if (col_ok && row < g.M) g.C[cbase + (unsigned)row * ldc] = v[q];
+            for (int q = 0; q < 8; q++) v[q] = fmaxf(v[q], 0.f);
           }
-          if (EPI == EPI_AUX) __builtin_amdgcn_sched_barrier(0);
+          if (interior) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) g.C[obase + (unsigned)AIT_ROW(h * 8 + q) * ldc] = v[q];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+              if (cok[b] && rbase + AIT_ROW(h * 8 + q) < g.M) g.C[obase + (unsigned)AIT_ROW(h * 8 + q) * ldc] = v[q];
+          }
         }
       }
     }
+#undef AIT_ROW
 }
 
 // one group of four k-steps: TM x TN MFMAs per step on the operand quads xa / xb
@@ -305,15 +384,27 @@ template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe>
 __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const GemmArgs g) {
   static_assert(C::MODE == MODE_DLDS && C::BK == 16 && C::BM % 16 == 0 && C::BN % 16 == 0,
                 "direct-to-LDS path needs 16-float slabs");
+  static_assert((C::BM + C::BN) * 16 / 256 <= 8 * (C::NT / 64), "at most 8 transfers per wave per slab");
   constexpr int BM = C::BM, BN = C::BN, BK = 16;
   constexpr int SA = BM * 16, SB = BN * 16;          // floats per slab image
   constexpr int NW = C::NT / 64;
   constexpr int GA = SA / 256, GB = SB / 256;        // 1-KB granules per slab
   constexpr int LA = (GA + NW - 1) / NW, LB = (GB + NW - 1) / NW;   // transfers per wave per slab
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* As = lds;                // [3][SA]
-  float* Bd = lds + 3 * SA;       // [3][SB]
+  constexpr int NS = C::NS;
+  constexpr int NP = LA + LB;     // transfers per wave per slab
+  static_assert(NS == 3 || NS == 4, "ring of 3 or 4 slabs");
+  static_assert(NS == 3 || (GA % NW == 0 && GB % NW == 0), "counted waits need the same transfer count in every wave");
+  float* As = lds;                // [NS][SA]
+  float* Bd = lds + NS * SA;      // [NS][SB]
 
+  // raw barrier: __syncthreads() is a fence + barrier, and the fence makes hipcc drain vmcnt(0) whenever it
+  // has stores of its own outstanding (the epilogue's), which would also drain the slab kept in flight
+  auto ring_barrier = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
   WorkMap wmap;
   wmap.init(g, BM, BN);
   const int W = gridDim.x / AIT_NXCD;
@@ -365,19 +456,21 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       }
     }
   };
-  auto request = [&](int slot) {     // issue the cursor's slab into ring slot `slot`, advance the cursor
-#pragma unroll
-    for (int i = 0; i < LA; i++) {
-      const int q = wave + i * NW;
-      if (GA % NW == 0 || q < GA) glds16(pa[i], As + slot * SA + q * 256);
-      pa[i] += step_a;
+  // one 1-KB transfer of the cursor's slab (piece < LA: operand A, else B) into ring slot `slot`
+  auto issue = [&](int piece, int slot) {
+    if (piece < LA) {
+      const int q = wave + piece * NW;
+      if (GA % NW == 0 || q < GA) glds16(pa[piece], As + slot * SA + q * 256);
+    } else {
+      const int q = wave + (piece - LA) * NW;
+      if (GB % NW == 0 || q < GB) glds16(pb[piece - LA], Bd + slot * SB + q * 256);
     }
+  };
+  auto advance = [&]() {             // cursor -> next slab of the stream (possibly the next tile's first)
 #pragma unroll
-    for (int i = 0; i < LB; i++) {
-      const int q = wave + i * NW;
-      if (GB % NW == 0 || q < GB) glds16(pb[i], Bd + slot * SB + q * 256);
-      pb[i] += step_b;
-    }
+    for (int i = 0; i < LA; i++) pa[i] += step_a;
+#pragma unroll
+    for (int i = 0; i < LB; i++) pb[i] += step_b;
     l_k += BK;
     if (l_k >= l_kend) {
       l_item += W;
@@ -385,12 +478,25 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       else l_valid = false;
     }
   };
+  auto request = [&](int slot) {     // whole slab at once (prologue)
+#pragma unroll
+    for (int i = 0; i < LA + LB; i++) issue(i, slot);
+    advance();
+  };
 
+  if constexpr ((C::KNOBS & KNOB_PRIO) != 0) {
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+  }
   set_tile(l_item);
   request(0);
   if (l_valid) request(1);
-  __builtin_amdgcn_s_waitcnt(0x0070);                // vmcnt(0) (lgkm/exp untouched)
-  __syncthreads();
+  if (NS == 4 && l_valid) {
+    request(2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");      // slabs 0 and 1 complete, slab 2 in flight
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  ring_barrier();
   float4 xa[C::TM], xb[C::TN], na[C::TM], nb[C::TN];
   fetch_group<AK, C::TM, BM>(As, wm, li, lk, 0, xa);
   fetch_group<BKC, C::TN, BN>(Bd, wn, li, lk, 0, xb);
@@ -410,9 +516,19 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     if constexpr (Probe::on) c0 = __builtin_amdgcn_s_memtime();
 
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      const int nxt = (cur == 2) ? 0 : cur + 1;
-      const int nxt2 = (nxt == 2) ? 0 : nxt + 1;
-      if (l_valid) request(nxt2);
+      const int nxt = (cur == NS - 1) ? 0 : cur + 1;
+      const int nxt2 = (cur == 0) ? NS - 1 : cur - 1;      // the slot iteration s-1 finished reading
+      // The transfers of slab s+NS-1 are issued one at a time BETWEEN the MFMA steps, not in a burst at
+      // the top of the iteration: right after the barrier every wave of the CU would be issuing them
+      // at once (an LDS-DMA costs its wave 60-180 cycles of issue) with no wave left to feed the
+      // matrix pipe; inside the MFMA stream the partner wave on the SIMD covers each one.
+      const bool feed = l_valid;         // wave-uniform
+      if constexpr ((C::KNOBS & KNOB_BURST) != 0) {
+        if (feed) {
+#pragma unroll
+          for (int i = 0; i < NP; i++) issue(i, nxt2);
+        }
+      }
 #pragma unroll
       for (int grp = 0; grp < 2; grp++) {
         // next group's operands: second half of this slab, then the first half of the NEXT slab of the
@@ -423,25 +539,50 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         fetch_group<AK, C::TM, BM>(an_, wm, li, lk, grp == 0 ? 1 : 0, na);
         fetch_group<BKC, C::TN, BN>(bn_, wn, li, lk, grp == 0 ? 1 : 0, nb);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_group<C::TM, C::TN>(acc, xa, xb);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+          for (int a = 0; a < C::TM; a++)
+#pragma unroll
+            for (int b = 0; b < C::TN; b++) {
+              const float fa = j == 0 ? xa[a].x : j == 1 ? xa[a].y : j == 2 ? xa[a].z : xa[a].w;
+              const float fb = j == 0 ? xb[b].x : j == 1 ? xb[b].y : j == 2 ? xb[b].z : xb[b].w;
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[a][b], 0, 0, 0);
+            }
+          const int piece = grp * 4 + j;       // one transfer behind each of the first NP MFMA steps
+          if ((C::KNOBS & KNOB_BURST) == 0 && piece < NP) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (feed) issue(piece, nxt2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
 #pragma unroll
         for (int a = 0; a < C::TM; a++) xa[a] = na[a];
 #pragma unroll
         for (int b = 0; b < C::TN; b++) xb[b] = nb[b];
       }
+      if (feed) advance();
       __builtin_amdgcn_sched_barrier(0);
+      // the slab the NEXT iteration prefetches from (s+2) must be complete behind the barrier: with a ring
+      // of 3 it is the one requested in this iteration (wait for everything); with 4 it was requested one
+      // iteration ago and the one requested now stays in flight (counted wait) -- unless nothing was
+      // requested now (end of the stream)
+      auto slab_wait = [&]() {
+        if (NS == 4 && feed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      };
       if constexpr (Probe::on) {
         const unsigned long long s0 = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_waitcnt(0x0070);
+        slab_wait();
         const unsigned long long s1 = __builtin_amdgcn_s_memtime();
-        __syncthreads();
+        ring_barrier();
         const unsigned long long s2 = __builtin_amdgcn_s_memtime();
         c_wait += s1 - s0;
         c_bar += s2 - s1;
         n_slab++;
       } else {
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        __syncthreads();
+        slab_wait();
+        ring_barrier();
       }
       cur = nxt;
     }
@@ -639,14 +780,20 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
   epilogue<C::TM, C::TN, EPI>(acc, g, m0, n0, wm, wn, li, lk);
 }
 
-// Resident workgroup slots of the persistent kernel: 2 per CU (72 KB of LDS each).  Queried per call
-// (no cached global state); a failed query falls back to the MI355X figure.
+// Resident workgroup slots of the persistent kernel: as many workgroups per CU as its LDS ring allows
+// (160 KB per CU; the product tiles: 72 KB -> 2).  Queried per call (no cached global state); a failed
+// query falls back to the MI355X figure.
+template <class C>
 inline int stream_slots() {
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     cus = 256;
-  return 2 * cus;
+  int per_cu = (int)(160 * 1024 / C::LDS);
+  const int by_waves = 32 / (C::NT / 64);
+  if (per_cu > by_waves) per_cu = by_waves;
+  if (per_cu > 4) per_cu = 4;
+  return (per_cu < 1 ? 1 : per_cu) * cus;
 }
 
 template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe>
@@ -658,7 +805,7 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
   if constexpr (C::MODE == MODE_DLDS) {
     // persistent: W workgroups per XCD, every one of them gets work (W <= items of the smallest chunk
     // is not required: a workgroup past its chunk's end exits at once)
-    if (slots <= 0) slots = stream_slots();
+    if (slots <= 0) slots = stream_slots<C>();
     const int w = max(1, min(wmap.chunk, slots / AIT_NXCD));
     blocks = (unsigned)(w * AIT_NXCD);
     kern = reinterpret_cast<const void*>(gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe>);
@@ -688,7 +835,9 @@ int dispatch_layout(const GemmArgs& g, bool ak, bool bk, hipStream_t s) {
 template <class C>
 int dispatch(const GemmArgs& g, bool ak, bool bk, hipStream_t s) {
   if (g.flags & AIT_GEMM_ATOMIC) return dispatch_layout<C, EPI_ATOMIC>(g, ak, bk, s);
-  if (g.residual || (g.flags & (AIT_GEMM_ACCUMULATE | AIT_GEMM_MASK_POS)))
+  const bool row_bias = g.bias && (g.flags & AIT_GEMM_BIAS_ROW);
+  if (g.residual && !(g.flags & AIT_GEMM_ACCUMULATE) && !row_bias) return dispatch_layout<C, EPI_RES>(g, ak, bk, s);
+  if (g.residual || (g.flags & (AIT_GEMM_ACCUMULATE | AIT_GEMM_MASK_POS)) || row_bias)
     return dispatch_layout<C, EPI_AUX>(g, ak, bk, s);
   return dispatch_layout<C, EPI_STORE>(g, ak, bk, s);
 }
@@ -701,7 +850,7 @@ inline int make_args(int trans_a, int trans_b, int M, int N, int K, float alpha,
                      const float* residual, int flags, int split_k, int c_colblk,
                      long long c_batch_stride, int BK, GemmArgs& g) {
   if (M < 0 || N < 0 || K < 0) return AIT_EINVAL;
-  if (!A || !B || !C) return AIT_EINVAL;
+  if (!C || (K > 0 && (!A || !B))) return AIT_EINVAL;     // (K == 0 never reads A or B)
   // float4 staging: row pitches and bases 16-B aligned; K % 4 only matters for an operand whose
   // reduction dimension is the contiguous one
   if ((lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||

@@ -268,7 +268,8 @@ AIT_API int ait_nms(const float* boxes, const int64_t* order, int n, float thr, 
 AIT_API size_t ait_nms_batched_workspace_bytes(int batch, int n) {
   if (n <= 0 || batch <= 0) return 0;
   const size_t nb = (size_t)(n + kTile - 1) / kTile;
-  return (size_t)batch * align_up((size_t)n * nb * 8, 256);
+  // image b's mask slab starts at word b*n*nb (8-byte accesses only: no per-image alignment needed)
+  return align_up((size_t)batch * n * nb * 8, 256);
 }
 
 AIT_API int ait_nms_batched(const float* boxes, int batch, int n, float thr, int max_keep,
@@ -286,17 +287,6 @@ AIT_API int ait_nms_batched(const float* boxes, int batch, int n, float thr, int
   if ((reinterpret_cast<uintptr_t>(boxes) & 15) != 0) return AIT_EINVAL;
   const int nb = (n + kTile - 1) / kTile;
   if ((size_t)nb * 8 > 60 * 1024) return AIT_EUNSUPPORTED;
-  if (((size_t)n * nb * 8) % 256 != 0) {
-    // per-image mask slabs must be contiguous for the z-sliced kernels: fall back to a loop
-    const size_t per = ait_nms_workspace_bytes(n);
-    if (workspace_bytes < per) return AIT_EWORKSPACE;
-    for (int b = 0; b < batch; b++) {
-      int rc = ait_nms(boxes + (size_t)b * n * 4, nullptr, n, thr, max_keep, workspace, per,
-                       keep + (size_t)b * keep_stride, n_keep + b, stream);
-      if (rc != AIT_OK) return rc;
-    }
-    return AIT_OK;
-  }
   auto* mask = reinterpret_cast<unsigned long long*>(workspace);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb, batch), dim3(kTile), 0, s,
                      reinterpret_cast<const float4*>(boxes), nullptr, n, thr, nb, mask);

@@ -325,8 +325,13 @@ AIT_API int ait_roi_align_nhwc_fwd(const float* feat, const float* rois, int n_r
   if (rc != AIT_OK) return rc;
   const size_t lds = sizeof(float) * ((size_t)H + (size_t)PW * W);
   if (lds > 60 * 1024) return AIT_EUNSUPPORTED;
-  hipLaunchKernelGGL(roi_align_nhwc_fwd_kernel, dim3(chunked_grid((long long)n_rois * PH)), dim3(kThreads),
-                     lds, s, feat, rois, n_rois, B, C, H, W, PH, wf, wi, out);
+  {
+    // algorithmic bytes: the feature read once, the RoIs, the pooled tensor written once
+    AitProbeScope probe(AIT_PROBE_ROI_FWD, 4.0 * ((double)B * C * H * W + 5.0 * n_rois + (double)n_rois * PH * PW * C), s,
+                        n_rois, B, C, H, W);
+    hipLaunchKernelGGL(roi_align_nhwc_fwd_kernel, dim3(chunked_grid((long long)n_rois * PH)), dim3(kThreads),
+                       lds, s, feat, rois, n_rois, B, C, H, W, PH, wf, wi, out);
+  }
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }
@@ -346,8 +351,12 @@ AIT_API int ait_roi_align_nhwc_bwd(const float* grad_out, const float* rois, int
   const int rc = make_tables(rois, n_rois, B, H, W, PH, PW, spatial_scale, sampling_ratio, workspace,
                              workspace_bytes, wf, wi, s);
   if (rc != AIT_OK) return rc;
-  hipLaunchKernelGGL(roi_align_nhwc_bwd_kernel, dim3(chunked_grid((long long)B * H * W)), dim3(kThreads), 0, s,
-                     grad_out, rois, n_rois, B, C, H, W, PH, wf, wi, grad_in);
+  {
+    AitProbeScope probe(AIT_PROBE_ROI_BWD, 4.0 * ((double)B * C * H * W + 5.0 * n_rois + (double)n_rois * PH * PW * C), s,
+                        n_rois, B, C, H, W);
+    hipLaunchKernelGGL(roi_align_nhwc_bwd_kernel, dim3(chunked_grid((long long)B * H * W)), dim3(kThreads), 0, s,
+                       grad_out, rois, n_rois, B, C, H, W, PH, wf, wi, grad_in);
+  }
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }

@@ -35,6 +35,7 @@ __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned lo
 
 struct RowMap {
   int seq_len, src_rows, rep;
+  int dy_rows;     // backward only: rows per sequence that `dy` holds (compacted gradient); == seq_len: all
 };
 // out row r=(q,t) -> source row of `a`, or -1 for a zero (padding) row
 __device__ __forceinline__ long long src_row(const RowMap m, long long r) {
@@ -130,20 +131,30 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
     const float* __restrict__ res, const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, long long rows, RowMap m, float p, unsigned long long seed,
     float* __restrict__ da, float* __restrict__ dres, float* __restrict__ dgamma,
-    float* __restrict__ dbeta) {
-  __shared__ float red[2][kRowsPerBlock][kD];
+    float* __restrict__ dbeta, float* __restrict__ dcolsum) {
+  __shared__ float red[3][kRowsPerBlock][kD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = lane * kVec;
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
-  float g[kVec], dg[kVec], db[kVec];
+  float g[kVec], dg[kVec], db[kVec], dc[kVec];
   load8(gamma + c0, g);
 #pragma unroll
-  for (int i = 0; i < kVec; i++) dg[i] = db[i] = 0.f;
+  for (int i = 0; i < kVec; i++) dg[i] = db[i] = dc[i] = 0.f;
   for (long long r = (long long)blockIdx.x * kRowsPerBlock + wave; r < rows;
        r += (long long)gridDim.x * kRowsPerBlock) {
     float z[kVec], ds[kVec], d[kVec];
     form_z(a, pos, res, m, r, c0, p, inv_keep, seed, z, ds);
-    load8(dy + (size_t)r * kD + c0, d);
+    if (m.dy_rows == m.seq_len) {
+      load8(dy + (size_t)r * kD + c0, d);
+    } else {   // compacted gradient: only the first dy_rows rows of a sequence received one
+      const long long q = r / m.seq_len;
+      const int t = (int)(r - q * m.seq_len);
+      if (t < m.dy_rows) load8(dy + (size_t)(q * m.dy_rows + t) * kD + c0, d);
+      else {
+#pragma unroll
+        for (int i = 0; i < kVec; i++) d[i] = 0.f;
+      }
+    }
     const float mu = mean[r], rs = rstd[r];
     float s1 = 0.f, s2 = 0.f, xh[kVec], wd[kVec];
 #pragma unroll
@@ -161,34 +172,87 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < kVec; i++) dz[i] = (wd[i] - s1 - xh[i] * s2) * rs;
     if (dres) store8(dres + (size_t)r * kD + c0, dz);
-    if (da) {
-      long long orow = r;
-      if (m.rep == 1) orow = src_row(m, r);  // source indexing; padded rows have no source
-      if (orow >= 0) {
+    if (da || dcolsum) {
+      const long long sr = src_row(m, r);      // padded rows have no source: no gradient, no column sum
+      if (sr >= 0) {
 #pragma unroll
-        for (int i = 0; i < kVec; i++) dz[i] *= ds[i];
-        store8(da + (size_t)orow * kD + c0, dz);
+        for (int i = 0; i < kVec; i++) {
+          dz[i] *= ds[i];
+          dc[i] += dz[i];
+        }
+        if (da) store8(da + (size_t)(m.rep == 1 ? sr : r) * kD + c0, dz);   // rep == 1: source indexing
       }
     }
   }
-  if (dgamma) {
+  if (dgamma || dcolsum) {
 #pragma unroll
     for (int i = 0; i < kVec; i++) {
       red[0][wave][c0 + i] = dg[i];
       red[1][wave][c0 + i] = db[i];
+      red[2][wave][c0 + i] = dc[i];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < kD; c += kThreads) {
-      float sg = 0.f, sb = 0.f;
+      float sg = 0.f, sb = 0.f, sc = 0.f;
 #pragma unroll
       for (int w = 0; w < kRowsPerBlock; w++) {
         sg += red[0][w][c];
         sb += red[1][w][c];
+        sc += red[2][w][c];
       }
-      unsafeAtomicAdd(dgamma + c, sg);
-      unsafeAtomicAdd(dbeta + c, sb);
+      if (dgamma) {
+        unsafeAtomicAdd(dgamma + c, sg);
+        unsafeAtomicAdd(dbeta + c, sb);
+      }
+      if (dcolsum) unsafeAtomicAdd(dcolsum + c, sc);
     }
   }
+}
+
+// out[c] += sum_r x[r*ld + c]: bias gradients (column sums over token rows).  One thread owns a
+// column quad (16-B loads, a row of the block is one coalesced segment), a block a band of rows;
+// one atomic per column per block.
+constexpr int kColsumRows = 128;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long rows, int cols,
+                                                     long long ld, float* __restrict__ out) {
+  const long long r0 = (long long)blockIdx.x * kColsumRows;
+  const long long r1 = r0 + kColsumRows < rows ? r0 + kColsumRows : rows;
+  for (int c4 = threadIdx.x + blockIdx.y * blockDim.x; c4 < cols / 4; c4 += blockDim.x * gridDim.y) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* __restrict__ p = x + r0 * ld + 4 * c4;
+#pragma unroll 8
+    for (long long r = r0; r < r1; r++, p += ld) {
+      const float4 v = *reinterpret_cast<const float4*>(p);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    unsafeAtomicAdd(out + 4 * c4 + 0, acc.x);
+    unsafeAtomicAdd(out + 4 * c4 + 1, acc.y);
+    unsafeAtomicAdd(out + 4 * c4 + 2, acc.z);
+    unsafeAtomicAdd(out + 4 * c4 + 3, acc.w);
+  }
+}
+
+// out[g*E + e] += sum_{j in this block's slice of rep} x[(g*rep + j)*E + e]: the gradient of a row block
+// that was repeated `rep` times (the query sequence over the proposals of its pair, Models.py:250).
+constexpr int kRepSlice = 16;
+__global__ __launch_bounds__(256) void rep_sum_kernel(const float* __restrict__ x, int rep, long long E,
+                                                      float* __restrict__ out) {
+  const long long e4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e4 * 4 >= E) return;
+  const int g = blockIdx.y;
+  const int j0 = blockIdx.z * kRepSlice, j1 = min(rep, j0 + kRepSlice);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* __restrict__ p = x + ((size_t)g * rep + j0) * E + 4 * e4;
+#pragma unroll 8
+  for (int j = j0; j < j1; j++, p += E) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  float* o = out + (size_t)g * E + 4 * e4;
+  unsafeAtomicAdd(o + 0, acc.x);
+  unsafeAtomicAdd(o + 1, acc.y);
+  unsafeAtomicAdd(o + 2, acc.z);
+  unsafeAtomicAdd(o + 3, acc.w);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -329,7 +393,7 @@ AIT_API int ait_ln_fwd(const float* a, const float* pos, const float* residual,
   if (d != kD) return AIT_EUNSUPPORTED;
   if (rows == 0) return AIT_OK;
   if (!a || !gamma || !beta || !y) return AIT_EINVAL;
-  RowMap m{seq_len, src_rows_per_seq, rep};
+  RowMap m{seq_len, src_rows_per_seq, rep, seq_len};
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(rows)), dim3(kThreads), 0, ait_stream(stream), a,
                      pos, residual, gamma, beta, rows, m, eps, p_drop, seed, y, mean, rstd);
   AIT_CHECK_LAUNCH();
@@ -338,22 +402,45 @@ AIT_API int ait_ln_fwd(const float* a, const float* pos, const float* residual,
 
 AIT_API int ait_ln_bwd(const float* dy, const float* a, const float* pos, const float* residual,
                        const float* gamma, const float* mean, const float* rstd, long long rows,
-                       int d, int seq_len, int src_rows_per_seq, int rep, float p_drop,
-                       unsigned long long seed, float* da, float* dres, float* dgamma,
-                       float* dbeta, void* stream) {
+                       int d, int seq_len, int src_rows_per_seq, int rep, int dy_rows_per_seq,
+                       float p_drop, unsigned long long seed, float* da, float* dres, float* dgamma,
+                       float* dbeta, float* dcolsum, void* stream) {
   if (rows < 0 || seq_len <= 0 || src_rows_per_seq <= 0 || src_rows_per_seq > seq_len ||
-      rep < 1 || p_drop < 0.f || p_drop >= 1.f)
+      rep < 1 || p_drop < 0.f || p_drop >= 1.f || dy_rows_per_seq <= 0 || dy_rows_per_seq > seq_len)
     return AIT_EINVAL;
   if (d != kD) return AIT_EUNSUPPORTED;
   if (rows == 0) return AIT_OK;
   if (!dy || !a || !gamma || !mean || !rstd) return AIT_EINVAL;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return AIT_EINVAL;
-  RowMap m{seq_len, src_rows_per_seq, rep};
+  RowMap m{seq_len, src_rows_per_seq, rep, dy_rows_per_seq};
   // fewer, fatter blocks: each block issues 2*512 atomics for the affine gradients
   long long b = (rows + 63) / 64;
   unsigned grid = (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(kThreads), 0, ait_stream(stream), dy, a, pos,
-                     residual, gamma, mean, rstd, rows, m, p_drop, seed, da, dres, dgamma, dbeta);
+                     residual, gamma, mean, rstd, rows, m, p_drop, seed, da, dres, dgamma, dbeta, dcolsum);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_colsum_f32(const float* x, long long rows, int cols, long long ld, float* out, void* stream) {
+  if (rows < 0 || cols < 0 || (cols & 3) || ld < cols || (ld & 3)) return AIT_EINVAL;
+  if (rows == 0 || cols == 0) return AIT_OK;
+  if (!x || !out || (reinterpret_cast<uintptr_t>(x) & 15)) return AIT_EINVAL;
+  const int threads = cols / 4 >= 256 ? 256 : (cols / 4 > 64 ? 128 : 64);
+  const unsigned gy = (unsigned)((cols / 4 + threads - 1) / threads);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + kColsumRows - 1) / kColsumRows), gy), dim3(threads), 0,
+                     ait_stream(stream), x, rows, cols, ld, out);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_rep_sum_f32(const float* x, int groups, int rep, long long E, float* out, void* stream) {
+  if (groups < 0 || rep < 1 || E < 0 || (E & 3)) return AIT_EINVAL;
+  if (groups == 0 || E == 0) return AIT_OK;
+  if (!x || !out || (reinterpret_cast<uintptr_t>(x) & 15)) return AIT_EINVAL;
+  hipLaunchKernelGGL(rep_sum_kernel, dim3((unsigned)((E / 4 + 255) / 256), (unsigned)groups,
+                                          (unsigned)((rep + kRepSlice - 1) / kRepSlice)),
+                     dim3(256), 0, ait_stream(stream), x, rep, E, out);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }

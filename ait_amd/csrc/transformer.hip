@@ -15,7 +15,11 @@
 // token-major (= channels-last feature maps), the layouts ait_roi_align_nhwc_fwd produces and the
 // SK / layer4 stage consumes.  All intermediates live in a caller-owned workspace
 // (ait_transformer_workspace_bytes); nothing is allocated, nothing is kept between calls.
-// Training goes through the Python autograd wrappers, which save what the backward needs.
+// Training: ait_transformer_fwd_train saves every activation the backward reads into a caller-owned
+// buffer; ait_transformer_bwd runs the whole backward (input gradients written, parameter gradients
+// accumulated), with the residual-gradient adds fused into the dgrad GEMM epilogues and the bias
+// gradients into the LayerNorm-backward / column-sum kernels.  The two sub-layer blocks are exported
+// the same way (ait_mha_block_*, ait_ffn_*).
 #include "common.h"
 
 namespace {
@@ -38,14 +42,6 @@ struct Bump {
   }
 };
 
-inline size_t ws_floats(long long bp, long long bs, long long ns) {
-  // emb_p, emb_q, x, qkv (also q | kv), O, u, gate, s, f, y, xc, h, f2, mem, d0, d1, d2 (+ slack per buffer)
-  const long long M = bp * T;
-  long long f = bp * ns * D + bs * T * D + M * D + M * 3 * D + M * D + M * DK + bp * D + bp * DK + M * D +
-                M * D + bp * ns * D + M * DI + M * D + bp * ns * D + M * D + M * D + M * D + bp * ns * 2 * D;
-  return (size_t)f + 32 * 64;
-}
-
 #define AIT_TRY(expr)            \
   do {                           \
     const int rc__ = (expr);     \
@@ -57,72 +53,207 @@ inline int linear(const float* x, int M, int K, const float* w, int N, const flo
                   void* s) {
   return ait_gemm_f32(0, 1, M, N, K, 1.f, x, K, w, K, y, N, b, nullptr, relu ? AIT_GEMM_RELU : 0, 1, 0, 0, s);
 }
-
-// one MultiHeadAttention block (SubLayers.py:68-102 with the selective heads of :22-39):
-//   xq [n*64, 512] queries (and residual); keys/values from xkv [n*kv_rows, 512] (xkv == xq: self)
-int mha_block(const float* xq, const float* xkv, int n, int kv_rows, int mask_mode, int n_valid,
-              const ait_mha_weights& w, float* qkv, float* O, float* u, float* gate, float* sp, float* f,
-              float* y, void* s) {
-  const int M = n * T;
-  const float *q, *k, *v;
-  int ldq, ldkv;
-  if (xkv == xq) {
-    AIT_TRY(linear(xq, M, D, w.w_qkv, 3 * D, nullptr, false, qkv, s));
-    q = qkv; k = qkv + D; v = qkv + 2 * D;
-    ldq = ldkv = 3 * D;
-  } else {
-    float* qp = qkv;
-    float* kv = qkv + (size_t)M * D;
-    AIT_TRY(linear(xq, M, D, w.w_qkv, D, nullptr, false, qp, s));
-    AIT_TRY(linear(xkv, n * kv_rows, D, w.w_qkv + (size_t)D * D, 2 * D, nullptr, false, kv, s));
-    q = qp; k = kv; v = kv + D;
-    ldq = D; ldkv = 2 * D;
+// dx [M, K_in] = dy [M, N_out] . W [N_out, K_in]  (+ residual, or gated by `residual` > 0 with mask_pos)
+inline int dgrad(const float* dy, int M, int N_out, const float* w, int K_in, const float* residual, bool mask_pos,
+                 float* dx, void* s) {
+  return ait_gemm_f32(0, 0, M, K_in, N_out, 1.f, dy, N_out, w, K_in, dx, K_in, nullptr, residual,
+                      mask_pos ? AIT_GEMM_MASK_POS : 0, 1, 0, 0, s);
+}
+// K-splits of a weight gradient [M_out, N_out] = sum over K tokens: multiples of 8 (each XCD owns whole
+// K-ranges), chosen so that tiles x splits fills the resident workgroup slots of the 256x128 kernel in
+// whole rounds with at least 256 tokens per split (the heuristic ait_amd/system.py used in round 1).
+inline int wgrad_splits(int M_out, int N_out, long long K) {
+  long long tiles, slots;
+  if (M_out >= 512) { tiles = (long long)((M_out + 255) / 256) * ((N_out + 127) / 128); slots = 512; }
+  else { tiles = (long long)((M_out + 127) / 128) * ((N_out + 127) / 128); slots = 1024; }
+  int best = 8;
+  double best_eff = -1.0;
+  for (int sp = 8; sp < (tiles <= 4 ? 129 : 65); sp += 8) {
+    if (K / sp < 256 && sp > 8) break;
+    const double rounds = (double)(tiles * sp) / (double)slots;
+    const double eff = rounds / (double)((tiles * sp + slots - 1) / slots > 0 ? (tiles * sp + slots - 1) / slots : 1);
+    if (eff > best_eff + 1e-9) { best = sp; best_eff = eff; }
   }
-  AIT_TRY(ait_attn_fwd(q, ldq, k, ldkv, v, ldkv, n, H, T, DK, kv_rows, mask_mode, n_valid, 0.125f, 0.f, 0,
-                       nullptr, O, s));
-  AIT_TRY(ait_sh_fwd(O, w.sk_w, w.sk_b, n, H, T, DK, u, gate, sp, s));
-  AIT_TRY(linear(u, M, DK, w.fc_w, D, nullptr, false, f, s));
-  return ait_ln_fwd(f, nullptr, xq, w.ln_g, w.ln_b, M, D, T, T, 1, kEps, 0.f, 0, y, nullptr, nullptr, s);
+  return best;
+}
+// dW [N_out, K_in] += dy [M, N_out]^T . x [M, K_in]   (split-K, fp32 atomics: accumulates)
+inline int wgrad(const float* dy, long long M, int N_out, const float* x, int K_in, float* dw, void* s) {
+  if (!dw) return AIT_OK;
+  const int sp = M >= 512 ? wgrad_splits(N_out, K_in, M) : 1;
+  return ait_gemm_f32(1, 0, N_out, K_in, (int)M, 1.f, dy, N_out, x, K_in, dw, K_in, nullptr, nullptr, AIT_GEMM_ATOMIC,
+                      sp, 0, 0, s);
 }
 
-// PositionwiseFeedForward (SubLayers.py:177-187) on `rows` token rows
-int ffn_block(const float* x, long long rows, const ait_ffn_weights& w, float* h, float* f, float* y, void* s) {
-  AIT_TRY(linear(x, (int)rows, D, w.w1, DI, w.b1, true, h, s));
-  AIT_TRY(linear(h, (int)rows, DI, w.w2, D, w.b2, false, f, s));
-  return ait_ln_fwd(f, nullptr, x, w.ln_g, w.ln_b, rows, D, T, T, 1, kEps, 0.f, 0, y, nullptr, nullptr, s);
+// buffers of one MultiHeadAttention block: scratch in eval, the saved activations in training
+struct MhaBuf {
+  float *qkv;          // self: [M, 1536];  cross: q [M, 512] then kv [n*kv_rows, 1024]
+  float *P;            // [n, 8, 64, 64] probabilities before dropout (training only)
+  float *O, *u, *gate, *s, *f;
+  float *mean, *rstd;  // of the closing LayerNorm (training only)
+};
+inline size_t mha_buf_floats(long long n, int kv_rows, bool cross, bool train) {
+  const size_t M = (size_t)n * T;
+  size_t f = (cross ? M * D + (size_t)n * kv_rows * 2 * D : M * 3 * D) + M * D + M * DK + (size_t)n * D +
+             (size_t)n * DK + M * D;
+  if (train) f += (size_t)n * H * T * T + 2 * M;
+  return f + 10 * 64;       // 256-B alignment slack per buffer
+}
+inline bool carve(Bump& b, MhaBuf& m, long long n, int kv_rows, bool cross, bool train) {
+  const size_t M = (size_t)n * T;
+  m.qkv = b.take(cross ? M * D + (size_t)n * kv_rows * 2 * D : M * 3 * D);
+  m.P = train ? b.take((size_t)n * H * T * T) : nullptr;
+  m.O = b.take(M * D);
+  m.u = b.take(M * DK);
+  m.gate = b.take((size_t)n * D);
+  m.s = b.take((size_t)n * DK);
+  m.f = b.take(M * D);
+  m.mean = train ? b.take(M) : nullptr;
+  m.rstd = train ? b.take(M) : nullptr;
+  return m.qkv && m.O && m.u && m.gate && m.s && m.f && (!train || (m.P && m.mean && m.rstd));
+}
+struct Qkv { const float *q, *k, *v; int ldq, ldkv; };
+inline Qkv views(const MhaBuf& m, long long n, bool cross) {
+  if (!cross) return Qkv{m.qkv, m.qkv + D, m.qkv + 2 * D, 3 * D, 3 * D};
+  const float* kv = m.qkv + (size_t)n * T * D;
+  return Qkv{m.qkv, kv, kv + D, D, 2 * D};
+}
+
+// one MultiHeadAttention block (SubLayers.py:68-102 with the selective heads of :22-39):
+//   xq [n*64, 512] queries (and residual); keys/values from xkv [n*kv_rows, 512] (xkv == xq: self).
+// p_fc: dropout rate behind fc (SubLayers.py:64,97), p_attn: on the probabilities (Modules.py:14,24);
+// both 0 in eval.  seed: the block's seed; its two sites derive theirs with ait_dropout_seed.
+int mha_block(const float* xq, const float* xkv, int n, int kv_rows, int mask_mode, int n_valid,
+              const ait_mha_weights& w, const MhaBuf& m, float p_fc, float p_attn, unsigned long long seed,
+              float* y, void* s) {
+  const int M = n * T;
+  const bool cross = xkv != xq;
+  if (!cross) {
+    AIT_TRY(linear(xq, M, D, w.w_qkv, 3 * D, nullptr, false, m.qkv, s));
+  } else {
+    AIT_TRY(linear(xq, M, D, w.w_qkv, D, nullptr, false, m.qkv, s));
+    AIT_TRY(linear(xkv, n * kv_rows, D, w.w_qkv + (size_t)D * D, 2 * D, nullptr, false, m.qkv + (size_t)M * D, s));
+  }
+  const Qkv v = views(m, n, cross);
+  AIT_TRY(ait_attn_fwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, n, H, T, DK, kv_rows, mask_mode, n_valid, 0.125f,
+                       p_attn, ait_dropout_seed(seed, 0), m.P, m.O, s));
+  AIT_TRY(ait_sh_fwd(m.O, w.sk_w, w.sk_b, n, H, T, DK, m.u, m.gate, m.s, s));
+  AIT_TRY(linear(m.u, M, DK, w.fc_w, D, nullptr, false, m.f, s));
+  return ait_ln_fwd(m.f, nullptr, xq, w.ln_g, w.ln_b, M, D, T, T, 1, kEps, p_fc, ait_dropout_seed(seed, 1), y, m.mean,
+                    m.rstd, s);
+}
+
+// scratch of the block's backward
+struct MhaBwdWs { float *df, *dres, *du, *dO, *dg, *dqkv; };
+inline size_t mha_bwd_ws_floats(long long n, int kv_rows, bool cross) {
+  const size_t M = (size_t)n * T;
+  return M * D * 3 + M * DK + (size_t)n * D + (cross ? M * D + (size_t)n * kv_rows * 2 * D : M * 3 * D) + 6 * 64;
+}
+inline bool carve(Bump& b, MhaBwdWs& w, long long n, int kv_rows, bool cross) {
+  const size_t M = (size_t)n * T;
+  w.df = b.take(M * D); w.dres = b.take(M * D); w.du = b.take(M * DK); w.dO = b.take(M * D);
+  w.dg = b.take((size_t)n * D);
+  w.dqkv = b.take(cross ? M * D + (size_t)n * kv_rows * 2 * D : M * 3 * D);
+  return w.df && w.dres && w.du && w.dO && w.dg && w.dqkv;
+}
+
+// backward of mha_block.  dy holds dy_rows (<= 64) rows per sequence (the rest received no gradient).
+// dxq [n*64, 512] and (cross) dxkv [n*kv_rows, 512] are WRITTEN; parameter gradients are ACCUMULATED.
+int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xkv, int n, int kv_rows,
+                  const ait_mha_weights& w, const MhaBuf& m, const MhaBwdWs& t, float p_fc, float p_attn,
+                  unsigned long long seed, float* dxq, float* dxkv, const ait_mha_grads& g, void* s) {
+  const int M = n * T;
+  const bool cross = xkv != xq;
+  // closing LayerNorm + dropout + residual: df (at fc's output), dres (the residual branch)
+  AIT_TRY(ait_ln_bwd(dy, m.f, nullptr, xq, w.ln_g, m.mean, m.rstd, M, D, T, T, 1, dy_rows, p_fc,
+                     ait_dropout_seed(seed, 1), t.df, t.dres, g.ln_g, g.ln_b, nullptr, s));
+  AIT_TRY(dgrad(t.df, M, D, w.fc_w, DK, nullptr, false, t.du, s));            // du = df fc_w
+  AIT_TRY(wgrad(t.df, M, D, m.u, DK, g.fc_w, s));                            // d fc_w += df^T u
+  AIT_TRY(ait_sh_bwd(t.du, m.O, m.gate, w.sk_w, n, H, T, DK, t.dO, t.dg, s));
+  AIT_TRY(wgrad(t.dg, n, D, m.s, DK, g.sk_w, s));                            // d sk_w += dg^T s
+  if (g.sk_b) AIT_TRY(ait_colsum_f32(t.dg, n, D, D, g.sk_b, s));
+  const Qkv v = views(m, n, cross);
+  float* dq = t.dqkv;
+  if (!cross) {
+    AIT_TRY(ait_attn_bwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
+                         ait_dropout_seed(seed, 0), dq, 3 * D, dq + D, 3 * D, dq + 2 * D, 3 * D, s));
+    AIT_TRY(dgrad(dq, M, 3 * D, w.w_qkv, D, t.dres, false, dxq, s));          // dx = dqkv W_qkv + dres
+    return wgrad(dq, M, 3 * D, xq, D, g.w_qkv, s);
+  }
+  float* dkv = t.dqkv + (size_t)M * D;
+  AIT_TRY(ait_attn_bwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
+                       ait_dropout_seed(seed, 0), dq, D, dkv, 2 * D, dkv + D, 2 * D, s));
+  AIT_TRY(dgrad(dq, M, D, w.w_qkv, D, t.dres, false, dxq, s));
+  if (dxkv) AIT_TRY(dgrad(dkv, n * kv_rows, 2 * D, w.w_qkv + (size_t)D * D, D, nullptr, false, dxkv, s));
+  AIT_TRY(wgrad(dq, M, D, xq, D, g.w_qkv, s));
+  return wgrad(dkv, (long long)n * kv_rows, 2 * D, xkv, D, g.w_qkv ? g.w_qkv + (size_t)D * D : nullptr, s);
+}
+
+// PositionwiseFeedForward (SubLayers.py:177-187) on `rows` token rows; h / f are scratch in eval and the
+// saved activations in training (with mean / rstd of the closing LayerNorm)
+struct FfnBuf { float *h, *f, *mean, *rstd; };
+int ffn_block(const float* x, long long rows, const ait_ffn_weights& w, const FfnBuf& m, float p,
+              unsigned long long seed, float* y, void* s) {
+  AIT_TRY(linear(x, (int)rows, D, w.w1, DI, w.b1, true, m.h, s));
+  AIT_TRY(linear(m.h, (int)rows, DI, w.w2, D, w.b2, false, m.f, s));
+  return ait_ln_fwd(m.f, nullptr, x, w.ln_g, w.ln_b, rows, D, T, T, 1, kEps, p, ait_dropout_seed(seed, 0), y, m.mean,
+                    m.rstd, s);
+}
+struct FfnBwdWs { float *df, *dres, *dh; };
+int ffn_block_bwd(const float* dy, const float* x, long long rows, const ait_ffn_weights& w, const FfnBuf& m,
+                  const FfnBwdWs& t, float p, unsigned long long seed, float* dx, const ait_ffn_grads& g, void* s) {
+  const int R = (int)rows;
+  // df at w_2's output (its column sums are d b2), dres on the residual branch
+  AIT_TRY(ait_ln_bwd(dy, m.f, nullptr, x, w.ln_g, m.mean, m.rstd, rows, D, T, T, 1, T, p, ait_dropout_seed(seed, 0),
+                     t.df, t.dres, g.ln_g, g.ln_b, g.b2, s));
+  AIT_TRY(wgrad(t.df, rows, D, m.h, DI, g.w2, s));                             // d W2 += df^T h
+  AIT_TRY(dgrad(t.df, R, D, w.w2, DI, m.h, true, t.dh, s));                    // dh = (df W2) [h > 0]
+  AIT_TRY(wgrad(t.dh, rows, DI, x, D, g.w1, s));                               // d W1 += dh^T x
+  if (g.b1) AIT_TRY(ait_colsum_f32(t.dh, rows, DI, DI, g.b1, s));
+  return dgrad(t.dh, R, DI, w.w1, D, t.dres, false, dx, s);                    // dx = dh W1 + dres
 }
 
 }  // namespace
 
+// Pure function: the seed of dropout site `site` under base seed `base` (splitmix64 finaliser).  The
+// training entry points derive every site's seed with it; a caller that composes the building blocks
+// itself (ait_amd/system.py's fine-grained path) uses the same function and gets the same masks.
+AIT_API unsigned long long ait_dropout_seed(unsigned long long base, int site) {
+  unsigned long long z = base + 0x9E3779B97F4A7C15ull * (unsigned long long)(site + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// sub-layer blocks: inference
+// ---------------------------------------------------------------------------------------------------
 AIT_API size_t ait_mha_block_workspace_bytes(int n_seq, int kv_rows) {
   if (n_seq <= 0 || kv_rows <= 0 || kv_rows > T) return 0;
-  const size_t M = (size_t)n_seq * T;
-  // qkv (or q | kv), O, u, gate, s, f
-  return (M * 3 * D + (size_t)n_seq * kv_rows * 2 * D + M * D + M * DK + (size_t)n_seq * D + (size_t)n_seq * DK + M * D) *
-             sizeof(float) + 8 * 256;
+  return mha_buf_floats(n_seq, kv_rows, true, false) * sizeof(float) + (size_t)n_seq * T * 2 * D * sizeof(float);
+}
+
+static int check_mha(const float* xq, const float*& xkv, int n_seq, int kv_rows, int mask_mode, const void* w) {
+  if (n_seq < 0 || kv_rows <= 0 || kv_rows > T || mask_mode < 0 || mask_mode > 2 || !w) return AIT_EINVAL;
+  if ((long long)n_seq * T > 0x7fffffffLL) return AIT_EUNSUPPORTED;
+  if (n_seq > 0 && !xq) return AIT_EINVAL;
+  if (!xkv || xkv == xq) {
+    if (kv_rows != T) return AIT_EINVAL;       // self-attention: keys are the 64 query tokens
+    xkv = xq;
+  }
+  return AIT_OK;
 }
 
 AIT_API int ait_mha_block_fwd(const float* xq, const float* xkv, int n_seq, int kv_rows, int mask_mode,
                               int n_valid_keys, const ait_mha_weights* w, void* workspace, size_t workspace_bytes,
                               float* y, void* stream) {
-  if (n_seq < 0 || kv_rows <= 0 || kv_rows > T || mask_mode < 0 || mask_mode > 2 || !w) return AIT_EINVAL;
+  AIT_TRY(check_mha(xq, xkv, n_seq, kv_rows, mask_mode, w));
   if (n_seq == 0) return AIT_OK;
-  if (!xq || !y || !workspace) return AIT_EINVAL;
-  if (!xkv || xkv == xq) {
-    if (kv_rows != T) return AIT_EINVAL;       // self-attention: keys are the 64 query tokens
-    xkv = xq;
-  }
+  if (!y || !workspace) return AIT_EINVAL;
   if (workspace_bytes < ait_mha_block_workspace_bytes(n_seq, kv_rows)) return AIT_EWORKSPACE;
-  const size_t M = (size_t)n_seq * T;
   Bump b{static_cast<char*>(workspace), workspace_bytes};
-  float* qkv = b.take(M * 3 * D + (size_t)n_seq * kv_rows * 2 * D);
-  float* O = b.take(M * D);
-  float* u = b.take(M * DK);
-  float* gate = b.take((size_t)n_seq * D);
-  float* sp = b.take((size_t)n_seq * DK);
-  float* f = b.take(M * D);
-  if (!qkv || !O || !u || !gate || !sp || !f) return AIT_EWORKSPACE;
-  return mha_block(xq, xkv, n_seq, kv_rows, mask_mode, n_valid_keys, *w, qkv, O, u, gate, sp, f, y, stream);
+  MhaBuf m;
+  if (!carve(b, m, n_seq, kv_rows, xkv != xq, false)) return AIT_EWORKSPACE;
+  return mha_block(xq, xkv, n_seq, kv_rows, mask_mode, n_valid_keys, *w, m, 0.f, 0.f, 0, y, stream);
 }
 
 AIT_API size_t ait_ffn_workspace_bytes(long long rows) {
@@ -137,11 +268,225 @@ AIT_API int ait_ffn_fwd(const float* x, long long rows, const ait_ffn_weights* w
   if (!x || !y || !workspace) return AIT_EINVAL;
   if (workspace_bytes < ait_ffn_workspace_bytes(rows)) return AIT_EWORKSPACE;
   Bump b{static_cast<char*>(workspace), workspace_bytes};
-  float* h = b.take((size_t)rows * DI);
-  float* f = b.take((size_t)rows * D);
-  if (!h || !f) return AIT_EWORKSPACE;
-  return ffn_block(x, rows, *w, h, f, y, stream);
+  FfnBuf m{b.take((size_t)rows * DI), b.take((size_t)rows * D), nullptr, nullptr};
+  if (!m.h || !m.f) return AIT_EWORKSPACE;
+  return ffn_block(x, rows, *w, m, 0.f, 0, y, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// sub-layer blocks: training (forward that saves, backward)
+// ---------------------------------------------------------------------------------------------------
+static bool bad_p(float p) { return !(p >= 0.f && p < 1.f); }
+
+AIT_API size_t ait_mha_block_saved_bytes(int n_seq, int kv_rows) {
+  if (n_seq <= 0 || kv_rows <= 0 || kv_rows > T) return 0;
+  return (mha_buf_floats(n_seq, kv_rows, true, true) + (size_t)n_seq * T * 2 * D) * sizeof(float);
+}
+
+AIT_API int ait_mha_block_fwd_train(const float* xq, const float* xkv, int n_seq, int kv_rows, int mask_mode,
+                                    int n_valid_keys, const ait_mha_weights* w, float p_drop, float p_attn_drop,
+                                    unsigned long long seed, void* saved, size_t saved_bytes, float* y, void* stream) {
+  AIT_TRY(check_mha(xq, xkv, n_seq, kv_rows, mask_mode, w));
+  if (bad_p(p_drop) || bad_p(p_attn_drop)) return AIT_EINVAL;
+  if (n_seq == 0) return AIT_OK;
+  if (!y || !saved) return AIT_EINVAL;
+  if (saved_bytes < ait_mha_block_saved_bytes(n_seq, kv_rows)) return AIT_EWORKSPACE;
+  Bump b{static_cast<char*>(saved), saved_bytes};
+  MhaBuf m;
+  if (!carve(b, m, n_seq, kv_rows, xkv != xq, true)) return AIT_EWORKSPACE;
+  return mha_block(xq, xkv, n_seq, kv_rows, mask_mode, n_valid_keys, *w, m, p_drop, p_attn_drop, seed, y, stream);
+}
+
+AIT_API size_t ait_mha_block_bwd_workspace_bytes(int n_seq, int kv_rows) {
+  if (n_seq <= 0 || kv_rows <= 0 || kv_rows > T) return 0;
+  return (mha_bwd_ws_floats(n_seq, kv_rows, true) + (size_t)n_seq * T * 2 * D) * sizeof(float);
+}
+
+AIT_API int ait_mha_block_bwd(const float* dy, const float* xq, const float* xkv, int n_seq, int kv_rows,
+                              int mask_mode, int n_valid_keys, const ait_mha_weights* w, float p_drop,
+                              float p_attn_drop, unsigned long long seed, const void* saved, size_t saved_bytes,
+                              void* workspace, size_t workspace_bytes, float* dxq, float* dxkv,
+                              const ait_mha_grads* grads, void* stream) {
+  (void)n_valid_keys;     // masked probabilities are exactly 0 in the saved P: the backward needs no mask
+  AIT_TRY(check_mha(xq, xkv, n_seq, kv_rows, mask_mode, w));
+  if (bad_p(p_drop) || bad_p(p_attn_drop) || !grads) return AIT_EINVAL;
+  if (n_seq == 0) return AIT_OK;
+  if (!dy || !dxq || !saved || !workspace) return AIT_EINVAL;
+  if (saved_bytes < ait_mha_block_saved_bytes(n_seq, kv_rows)) return AIT_EWORKSPACE;
+  if (workspace_bytes < ait_mha_block_bwd_workspace_bytes(n_seq, kv_rows)) return AIT_EWORKSPACE;
+  const bool cross = xkv != xq;
+  Bump b{static_cast<char*>(const_cast<void*>(saved)), saved_bytes};
+  MhaBuf m;
+  if (!carve(b, m, n_seq, kv_rows, cross, true)) return AIT_EWORKSPACE;
+  Bump bw{static_cast<char*>(workspace), workspace_bytes};
+  MhaBwdWs t;
+  if (!carve(bw, t, n_seq, kv_rows, cross)) return AIT_EWORKSPACE;
+  return mha_block_bwd(dy, T, xq, xkv, n_seq, kv_rows, *w, m, t, p_drop, p_attn_drop, seed, dxq, dxkv, *grads, stream);
+}
+
+AIT_API size_t ait_ffn_saved_bytes(long long rows) {
+  if (rows <= 0) return 0;
+  return ((size_t)rows * (DI + D + 2)) * sizeof(float) + 6 * 256;
+}
+static bool carve_ffn(Bump& b, FfnBuf& m, long long rows) {
+  m.h = b.take((size_t)rows * DI); m.f = b.take((size_t)rows * D);
+  m.mean = b.take((size_t)rows); m.rstd = b.take((size_t)rows);
+  return m.h && m.f && m.mean && m.rstd;
+}
+
+AIT_API int ait_ffn_fwd_train(const float* x, long long rows, const ait_ffn_weights* w, float p_drop,
+                              unsigned long long seed, void* saved, size_t saved_bytes, float* y, void* stream) {
+  if (rows < 0 || rows > 0x7fffffffLL || !w || bad_p(p_drop)) return AIT_EINVAL;
+  if (rows == 0) return AIT_OK;
+  if (!x || !y || !saved) return AIT_EINVAL;
+  if (saved_bytes < ait_ffn_saved_bytes(rows)) return AIT_EWORKSPACE;
+  Bump b{static_cast<char*>(saved), saved_bytes};
+  FfnBuf m;
+  if (!carve_ffn(b, m, rows)) return AIT_EWORKSPACE;
+  return ffn_block(x, rows, *w, m, p_drop, seed, y, stream);
+}
+
+AIT_API size_t ait_ffn_bwd_workspace_bytes(long long rows) {
+  if (rows <= 0) return 0;
+  return ((size_t)rows * (2 * D + DI)) * sizeof(float) + 4 * 256;
+}
+static bool carve_ffn_ws(Bump& b, FfnBwdWs& t, long long rows) {
+  t.df = b.take((size_t)rows * D); t.dres = b.take((size_t)rows * D); t.dh = b.take((size_t)rows * DI);
+  return t.df && t.dres && t.dh;
+}
+
+AIT_API int ait_ffn_bwd(const float* dy, const float* x, long long rows, const ait_ffn_weights* w, float p_drop,
+                        unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
+                        size_t workspace_bytes, float* dx, const ait_ffn_grads* grads, void* stream) {
+  if (rows < 0 || rows > 0x7fffffffLL || !w || !grads || bad_p(p_drop)) return AIT_EINVAL;
+  if (rows == 0) return AIT_OK;
+  if (!dy || !x || !dx || !saved || !workspace) return AIT_EINVAL;
+  if (saved_bytes < ait_ffn_saved_bytes(rows) || workspace_bytes < ait_ffn_bwd_workspace_bytes(rows)) return AIT_EWORKSPACE;
+  Bump b{static_cast<char*>(const_cast<void*>(saved)), saved_bytes};
+  FfnBuf m;
+  if (!carve_ffn(b, m, rows)) return AIT_EWORKSPACE;
+  Bump bw{static_cast<char*>(workspace), workspace_bytes};
+  FfnBwdWs t;
+  if (!carve_ffn_ws(bw, t, rows)) return AIT_EWORKSPACE;
+  return ffn_block_bwd(dy, x, rows, *w, m, t, p_drop, seed, dx, *grads, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the whole operator
+// ---------------------------------------------------------------------------------------------------
+namespace {
+// everything a forward produces; in eval the buffers of consecutive blocks alias, in training all are kept
+struct AitBufs {
+  float *emb_p, *emb_q;
+  float *x0, *mean0, *rstd0;        // encoder prologue output / LayerNorm statistics
+  MhaBuf enc_slf;
+  float *y1, *xc;                   // encoder self-attention block output; its n_src real rows
+  FfnBuf enc_ffn;
+  float *mem;                       // encoder memory [bp*n_src, 512]
+  float *xd, *meand, *rstdd;        // decoder prologue
+  MhaBuf dec_slf;
+  float *d1;
+  MhaBuf dec_enc;
+  float *d2;
+  FfnBuf dec_ffn;
+  float *d3;
+};
+inline size_t ait_saved_floats(long long bp, long long bs, long long ns) {
+  const size_t M = (size_t)bp * T;
+  return (size_t)bp * ns * D + (size_t)bs * T * D + M * D + 2 * M + mha_buf_floats(bp, T, false, true) + M * D +
+         (size_t)bp * ns * D + (size_t)bp * ns * (DI + D + 2) + (size_t)bp * ns * D + M * D + 2 * M +
+         mha_buf_floats(bp, T, false, true) + M * D + mha_buf_floats(bp, (int)ns, true, true) + M * D +
+         M * (DI + D + 2) + M * D + 64 * 64;
+}
+inline bool carve_train(Bump& b, AitBufs& a, long long bp, long long bs, int ns) {
+  const size_t M = (size_t)bp * T, Mc = (size_t)bp * ns;
+  a.emb_p = b.take(Mc * D); a.emb_q = b.take((size_t)bs * T * D);
+  a.x0 = b.take(M * D); a.mean0 = b.take(M); a.rstd0 = b.take(M);
+  bool ok = carve(b, a.enc_slf, bp, T, false, true);
+  a.y1 = b.take(M * D);
+  a.xc = ns < T ? b.take(Mc * D) : a.y1;
+  ok = ok && carve_ffn(b, a.enc_ffn, (long long)Mc);
+  a.mem = b.take(Mc * D);
+  a.xd = b.take(M * D); a.meand = b.take(M); a.rstdd = b.take(M);
+  ok = ok && carve(b, a.dec_slf, bp, T, false, true);
+  a.d1 = b.take(M * D);
+  ok = ok && carve(b, a.dec_enc, bp, ns, true, true);
+  a.d2 = b.take(M * D);
+  ok = ok && carve_ffn(b, a.dec_ffn, (long long)M);
+  a.d3 = b.take(M * D);
+  return ok && a.emb_p && a.emb_q && a.x0 && a.mean0 && a.rstd0 && a.y1 && a.xc && a.mem && a.xd && a.meand &&
+         a.rstdd && a.d1 && a.d2 && a.d3;
+}
+inline size_t ws_floats(long long bp, long long bs, long long ns) {
+  const size_t M = (size_t)bp * T;
+  return (size_t)bp * ns * D + (size_t)bs * T * D + M * D + mha_buf_floats(bp, (int)ns, true, false) + M * 2 * D +
+         M * D + (size_t)bp * ns * D + M * DI + M * D + (size_t)bp * ns * D + 3 * M * D + 32 * 64;
+}
+inline bool carve_eval(Bump& b, AitBufs& a, long long bp, long long bs, int ns) {
+  const size_t M = (size_t)bp * T, Mc = (size_t)bp * ns;
+  a.emb_p = b.take(Mc * D); a.emb_q = b.take((size_t)bs * T * D);
+  a.x0 = b.take(M * D); a.mean0 = a.rstd0 = nullptr;
+  // one attention scratch set, sized for the widest use (q | kv of the cross block fits in the self block's qkv)
+  MhaBuf m;
+  m.qkv = b.take(M * 3 * D + Mc * 2 * D);
+  m.P = nullptr;
+  m.O = b.take(M * D); m.u = b.take(M * DK); m.gate = b.take((size_t)bp * D); m.s = b.take((size_t)bp * DK);
+  m.f = b.take(M * D); m.mean = m.rstd = nullptr;
+  a.enc_slf = a.dec_slf = a.dec_enc = m;
+  a.y1 = b.take(M * D);
+  a.xc = ns < T ? b.take(Mc * D) : a.y1;
+  FfnBuf f{b.take(M * DI), m.f, nullptr, nullptr};
+  a.enc_ffn = a.dec_ffn = f;
+  a.mem = b.take(Mc * D);
+  a.xd = a.x0; a.meand = a.rstdd = nullptr;
+  a.d1 = b.take(M * D); a.d2 = b.take(M * D); a.d3 = a.d1;
+  return m.qkv && m.O && m.u && m.gate && m.s && m.f && a.emb_p && a.emb_q && a.x0 && a.y1 && a.xc && f.h && a.mem &&
+         a.d1 && a.d2;
+}
+
+// block seeds of the operator's ten dropout sites (two per attention block, one per feed-forward / prologue)
+enum { kSeedEncPro = 16, kSeedEncSlf, kSeedEncFfn, kSeedDecPro, kSeedDecSlf, kSeedDecEnc, kSeedDecFfn };
+
+int ait_forward(const float* x_props, const float* x_query, int bp, int bs, int n_src, const ait_transformer_weights* w,
+                const AitBufs& a, float p, float p_attn, unsigned long long seed, float* out, void* stream) {
+  hipStream_t hs = ait_stream(stream);
+  const int M = bp * T, P = bp / bs;
+  // embeddings (1x1 convolutions on token rows)
+  AIT_TRY(linear(x_props, bp * n_src, C2, w->enc_emb_w, D, w->enc_emb_b, false, a.emb_p, stream));
+  AIT_TRY(linear(x_query, bs * T, C2, w->dec_emb_w, D, w->dec_emb_b, false, a.emb_q, stream));
+  // ---- encoder (Models.py:83-111): zero-pad n_src -> 64 rows inside the LayerNorm row map --------
+  AIT_TRY(ait_ln_fwd(a.emb_p, w->pos_table, nullptr, w->enc_ln_g, w->enc_ln_b, M, D, T, n_src, 1, kEps, p,
+                     ait_dropout_seed(seed, kSeedEncPro), a.x0, a.mean0, a.rstd0, stream));
+  AIT_TRY(mha_block(a.x0, a.x0, bp, T, /*key padding*/ 1, n_src, w->enc_slf, a.enc_slf, p, p_attn,
+                    ait_dropout_seed(seed, kSeedEncSlf), a.y1, stream));
+  // only the n_src real rows of each sequence are read again: compact them (dead padded rows are
+  // masked as keys everywhere downstream)
+  if (n_src < T) {
+    if (hipMemcpy2DAsync(a.xc, (size_t)n_src * D * sizeof(float), a.y1, (size_t)T * D * sizeof(float),
+                         (size_t)n_src * D * sizeof(float), bp, hipMemcpyDeviceToDevice, hs) != hipSuccess)
+      return AIT_ELAUNCH;
+  }
+  AIT_TRY(ffn_block(a.xc, (long long)bp * n_src, w->enc_ffn, a.enc_ffn, p, ait_dropout_seed(seed, kSeedEncFfn), a.mem,
+                    stream));
+  // ---- decoder (Models.py:143-172): the query sequence of a pair repeated over its P proposals ----
+  AIT_TRY(ait_ln_fwd(a.emb_q, w->pos_table, nullptr, w->dec_ln_g, w->dec_ln_b, M, D, T, T, P, kEps, p,
+                     ait_dropout_seed(seed, kSeedDecPro), a.xd, a.meand, a.rstdd, stream));
+  AIT_TRY(mha_block(a.xd, a.xd, bp, T, /*causal*/ 2, 0, w->dec_slf, a.dec_slf, p, p_attn,
+                    ait_dropout_seed(seed, kSeedDecSlf), a.d1, stream));
+  AIT_TRY(mha_block(a.d1, a.mem, bp, n_src, /*none: the memory is unpadded*/ n_src < T ? 0 : 1, n_src, w->dec_enc,
+                    a.dec_enc, p, p_attn, ait_dropout_seed(seed, kSeedDecEnc), a.d2, stream));
+  AIT_TRY(ffn_block(a.d2, M, w->dec_ffn, a.dec_ffn, p, ait_dropout_seed(seed, kSeedDecFfn), a.d3, stream));
+  // dec_trans back to 2d channels per token
+  return linear(a.d3, M, D, w->dec_trans_w, C2, w->dec_trans_b, false, out, stream);
+}
+
+int check_ait(int bp, int bs, int n_src, const void* w) {
+  if (bp < 0 || bs <= 0 || n_src <= 0 || n_src > T || !w) return AIT_EINVAL;
+  if (bp % bs) return AIT_EINVAL;
+  if ((long long)bp * T > 0x7fffffffLL) return AIT_EUNSUPPORTED;   // GEMM row counts are ints
+  return AIT_OK;
+}
+}  // namespace
 
 AIT_API size_t ait_transformer_workspace_bytes(int bp, int bs, int n_src) {
   if (bp <= 0 || bs <= 0 || n_src <= 0 || n_src > T) return 0;
@@ -151,60 +496,118 @@ AIT_API size_t ait_transformer_workspace_bytes(int bp, int bs, int n_src) {
 AIT_API int ait_transformer_fwd(const float* x_props, const float* x_query, int bp, int bs, int n_src,
                                 const ait_transformer_weights* w, void* workspace, size_t workspace_bytes,
                                 float* out, void* stream) {
-  if (bp < 0 || bs <= 0 || n_src <= 0 || n_src > T || !w) return AIT_EINVAL;
-  if (bp % bs) return AIT_EINVAL;
+  AIT_TRY(check_ait(bp, bs, n_src, w));
   if (bp == 0) return AIT_OK;
   if (!x_props || !x_query || !out || !workspace) return AIT_EINVAL;
   if (workspace_bytes < ait_transformer_workspace_bytes(bp, bs, n_src)) return AIT_EWORKSPACE;
-  if ((long long)bp * T > 0x7fffffffLL) return AIT_EUNSUPPORTED;   // GEMM row counts are ints
-  hipStream_t hs = ait_stream(stream);
-  const int M = bp * T, P = bp / bs;
   Bump b{static_cast<char*>(workspace), workspace_bytes};
-  float* emb_p = b.take((size_t)bp * n_src * D);
-  float* emb_q = b.take((size_t)bs * T * D);
-  float* x = b.take((size_t)M * D);
-  float* qkv = b.take((size_t)M * 3 * D + (size_t)bp * n_src * 2 * D);
-  float* O = b.take((size_t)M * D);
-  float* u = b.take((size_t)M * DK);
-  float* gate = b.take((size_t)bp * D);
-  float* sp = b.take((size_t)bp * DK);
-  float* f = b.take((size_t)M * D);
-  float* y = b.take((size_t)M * D);
-  float* xc = b.take((size_t)bp * n_src * D);
-  float* h = b.take((size_t)M * DI);
-  float* mem = b.take((size_t)bp * n_src * D);
-  float* d1 = b.take((size_t)M * D);
-  float* d2 = b.take((size_t)M * D);
-  if (!emb_p || !emb_q || !x || !qkv || !O || !u || !gate || !sp || !f || !y || !xc || !h || !mem || !d1 || !d2)
-    return AIT_EWORKSPACE;
+  AitBufs a;
+  if (!carve_eval(b, a, bp, bs, n_src)) return AIT_EWORKSPACE;
+  return ait_forward(x_props, x_query, bp, bs, n_src, w, a, 0.f, 0.f, 0, out, stream);
+}
 
-  // embeddings (1x1 convolutions on token rows)
-  AIT_TRY(linear(x_props, bp * n_src, C2, w->enc_emb_w, D, w->enc_emb_b, false, emb_p, stream));
-  AIT_TRY(linear(x_query, bs * T, C2, w->dec_emb_w, D, w->dec_emb_b, false, emb_q, stream));
+AIT_API size_t ait_transformer_saved_bytes(int bp, int bs, int n_src) {
+  if (bp <= 0 || bs <= 0 || n_src <= 0 || n_src > T) return 0;
+  return ait_saved_floats(bp, bs, n_src) * sizeof(float) + 64 * 256;
+}
 
-  // ---- encoder (Models.py:83-111): zero-pad n_src -> 64 rows inside the LayerNorm row map --------
-  AIT_TRY(ait_ln_fwd(emb_p, w->pos_table, nullptr, w->enc_ln_g, w->enc_ln_b, M, D, T, n_src, 1, kEps, 0.f, 0, x,
-                     nullptr, nullptr, stream));
-  AIT_TRY(mha_block(x, x, bp, T, /*key padding*/ 1, n_src, w->enc_slf, qkv, O, u, gate, sp, f, y, stream));
-  // only the n_src real rows of each sequence are read again: compact them (dead padded rows are
-  // masked as keys everywhere downstream)
-  if (n_src < T) {
-    if (hipMemcpy2DAsync(xc, (size_t)n_src * D * sizeof(float), y, (size_t)T * D * sizeof(float),
-                         (size_t)n_src * D * sizeof(float), bp, hipMemcpyDeviceToDevice, hs) != hipSuccess)
-      return AIT_ELAUNCH;
-  } else {
-    xc = y;
+AIT_API int ait_transformer_fwd_train(const float* x_props, const float* x_query, int bp, int bs, int n_src,
+                                      const ait_transformer_weights* w, float p_drop, float p_attn_drop,
+                                      unsigned long long seed, void* saved, size_t saved_bytes, float* out,
+                                      void* stream) {
+  AIT_TRY(check_ait(bp, bs, n_src, w));
+  if (bad_p(p_drop) || bad_p(p_attn_drop)) return AIT_EINVAL;
+  if (bp == 0) return AIT_OK;
+  if (!x_props || !x_query || !out || !saved) return AIT_EINVAL;
+  if (saved_bytes < ait_transformer_saved_bytes(bp, bs, n_src)) return AIT_EWORKSPACE;
+  Bump b{static_cast<char*>(saved), saved_bytes};
+  AitBufs a;
+  if (!carve_train(b, a, bp, bs, n_src)) return AIT_EWORKSPACE;
+  return ait_forward(x_props, x_query, bp, bs, n_src, w, a, p_drop, p_attn_drop, seed, out, stream);
+}
+
+AIT_API size_t ait_transformer_bwd_workspace_bytes(int bp, int bs, int n_src) {
+  if (bp <= 0 || bs <= 0 || n_src <= 0 || n_src > T) return 0;
+  const size_t M = (size_t)bp * T;
+  // three gradient carriers [M, 512], d_emb_q, the widest block scratch (attention or feed-forward)
+  size_t blk = mha_bwd_ws_floats(bp, T, true) + M * 2 * D;
+  const size_t ffn = M * (2 * D + DI);
+  if (ffn > blk) blk = ffn;
+  return (3 * M * D + (size_t)bs * T * D + blk) * sizeof(float) + 32 * 256;
+}
+
+AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const float* x_query, int bp, int bs,
+                                int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
+                                unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
+                                size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                                const ait_transformer_grads* g, void* stream) {
+  AIT_TRY(check_ait(bp, bs, n_src, w));
+  if (bad_p(p_drop) || bad_p(p_attn_drop) || !g) return AIT_EINVAL;
+  if (bp == 0) return AIT_OK;
+  if (!d_out || !x_props || !x_query || !saved || !workspace) return AIT_EINVAL;
+  if (saved_bytes < ait_transformer_saved_bytes(bp, bs, n_src)) return AIT_EWORKSPACE;
+  if (workspace_bytes < ait_transformer_bwd_workspace_bytes(bp, bs, n_src)) return AIT_EWORKSPACE;
+  hipStream_t hs = ait_stream(stream);
+  const int M = bp * T, P = bp / bs, Mc = bp * n_src;
+  Bump bs_{static_cast<char*>(const_cast<void*>(saved)), saved_bytes};
+  AitBufs a;
+  if (!carve_train(bs_, a, bp, bs, n_src)) return AIT_EWORKSPACE;
+  Bump b{static_cast<char*>(workspace), workspace_bytes};
+  float* ga = b.take((size_t)M * D);
+  float* gb = b.take((size_t)M * D);
+  float* gc = b.take((size_t)M * D);
+  float* d_emb_q = b.take((size_t)bs * T * D);
+  if (!ga || !gb || !gc || !d_emb_q) return AIT_EWORKSPACE;
+  const Bump blk = b;        // every block carves its scratch from the same remainder
+  const float p = p_drop, pa = p_attn_drop;
+
+  // dec_trans: out = d3 W^T + b
+  if (g->dec_trans_b) AIT_TRY(ait_colsum_f32(d_out, M, C2, C2, g->dec_trans_b, stream));
+  AIT_TRY(wgrad(d_out, M, C2, a.d3, D, g->dec_trans_w, stream));
+  AIT_TRY(dgrad(d_out, M, C2, w->dec_trans_w, D, nullptr, false, ga, stream));                  // ga = d d3
+  {  // decoder feed-forward: d d3 -> d d2
+    Bump bb = blk; FfnBwdWs t;
+    if (!carve_ffn_ws(bb, t, M)) return AIT_EWORKSPACE;
+    AIT_TRY(ffn_block_bwd(ga, a.d2, M, w->dec_ffn, a.dec_ffn, t, p, ait_dropout_seed(seed, kSeedDecFfn), gb, g->dec_ffn,
+                          stream));
   }
-  AIT_TRY(ffn_block(xc, (long long)bp * n_src, w->enc_ffn, h, f, mem, stream));
+  float* d_mem = gc;     // [Mc, 512]
+  {  // decoder cross-attention: d d2 -> d d1, d mem
+    Bump bb = blk; MhaBwdWs t;
+    if (!carve(bb, t, bp, n_src, true)) return AIT_EWORKSPACE;
+    AIT_TRY(mha_block_bwd(gb, T, a.d1, a.mem, bp, n_src, w->dec_enc, a.dec_enc, t, p, pa,
+                          ait_dropout_seed(seed, kSeedDecEnc), ga, d_mem, g->dec_enc, stream));
+  }
+  {  // decoder self-attention: d d1 -> d xd
+    Bump bb = blk; MhaBwdWs t;
+    if (!carve(bb, t, bp, T, false)) return AIT_EWORKSPACE;
+    AIT_TRY(mha_block_bwd(ga, T, a.xd, a.xd, bp, T, w->dec_slf, a.dec_slf, t, p, pa, ait_dropout_seed(seed, kSeedDecSlf),
+                          gb, nullptr, g->dec_slf, stream));
+  }
+  // decoder prologue: LayerNorm(dropout(repeat_P(emb_q) + pos)); the P copies' gradients are summed
+  AIT_TRY(ait_ln_bwd(gb, a.emb_q, w->pos_table, nullptr, w->dec_ln_g, a.meand, a.rstdd, M, D, T, T, P, T, p,
+                     ait_dropout_seed(seed, kSeedDecPro), ga, nullptr, g->dec_ln_g, g->dec_ln_b, g->dec_emb_b, stream));
+  if (hipMemsetAsync(d_emb_q, 0, (size_t)bs * T * D * sizeof(float), hs) != hipSuccess) return AIT_ELAUNCH;
+  AIT_TRY(ait_rep_sum_f32(ga, bs, P, (long long)T * D, d_emb_q, stream));
+  AIT_TRY(wgrad(d_emb_q, (long long)bs * T, D, x_query, C2, g->dec_emb_w, stream));
+  if (d_x_query) AIT_TRY(dgrad(d_emb_q, bs * T, D, w->dec_emb_w, C2, nullptr, false, d_x_query, stream));
 
-  // ---- decoder (Models.py:143-172): the query sequence of a pair repeated over its P proposals ----
-  AIT_TRY(ait_ln_fwd(emb_q, w->pos_table, nullptr, w->dec_ln_g, w->dec_ln_b, M, D, T, T, P, kEps, 0.f, 0, x,
-                     nullptr, nullptr, stream));
-  AIT_TRY(mha_block(x, x, bp, T, /*causal*/ 2, 0, w->dec_slf, qkv, O, u, gate, sp, f, d1, stream));
-  AIT_TRY(mha_block(d1, mem, bp, n_src, /*none: the memory is unpadded*/ n_src < T ? 0 : 1, n_src, w->dec_enc, qkv, O,
-                    u, gate, sp, f, d2, stream));
-  AIT_TRY(ffn_block(d2, M, w->dec_ffn, h, f, d1, stream));
-
-  // dec_trans back to 2d channels per token
-  return linear(d1, M, D, w->dec_trans_w, C2, w->dec_trans_b, false, out, stream);
+  {  // encoder feed-forward on the compacted rows: d mem -> d xc
+    Bump bb = blk; FfnBwdWs t;
+    if (!carve_ffn_ws(bb, t, Mc)) return AIT_EWORKSPACE;
+    AIT_TRY(ffn_block_bwd(d_mem, a.xc, Mc, w->enc_ffn, a.enc_ffn, t, p, ait_dropout_seed(seed, kSeedEncFfn), ga,
+                          g->enc_ffn, stream));
+  }
+  {  // encoder self-attention: its output received a gradient only on the n_src real rows of a sequence
+    Bump bb = blk; MhaBwdWs t;
+    if (!carve(bb, t, bp, T, false)) return AIT_EWORKSPACE;
+    AIT_TRY(mha_block_bwd(ga, n_src, a.x0, a.x0, bp, T, w->enc_slf, a.enc_slf, t, p, pa,
+                          ait_dropout_seed(seed, kSeedEncSlf), gb, nullptr, g->enc_slf, stream));
+  }
+  // encoder prologue: LayerNorm(dropout(pad(emb_p) + pos)); the gradient is indexed by source row
+  AIT_TRY(ait_ln_bwd(gb, a.emb_p, w->pos_table, nullptr, w->enc_ln_g, a.mean0, a.rstd0, M, D, T, n_src, 1, T, p,
+                     ait_dropout_seed(seed, kSeedEncPro), ga, nullptr, g->enc_ln_g, g->enc_ln_b, g->enc_emb_b, stream));
+  AIT_TRY(wgrad(ga, Mc, D, x_props, C2, g->enc_emb_w, stream));
+  if (d_x_props) AIT_TRY(dgrad(ga, Mc, D, w->enc_emb_w, C2, nullptr, false, d_x_props, stream));
+  return AIT_OK;
 }

@@ -30,24 +30,6 @@ def _gemm_fn(exact=False):
     return {"f32": L.ait_gemm_f32, "bf16": L.ait_gemm_bf16, "bf16x3": L.ait_gemm_bf16x3}[MATMUL_DTYPE]
 
 
-# When set to a list, every GEMM launch appends (flops, start_event, end_event) recorded on the
-# launch stream (bench.py's live roofline measurement).
-GEMM_PROFILE = None
-
-
-def _profiled(fn, flops, device, tag=None):
-    if GEMM_PROFILE is None:
-        return fn()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    st = torch.cuda.current_stream(device)
-    e0.record(st)
-    rc = fn()
-    e1.record(st)
-    GEMM_PROFILE.append((flops, e0, e1) if tag is None else (flops, e0, e1, tag))
-    return rc
-
-
 def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, relu=False,
          accumulate=False, alpha=1.0, split_k=1, bias_row=False, c_colblk=0, c_batch_stride=0,
          out_shape=None, exact=False):
@@ -72,17 +54,30 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, 
         out = torch.empty(out_shape or (M, N), dtype=torch.float32, device=a.device)
         if accumulate or split_k > 1:
             out.zero_()
+    else:
+        # a caller-supplied destination is written in place: it must be exactly what the kernel
+        # addresses.  With split_k > 1 the partial tiles are ADDED to `out` with atomics: the caller
+        # has zeroed it (or wants the product accumulated into what it holds).
+        if not out.is_cuda or out.device != a.device or out.dtype != torch.float32:
+            raise _lib.AitHipError("gemm: `out` must be a float32 tensor on %s" % (a.device,))
+        if c_colblk == 0:
+            if out.dim() != 2 or tuple(out.shape) != (M, N) or out.stride(1) != 1 or out.stride(0) < N:
+                raise _lib.AitHipError("gemm: `out` must be [%d, %d] with unit column stride (got %s, strides %s)"
+                                       % (M, N, tuple(out.shape), out.stride()))
+        elif not out.is_contiguous() or (out_shape is not None and tuple(out.shape) != tuple(out_shape)):
+            raise _lib.AitHipError("gemm: column-blocked `out` must be contiguous and of shape out_shape")
     ldc = c_colblk if c_colblk > 0 else out.stride(0)
+    # (an empty reduction, K == 0, never reads A or B: any legal pitch will do)
+    lda, ldb = (a.stride(0), b.stride(0)) if K > 0 else (4, 4)
     flags = (_lib.GEMM_RELU if relu else 0) \
         | (_lib.GEMM_ACCUMULATE if accumulate and split_k == 1 else 0) \
         | (_lib.GEMM_ATOMIC if split_k > 1 else 0) | (_lib.GEMM_BIAS_ROW if bias_row else 0)
     with torch.cuda.device(a.device):
-        rc = _profiled(lambda: _gemm_fn(exact)(
-            int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.dev_ptr(a), a.stride(0),
-            _lib.dev_ptr(b), b.stride(0), ctypes.c_void_p(out.data_ptr()), ldc, _p(bias),
+        rc = _gemm_fn(exact)(
+            int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.dev_ptr(a), lda,
+            _lib.dev_ptr(b), ldb, ctypes.c_void_p(out.data_ptr()), ldc, _p(bias),
             _p(residual), flags, int(split_k), int(c_colblk), int(c_batch_stride),
-            _lib.cur_stream(a.device)), 2.0 * M * N * K, a.device,
-            (M, N, K, int(trans_a), int(trans_b), int(split_k), int(c_colblk)))
+            _lib.cur_stream(a.device))
     _lib.check(rc, "ait_gemm_f32")
     return out
 
@@ -94,10 +89,10 @@ def gemm_relu_bwd(dy, w, act, out=None):
     if out is None:
         out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
     with torch.cuda.device(dy.device):
-        rc = _profiled(lambda: _gemm_fn()(
+        rc = _gemm_fn()(
             0, 0, M, K, N, 1.0, _lib.dev_ptr(dy), dy.stride(0), _lib.dev_ptr(w), w.stride(0),
             _lib.dev_ptr(out), out.stride(0), None, _lib.dev_ptr(act), _lib.GEMM_MASK_POS, 1, 0, 0,
-            _lib.cur_stream(dy.device)), 2.0 * M * N * K, dy.device, (M, K, N, 0, 0, 1, -1))
+            _lib.cur_stream(dy.device))
     _lib.check(rc, "ait_gemm_f32(mask)")
     return out
 
@@ -119,21 +114,50 @@ def ln_fwd(a, pos, residual, gamma, beta, rows, seq_len, src_rows, rep, eps, p, 
 
 
 def ln_bwd(dy, a, pos, residual, gamma, mean, rstd, rows, seq_len, src_rows, rep, p, seed,
-           need_da=True, need_dres=True):
+           need_da=True, need_dres=True, dy_rows=None, colsum=False):
+    """colsum=True also returns the column sums of da (the bias gradient of the linear layer that
+    produced `a`) as a fifth value; dy_rows: dy holds only that many rows per sequence."""
     dev = dy.device
     da = None
     if need_da:
         n_src = a.shape[0] if rep == 1 else rows
         da = torch.empty((n_src, D_MODEL), dtype=torch.float32, device=dev)
     dres = torch.empty((rows, D_MODEL), dtype=torch.float32, device=dev) if need_dres else None
-    dgb = torch.zeros((2, D_MODEL), dtype=torch.float32, device=dev)
+    dgb = torch.zeros((3, D_MODEL), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.lib().ait_ln_bwd(_p(dy), _p(a), _p(pos), _p(residual), _p(gamma), _p(mean),
-                                   _p(rstd), rows, D_MODEL, seq_len, src_rows, rep, float(p),
+                                   _p(rstd), rows, D_MODEL, seq_len, src_rows, rep,
+                                   seq_len if dy_rows is None else int(dy_rows), float(p),
                                    int(seed), _p(da), _p(dres), _p(dgb[0]), _p(dgb[1]),
-                                   _lib.cur_stream(dev))
+                                   _p(dgb[2]) if colsum else None, _lib.cur_stream(dev))
     _lib.check(rc, "ait_ln_bwd")
+    if colsum:
+        return da, dres, dgb[0], dgb[1], dgb[2]
     return da, dres, dgb[0], dgb[1]
+
+
+def colsum(x):
+    """sum over the rows of a 2-D tensor (bias gradients) -> [cols]"""
+    assert x.dim() == 2 and x.stride(1) == 1
+    out = torch.zeros((x.shape[1],), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().ait_colsum_f32(ctypes.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], x.stride(0),
+                                       _p(out), _lib.cur_stream(x.device))
+    _lib.check(rc, "ait_colsum_f32")
+    return out
+
+
+def rep_sum(x, groups, rep, E):
+    """x [groups*rep*E] -> out [groups*E]: sum over the rep copies of each E-float block"""
+    out = torch.zeros((groups * E,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().ait_rep_sum_f32(_p(x), int(groups), int(rep), int(E), _p(out), _lib.cur_stream(x.device))
+    _lib.check(rc, "ait_rep_sum_f32")
+    return out
+
+
+def dropout_seed(base, site):
+    return int(_lib.lib().ait_dropout_seed(int(base), int(site)))
 
 
 def sh_fwd(O, sk_w, sk_b):

@@ -14,7 +14,6 @@ import ctypes
 
 from . import _lib
 
-
 class _ROIAlign(Function):
     @staticmethod
     def forward(ctx, input, roi, output_size, spatial_scale, sampling_ratio):
@@ -162,7 +161,7 @@ def nms_sorted_batched(dets, threshold, max_keep=0):
     keep = torch.empty((b, max(n, 1)), dtype=torch.int64, device=dets.device)
     n_keep = torch.zeros((b,), dtype=torch.int32, device=dets.device)
     L = _lib.lib()
-    ws_bytes = max(L.ait_nms_batched_workspace_bytes(b, n), L.ait_nms_workspace_bytes(n))
+    ws_bytes = L.ait_nms_batched_workspace_bytes(b, n)
     ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dets.device)
     with torch.cuda.device(dets.device):
         rc = L.ait_nms_batched(_lib.dev_ptr(dets) if n else None, b, n, float(threshold),

@@ -30,9 +30,40 @@ LN_EPS = 1e-6
 SEQ = 64          # tokens per sequence on the AIT path (8x8 query cells)
 
 
+def _rank_salt():
+    """Distinct per data-parallel rank: ranks are usually seeded identically (identical initial
+    weights), and a dropout mask is a pure function of (seed, element index) -- without the salt every
+    rank would draw bit-identical masks each step."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        r = torch.distributed.get_rank()
+    else:
+        r = int(os.environ.get("RANK", "0"))
+    return (r * 0x9E3779B97F4A7C15) & (2 ** 62 - 1)
+
+
+_SEED_QUEUE = None      # fine-grained Transformer.forward: the site seeds the C entry points would derive
+
+
 def _new_seed():
-    """64-bit dropout seed drawn from torch's CPU generator (reproducible under manual_seed)."""
-    return int(torch.randint(0, 2 ** 62, (1,)).item())
+    """Dropout seed: drawn from torch's CPU generator (reproducible under manual_seed) and salted with
+    the rank.  Inside the fine-grained Transformer.forward the ten site seeds are taken, in call order,
+    from the list derived with ait_dropout_seed -- the masks of ait_transformer_fwd_train."""
+    if _SEED_QUEUE:
+        return _SEED_QUEUE.pop(0)
+    return int(torch.randint(0, 2 ** 62, (1,)).item()) ^ _rank_salt()
+
+
+# block seed indices of csrc/transformer.hip (kSeedEncPro ...), in the order the fine-grained path
+# reaches its dropout sites; attention blocks have two sites (probabilities 0, fc output 1)
+_SITE_ORDER = ((16, 0), (17, 0), (17, 1), (18, 0), (19, 0), (20, 0), (20, 1), (21, 0), (21, 1), (22, 0))
+
+
+def _site_seeds(base):
+    out = []
+    for blk, site in _SITE_ORDER:
+        b = ops.dropout_seed(base, blk)
+        out.append(b if blk in (16, 19) else ops.dropout_seed(b, site))
+    return out
 
 
 # ------------------------------------------------------------------------------------------
@@ -102,7 +133,7 @@ class _Linear(torch.autograd.Function):
         dy = dy.contiguous()
         dx = ops.gemm(dy, w, trans_b=False) if ctx.needs_input_grad[0] else None
         dw = _wgrad(dy, x) if ctx.needs_input_grad[1] else None
-        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = ops.colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 
@@ -121,10 +152,10 @@ class _FFN(torch.autograd.Function):
         x, w1, w2, h = ctx.saved_tensors
         df = df.contiguous()
         dw2 = _wgrad(df, h)
-        db2 = df.sum(0)
+        db2 = ops.colsum(df)
         dh = ops.gemm_relu_bwd(df, w2, h)          # (df W2) gated by h > 0
         dw1 = _wgrad(dh, x)
-        db1 = dh.sum(0)
+        db1 = ops.colsum(dh)
         dx = ops.gemm(dh, w1, trans_b=False)
         return dx, dw1, db1, dw2, db2
 
@@ -149,7 +180,8 @@ class _DropResLN(torch.autograd.Function):
                                       seq_len, src_rows, rep, p, seed,
                                       need_da=ctx.needs_input_grad[0], need_dres=need_res)
         if da is not None and rep > 1:   # the query sequence was repeated over the proposals
-            da = da.view(-1, rep, src_rows, ops.D_MODEL).sum(1).reshape(-1, ops.D_MODEL)
+            E = src_rows * ops.D_MODEL
+            da = ops.rep_sum(da, da.numel() // (rep * E), rep, E).view(-1, ops.D_MODEL)
         return da, None, dres, dg, db, None, None, None, None, None, None
 
 
@@ -217,7 +249,7 @@ class _SelectiveHeads(torch.autograd.Function):
         dO, dg = ops.sh_bwd(du.contiguous(), O, gate, sk_w)
         dw = ops.gemm(dg, s, trans_a=True, trans_b=False,
                       split_k=8 if dg.shape[0] >= 512 else 1)       # [H*dv, dv] = dg^T s
-        return dO, dw, dg.sum(0)
+        return dO, dw, ops.colsum(dg)
 
 
 class _ToNCHW(torch.autograd.Function):
@@ -240,7 +272,74 @@ class _ToNCHW(torch.autograd.Function):
         dyt = dy.reshape(n_seq, ch, T).transpose(1, 2).reshape(n_seq * T, ch)   # [M, ch]
         dx = ops.gemm(dyt, w, trans_b=False)
         dw = _wgrad(dyt, x)
-        return dx, dw, dyt.sum(0), None, None
+        return dx, dw, ops.colsum(dyt.contiguous()), None, None
+
+
+class _TransformerFn(torch.autograd.Function):
+    """The whole AIT operator in training: ait_transformer_fwd_train / ait_transformer_bwd
+    (include/ait_hip.h).  One autograd node: the forward saves its activations into ONE buffer the
+    library lays out, the backward writes both input gradients and accumulates the 46 parameter
+    gradients into one zero-filled buffer whose views are handed to autograd."""
+
+    @staticmethod
+    def forward(ctx, xp, xq, bp, bs, n_s, p, p_attn, seed, W, keep, *params):
+        L = _lib.lib()
+        dev = xp.device
+        xp, xq = xp.contiguous(), xq.contiguous()
+        nbytes = int(L.ait_transformer_saved_bytes(bp, bs, n_s))
+        saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((bp * SEQ, xp.shape[1]), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.ait_transformer_fwd_train(_lib.dev_ptr(xp), _lib.dev_ptr(xq), bp, bs, n_s, ctypes.byref(W),
+                                             float(p), float(p_attn), int(seed), ctypes.c_void_p(saved.data_ptr()),
+                                             nbytes, _lib.dev_ptr(out), _lib.cur_stream(dev))
+        _lib.check(rc, "ait_transformer_fwd_train")
+        ctx.save_for_backward(xp, xq, saved)
+        ctx.W, ctx.keep = W, keep              # (keep owns the concatenated QKV matrices W points into)
+        ctx.cfg = (bp, bs, n_s, float(p), float(p_attn), int(seed))
+        ctx.shapes = [tuple(t.shape) for t in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        L = _lib.lib()
+        xp, xq, saved = ctx.saved_tensors
+        bp, bs, n_s, p, p_attn, seed = ctx.cfg
+        dev = xp.device
+        d_out = d_out.contiguous()
+        # one zero-filled buffer for every parameter gradient (they are ACCUMULATED by the library)
+        sizes = [int(np.prod(sh)) for sh in ctx.shapes]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        views, o = [], 0
+        for sh, n in zip(ctx.shapes, sizes):
+            views.append(flat[o:o + n].view(sh))
+            o += n
+        G = _lib.TransformerGrads()
+        ptr = lambda i: views[i].data_ptr()
+        G.enc_emb_w, G.enc_emb_b, G.dec_emb_w, G.dec_emb_b = ptr(0), ptr(1), ptr(2), ptr(3)
+        G.dec_trans_w, G.dec_trans_b = ptr(4), ptr(5)
+        G.enc_ln_g, G.enc_ln_b, G.dec_ln_g, G.dec_ln_b = ptr(6), ptr(7), ptr(8), ptr(9)
+        for j, name in enumerate(("enc_slf", "dec_slf", "dec_enc")):
+            b = 10 + 8 * j       # w_qs, w_ks, w_vs (contiguous = the [1536, 512] layout of w_qkv), sk.w, sk.b, fc, ln
+            g = getattr(G, name)
+            g.w_qkv, g.sk_w, g.sk_b, g.fc_w, g.ln_g, g.ln_b = ptr(b), ptr(b + 3), ptr(b + 4), ptr(b + 5), ptr(b + 6), ptr(b + 7)
+        for j, name in enumerate(("enc_ffn", "dec_ffn")):
+            b = 34 + 6 * j
+            g = getattr(G, name)
+            g.w1, g.b1, g.w2, g.b2, g.ln_g, g.ln_b = (ptr(b + i) for i in range(6))
+        dxp = torch.empty_like(xp) if ctx.needs_input_grad[0] else None
+        dxq = torch.empty_like(xq) if ctx.needs_input_grad[1] else None
+        wbytes = int(L.ait_transformer_bwd_workspace_bytes(bp, bs, n_s))
+        ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.ait_transformer_bwd(_lib.dev_ptr(d_out), _lib.dev_ptr(xp), _lib.dev_ptr(xq), bp, bs, n_s,
+                                       ctypes.byref(ctx.W), p, p_attn, seed, ctypes.c_void_p(saved.data_ptr()),
+                                       saved.numel(), ctypes.c_void_p(ws.data_ptr()), wbytes,
+                                       None if dxp is None else _lib.dev_ptr(dxp),
+                                       None if dxq is None else _lib.dev_ptr(dxq), ctypes.byref(G),
+                                       _lib.cur_stream(dev))
+        _lib.check(rc, "ait_transformer_bwd")
+        return (dxp, dxq, None, None, None, None, None, None, None, None) + tuple(views)
 
 
 # ------------------------------------------------------------------------------------------
@@ -331,18 +430,23 @@ class MultiHeadAttention(nn.Module):
         H, d = self.n_head, self.d_k
         mode, n_valid = _mask_code(mask)
         p = self.p if self.training else 0.0
+        # the probabilities' dropout rate is ScaledDotProductAttention's own (fixed at 0.1 by the
+        # reference's constructor, Modules.py:14 / SubLayers.py:61), not the sub-layer's `dropout`.
+        # The returned `attn` holds the probabilities BEFORE dropout (the reference returns them
+        # after; its callers discard them, Layers.py:26-29).
+        p_attn = self.attention.dropout.p if self.training else 0.0
         xq = x_q.reshape(n_seq * SEQ, self.d_model)
         if x_kv is x_q:
             w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
             qkv = _Linear.apply(xq, w, None)
-            O, attn = _AttnSelf.apply(qkv, n_seq, H, d, mode, n_valid, 1.0 / self.d_k ** 0.5, p,
+            O, attn = _AttnSelf.apply(qkv, n_seq, H, d, mode, n_valid, 1.0 / self.d_k ** 0.5, p_attn,
                                       _new_seed())
         else:
             xkv = x_kv.reshape(n_seq * x_kv.size(1), self.d_model)
             qp = _Linear.apply(xq, self.w_qs.weight, None)
             kv = _Linear.apply(xkv, torch.cat([self.w_ks.weight, self.w_vs.weight], 0), None)
             O, attn = _AttnCross.apply(qp, kv, n_seq, H, d, mode, n_valid, 1.0 / self.d_k ** 0.5,
-                                       p, _new_seed())
+                                       p_attn, _new_seed())
         u = _SelectiveHeads.apply(O, self.sh.sk.weight, self.sh.sk.bias)      # [n, T, dv]
         f = _Linear.apply(u.view(n_seq * SEQ, d), self.fc.weight, None)
         y = _DropResLN.apply(f, None, xq, self.layer_norm.weight, self.layer_norm.bias,
@@ -547,6 +651,30 @@ class Transformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
+    def _param_list(self):
+        """the 46 parameters in the order of ait_transformer_grads (_TransformerFn.backward)"""
+        enc, dec = self.encoder.layer_stack[0], self.decoder.layer_stack[0]
+        ps = [self.enc_emb[0].weight, self.enc_emb[0].bias, self.dec_emb[0].weight, self.dec_emb[0].bias,
+              self.dec_trans[0].weight, self.dec_trans[0].bias, self.encoder.layer_norm.weight,
+              self.encoder.layer_norm.bias, self.decoder.layer_norm.weight, self.decoder.layer_norm.bias]
+        for m in (enc.slf_attn, dec.slf_attn, dec.enc_attn):
+            ps += [m.w_qs.weight, m.w_ks.weight, m.w_vs.weight, m.sh.sk.weight, m.sh.sk.bias, m.fc.weight,
+                   m.layer_norm.weight, m.layer_norm.bias]
+        for m in (enc.pos_ffn, dec.pos_ffn):
+            ps += [m.w_1.weight, m.w_1.bias, m.w_2.weight, m.w_2.bias, m.layer_norm.weight, m.layer_norm.bias]
+        return ps
+
+    def _c_weights_cached(self):
+        """_c_weights(), rebuilt only when a parameter changed (the concatenated QKV matrices are
+        copies: an optimizer step bumps the parameters' version counters and invalidates them)."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        c = getattr(self, "_ait_wcache", None)
+        if c is None or c[0] != key:
+            W, keep = self._c_weights()
+            c = (key, W, keep)
+            self._ait_wcache = c
+        return c[1], c[2]
+
     def _c_weights(self):
         """ait_transformer_weights (include/ait_hip.h) over this module's parameters; the returned
         keep-alive list owns the concatenated QKV matrices."""
@@ -608,8 +736,10 @@ class Transformer(nn.Module):
         n_s, n_t = hp * wp, hq * wq
         if n_t != SEQ or n_s > SEQ or bp % bs:
             raise NotImplementedError("AIT HIP path: query must be 8x8 cells, proposals <= 64 cells")
+        # (the C entry points multiply in exact fp32; the opt-in bf16 matmul modes of ops.set_matmul_dtype
+        # go through the fine-grained composition, whose GEMM calls honour the switch)
         if (not self.training and not torch.is_grad_enabled() and len(self.encoder.layer_stack) == 1
-                and os.environ.get("AIT_COMPACT_MEMORY", "1") != "0"):
+                and os.environ.get("AIT_COMPACT_MEMORY", "1") != "0" and ops.MATMUL_DTYPE == "f32"):
             # inference: the whole operator is ONE call into the C ABI (ait_transformer_fwd)
             xp = x_props.reshape(bp, c2, n_s).transpose(1, 2).reshape(bp * n_s, c2).contiguous()
             xq = x_query.reshape(bs, c2, n_t).transpose(1, 2).reshape(bs * n_t, c2).contiguous()
@@ -622,6 +752,28 @@ class Transformer(nn.Module):
         # NCHW -> token-major rows for the embedding GEMMs
         xp = x_props.reshape(bp, c2, n_s).transpose(1, 2).reshape(bp * n_s, c2)
         xq = x_query.reshape(bs, c2, n_t).transpose(1, 2).reshape(bs * n_t, c2)
+        p = self.encoder.p if self.training else 0.0
+        p_attn = self.encoder.layer_stack[0].slf_attn.attention.dropout.p if self.training else 0.0
+        base_seed = _new_seed()
+        fine = os.environ.get("AIT_PY_COMPOSE", "0") == "1" or os.environ.get("AIT_COMPACT_MEMORY", "1") == "0" \
+            or ops.MATMUL_DTYPE != "f32"
+        if len(self.encoder.layer_stack) == 1 and len(self.decoder.layer_stack) == 1 and not fine:
+            # training: the whole operator is ONE autograd node over ait_transformer_fwd_train / _bwd
+            W, keep = self._c_weights_cached()
+            out = _TransformerFn.apply(xp, xq, bp, bs, n_s, p, p_attn, base_seed, W, keep, *self._param_list())
+            if self.channels_last_out:
+                return out.view(bp, hq, wq, c2).permute(0, 3, 1, 2)
+            return out.view(bp, n_t, c2).transpose(1, 2).reshape(bp, c2, hq, wq)
+        # fine-grained composition (AIT_PY_COMPOSE=1): autograd over the building blocks, with the site
+        # seeds the C entry points derive -- same kernels, same order, same masks
+        global _SEED_QUEUE
+        _SEED_QUEUE = _site_seeds(base_seed)
+        try:
+            return self._forward_fine(x_props, x_query, xp, xq, bp, bs, P, d, c2, n_s, n_t, hq, wq)
+        finally:
+            _SEED_QUEUE = None
+
+    def _forward_fine(self, x_props, x_query, xp, xq, bp, bs, P, d, c2, n_s, n_t, hq, wq):
         emb_p = _Linear.apply(xp, self.enc_emb[0].weight.view(d, c2), self.enc_emb[0].bias)
         emb_q = _Linear.apply(xq, self.dec_emb[0].weight.view(d, c2), self.dec_emb[0].bias)
         src_mask, trg_mask = KeyPadMask(n_s), CausalMask()

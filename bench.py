@@ -25,6 +25,37 @@ sys.path.insert(0, ROOT)
 
 METRIC = "(target,query) pairs/sec fwd+bwd, ResNet50 300 proposals, at 1/2/4/8 MI355X"
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+AIT_TFLOP_PER_PAIR = 0.911       # AIT forward + backward at P = 300, as computed by the reference
+
+
+def measured_peaks(device):
+    """What this box attains on the two rooflines, next to the spec peaks: a register-only
+    v_mfma_f32_32x32x2_f32 loop (scripts/mfma_peak.hip, built by __graft_entry__.build(), run as a child
+    process) and a 1-GiB device-to-device copy."""
+    import subprocess
+    out = {"mfma_f32_tflops": None, "hbm_copy_gbs": None}
+    exe = os.path.join(ROOT, "scripts", "_mfma_peak")
+    if os.path.exists(exe):
+        try:
+            r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=60)
+            vals = [float(l.split("ms")[1].split("TFLOP/s")[0]) for l in r.stdout.splitlines() if "TFLOP/s" in l]
+            out["mfma_f32_tflops"] = max(vals) if vals else None
+        except Exception:
+            pass
+    x = torch.empty(1 << 28, dtype=torch.float32, device=device)
+    y = torch.empty_like(x)
+    for _ in range(2):
+        y.copy_(x)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        y.copy_(x)
+    e1.record()
+    torch.cuda.synchronize()
+    out["hbm_copy_gbs"] = 5 * 2 * x.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9     # read + write
+    del x, y
+    return out
 
 
 def synth_batch(bs, seed, device, im_hw=(600, 1000), q=128, max_gt=20, n_gt=3):
@@ -71,9 +102,11 @@ def total_cost(out):
     return out[3].mean() + out[4].mean() + out[5].mean() + out[7].mean() + out[6].mean()
 
 
-def cpu_baseline(P, seconds_budget=25.0):
+def cpu_baseline(P, seconds_budget=16.0):
     """The CPU oracle (oracle/detector_ref.py, a port of the reference path; the reference itself
-    cannot run backward on CPU) timed on this box's host cores on ONE pair at a time."""
+    cannot run backward on CPU) timed on this box's host cores on ONE pair at a time.  `value` is
+    SURVEY 8d's figure (ii), the full forward + backward; (i) the eval forward and (iii) the AIT alone
+    ride along."""
     try:
         from oracle import detector_ref
     except Exception as e:          # the checker is optional for the timing run
@@ -81,10 +114,15 @@ def cpu_baseline(P, seconds_budget=25.0):
                 "sample": "oracle unavailable: %r" % (e,)}
     cores = min(64, os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    return detector_ref.time_train_step(P=P, cores=cores, seconds_budget=seconds_budget)
+    out = detector_ref.time_train_step(P=P, cores=cores, seconds_budget=seconds_budget)
+    ev = detector_ref.time_eval_forward(P=P, cores=cores, seconds_budget=5.0)
+    ao = detector_ref.time_ait_only(P=P, cores=cores, seconds_budget=6.0)
+    out["eval_forward"] = {"value": ev["value"], "unit": "pairs/s", "sample": ev["sample"]}
+    out["ait_only_fwd_bwd"] = {"value": ao["value"], "unit": "pairs/s", "sample": ao["sample"]}
+    return out
 
 
-def pmc_traffic_per_launch(kernel_prefix="gemm_f32_kernel"):
+def pmc_traffic_per_launch(kernel_prefix="gemm_f32_"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
     same command (profiles/pmc_fetch_r*.csv, pmc_write_r*.csv; separate --pmc runs, summarised by
     scripts/pmc_summary.py).  Correction per MI355X_MICROARCH.md "HBM": FETCH_SIZE reports half
@@ -149,33 +187,54 @@ def main():
         total_cost(out).backward()
         opt.step()
 
+    peaks = measured_peaks(device) if rank == 0 else None
     for _ in range(args.warmup):
         step()
-    ops.GEMM_PROFILE = []
+    # live roofline measurement: the library brackets every GEMM / RoIAlign launch of the timed region with
+    # HIP events on its launch stream (include/ait_hip.h "Measurement"), wherever the launch comes from
+    probe = _lib.Probe(1024 * max(1, args.steps))
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    with probe:
+        for _ in range(args.steps):
+            step()
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
-    prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
     elapsed = D.max_over_ranks(elapsed, device)
 
     if rank != 0:
         return
+    entries = probe.entries()
+    # (flops, ms, (M, N, K, trans_a, trans_b, splits))
+    prof = [(e[1], e[2], e[3]) for e in entries if e[0] == _lib.PROBE_GEMM]
+    roi_prof = [(e[1], e[2], "fwd" if e[0] == _lib.PROBE_ROI_FWD else "bwd") for e in entries
+                if e[0] in (_lib.PROBE_ROI_FWD, _lib.PROBE_ROI_BWD)]
     flops = sum(p[0] for p in prof)
-    gemm_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
+    gemm_ms = sum(p[1] for p in prof)
     achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     pairs = world * args.bs * args.steps
     # dense MFMA peak for the arithmetic: fp32, bf16, or bf16 / 3 MFMAs per product
     peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.dtype]
     pmc = pmc_traffic_per_launch() if args.dtype == "f32" else None
     # algorithmic bytes of the same launches: each operand read once, the output written once
-    alg = sum(4.0 * (p[3][0] * p[3][2] + p[3][1] * p[3][2] + p[3][0] * p[3][1]) for p in prof) / max(1, len(prof))
+    alg = sum(4.0 * (p[2][0] * p[2][2] + p[2][1] * p[2][2] + p[2][0] * p[2][1]) for p in prof) / max(1, len(prof))
+    def roi_entry(tag):
+        ev = [p for p in roi_prof if p[2] == tag]
+        if not ev:
+            return None
+        ms = sum(p[1] for p in ev) / len(ev)
+        b = sum(p[0] for p in ev) / len(ev)
+        gbs = b / (ms * 1e-3) / 1e9
+        return {"kernel": "roi_align_nhwc_%s_kernel" % tag, "bound": "hbm", "achieved": gbs,
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "ms_per_launch": ms,
+                "algorithmic_bytes_per_launch": b, "launches_per_step": len(ev) // max(1, args.steps),
+                "traffic": pmc_traffic_per_launch("roi_align_nhwc_%s_kernel" % tag)}
+
+    value = pairs / elapsed
     line = {
-        "metric": METRIC, "value": pairs / elapsed, "unit": "pairs/s", "n_gpus": world,
+        "metric": METRIC, "value": value, "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32", "bf16": "bf16 (AIT GEMM operands; fp32 accumulate, fp32 elsewhere)",
@@ -183,11 +242,13 @@ def main():
         "data": "synthetic",
         "config": {"workload": "ResNet50 VOC seen-classes, %d proposals, bs=%d per GPU, "
                                "fwd+bwd+SGD step (BASELINE.json configs[1])" % (args.proposals, args.bs),
+                   "variant": "voc (MultiHeadAttention co-attention, 9 anchors)",
                    "pairs_per_gpu": args.bs, "global_batch": world * args.bs,
+                   "collective": "none" if world == 1 else "DDP gradient all-reduce over RCCL (nccl), 25 MB buckets",
                    "proposals": args.proposals, "target": "600x1000", "query": "128x128",
                    "parallelism": "dp%d" % world, "miopen_find_db": bool(tuned)},
         "roofline": {"bound": "mfma",
-                     "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)" if args.dtype == "f32"
+                     "kernel": "gemm_f32_stream_kernel / gemm_f32_kernel (v_mfma_f32_32x32x2_f32)" if args.dtype == "f32"
                                else "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16%s)" % (", 3 per product" if args.dtype == "bf16x3" else ""),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak,
@@ -195,18 +256,26 @@ def main():
                      "traffic_detail": pmc, "algorithmic_bytes_per_launch": alg,
                      "launches_per_step": len(prof) // max(1, args.steps),
                      "gemm_ms_per_step": gemm_ms / max(1, args.steps),
-                     "gemm_gflop_per_step": flops / max(1, args.steps) / 1e9},
+                     "gemm_gflop_per_step": flops / max(1, args.steps) / 1e9,
+                     # BASELINE.md 4 / SURVEY 8d: the whole AIT path end to end against the matrix peak --
+                     # pairs/s x 0.911 TFLOP (as-computed-by-reference FLOPs of one pair) per GPU
+                     "e2e_ait_frac": value / world * AIT_TFLOP_PER_PAIR / peak if args.dtype == "f32" else None,
+                     "measured_peak": peaks["mfma_f32_tflops"] if peaks else None,
+                     "frac_of_measured_peak": (achieved / peaks["mfma_f32_tflops"]) if peaks and peaks["mfma_f32_tflops"]
+                                              and args.dtype == "f32" else None},
+        "roofline_roi_align": {"fwd": roi_entry("fwd"), "bwd": roi_entry("bwd"),
+                               "measured_peak_gbs": peaks["hbm_copy_gbs"] if peaks else None},
     }
     if os.environ.get("AIT_BENCH_GEMM_TABLE"):
         import collections
         tab = collections.OrderedDict()
         for p in prof:
-            t = tab.setdefault(p[3], [0.0, 0])
-            t[0] += p[1].elapsed_time(p[2])
+            t = tab.setdefault(p[2], [0.0, 0])
+            t[0] += p[1]
             t[1] += 1
         for k, (ms, n) in sorted(tab.items(), key=lambda kv: -kv[1][0]):
             fl = 2.0 * k[0] * k[1] * k[2]
-            print("gemm M=%6d N=%5d K=%6d ta=%d tb=%d sk=%2d colblk=%3d : %2d/step %8.1f us  %6.1f TF/s  %5.2f ms/step"
+            print("gemm M=%6d N=%5d K=%6d ta=%d tb=%d splits=%2d : %2d/step %8.1f us  %6.1f TF/s  %5.2f ms/step"
                   % (k + (n // args.steps, 1e3 * ms / n, fl / (ms / n) / 1e9, ms / args.steps)), file=sys.stderr)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.proposals)

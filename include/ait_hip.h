@@ -35,6 +35,27 @@ int ait_abi_version(void);
 const char* ait_strerror(int code);
 
 /* ---------------------------------------------------------------------------------------
+ * Measurement (bench.py's live roofline; no reference counterpart).  While a probe is ATTACHED to the
+ * calling thread, the GEMM and RoIAlign entry points -- however they are reached, directly or from
+ * inside ait_transformer_* -- bracket their launches with a HIP event pair on the launch stream and
+ * note the launch's algorithmic work: kind AIT_PROBE_GEMM: flops = 2*M*N*K, dims = {M, N, K, trans_a,
+ * trans_b, splits}; AIT_PROBE_ROI_FWD / _BWD: algorithmic bytes (feature once + RoIs + pooled
+ * tensor once), dims = {n_rois, B, C, H, W, 0}.  The probe owns its events (created by
+ * ait_probe_create, at most `capacity` launches are recorded); ait_probe_get reports a launch's elapsed
+ * milliseconds once the stream has been synchronised.  Attach state is per thread; with no probe
+ * attached (the default) the entry points do nothing extra.
+ * ------------------------------------------------------------------------------------- */
+#define AIT_PROBE_GEMM 1
+#define AIT_PROBE_ROI_FWD 2
+#define AIT_PROBE_ROI_BWD 3
+void* ait_probe_create(int capacity);
+void ait_probe_destroy(void* probe);
+void ait_probe_attach(void* probe);          /* NULL detaches */
+int ait_probe_reset(void* probe);
+int ait_probe_count(void* probe);
+int ait_probe_get(void* probe, int i, int* kind, double* work, float* ms, int* dims6);
+
+/* ---------------------------------------------------------------------------------------
  * RoIAlign.  Replaces model._C.roi_align_forward / roi_align_backward
  *   (lib/model/csrc/vision.cpp:9-10, lib/model/csrc/ROIAlign.h:11-45; kernels
  *    lib/model/csrc/cuda/ROIAlign_cuda.cu:65-122,178-254; CPU semantics
@@ -173,10 +194,20 @@ int ait_gemm_bf16x3(int trans_a, int trans_b, int M, int N, int K, float alpha, 
  *   Dropout: stateless hash of (seed, r*d + c); p_drop = 0 disables it.
  * ait_ln_bwd:   recomputes z from (a, pos, residual, seed); writes
  *   da   = dropout-mask * dz.  rep == 1: indexed by SOURCE row (padding rows dropped);
- *          rep  > 1: indexed by output row (the caller sums over the rep copies).  May be NULL.
+ *          rep  > 1: indexed by output row (the caller sums over the rep copies, ait_rep_sum_f32).
+ *          May be NULL.
  *   dres = dz [rows, d], may be NULL.
  *   dgamma, dbeta [d]: ACCUMULATED with atomics (caller zeroes or carries a running sum); both
  *          NULL or both non-NULL.
+ *   dcolsum [d]: ACCUMULATES the column sums of da over the rows that have a source = the gradient
+ *          of the bias of the linear layer that produced `a` (replaces autograd's dy.sum(0)); may
+ *          be NULL.
+ *   dy_rows_per_seq: dy holds only the first dy_rows_per_seq rows of every sequence (row
+ *          (q, t) at dy[q*dy_rows_per_seq + t]); the other rows received no gradient (the
+ *          encoder output, of which only the n_src real rows are read again).  == seq_len: all.
+ * ait_colsum_f32:  out[c] += sum_r x[r*ld + c]  (bias gradients; cols % 4 == 0).
+ * ait_rep_sum_f32: out[g*E + e] += sum_{j < rep} x[(g*rep + j)*E + e]  (gradient of a block of E
+ *          floats repeated rep times: the query sequence over the proposals, Models.py:250).
  * ------------------------------------------------------------------------------------- */
 int ait_ln_fwd(const float* a, const float* pos, const float* residual, const float* gamma,
                const float* beta, long long rows, int d, int seq_len, int src_rows_per_seq,
@@ -184,8 +215,11 @@ int ait_ln_fwd(const float* a, const float* pos, const float* residual, const fl
                float* rstd, void* stream);
 int ait_ln_bwd(const float* dy, const float* a, const float* pos, const float* residual,
                const float* gamma, const float* mean, const float* rstd, long long rows, int d,
-               int seq_len, int src_rows_per_seq, int rep, float p_drop, unsigned long long seed,
-               float* da, float* dres, float* dgamma, float* dbeta, void* stream);
+               int seq_len, int src_rows_per_seq, int rep, int dy_rows_per_seq, float p_drop,
+               unsigned long long seed, float* da, float* dres, float* dgamma, float* dbeta,
+               float* dcolsum, void* stream);
+int ait_colsum_f32(const float* x, long long rows, int cols, long long ld, float* out, void* stream);
+int ait_rep_sum_f32(const float* x, int groups, int rep, long long E, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Selective heads + head sum (H = 8, T = 64, dv = 64 only).
@@ -236,8 +270,8 @@ int ait_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* 
  *   out     [bp * 64, 1024]     token-major (= channels-last [bp, 8, 8, 1024])
  * Weights: plain pointers into the state_dict tensors; w_qkv is the row concatenation
  * [w_qs.weight; w_ks.weight; w_vs.weight] ([1536, 512]).  Workspace: caller-owned scratch of
- * ait_transformer_workspace_bytes(bp, bs, n_src) bytes.  Training (dropout, saved activations)
- * goes through the autograd wrappers of ait_amd/system.py.
+ * ait_transformer_workspace_bytes(bp, bs, n_src) bytes.  Training (dropout, saved activations,
+ * backward): the *_fwd_train / *_bwd entry points below.
  * ------------------------------------------------------------------------------------- */
 typedef struct {
   const float *w_qkv;            /* [1536, 512]  Q | K | V row blocks, no bias */
@@ -277,6 +311,78 @@ size_t ait_transformer_workspace_bytes(int bp, int bs, int n_src);
 int ait_transformer_fwd(const float* x_props, const float* x_query, int bp, int bs, int n_src,
                         const ait_transformer_weights* w, void* workspace, size_t workspace_bytes,
                         float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Training: the same blocks with dropout, a forward that SAVES what the backward needs, and the
+ * backward.  Replaces the autograd graph PyTorch builds over MultiHeadAttention.forward
+ * (lib/model/system/SubLayers.py:68-102), PositionwiseFeedForward.forward (:177-187) and
+ * Transformer.forward (lib/model/system/Models.py:231-280) when trainval_net_voc.py:420 calls
+ * loss.backward().
+ *
+ *   saved      caller-owned buffer of ait_*_saved_bytes(...) bytes: written by *_fwd_train, read by
+ *              *_bwd (layout private to the library); the block INPUTS (xq / xkv / x, x_props /
+ *              x_query) are not copied -- the caller keeps them alive and passes them again.
+ *   workspace  scratch of the backward (ait_*_bwd_workspace_bytes).
+ *   p_drop     dropout rate behind fc / w_2 / the positional prologue (the module's `dropout`);
+ *   p_attn_drop  rate on the attention probabilities (fixed at 0.1 by the reference's
+ *              ScaledDotProductAttention constructor, Modules.py:14).  0 <= p < 1; 0 disables.
+ *   seed       one 64-bit seed per call; every dropout site inside derives its own with
+ *              ait_dropout_seed (masks are a stateless hash of (site seed, element index), recomputed
+ *              -- never stored -- by the backward, which must be given the same seed).
+ *   gradients  INPUT gradients (dxq, dxkv, dx, d_x_props, d_x_query) are WRITTEN (d_x_props /
+ *              d_x_query / dxkv may be NULL: not computed).  PARAMETER gradients are ACCUMULATED into
+ *              the buffers of the ait_*_grads struct (the weight-gradient products are split-K sums
+ *              combined with fp32 atomics); the caller zero-fills them for a plain gradient, or keeps
+ *              a running sum across micro-batches.  A NULL member skips that gradient.
+ *              w_qkv's gradient has the layout of w_qkv: rows [0,512) d w_qs, [512,1024) d w_ks,
+ *              [1024,1536) d w_vs.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  float *w_qkv, *sk_w, *sk_b, *fc_w, *ln_g, *ln_b;
+} ait_mha_grads;
+typedef struct {
+  float *w1, *b1, *w2, *b2, *ln_g, *ln_b;
+} ait_ffn_grads;
+typedef struct {
+  float *enc_emb_w, *enc_emb_b, *dec_emb_w, *dec_emb_b, *dec_trans_w, *dec_trans_b;
+  float *enc_ln_g, *enc_ln_b, *dec_ln_g, *dec_ln_b;
+  ait_mha_grads enc_slf, dec_slf, dec_enc;
+  ait_ffn_grads enc_ffn, dec_ffn;
+} ait_transformer_grads;
+
+/* seed of dropout site `site` under base seed `base` (pure function, splitmix64 finaliser) */
+unsigned long long ait_dropout_seed(unsigned long long base, int site);
+
+size_t ait_mha_block_saved_bytes(int n_seq, int kv_rows);
+int ait_mha_block_fwd_train(const float* xq, const float* xkv, int n_seq, int kv_rows, int mask_mode,
+                            int n_valid_keys, const ait_mha_weights* w, float p_drop, float p_attn_drop,
+                            unsigned long long seed, void* saved, size_t saved_bytes, float* y, void* stream);
+size_t ait_mha_block_bwd_workspace_bytes(int n_seq, int kv_rows);
+int ait_mha_block_bwd(const float* dy, const float* xq, const float* xkv, int n_seq, int kv_rows,
+                      int mask_mode, int n_valid_keys, const ait_mha_weights* w, float p_drop,
+                      float p_attn_drop, unsigned long long seed, const void* saved, size_t saved_bytes,
+                      void* workspace, size_t workspace_bytes, float* dxq, float* dxkv,
+                      const ait_mha_grads* grads, void* stream);
+
+size_t ait_ffn_saved_bytes(long long rows);
+int ait_ffn_fwd_train(const float* x, long long rows, const ait_ffn_weights* w, float p_drop,
+                      unsigned long long seed, void* saved, size_t saved_bytes, float* y, void* stream);
+size_t ait_ffn_bwd_workspace_bytes(long long rows);
+int ait_ffn_bwd(const float* dy, const float* x, long long rows, const ait_ffn_weights* w, float p_drop,
+                unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
+                size_t workspace_bytes, float* dx, const ait_ffn_grads* grads, void* stream);
+
+size_t ait_transformer_saved_bytes(int bp, int bs, int n_src);
+int ait_transformer_fwd_train(const float* x_props, const float* x_query, int bp, int bs, int n_src,
+                              const ait_transformer_weights* w, float p_drop, float p_attn_drop,
+                              unsigned long long seed, void* saved, size_t saved_bytes, float* out,
+                              void* stream);
+size_t ait_transformer_bwd_workspace_bytes(int bp, int bs, int n_src);
+int ait_transformer_bwd(const float* d_out, const float* x_props, const float* x_query, int bp, int bs,
+                        int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
+                        unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
+                        size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                        const ait_transformer_grads* grads, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Frozen batch-norm + residual + ReLU, one pass (NCHW fp32, x [n,C,HW]).

@@ -571,6 +571,53 @@ def time_train_step(P=300, cores=1, seconds_budget=25.0, seed=5):
                       "oracle/native.c run single-threaded; median of all but the first" % (it, P, cores)}
 
 
+def time_eval_forward(P=300, cores=1, seconds_budget=8.0, seed=5):
+    """cpu_baseline figure (i) of SURVEY 8d: full eval forward of ONE pair (600x1000 target, P proposals)."""
+    cfgd = default_config()
+    cfgd["TEST"]["RPN_POST_NMS_TOP_N"] = P
+    sd = make_detector_state_dict(seed, reference_shapes())
+    times, t_start, it = [], time.perf_counter(), 0
+    while True:
+        ins = synth_inputs(1, 200 + it)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            detector_forward(sd, cfgd, *ins, False)
+        times.append(time.perf_counter() - t0)
+        it += 1
+        if time.perf_counter() - t_start > seconds_budget or it >= 5:
+            break
+    best = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    return {"value": 1.0 / best, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d single-pair eval forwards (600x1000 target, P=%d), median of all but the first" % (it, P)}
+
+
+def time_ait_only(P=300, cores=1, seconds_budget=8.0, seed=5):
+    """cpu_baseline figure (iii) of SURVEY 8d: the AIT alone, forward + backward, for ONE pair's P proposals
+    (oracle/ait_ref.transformer_forward on [P,1024,7,7] / [1,1024,8,8])."""
+    from . import ait_ref as A
+    sd = A.make_ait_state_dict(seed=seed)
+    for v in sd.values():
+        if v.dtype.is_floating_point and v.dim() > 0:
+            v.requires_grad_(True)
+    rs = np.random.RandomState(7)
+    xp = torch.from_numpy(rs.standard_normal((P, 1024, 7, 7)).astype(np.float32)).requires_grad_(True)
+    xq = torch.from_numpy(rs.standard_normal((1, 1024, 8, 8)).astype(np.float32)).requires_grad_(True)
+    times, t_start, it = [], time.perf_counter(), 0
+    while True:
+        t0 = time.perf_counter()
+        y = A.transformer_forward(sd, xp, xq)
+        y.backward(torch.ones_like(y))
+        times.append(time.perf_counter() - t0)
+        for v in list(sd.values()) + [xp, xq]:
+            v.grad = None
+        it += 1
+        if time.perf_counter() - t_start > seconds_budget or it >= 5:
+            break
+    best = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    return {"value": 1.0 / best, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d AIT-only fwd+bwd iterations for one pair's %d proposals, median of all but the first" % (it, P)}
+
+
 def postprocess_detections(cfgd, rois, cls_prob, bbox_pred, im_info, im_scale, nms_thr=0.3, thresh=0.0,
                            max_per_image=100):
     """test_net_coco.py:381-449 restated on the CPU (class-agnostic, one image)."""

@@ -24,11 +24,22 @@ using namespace ait_gemm;
 
 using NewD = Cfg<256, 128, 16, 4, 2, 4, MODE_DLDS>;
 using NewD4 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS>;
+// sweep variants (all produce the same results)
+using V_burst = Cfg<256, 128, 16, 4, 2, 4, MODE_DLDS, 3, KNOB_BURST>;
+using V_prio = Cfg<256, 128, 16, 4, 2, 4, MODE_DLDS, 3, KNOB_PRIO>;
+using V_ring4 = Cfg<256, 128, 16, 4, 2, 2, MODE_DLDS, 4, 0>;             // 96 KB: one workgroup per CU
+using V_ring4b = Cfg<256, 128, 16, 4, 2, 2, MODE_DLDS, 4, KNOB_BURST>;
+using V_d4 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, 0>;                // 4 waves of 128x64
+using V_d4b = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_BURST>;
+using V_128 = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 3, 0>;               // 48 KB: three workgroups per CU
+using V_128r4 = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, 0>;             // 64 KB: two
+using V_256sq = Cfg<256, 256, 16, 4, 4, 4, MODE_DLDS, 3, 0>;             // 16 waves, 96 KB: one workgroup per CU
 #ifndef NO_OLD
 using OldD = ait_gemm_old::Cfg<256, 128, 16, 4, 2, 2, 6 + 256>;
 using OldD4 = ait_gemm_old::Cfg<256, 128, 16, 2, 2, 2, 6 + 256>;
 #endif
 
+#define LAB_RES (1 << 20)      // lab-only flag: pass a residual operand
 struct Shape {
   const char* name;
   int M, N, K, ta, tb, sk, flags;   // flags: AIT_GEMM_RELU (with a bias) | AIT_GEMM_ATOMIC is implied by sk > 1
@@ -46,6 +57,10 @@ static const Shape SHAPES[] = {
     {"qkvK4 NT", 76800, 1536, 4096, 0, 1, 1, 0},     // same tiles, 8x the slabs per tile
     {"l4c1  NT", 19200, 512, 2048, 0, 1, 1, AIT_GEMM_RELU},
     {"l4c3  NT", 19200, 2048, 512, 0, 1, 1, AIT_GEMM_RELU},
+    {"dx+r  NN", 76800, 512, 2048, 0, 0, 1, LAB_RES},                      // dgrad + residual-gradient add
+    {"dhmsk NN", 76800, 2048, 512, 0, 0, 1, LAB_RES | AIT_GEMM_MASK_POS},  // dgrad gated by the saved ReLU
+    {"fc    NT", 76800, 512, 64, 0, 1, 1, 0},                              // K = 64: four slabs per tile
+    {"trans NT", 76800, 1024, 512, 0, 1, 1, AIT_GEMM_RELU},                // dec_trans shape (+ bias)
 };
 static const int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 
@@ -63,7 +78,7 @@ __global__ void fill_kernel(float* p, size_t n, unsigned seed) {
 
 struct Problem {
   Shape s;
-  float *A, *B, *C, *C2, *bias;
+  float *A, *B, *C, *C2, *bias, *res;
   unsigned long long* probe;
   GemmArgs g;
 };
@@ -73,6 +88,8 @@ static void setup(Problem& p, const Shape& s) {
   const size_t na = (size_t)s.M * s.K, nb = (size_t)s.N * s.K, nc = (size_t)s.M * s.N;
   CK(hipMalloc(&p.A, na * 4)); CK(hipMalloc(&p.B, nb * 4)); CK(hipMalloc(&p.C, nc * 4)); CK(hipMalloc(&p.C2, nc * 4));
   CK(hipMalloc(&p.bias, (size_t)s.N * 4));
+  CK(hipMalloc(&p.res, nc * 4));
+  fill_kernel<<<2048, 256>>>(p.res, nc, 0x777u);
   CK(hipMalloc(&p.probe, 4096 * AIT_PROBE_WORDS * 8));
   fill_kernel<<<2048, 256>>>(p.A, na, 0x1234567u);
   fill_kernel<<<2048, 256>>>(p.B, nb, 0x89abcdeu);
@@ -80,25 +97,38 @@ static void setup(Problem& p, const Shape& s) {
   CK(hipMemset(p.C, 0, nc * 4)); CK(hipMemset(p.C2, 0, nc * 4));
   CK(hipDeviceSynchronize());
   const int lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
-  const int flags = s.flags | (s.sk > 1 ? AIT_GEMM_ATOMIC : 0);
+  const int flags = (s.flags & ~LAB_RES) | (s.sk > 1 ? AIT_GEMM_ATOMIC : 0);
   int rc = make_args(s.ta, s.tb, s.M, s.N, s.K, 1.f, p.A, lda, p.B, ldb, p.C, s.N,
-                     (s.flags & AIT_GEMM_RELU) ? p.bias : nullptr, nullptr, flags, s.sk, 0, 0, 16, p.g);
+                     (s.flags & AIT_GEMM_RELU) ? p.bias : nullptr, (s.flags & LAB_RES) ? p.res : nullptr, flags, s.sk, 0,
+                     0, 16, p.g);
   if (rc) { printf("make_args rc %d\n", rc); exit(1); }
 }
 static void teardown(Problem& p) {
-  hipFree(p.A); hipFree(p.B); hipFree(p.C); hipFree(p.C2); hipFree(p.bias); hipFree(p.probe);
+  hipFree(p.A); hipFree(p.B); hipFree(p.C); hipFree(p.C2); hipFree(p.bias); hipFree(p.res); hipFree(p.probe);
 }
 
 // variant 0: round-1 kernel; 1: current kernel; 2: current kernel with the stamp probe
+template <class T, bool AK, bool BKC, class Probe>
+static int run_epi(const GemmArgs& g, int slots) {
+  if (g.flags & AIT_GEMM_ATOMIC) return launch<T, AK, BKC, EPI_ATOMIC, Probe>(g, 0, slots);
+  if (g.residual) return launch<T, AK, BKC, EPI_RES, Probe>(g, 0, slots);
+  return launch<T, AK, BKC, EPI_STORE, Probe>(g, 0, slots);
+}
+template <class T>
+static int run_tile(const GemmArgs& g, bool ak, bool bk, int slots) {
+  if (!ak && !bk) return run_epi<T, false, false, NoProbe>(g, slots);
+  if (ak && bk) return run_epi<T, true, true, NoProbe>(g, slots);
+  if (ak && !bk) return run_epi<T, true, false, NoProbe>(g, slots);
+  return run_epi<T, false, true, NoProbe>(g, slots);
+}
+static const char* VNAMES[] = {"old", "new", "probe", "burst", "prio", "ring4", "ring4+burst", "4waves", "4waves+burst",
+                               "128sq", "128sq ring4", "256sq 16w"};
 template <class Probe>
 static int run_new(const GemmArgs& g, bool ak, bool bk, int slots) {
-  const bool atomic = (g.flags & AIT_GEMM_ATOMIC) != 0;
-  if (!ak && !bk) {
-    return atomic ? launch<NewD4, false, false, EPI_ATOMIC, Probe>(g, 0, slots) : launch<NewD4, false, false, EPI_STORE, Probe>(g, 0, slots);
-  }
-  if (ak && bk) return atomic ? launch<NewD, true, true, EPI_ATOMIC, Probe>(g, 0, slots) : launch<NewD, true, true, EPI_STORE, Probe>(g, 0, slots);
-  if (ak && !bk) return atomic ? launch<NewD, true, false, EPI_ATOMIC, Probe>(g, 0, slots) : launch<NewD, true, false, EPI_STORE, Probe>(g, 0, slots);
-  return atomic ? launch<NewD, false, true, EPI_ATOMIC, Probe>(g, 0, slots) : launch<NewD, false, true, EPI_STORE, Probe>(g, 0, slots);
+  if (!ak && !bk) return run_epi<NewD4, false, false, Probe>(g, slots);
+  if (ak && bk) return run_epi<NewD, true, true, Probe>(g, slots);
+  if (ak && !bk) return run_epi<NewD, true, false, Probe>(g, slots);
+  return run_epi<NewD, false, true, Probe>(g, slots);
 }
 #ifndef NO_OLD
 static int run_old(const GemmArgs& gn, bool ak, bool bk) {
@@ -118,6 +148,18 @@ static int run(Problem& p, int variant, float* out) {
   const bool ak = !p.s.ta, bk = p.s.tb != 0;
   if (variant == 1) return run_new<NoProbe>(g, ak, bk, g_slots);
   if (variant == 2) { g.probe = p.probe; return run_new<StampProbe>(g, ak, bk, g_slots); }
+  switch (variant) {
+    case 3: return run_tile<V_burst>(g, ak, bk, g_slots);
+    case 4: return run_tile<V_prio>(g, ak, bk, g_slots);
+    case 5: return run_tile<V_ring4>(g, ak, bk, g_slots);
+    case 6: return run_tile<V_ring4b>(g, ak, bk, g_slots);
+    case 7: return run_tile<V_d4>(g, ak, bk, g_slots);
+    case 8: return run_tile<V_d4b>(g, ak, bk, g_slots);
+    case 9: return run_tile<V_128>(g, ak, bk, g_slots);
+    case 10: return run_tile<V_128r4>(g, ak, bk, g_slots);
+    case 11: return run_tile<V_256sq>(g, ak, bk, g_slots);
+    default: break;
+  }
 #ifndef NO_OLD
   return run_old(g, ak, bk);
 #else
@@ -181,6 +223,41 @@ static void mode_ab(int rounds, int first, int last) {
   }
 }
 
+// every variant on every shape, interleaved rounds in one process; median TF/s
+static void mode_sweep(int rounds, int first, int last) {
+  const int vs[] = {0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+  const int nv = sizeof(vs) / sizeof(vs[0]);
+  printf("%-9s %6s %5s %6s |", "shape", "M", "N", "K");
+  for (int i = 0; i < nv; i++) printf(" %12s", VNAMES[vs[i]]);
+  printf("\n");
+  for (int si = first; si < last; si++) {
+    Problem p;
+    setup(p, SHAPES[si]);
+    const size_t nc = (size_t)p.s.M * p.s.N;
+    std::vector<std::vector<double>> t(nv);
+    std::vector<int> ok(nv, 1);
+    CK(hipMemset(p.C, 0, nc * 4));
+    run(p, 1, p.C);
+    for (int i = 0; i < nv; i++) {       // correctness of every variant against the current kernel
+      CK(hipMemset(p.C2, 0, nc * 4));
+      const int rc = run(p, vs[i], p.C2);
+      CK(hipDeviceSynchronize());
+      if (rc != 0 || max_diff(p, 1) > (p.s.sk > 1 ? 1e-5 : 0.0)) ok[i] = 0;
+      if (rc == 0) time_launches(p, vs[i], p.C2, 3);
+    }
+    for (int r = 0; r < rounds; r++)
+      for (int i = 0; i < nv; i++) t[i].push_back(tflops(p.s, time_launches(p, vs[i], p.C2, 8)));
+    printf("%-9s %6d %5d %6d |", p.s.name, p.s.M, p.s.N, p.s.K);
+    for (int i = 0; i < nv; i++) {
+      std::sort(t[i].begin(), t[i].end());
+      printf(" %10.1f%s", t[i][rounds / 2], ok[i] ? "  " : " X");
+    }
+    printf("\n");
+    fflush(stdout);
+    teardown(p);
+  }
+}
+
 static void mode_probe(int first, int last) {
   for (int si = first; si < last; si++) {
     Problem p;
@@ -235,9 +312,104 @@ static void mode_probe(int first, int last) {
     printf("  wave 0: %.0f cycles per slab (matrix-pipe floor %d x 64 x %d waves/SIMD = %d); vmcnt wait %.2f %%, barrier %.2f %% of the slab loop; %.1f tiles and %.0f slabs per workgroup\n",
            loop / slabs, mfma_per_slab, waves_per_simd, mfma_per_slab * 64 * waves_per_simd, 100.0 * wait / loop, 100.0 * bar / loop, tiles / ids.size(), slabs / ids.size());
     printf("  slab loop = %.1f %% of workgroup lifetime (cycles); shader clock %.2f GHz\n", 100.0 * loop / clk_c, clk_c / clk_t * 1e-9);
+    {  // the two workgroups of a CU: the one that ends first ("first") and its partner ("second")
+      std::map<unsigned long long, std::vector<int>> by_cu;
+      for (int b : ids) {
+        const unsigned long long* q = &h[(size_t)b * AIT_PROBE_WORDS];
+        const unsigned hw = (unsigned)q[7], xcc = (unsigned)(q[7] >> 32) & 0xf;
+        by_cu[((unsigned long long)xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)].push_back(b);
+      }
+      double fa = 0, fb = 0, ea = 0, eb = 0, cu_end = 0; int n2 = 0; double min_cu_end = 1e30, max_cu_end = 0;
+      for (auto& kv : by_cu) {
+        double last = 0;
+        for (int b : kv.second) last = std::max(last, (double)(h[(size_t)b * AIT_PROBE_WORDS + 1] - t0) * 0.01);
+        min_cu_end = std::min(min_cu_end, last); max_cu_end = std::max(max_cu_end, last); cu_end += last;
+        if (kv.second.size() != 2) continue;
+        const unsigned long long* q0 = &h[(size_t)kv.second[0] * AIT_PROBE_WORDS];
+        const unsigned long long* q1 = &h[(size_t)kv.second[1] * AIT_PROBE_WORDS];
+        const unsigned long long* A = q0[1] <= q1[1] ? q0 : q1;
+        const unsigned long long* B = q0[1] <= q1[1] ? q1 : q0;
+        fa += (double)A[2] / A[5]; fb += (double)B[2] / B[5];
+        ea += (A[1] - t0) * 0.01; eb += (B[1] - t0) * 0.01; n2++;
+      }
+      if (n2) printf("  per CU (2 workgroups): first ends at %.1f us with %.0f cycles/slab, second at %.1f us with %.0f cycles/slab\n",
+                     ea / n2, fa / n2, eb / n2, fb / n2);
+      printf("  CU end times: min %.1f mean %.1f max %.1f us (span %.1f)\n", min_cu_end, cu_end / by_cu.size(), max_cu_end, span);
+    }
     fflush(stdout);
     teardown(p);
   }
+}
+
+
+// ---- micro: what one SIMD loses to the instructions around its MFMAs --------------------------------------
+// Every wave runs `iters` blocks of 32 independent v_mfma_f32_32x32x2_f32 (4 accumulators) with, spread
+// between them, G global_load_lds_dwordx4 (from an L2-resident buffer into its own LDS region), R
+// ds_read_b128 (results consumed by the MFMAs of the next block) and optionally one barrier per block.
+template <int G, int R, bool BAR>
+__global__ __launch_bounds__(512, 2) void micro_kernel(const float* __restrict__ src, float* __restrict__ out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  f32x16 acc[4];
+  for (int i = 0; i < 4; i++) for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  float4 x[8];
+  for (int i = 0; i < 8; i++) x[i] = make_float4(lane * 1e-3f + i, 1.f, 2.f, 3.f);
+  float* mine = lds + wave * 2048;                      // 8 KB per wave
+  const float* gp = src + ((size_t)blockIdx.x * 8 + wave) * 4096 + lane * 4;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        const float fa = x[j][a & 3], fb = x[(j + 1) & 7][(a + 1) & 3];
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[a], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (j < G) glds16(gp + (j & 3) * 256, mine + (j & 1) * 256);
+      if (j < R) x[j] = *reinterpret_cast<const float4*>(mine + 512 + ((lane * 4 + j * 256) & 1023));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (G > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (BAR) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+  }
+  float sacc = 0.f;
+  for (int a = 0; a < 4; a++) for (int r = 0; r < 16; r++) sacc += acc[a][r];
+  out[(size_t)blockIdx.x * 512 + threadIdx.x] = sacc;
+}
+template <int G, int R, bool BAR>
+static void micro_case(const float* src, float* out, int wgs_per_cu) {
+  const int iters = 4000, blocks = 256 * wgs_per_cu;
+  auto k = micro_kernel<G, R, BAR>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 72 * 1024, 0, src, out, 200);
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 72 * 1024, 0, src, out, iters);
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double fl = (double)blocks * 8 * iters * 32.0 * 4096.0;
+  printf("  %d wg/CU  glds/32mfma %d  ds_read_b128/32mfma %d  barrier %d : %6.1f TF/s\n", wgs_per_cu, G, R, (int)BAR, fl / ms / 1e9);
+  fflush(stdout);
+}
+static void mode_micro() {
+  float *src, *out;
+  CK(hipMalloc(&src, (size_t)512 * 8 * 4096 * 4 + 65536)); CK(hipMalloc(&out, (size_t)512 * 512 * 4));
+  fill_kernel<<<1024, 256>>>(src, (size_t)512 * 8 * 4096, 0x42u);
+  CK(hipDeviceSynchronize());
+  for (int w = 1; w <= 2; w++) {
+    micro_case<0, 0, false>(src, out, w);
+    micro_case<0, 8, false>(src, out, w);
+    micro_case<0, 8, true>(src, out, w);
+    micro_case<1, 8, true>(src, out, w);
+    micro_case<3, 8, true>(src, out, w);
+    micro_case<3, 8, false>(src, out, w);
+    micro_case<3, 0, false>(src, out, w);
+    micro_case<6, 8, true>(src, out, w);
+    micro_case<6, 0, false>(src, out, w);
+  }
+  hipFree(src); hipFree(out);
 }
 
 static void mode_pmc(int si, int variant, int n) {
@@ -255,6 +427,8 @@ int main(int argc, char** argv) {
   if (getenv("LAB_SHAPES")) { sscanf(getenv("LAB_SHAPES"), "%d:%d", &first, &last); }
   if (!strcmp(mode, "ab")) mode_ab(argc > 2 ? atoi(argv[2]) : 5, first, last);
   else if (!strcmp(mode, "probe")) mode_probe(first, last);
+  else if (!strcmp(mode, "micro")) mode_micro();
+  else if (!strcmp(mode, "sweep")) mode_sweep(argc > 2 ? atoi(argv[2]) : 5, first, last);
   else if (!strcmp(mode, "pmc")) mode_pmc(atoi(argv[2]), atoi(argv[3]), argc > 4 ? atoi(argv[4]) : 10);
   else { printf("unknown mode\n"); return 1; }
   return 0;

@@ -357,15 +357,20 @@ def test_transformer_full_size_is_batch_invariant_and_linear_in_the_cotangent():
         assert float((v + 2.0 * u).norm()) <= 1e-5 * float(u.norm())
 
 
-def test_transformer_c_entry_point_equals_the_autograd_composition():
+def test_transformer_c_entry_point_equals_the_autograd_composition(monkeypatch):
     """ait_transformer_fwd (the whole AIT forward behind ONE C-ABI call, used by eval-mode inference
-    under torch.no_grad) against the same module run through the Python autograd composition:
-    same kernels in the same order -> the same bits; and both against the fp32 oracle."""
+    under torch.no_grad) against the same module run through the training entry point and through the
+    fine-grained Python autograd composition: same kernels in the same order -> the same bits; and all
+    against the fp32 oracle."""
     t = _transformer(3).eval()
     xp0, xq0 = seeded(301, (6, 1024, 7, 7)), seeded(302, (2, 1024, 8, 8))
     xp, xq = _dev(xp0), _dev(xq0)
     with torch.enable_grad():
         y_py = t(x_props=xp.clone().requires_grad_(True), x_query=xq).detach()
+        monkeypatch.setenv("AIT_PY_COMPOSE", "1")
+        y_fine = t(x_props=xp.clone().requires_grad_(True), x_query=xq).detach()
+        monkeypatch.setenv("AIT_PY_COMPOSE", "0")
+    assert torch.equal(y_fine, y_py)
     with torch.no_grad():
         y_c = t(x_props=xp, x_query=xq)
         t.channels_last_out = True
@@ -425,4 +430,154 @@ def test_c_sublayer_blocks_match_the_modules():
                          _lib.dev_ptr(y), None) == -2
     assert L.ait_mha_block_fwd(_lib.dev_ptr(x), None, n, 49, 0, 0, ctypes.byref(W.enc_slf),
                                ctypes.c_void_p(ws.data_ptr()), nbytes, _lib.dev_ptr(y), None) == -1
+    del keep
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_transformer_training_c_path_equals_the_fine_grained_composition(monkeypatch, train):
+    """Transformer.forward with gradients = ONE autograd node over ait_transformer_fwd_train /
+    ait_transformer_bwd.  Against the fine-grained composition (autograd over the building blocks,
+    AIT_PY_COMPOSE=1), with dropout ON in train mode (both derive the ten site seeds with
+    ait_dropout_seed from the same base seed): the forward is the same kernels in the same order -> the
+    same bits; input gradients likewise; parameter gradients agree to summation order (split-K atomics,
+    column sums)."""
+    t = _transformer(3)
+    t.train(train)
+    xp0, xq0, cot0 = seeded(301, (6, 1024, 7, 7)), seeded(302, (2, 1024, 8, 8)), seeded(303, (6, 1024, 8, 8))
+
+    def run(fine):
+        monkeypatch.setenv("AIT_PY_COMPOSE", "1" if fine else "0")
+        t.zero_grad(set_to_none=True)
+        xp, xq = _dev(xp0).requires_grad_(True), _dev(xq0).requires_grad_(True)
+        torch.manual_seed(11)
+        y = t(x_props=xp, x_query=xq)
+        y.backward(_dev(cot0))
+        return y.detach(), xp.grad, xq.grad, {k: p.grad.clone() for k, p in t.named_parameters()}
+
+    yc, gpc, gqc, gc = run(False)
+    yf, gpf, gqf, gf = run(True)
+    assert torch.equal(yc, yf)
+    if train:                                   # dropout really was on, and really was seeded
+        torch.manual_seed(12)
+        monkeypatch.setenv("AIT_PY_COMPOSE", "0")
+        assert not torch.equal(t(x_props=_dev(xp0), x_query=_dev(xq0)), yc)
+    assert _rel(gpc, gpf) < 1e-6 and _rel(gqc, gqf) < 1e-5
+    assert len(gc) == 46
+    for k in gf:
+        assert _rel(gc[k], gf[k]) < 2e-5, (k, _rel(gc[k], gf[k]))
+
+
+def test_c_training_blocks_match_the_modules():
+    """ait_mha_block_fwd_train / ait_mha_block_bwd and ait_ffn_fwd_train / ait_ffn_bwd against
+    the Python modules (autograd over the building blocks) with dropout on and the same site seeds: self
+    attention under both masks, cross-attention over an unpadded 49-token memory, the feed-forward block."""
+    import ctypes
+    from ait_amd import _lib, ops, system
+    from ait_amd.system import CausalMask, KeyPadMask
+    t = _transformer(3).train()
+    L = _lib.lib()
+    n, seed = 5, 0x1234ABCD5678
+    W, keep = t._c_weights()
+    enc, dec = t.encoder.layer_stack[0], t.decoder.layer_stack[0]
+
+    def grads_struct(mod, cls, names):
+        G, bufs = cls(), {}
+        for field, pname in names:
+            shape = dict(mod.named_parameters())[pname].shape if pname else (1536, 512)
+            bufs[field] = torch.zeros(tuple(shape), device="cuda")
+            setattr(G, field, bufs[field].data_ptr())
+        return G, bufs
+
+    def mha_case(mod, wstruct, xq0, xkv0, kv_rows, mode, n_valid, mask):
+        xq = _dev(xq0).requires_grad_(True)
+        xkv = None if xkv0 is None else _dev(xkv0).requires_grad_(True)
+        cot = _dev(seeded(55, (n, 64, 512)))
+        # module (fine-grained) with the block's two site seeds
+        system._SEED_QUEUE = [ops.dropout_seed(seed, 0), ops.dropout_seed(seed, 1)]
+        try:
+            mod.zero_grad(set_to_none=True)
+            y_ref = mod(xq, xq if xkv is None else xkv, xq if xkv is None else xkv, mask=mask)[0]
+        finally:
+            system._SEED_QUEUE = None
+        y_ref.backward(cot)
+        # C block
+        sb = int(L.ait_mha_block_saved_bytes(n, kv_rows))
+        saved = torch.empty(sb, dtype=torch.uint8, device="cuda")
+        y = torch.empty(n * 64, 512, device="cuda")
+        xkv_p = None if xkv is None else _lib.dev_ptr(xkv.detach().reshape(-1, 512))
+        rc = L.ait_mha_block_fwd_train(_lib.dev_ptr(xq.detach().reshape(-1, 512)), xkv_p, n, kv_rows, mode, n_valid,
+                                       ctypes.byref(wstruct), 0.1, 0.1, seed, ctypes.c_void_p(saved.data_ptr()), sb,
+                                       _lib.dev_ptr(y), None)
+        _lib.check(rc, "ait_mha_block_fwd_train")
+        torch.cuda.synchronize()
+        assert torch.equal(y.view(n, 64, 512), y_ref.detach())
+        G, bufs = grads_struct(mod, _lib.MhaGrads, [("w_qkv", None), ("sk_w", "sh.sk.weight"), ("sk_b", "sh.sk.bias"),
+                                                     ("fc_w", "fc.weight"), ("ln_g", "layer_norm.weight"),
+                                                     ("ln_b", "layer_norm.bias")])
+        wb = int(L.ait_mha_block_bwd_workspace_bytes(n, kv_rows))
+        ws = torch.empty(wb, dtype=torch.uint8, device="cuda")
+        dxq = torch.empty(n * 64, 512, device="cuda")
+        dxkv = None if xkv is None else torch.empty(n * kv_rows, 512, device="cuda")
+        rc = L.ait_mha_block_bwd(_lib.dev_ptr(cot.reshape(-1, 512)), _lib.dev_ptr(xq.detach().reshape(-1, 512)), xkv_p, n,
+                                 kv_rows, mode, n_valid, ctypes.byref(wstruct), 0.1, 0.1, seed,
+                                 ctypes.c_void_p(saved.data_ptr()), sb, ctypes.c_void_p(ws.data_ptr()), wb,
+                                 _lib.dev_ptr(dxq), None if dxkv is None else _lib.dev_ptr(dxkv), ctypes.byref(G), None)
+        _lib.check(rc, "ait_mha_block_bwd")
+        torch.cuda.synchronize()
+        assert _rel(dxq.view(n, 64, 512), xq.grad) < 1e-6
+        if dxkv is not None:
+            assert _rel(dxkv.view(n, kv_rows, 512), xkv.grad) < 1e-6
+        wq = torch.cat([mod.w_qs.weight.grad, mod.w_ks.weight.grad, mod.w_vs.weight.grad], 0)
+        assert _rel(bufs["w_qkv"], wq) < 2e-5
+        for field, pname in (("sk_w", "sh.sk.weight"), ("sk_b", "sh.sk.bias"), ("fc_w", "fc.weight"),
+                             ("ln_g", "layer_norm.weight"), ("ln_b", "layer_norm.bias")):
+            assert _rel(bufs[field], dict(mod.named_parameters())[pname].grad) < 2e-5, field
+
+    mha_case(enc.slf_attn, W.enc_slf, seeded(401, (n, 64, 512)), None, 64, 1, 49, KeyPadMask(49))
+    mha_case(dec.slf_attn, W.dec_slf, seeded(401, (n, 64, 512)), None, 64, 2, 0, CausalMask())
+    mha_case(dec.enc_attn, W.dec_enc, seeded(401, (n, 64, 512)), seeded(402, (n, 49, 512)), 49, 0, 49, None)
+
+    # feed-forward block
+    mod, rows = dec.pos_ffn, n * 64
+    x = _dev(seeded(403, (n, 64, 512))).requires_grad_(True)
+    cot = _dev(seeded(56, (n, 64, 512)))
+    system._SEED_QUEUE = [ops.dropout_seed(seed, 0)]
+    try:
+        mod.zero_grad(set_to_none=True)
+        y_ref = mod(x)
+    finally:
+        system._SEED_QUEUE = None
+    y_ref.backward(cot)
+    sb = int(L.ait_ffn_saved_bytes(rows))
+    saved = torch.empty(sb, dtype=torch.uint8, device="cuda")
+    y = torch.empty(rows, 512, device="cuda")
+    _lib.check(L.ait_ffn_fwd_train(_lib.dev_ptr(x.detach().reshape(-1, 512)), rows, ctypes.byref(W.dec_ffn), 0.1, seed,
+                                   ctypes.c_void_p(saved.data_ptr()), sb, _lib.dev_ptr(y), None), "ait_ffn_fwd_train")
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(n, 64, 512), y_ref.detach())
+    G, bufs = grads_struct(mod, _lib.FfnGrads, [("w1", "w_1.weight"), ("b1", "w_1.bias"), ("w2", "w_2.weight"),
+                                                ("b2", "w_2.bias"), ("ln_g", "layer_norm.weight"),
+                                                ("ln_b", "layer_norm.bias")])
+    wb = int(L.ait_ffn_bwd_workspace_bytes(rows))
+    ws = torch.empty(wb, dtype=torch.uint8, device="cuda")
+    dx = torch.empty(rows, 512, device="cuda")
+    _lib.check(L.ait_ffn_bwd(_lib.dev_ptr(cot.reshape(-1, 512)), _lib.dev_ptr(x.detach().reshape(-1, 512)), rows,
+                             ctypes.byref(W.dec_ffn), 0.1, seed, ctypes.c_void_p(saved.data_ptr()), sb,
+                             ctypes.c_void_p(ws.data_ptr()), wb, _lib.dev_ptr(dx), ctypes.byref(G), None), "ait_ffn_bwd")
+    torch.cuda.synchronize()
+    assert _rel(dx.view(n, 64, 512), x.grad) < 1e-6
+    for field, pname in (("w1", "w_1.weight"), ("b1", "w_1.bias"), ("w2", "w_2.weight"), ("b2", "w_2.bias"),
+                         ("ln_g", "layer_norm.weight"), ("ln_b", "layer_norm.bias")):
+        assert _rel(bufs[field], dict(mod.named_parameters())[pname].grad) < 2e-5, field
+    # argument checking: a saved buffer that is too small, a NULL gradient struct, a bad rate
+    assert L.ait_ffn_bwd(_lib.dev_ptr(cot.reshape(-1, 512)), _lib.dev_ptr(x.detach().reshape(-1, 512)), rows,
+                         ctypes.byref(W.dec_ffn), 0.1, seed, ctypes.c_void_p(saved.data_ptr()), 64,
+                         ctypes.c_void_p(ws.data_ptr()), wb, _lib.dev_ptr(dx), ctypes.byref(G), None) == -2
+    assert L.ait_ffn_fwd_train(_lib.dev_ptr(x.detach().reshape(-1, 512)), rows, ctypes.byref(W.dec_ffn), 1.5, seed,
+                               ctypes.c_void_p(saved.data_ptr()), sb, _lib.dev_ptr(y), None) == -1
+    assert L.ait_dropout_seed(7, 3) == L.ait_dropout_seed(7, 3) != L.ait_dropout_seed(7, 4)
     del keep

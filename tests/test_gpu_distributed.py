@@ -41,7 +41,7 @@ WORKER = textwrap.dedent("""
     ins = [t.to(dev) for t in R.synth_inputs(1, 500 + rank, im_hw=(320, 480))]
     watch = ["transformer.encoder.layer_stack.0.slf_attn.w_qs.weight", "transformer.dec_trans.0.bias",
              "transformer.enc_emb.0.weight", "RCNN_cls_score.1.weight", "RCNN_bbox_pred.weight",
-             "coattention.img_trans.0.weight", "RCNN_rpn.RPN_Conv.bias", "RCNN_top.0.2.conv3.weight",
+             "coattention.img_trans.0.weight", "RCNN_rpn.RPN_Conv.bias", "RCNN_base.backbone.layer4.2.conv3.weight",
              "RCNN_base.backbone.layer3.5.conv3.weight", "sk.sk_props.convs.1.0.weight"]
     params = dict(m.named_parameters())
 

@@ -17,7 +17,9 @@ def _ref(a, b, ta, tb):
                                    (40000, 64, 128),     # 256x64 tile (narrow outputs)
                                    (33000, 512, 64),     # 256x128 tile, slabs direct to LDS (K % 16 == 0)
                                    (33000, 512, 72),     # 256x128 tile, register-staged slabs (K tail)
-                                   (33002, 520, 64)])    # ragged M / N edges on both
+                                   (33002, 520, 64),     # ragged M / N edges on both
+                                   (70000, 1536, 32),    # persistent kernel: 3288 tiles, several per workgroup, 2 slabs each
+                                   (66000, 132, 16)])    # ... one slab per tile (the ring crosses a tile every iteration)
 def test_gemm_layouts(ta, tb, M, N, K):
     from ait_amd import ops
     torch.manual_seed(M * 7 + N * 3 + K)
@@ -70,6 +72,37 @@ def test_gemm_epilogues():
                    out_shape=(P, CH, 64))
     want = (dec.double() @ wt.double().t() + bch.double()).view(P, 64, CH).transpose(1, 2)
     assert torch.allclose(out.double(), want, rtol=1e-5, atol=1e-4)
+
+
+def test_gemm_empty_reduction_is_the_epilogue_of_zero():
+    """K == 0 (an empty token batch in a weight gradient, an empty feature in a forward): the product
+    is zero, so C = bias / residual / zero -- not a crash (round-1 advisor finding)."""
+    from ait_amd import ops
+    M, N = 300, 136
+    bias = torch.randn(N, device="cuda")
+    res = torch.randn(M, N, device="cuda")
+    a, w = torch.zeros(M, 0, device="cuda"), torch.zeros(N, 0, device="cuda")
+    assert torch.equal(ops.gemm(a, w), torch.zeros(M, N, device="cuda"))
+    assert torch.equal(ops.gemm(a, w, bias=bias, residual=res, relu=True), torch.relu(res + bias))
+    # weight-gradient layout with no tokens: dW = dy[0,N]^T x[0,K]
+    dw = ops.gemm(torch.zeros(0, 512, device="cuda"), torch.zeros(0, 2048, device="cuda"), trans_a=True,
+                  trans_b=False, split_k=8)
+    assert tuple(dw.shape) == (512, 2048) and float(dw.abs().max()) == 0.0
+
+
+def test_gemm_out_argument_is_validated():
+    from ait_amd import _lib, ops
+    a, w = torch.randn(64, 32, device="cuda"), torch.randn(48, 32, device="cuda")
+    good = torch.empty(64, 48, device="cuda")
+    ops.gemm(a, w, out=good)
+    assert torch.allclose(good, a @ w.t(), atol=1e-4)
+    wide = torch.empty(64, 96, device="cuda")
+    ops.gemm(a, w, out=wide[:, :48])                       # row pitch 96: legal
+    assert torch.allclose(wide[:, :48], a @ w.t(), atol=1e-4)
+    for bad in (torch.empty(48, 64, device="cuda").t(), torch.empty(64, 47, device="cuda"),
+                torch.empty(64, 48, device="cuda", dtype=torch.float64), torch.empty(64, 48)):
+        with pytest.raises(_lib.AitHipError):
+            ops.gemm(a, w, out=bad)
 
 
 def test_gemm_rejects_unaligned():

@@ -39,6 +39,9 @@ SIGNATURES = {
     "ait_sk_sqsum_bwd": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _vp]),
     "ait_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
                           _i, ctypes.c_longlong, _vp]),
+    "ait_conv_fwd_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "ait_conv_bwd_data_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "ait_conv_bwd_weight_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "ait_gemm_bf16": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
                            _i, ctypes.c_longlong, _vp]),
     "ait_gemm_bf16x3": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
@@ -110,6 +113,11 @@ class MhaWeights(ctypes.Structure):
 class FfnWeights(ctypes.Structure):
     """ait_ffn_weights."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("w1", "b1", "w2", "b2", "ln_g", "ln_b")]
+
+
+class ConvGeom(ctypes.Structure):
+    """ait_conv_geom."""
+    _fields_ = [(n, ctypes.c_int) for n in ("n", "in_h", "in_w", "out_h", "out_w", "kh", "kw", "stride", "pad")]
 
 
 class TransformerWeights(ctypes.Structure):

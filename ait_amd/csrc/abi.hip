@@ -1,6 +1,7 @@
 // ait_amd/csrc/abi.hip -- ABI version + error strings of libait_hip.so.
 #include "common.h"
 
+#include <atomic>
 #include <new>
 
 
@@ -20,9 +21,10 @@ AIT_API const char* ait_strerror(int code) {
 
 // ---- measurement probe --------------------------------------------------------------------------------
 namespace {
-thread_local AitProbe* g_probe = nullptr;
+// process-wide (not per thread): PyTorch runs the backward on its autograd engine's threads
+std::atomic<AitProbe*> g_probe{nullptr};
 }
-AitProbe* ait_probe_current() { return g_probe; }
+AitProbe* ait_probe_current() { return g_probe.load(std::memory_order_acquire); }
 
 AIT_API void* ait_probe_create(int capacity) {
   if (capacity <= 0) return nullptr;
@@ -42,13 +44,13 @@ AIT_API void* ait_probe_create(int capacity) {
 AIT_API void ait_probe_destroy(void* probe) {
   AitProbe* p = static_cast<AitProbe*>(probe);
   if (!p) return;
-  if (g_probe == p) g_probe = nullptr;
+  if (g_probe.load() == p) g_probe.store(nullptr);
   for (int i = 0; i < p->cap; i++) { (void)hipEventDestroy(p->e[i].e0); (void)hipEventDestroy(p->e[i].e1); }
   delete[] p->e;
   delete p;
 }
 
-AIT_API void ait_probe_attach(void* probe) { g_probe = static_cast<AitProbe*>(probe); }
+AIT_API void ait_probe_attach(void* probe) { g_probe.store(static_cast<AitProbe*>(probe), std::memory_order_release); }
 
 AIT_API int ait_probe_reset(void* probe) {
   AitProbe* p = static_cast<AitProbe*>(probe);
@@ -57,11 +59,15 @@ AIT_API int ait_probe_reset(void* probe) {
   return AIT_OK;
 }
 
-AIT_API int ait_probe_count(void* probe) { return probe ? static_cast<AitProbe*>(probe)->n : 0; }
+AIT_API int ait_probe_count(void* probe) {
+  if (!probe) return 0;
+  const AitProbe* p = static_cast<AitProbe*>(probe);
+  return p->n < p->cap ? p->n : p->cap;
+}
 
 AIT_API int ait_probe_get(void* probe, int i, int* kind, double* work, float* ms, int* dims6) {
   AitProbe* p = static_cast<AitProbe*>(probe);
-  if (!p || i < 0 || i >= p->n) return AIT_EINVAL;
+  if (!p || i < 0 || i >= p->n || i >= p->cap) return AIT_EINVAL;
   const AitProbeEntry& e = p->e[i];
   float t = 0.f;
   if (hipEventElapsedTime(&t, e.e0, e.e1) != hipSuccess) return AIT_ELAUNCH;     // not yet complete: synchronise first

@@ -15,6 +15,12 @@
 
 static inline hipStream_t ait_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+#define AIT_TRY_RC(expr)               \
+  do {                                 \
+    const int rc_try__ = (expr);       \
+    if (rc_try__ != AIT_OK) return rc_try__; \
+  } while (0)
+
 // ---- measurement probe (include/ait_hip.h "Measurement"): while a probe is attached to the calling
 // thread, the instrumented entry points bracket their launches with a HIP event pair on the launch
 // stream and note the algorithmic work.  Detached (the default): one thread-local pointer test.
@@ -25,7 +31,8 @@ struct AitProbeEntry {
   hipEvent_t e0, e1;
 };
 struct AitProbe {
-  int cap, n;
+  int cap;
+  volatile int n;         // claimed with an atomic add: launches may come from several host threads
   AitProbeEntry* e;
 };
 AitProbe* ait_probe_current();
@@ -36,8 +43,10 @@ struct AitProbeScope {
                 int d5 = 0)
       : s(stream) {
     AitProbe* p = ait_probe_current();
-    if (!p || p->n >= p->cap) return;
-    ent = &p->e[p->n++];
+    if (!p) return;
+    const int slot = __atomic_fetch_add(const_cast<int*>(&p->n), 1, __ATOMIC_RELAXED);
+    if (slot >= p->cap) return;
+    ent = &p->e[slot];
     ent->kind = kind; ent->work = work;
     ent->dims[0] = d0; ent->dims[1] = d1; ent->dims[2] = d2; ent->dims[3] = d3; ent->dims[4] = d4; ent->dims[5] = d5;
     (void)hipEventRecord(ent->e0, s);

@@ -37,17 +37,17 @@
 namespace {
 using namespace ait_gemm;
 // Product tiles (measured on MI355X with scripts/gemm_lab.hip / scripts/tune_gemm.py):
-//   Tile256D   256x128, 8 waves (64x64 each), slabs global -> LDS directly, PERSISTENT (the slab ring
-//              runs across tile boundaries): every large product with K % 16 == 0.
-//   Tile256D4  the same with FOUR waves owning 128x64 each (8 MFMA tiles, 0.75 operand fetches per MFMA
-//              instead of 1.0): the weight-gradient layout, where both operands are K-outer and every
-//              operand fetch is four ds_read_b32.
+//   Tile256D   256x128, FOUR waves owning 128x64 each (8 MFMA tiles per wave, 0.75 operand fetches per MFMA;
+//              two workgroups per CU put two waves of DIFFERENT workgroups on every SIMD, so their barrier
+//              phases are decoupled), slabs global -> LDS directly, PERSISTENT (the slab ring runs across
+//              tile boundaries): every large product with K % 16 == 0.  Measured against the 8-wave
+//              (64x64 per wave) form of the same tile: +2..5 % on every layout (scripts/gemm_lab.hip sweep,
+//              profiles/r02_gemm_lab_sweep.txt).
 //   Tile256    256x128, register-staged three-slab ring: large products whose K is not a multiple of 16.
 //   Tile128    128x128 register-staged double buffer: outputs with few rows.
 //   TileN64    256x64 for the 64-column SHBlock / fc products (no dead half tile).
 //   Tile64     64x64 for few-tile problems (the bs*64-row query side): latency, not throughput.
-using Tile256D = Cfg<256, 128, 16, 4, 2, 4, MODE_DLDS>;   // MINW 4: <= 128 VGPRs, two workgroups per CU
-using Tile256D4 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS>;
+using Tile256D = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS>;
 using Tile256 = Cfg<256, 128, 16, 4, 2, 2, MODE_RING>;
 using Tile128 = Cfg<128, 128, 16, 2, 2, 2, MODE_DB>;
 using TileN64 = Cfg<256, 64, 16, 4, 1, 2, MODE_DB>;
@@ -70,11 +70,111 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   if (N <= 64 && (long long)((M + 255) / 256) * g.splits >= 128) return dispatch<TileN64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   if (M >= 512 && tiles256 >= 512) {
     const bool direct = K > 0 && (K % 16 == 0) && (!trans_a || (M % 4 == 0 && M >= 4)) && (trans_b || (N % 4 == 0 && N >= 4));
-    if (direct && trans_a && !trans_b) return dispatch<Tile256D4>(g, false, false, ait_stream(stream));
     if (direct) return dispatch<Tile256D>(g, !trans_a, trans_b != 0, ait_stream(stream));
     return dispatch<Tile256>(g, !trans_a, trans_b != 0, ait_stream(stream));
   }
   const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * g.splits;
   if (tiles128 < 128) return dispatch<Tile64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   return dispatch<Tile128>(g, !trans_a, trans_b != 0, ait_stream(stream));
+}
+
+// =========================================================================================================
+// Convolutions over channels-last maps as implicit GEMMs on the same persistent kernel (the
+// 3x3 convolutions of RCNN_top / layer4, resnet_sys_transformer_sk_dilat.py:85-111,482-491).  No im2col
+// buffer: the LDS-DMA of the gathered operand takes its per-lane source address from the window geometry
+// (ConvGeom, gemm_f32_impl.h); positions outside the map read a caller-provided row of zeros.
+// =========================================================================================================
+namespace {
+using Tile128D = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4>;
+
+inline int log2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int s = 0;
+  while ((1 << s) < v) s++;
+  return s;
+}
+
+struct ConvDims { long long rows; int taps; };
+
+inline int check_geom(const ait_conv_geom* q, int cin, int cout) {
+  if (!q || q->n < 0 || q->in_h <= 0 || q->in_w <= 0 || q->out_h <= 0 || q->out_w <= 0 || q->kh <= 0 || q->kw <= 0 ||
+      q->stride <= 0 || q->pad < 0 || cin <= 0 || cout <= 0)
+    return AIT_EINVAL;
+  if (log2_exact(q->stride) < 0) return AIT_EUNSUPPORTED;
+  // every output position must see the window the geometry describes
+  if ((q->out_h - 1) * q->stride - q->pad + q->kh - 1 < 0 || (q->out_w - 1) * q->stride - q->pad + q->kw - 1 < 0)
+    return AIT_EINVAL;
+  return AIT_OK;
+}
+
+template <class T, int CONV, bool AK, bool BKC>
+int conv_launch(const GemmArgs& g, hipStream_t s) {
+  if (g.flags & AIT_GEMM_ATOMIC) return launch<T, AK, BKC, EPI_ATOMIC, NoProbe, CONV>(g, s);
+  if (g.residual) return launch<T, AK, BKC, EPI_RES, NoProbe, CONV>(g, s);
+  return launch<T, AK, BKC, EPI_STORE, NoProbe, CONV>(g, s);
+}
+template <int CONV, bool AK, bool BKC>
+int conv_dispatch(const GemmArgs& g, hipStream_t s) {
+  const long long tiles256 = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128) * g.splits;
+  if (tiles256 >= 512) return conv_launch<Tile256D, CONV, AK, BKC>(g, s);
+  return conv_launch<Tile128D, CONV, AK, BKC>(g, s);     // few tiles: 128x128, three to a CU
+}
+}  // namespace
+
+AIT_API int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_conv_geom* q, int cin, int cout,
+                             const float* bias, const float* residual, int flags, float* y, int ldy,
+                             const float* zeros, size_t zeros_floats, void* stream) {
+  AIT_TRY_RC(check_geom(q, cin, cout));
+  const int hw = log2_exact(q->out_h * q->out_w), ws = log2_exact(q->out_w);
+  if (hw < 0 || ws < 0 || (cin & 15) || (cout & 3)) return AIT_EUNSUPPORTED;
+  const long long rows = (long long)q->n * q->out_h * q->out_w;
+  if (rows == 0) return AIT_OK;
+  if (rows > 0x7fffffffLL / 4 || !x || !w || !y || !zeros || zeros_floats < (size_t)cin + 144) return AIT_EINVAL;
+  if (flags & ~(AIT_GEMM_RELU | AIT_GEMM_MASK_POS)) return AIT_EINVAL;
+  const int taps = q->kh * q->kw;
+  GemmArgs g;
+  AIT_TRY_RC(make_args(0, 1, (int)rows, cout, taps * cin, 1.f, x, ldx, w, taps * cin, y, ldy, bias, residual, flags, 1, 0, 0,
+                       16, g));
+  g.conv = ConvGeom{hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cin, 0, zeros};
+  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cin, ait_stream(stream), (int)rows, cout, taps * cin, 0, 1, 1);
+  return conv_dispatch<CONV_A, true, true>(g, ait_stream(stream));
+}
+
+AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, const ait_conv_geom* q, int cin, int cout,
+                                  const float* residual, int flags, float* dx, int lddx, const float* zeros,
+                                  size_t zeros_floats, void* stream) {
+  AIT_TRY_RC(check_geom(q, cin, cout));
+  const int hw = log2_exact(q->in_h * q->in_w), ws = log2_exact(q->in_w);
+  if (hw < 0 || ws < 0 || (cout & 15) || (cin & 3)) return AIT_EUNSUPPORTED;
+  const long long rows = (long long)q->n * q->in_h * q->in_w;
+  if (rows == 0) return AIT_OK;
+  if (rows > 0x7fffffffLL / 4 || !dy || !w || !dx || !zeros || zeros_floats < (size_t)cout + 144) return AIT_EINVAL;
+  if (flags & ~AIT_GEMM_MASK_POS) return AIT_EINVAL;
+  const int taps = q->kh * q->kw;
+  GemmArgs g;
+  // B is addressed per tap (retap): K-outer rows (t, co) at w + t*cin + co*(taps*cin)
+  AIT_TRY_RC(make_args(0, 0, (int)rows, cin, taps * cout, 1.f, dy, lddy, w, taps * cin, dx, lddx, nullptr, residual, flags, 1, 0,
+                       0, 16, g));
+  g.conv = ConvGeom{hw, ws, q->out_h, q->out_w, q->kw, 1, -1, q->pad, log2_exact(q->stride), cout, (long long)cin, zeros};
+  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cin * taps * cout, ait_stream(stream), (int)rows, cin, taps * cout, 0, 0, 1);
+  return conv_dispatch<CONV_A, true, false>(g, ait_stream(stream));
+}
+
+AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, int ldx, const ait_conv_geom* q, int cin,
+                                    int cout, float* dw, int split_k, const float* zeros, size_t zeros_floats,
+                                    void* stream) {
+  AIT_TRY_RC(check_geom(q, cin, cout));
+  const int hw = log2_exact(q->out_h * q->out_w), ws = log2_exact(q->out_w);
+  const long long rows = (long long)q->n * q->out_h * q->out_w;
+  if (hw < 0 || ws < 0 || (cin % 128) || (cout & 3) || (rows & 15)) return AIT_EUNSUPPORTED;
+  if (rows == 0) return AIT_OK;
+  if (rows > 0x7fffffffLL / 4 || !dy || !x || !dw || !zeros || zeros_floats < (size_t)cin + 144) return AIT_EINVAL;
+  const int taps = q->kh * q->kw;
+  GemmArgs g;
+  AIT_TRY_RC(make_args(1, 0, cout, taps * cin, (int)rows, 1.f, dy, lddy, x, ldx, dw, taps * cin, nullptr, nullptr,
+                       AIT_GEMM_ATOMIC, split_k < 1 ? 1 : split_k, 0, 0, 16, g));
+  g.conv = ConvGeom{hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cin, 0, zeros};
+  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cin, ait_stream(stream), cout, taps * cin, (int)rows, 1, 0,
+                      g.splits);
+  return conv_launch<Tile256D, CONV_B, false, false>(g, ait_stream(stream));
 }

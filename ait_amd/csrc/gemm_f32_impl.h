@@ -20,6 +20,39 @@ namespace ait_gemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Implicit-GEMM view of a convolution over channels-last maps (gemm_f32_stream_kernel, CONV != 0).
+// The GEMM's row index r runs over the positions (image, y, x) of the "row map" (rows_h x rows_w, both
+// powers of two); tap t = (ty, tx) of a kh x kw window pairs row position (y, x) with position
+//     (y * a + c + ty * b,  x * a + c + tx * b) / 2^div_shift        (exact division, inside src_h x src_w)
+// of the gathered tensor, or with nothing (a row of zeros):
+//     forward / weight gradient: rows = output map, gathered = input:  a = stride, b = 1,  c = -pad, div 1
+//     data gradient:             rows = input map,  gathered = dy:     a = 1,      b = -1, c = +pad, div = stride
+//   CONV_A (1): A[r, t*seg + ch] = src[gather(r, t), ch]; B is the weight [cout][kh*kw][seg] read either
+//               K-contiguous (forward: B[n = cout][k]) or K-outer (data gradient: row k = (t, cout) of tap t
+//               at B + t*b_tap_stride + cout*ldb);
+//   CONV_B (2): weight gradient, C[cout, t*seg + ch] += sum_r A[r, cout] * src[gather(r, t), ch]: the K-outer
+//               operand B is gathered row by row, the tap is fixed per output column tile (seg % BN == 0).
+struct ConvGeom {
+  int rows_hw_shift, rows_w_shift;      // log2(rows_h * rows_w), log2(rows_w)
+  int src_h, src_w;
+  int kw;                               // taps per window row
+  int a, b, c, div_shift;
+  int seg;                              // reduction floats per tap (channels of the gathered tensor)
+  long long b_tap_stride;               // CONV_A with K-outer B
+  const float* zero;                    // >= max(seg, BN) + 16 floats of zeros
+};
+enum { CONV_NONE = 0, CONV_A = 1, CONV_B = 2 };
+
+__device__ __forceinline__ int conv_src_row(const ConvGeom& c, int r, int tap) {
+  const int img = r >> c.rows_hw_shift, rem = r & ((1 << c.rows_hw_shift) - 1);
+  const int y = rem >> c.rows_w_shift, x = rem & ((1 << c.rows_w_shift) - 1);
+  const int ty = tap / c.kw, tx = tap - ty * c.kw;
+  const int ny = y * c.a + c.c + ty * c.b, nx = x * c.a + c.c + tx * c.b;
+  const int sy = ny >> c.div_shift, sx = nx >> c.div_shift;
+  const bool ok = ny >= 0 && nx >= 0 && ((ny | nx) & ((1 << c.div_shift) - 1)) == 0 && sy < c.src_h && sx < c.src_w;
+  return ok ? (img * c.src_h + sy) * c.src_w + sx : -1;
+}
+
 struct GemmArgs {
   const float* A;
   const float* B;
@@ -35,6 +68,7 @@ struct GemmArgs {
   int k_per_split;
   int splits;
   unsigned long long* probe;   // diagnostic stamps (scripts/gemm_lab.hip); NULL in the product
+  ConvGeom conv;               // CONV != 0 kernels only
 };
 
 enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
@@ -380,10 +414,12 @@ struct WorkMap {
 // slab s+1 before that barrier, so the MFMA stream runs across it -- and across the epilogue of a
 // finished tile, whose stores are issued while the next tile's first slabs are already in LDS.
 // =========================================================================================================
-template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe>
+template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe, int CONV = CONV_NONE>
 __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const GemmArgs g) {
   static_assert(C::MODE == MODE_DLDS && C::BK == 16 && C::BM % 16 == 0 && C::BN % 16 == 0,
                 "direct-to-LDS path needs 16-float slabs");
+  static_assert(CONV != CONV_A || AK, "the gathered operand of CONV_A is K-contiguous");
+  static_assert(CONV != CONV_B || (!AK && !BKC), "CONV_B is the weight-gradient layout");
   static_assert((C::BM + C::BN) * 16 / 256 <= 8 * (C::NT / 64), "at most 8 transfers per wave per slab");
   constexpr int BM = C::BM, BN = C::BN, BK = 16;
   constexpr int SA = BM * 16, SB = BN * 16;          // floats per slab image
@@ -427,22 +463,45 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   const size_t step_a = AK ? 16 : (size_t)16 * g.lda;
   const size_t step_b = BKC ? 16 : (size_t)16 * g.ldb;
   int l_item = j, l_k = 0, l_kend = 0;
+  int l_n0 = 0;                     // column origin of the load cursor's tile (CONV kernels)
+  int arow[LA];                     // CONV_A: this lane's (clamped) GEMM row per A transfer
   bool l_valid = true;
+  // CONV_A: operand pointers at reduction index l_k = tap * seg + kin
+  auto retap = [&]() {
+    const int tap = l_k / g.conv.seg, kin = l_k - tap * g.conv.seg;
+#pragma unroll
+    for (int i = 0; i < LA; i++) {
+      const int row = (wave + i * NW) * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      const int src = conv_src_row(g.conv, arow[i], tap);
+      pa[i] = (src >= 0 ? g.A + (size_t)src * g.lda : g.conv.zero) + kin + chunk * 4;
+    }
+    if (!BKC) {
+#pragma unroll
+      for (int i = 0; i < LB; i++) {
+        const int e = (wave + i * NW) * 256 + lane * 4;
+        pb[i] = g.B + tap * g.conv.b_tap_stride + (size_t)(kin + e / BN) * g.ldb + min(l_n0 + e % BN, g.N - 4);
+      }
+    }
+  };
   auto set_tile = [&](int id) {
     int m0, n0;
     wmap.decode(g, base + id, BM, BN, m0, n0, l_k, l_kend);
+    l_n0 = n0;
 #pragma unroll
     for (int i = 0; i < LA; i++) {
       const int q = wave + i * NW;
       if (AK) {
         const int row = q * 16 + (lane >> 2);
         const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        pa[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + l_k + chunk * 4;
+        if (CONV == CONV_A) arow[i] = min(m0 + row, g.M - 1);
+        else pa[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + l_k + chunk * 4;
       } else {
         const int e = q * 256 + lane * 4;            // element of the [16][BM] image
         pa[i] = g.A + (size_t)(l_k + e / BM) * g.lda + min(m0 + e % BM, g.M - 4);
       }
     }
+    if (CONV == CONV_B) return;      // the gathered operand is addressed transfer by transfer (issue)
 #pragma unroll
     for (int i = 0; i < LB; i++) {
       const int q = wave + i * NW;
@@ -450,11 +509,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         const int row = q * 16 + (lane >> 2);
         const int chunk = (lane & 3) ^ ((row >> 2) & 3);
         pb[i] = g.B + (size_t)min(n0 + row, g.N - 1) * g.ldb + l_k + chunk * 4;
-      } else {
+      } else if (CONV != CONV_A) {
         const int e = q * 256 + lane * 4;
         pb[i] = g.B + (size_t)(l_k + e / BN) * g.ldb + min(n0 + e % BN, g.N - 4);
       }
     }
+    if (CONV == CONV_A) retap();
   };
   // one 1-KB transfer of the cursor's slab (piece < LA: operand A, else B) into ring slot `slot`
   auto issue = [&](int piece, int slot) {
@@ -463,19 +523,34 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       if (GA % NW == 0 || q < GA) glds16(pa[piece], As + slot * SA + q * 256);
     } else {
       const int q = wave + (piece - LA) * NW;
-      if (GB % NW == 0 || q < GB) glds16(pb[piece - LA], Bd + slot * SB + q * 256);
+      if (GB % NW == 0 || q < GB) {
+        if (CONV == CONV_B) {
+          // weight gradient: row k of the K-outer operand is the source position that tap (fixed by the
+          // column tile) pairs with GEMM row k; nothing to pair with -> the row of zeros
+          const int e = q * 256 + lane * 4;
+          const int tap = l_n0 / g.conv.seg, ch0 = l_n0 - tap * g.conv.seg;
+          const int src = conv_src_row(g.conv, l_k + e / BN, tap);
+          glds16((src >= 0 ? g.B + (size_t)src * g.ldb + ch0 : g.conv.zero) + e % BN, Bd + slot * SB + q * 256);
+        } else {
+          glds16(pb[piece - LA], Bd + slot * SB + q * 256);
+        }
+      }
     }
   };
   auto advance = [&]() {             // cursor -> next slab of the stream (possibly the next tile's first)
 #pragma unroll
     for (int i = 0; i < LA; i++) pa[i] += step_a;
+    if (CONV != CONV_B) {
 #pragma unroll
-    for (int i = 0; i < LB; i++) pb[i] += step_b;
+      for (int i = 0; i < LB; i++) pb[i] += step_b;
+    }
     l_k += BK;
     if (l_k >= l_kend) {
       l_item += W;
       if (l_item < lim) set_tile(l_item);
       else l_valid = false;
+    } else if (CONV == CONV_A) {
+      if (l_k % g.conv.seg == 0) retap();      // next tap: new source rows (and, K-outer weights, new tap base)
     }
   };
   auto request = [&](int slot) {     // whole slab at once (prologue)
@@ -796,7 +871,7 @@ inline int stream_slots() {
   return (per_cu < 1 ? 1 : per_cu) * cus;
 }
 
-template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe>
+template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe, int CONV = CONV_NONE>
 int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
   WorkMap wmap;
   wmap.init(g, C::BM, C::BN);
@@ -808,7 +883,7 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
     if (slots <= 0) slots = stream_slots<C>();
     const int w = max(1, min(wmap.chunk, slots / AIT_NXCD));
     blocks = (unsigned)(w * AIT_NXCD);
-    kern = reinterpret_cast<const void*>(gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe>);
+    kern = reinterpret_cast<const void*>(gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV>);
   } else {
     blocks = (unsigned)(wmap.chunk * AIT_NXCD);
     kern = reinterpret_cast<const void*>(gemm_f32_kernel<C, AK, BKC, EPI>);
@@ -817,7 +892,7 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
       hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) != hipSuccess)
     return AIT_ELAUNCH;
   if constexpr (C::MODE == MODE_DLDS)
-    hipLaunchKernelGGL((gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe>), dim3(blocks), dim3(C::NT), C::LDS, s, g);
+    hipLaunchKernelGGL((gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV>), dim3(blocks), dim3(C::NT), C::LDS, s, g);
   else
     hipLaunchKernelGGL((gemm_f32_kernel<C, AK, BKC, EPI>), dim3(blocks), dim3(C::NT), C::LDS, s, g);
   AIT_CHECK_LAUNCH();
@@ -865,6 +940,7 @@ inline int make_args(int trans_a, int trans_b, int M, int N, int K, float alpha,
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.c_colblk = c_colblk; g.c_batch = c_batch_stride; g.alpha = alpha; g.flags = flags;
   g.probe = nullptr;
+  g.conv = ConvGeom{};
   // 32-bit element offsets in the epilogue
   {
     const unsigned long long rows = (unsigned long long)(M > 0 ? M - 1 : 0) * (unsigned long long)(ldc > 0 ? ldc : 0);

@@ -333,6 +333,75 @@ class _Conv1x1BnAct(torch.autograd.Function):
         return dx, dw, None, None, None, dres, None
 
 
+class _Conv3x3BnAct(torch.autograd.Function):
+    """k x k convolution (stride 1 or 2) + frozen BatchNorm (+ ReLU) over a channels-last tensor whose maps
+    have power-of-two sides (the 4x4 maps of layer4 on the proposal tail): an implicit GEMM on the matrix-core
+    kernel (ait_conv_fwd_f32), the BatchNorm's scale folded into the weights and its shift / the ReLU in the
+    epilogue.  Backward: one masking pass dz = dy * [y > 0], then ait_conv_bwd_data_f32 and
+    ait_conv_bwd_weight_f32 (dW = scale * (dz^T (*) x))."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, ones, relu, stride, pad):
+        n, cin, h, w = x.shape
+        cout, _, kh, kw = weight.shape
+        oh, ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+        xm = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)                  # view of channels-last x
+        w2 = (weight.permute(0, 2, 3, 1) * scale.view(-1, 1, 1, 1)).contiguous()       # [cout, kh, kw, cin]
+        geom = ops.conv_geom(n, (h, w), (oh, ow), (kh, kw), stride, pad)
+        ym = ops.conv_fwd(xm, w2, geom, bias=shift, relu=relu)
+        y = ym.view(n, oh, ow, cout).permute(0, 3, 1, 2)
+        ctx.save_for_backward(xm, w2, scale, ones, y if relu else None)
+        ctx.geom, ctx.relu, ctx.k, ctx.xshape = geom, relu, (kh, kw), (n, cin, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, w2, scale, ones, y = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dz = ops.bn_act_bwd(dy, y, ones, True, False)[0] if ctx.relu else dy
+        n, cout = dz.shape[0], dz.shape[1]
+        dzm = dz.permute(0, 2, 3, 1).reshape(-1, cout)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            n_, cin, h, w = ctx.xshape
+            dx = ops.conv_bwd_data(dzm, w2, ctx.geom).view(n_, h, w, cin).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            rows = dzm.shape[0]
+            dw = ops.conv_bwd_weight(dzm, xm, ctx.geom, ctx.k[0], ctx.k[1], split_k=max(8, min(64, rows // 2048 // 8 * 8)))
+            dw = (dw * scale.view(-1, 1, 1, 1)).permute(0, 3, 1, 2)         # [cout, cin, kh, kw] (channels-last strides)
+        return dx, dw, None, None, None, None, None, None
+
+
+# Proposal tail (RCNN_top = layer4 on the 4x4 maps behind the SK block) on the library's own matrix-core
+# kernels: 1x1 convolutions as GEMMs, 3x3 convolutions as implicit GEMMs, the frozen BatchNorm / residual /
+# ReLU in their epilogues (SURVEY 8f-1).  OPT-IN (AIT_TOP_HIP=1): measured on MI355X at bs=4, P=300 the step
+# takes 76.1 ms with it against 69.8 ms on MIOpen's NHWC implicit-GEMM assembly kernels -- the products have
+# 19200 rows, i.e. 300 tiles of 256x128 on 512 workgroup slots, and run at 90-118 TFLOP/s against MIOpen's
+# ~125 (DESIGN.md 3.7); parity-tested either way (tests/test_gpu_ops.py).
+_TOP_HIP = os.environ.get("AIT_TOP_HIP", "0") == "1"
+_TOP_HIP_MIN_ROWS = 4096      # fewer rows (the query side: bs*16) are one workgroup's serial K loop: MIOpen
+
+
+def conv3x3_bn_act(x, conv, bn, relu=True, stride=None):
+    """relu(bn(conv(x))) for a bias-free k x k convolution; the implicit-GEMM path needs channels-last fp32
+    GPU activations, a frozen BN and power-of-two map sides, everything else is conv (MIOpen) + bn_act."""
+    stride = conv.stride[0] if stride is None else stride
+    if (_TOP_HIP and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _bn_frozen(bn) and conv.groups == 1
+            and conv.bias is None and conv.dilation == (1, 1) and conv.padding[0] == conv.padding[1]
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        kh, kw = conv.kernel_size
+        pad = conv.padding[0]
+        h, w = x.shape[2], x.shape[3]
+        oh, ow = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+        rows = x.shape[0] * oh * ow
+        if ops.conv_supported((h, w), (oh, ow), stride, conv.in_channels, conv.out_channels) and rows % 16 == 0 \
+                and rows >= _TOP_HIP_MIN_ROWS:
+            scale, shift, ones = _bn_affine(bn)
+            return _Conv3x3BnAct.apply(x, conv.weight, scale, shift, ones, relu, stride, pad)
+    y = conv(x) if stride == conv.stride[0] else F.conv2d(x, conv.weight, None, stride, conv.padding)
+    return bn_act(y, bn, relu=relu)
+
+
 # OFF by default: measured on MI355X, MIOpen's NHWC implicit-GEMM assembly kernels beat
 # ait_gemm_f32 on these shapes even with the BN/ReLU pass fused away (bs=4, P=300: 75.9 ms/step
 # without, 78.2 with layer4 only, 81.2 with layer3+4, 82.9 with every 1x1).  Kept as an opt-in
@@ -342,16 +411,18 @@ _CONV1X1_GEMM = os.environ.get("AIT_CONV1X1_GEMM", "0") == "1"
 _CONV1X1_MIN_C = int(os.environ.get("AIT_CONV1X1_MIN_C", "512"))
 
 
-def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, stride1=False):
+def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, stride1=False, hip=False):
     """relu(bn(conv(x)) + residual) for a bias-free 1x1 convolution.  `stride1`: run the
     convolution at stride 1 whatever conv.stride says (the input is already subsampled).
     Channels-last fp32 GPU activations with a frozen BN take the single-GEMM path above; everything
     else is conv (MIOpen) + bn_act."""
     stride = (1, 1) if stride1 else conv.stride
-    if (_CONV1X1_GEMM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _bn_frozen(bn)
+    if hip and x.numel() // max(1, x.shape[1]) < _TOP_HIP_MIN_ROWS:
+        hip = False
+    if ((_CONV1X1_GEMM or hip) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _bn_frozen(bn)
             and conv.kernel_size == (1, 1) and stride == (1, 1) and conv.groups == 1 and conv.bias is None
             and conv.padding == (0, 0) and conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0
-            and min(conv.in_channels, conv.out_channels) >= _CONV1X1_MIN_C
+            and (hip or min(conv.in_channels, conv.out_channels) >= _CONV1X1_MIN_C)
             and x.is_contiguous(memory_format=torch.channels_last)
             and (residual is None or residual.is_contiguous(memory_format=torch.channels_last))):
         scale, shift, ones = _bn_affine(bn)
@@ -385,8 +456,11 @@ class Bottleneck(nn.Module):
         convolutions (the first block of the next stage); the block then produces just those
         positions -- conv2 runs at stride s (same 3x3 sums at the kept positions), conv3, the
         frozen BN, the residual and the ReLU are position-wise."""
-        out = conv1x1_bn_act(x, self.conv1, self.bn1, stride1=subsampled)
-        if out_stride == 1:
+        hip = getattr(self, "_ait_hip", False)            # set on the blocks of RCNN_top (see resnet._init_modules)
+        out = conv1x1_bn_act(x, self.conv1, self.bn1, stride1=subsampled, hip=hip)
+        if hip and out_stride == 1:
+            out = conv3x3_bn_act(out, self.conv2, self.bn2)
+        elif out_stride == 1:
             out = bn_act(self.conv2(out), self.bn2)
         else:
             out = bn_act(F.conv2d(out, self.conv2.weight, None, out_stride, self.conv2.padding), self.bn2)
@@ -395,8 +469,19 @@ class Bottleneck(nn.Module):
         elif out_stride != 1:
             raise ValueError("out_stride needs an identity shortcut")
         else:
-            identity = conv1x1_bn_act(x, self.downsample[0], self.downsample[1], relu=False, stride1=subsampled)
-        return conv1x1_bn_act(out, self.conv3, self.bn3, residual=identity)
+            identity = conv1x1_bn_act(x, self.downsample[0], self.downsample[1], relu=False, stride1=subsampled, hip=hip)
+        return conv1x1_bn_act(out, self.conv3, self.bn3, residual=identity, hip=hip)
+
+
+def _c4_size(h, w):
+    """feature size of the C4 trunk for an h x w image: 7x7 stride-2 pad-3 stem, 3x3 stride-2 ceil-mode
+    max-pool without padding, two stride-2 stages (resnet_sys_transformer_sk_dilat.py:117-125,78)"""
+    def one(n):
+        n = (n + 6 - 7) // 2 + 1
+        n = -((n - 3) // -2) + 1
+        n = (n - 1) // 2 + 1
+        return (n - 1) // 2 + 1
+    return one(h), one(w)
 
 
 def _opens_with_stride2_1x1(stage):
@@ -533,6 +618,10 @@ class _fasterRCNN(nn.Module):
     def forward(self, image, query, img_info, gt_boxes, num_boxes):
         bs = image.size(0)
         img_info, gt_boxes, num_boxes = img_info.data, gt_boxes.data, num_boxes.data
+        if self.training and image.is_cuda:
+            # the RPN's anchor targets depend only on the inputs: their device part is enqueued FIRST and the
+            # two counts per image the host-side sampling needs cross PCIe while the backbone runs
+            self.RCNN_rpn.RPN_anchor_target.begin(gt_boxes, img_info, *_c4_size(image.size(2), image.size(3)))
 
         image_feat, _ = self.RCNN_base(image)                 # [bs, 1024, H_i, W_i]
         query_feat, _ = self.RCNN_base(query)                 # [bs, 1024, 8, 8]
@@ -632,6 +721,8 @@ class resnet(_fasterRCNN):
             raise NotImplementedError("ImageNet weights are loaded with load_state_dict by the driver")
         self.RCNN_base = RCNNBackbone(cfg, backbone=net)
         self.RCNN_top = nn.Sequential(net.layer4)
+        for blk in net.layer4:
+            blk._ait_hip = _TOP_HIP
         self.RCNN_cls_score = nn.Sequential(nn.Linear(2048 * 2, 8), nn.Linear(8, 2))
         self.RCNN_bbox_pred = nn.Linear(2048, 4 if self.class_agnostic else 4 * self.n_classes)
 

@@ -276,3 +276,70 @@ def sk_sqsum_bwd(dy, a, b):
                                          _lib.cur_stream(a.device))
     _lib.check(rc, "ait_sk_sqsum_bwd")
     return da, db
+
+
+# ------------------------------------------------------------------------------------------
+# convolutions over channels-last maps as implicit GEMMs (ait_conv_*_f32)
+# ------------------------------------------------------------------------------------------
+_ZEROS = {}
+
+
+def _zeros(device, n=8192):
+    """the row of zeros a window position outside the map reads (one per device, never written)"""
+    key = (str(device), n)
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(n, dtype=torch.float32, device=device)
+    return _ZEROS[key]
+
+
+def conv_geom(n, in_hw, out_hw, k, stride, pad):
+    g = _lib.ConvGeom()
+    g.n, g.in_h, g.in_w, g.out_h, g.out_w = int(n), int(in_hw[0]), int(in_hw[1]), int(out_hw[0]), int(out_hw[1])
+    g.kh, g.kw, g.stride, g.pad = int(k[0]), int(k[1]), int(stride), int(pad)
+    return g
+
+
+def conv_supported(in_hw, out_hw, stride, cin, cout):
+    """what ait_conv_*_f32 take (forward, data and weight gradient all together)"""
+    p2 = lambda v: v > 0 and (v & (v - 1)) == 0
+    return (p2(in_hw[1]) and p2(in_hw[0] * in_hw[1]) and p2(out_hw[1]) and p2(out_hw[0] * out_hw[1]) and p2(stride)
+            and cin % 128 == 0 and cout % 16 == 0 and max(cin, cout) + 144 <= 8192)
+
+
+def conv_fwd(x, w, geom, bias=None, residual=None, relu=False):
+    """x [rows_in, cin] token rows of a channels-last map, w [cout, kh, kw, cin] -> y [rows_out, cout]"""
+    cout, cin = w.shape[0], w.shape[3]
+    rows = geom.n * geom.out_h * geom.out_w
+    y = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    z = _zeros(x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().ait_conv_fwd_f32(_lib.dev_ptr(x), x.stride(0), _lib.dev_ptr(w), ctypes.byref(geom), cin, cout,
+                                         _p(bias), _p(residual), _lib.GEMM_RELU if relu else 0, _p(y), cout, _p(z),
+                                         z.numel(), _lib.cur_stream(x.device))
+    _lib.check(rc, "ait_conv_fwd_f32")
+    return y
+
+
+def conv_bwd_data(dy, w, geom, residual=None, mask_pos=False):
+    cout, cin = w.shape[0], w.shape[3]
+    rows = geom.n * geom.in_h * geom.in_w
+    dx = torch.empty((rows, cin), dtype=torch.float32, device=dy.device)
+    z = _zeros(dy.device)
+    with torch.cuda.device(dy.device):
+        rc = _lib.lib().ait_conv_bwd_data_f32(_lib.dev_ptr(dy), dy.stride(0), _lib.dev_ptr(w), ctypes.byref(geom), cin, cout,
+                                              _p(residual), _lib.GEMM_MASK_POS if mask_pos else 0, _p(dx), cin, _p(z),
+                                              z.numel(), _lib.cur_stream(dy.device))
+    _lib.check(rc, "ait_conv_bwd_data_f32")
+    return dx
+
+
+def conv_bwd_weight(dy, x, geom, kh, kw, split_k=8):
+    cout, cin = dy.shape[1], x.shape[1]
+    dw = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=dy.device)
+    z = _zeros(dy.device)
+    with torch.cuda.device(dy.device):
+        rc = _lib.lib().ait_conv_bwd_weight_f32(_lib.dev_ptr(dy), dy.stride(0), _lib.dev_ptr(x), x.stride(0),
+                                                ctypes.byref(geom), cin, cout, _p(dw), int(split_k), _p(z), z.numel(),
+                                                _lib.cur_stream(dy.device))
+    _lib.check(rc, "ait_conv_bwd_weight_f32")
+    return dw

@@ -193,26 +193,43 @@ class _AnchorTargetLayer(nn.Module):
         self._grid = _AnchorGrid(feat_stride, scales, ratios)
         self._num_anchors = self._grid.A
         self._allowed_border = 0
+        self._inside = {}
 
     def forward(self, input):
         rpn_cls_score, gt_boxes, im_info, num_boxes = input
         H, W = rpn_cls_score.size(2), rpn_cls_score.size(3)
+        pending = self._pending
+        self._pending = None
+        if pending is None or pending[0] != (H, W, gt_boxes.data_ptr()):
+            pending = self.prepare(gt_boxes, im_info, H, W)
+        return self.finish(pending)
+
+    _pending = None
+
+    def prepare(self, gt_boxes, im_info, H, W):
+        """Everything this layer computes depends only on the INPUTS (anchors, gt boxes, image size), not on
+        the network: the device part (IoU, arg-max, labels) and the two per-image counts the host-side
+        sampling needs are therefore enqueued at the very start of the detector's forward, and the counts
+        travel to the host while the GPU runs the backbone (no GPU-idle gap at the sampler).
+        Returns the pending state consumed by finish() / forward()."""
         b = gt_boxes.size(0)
-        A = self._num_anchors
         dev = gt_boxes.device
         all_anchors = self._grid.get(H, W, dev)
-        total = all_anchors.size(0)
         bd = self._allowed_border
-        im_w, im_h = int(im_info[0][1]), int(im_info[0][0])
-        inside = ((all_anchors[:, 0] >= -bd) & (all_anchors[:, 1] >= -bd) &
-                  (all_anchors[:, 2] < im_w + bd) & (all_anchors[:, 3] < im_h + bd))
-        inds_inside = torch.nonzero(inside).view(-1)
+        # (im_info rows are identical within a batch of the reference's drivers; like the reference, row 0 decides)
+        key = (H, W, str(dev))
+        if key not in self._inside:
+            im_h, im_w = float(im_info[0][0]), float(im_info[0][1])        # one tiny D2H, once per feature size
+            inside = ((all_anchors[:, 0] >= -bd) & (all_anchors[:, 1] >= -bd) &
+                      (all_anchors[:, 2] < int(im_w) + bd) & (all_anchors[:, 3] < int(im_h) + bd))
+            self._inside[key] = (torch.nonzero(inside).view(-1), (im_h, im_w))
+        inds_inside, _ = self._inside[key]
         anchors = all_anchors[inds_inside]
-        n_in = anchors.size(0)
 
         overlaps = bbox_overlaps_batch(anchors, gt_boxes)                 # [b, n_in, G]
         max_ov, argmax_ov = overlaps.max(2)
         gt_max = overlaps.max(1)[0]
+        n_in = anchors.size(0)
         labels = gt_boxes.new_full((b, n_in), -1)
         if not cfg.TRAIN.RPN_CLOBBER_POSITIVES:
             labels[max_ov < cfg.TRAIN.RPN_NEGATIVE_OVERLAP] = 0
@@ -222,25 +239,74 @@ class _AnchorTargetLayer(nn.Module):
         labels[max_ov >= cfg.TRAIN.RPN_POSITIVE_OVERLAP] = 1
         if cfg.TRAIN.RPN_CLOBBER_POSITIVES:
             labels[max_ov < cfg.TRAIN.RPN_NEGATIVE_OVERLAP] = 0
+        counts = torch.stack(((labels == 1).sum(1), (labels == 0).sum(1)), 1)       # [b, 2] int64
+        if dev.type == "cuda":
+            host = torch.empty((b, 2), dtype=torch.int64, pin_memory=True)
+            host.copy_(counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        else:
+            host, ev = counts, None
+        return ((H, W, gt_boxes.data_ptr()), gt_boxes, inds_inside, anchors, argmax_ov, labels, host, ev,
+                all_anchors.size(0))
 
-        # ---- subsampling on the host: one D2H + one H2D, reference RNG call order ----------
+    def begin(self, gt_boxes, im_info, H, W):
+        """called by the detector before the backbone is enqueued (see prepare)"""
+        self._pending = self.prepare(gt_boxes, im_info, H, W)
+
+    def finish(self, pending):
+        (H, W, _), gt_boxes, inds_inside, anchors, argmax_ov, labels, host, ev, total = pending
+        b, n_in = labels.shape
+        A = self._num_anchors
+        dev = gt_boxes.device
+        # ---- subsampling: the reference's NumPy global-RNG call sequence (index parity), driven by the two
+        # counts per image; WHICH anchors the drawn positions denote is resolved on the device ----------
+        if ev is not None:
+            ev.synchronize()
+        cnt = host.numpy()
         num_fg = int(cfg.TRAIN.RPN_FG_FRACTION * cfg.TRAIN.RPN_BATCHSIZE)
-        lab = labels.cpu().numpy()
-        sum_bg = (lab == 0).sum(1)
+        dis_fg, dis_bg, n_fg_after, n_bg_after = [], [], [], []
         for i in range(b):
-            fg = np.nonzero(lab[i] == 1)[0]
-            if fg.size > num_fg:
-                perm = np.random.permutation(fg.size)
-                lab[i, fg[perm[:fg.size - num_fg]]] = -1
-            num_bg = cfg.TRAIN.RPN_BATCHSIZE - int((lab[i] == 1).sum())
-            if sum_bg[i] > num_bg:
-                bg = np.nonzero(lab[i] == 0)[0]
-                perm = np.random.permutation(bg.size)
-                lab[i, bg[perm[:bg.size - num_bg]]] = -1
+            n_f, n_b = int(cnt[i, 0]), int(cnt[i, 1])
+            d = np.empty((0,), np.int64)
+            if n_f > num_fg:
+                d = np.random.permutation(n_f)[:n_f - num_fg]
+            dis_fg.append(d)
+            n_f = min(n_f, num_fg)
+            num_bg = cfg.TRAIN.RPN_BATCHSIZE - n_f
+            d = np.empty((0,), np.int64)
+            if n_b > num_bg:
+                d = np.random.permutation(n_b)[:n_b - num_bg]
+            dis_bg.append(d)
+            n_fg_after.append(n_f)
+            n_bg_after.append(min(n_b, num_bg))
         # uniform example weighting; like the reference, the count comes from the LAST image
         assert cfg.TRAIN.RPN_POSITIVE_WEIGHT < 0
-        num_examples = int((lab[b - 1] >= 0).sum())
-        labels = torch.from_numpy(lab).to(dev)
+        num_examples = n_fg_after[b - 1] + n_bg_after[b - 1]
+
+        def disable(lab, want, drawn):
+            """lab[i, (want-th class member list)[drawn[i]]] = -1: the k-th member of a class in ascending
+            anchor order is found with a stable sort of the class mask (no data-dependent shapes)."""
+            m = max(d.size for d in drawn)
+            if m == 0:
+                return lab
+            pos = np.zeros((b, m), np.int64)
+            ok = np.zeros((b, m), np.bool_)
+            for i, d in enumerate(drawn):
+                pos[i, :d.size] = d
+                ok[i, :d.size] = True
+            pos_t = torch.from_numpy(pos).to(dev, non_blocking=True)
+            ok_t = torch.from_numpy(ok).to(dev, non_blocking=True)
+            members = torch.sort((lab != want).to(torch.uint8), dim=1, stable=True)[1]      # class members first, ascending
+            idx = torch.gather(members, 1, pos_t)
+            # padding entries rewrite an already disabled slot: route them to column n_in (a scratch column)
+            idx = torch.where(ok_t, idx, torch.full_like(idx, n_in))
+            ext = torch.cat([lab, lab.new_zeros((b, 1))], 1)
+            ext.scatter_(1, idx, -1.0)
+            return ext[:, :n_in]
+
+        labels = disable(labels, 1, dis_fg)
+        labels = disable(labels, 0, dis_bg)
 
         gt_for_anchor = torch.gather(gt_boxes[:, :, :4], 1, argmax_ov.unsqueeze(2).expand(-1, -1, 4))
         targets = bbox_transform_batch(anchors, gt_for_anchor)            # [b, n_in, 4]
@@ -283,28 +349,44 @@ class _ProposalTargetLayer(nn.Module):
         max_ov, assign = overlaps.max(2)
         labels = torch.gather(gt_boxes[:, :, 4], 1, assign)
 
-        mo = max_ov.cpu().numpy()                       # the one D2H of this layer
-        keep = np.zeros((b, P), np.int64)
+        # ---- sampling: the host needs only the two class sizes per image to make the reference's RNG calls
+        # (index parity); which RoIs the drawn positions denote is resolved on the device -------------
+        fg_mask = max_ov >= cfg.TRAIN.FG_THRESH
+        bg_mask = (max_ov < cfg.TRAIN.BG_THRESH_HI) & (max_ov >= cfg.TRAIN.BG_THRESH_LO)
+        counts = torch.stack((fg_mask.sum(1), bg_mask.sum(1)), 1)
+        host = torch.empty((b, 2), dtype=torch.int64, pin_memory=True) if dev.type == "cuda" else None
+        if host is not None:
+            host.copy_(counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+        # (enqueued while the counts travel) class member lists in ascending RoI order
+        fg_members = torch.sort((~fg_mask).to(torch.uint8), dim=1, stable=True)[1]
+        bg_members = torch.sort((~bg_mask).to(torch.uint8), dim=1, stable=True)[1]
+        if host is not None:
+            ev.synchronize()
+            cnt = host.numpy()
+        else:
+            cnt = counts.numpy()
+        pos = np.zeros((b, P), np.int64)
         n_fg = np.zeros((b,), np.int64)
         for i in range(b):
-            fg = np.nonzero(mo[i] >= cfg.TRAIN.FG_THRESH)[0]
-            bg = np.nonzero((mo[i] < cfg.TRAIN.BG_THRESH_HI) & (mo[i] >= cfg.TRAIN.BG_THRESH_LO))[0]
-            if fg.size > 0 and bg.size > 0:
-                k = min(fg_per_image, fg.size)
-                fg = fg[np.random.permutation(fg.size)[:k]]
-                bg = bg[np.floor(np.random.rand(P - k) * bg.size).astype(np.int64)]
-            elif fg.size > 0:
-                fg = fg[np.floor(np.random.rand(P) * fg.size).astype(np.int64)]
-                bg, k = fg[:0], P
-            elif bg.size > 0:
-                bg = bg[np.floor(np.random.rand(P) * bg.size).astype(np.int64)]
-                fg, k = bg[:0], 0
+            n_f, n_b = int(cnt[i, 0]), int(cnt[i, 1])
+            if n_f > 0 and n_b > 0:
+                k = min(fg_per_image, n_f)
+                pos[i, :k] = np.random.permutation(n_f)[:k]
+                pos[i, k:] = np.floor(np.random.rand(P - k) * n_b).astype(np.int64)
+            elif n_f > 0:
+                pos[i] = np.floor(np.random.rand(P) * n_f).astype(np.int64)
+                k = P
+            elif n_b > 0:
+                pos[i] = np.floor(np.random.rand(P) * n_b).astype(np.int64)
+                k = 0
             else:
                 raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
-            keep[i] = np.concatenate([fg, bg])
             n_fg[i] = k
-        keep_t = torch.from_numpy(keep).to(dev)
-        is_fg = torch.arange(P, device=dev).unsqueeze(0) < torch.from_numpy(n_fg).to(dev).unsqueeze(1)
+        pos_t = torch.from_numpy(pos).to(dev, non_blocking=True)
+        is_fg = torch.arange(P, device=dev).unsqueeze(0) < torch.from_numpy(n_fg).to(dev, non_blocking=True).unsqueeze(1)
+        keep_t = torch.where(is_fg, torch.gather(fg_members, 1, pos_t), torch.gather(bg_members, 1, pos_t))
 
         labels_b = torch.gather(labels, 1, keep_t) * is_fg.to(dt)
         rois_b = torch.gather(all_rois, 1, keep_t.unsqueeze(2).expand(-1, -1, 5)).clone()

@@ -35,15 +35,15 @@ int ait_abi_version(void);
 const char* ait_strerror(int code);
 
 /* ---------------------------------------------------------------------------------------
- * Measurement (bench.py's live roofline; no reference counterpart).  While a probe is ATTACHED to the
- * calling thread, the GEMM and RoIAlign entry points -- however they are reached, directly or from
+ * Measurement (bench.py's live roofline; no reference counterpart).  While a probe is ATTACHED, the GEMM and RoIAlign entry points -- however they are reached, directly or from
  * inside ait_transformer_* -- bracket their launches with a HIP event pair on the launch stream and
  * note the launch's algorithmic work: kind AIT_PROBE_GEMM: flops = 2*M*N*K, dims = {M, N, K, trans_a,
  * trans_b, splits}; AIT_PROBE_ROI_FWD / _BWD: algorithmic bytes (feature once + RoIs + pooled
  * tensor once), dims = {n_rois, B, C, H, W, 0}.  The probe owns its events (created by
  * ait_probe_create, at most `capacity` launches are recorded); ait_probe_get reports a launch's elapsed
- * milliseconds once the stream has been synchronised.  Attach state is per thread; with no probe
- * attached (the default) the entry points do nothing extra.
+ * milliseconds once the stream has been synchronised.  The attached probe is process-wide (PyTorch runs
+ * backward passes on its autograd engine's threads); with no probe attached (the default) the entry
+ * points do nothing extra.
  * ------------------------------------------------------------------------------------- */
 #define AIT_PROBE_GEMM 1
 #define AIT_PROBE_ROI_FWD 2
@@ -159,6 +159,35 @@ int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, con
                  int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
                  const float* residual, int flags, int split_k, int c_colblk,
                  long long c_batch_stride, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Convolutions over CHANNELS-LAST maps as implicit GEMMs on the same matrix-core kernel (no im2col buffer).
+ * Replace the ATen / cuDNN convolution calls (forward, data gradient, weight gradient) behind the 3x3
+ * convolutions of RCNN_top = ResNet layer4 applied to the AIT output
+ *   (lib/model/faster_rcnn/resnet_sys_transformer_sk_dilat.py:85-111 Bottleneck.conv2, :482-491 _head_to_tail).
+ *   x   [n*in_h*in_w, cin]   row (image, y, x) of a channels-last map, row pitch ldx
+ *   y   [n*out_h*out_w, cout], dy likewise; dx like x
+ *   w   [cout][kh][kw][cin]  (= the channels-last memory of a PyTorch conv weight [cout, cin, kh, kw]); dw likewise
+ *   y  = conv(x, w) (+ bias[cout]) (+ residual, same addressing as y) (ReLU with AIT_GEMM_RELU)
+ *   dx = conv_transpose(dy, w) (+ residual, or gated by residual > 0 with AIT_GEMM_MASK_POS)
+ *   dw += dy^T (*) x     ACCUMULATED (split-K partial sums combined with fp32 atomics; caller zero-fills)
+ *   zeros: caller-owned device buffer of >= max(cin, cout) + 144 floats that holds zeros (what a window
+ *          position outside the map reads).
+ * Requirements (else AIT_EUNSUPPORTED): the map the GEMM rows run over (out_h x out_w for forward / weight
+ * gradient, in_h x in_w for the data gradient) has power-of-two width and area; stride a power of two;
+ * cin % 16 == 0 (forward), cout % 16 == 0 (data gradient), cin % 128 == 0 and rows % 16 == 0 (weight gradient).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  int n, in_h, in_w, out_h, out_w, kh, kw, stride, pad;
+} ait_conv_geom;
+int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_conv_geom* geom, int cin, int cout,
+                     const float* bias, const float* residual, int flags, float* y, int ldy, const float* zeros,
+                     size_t zeros_floats, void* stream);
+int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, const ait_conv_geom* geom, int cin, int cout,
+                          const float* residual, int flags, float* dx, int lddx, const float* zeros,
+                          size_t zeros_floats, void* stream);
+int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, int ldx, const ait_conv_geom* geom, int cin,
+                            int cout, float* dw, int split_k, const float* zeros, size_t zeros_floats, void* stream);
 
 /* bf16 matrix-core variant (BASELINE cfg 5): identical interface, layouts and epilogues; A and B
  * stay fp32 in memory, are rounded to bf16 (RNE) while being staged into LDS, multiplied on

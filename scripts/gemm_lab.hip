@@ -40,6 +40,8 @@ using OldD4 = ait_gemm_old::Cfg<256, 128, 16, 2, 2, 2, 6 + 256>;
 #endif
 
 #define LAB_RES (1 << 20)      // lab-only flag: pass a residual operand
+#define LAB_ALIAS_A (1 << 21)
+#define LAB_ALIAS_B (1 << 22)
 struct Shape {
   const char* name;
   int M, N, K, ta, tb, sk, flags;   // flags: AIT_GEMM_RELU (with a bias) | AIT_GEMM_ATOMIC is implied by sk > 1
@@ -61,6 +63,12 @@ static const Shape SHAPES[] = {
     {"dhmsk NN", 76800, 2048, 512, 0, 0, 1, LAB_RES | AIT_GEMM_MASK_POS},  // dgrad gated by the saved ReLU
     {"fc    NT", 76800, 512, 64, 0, 1, 1, 0},                              // K = 64: four slabs per tile
     {"trans NT", 76800, 1024, 512, 0, 1, 1, AIT_GEMM_RELU},                // dec_trans shape (+ bias)
+    // timing-only experiments (results meaningless): operand rows aliased onto one row (row pitch 0), so that
+    // the loads are served from L1 / L2 whatever the tile -- what the kernel does with the memory system taken away
+    {"qkv aA NT", 76800, 1536, 512, 0, 1, 1, LAB_ALIAS_A},
+    {"qkv aB NT", 76800, 1536, 512, 0, 1, 1, LAB_ALIAS_B},
+    {"qkv aAB  ", 76800, 1536, 512, 0, 1, 1, LAB_ALIAS_A | LAB_ALIAS_B},
+    {"ffn2 aAB ", 76800, 512, 2048, 0, 1, 1, LAB_ALIAS_A | LAB_ALIAS_B},
 };
 static const int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 
@@ -97,11 +105,13 @@ static void setup(Problem& p, const Shape& s) {
   CK(hipMemset(p.C, 0, nc * 4)); CK(hipMemset(p.C2, 0, nc * 4));
   CK(hipDeviceSynchronize());
   const int lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
-  const int flags = (s.flags & ~LAB_RES) | (s.sk > 1 ? AIT_GEMM_ATOMIC : 0);
+  const int flags = (s.flags & ~(LAB_RES | LAB_ALIAS_A | LAB_ALIAS_B)) | (s.sk > 1 ? AIT_GEMM_ATOMIC : 0);
   int rc = make_args(s.ta, s.tb, s.M, s.N, s.K, 1.f, p.A, lda, p.B, ldb, p.C, s.N,
                      (s.flags & AIT_GEMM_RELU) ? p.bias : nullptr, (s.flags & LAB_RES) ? p.res : nullptr, flags, s.sk, 0,
                      0, 16, p.g);
   if (rc) { printf("make_args rc %d\n", rc); exit(1); }
+  if (s.flags & LAB_ALIAS_A) p.g.lda = 0;
+  if (s.flags & LAB_ALIAS_B) p.g.ldb = 0;
 }
 static void teardown(Problem& p) {
   hipFree(p.A); hipFree(p.B); hipFree(p.C); hipFree(p.C2); hipFree(p.bias); hipFree(p.res); hipFree(p.probe);

@@ -9,7 +9,7 @@ for f in glob.glob(sys.argv[1] + "/*/*counter_collection.csv"):
         if not m or k.startswith("void at::") or "at::native" in k or "rocprim" in k:
             continue
         name = m.group(1) or m.group(2)
-        if name == "gemm_f32_kernel":
+        if name.startswith("gemm_f32_"):
             name += "[grid=%s]" % r["Grid_Size"]
         a = agg[name][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"]); a[1] += 1

@@ -4,7 +4,7 @@ import collections, csv, sys
 steps = float(sys.argv[2])
 rows = list(csv.reader(l for l in open(sys.argv[1]) if not l.startswith('#')))[1:]
 def c(n):
-    if 'gemm_f32_kernel' in n or 'gemm_bf16_kernel' in n: return 'ait_gemm'
+    if 'gemm_f32_' in n or 'gemm_bf16_kernel' in n: return 'ait_gemm'
     if 'Sp3AsmConv' in n: return 'miopen winograd'
     if n.startswith('igemm_'): return 'miopen ' + n[:9]
     if 'bwd_weight' in n or n.startswith('_ZN2ck'): return 'miopen ck'
@@ -14,7 +14,7 @@ def c(n):
     if 'naive_conv' in n or 'miopen' in n.lower() or 'gridwise' in n.lower(): return 'miopen other'
     if 'at::native' in n or 'rocprim' in n or 'at::cuda' in n: return 'torch elementwise / reduce / index'
     if 'anonymous' in n:
-        for k in ('roi_align', 'attn', 'bn_act', 'ln_', 'sh_', 'nms', 'sk_'):
+        for k in ('roi_align', 'attn', 'bn_act', 'ln_', 'sh_', 'nms', 'sk_', 'colsum', 'rep_sum'):
             if k in n: return 'ait ' + k.strip('_')
         return 'ait other'
     return 'other: ' + n[:50]

@@ -6,7 +6,7 @@ d, warmup, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 min_gap = float(sys.argv[4]) if len(sys.argv) > 4 else 15.0
 f = (glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[0]
 rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f)))
-gi = [i for i, r in enumerate(rows) if "gemm_f32_kernel" in r[2]]
+gi = [i for i, r in enumerate(rows) if "gemm_f32_" in r[2]]
 per = len(gi) // (warmup + steps)
 region = rows[gi[warmup * per]:]
 short = lambda k: k.replace("(anonymous namespace)::", "").replace("void ", "").replace("at::native::", "")[:70]

@@ -12,7 +12,7 @@ rows = []
 for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-gemm_idx = [i for i, r in enumerate(rows) if "gemm_f32_kernel" in r[2]]
+gemm_idx = [i for i, r in enumerate(rows) if "gemm_f32_" in r[2]]
 per_step = len(gemm_idx) // (warmup + steps)
 start = gemm_idx[warmup * per_step]
 region = rows[start:]

@@ -66,8 +66,9 @@ WORKER = textwrap.dedent("""
         dist.all_gather(mine, alone[k])
         mean = (mine[0] + mine[1]) / world
         rel = float((got[k] - mean).norm() / (mean.norm() + 1e-20))
-        # (MIOpen's split-K weight-gradient kernels use atomics: two runs differ in the last bits)
-        assert rel < 1e-4, (k, rel)
+        # (split-K weight-gradient kernels -- MIOpen's and this library's -- sum with atomics: two runs of the
+        # same step differ by ~1e-4 relative; gradients of DIFFERENT shards differ by O(1))
+        assert rel < 1e-3, (k, rel)
         assert float((mine[0] - mine[1]).norm()) > 0, "shards were not different: " + k
     t = D.max_over_ranks(1.0 + rank, dev)
     assert t == 2.0

@@ -303,3 +303,81 @@ def test_nms_fuzz_bit_exact_vs_oracle():
     for b in range(4):
         ref = native.nms(bx[b], sc, 0.7)[:300]
         assert int(cnt[b]) == len(ref) and np.array_equal(keep[b, :len(ref)].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("n,cin,cout,hw,k,stride,pad", [
+    (37, 512, 512, 4, 3, 1, 1),      # layer4.conv2 on the proposal tail (4x4 maps); 592 rows: 128x128 tiles
+    (300, 256, 128, 4, 3, 1, 1),     # 4800 rows: both tile shapes' edges
+    (40, 128, 64, 8, 3, 2, 1),       # stride 2: 8x8 -> 4x4 (the SK block's window geometry)
+    (16, 128, 256, 2, 1, 1, 0),      # 1x1 on 2x2 maps (degenerate window)
+    (1300, 512, 512, 4, 3, 1, 1),    # 20800 rows: 256x128 tiles (>= 512 of them in the data gradient)
+])
+def test_implicit_gemm_convolutions_vs_torch(n, cin, cout, hw, k, stride, pad):
+    """ait_conv_fwd_f32 / ait_conv_bwd_data_f32 / ait_conv_bwd_weight_f32 (channels-last implicit GEMMs, no
+    im2col) against torch's convolution in float64: forward with bias + residual + ReLU, both gradients."""
+    from ait_amd import ops
+    torch.manual_seed(n + cin + hw)
+    oh = (hw + 2 * pad - k) // stride + 1
+    x = torch.randn(n, cin, hw, hw, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, k, k, device="cuda") * (1.0 / (cin * k * k) ** 0.5)).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(cout, device="cuda")
+    res = torch.randn(n * oh * oh, cout, device="cuda")
+    xm = x.permute(0, 2, 3, 1).reshape(n * hw * hw, cin)
+    wm = w.permute(0, 2, 3, 1).contiguous()
+    geom = ops.conv_geom(n, (hw, hw), (oh, oh), (k, k), stride, pad)
+    assert ops.conv_supported((hw, hw), (oh, oh), stride, cin, cout)
+    y = ops.conv_fwd(xm, wm, geom, bias=bias, residual=res, relu=True)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), stride, pad)
+    ref = torch.relu(ref.permute(0, 2, 3, 1).reshape(-1, cout) + res.double())
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+    y0 = ops.conv_fwd(xm, wm, geom)
+    ref0 = torch.nn.functional.conv2d(x.double(), w.double(), None, stride, pad).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert float((y0.double() - ref0).abs().max()) <= 2e-5 * float(ref0.abs().max()) + 1e-6
+    # gradients
+    dy = torch.randn(n * oh * oh, cout, device="cuda")
+    dyn = dy.view(n, oh, oh, cout).permute(0, 3, 1, 2).double()
+    dx_ref = torch.nn.grad.conv2d_input((n, cin, hw, hw), w.double(), dyn, stride, pad).permute(0, 2, 3, 1).reshape(-1, cin)
+    dx = ops.conv_bwd_data(dy, wm, geom)
+    assert float((dx.double() - dx_ref).abs().max()) <= 2e-5 * float(dx_ref.abs().max()) + 1e-6
+    gate = torch.randn(n * hw * hw, cin, device="cuda")
+    dxm = ops.conv_bwd_data(dy, wm, geom, residual=gate, mask_pos=True)
+    assert float((dxm.double() - dx_ref * (gate > 0)).abs().max()) <= 2e-5 * float(dx_ref.abs().max()) + 1e-6
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), dyn, stride, pad).permute(0, 2, 3, 1)
+    dw = ops.conv_bwd_weight(dy, xm, geom, k, k, split_k=8)
+    assert float((dw.double() - dw_ref).abs().max()) <= 5e-5 * float(dw_ref.abs().max()) + 1e-6
+
+
+def test_layer4_block_on_hip_convolutions_matches_miopen():
+    """Bottleneck of RCNN_top with its convolutions on the library's kernels (1x1 as GEMMs, 3x3 as implicit
+    GEMMs, frozen BN / residual / ReLU in the epilogues) against the same block on MIOpen + bn_act: outputs
+    and every gradient."""
+    import ait_amd.faster_rcnn as fr
+    torch.manual_seed(3)
+    blk = fr.Bottleneck(2048, 512).cuda()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+            m.weight.requires_grad_(False)
+            m.bias.requires_grad_(False)
+    blk.eval().to(memory_format=torch.channels_last)
+    x0 = torch.randn(300, 2048, 4, 4, device="cuda").contiguous(memory_format=torch.channels_last)
+    cot = torch.randn(300, 2048, 4, 4, device="cuda").contiguous(memory_format=torch.channels_last)
+    outs = {}
+    for hip in (False, True):
+        blk._ait_hip = hip
+        blk.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        y = blk(x)
+        y.backward(cot)
+        outs[hip] = (y.detach(), x.grad, {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None})
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    assert rel(outs[True][0], outs[False][0]) < 1e-5
+    # (three ReLU masks between output and input: pre-activations within rounding of 0 flip their mask bit
+    # between two implementations -- DESIGN.md 4, item 3 -- so the gradients agree to ~3e-4, not 1e-5)
+    assert rel(outs[True][1], outs[False][1]) < 1e-3
+    assert set(outs[True][2]) == set(outs[False][2]) == {"conv1.weight", "conv2.weight", "conv3.weight"}
+    for k in outs[False][2]:
+        assert rel(outs[True][2][k], outs[False][2][k]) < 1e-3, k

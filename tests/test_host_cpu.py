@@ -48,3 +48,35 @@ def test_product_refuses_cpu_tensors():
     from ait_amd import _lib
     with pytest.raises(_lib.AitHipError):
         _lib.dev_ptr(torch.zeros(4))
+
+
+def test_samplers_index_parity_on_cpu_tensors(golden):
+    """The two training samplers (rpn/anchor_target_layer.py:128-175, rpn/proposal_target_layer_cascade.py:
+    148-190) are host logic over tensor ops: on CPU tensors they must reproduce the reference's sampled
+    indices under its NumPy RNG call order exactly as on the GPU (goldens g7 / g8)."""
+    from oracle import cases
+    from oracle.digest import compare
+    from ait_amd.config import cfg
+    from ait_amd.rpn import _AnchorTargetLayer, _ProposalTargetLayer
+    g = golden("g8_target_layers")
+    prob, deltas, info = cases.rpn_case()
+    gt, nb = torch.from_numpy(cases.gt_case()), torch.tensor([3, 3])
+    np.random.seed(3)
+    labels, targets, w_in, w_out = _AnchorTargetLayer(16, [8, 16, 32], [0.5, 1, 2])(
+        (torch.from_numpy(prob), gt, torch.from_numpy(info), nb))
+    assert np.array_equal(labels.numpy().astype(np.int8), g["atl_labels"])
+    for name, t in (("atl_targets", targets), ("atl_w_in", w_in), ("atl_w_out", w_out)):
+        ok, msg = compare(name, t.contiguous(), g, 1e-5, 1e-5)
+        assert ok, msg
+    rois = torch.from_numpy(golden("g7_proposal_layer")["rois_TRAIN"])
+    saved = cfg.TRAIN.BATCH_SIZE
+    try:
+        for P in (128, 300):
+            cfg.TRAIN.BATCH_SIZE = P
+            r, lab, tg, wi, wo = _ProposalTargetLayer(2)(rois, gt, nb)
+            assert np.array_equal(r.numpy(), g["ptl%d_rois" % P])
+            assert np.array_equal(lab.numpy(), g["ptl%d_labels" % P])
+            np.testing.assert_allclose(tg.numpy(), g["ptl%d_targets" % P], rtol=1e-5, atol=1e-5)
+            assert np.array_equal(wi.numpy(), g["ptl%d_w_in" % P])
+    finally:
+        cfg.TRAIN.BATCH_SIZE = saved

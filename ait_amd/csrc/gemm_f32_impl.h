@@ -69,6 +69,8 @@ struct GemmArgs {
   int splits;
   unsigned long long* probe;   // diagnostic stamps (scripts/gemm_lab.hip); NULL in the product
   ConvGeom conv;               // CONV != 0 kernels only
+  int batch;                   // register-staged kernels: independent problems along gridDim.y ...
+  long long sA, sB, sC;        // ... whose operands are this many floats apart
 };
 
 enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
@@ -688,8 +690,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
 // Register-staged kernels (MODE_DB / MODE_RING): one workgroup per work item.
 // =========================================================================================================
 template <class C, bool AK, bool BKC, int EPI>
-__global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs g_in) {
   static_assert(C::MODE != MODE_DLDS, "the direct-to-LDS tiles run gemm_f32_stream_kernel");
+  GemmArgs g = g_in;
+  if (g.batch > 1) {             // batched launch: problem blockIdx.y
+    g.A += (size_t)blockIdx.y * g.sA;
+    g.B += (size_t)blockIdx.y * g.sB;
+    g.C += (size_t)blockIdx.y * g.sC;
+    if (g.residual) g.residual += (size_t)blockIdx.y * g.sC;
+  }
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* As = lds;                              // [NBUF][BK][PA]
@@ -894,7 +903,8 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
   if constexpr (C::MODE == MODE_DLDS)
     hipLaunchKernelGGL((gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV>), dim3(blocks), dim3(C::NT), C::LDS, s, g);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<C, AK, BKC, EPI>), dim3(blocks), dim3(C::NT), C::LDS, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<C, AK, BKC, EPI>), dim3(blocks, g.batch > 1 ? g.batch : 1), dim3(C::NT), C::LDS,
+                       s, g);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }
@@ -928,8 +938,11 @@ inline int make_args(int trans_a, int trans_b, int M, int N, int K, float alpha,
   if (!C || (K > 0 && (!A || !B))) return AIT_EINVAL;     // (K == 0 never reads A or B)
   // float4 staging: row pitches and bases 16-B aligned; K % 4 only matters for an operand whose
   // reduction dimension is the contiguous one
+  // (K % 4 != 0 with a K-contiguous A and a K-outer B: the last 16-byte load of an A row runs into the
+  // row's padding -- lda >= K rounded up to 4, padding FINITE -- and meets rows of B that read as zero)
+  const bool k_tail_ok = !(K & 3) || (trans_a && !trans_b) || (!trans_a && !trans_b && lda >= ((K + 3) & ~3));
   if ((lda & 3) || (ldb & 3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
-      (reinterpret_cast<uintptr_t>(B) & 15) || ((K & 3) && (!trans_a || trans_b)))
+      (reinterpret_cast<uintptr_t>(B) & 15) || !k_tail_ok)
     return AIT_EUNSUPPORTED;
   if (split_k < 1) split_k = 1;
   if (split_k > 1 && !(flags & AIT_GEMM_ATOMIC)) return AIT_EINVAL;
@@ -941,6 +954,7 @@ inline int make_args(int trans_a, int trans_b, int M, int N, int K, float alpha,
   g.c_colblk = c_colblk; g.c_batch = c_batch_stride; g.alpha = alpha; g.flags = flags;
   g.probe = nullptr;
   g.conv = ConvGeom{};
+  g.batch = 1; g.sA = g.sB = g.sC = 0;
   // 32-bit element offsets in the epilogue
   {
     const unsigned long long rows = (unsigned long long)(M > 0 ? M - 1 : 0) * (unsigned long long)(ldc > 0 ? ldc : 0);

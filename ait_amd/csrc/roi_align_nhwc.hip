@@ -199,6 +199,66 @@ __global__ __launch_bounds__(kThreads) void roi_align_nhwc_fwd_kernel(
   }
 }
 
+// Forward, channel-sliced (C % 1024 == 0... any C that is a multiple of 8 * 128 floats): workgroup = (RoI,
+// 128-channel slice); blocks b and b + 8 share an XCD, so slice = b % 8 pins ONE eighth of the channels to
+// every XCD: its L2 sees the feature slice of one image (H*W*512 B = 1.2 MB at 38x63) while the RoIs of that
+// image stream by in order -- the feature is fetched from HBM once instead of once per overlapping RoI
+// (round 1: 10-21x re-fetch with whole-C workgroups spread over all XCDs).  Eight groups of 32 lanes: group
+// ph < PH owns bin row ph, a lane 4 channels and the PW accumulators of its row.
+__global__ __launch_bounds__(kThreads) void roi_align_nhwc_fwd_sliced_kernel(
+    const float* __restrict__ feat, const float* __restrict__ rois, int n_rois, int B, int C, int H, int W,
+    int PH, const float* __restrict__ wf, const int* __restrict__ wi, float* __restrict__ out) {
+  constexpr int PW = kPW;
+  const int slice = blockIdx.x % AIT_NXCD, n = blockIdx.x / AIT_NXCD;
+  if (n >= n_rois) return;
+  const int C4 = C >> 2, S4 = C4 / AIT_NXCD;             // float4 per slice (32 for C = 1024)
+  const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
+  const int* __restrict__ ti = wi + (size_t)n * tab_ints(PH, PW);
+  const int* lim = ti + 2 * PH + 2 * PW;
+  const int xmin = lim[2], xmax = lim[3];
+  const int b = (int)rois[5 * n];
+  const bool dead = xmax < xmin || b < 0 || b >= B;
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // wy[PH][H] | wx[PW][W]
+  float* s_wy = sm;
+  float* s_wx = sm + (size_t)PH * H;
+  const float* __restrict__ gw = wf + (size_t)n * tab_floats(H, W, PH, PW);
+  if (!dead) {
+    for (int i = threadIdx.x; i < PH * H + PW * W; i += kThreads) sm[i] = gw[i];
+  }
+  int bx_lo[PW], bx_hi[PW];
+#pragma unroll
+  for (int p = 0; p < PW; p++) {
+    bx_lo[p] = ti[2 * PH + 2 * p];
+    bx_hi[p] = ti[2 * PH + 2 * p + 1];
+  }
+  __syncthreads();
+  if (grp >= PH) return;
+  const int ph = grp;
+  const int ylo = ti[2 * ph], yhi = ti[2 * ph + 1];
+  float4* __restrict__ o = reinterpret_cast<float4*>(out) + ((size_t)n * PH + ph) * PW * C4 + slice * S4;
+  const float4* __restrict__ f0 = reinterpret_cast<const float4*>(feat) + (size_t)(dead ? 0 : b) * H * W * C4 + slice * S4;
+  for (int c4 = l; c4 < S4; c4 += 32) {
+    float4 acc[PW];
+#pragma unroll
+    for (int p = 0; p < PW; p++) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!dead) {
+      for (int y = ylo; y <= yhi; y++) {
+        const float wyv = s_wy[ph * H + y];
+        if (wyv == 0.f) continue;
+        const float4* __restrict__ frow = f0 + (size_t)y * W * C4 + c4;
+#pragma unroll
+        for (int p = 0; p < PW; p++) {
+          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int x = bx_lo[p]; x <= bx_hi[p]; x++) t = fma4(s_wx[p * W + x], frow[(size_t)x * C4], t);
+          acc[p] = fma4(wyv, t, acc[p]);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PW; p++) o[(size_t)p * C4 + c4] = acc[p];
+  }
+}
+
 // Backward: workgroup = one feature cell.  The RoIs are scanned in chunks of 256 (one per lane);
 // the covering ones are compacted IN ROI ORDER into LDS together with their 2*PW weights for this
 // cell, then every lane accumulates its 4 channels over that list.
@@ -324,13 +384,18 @@ AIT_API int ait_roi_align_nhwc_fwd(const float* feat, const float* rois, int n_r
                              workspace_bytes, wf, wi, s);
   if (rc != AIT_OK) return rc;
   const size_t lds = sizeof(float) * ((size_t)H + (size_t)PW * W);
+  const size_t lds_sliced = sizeof(float) * ((size_t)PH * H + (size_t)PW * W);
   if (lds > 60 * 1024) return AIT_EUNSUPPORTED;
   {
     // algorithmic bytes: the feature read once, the RoIs, the pooled tensor written once
     AitProbeScope probe(AIT_PROBE_ROI_FWD, 4.0 * ((double)B * C * H * W + 5.0 * n_rois + (double)n_rois * PH * PW * C), s,
                         n_rois, B, C, H, W);
-    hipLaunchKernelGGL(roi_align_nhwc_fwd_kernel, dim3(chunked_grid((long long)n_rois * PH)), dim3(kThreads),
-                       lds, s, feat, rois, n_rois, B, C, H, W, PH, wf, wi, out);
+    if (C % (4 * AIT_NXCD * 4) == 0 && lds_sliced <= 60 * 1024 && PH <= kThreads / 32)
+      hipLaunchKernelGGL(roi_align_nhwc_fwd_sliced_kernel, dim3((unsigned)n_rois * AIT_NXCD), dim3(kThreads),
+                         lds_sliced, s, feat, rois, n_rois, B, C, H, W, PH, wf, wi, out);
+    else
+      hipLaunchKernelGGL(roi_align_nhwc_fwd_kernel, dim3(chunked_grid((long long)n_rois * PH)), dim3(kThreads),
+                         lds, s, feat, rois, n_rois, B, C, H, W, PH, wf, wi, out);
   }
   AIT_CHECK_LAUNCH();
   return AIT_OK;

@@ -157,6 +157,34 @@ class CoAttentionModule(nn.Module):
         return non_img, non_qry
 
 
+class _Bmm(torch.autograd.Function):
+    """Batched C = alpha * op(A) op(B) on the matrix cores (one launch per product, forward and backward)."""
+
+    @staticmethod
+    def forward(ctx, a, b, trans_a, trans_b, alpha):
+        ctx.save_for_backward(a, b)
+        ctx.cfg = (trans_a, trans_b, alpha)
+        return ops.bgemm(a, b, trans_a, trans_b, alpha)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        ta, tb, alpha = ctx.cfg
+        da = db = None
+        if not ta and tb:            # C = A B^T
+            da = ops.bgemm(dc, b, False, False, alpha) if ctx.needs_input_grad[0] else None     # dC B
+            db = ops.bgemm(dc, a, True, False, alpha) if ctx.needs_input_grad[1] else None      # dC^T A
+        elif not ta and not tb:      # C = A B
+            da = ops.bgemm(dc, b, False, True, alpha) if ctx.needs_input_grad[0] else None      # dC B^T
+            db = ops.bgemm(a, dc, True, False, alpha) if ctx.needs_input_grad[1] else None      # A^T dC
+        elif ta and not tb:          # C = A^T B
+            da = ops.bgemm(b, dc, False, True, alpha) if ctx.needs_input_grad[0] else None      # B dC^T
+            db = ops.bgemm(a, dc, False, False, alpha) if ctx.needs_input_grad[1] else None     # A dC
+        else:
+            raise NotImplementedError
+        return da, db, None, None, None
+
+
 class CoAttention(nn.Module):
     """Non-local image <-> query co-attention of the COCO variant
     (lib/model/modules/blocks_coatt_transformer_sk.py:17-122, 'division' normalisation,
@@ -180,7 +208,35 @@ class CoAttention(nn.Module):
                 nn.init.constant_(m.weight, 0)
                 nn.init.constant_(m.bias, 0)
 
+    def _forward_hip(self, x_img, x_qry):
+        """Token-major on the library's kernels: the five 1x1 embeddings as GEMMs over the channels-last
+        token rows, the three non-local products as batched GEMMs (ait_gemm_f32_batched).  The 'division'
+        normalisation is the products' alpha; GroupNorm and the residual stay on torch."""
+        bz, C, h_i, w_i = x_img.shape
+        _, _, h_q, w_q = x_qry.shape
+        ch, n_i, n_q = self.c_hidden, h_i * w_i, h_q * w_q
+        ti = x_img.permute(0, 2, 3, 1).reshape(bz * n_i, C)
+        tq = x_qry.permute(0, 2, 3, 1).reshape(bz * n_q, C)
+        lin = lambda conv, t: _Linear.apply(t, conv.weight.view(conv.out_channels, -1), conv.bias)
+        emb_img = lin(self.emb, ti).view(bz, n_i, ch)
+        emb_qry = lin(self.emb, tq).view(bz, n_q, ch)
+        rho_qry = lin(self.rho, tq).view(bz, n_q, ch)
+        phi_img = lin(self.phi, ti).view(bz, n_i, ch)                     # (tokens: the reference's [bz, ch, N_i] transposed)
+        rel = _Bmm.apply(rho_qry, phi_img, False, True, 1.0)              # [bz, N_q, N_i]
+        non_img_t = _Bmm.apply(rel, emb_qry, True, False, 1.0 / n_q)      # (rel^T / N_q) emb_qry  [bz, N_i, ch]
+        non_qry_t = _Bmm.apply(rel, emb_img, False, False, 1.0 / n_i)     # (rel / N_i) emb_img    [bz, N_q, ch]
+        om, th = self.omega[0], self.theta[0]
+        non_img = lin(th, non_img_t.reshape(bz * n_i, ch)).view(bz, h_i, w_i, C).permute(0, 3, 1, 2)
+        non_qry = lin(om, non_qry_t.reshape(bz * n_q, ch)).view(bz, h_q, w_q, C).permute(0, 3, 1, 2)
+        non_img, non_qry = self.theta[1](non_img), self.omega[1](non_qry)
+        if self.with_residual:
+            non_img, non_qry = non_img + x_img, non_qry + x_qry
+        return non_img, non_qry
+
     def forward(self, x_img, x_qry):
+        if (x_img.is_cuda and x_img.dtype == torch.float32 and self.normlization == 'division'
+                and os.environ.get("AIT_COATT_TORCH", "0") != "1"):
+            return self._forward_hip(x_img, x_qry)
         bz, _, h_i, w_i = x_img.shape
         _, _, h_q, w_q = x_qry.shape
         ch = self.c_hidden
@@ -212,6 +268,8 @@ class CoAttentionModuleCOCO(nn.Module):
                                        with_residual=True, normlization='division')
 
     def forward(self, x_img, x_qry):
+        if x_img.is_cuda:           # token-major kernels: channels-last features are taken as they are
+            return self.coattention(x_img, x_qry)
         return self.coattention(x_img.contiguous(), x_qry.contiguous())
 
 

@@ -82,6 +82,50 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, 
     return out
 
 
+def _pad4(n):
+    return (n + 3) & ~3
+
+
+def bmat(batch, rows, cols, device):
+    """zero-filled [batch, rows, cols] whose row pitch is a multiple of 4 floats (the layout bgemm operands
+    need when cols % 4 != 0: the 2394-token image side of the co-attention)"""
+    return torch.zeros((batch, rows, _pad4(cols)), dtype=torch.float32, device=device)[:, :, :cols]
+
+
+def bgemm(a, b, trans_a=False, trans_b=True, alpha=1.0, out=None, accumulate=False):
+    """Batched out[i] (op)= alpha * op(a[i]) @ op(b[i]) in ONE launch (ait_gemm_f32_batched).  a, b, out are
+    3-D with unit column stride, a row pitch that is a multiple of 4 and equal batch counts."""
+    bz = a.shape[0]
+    M, K = (a.shape[2], a.shape[1]) if trans_a else (a.shape[1], a.shape[2])
+    N = b.shape[1] if trans_b else b.shape[2]
+    Kb = b.shape[2] if trans_b else b.shape[1]
+    if K != Kb or b.shape[0] != bz:
+        raise ValueError("bgemm: operand shapes differ")
+
+    def ok(t):
+        return t.stride(2) == 1 and t.stride(1) % 4 == 0 and t.stride(1) >= t.shape[2] and t.stride(0) % 4 == 0
+    if not ok(a):
+        a2 = bmat(bz, a.shape[1], a.shape[2], a.device)
+        a2.copy_(a)
+        a = a2
+    if not ok(b):
+        b2 = bmat(bz, b.shape[1], b.shape[2], b.device)
+        b2.copy_(b)
+        b = b2
+    if out is None:
+        out = bmat(bz, M, N, a.device)
+    for t in (a, b, out):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise _lib.AitHipError("bgemm: float32 GPU tensors only (no CPU fallback)")
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().ait_gemm_f32_batched(
+            int(trans_a), int(trans_b), M, N, K, float(alpha), ctypes.c_void_p(a.data_ptr()), a.stride(1), a.stride(0),
+            ctypes.c_void_p(b.data_ptr()), b.stride(1), b.stride(0), ctypes.c_void_p(out.data_ptr()), out.stride(1),
+            out.stride(0), bz, _lib.GEMM_ACCUMULATE if accumulate else 0, _lib.cur_stream(a.device))
+    _lib.check(rc, "ait_gemm_f32_batched")
+    return out
+
+
 def gemm_relu_bwd(dy, w, act, out=None):
     """dh = (dy @ w) masked by act > 0   (dy [M,N], w [N,K] row-major, act [M,K])."""
     M, N = dy.shape

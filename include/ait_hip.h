@@ -160,6 +160,15 @@ int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, con
                  const float* residual, int flags, int split_k, int c_colblk,
                  long long c_batch_stride, void* stream);
 
+/* Batched form: `batch` independent products, operand b at base + b*stride (floats), one launch.  Replaces
+ * the three torch.matmul of the COCO variant's image-level co-attention
+ *   (lib/model/modules/blocks_coatt_transformer_sk.py:86-110) and their autograd backward.
+ * flags: 0 or AIT_GEMM_ACCUMULATE.  K % 4 != 0 is accepted for trans_a == 0 && trans_b == 0 when
+ * lda >= K rounded up to 4 and A's row padding holds finite values (the 2394-token image side). */
+int ait_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, int lda,
+                         long long stride_a, const float* B, int ldb, long long stride_b, float* C, int ldc,
+                         long long stride_c, int batch, int flags, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Convolutions over CHANNELS-LAST maps as implicit GEMMs on the same matrix-core kernel (no im2col buffer).
  * Replace the ATen / cuDNN convolution calls (forward, data gradient, weight gradient) behind the 3x3

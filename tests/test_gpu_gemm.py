@@ -216,3 +216,36 @@ def test_gemm_large_tile_direct_to_lds_epilogues():
     out = ops.gemm(wt, dec, bias=bch, bias_row=True, c_colblk=64, c_batch_stride=CH * 64, out_shape=(P, CH, 64))
     want = (dec.double() @ wt.double().t() + bch.double()).view(P, 64, CH).transpose(1, 2)
     assert torch.allclose(out.double(), want, **tol)
+
+
+def test_batched_gemm_layouts_and_autograd():
+    """ait_gemm_f32_batched on the COCO co-attention shapes (blocks_coatt_transformer_sk.py:86-110: 64 query
+    tokens x 2394 image tokens x 512 channels) against torch.bmm in float64, forward and through _Bmm's backward;
+    2394 % 4 != 0 exercises the padded row pitch."""
+    from ait_amd import ops
+    from ait_amd.faster_rcnn import _Bmm
+    torch.manual_seed(5)
+    bz, nq, ni, ch = 3, 64, 2394, 512
+    rho = torch.randn(bz, nq, ch, device="cuda", requires_grad=True)
+    phi = torch.randn(bz, ni, ch, device="cuda", requires_grad=True)
+    eq = torch.randn(bz, nq, ch, device="cuda", requires_grad=True)
+    ei = torch.randn(bz, ni, ch, device="cuda", requires_grad=True)
+    rel = _Bmm.apply(rho, phi, False, True, 1.0)
+    a = _Bmm.apply(rel, eq, True, False, 1.0 / nq)
+    b = _Bmm.apply(rel, ei, False, False, 1.0 / ni)
+    ca, cb = torch.randn_like(a), torch.randn_like(b)
+    g = torch.autograd.grad([a, b], [rho, phi, eq, ei], [ca, cb])
+    R, P, Q, I = (t.detach().double().requires_grad_(True) for t in (rho, phi, eq, ei))
+    rel_r = R @ P.transpose(1, 2)
+    a_r = rel_r.transpose(1, 2) @ Q / nq
+    b_r = rel_r @ I / ni
+    g_r = torch.autograd.grad([a_r, b_r], [R, P, Q, I], [ca.double(), cb.double()])
+    rel_err = lambda x, y: float((x.double() - y).norm() / y.norm())
+    assert tuple(rel.shape) == (bz, nq, ni) and rel.stride(1) % 4 == 0
+    assert rel_err(rel, rel_r) < 1e-6 and rel_err(a, a_r) < 1e-6 and rel_err(b, b_r) < 1e-6
+    for x, y in zip(g, g_r):
+        assert rel_err(x, y) < 2e-6
+    # accumulate into an existing output; a non-padded operand is re-laid-out, not misread
+    out = ops.bgemm(rho.detach(), phi.detach().contiguous(), False, True)
+    ops.bgemm(rho.detach(), phi.detach(), False, True, alpha=0.5, out=out, accumulate=True)
+    assert rel_err(out, 1.5 * rel_r) < 1e-6

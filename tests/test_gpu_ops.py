@@ -248,7 +248,9 @@ def test_roi_align_channels_last_fuzz_vs_oracle():
     from ait_amd.roi_layers import ROIAlign
     rs = np.random.RandomState(1234)
     for case in range(12):
-        B = int(rs.randint(1, 4)); C = int(rs.choice([4, 12, 64, 260, 1028])); H = int(rs.randint(3, 41)); W = int(rs.randint(3, 70))
+        # (C = 128 / 256 / 1024: the channel-sliced forward, one 128-channel-multiple slice per XCD)
+        B = int(rs.randint(1, 4)); C = int([4, 12, 64, 260, 1028, 128, 256, 1024, 128, 256, 64, 1024][case])
+        H = int(rs.randint(3, 41)); W = int(rs.randint(3, 70))
         n = int(rs.choice([1, 7, 255, 256, 257, 600])); sr = int(rs.choice([0, 0, 1, 3]))
         feat = rs.standard_normal((B, C, H, W)).astype(np.float32)
         x1 = rs.uniform(-40, W * 16, n); y1 = rs.uniform(-40, H * 16, n)

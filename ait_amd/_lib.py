@@ -39,7 +39,12 @@ SIGNATURES = {
     "ait_sk_sqsum_bwd": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _vp]),
     "ait_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
                           _i, ctypes.c_longlong, _vp]),
-    "ait_gemm_f32_batched": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _ll, _vp, _i, _ll, _vp, _i, _ll, _i, _i, _vp]),
+    "ait_gemm_f32_batched": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _ll, _ll, _vp, _i, _ll, _ll, _vp, _i, _ll, _ll, _i, _i,
+                                  _i, _i, _vp]),
+    "ait_softmax_rows_fwd": (_i, [_vp, _ll, _i, _ll, _f, _ull, _vp, _vp, _vp]),
+    "ait_softmax_rows_bwd": (_i, [_vp, _vp, _ll, _i, _ll, _f, _ull, _vp, _vp]),
+    "ait_sh_general_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ait_sh_general_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ait_conv_fwd_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "ait_conv_bwd_data_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "ait_conv_bwd_weight_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),

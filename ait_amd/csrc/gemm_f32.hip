@@ -78,24 +78,27 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   return dispatch<Tile128>(g, !trans_a, trans_b != 0, ait_stream(stream));
 }
 
-// Batched form: `batch` independent products C_b (op)= alpha * opA(A_b) . opB(B_b) whose operands are strideX
-// floats apart, one launch (gridDim.y = batch).  The image-level co-attention products of the COCO variant
+// Batched form: batch x batch2 independent products C_ij (op)= alpha * opA(A_ij) . opB(B_ij), operand (i, j) at
+// base + i*stride + j*stride2 floats, one launch (gridDim.y x gridDim.z).  The image-level co-attention products of the COCO variant
 // (lib/model/modules/blocks_coatt_transformer_sk.py:86-110: rel = rho(qry) . phi(img), i2q . emb(qry),
 // q2i . emb(img), three torch.matmul over the batch) and their backward.  Few-tile problems: the
 // register-staged tiles.
 AIT_API int ait_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, int lda,
-                                 long long stride_a, const float* B, int ldb, long long stride_b, float* C, int ldc,
-                                 long long stride_c, int batch, int flags, void* stream) {
-  if (batch < 0 || (flags & ~AIT_GEMM_ACCUMULATE)) return AIT_EINVAL;
-  if (batch == 0 || M == 0 || N == 0) return (M < 0 || N < 0 || K < 0) ? AIT_EINVAL : AIT_OK;
-  if (batch > 65535 || (stride_a & 3) || (stride_b & 3)) return AIT_EUNSUPPORTED;
+                                 long long stride_a, long long stride_a2, const float* B, int ldb, long long stride_b,
+                                 long long stride_b2, float* C, int ldc, long long stride_c, long long stride_c2,
+                                 int batch, int batch2, int flags, int split_k, void* stream) {
+  if (batch < 0 || batch2 < 0 || (flags & ~(AIT_GEMM_ACCUMULATE | AIT_GEMM_ATOMIC))) return AIT_EINVAL;
+  if (batch == 0 || batch2 == 0 || M == 0 || N == 0) return (M < 0 || N < 0 || K < 0) ? AIT_EINVAL : AIT_OK;
+  if (batch > 65535 || batch2 > 65535 || ((stride_a | stride_b | stride_a2 | stride_b2) & 3)) return AIT_EUNSUPPORTED;
   GemmArgs g;
-  const int rc = make_args(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, nullptr, flags, 1, 0, 0,
+  const int rc = make_args(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, nullptr, nullptr, flags, split_k, 0, 0,
                            Tile128::BK, g);
   if (rc != AIT_OK) return rc;
   g.batch = batch; g.sA = stride_a; g.sB = stride_b; g.sC = stride_c;
-  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * M * N * K * batch, ait_stream(stream), M, N, K, trans_a, trans_b, batch);
-  const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  g.batch2 = batch2; g.sA2 = stride_a2; g.sB2 = stride_b2; g.sC2 = stride_c2;
+  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * M * N * K * batch * batch2, ait_stream(stream), M, N, K, trans_a, trans_b,
+                      batch * batch2);
+  const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch * batch2 * g.splits;
   if (tiles128 < 128) return dispatch<Tile64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   return dispatch<Tile128>(g, !trans_a, trans_b != 0, ait_stream(stream));
 }

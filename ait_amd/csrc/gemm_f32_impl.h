@@ -69,8 +69,9 @@ struct GemmArgs {
   int splits;
   unsigned long long* probe;   // diagnostic stamps (scripts/gemm_lab.hip); NULL in the product
   ConvGeom conv;               // CONV != 0 kernels only
-  int batch;                   // register-staged kernels: independent problems along gridDim.y ...
+  int batch, batch2;           // register-staged kernels: independent problems along gridDim.y (x gridDim.z) ...
   long long sA, sB, sC;        // ... whose operands are this many floats apart
+  long long sA2, sB2, sC2;     // (second batch level: the heads of an attention product)
 };
 
 enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
@@ -693,11 +694,11 @@ template <class C, bool AK, bool BKC, int EPI>
 __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs g_in) {
   static_assert(C::MODE != MODE_DLDS, "the direct-to-LDS tiles run gemm_f32_stream_kernel");
   GemmArgs g = g_in;
-  if (g.batch > 1) {             // batched launch: problem blockIdx.y
-    g.A += (size_t)blockIdx.y * g.sA;
-    g.B += (size_t)blockIdx.y * g.sB;
-    g.C += (size_t)blockIdx.y * g.sC;
-    if (g.residual) g.residual += (size_t)blockIdx.y * g.sC;
+  if (g.batch > 1 || g.batch2 > 1) {     // batched launch: problem (blockIdx.y, blockIdx.z)
+    g.A += (size_t)blockIdx.y * g.sA + (size_t)blockIdx.z * g.sA2;
+    g.B += (size_t)blockIdx.y * g.sB + (size_t)blockIdx.z * g.sB2;
+    g.C += (size_t)blockIdx.y * g.sC + (size_t)blockIdx.z * g.sC2;
+    if (g.residual) g.residual += (size_t)blockIdx.y * g.sC + (size_t)blockIdx.z * g.sC2;
   }
   constexpr int BM = C::BM, BN = C::BN, BK = C::BK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -903,8 +904,8 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
   if constexpr (C::MODE == MODE_DLDS)
     hipLaunchKernelGGL((gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV>), dim3(blocks), dim3(C::NT), C::LDS, s, g);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<C, AK, BKC, EPI>), dim3(blocks, g.batch > 1 ? g.batch : 1), dim3(C::NT), C::LDS,
-                       s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<C, AK, BKC, EPI>), dim3(blocks, g.batch > 1 ? g.batch : 1, g.batch2 > 1 ? g.batch2 : 1),
+                       dim3(C::NT), C::LDS, s, g);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }
@@ -954,7 +955,7 @@ inline int make_args(int trans_a, int trans_b, int M, int N, int K, float alpha,
   g.c_colblk = c_colblk; g.c_batch = c_batch_stride; g.alpha = alpha; g.flags = flags;
   g.probe = nullptr;
   g.conv = ConvGeom{};
-  g.batch = 1; g.sA = g.sB = g.sC = 0;
+  g.batch = g.batch2 = 1; g.sA = g.sB = g.sC = g.sA2 = g.sB2 = g.sC2 = 0;
   // 32-bit element offsets in the epilogue
   {
     const unsigned long long rows = (unsigned long long)(M > 0 ? M - 1 : 0) * (unsigned long long)(ldc > 0 ? ldc : 0);

@@ -375,6 +375,175 @@ __global__ __launch_bounds__(kThreads) void sh_bwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row softmax with dropout over [rows, cols] score matrices (any cols): the image-level co-attention
+// (faster_rcnn_sys_transformer_sk_dilat.py:31-102) runs MultiHeadAttention with 2394 image tokens on one
+// side, so its score matrix does not fit the 64x64 register tile of attn.hip; scores and P.V go through
+// the batched matrix-core GEMM and this kernel does Modules.py:24 (softmax, dropout) in between.
+// One wave per row; y = softmax(x) (kept for the backward), yd = dropout(y) (what multiplies V).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void softmax_rows_fwd_kernel(const float* __restrict__ x, long long rows, int cols,
+                                                                    long long ld, float p, unsigned long long seed,
+                                                                    float* __restrict__ y, float* __restrict__ yd) {
+  const int lane = threadIdx.x & 63;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long long r = (long long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); r < rows;
+       r += (long long)gridDim.x * (kThreads / 64)) {
+    const float* __restrict__ xr = x + r * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, xr[c]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < cols; c += 64) sum += expf(xr[c] - m);
+    const float inv = 1.f / wave_sum(sum);
+    for (int c = lane; c < cols; c += 64) {
+      const float v = expf(xr[c] - m) * inv;
+      y[r * ld + c] = v;
+      if (yd != y) yd[r * ld + c] = p > 0.f ? v * drop_scale(seed, (unsigned long long)r * cols + c, p, inv_keep) : v;
+    }
+  }
+}
+
+// dx = y * (dP - sum_c dP*y) with dP = dyd * mask/(1-p)
+__global__ __launch_bounds__(kThreads) void softmax_rows_bwd_kernel(const float* __restrict__ dyd, const float* __restrict__ y,
+                                                                    long long rows, int cols, long long ld, float p,
+                                                                    unsigned long long seed, float* __restrict__ dx) {
+  const int lane = threadIdx.x & 63;
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  for (long long r = (long long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6); r < rows;
+       r += (long long)gridDim.x * (kThreads / 64)) {
+    float dot = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+      const float d = dyd[r * ld + c] * (p > 0.f ? drop_scale(seed, (unsigned long long)r * cols + c, p, inv_keep) : 1.f);
+      dot += d * y[r * ld + c];
+    }
+    dot = wave_sum(dot);
+    for (int c = lane; c < cols; c += 64) {
+      const float d = dyd[r * ld + c] * (p > 0.f ? drop_scale(seed, (unsigned long long)r * cols + c, p, inv_keep) : 1.f);
+      dx[r * ld + c] = y[r * ld + c] * (d - dot);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Selective heads for ANY sequence length T (the co-attention's 2394-token side): the same arithmetic
+// as sh_fwd_kernel / sh_bwd_kernel (SubLayers.py:22-39,92) cut into passes that scale over T:
+//   pool   ssum[b,c]  = sum_{h,t} O[b,h,t,c]                       (grid over token chunks, atomics)
+//   gate   s = ssum/T; g = sk_w s + sk_b; gate = softmax over heads  (one workgroup per sequence)
+//   apply  u[b,t,c]   = sum_h O[b,h,t,c] * gate[b,h,c]
+// backward: dgr[b,h,c] = sum_t du[b,t,c] O[b,h,t,c] (atomics); softmax backward -> dg, ds = sk_w^T dg / T;
+//           dO[b,h,t,c] = du[b,t,c] gate[b,h,c] + ds[b,c]
+// ---------------------------------------------------------------------------------------------
+constexpr int kShTok = 64;     // tokens per workgroup in the pool / apply passes
+
+__global__ __launch_bounds__(kThreads) void shg_pool_kernel(const float* __restrict__ O, int T, float* __restrict__ ssum) {
+  __shared__ float part[4][kC];
+  const int b = blockIdx.y, t0 = blockIdx.x * kShTok, c = threadIdx.x & 63, tq = threadIdx.x >> 6;
+  const float* __restrict__ Ob = O + (size_t)b * kH * T * kC;
+  float acc = 0.f;
+  for (int h = 0; h < kH; h++)
+    for (int t = t0 + tq; t < min(T, t0 + kShTok); t += 4) acc += Ob[((size_t)h * T + t) * kC + c];
+  part[tq][c] = acc;
+  __syncthreads();
+  if (threadIdx.x < kC) unsafeAtomicAdd(ssum + (size_t)b * kC + c, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+}
+
+__global__ __launch_bounds__(kThreads) void shg_gate_kernel(const float* __restrict__ ssum, float inv_T,
+                                                            const float* __restrict__ sk_w, const float* __restrict__ sk_b,
+                                                            float* __restrict__ gate_out, float* __restrict__ s_out) {
+  __shared__ float s[kC];
+  __shared__ float gate[kH * kC];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  if (tid < kC) {
+    s[tid] = ssum[(size_t)n * kC + tid] * inv_T;
+    s_out[(size_t)n * kC + tid] = s[tid];
+  }
+  __syncthreads();
+  for (int j = tid; j < kH * kC; j += kThreads) {
+    float d = sk_b[j];
+    for (int q = 0; q < kC; q++) d += sk_w[(size_t)j * kC + q] * s[q];
+    gate[j] = d;
+  }
+  __syncthreads();
+  if (tid < kC) {
+    float mx = gate[tid];
+    for (int h = 1; h < kH; h++) mx = fmaxf(mx, gate[h * kC + tid]);
+    float e[kH], sum = 0.f;
+    for (int h = 0; h < kH; h++) { e[h] = expf(gate[h * kC + tid] - mx); sum += e[h]; }
+    for (int h = 0; h < kH; h++) gate_out[(size_t)n * kH * kC + h * kC + tid] = e[h] / sum;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void shg_apply_kernel(const float* __restrict__ O, const float* __restrict__ gate,
+                                                             int T, float* __restrict__ u) {
+  const int b = blockIdx.y, t0 = blockIdx.x * kShTok, c = threadIdx.x & 63, tq = threadIdx.x >> 6;
+  const float* __restrict__ Ob = O + (size_t)b * kH * T * kC;
+  float gl[kH];
+  for (int h = 0; h < kH; h++) gl[h] = gate[(size_t)b * kH * kC + h * kC + c];
+  for (int t = t0 + tq; t < min(T, t0 + kShTok); t += 4) {
+    float v = 0.f;
+    for (int h = 0; h < kH; h++) v += Ob[((size_t)h * T + t) * kC + c] * gl[h];
+    u[((size_t)b * T + t) * kC + c] = v;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void shg_bwd_reduce_kernel(const float* __restrict__ du, const float* __restrict__ O,
+                                                                  int T, float* __restrict__ dgr) {
+  __shared__ float part[4][kH * kC];
+  const int b = blockIdx.y, t0 = blockIdx.x * kShTok, c = threadIdx.x & 63, tq = threadIdx.x >> 6;
+  const float* __restrict__ Ob = O + (size_t)b * kH * T * kC;
+  float acc[kH];
+  for (int h = 0; h < kH; h++) acc[h] = 0.f;
+  for (int t = t0 + tq; t < min(T, t0 + kShTok); t += 4) {
+    const float d = du[((size_t)b * T + t) * kC + c];
+    for (int h = 0; h < kH; h++) acc[h] += d * Ob[((size_t)h * T + t) * kC + c];
+  }
+  for (int h = 0; h < kH; h++) part[tq][h * kC + c] = acc[h];
+  __syncthreads();
+  for (int j = threadIdx.x; j < kH * kC; j += kThreads)
+    unsafeAtomicAdd(dgr + (size_t)b * kH * kC + j, part[0][j] + part[1][j] + part[2][j] + part[3][j]);
+}
+
+// per sequence: dg = softmax backward over heads of dgr; ds = sk_w^T dg / T
+__global__ __launch_bounds__(kThreads) void shg_bwd_gate_kernel(const float* __restrict__ dgr, const float* __restrict__ gate,
+                                                                const float* __restrict__ sk_w, float inv_T,
+                                                                float* __restrict__ dg_out, float* __restrict__ ds_out) {
+  __shared__ float dg[kH * kC];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  if (tid < kC) {
+    float gl[kH], dgt[kH], dot = 0.f;
+    for (int h = 0; h < kH; h++) {
+      gl[h] = gate[(size_t)n * kH * kC + h * kC + tid];
+      dgt[h] = dgr[(size_t)n * kH * kC + h * kC + tid];
+      dot += dgt[h] * gl[h];
+    }
+    for (int h = 0; h < kH; h++) {
+      const float v = gl[h] * (dgt[h] - dot);
+      dg[h * kC + tid] = v;
+      dg_out[(size_t)n * kH * kC + h * kC + tid] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < kC) {
+    float d = 0.f;
+    for (int j = 0; j < kH * kC; j++) d += sk_w[(size_t)j * kC + tid] * dg[j];
+    ds_out[(size_t)n * kC + tid] = d * inv_T;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void shg_bwd_apply_kernel(const float* __restrict__ du, const float* __restrict__ gate,
+                                                                 const float* __restrict__ ds, int T, float* __restrict__ dO) {
+  const int b = blockIdx.y, t0 = blockIdx.x * kShTok, c = threadIdx.x & 63, tq = threadIdx.x >> 6;
+  float gl[kH];
+  for (int h = 0; h < kH; h++) gl[h] = gate[(size_t)b * kH * kC + h * kC + c];
+  const float dsc = ds[(size_t)b * kC + c];
+  float* __restrict__ dOb = dO + (size_t)b * kH * T * kC;
+  for (int t = t0 + tq; t < min(T, t0 + kShTok); t += 4) {
+    const float d = du[((size_t)b * T + t) * kC + c];
+    for (int h = 0; h < kH; h++) dOb[((size_t)h * T + t) * kC + c] = d * gl[h] + dsc;
+  }
+}
+
 inline unsigned ln_grid(long long rows) {
   long long b = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
   return (unsigned)(b < 4096 ? (b > 0 ? b : 1) : 4096);
@@ -465,6 +634,69 @@ AIT_API int ait_sh_bwd(const float* du, const float* O, const float* gate, const
   if (!du || !O || !gate || !sk_w || !dO || !dg) return AIT_EINVAL;
   hipLaunchKernelGGL(sh_bwd_kernel, dim3(n_seq), dim3(kThreads), 0, ait_stream(stream), du, O, gate,
                      sk_w, dO, dg);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_softmax_rows_fwd(const float* x, long long rows, int cols, long long ld, float p_drop,
+                                 unsigned long long seed, float* y, float* y_drop, void* stream) {
+  if (rows < 0 || cols <= 0 || ld < cols || p_drop < 0.f || p_drop >= 1.f) return AIT_EINVAL;
+  if (rows == 0) return AIT_OK;
+  if (!x || !y || !y_drop) return AIT_EINVAL;
+  const long long b = (rows + 3) / 4;
+  hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(kThreads), 0, ait_stream(stream),
+                     x, rows, cols, ld, p_drop, seed, y, y_drop);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_softmax_rows_bwd(const float* dy_drop, const float* y, long long rows, int cols, long long ld, float p_drop,
+                                 unsigned long long seed, float* dx, void* stream) {
+  if (rows < 0 || cols <= 0 || ld < cols || p_drop < 0.f || p_drop >= 1.f) return AIT_EINVAL;
+  if (rows == 0) return AIT_OK;
+  if (!dy_drop || !y || !dx) return AIT_EINVAL;
+  const long long b = (rows + 3) / 4;
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(kThreads), 0, ait_stream(stream),
+                     dy_drop, y, rows, cols, ld, p_drop, seed, dx);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_sh_general_fwd(const float* O, const float* sk_w, const float* sk_b, int n_seq, int H, int T, int dv,
+                               float* u, float* gate, float* s, void* stream) {
+  if (n_seq < 0 || T <= 0) return AIT_EINVAL;
+  if (H != kH || dv != kC || n_seq > 65535) return AIT_EUNSUPPORTED;
+  if (n_seq == 0) return AIT_OK;
+  if (!O || !sk_w || !sk_b || !u || !gate || !s) return AIT_EINVAL;
+  hipStream_t st = ait_stream(stream);
+  // `s` doubles as the accumulator of the pooled sums before the gate pass rescales it in place
+  if (hipMemsetAsync(s, 0, sizeof(float) * (size_t)n_seq * kC, st) != hipSuccess) return AIT_ELAUNCH;
+  const dim3 grid((unsigned)((T + kShTok - 1) / kShTok), (unsigned)n_seq);
+  hipLaunchKernelGGL(shg_pool_kernel, grid, dim3(kThreads), 0, st, O, T, s);
+  AIT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(shg_gate_kernel, dim3(n_seq), dim3(kThreads), 0, st, s, 1.f / (float)T, sk_w, sk_b, gate, s);
+  AIT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(shg_apply_kernel, grid, dim3(kThreads), 0, st, O, gate, T, u);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_sh_general_bwd(const float* du, const float* O, const float* gate, const float* sk_w, int n_seq, int H,
+                               int T, int dv, float* dO, float* dg, float* workspace, void* stream) {
+  if (n_seq < 0 || T <= 0) return AIT_EINVAL;
+  if (H != kH || dv != kC || n_seq > 65535) return AIT_EUNSUPPORTED;
+  if (n_seq == 0) return AIT_OK;
+  if (!du || !O || !gate || !sk_w || !dO || !dg || !workspace) return AIT_EINVAL;
+  hipStream_t st = ait_stream(stream);
+  float* dgr = workspace;                            // [n_seq, H*dv]
+  float* ds = workspace + (size_t)n_seq * kH * kC;   // [n_seq, dv]
+  if (hipMemsetAsync(dgr, 0, sizeof(float) * (size_t)n_seq * kH * kC, st) != hipSuccess) return AIT_ELAUNCH;
+  const dim3 grid((unsigned)((T + kShTok - 1) / kShTok), (unsigned)n_seq);
+  hipLaunchKernelGGL(shg_bwd_reduce_kernel, grid, dim3(kThreads), 0, st, du, O, T, dgr);
+  AIT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(shg_bwd_gate_kernel, dim3(n_seq), dim3(kThreads), 0, st, dgr, gate, sk_w, 1.f / (float)T, dg, ds);
+  AIT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(shg_bwd_apply_kernel, grid, dim3(kThreads), 0, st, du, gate, ds, T, dO);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }

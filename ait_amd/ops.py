@@ -87,43 +87,117 @@ def _pad4(n):
 
 
 def bmat(batch, rows, cols, device):
-    """zero-filled [batch, rows, cols] whose row pitch is a multiple of 4 floats (the layout bgemm operands
-    need when cols % 4 != 0: the 2394-token image side of the co-attention)"""
-    return torch.zeros((batch, rows, _pad4(cols)), dtype=torch.float32, device=device)[:, :, :cols]
+    """zero-filled [*batch, rows, cols] whose row pitch is a multiple of 4 floats (the layout bgemm operands
+    need when cols % 4 != 0: the 2394-token image side of the co-attention); `batch` an int or a tuple"""
+    batch = (batch,) if isinstance(batch, int) else tuple(batch)
+    return torch.zeros(batch + (rows, _pad4(cols)), dtype=torch.float32, device=device)[..., :cols]
 
 
 def bgemm(a, b, trans_a=False, trans_b=True, alpha=1.0, out=None, accumulate=False):
-    """Batched out[i] (op)= alpha * op(a[i]) @ op(b[i]) in ONE launch (ait_gemm_f32_batched).  a, b, out are
-    3-D with unit column stride, a row pitch that is a multiple of 4 and equal batch counts."""
-    bz = a.shape[0]
-    M, K = (a.shape[2], a.shape[1]) if trans_a else (a.shape[1], a.shape[2])
-    N = b.shape[1] if trans_b else b.shape[2]
-    Kb = b.shape[2] if trans_b else b.shape[1]
-    if K != Kb or b.shape[0] != bz:
-        raise ValueError("bgemm: operand shapes differ")
+    """Batched out[i(,j)] (op)= alpha * op(a[i(,j)]) @ op(b[i(,j)]) in ONE launch (ait_gemm_f32_batched).
+    a, b, out: 3-D [batch, rows, cols] or 4-D [batch, batch2, rows, cols] float32 GPU tensors (any batch
+    strides -- e.g. the per-head views of a [tokens, 8*64] projection) with unit column stride and row / batch
+    pitches that are multiples of 4 floats; an operand that is not is copied into such a layout."""
+    nb = a.dim() - 2
+    if nb not in (1, 2) or b.dim() != a.dim() or a.shape[:nb] != b.shape[:nb]:
+        raise ValueError("bgemm: operand batch shapes differ")
+    M, K = (a.shape[-1], a.shape[-2]) if trans_a else (a.shape[-2], a.shape[-1])
+    N = b.shape[-2] if trans_b else b.shape[-1]
+    Kb = b.shape[-1] if trans_b else b.shape[-2]
+    if K != Kb:
+        raise ValueError("bgemm: reduction dims differ (%d vs %d)" % (K, Kb))
 
     def ok(t):
-        return t.stride(2) == 1 and t.stride(1) % 4 == 0 and t.stride(1) >= t.shape[2] and t.stride(0) % 4 == 0
-    if not ok(a):
-        a2 = bmat(bz, a.shape[1], a.shape[2], a.device)
-        a2.copy_(a)
-        a = a2
-    if not ok(b):
-        b2 = bmat(bz, b.shape[1], b.shape[2], b.device)
-        b2.copy_(b)
-        b = b2
+        return t.stride(-1) == 1 and t.stride(-2) % 4 == 0 and t.stride(-2) >= t.shape[-1] and \
+            all(st % 4 == 0 for st in t.stride()[:nb]) and t.data_ptr() % 16 == 0
+
+    def fix(t):
+        if ok(t):
+            return t
+        t2 = bmat(tuple(t.shape[:nb]), t.shape[-2], t.shape[-1], t.device)
+        t2.copy_(t)
+        return t2
+    a, b = fix(a), fix(b)
+    # a long reduction of few small products (the 2394-token side as the reduction dim): split-K, partial sums
+    # combined with atomics into a zero-filled result
+    n_prob = a.shape[0] * (a.shape[1] if nb == 2 else 1)
+    split_k = 8 if (K >= 1024 and n_prob * ((M + 63) // 64) * ((N + 63) // 64) <= 256 and not accumulate) else 1
     if out is None:
-        out = bmat(bz, M, N, a.device)
+        out = bmat(tuple(a.shape[:nb]), M, N, a.device)
+    elif split_k > 1:
+        out.zero_()
     for t in (a, b, out):
         if not t.is_cuda or t.dtype != torch.float32:
             raise _lib.AitHipError("bgemm: float32 GPU tensors only (no CPU fallback)")
+    if tuple(out.shape) != tuple(a.shape[:nb]) + (M, N) or out.stride(-1) != 1:
+        raise _lib.AitHipError("bgemm: bad `out`")
+    s1 = lambda t: t.stride(0)
+    s2 = lambda t: t.stride(1) if nb == 2 else 0
     with torch.cuda.device(a.device):
         rc = _lib.lib().ait_gemm_f32_batched(
-            int(trans_a), int(trans_b), M, N, K, float(alpha), ctypes.c_void_p(a.data_ptr()), a.stride(1), a.stride(0),
-            ctypes.c_void_p(b.data_ptr()), b.stride(1), b.stride(0), ctypes.c_void_p(out.data_ptr()), out.stride(1),
-            out.stride(0), bz, _lib.GEMM_ACCUMULATE if accumulate else 0, _lib.cur_stream(a.device))
+            int(trans_a), int(trans_b), M, N, K, float(alpha), ctypes.c_void_p(a.data_ptr()), a.stride(-2), s1(a), s2(a),
+            ctypes.c_void_p(b.data_ptr()), b.stride(-2), s1(b), s2(b), ctypes.c_void_p(out.data_ptr()), out.stride(-2),
+            s1(out), s2(out), a.shape[0], a.shape[1] if nb == 2 else 1,
+            _lib.GEMM_ATOMIC if split_k > 1 else (_lib.GEMM_ACCUMULATE if accumulate else 0), split_k,
+            _lib.cur_stream(a.device))
     _lib.check(rc, "ait_gemm_f32_batched")
     return out
+
+
+def softmax_rows(x, p, seed):
+    """x [..., rows, cols] (row pitch ld = x.stride(-2), dense batch dims) -> (y, y_drop) of the same layout"""
+    cols, ld = x.shape[-1], x.stride(-2)
+    rows = x.numel() // cols
+    base = x.as_strided((rows, cols), (ld, 1))
+    y = torch.zeros((rows, ld), dtype=torch.float32, device=x.device)[:, :cols]        # (zero row padding)
+    yd = torch.zeros((rows, ld), dtype=torch.float32, device=x.device)[:, :cols] if p > 0 else y
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().ait_softmax_rows_fwd(ctypes.c_void_p(base.data_ptr()), rows, cols, ld, float(p), int(seed),
+                                             ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(yd.data_ptr()),
+                                             _lib.cur_stream(x.device))
+    _lib.check(rc, "ait_softmax_rows_fwd")
+    shape = tuple(x.shape)
+    view = lambda t: t.as_strided(shape, x.stride())
+    return view(y), view(yd)
+
+
+def softmax_rows_bwd(dyd, y, p, seed):
+    cols, ld = y.shape[-1], y.stride(-2)
+    rows = y.numel() // cols
+    if dyd.stride() != y.stride():
+        d2 = torch.zeros((rows, ld), dtype=torch.float32, device=y.device)[:, :cols].as_strided(tuple(y.shape), y.stride())
+        d2.copy_(dyd)
+        dyd = d2
+    dx = torch.zeros((rows, ld), dtype=torch.float32, device=y.device)[:, :cols]
+    with torch.cuda.device(y.device):
+        rc = _lib.lib().ait_softmax_rows_bwd(ctypes.c_void_p(dyd.data_ptr()), ctypes.c_void_p(y.data_ptr()), rows, cols, ld,
+                                             float(p), int(seed), ctypes.c_void_p(dx.data_ptr()), _lib.cur_stream(y.device))
+    _lib.check(rc, "ait_softmax_rows_bwd")
+    return dx.as_strided(tuple(y.shape), y.stride())
+
+
+def sh_general_fwd(O, sk_w, sk_b):
+    n, H, T, dv = O.shape
+    u = torch.empty((n, T, dv), dtype=torch.float32, device=O.device)
+    gate = torch.empty((n, H * dv), dtype=torch.float32, device=O.device)
+    s = torch.empty((n, dv), dtype=torch.float32, device=O.device)
+    with torch.cuda.device(O.device):
+        rc = _lib.lib().ait_sh_general_fwd(_p(O), _p(sk_w), _p(sk_b), n, H, T, dv, _p(u), _p(gate), _p(s),
+                                           _lib.cur_stream(O.device))
+    _lib.check(rc, "ait_sh_general_fwd")
+    return u, gate, s
+
+
+def sh_general_bwd(du, O, gate, sk_w):
+    n, H, T, dv = O.shape
+    dO = torch.empty_like(O)
+    dg = torch.empty((n, H * dv), dtype=torch.float32, device=O.device)
+    ws = torch.empty((n * (H * dv + dv),), dtype=torch.float32, device=O.device)
+    with torch.cuda.device(O.device):
+        rc = _lib.lib().ait_sh_general_bwd(_p(du), _p(O), _p(gate), _p(sk_w), n, H, T, dv, _p(dO), _p(dg), _p(ws),
+                                           _lib.cur_stream(O.device))
+    _lib.check(rc, "ait_sh_general_bwd")
+    return dO, dg
 
 
 def gemm_relu_bwd(dy, w, act, out=None):

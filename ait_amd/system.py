@@ -252,6 +252,61 @@ class _SelectiveHeads(torch.autograd.Function):
         return dO, dw, ops.colsum(dg)
 
 
+class _SelectiveHeadsAnyT(torch.autograd.Function):
+    """_SelectiveHeads for any sequence length (the 2394-token side of the image-level co-attention)."""
+
+    @staticmethod
+    def forward(ctx, O, sk_w, sk_b):
+        u, gate, s = ops.sh_general_fwd(O, sk_w, sk_b)
+        ctx.save_for_backward(O, sk_w, gate, s)
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        O, sk_w, gate, s = ctx.saved_tensors
+        dO, dg = ops.sh_general_bwd(du.contiguous(), O, gate, sk_w)
+        dw = ops.gemm(dg, s, trans_a=True, trans_b=False, split_k=1)       # [H*dv, dv] = dg^T s (a handful of rows)
+        return dO, dw, ops.colsum(dg)
+
+
+class _AttnAnyLen(torch.autograd.Function):
+    """softmax((q/T) k^T) -> dropout -> . v for any len_q / len_k (no mask): the score and P.V products as
+    batched matrix-core GEMMs over (image, head), Modules.py:24's softmax + dropout as one row kernel between
+    them.  qp [bs*len_q, H*d], kp / vp [bs*len_k, H*d] (the projections as they come out of the GEMMs: the
+    per-head operands are strided VIEWS, nothing is transposed or copied) -> O [bs, H, len_q, d], attn."""
+
+    @staticmethod
+    def forward(ctx, qp, kp, vp, bs, H, d, scale, p, seed):
+        lq, lk = qp.shape[0] // bs, kp.shape[0] // bs
+        heads = lambda t, L: t.view(bs, L, H, d).permute(0, 2, 1, 3)       # [bs, H, L, d] strided view
+        qh, kh, vh = heads(qp, lq), heads(kp, lk), heads(vp, lk)
+        S = ops.bgemm(qh, kh, False, True, scale)                          # [bs, H, lq, lk]
+        P, Pd = ops.softmax_rows(S, p, seed)
+        O = ops.bgemm(Pd, vh, False, False)                                # [bs, H, lq, d]
+        if not O.is_contiguous():
+            O = O.contiguous()
+        ctx.save_for_backward(qp, kp, vp, P, Pd)
+        ctx.cfg = (bs, H, d, scale, p, seed)
+        ctx.mark_non_differentiable(Pd)
+        return O, Pd
+
+    @staticmethod
+    def backward(ctx, dO, _dP):
+        qp, kp, vp, P, Pd = ctx.saved_tensors
+        bs, H, d, scale, p, seed = ctx.cfg
+        lq, lk = qp.shape[0] // bs, kp.shape[0] // bs
+        heads = lambda t, L: t.view(bs, L, H, d).permute(0, 2, 1, 3)
+        qh, kh, vh = heads(qp, lq), heads(kp, lk), heads(vp, lk)
+        dO = dO.contiguous()
+        dq, dk, dv = torch.empty_like(qp), torch.empty_like(kp), torch.empty_like(vp)
+        ops.bgemm(Pd, dO, True, False, out=heads(dv, lk))                  # dV = Pd^T dO
+        dPd = ops.bgemm(dO, vh, False, True)                               # dPd = dO V^T   [bs, H, lq, lk]
+        dS = ops.softmax_rows_bwd(dPd, P, p, seed)
+        ops.bgemm(dS, kh, False, False, scale, out=heads(dq, lq))          # dQ = scale dS K
+        ops.bgemm(dS, qh, True, False, scale, out=heads(dk, lk))           # dK = scale dS^T Q
+        return dq, dk, dv, None, None, None, None, None, None
+
+
 class _ToNCHW(torch.autograd.Function):
     """y[p, ch, t] = sum_k x[p*T + t, k] W[ch, k] + b[ch]: the dec_trans 1x1 conv written straight
     into NCHW by the GEMM epilogue (Models.py:276-278)."""
@@ -453,7 +508,45 @@ class MultiHeadAttention(nn.Module):
                              n_seq * SEQ, SEQ, SEQ, 1, p, _new_seed())
         return y.view(n_seq, SEQ, self.d_model), attn
 
+    def _forward_any_len(self, q, k):
+        """The image-level co-attention's shapes (len_q or len_k = H_i*W_i, no mask) on the library's kernels:
+        projections and the score / P.V products on the matrix cores, softmax + dropout, selective heads and
+        dropout + residual + LayerNorm as row kernels.  Same arithmetic as _forward_generic."""
+        H, d = self.n_head, self.d_k
+        bs, len_q, len_k = q.size(0), q.size(1), k.size(1)
+        p = self.p if self.training else 0.0
+        p_attn = self.attention.dropout.p if self.training else 0.0
+        xq = q.reshape(bs * len_q, self.d_model)
+        xk = k.reshape(bs * len_k, self.d_model)
+        qp = _Linear.apply(xq, self.w_qs.weight, None)
+        kv = _Linear.apply(xk, self._kv_weight(), None)                    # K | V column blocks
+        kp, vp = kv[:, :H * d], kv[:, H * d:]
+        O, attn = _AttnAnyLen.apply(qp, kp, vp, bs, H, d, 1.0 / self.attention.temperature, p_attn, _new_seed())
+        if len_q == SEQ:
+            u = _SelectiveHeads.apply(O, self.sh.sk.weight, self.sh.sk.bias)
+        else:
+            u = _SelectiveHeadsAnyT.apply(O, self.sh.sk.weight, self.sh.sk.bias)
+        f = _Linear.apply(u.reshape(bs * len_q, d), self.fc.weight, None)
+        y = _DropResLN.apply(f, None, xq, self.layer_norm.weight, self.layer_norm.bias, bs * len_q, len_q, len_q, 1,
+                             p, _new_seed())
+        return y.view(bs, len_q, self.d_model), attn
+
+    def _kv_weight(self):
+        """[w_ks; w_vs] as one [2*H*d, d_model] matrix, rebuilt only when a weight changed"""
+        key = (self.w_ks.weight._version, self.w_vs.weight._version, self.w_ks.weight.data_ptr(), self.w_vs.weight.data_ptr())
+        c = getattr(self, "_ait_kv", None)
+        if c is None or c[0] != key or torch.is_grad_enabled():
+            w = torch.cat([self.w_ks.weight, self.w_vs.weight], 0)
+            if torch.is_grad_enabled():
+                return w                        # (keeps the autograd edge to both parameters)
+            self._ait_kv = c = (key, w)
+        return c[1]
+
     def _forward_generic(self, q, k, v, mask):
+        if (q.is_cuda and q.dtype == torch.float32 and mask is None and (k is v) and self.n_head == 8 and self.d_k == 64
+                and self.d_v == 64 and self.d_model == ops.D_MODEL and self.dist == 'softmax'
+                and os.environ.get("AIT_COATT_TORCH", "0") != "1"):
+            return self._forward_any_len(q, k)
         d_k, d_v, n_head = self.d_k, self.d_v, self.n_head
         sz_b, len_q, len_k = q.size(0), q.size(1), k.size(1)
         residual = q

@@ -160,14 +160,33 @@ int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, con
                  const float* residual, int flags, int split_k, int c_colblk,
                  long long c_batch_stride, void* stream);
 
-/* Batched form: `batch` independent products, operand b at base + b*stride (floats), one launch.  Replaces
- * the three torch.matmul of the COCO variant's image-level co-attention
- *   (lib/model/modules/blocks_coatt_transformer_sk.py:86-110) and their autograd backward.
- * flags: 0 or AIT_GEMM_ACCUMULATE.  K % 4 != 0 is accepted for trans_a == 0 && trans_b == 0 when
+/* Batched form: batch x batch2 independent products, operand (i, j) at base + i*stride + j*stride2 (floats),
+ * one launch.  Replaces the three torch.matmul of the COCO variant's image-level co-attention
+ *   (lib/model/modules/blocks_coatt_transformer_sk.py:86-110), the per-(image, head) score and P.V products of
+ * the VOC variant's (lib/model/system/Modules.py:18,27 at len_q or len_k = H_i*W_i, second batch level = heads),
+ * and their autograd backward.
+ * flags: 0, AIT_GEMM_ACCUMULATE, or AIT_GEMM_ATOMIC with split_k > 1 (long reductions of few small products:
+ * partial sums ADDED to C with fp32 atomics; the caller zero-fills C).  K % 4 != 0 is accepted for trans_a == 0 && trans_b == 0 when
  * lda >= K rounded up to 4 and A's row padding holds finite values (the 2394-token image side). */
 int ait_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, int lda,
-                         long long stride_a, const float* B, int ldb, long long stride_b, float* C, int ldc,
-                         long long stride_c, int batch, int flags, void* stream);
+                         long long stride_a, long long stride_a2, const float* B, int ldb, long long stride_b,
+                         long long stride_b2, float* C, int ldc, long long stride_c, long long stride_c2, int batch,
+                         int batch2, int flags, int split_k, void* stream);
+
+/* Row softmax + dropout over [rows, cols] matrices with row pitch ld (Modules.py:24 for score matrices that do
+ * not fit attn.hip's 64x64 tile): y = softmax(x) per row, y_drop = dropout(y) (stateless hash of (seed, r*cols + c);
+ * y_drop may alias y when p_drop == 0).  Backward: dx = y * (dP - sum_c dP*y), dP = dy_drop * mask / (1-p). */
+int ait_softmax_rows_fwd(const float* x, long long rows, int cols, long long ld, float p_drop, unsigned long long seed,
+                         float* y, float* y_drop, void* stream);
+int ait_softmax_rows_bwd(const float* dy_drop, const float* y, long long rows, int cols, long long ld, float p_drop,
+                         unsigned long long seed, float* dx, void* stream);
+
+/* Selective heads (ait_sh_fwd / ait_sh_bwd) for ANY sequence length T (H = 8, dv = 64): the co-attention's
+ * 2394-token side.  workspace (backward): n_seq * (H*dv + dv) floats of scratch. */
+int ait_sh_general_fwd(const float* O, const float* sk_w, const float* sk_b, int n_seq, int H, int T, int dv, float* u,
+                       float* gate, float* s, void* stream);
+int ait_sh_general_bwd(const float* du, const float* O, const float* gate, const float* sk_w, int n_seq, int H, int T,
+                       int dv, float* dO, float* dg, float* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Convolutions over CHANNELS-LAST maps as implicit GEMMs on the same matrix-core kernel (no im2col buffer).

@@ -581,3 +581,46 @@ def test_c_training_blocks_match_the_modules():
                                ctypes.c_void_p(saved.data_ptr()), sb, _lib.dev_ptr(y), None) == -1
     assert L.ait_dropout_seed(7, 3) == L.ait_dropout_seed(7, 3) != L.ait_dropout_seed(7, 4)
     del keep
+
+
+@pytest.mark.parametrize("lq,lk", [(2394, 64), (64, 2394), (200, 72)])
+def test_any_length_attention_block_matches_the_torch_composition(monkeypatch, lq, lk):
+    """MultiHeadAttention at the image-level co-attention's shapes (faster_rcnn_sys_transformer_sk_dilat.py:31-102:
+    2394 image tokens x 64 query tokens, both directions): projections, batched score / P.V products, row softmax,
+    any-T selective heads and the LayerNorm tail on the library's kernels against the torch composition of the same
+    module (AIT_COATT_TORCH=1), outputs and all gradients at dropout 0; dropout statistics separately."""
+    from ait_amd.system import MultiHeadAttention
+    torch.manual_seed(lq + lk)
+    m = MultiHeadAttention(8, 512, 64, 64, dropout=0.1).cuda().eval()
+    q0 = torch.randn(3, lq, 512, device="cuda")
+    k0 = torch.randn(3, lk, 512, device="cuda")
+    cot = torch.randn(3, lq, 512, device="cuda")
+
+    def run(torch_path):
+        monkeypatch.setenv("AIT_COATT_TORCH", "1" if torch_path else "0")
+        m.zero_grad(set_to_none=True)
+        q, k = q0.clone().requires_grad_(True), k0.clone().requires_grad_(True)
+        y, attn = m(q, k, k, mask=None)
+        y.backward(cot)
+        return y.detach(), attn.detach(), q.grad, k.grad, {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    yh, ah, gqh, gkh, gh = run(False)
+    yt, at, gqt, gkt, gt = run(True)
+    assert tuple(ah.shape) == tuple(at.shape) == (3, 8, lq, lk)
+    assert _rel(yh, yt) < 1e-5 and _rel(ah, at) < 1e-5
+    assert _rel(gqh, gqt) < 1e-4 and _rel(gkh, gkt) < 1e-4
+    for n in gt:
+        assert _rel(gh[n], gt[n]) < 1e-4, n
+    # training mode: the probabilities' dropout keeps ~90 %, scales by 1/0.9, and is seeded
+    monkeypatch.setenv("AIT_COATT_TORCH", "0")
+    m.train()
+    torch.manual_seed(3)
+    y1, a1 = m(q0, k0, k0, mask=None)
+    torch.manual_seed(3)
+    y2, _ = m(q0, k0, k0, mask=None)
+    y3, _ = m(q0, k0, k0, mask=None)
+    # (same seed -> same masks; the any-T selective heads pool with atomics, so equal to rounding, not bitwise)
+    assert _rel(y1, y2) < 1e-5 and _rel(y1, y3) > 1e-3
+    kept = float((a1 != 0).float().mean())
+    assert abs(kept - 0.9) < 0.01
+    assert abs(float(a1.sum(-1).mean()) - 1.0) < 0.01         # rows of dropout(P) still sum to ~1 on average

@@ -47,7 +47,7 @@ using namespace ait_gemm;
 //   Tile128    128x128 register-staged double buffer: outputs with few rows.
 //   TileN64    256x64 for the 64-column SHBlock / fc products (no dead half tile).
 //   Tile64     64x64 for few-tile problems (the bs*64-row query side): latency, not throughput.
-using Tile256D = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS>;
+using Tile256D = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD>;
 using Tile256 = Cfg<256, 128, 16, 4, 2, 2, MODE_RING>;
 using Tile128 = Cfg<128, 128, 16, 2, 2, 2, MODE_DB>;
 using TileN64 = Cfg<256, 64, 16, 4, 1, 2, MODE_DB>;
@@ -68,14 +68,25 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   //   A: !trans_a  (A is [M,K]);   B: trans_b (B is [N,K])
   const long long tiles256 = (long long)((M + 255) / 256) * ((N + 127) / 128) * g.splits;
   if (N <= 64 && (long long)((M + 255) / 256) * g.splits >= 128) return dispatch<TileN64>(g, !trans_a, trans_b != 0, ait_stream(stream));
-  if (M >= 512 && tiles256 >= 512) {
-    const bool direct = K > 0 && (K % 16 == 0) && (!trans_a || (M % 4 == 0 && M >= 4)) && (trans_b || (N % 4 == 0 && N >= 4));
+  const bool direct = K > 0 && (K % 16 == 0) && (!trans_a || (M % 4 == 0 && M >= 4)) && (trans_b || (N % 4 == 0 && N >= 4));
+  // with the stream-K work list the persistent tile also serves products of a few hundred tiles (their
+  // slabs are spread over all workgroups): layer4-sized and co-attention-sized products
+  const bool few_tiles_sk = direct && g.splits == 1 && !(flags & AIT_GEMM_ATOMIC) && K >= 512 && tiles256 >= 96 &&
+                            stream_k_mode() != 0;
+  if (M >= 512 && (tiles256 >= 512 || few_tiles_sk)) {
     if (direct) return dispatch<Tile256D>(g, !trans_a, trans_b != 0, ait_stream(stream));
     return dispatch<Tile256>(g, !trans_a, trans_b != 0, ait_stream(stream));
   }
   const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * g.splits;
   if (tiles128 < 128) return dispatch<Tile64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   return dispatch<Tile128>(g, !trans_a, trans_b != 0, ait_stream(stream));
+}
+
+// Frees the stream-K scratch buffers (one per device and stream that ran a stream-K launch; see
+// gemm_f32_impl.h).  The streams must be idle.
+AIT_API int ait_gemm_workspace_release(void) {
+  sk_release();
+  return AIT_OK;
 }
 
 // Batched form: batch x batch2 independent products C_ij (op)= alpha * opA(A_ij) . opB(B_ij), operand (i, j) at
@@ -110,7 +121,7 @@ AIT_API int ait_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, 
 // (ConvGeom, gemm_f32_impl.h); positions outside the map read a caller-provided row of zeros.
 // =========================================================================================================
 namespace {
-using Tile128D = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4>;
+using Tile128D = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, KNOB_SPREAD>;
 
 inline int log2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;
@@ -141,7 +152,8 @@ int conv_launch(const GemmArgs& g, hipStream_t s) {
 template <int CONV, bool AK, bool BKC>
 int conv_dispatch(const GemmArgs& g, hipStream_t s) {
   const long long tiles256 = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128) * g.splits;
-  if (tiles256 >= 512) return conv_launch<Tile256D, CONV, AK, BKC>(g, s);
+  if (tiles256 >= 512 || (tiles256 >= 96 && g.K >= 512 && g.splits == 1 && !(g.flags & AIT_GEMM_ATOMIC) && stream_k_mode() != 0))
+    return conv_launch<Tile256D, CONV, AK, BKC>(g, s);
   return conv_launch<Tile128D, CONV, AK, BKC>(g, s);     // few tiles: 128x128, three to a CU
 }
 }  // namespace

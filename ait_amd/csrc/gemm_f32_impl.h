@@ -15,10 +15,15 @@
 // file; they live in the history at 81edb57 and their results in DESIGN.md section 3.1.)
 #pragma once
 #include "common.h"
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace ait_gemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Implicit-GEMM view of a convolution over channels-last maps (gemm_f32_stream_kernel, CONV != 0).
 // The GEMM's row index r runs over the positions (image, y, x) of the "row map" (rows_h x rows_w, both
@@ -72,6 +77,8 @@ struct GemmArgs {
   int batch, batch2;           // register-staged kernels: independent problems along gridDim.y (x gridDim.z) ...
   long long sA, sB, sC;        // ... whose operands are this many floats apart
   long long sA2, sB2, sC2;     // (second batch level: the heads of an attention product)
+  float* sk_ws;                // stream-K: one BM x BN partial tile per workgroup; NULL = whole tiles only
+  unsigned* sk_flags;          // stream-K: one "partial published" word per workgroup (zero between launches)
 };
 
 enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
@@ -84,7 +91,9 @@ enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
 //   KNOB_BURST  the transfers of a slab are issued back to back at the top of the iteration instead of one
 //               behind each of the first MFMA steps
 //   KNOB_PRIO   the second-dispatched half of the workgroup's waves runs at s_setprio 1
-enum { KNOB_BURST = 1, KNOB_PRIO = 2 };
+//   KNOB_SPREAD the LDS reads of the next k-step group are issued one 32-row tile at a time ahead of each
+//               MFMA step instead of all together in front of the group
+enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4 };
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int MODE_ = MODE_DB, int NS_ = 3, int KNOBS_ = 0>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_, MODE = MODE_;
@@ -185,7 +194,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 // awaited (vmcnt) before the barrier that publishes it.
 __device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
   const unsigned dst = (unsigned)(size_t)(lds_void*)lds_dst;      // wave-uniform LDS address
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "m0", "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "m0", "memory");
 }
 
 // operands of k-step group g (4 MFMA steps) of one slab for TILES 32-row tiles starting at row0
@@ -201,6 +210,13 @@ __device__ __forceinline__ void fetch_group(const float* __restrict__ slab, int 
       x[t] = make_float4(p[0], p[PITCH], p[2 * PITCH], p[3 * PITCH]);
     }
   }
+}
+
+template <bool ROWIMG, int PITCH>
+__device__ __forceinline__ float4 fetch_tile(const float* __restrict__ slab, int row0, int li, int lk, int g, int t) {
+  if (ROWIMG) return *reinterpret_cast<const float4*>(slab + rowimg_off(row0 + t * 32 + li, 2 * lk + g));
+  const float* p = slab + (8 * lk + 4 * g) * PITCH + row0 + t * 32 + li;
+  return make_float4(p[0], p[PITCH], p[2 * PITCH], p[3 * PITCH]);
 }
 
 // AK / BKC: true when that operand is stored with the reduction dimension contiguous.
@@ -258,35 +274,35 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
   }
 
   if (EPI == EPI_RES) {
-    // ---- residual add / ReLU-backward gate, software-pipelined over the 4*TM*TN quarter tiles (4 rows
-    // each): the loads of quarter i+1 are issued BEFORE the stores of quarter i, so the wait for them is
-    // a counted vmcnt that leaves those stores in flight
+    // ---- residual add / ReLU-backward gate, software-pipelined over the TM*TN MFMA tiles: the 16 loads
+    // of tile i+1 are issued BEFORE the 16 stores of tile i, so the wait for them is a counted vmcnt that
+    // leaves those stores in flight, and a tile costs one load round trip (a quarter-tile pipeline, four
+    // round trips per MFMA tile, measured 13 % slower on the ReLU-gated dgrad shape)
     const bool mask_pos = (g.flags & AIT_GEMM_MASK_POS) != 0;
-    constexpr int NQ = 4 * TM * TN;
-    float x[4], xn[4];
-    auto row_of = [&](int i, int q) { return m0 + wm + (i / (4 * TN)) * 32 + 4 * lk + 8 * (i & 3) + q; };
-    auto col_of = [&](int i) { return (i / 4) % TN; };
+    constexpr int NT_ = TM * TN;
+    float x[16], xn[16];
+    auto row_of = [&](int i, int r) { return m0 + wm + (i / TN) * 32 + 4 * lk + AIT_ROW(r); };
 #pragma unroll
-    for (int q = 0; q < 4; q++) x[q] = g.residual[cb[col_of(0)] + (unsigned)min(row_of(0, q), g.M - 1) * ldc];
+    for (int r = 0; r < 16; r++) x[r] = g.residual[cb[0] + (unsigned)min(row_of(0, r), g.M - 1) * ldc];
 #pragma unroll
-    for (int i = 0; i < NQ; i++) {
-      const int a = i / (4 * TN), b = col_of(i);
-      if (i + 1 < NQ) {
+    for (int i = 0; i < NT_; i++) {
+      const int a = i / TN, b = i % TN;
+      if (i + 1 < NT_) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) xn[q] = g.residual[cb[col_of(i + 1)] + (unsigned)min(row_of(i + 1, q), g.M - 1) * ldc];
+        for (int r = 0; r < 16; r++) xn[r] = g.residual[cb[(i + 1) % TN] + (unsigned)min(row_of(i + 1, r), g.M - 1) * ldc];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        float v = g.alpha * acc[a][b][4 * (i & 3) + q] + bcol[b];
-        v = mask_pos ? (x[q] > 0.f ? v : 0.f) : v + x[q];
+      for (int r = 0; r < 16; r++) {
+        float v = g.alpha * acc[a][b][r] + bcol[b];
+        v = mask_pos ? (x[r] > 0.f ? v : 0.f) : v + x[r];
         if (relu) v = fmaxf(v, 0.f);
-        const int row = row_of(i, q);
+        const int row = row_of(i, r);
         if (interior || (cok[b] && row < g.M)) g.C[cb[b] + (unsigned)row * ldc] = v;
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 4; q++) x[q] = xn[q];
+      for (int r = 0; r < 16; r++) x[r] = xn[r];
     }
     return;
   }
@@ -449,8 +465,47 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   const int W = gridDim.x / AIT_NXCD;
   const int xcd = blockIdx.x % AIT_NXCD, j = blockIdx.x / AIT_NXCD;
   const int base = xcd * wmap.chunk;
-  const int lim = min(wmap.items - base, wmap.chunk);     // items in this XCD's chunk
-  if (j >= lim) return;
+  const int lim = max(0, min(wmap.items - base, wmap.chunk));     // items in this XCD's chunk
+
+  // ---- work list of this workgroup: [stream-K pieces] [whole items dp0, dp0 + W, ...] ------------------
+  // With a partial-tile workspace (g.sk_ws) the r = lim % W tiles that would form an under-filled last
+  // round are not handed out whole: their r * K/16 slabs are cut into equal contiguous runs, one per
+  // workgroup, done FIRST.  A run covers the tail of one tile and/or the head of the next, so a
+  // workgroup has at most two pieces; the piece that starts a tile (kbeg == 0) owns it: it is that
+  // workgroup's last piece, and after it the owner adds the partial tiles the following workgroups
+  // published (fixed order: results do not depend on timing) and runs the epilogue.  A piece that does
+  // not start its tile is always its workgroup's FIRST piece, so it is published before that workgroup
+  // ever waits: waits only point at higher workgroup ids and cannot form a cycle.
+  constexpr int SK_MIN = 4;          // slabs per run at least
+  int sk_r = 0, sk_total = 0, sk_w = 1, n_sk = 0;
+  int skA_tile = 0, skA_kb = 0, skA_ke = 0, skB_ke = 0;
+  const int ns = g.K / BK;
+  if (g.sk_ws != nullptr) {
+    sk_r = lim % W;
+    sk_total = sk_r * ns;
+    sk_w = max(1, min(W, sk_total / SK_MIN));
+    if (sk_r > 0 && j < sk_w) {
+      const int lo = (int)((long long)j * sk_total / sk_w), hi = (int)((long long)(j + 1) * sk_total / sk_w);
+      skA_tile = lo / ns;
+      const int e0 = min(hi, (skA_tile + 1) * ns);
+      skA_kb = (lo - skA_tile * ns) * BK;
+      skA_ke = (e0 - skA_tile * ns) * BK;
+      n_sk = 1;
+      if (hi > e0) { skB_ke = (hi - e0) * BK; n_sk = 2; }
+    }
+  }
+  const int dp0 = sk_r + j;
+  const int n_items = n_sk + (dp0 < lim ? (lim - dp0 + W - 1) / W : 0);
+  if (n_items == 0) return;
+  // item it -> id within the chunk, K range
+  auto get_item = [&](int it, int& m0, int& n0, int& kb, int& ke) {
+    const int id = it < n_sk ? skA_tile + it : dp0 + (it - n_sk) * W;
+    wmap.decode(g, base + id, BM, BN, m0, n0, kb, ke);
+    if (it < n_sk) {
+      kb = it == 0 ? skA_kb : 0;
+      ke = it == 0 ? skA_ke : skB_ke;
+    }
+  };
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -465,7 +520,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   const float* pb[LB];
   const size_t step_a = AK ? 16 : (size_t)16 * g.lda;
   const size_t step_b = BKC ? 16 : (size_t)16 * g.ldb;
-  int l_item = j, l_k = 0, l_kend = 0;
+  int l_item = 0, l_k = 0, l_kend = 0;
   int l_n0 = 0;                     // column origin of the load cursor's tile (CONV kernels)
   int arow[LA];                     // CONV_A: this lane's (clamped) GEMM row per A transfer
   bool l_valid = true;
@@ -487,9 +542,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       }
     }
   };
-  auto set_tile = [&](int id) {
+  auto set_tile = [&](int it) {
     int m0, n0;
-    wmap.decode(g, base + id, BM, BN, m0, n0, l_k, l_kend);
+    get_item(it, m0, n0, l_k, l_kend);
     l_n0 = n0;
 #pragma unroll
     for (int i = 0; i < LA; i++) {
@@ -549,8 +604,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     }
     l_k += BK;
     if (l_k >= l_kend) {
-      l_item += W;
-      if (l_item < lim) set_tile(l_item);
+      l_item += 1;
+      if (l_item < n_items) set_tile(l_item);
       else l_valid = false;
     } else if (CONV == CONV_A) {
       if (l_k % g.conv.seg == 0) retap();      // next tap: new source rows (and, K-outer weights, new tap base)
@@ -580,9 +635,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   fetch_group<BKC, C::TN, BN>(Bd, wn, li, lk, 0, xb);
   int cur = 0;
 
-  for (int item = j; item < lim; item += W) {
+  for (int item = 0; item < n_items; item++) {
     int m0, n0, kbeg, kend;
-    wmap.decode(g, base + item, BM, BN, m0, n0, kbeg, kend);
+    get_item(item, m0, n0, kbeg, kend);
     f32x16 acc[C::TM][C::TN];
 #pragma unroll
     for (int a = 0; a < C::TM; a++)
@@ -613,12 +668,25 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         // stream (complete in LDS since the last barrier; possibly the first slab of the next tile)
         const float* an_ = As + (grp == 0 ? cur : nxt) * SA;
         const float* bn_ = Bd + (grp == 0 ? cur : nxt) * SB;
-        __builtin_amdgcn_sched_barrier(0);
-        fetch_group<AK, C::TM, BM>(an_, wm, li, lk, grp == 0 ? 1 : 0, na);
-        fetch_group<BKC, C::TN, BN>(bn_, wn, li, lk, grp == 0 ? 1 : 0, nb);
-        __builtin_amdgcn_sched_barrier(0);
+        constexpr bool kSpread = (C::KNOBS & KNOB_SPREAD) != 0;
+        constexpr int kPieces = C::TM + C::TN;
+        if constexpr (!kSpread) {
+          __builtin_amdgcn_sched_barrier(0);
+          fetch_group<AK, C::TM, BM>(an_, wm, li, lk, grp == 0 ? 1 : 0, na);
+          fetch_group<BKC, C::TN, BN>(bn_, wn, li, lk, grp == 0 ? 1 : 0, nb);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
+          if constexpr (kSpread) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pc = j * kPieces / 4; pc < (j + 1) * kPieces / 4; pc++) {
+              if (pc < C::TM) na[pc] = fetch_tile<AK, BM>(an_, wm, li, lk, grp == 0 ? 1 : 0, pc);
+              else nb[pc - C::TM] = fetch_tile<BKC, BN>(bn_, wn, li, lk, grp == 0 ? 1 : 0, pc - C::TM);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int a = 0; a < C::TM; a++)
 #pragma unroll
@@ -665,7 +733,64 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       cur = nxt;
     }
     if constexpr (Probe::on) { c_loop += __builtin_amdgcn_s_memtime() - c0; n_tile++; }
-    epilogue<C::TM, C::TN, EPI>(acc, g, m0, n0, wm, wn, li, lk);
+    bool finish = true;          // this workgroup writes the tile
+    if (item < n_sk && (kbeg != 0 || kend != g.K)) {
+      // Inter-workgroup hand-off in the write-through form: every byte of a partial tile is stored sc1
+      // and read with sc1 loads (per-XCD L2s are not coherent), the flag is an agent-scope word.
+      if (kbeg != 0) {                             // publish
+        finish = false;
+        __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(
+            g.sk_ws + (size_t)blockIdx.x * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+        for (int a = 0; a < C::TM; a++)
+#pragma unroll
+          for (int b = 0; b < C::TN; b++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              u32x4 v;
+              v.x = __float_as_uint(acc[a][b][4 * q]); v.y = __float_as_uint(acc[a][b][4 * q + 1]);
+              v.z = __float_as_uint(acc[a][b][4 * q + 2]); v.w = __float_as_uint(acc[a][b][4 * q + 3]);
+              __builtin_amdgcn_raw_buffer_store_b128(v, ws, (int)threadIdx.x * 16, ((a * C::TN + b) * 4 + q) * C::NT * 16, 16);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains (also the slabs in flight)
+        ring_barrier();
+        if (threadIdx.x == 0)
+          __hip_atomic_store(g.sk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {                                     // own: gather the runs that follow, in workgroup order
+        const int tile_end = (skA_tile + (item == 0 ? 1 : 2)) * ns;      // first slab past this tile
+        for (int jj = j + 1; jj < sk_w; jj++) {
+          if ((int)((long long)jj * sk_total / sk_w) >= tile_end) break;
+          const int peer = jj * AIT_NXCD + xcd;
+          if (threadIdx.x == 0) {
+            while (__hip_atomic_load(g.sk_flags + peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+              __builtin_amdgcn_s_sleep(2);
+            __hip_atomic_store(g.sk_flags + peer, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          ring_barrier();
+          __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(
+              g.sk_ws + (size_t)peer * (BM * BN), 0, BM * BN * 4, 0x00020000);
+          // 16 loads in flight per thread (one round trip per half tile, not one per MFMA tile)
+          constexpr int NQ = C::TM * C::TN * 4, QB = NQ < 16 ? NQ : 16;
+          static_assert(NQ % QB == 0, "partial tile in whole batches");
+#pragma unroll
+          for (int q0 = 0; q0 < NQ; q0 += QB) {
+            u32x4 t[QB];
+#pragma unroll
+            for (int i = 0; i < QB; i++)
+              t[i] = __builtin_amdgcn_raw_buffer_load_b128(ws, (int)threadIdx.x * 16, (q0 + i) * C::NT * 16, 16);
+#pragma unroll
+            for (int i = 0; i < QB; i++) {
+              const int idx = q0 + i, ab = idx >> 2, q = idx & 3;
+              f32x16& d = acc[ab / C::TN][ab % C::TN];
+              d[4 * q] += __uint_as_float(t[i].x); d[4 * q + 1] += __uint_as_float(t[i].y);
+              d[4 * q + 2] += __uint_as_float(t[i].z); d[4 * q + 3] += __uint_as_float(t[i].w);
+            }
+          }
+        }
+      }
+    }
+    if (finish) epilogue<C::TM, C::TN, EPI>(acc, g, m0, n0, wm, wn, li, lk);
     // (the operand quads are dead across the epilogue -- its address arithmetic needs the registers --
     // and are fetched again from the next tile's first slab, complete in LDS since the last barrier)
     __builtin_amdgcn_sched_barrier(0);
@@ -868,6 +993,48 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
 // Resident workgroup slots of the persistent kernel: as many workgroups per CU as its LDS ring allows
 // (160 KB per CU; the product tiles: 72 KB -> 2).  Queried per call (no cached global state); a failed
 // query falls back to the MI355X figure.
+// Stream-K scratch: one partial tile per workgroup + one flag word per workgroup, kept per (device, stream)
+// -- launches on one stream are ordered, so they can share it; two streams never do.  Allocated on first
+// use (the only allocation this library makes; ait_gemm_workspace_release() frees it), flags zeroed once:
+// every flag a launch sets is cleared again by the workgroup that consumes it.
+struct SkWorkspace { float* ws = nullptr; unsigned* flags = nullptr; size_t bytes = 0; int nflags = 0; };
+inline int& stream_k_mode() {          // 1 on, 0 off (AIT_GEMM_STREAMK=0); the lab harness flips it
+  static int mode = [] { const char* e = getenv("AIT_GEMM_STREAMK"); return (e && e[0] == '0') ? 0 : 1; }();
+  return mode;
+}
+struct SkPool {
+  std::mutex mu;
+  std::map<std::pair<int, hipStream_t>, SkWorkspace> pool;
+};
+inline SkPool& sk_pool() { static SkPool p; return p; }
+inline int sk_workspace(hipStream_t s, size_t bytes, int nflags, SkWorkspace& out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return AIT_ELAUNCH;
+  SkPool& p = sk_pool();
+  std::lock_guard<std::mutex> lock(p.mu);
+  SkWorkspace& e = p.pool[std::make_pair(dev, s)];
+  if (e.bytes < bytes || e.nflags < nflags) {
+    if (e.ws) (void)hipFree(e.ws);
+    e = SkWorkspace();
+    const size_t fbytes = ((size_t)nflags * 4 + 255) / 256 * 256;
+    void* mem = nullptr;
+    if (hipMalloc(&mem, bytes + fbytes) != hipSuccess) { (void)hipGetLastError(); return AIT_ELAUNCH; }
+    if (hipMemset((char*)mem + bytes, 0, fbytes) != hipSuccess) { (void)hipFree(mem); return AIT_ELAUNCH; }
+    e.ws = (float*)mem;
+    e.flags = (unsigned*)((char*)mem + bytes);
+    e.bytes = bytes;
+    e.nflags = nflags;
+  }
+  out = e;
+  return AIT_OK;
+}
+inline void sk_release() {
+  SkPool& p = sk_pool();
+  std::lock_guard<std::mutex> lock(p.mu);
+  for (auto& kv : p.pool) if (kv.second.ws) (void)hipFree(kv.second.ws);
+  p.pool.clear();
+}
+
 template <class C>
 inline int stream_slots() {
   int dev = 0, cus = 0;
@@ -883,6 +1050,9 @@ inline int stream_slots() {
 
 template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe, int CONV = CONV_NONE>
 int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
+  GemmArgs gl = g;
+  gl.sk_ws = nullptr;
+  gl.sk_flags = nullptr;
   WorkMap wmap;
   wmap.init(g, C::BM, C::BN);
   unsigned blocks;
@@ -891,7 +1061,24 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
     // persistent: W workgroups per XCD, every one of them gets work (W <= items of the smallest chunk
     // is not required: a workgroup past its chunk's end exits at once)
     if (slots <= 0) slots = stream_slots<C>();
-    const int w = max(1, min(wmap.chunk, slots / AIT_NXCD));
+    int w = max(1, min(wmap.chunk, slots / AIT_NXCD));
+    // stream-K for the tiles of an under-filled last round (see the kernel): worth it unless that round is
+    // nearly full anyway; needs whole 16-float slabs and a reduction long enough to cut
+    // Cost model in slab-times (measured on the lab shapes, scripts/gemm_lab.hip sweep): whole tiles cost
+    // the last round one tile (K/16 slabs) -- about 0.62 of one when at most half the slots are busy, a
+    // workgroup alone on its CU runs faster -- stream-K costs rem/W of a tile plus ~9 slab-times of
+    // publishing and gathering partial tiles.
+    const int wfull = max(1, slots / AIT_NXCD), rem = wmap.chunk % wfull;
+    const double last_round = (rem * 2 <= wfull) ? 0.62 : 1.0;
+    const bool sk_pays = (g.K / 16) * (last_round - (double)rem / wfull) > 9.0;
+    if (EPI != EPI_ATOMIC && g.splits == 1 && g.K % 16 == 0 && rem > 0 && sk_pays && stream_k_mode() != 0) {
+      SkWorkspace sk;
+      if (sk_workspace(s, (size_t)wfull * AIT_NXCD * C::BM * C::BN * sizeof(float), wfull * AIT_NXCD, sk) == AIT_OK) {
+        gl.sk_ws = sk.ws;
+        gl.sk_flags = sk.flags;
+        w = wfull;
+      }
+    }
     blocks = (unsigned)(w * AIT_NXCD);
     kern = reinterpret_cast<const void*>(gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV>);
   } else {
@@ -902,7 +1089,7 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
       hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) != hipSuccess)
     return AIT_ELAUNCH;
   if constexpr (C::MODE == MODE_DLDS)
-    hipLaunchKernelGGL((gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV>), dim3(blocks), dim3(C::NT), C::LDS, s, g);
+    hipLaunchKernelGGL((gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV>), dim3(blocks), dim3(C::NT), C::LDS, s, gl);
   else
     hipLaunchKernelGGL((gemm_f32_kernel<C, AK, BKC, EPI>), dim3(blocks, g.batch > 1 ? g.batch : 1, g.batch2 > 1 ? g.batch2 : 1),
                        dim3(C::NT), C::LDS, s, g);
@@ -954,6 +1141,8 @@ inline int make_args(int trans_a, int trans_b, int M, int N, int K, float alpha,
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.c_colblk = c_colblk; g.c_batch = c_batch_stride; g.alpha = alpha; g.flags = flags;
   g.probe = nullptr;
+  g.sk_ws = nullptr;
+  g.sk_flags = nullptr;
   g.conv = ConvGeom{};
   g.batch = g.batch2 = 1; g.sA = g.sB = g.sC = g.sA2 = g.sB2 = g.sC2 = 0;
   // 32-bit element offsets in the epilogue

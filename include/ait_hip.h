@@ -160,6 +160,17 @@ int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, con
                  const float* residual, int flags, int split_k, int c_colblk,
                  long long c_batch_stride, void* stream);
 
+/* Scratch of the persistent GEMM's stream-K scheduler.  When a product's tile count leaves the last round of
+ * the persistent kernel badly filled (or is smaller than one round: layer4- and co-attention-sized
+ * products), the slabs of those tiles are spread evenly over all workgroups; a workgroup that computes part
+ * of a tile it does not own publishes a partial tile (write-through stores + an agent-scope flag), the
+ * owner adds the partials in a fixed order and runs the epilogue -- results do not depend on timing.  That
+ * needs 64 MiB + 2 KiB of device memory per (device, stream), which the library allocates on the first such
+ * launch on a stream: the ONE allocation this library makes (hipMalloc, so: not while the stream is being
+ * captured).  ait_gemm_workspace_release() frees all of them (streams idle); AIT_GEMM_STREAMK=0 in the
+ * environment keeps the scheduler to whole tiles and the library allocation-free. */
+int ait_gemm_workspace_release(void);
+
 /* Batched form: batch x batch2 independent products, operand (i, j) at base + i*stride + j*stride2 (floats),
  * one launch.  Replaces the three torch.matmul of the COCO variant's image-level co-attention
  *   (lib/model/modules/blocks_coatt_transformer_sk.py:86-110), the per-(image, head) score and P.V products of

@@ -218,6 +218,61 @@ def test_gemm_large_tile_direct_to_lds_epilogues():
     assert torch.allclose(out.double(), want, **tol)
 
 
+def _abs_bound(a, b, ta, tb):
+    return 6e-7 * (a.double().abs().t() if ta else a.double().abs()) @ \
+        (b.double().abs().t() if tb else b.double().abs()) + 1e-6
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [
+    (19200, 512, 2048, False, True),      # layer4 1x1: 300 tiles < one round of 512 -> every tile cut (stream-K only)
+    (9576, 512, 1024, False, False),      # co-attention token product: 152 tiles
+    (76800, 1536, 512, False, True),      # 3600 tiles = 7 rounds + 16 tiles: the 16 are cut 8 ways
+    (58800, 1024, 512, False, True),      # 49-row sequences: 230 x 8 tiles, 38 left per XCD
+    (40000, 512, 1024, False, False),     # ragged last M tile inside a cut tile
+    (2048, 4096, 3072, True, False),      # K-outer A without split-K: 256 tiles of 192 slabs
+])
+def test_gemm_stream_k_work_list(M, N, K, ta, tb):
+    """Tile counts that leave the persistent kernel's last round badly filled: the slabs of those tiles
+    are spread over all workgroups and the owner of each tile adds the published partial tiles in a
+    fixed order (gemm_f32_impl.h) -- same fp32 error fence as whole tiles, bias + ReLU applied once,
+    and bit-identical from launch to launch (no atomics)."""
+    from ait_amd import ops
+    torch.manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), device="cuda")
+    b = torch.randn((N, K) if tb else (K, N), device="cuda")
+    bias = torch.randn(N, device="cuda")
+    c = ops.gemm(a, b, trans_a=ta, trans_b=tb)
+    assert bool(((c.double() - _ref(a, b, ta, tb)).abs() <= _abs_bound(a, b, ta, tb)).all())
+    c2 = ops.gemm(a, b, trans_a=ta, trans_b=tb)
+    assert torch.equal(c, c2)
+    r = ops.gemm(a, b, trans_a=ta, trans_b=tb, bias=bias, relu=True)
+    want = torch.relu(_ref(a, b, ta, tb) + bias.double())
+    assert bool(((r.double() - want).abs() <= _abs_bound(a, b, ta, tb)).all())
+    if not ta:
+        res = torch.randn(M, N, device="cuda")
+        r = ops.gemm(a, b, trans_a=ta, trans_b=tb, residual=res)
+        assert bool(((r.double() - _ref(a, b, ta, tb) - res.double()).abs() <= _abs_bound(a, b, ta, tb)).all())
+
+
+def test_gemm_stream_k_back_to_back_launches_reuse_the_flags():
+    """Every flag a stream-K launch sets is cleared by the workgroup that consumes it: many launches in a
+    row on one stream (different shapes sharing the scratch) stay correct."""
+    from ait_amd import ops
+    torch.manual_seed(5)
+    shapes = [(19200, 512, 2048), (9576, 1024, 512), (19200, 2048, 512), (76800, 1536, 512)]
+    ops_in = [(torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")) for M, N, K in shapes]
+    outs = []
+    for rep in range(3):
+        for a, w in ops_in:
+            outs.append(ops.gemm(a, w, trans_b=True))
+    for i, (a, w) in enumerate(ops_in):
+        want = a.double() @ w.double().t()
+        for rep in range(3):
+            got = outs[rep * len(shapes) + i]
+            assert bool(((got.double() - want).abs() <= _abs_bound(a, w, False, True)).all())
+            assert torch.equal(got, outs[i])
+
+
 def test_batched_gemm_layouts_and_autograd():
     """ait_gemm_f32_batched on the COCO co-attention shapes (blocks_coatt_transformer_sk.py:86-110: 64 query
     tokens x 2394 image tokens x 512 channels) against torch.bmm in float64, forward and through _Bmm's backward;

@@ -33,7 +33,10 @@ AIT_API void* ait_probe_create(int capacity) {
   p->e = new (std::nothrow) AitProbeEntry[capacity];
   if (!p->e) { delete p; return nullptr; }
   for (int i = 0; i < capacity; i++) {
-    if (hipEventCreate(&p->e[i].e0) != hipSuccess || hipEventCreate(&p->e[i].e1) != hipSuccess) {
+    // timing-only events: no system-scope release/acquire fence at the record (the default flavour writes
+    // back and invalidates the caches around the launch it brackets, which slows what is being measured)
+    if (hipEventCreateWithFlags(&p->e[i].e0, hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&p->e[i].e1, hipEventDisableSystemFence) != hipSuccess) {
       p->cap = i;          // what was created is what can be used
       break;
     }

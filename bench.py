@@ -122,6 +122,34 @@ def cpu_baseline(P, seconds_budget=16.0):
     return out
 
 
+def pmc_clock_and_util():
+    """Clock-independent matrix-pipe utilisation and the effective shader clock of the GEMM launches inside
+    this step, from the committed `rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace`
+    pass over this same command (scripts/profile_bench.sh, scripts/pmc_clock.py): the step runs its
+    GEMMs below the 2.4 GHz the 157.3 TFLOP/s peak assumes."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_mfma_util_and_clock.txt")))
+    if not files:
+        return None
+    util, clk, n_clk, in_clock = None, 0.0, 0, False
+    for l in open(files[-1]):
+        m = re.match(r"\s*([\d.]+) % mean over all (\d+) launches", l)
+        if m:
+            util = float(m.group(1)) / 100.0
+        if l.startswith("effective clock"):
+            in_clock = True
+            continue
+        m = re.match(r"\s*([\d.]+) median\s+[\d.]+ min\s+[\d.]+ max\s+n=(\d+)", l)
+        if in_clock and m:
+            clk += float(m.group(1)) * int(m.group(2))
+            n_clk += int(m.group(2))
+    if util is None or n_clk == 0:
+        return None
+    return {"mfma_util": util, "effective_clock_ghz": clk / n_clk, "nominal_clock_ghz": 2.4,
+            "source": "profiles/" + os.path.basename(files[-1])}
+
+
 def pmc_traffic_per_launch(kernel_prefix="gemm_f32_"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
     same command (profiles/pmc_fetch_r*.csv, pmc_write_r*.csv; separate --pmc runs, summarised by
@@ -196,9 +224,13 @@ def main():
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    with probe:
+    if os.environ.get("AIT_BENCH_NO_PROBE") == "1":       # diagnostic: what the event brackets cost the step
         for _ in range(args.steps):
             step()
+    else:
+        with probe:
+            for _ in range(args.steps):
+                step()
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
@@ -227,10 +259,11 @@ def main():
         ms = sum(p[1] for p in ev) / len(ev)
         b = sum(p[0] for p in ev) / len(ev)
         gbs = b / (ms * 1e-3) / 1e9
-        return {"kernel": "roi_align_nhwc_%s_kernel" % tag, "bound": "hbm", "achieved": gbs,
+        return {"kernel": "roi_align_nhwc_fwd_sliced_kernel" if tag == "fwd" else "roi_align_nhwc_bwd_kernel",
+                "bound": "hbm", "achieved": gbs,
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "ms_per_launch": ms,
                 "algorithmic_bytes_per_launch": b, "launches_per_step": len(ev) // max(1, args.steps),
-                "traffic": pmc_traffic_per_launch("roi_align_nhwc_%s_kernel" % tag)}
+                "traffic": pmc_traffic_per_launch("roi_align_nhwc_%s" % tag)}
 
     value = pairs / elapsed
     line = {
@@ -253,7 +286,8 @@ def main():
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak,
                      "traffic": pmc["bytes_per_launch"] if pmc else None,
-                     "traffic_detail": pmc, "algorithmic_bytes_per_launch": alg,
+                     "traffic_detail": pmc, "clock_and_mfma_util": pmc_clock_and_util() if args.dtype == "f32" else None,
+                     "algorithmic_bytes_per_launch": alg,
                      "launches_per_step": len(prof) // max(1, args.steps),
                      "gemm_ms_per_step": gemm_ms / max(1, args.steps),
                      "gemm_gflop_per_step": flops / max(1, args.steps) / 1e9,

@@ -293,6 +293,72 @@ static void mode_sweep(int rounds, int first, int last) {
   }
 }
 
+// The same launch queued continuously for `seconds` (64 launches per timed window, windows back to back
+// with no host gap): does the rate hold once the chip is in its sustained power state?  (The sweep times
+// bursts of 8 launches between host synchronisations.)
+static void mode_sustain(int variant, double seconds, int si) {
+  Problem p;
+  setup(p, SHAPES[si]);
+  const int per = 64, nwin = 256;
+  std::vector<hipEvent_t> ev(nwin + 1);
+  for (auto& e : ev) CK(hipEventCreate(&e));
+  const float one = time_launches(p, variant, p.C, 8);
+  int windows = (int)(seconds * 1000.0 / (one * per)) + 1;
+  if (windows > nwin) windows = nwin;
+  CK(hipEventRecord(ev[0], 0));
+  for (int w = 0; w < windows; w++) {
+    for (int i = 0; i < per; i++) run(p, variant, p.C);
+    CK(hipEventRecord(ev[w + 1], 0));
+  }
+  CK(hipEventSynchronize(ev[windows]));
+  printf("%s variant %s: burst of 8 = %.1f TF; sustained windows of %d launches:\n", p.s.name, VNAMES[variant], tflops(p.s, one), per);
+  for (int w = 0; w < windows; w++) {
+    float ms;
+    CK(hipEventElapsedTime(&ms, ev[w], ev[w + 1]));
+    printf(" %.1f", tflops(p.s, ms / per));
+    if (w % 16 == 15) printf("\n");
+  }
+  printf("\n");
+  teardown(p);
+}
+
+// Each launch timed on its own (events on the stream), (a) back to back, (b) with a memory-bound kernel
+// (a 1-GiB fill, ~0.25 ms) between the launches, (c) with a host synchronisation before every launch --
+// the three situations a GEMM meets inside the model's step.
+static void mode_interleave(int variant, int first, int last) {
+  float* scratch;
+  const size_t nscr = (size_t)256 << 20;
+  CK(hipMalloc(&scratch, nscr * 4));
+  for (int si = first; si < last; si++) {
+    Problem p;
+    setup(p, SHAPES[si]);
+    const int n = 24;
+    std::vector<hipEvent_t> e0(n), e1(n);
+    for (int i = 0; i < n; i++) { CK(hipEventCreate(&e0[i])); CK(hipEventCreate(&e1[i])); }
+    time_launches(p, variant, p.C, 8);
+    double med[3];
+    for (int mode = 0; mode < 3; mode++) {
+      for (int i = 0; i < n; i++) {
+        if (mode == 1) hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, scratch, nscr, (unsigned)i);
+        if (mode == 2) CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0[i], 0));
+        run(p, variant, p.C);
+        CK(hipEventRecord(e1[i], 0));
+      }
+      CK(hipDeviceSynchronize());
+      std::vector<double> t;
+      for (int i = 0; i < n; i++) { float ms; CK(hipEventElapsedTime(&ms, e0[i], e1[i])); t.push_back(tflops(p.s, ms)); }
+      std::sort(t.begin(), t.end());
+      med[mode] = t[n / 2];
+    }
+    printf("%-9s %6d %5d %6d | back-to-back %6.1f | after a 1-GiB fill %6.1f | after a host sync %6.1f  TFLOP/s (median of %d)\n",
+           p.s.name, p.s.M, p.s.N, p.s.K, med[0], med[1], med[2], n);
+    fflush(stdout);
+    teardown(p);
+  }
+  CK(hipFree(scratch));
+}
+
 static void mode_probe(int first, int last) {
   for (int si = first; si < last; si++) {
     Problem p;
@@ -464,6 +530,8 @@ int main(int argc, char** argv) {
   else if (!strcmp(mode, "probe")) mode_probe(first, last);
   else if (!strcmp(mode, "micro")) mode_micro();
   else if (!strcmp(mode, "sweep")) mode_sweep(argc > 2 ? atoi(argv[2]) : 5, first, last);
+  else if (!strcmp(mode, "interleave")) mode_interleave(argc > 2 ? atoi(argv[2]) : 13, first, last);
+  else if (!strcmp(mode, "sustain")) mode_sustain(argc > 2 ? atoi(argv[2]) : 13, argc > 3 ? atof(argv[3]) : 3.0, first);
   else if (!strcmp(mode, "pmc")) mode_pmc(atoi(argv[2]), atoi(argv[3]), argc > 4 ? atoi(argv[4]) : 10);
   else { printf("unknown mode\n"); return 1; }
   return 0;

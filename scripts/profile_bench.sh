@@ -14,7 +14,11 @@ cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c -d "$root/$out/pmc_$c" --output-format csv -- python3 "$root/bench.py" --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> "$root/$out/pmc_$c.err"
 done
+timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -d "$root/$out/pmc_clock" --output-format csv -- python3 "$root/bench.py" --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2> "$root/$out/pmc_clock.err"
 cd "$root"
+python3 scripts/pmc_clock.py "$out/pmc_clock" gemm_f32_stream > "$out/${tag}_gemm_mfma_util_and_clock.txt" 2>&1
+python3 scripts/pmc_clock.py "$out/pmc_clock" gemm_f32_stream list | awk 'f && $3 > 100; /effective clock/ {f=1}' | tail -330 > "$out/${tag}_effective_clock_per_dispatch.txt" 2>&1
+rm -rf "$out/pmc_clock"
 python3 scripts/pmc_summary.py "$out/pmc_FETCH_SIZE" "$out/pmc_fetch_${tag}.csv" > /dev/null 2>&1
 python3 scripts/pmc_summary.py "$out/pmc_WRITE_SIZE" "$out/pmc_write_${tag}.csv" > /dev/null 2>&1
 rm -rf "$out/trace" "$out/pmc_FETCH_SIZE" "$out/pmc_WRITE_SIZE"

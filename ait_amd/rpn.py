@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .config import cfg
+from . import _lib
 from .roi_layers import nms_sorted_batched
 
 
@@ -155,6 +156,11 @@ class _ProposalLayer(nn.Module):
 
     def forward(self, input):
         probs, deltas, im_info, cfg_key = input
+        return self._run(probs, deltas, im_info, cfg_key)
+
+    def _run(self, probs, deltas, im_info, cfg_key):
+        if probs.is_cuda and probs.dtype == torch.float32:
+            return self._run_hip(probs, deltas, im_info, cfg_key)
         A = self._num_anchors
         pre_n = cfg[cfg_key].RPN_PRE_NMS_TOP_N
         post_n = cfg[cfg_key].RPN_POST_NMS_TOP_N
@@ -179,6 +185,40 @@ class _ProposalLayer(nn.Module):
         out[:, :, 1:] = torch.where(live.unsqueeze(2), sel, torch.zeros_like(sel))
         out[:, :, 0] = torch.arange(b, device=scores.device, dtype=scores.dtype).unsqueeze(1)
         return out
+
+
+    def _run_hip(self, probs, deltas, im_info, cfg_key):
+        """the same layer on the library's kernels: decode + clip + score re-layout in one launch, sort,
+        gather, batched NMS, assembly in one launch (include/ait_hip.h "Box arithmetic")"""
+        A = self._num_anchors
+        pre_n = cfg[cfg_key].RPN_PRE_NMS_TOP_N
+        post_n = cfg[cfg_key].RPN_POST_NMS_TOP_N
+        thr = cfg[cfg_key].RPN_NMS_THRESH
+        b, _, H, W = deltas.shape
+        dev = probs.device
+        probs, deltas = probs.contiguous(), deltas.contiguous()      # NCHW, as the RPN head's convolutions leave them
+        im_info = im_info.to(torch.float32).contiguous()
+        anchors = self._grid.get(H, W, dev)
+        N = H * W * A
+        boxes = torch.empty((b, N, 4), dtype=torch.float32, device=dev)
+        scores = torch.empty((b, N), dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            st = _lib.cur_stream(dev)
+            _lib.check(L.ait_rpn_decode(_lib.dev_ptr(probs), _lib.dev_ptr(deltas), _lib.dev_ptr(anchors),
+                                        _lib.dev_ptr(im_info), b, A, H, W, _lib.dev_ptr(boxes), _lib.dev_ptr(scores), st),
+                       "ait_rpn_decode")
+            order = torch.sort(scores, 1, True)[1]
+            if 0 < pre_n < scores.numel():          # (the reference compares with numel of the batch)
+                order = order[:, :pre_n]
+            cand = torch.gather(boxes, 1, order.unsqueeze(2).expand(-1, -1, 4)).contiguous()   # [b, n, 4]
+            n = cand.size(1)
+            keep, n_keep = nms_sorted_batched(cand, thr, post_n)          # one launch pair, no sync
+            out = torch.empty((b, post_n, 5), dtype=torch.float32, device=dev)
+            _lib.check(L.ait_proposals_assemble(_lib.dev_ptr(cand), n, _lib.dev_ptr(keep, torch.int64), keep.stride(0),
+                                                keep.size(1), _lib.dev_ptr(n_keep, torch.int32), b, post_n,
+                                                _lib.dev_ptr(out), st), "ait_proposals_assemble")
+        return out.to(probs.dtype)
 
 
 # ------------------------------------------------------------------------------------------
@@ -339,30 +379,22 @@ class _ProposalTargetLayer(nn.Module):
     def forward(self, all_rois, gt_boxes, num_boxes):
         dev, dt = gt_boxes.device, gt_boxes.dtype
         b = gt_boxes.size(0)
-        gt_as_rois = torch.zeros_like(gt_boxes)
-        gt_as_rois[:, :, 1:5] = gt_boxes[:, :, :4]
-        all_rois = torch.cat([all_rois, gt_as_rois], 1)
         P = int(cfg.TRAIN.BATCH_SIZE)
         fg_per_image = int(np.round(cfg.TRAIN.FG_FRACTION * P)) or 1
-
-        overlaps = bbox_overlaps_batch(all_rois, gt_boxes)
-        max_ov, assign = overlaps.max(2)
-        labels = torch.gather(gt_boxes[:, :, 4], 1, assign)
+        gpu = dev.type == "cuda"
+        hip = gpu and all_rois.dtype == torch.float32 and gt_boxes.dtype == torch.float32
+        if hip:
+            all_rois, assign, labels, counts, fg_members, bg_members = self._classify_hip(all_rois, gt_boxes)
+        else:
+            all_rois, assign, labels, counts, fg_members, bg_members = self._classify(all_rois, gt_boxes)
 
         # ---- sampling: the host needs only the two class sizes per image to make the reference's RNG calls
         # (index parity); which RoIs the drawn positions denote is resolved on the device -------------
-        fg_mask = max_ov >= cfg.TRAIN.FG_THRESH
-        bg_mask = (max_ov < cfg.TRAIN.BG_THRESH_HI) & (max_ov >= cfg.TRAIN.BG_THRESH_LO)
-        counts = torch.stack((fg_mask.sum(1), bg_mask.sum(1)), 1)
-        host = torch.empty((b, 2), dtype=torch.int64, pin_memory=True) if dev.type == "cuda" else None
-        if host is not None:
+        if gpu:
+            host = torch.empty((b, 2), dtype=torch.int64, pin_memory=True)
             host.copy_(counts, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
-        # (enqueued while the counts travel) class member lists in ascending RoI order
-        fg_members = torch.sort((~fg_mask).to(torch.uint8), dim=1, stable=True)[1]
-        bg_members = torch.sort((~bg_mask).to(torch.uint8), dim=1, stable=True)[1]
-        if host is not None:
             ev.synchronize()
             cnt = host.numpy()
         else:
@@ -385,7 +417,81 @@ class _ProposalTargetLayer(nn.Module):
                 raise ValueError("bg_num_rois = 0 and fg_num_rois = 0, this should not happen!")
             n_fg[i] = k
         pos_t = torch.from_numpy(pos).to(dev, non_blocking=True)
-        is_fg = torch.arange(P, device=dev).unsqueeze(0) < torch.from_numpy(n_fg).to(dev, non_blocking=True).unsqueeze(1)
+        n_fg_t = torch.from_numpy(n_fg).to(dev, non_blocking=True)
+        if hip:
+            return self._gather_hip(pos_t, n_fg_t, fg_members, bg_members, labels, all_rois, assign, gt_boxes)
+        return self._gather(pos_t, n_fg_t, fg_members, bg_members, labels, all_rois, assign, gt_boxes)
+
+    def _classify_hip(self, rois, gt_boxes):
+        """_classify in one launch (ait_roi_classify)"""
+        dev = gt_boxes.device
+        rois, gt = rois.contiguous(), gt_boxes.contiguous()
+        b, R0, G = gt.size(0), rois.size(1), gt.size(1)
+        R = R0 + G
+        all_rois = torch.empty((b, R, 5), dtype=torch.float32, device=dev)
+        assign = torch.empty((b, R), dtype=torch.int64, device=dev)
+        labels = torch.empty((b, R), dtype=torch.float32, device=dev)
+        counts = torch.empty((b, 2), dtype=torch.int64, device=dev)
+        fg_members = torch.empty((b, R), dtype=torch.int64, device=dev)
+        bg_members = torch.empty((b, R), dtype=torch.int64, device=dev)
+        L = _lib.lib()
+        ws_bytes = L.ait_roi_classify_workspace_bytes(b, R0, G)
+        ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.ait_roi_classify(_lib.dev_ptr(rois), b, R0, _lib.dev_ptr(gt), G, gt.size(2),
+                                    float(cfg.TRAIN.FG_THRESH), float(cfg.TRAIN.BG_THRESH_HI), float(cfg.TRAIN.BG_THRESH_LO),
+                                    _lib.dev_ptr(ws, torch.uint8), ws_bytes, _lib.dev_ptr(all_rois),
+                                    _lib.dev_ptr(assign, torch.int64), _lib.dev_ptr(labels), _lib.dev_ptr(counts, torch.int64),
+                                    _lib.dev_ptr(fg_members, torch.int64), _lib.dev_ptr(bg_members, torch.int64),
+                                    _lib.cur_stream(dev))
+        _lib.check(rc, "ait_roi_classify")
+        return all_rois, assign, labels, counts, fg_members, bg_members
+
+    def _gather_hip(self, pos_t, n_fg_t, fg_members, bg_members, labels, all_rois, assign, gt_boxes):
+        """_gather in one launch (ait_roi_sample_gather)"""
+        import ctypes
+        dev = gt_boxes.device
+        gt = gt_boxes.contiguous()
+        b, P = pos_t.shape
+        R, G = all_rois.size(1), gt.size(1)
+        rois_b = torch.empty((b, P, 5), dtype=torch.float32, device=dev)
+        labels_b = torch.empty((b, P), dtype=torch.float32, device=dev)
+        targets = torch.empty((b, P, 4), dtype=torch.float32, device=dev)
+        inside_w = torch.empty((b, P, 4), dtype=torch.float32, device=dev)
+        outside_w = torch.empty((b, P, 4), dtype=torch.float32, device=dev)
+        f4 = ctypes.c_float * 4
+        with torch.cuda.device(dev):
+            rc = _lib.lib().ait_roi_sample_gather(
+                _lib.dev_ptr(pos_t.contiguous(), torch.int64), _lib.dev_ptr(n_fg_t.contiguous(), torch.int64), b, P, R,
+                _lib.dev_ptr(fg_members, torch.int64), _lib.dev_ptr(bg_members, torch.int64), _lib.dev_ptr(labels),
+                _lib.dev_ptr(all_rois), _lib.dev_ptr(assign, torch.int64), _lib.dev_ptr(gt), G, gt.size(2),
+                f4(*[float(v) for v in cfg.TRAIN.BBOX_NORMALIZE_MEANS]), f4(*[float(v) for v in cfg.TRAIN.BBOX_NORMALIZE_STDS]),
+                f4(*[float(v) for v in cfg.TRAIN.BBOX_INSIDE_WEIGHTS]), int(bool(cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED)),
+                _lib.dev_ptr(rois_b), _lib.dev_ptr(labels_b), _lib.dev_ptr(targets), _lib.dev_ptr(inside_w),
+                _lib.dev_ptr(outside_w), _lib.cur_stream(dev))
+        _lib.check(rc, "ait_roi_sample_gather")
+        return rois_b, labels_b, targets, inside_w, outside_w
+
+    def _classify(self, all_rois, gt_boxes):
+        """RoIs (+ the gt boxes as RoIs) -> best gt per RoI, its class, the fg / bg class sizes per image and
+        the class member lists in ascending RoI order (stable sort of the class mask: no data-dependent shape)"""
+        gt_as_rois = torch.zeros_like(gt_boxes)
+        gt_as_rois[:, :, 1:5] = gt_boxes[:, :, :4]
+        all_rois = torch.cat([all_rois, gt_as_rois], 1)
+        overlaps = bbox_overlaps_batch(all_rois, gt_boxes)
+        max_ov, assign = overlaps.max(2)
+        labels = torch.gather(gt_boxes[:, :, 4], 1, assign)
+        fg_mask = max_ov >= cfg.TRAIN.FG_THRESH
+        bg_mask = (max_ov < cfg.TRAIN.BG_THRESH_HI) & (max_ov >= cfg.TRAIN.BG_THRESH_LO)
+        counts = torch.stack((fg_mask.sum(1), bg_mask.sum(1)), 1)
+        fg_members = torch.sort((~fg_mask).to(torch.uint8), dim=1, stable=True)[1]
+        bg_members = torch.sort((~bg_mask).to(torch.uint8), dim=1, stable=True)[1]
+        return all_rois, assign, labels, counts, fg_members, bg_members
+
+    def _gather(self, pos_t, n_fg_t, fg_members, bg_members, labels, all_rois, assign, gt_boxes):
+        dev, dt = gt_boxes.device, gt_boxes.dtype
+        b, P = pos_t.shape
+        is_fg = torch.arange(P, device=dev).unsqueeze(0) < n_fg_t.unsqueeze(1)
         keep_t = torch.where(is_fg, torch.gather(fg_members, 1, pos_t), torch.gather(bg_members, 1, pos_t))
 
         labels_b = torch.gather(labels, 1, keep_t) * is_fg.to(dt)
@@ -396,16 +502,26 @@ class _ProposalTargetLayer(nn.Module):
 
         targets = bbox_transform_batch(rois_b[:, :, 1:5], gt_b[:, :, :4])
         if cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED:
-            means = torch.tensor(cfg.TRAIN.BBOX_NORMALIZE_MEANS, device=dev, dtype=dt)
-            stds = torch.tensor(cfg.TRAIN.BBOX_NORMALIZE_STDS, device=dev, dtype=dt)
-            targets = (targets - means) / stds
+            targets = (targets - _const(cfg.TRAIN.BBOX_NORMALIZE_MEANS, dev, dt)) / _const(cfg.TRAIN.BBOX_NORMALIZE_STDS, dev, dt)
         pos = (labels_b > 0).unsqueeze(2).to(dt)
         # an image whose sampled labels sum to zero gets no regression targets at all
         pos = pos * (labels_b.sum(1) != 0).view(b, 1, 1).to(dt)
         bbox_targets = targets * pos
-        inside_w = pos * torch.tensor(cfg.TRAIN.BBOX_INSIDE_WEIGHTS, device=dev, dtype=dt)
+        inside_w = pos * _const(cfg.TRAIN.BBOX_INSIDE_WEIGHTS, dev, dt)
         outside_w = (inside_w > 0).to(dt)
         return rois_b, labels_b, bbox_targets, inside_w, outside_w
+
+
+_CONSTS = {}
+
+
+def _const(values, dev, dt):
+    """small config vectors as device tensors, uploaded once (an upload inside a graph capture is not allowed)"""
+    key = (tuple(float(v) for v in values), str(dev), dt)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(key[0], device=dev, dtype=dt)
+    return t
 
 
 class _RPN(nn.Module):
@@ -449,8 +565,8 @@ class _RPN(nn.Module):
             labels, targets, w_in, w_out = self.RPN_anchor_target((cls_score.data, gt_boxes, im_info, num_boxes))
             logits = score_2.permute(0, 2, 3, 1).reshape(-1, 2)
             labels = labels.view(-1)
-            keep = torch.nonzero(labels != -1).view(-1)
-            self.rpn_loss_cls = F.cross_entropy(logits.index_select(0, keep),
-                                                labels.index_select(0, keep).long())
+            # (the reference selects the labelled anchors with nonzero() + index_select, a host synchronisation;
+            # the mean over the same anchors without one)
+            self.rpn_loss_cls = F.cross_entropy(logits, labels.long(), ignore_index=-1)
             self.rpn_loss_box = _smooth_l1_loss(bbox_pred, targets, w_in, w_out, sigma=3, dim=[1, 2, 3])
         return rois, self.rpn_loss_cls, self.rpn_loss_box

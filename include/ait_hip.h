@@ -123,6 +123,44 @@ int ait_nms_batched(const float* boxes, int batch, int n, float thr, int max_kee
                     long long keep_stride, int32_t* n_keep, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Box arithmetic of the proposal layer and the proposal-target layer, one launch per stage (SURVEY 8 rows
+ * a12 / a13 / f2).  Each entry replaces a chain of 15-40 elementwise / gather tensor expressions of the
+ * reference; all are written in the reference's fp32 operation order (built with -ffp-contract=off), so
+ * clipping, IoU thresholds and class membership see the same values.
+ *
+ * ait_rpn_decode         lib/model/rpn/proposal_layer.py:66-117 + bbox_transform.py:74-117
+ *   (bbox_transform_inv, clip_boxes): probs [b,2A,H,W] (softmax output; channel A+a = fg score of anchor
+ *   a), deltas [b,4A,H,W] (channel 4a+c), anchors [H*W*A,4] in (h, w, a) order, im_info [b,3] = (height,
+ *   width, scale)  ->  boxes [b,H*W*A,4] clipped to the image, scores [b,H*W*A].
+ * ait_proposals_assemble proposal_layer.py:150-160: survivors keep[i][0 .. n_keep[i]) of the sorted candidates
+ *   cand [b,n,4]  ->  out [b,post_n,5] = (image index, box), zero boxes after the last survivor.
+ * ait_roi_classify       proposal_target_layer_cascade.py:49-52,128-150 + bbox_transform.py:167-211:
+ *   rois [b,R0,5] and gt [b,G,gt_cols>=5] (x1,y1,x2,y2,class)  ->  all_rois [b,R0+G,5] (the gt boxes appended
+ *   as RoIs), assign [b,R] (best gt, first maximum; zero-area gt -> IoU 0, zero-area RoI -> -1), labels [b,R],
+ *   counts [b,2] = (#fg: IoU >= fg_thresh, #bg: bg_lo <= IoU < bg_hi) -- the only numbers the reference's
+ *   host-side RNG calls need -- and fg_members / bg_members [b,R]: the class members in ascending RoI order,
+ *   followed by the non-members (what a stable sort of the class mask yields).
+ * ait_roi_sample_gather  proposal_target_layer_cascade.py:86-126,160-213: sample s of image i is member
+ *   pos[i][s] of the fg class if s < n_fg[i], else of the bg class  ->  rois_b [b,P,5], labels_b [b,P] (0 for
+ *   bg), bbox_targets [b,P,4] ((t - mean) / std when normalize), inside / outside weights [b,P,4]; an image
+ *   whose sampled labels are all 0 gets no regression targets.  means / stds / inside_weights: HOST arrays of 4.
+ * ------------------------------------------------------------------------------------- */
+int ait_rpn_decode(const float* probs, const float* deltas, const float* anchors, const float* im_info, int b,
+                   int A, int H, int W, float* boxes, float* scores, void* stream);
+int ait_proposals_assemble(const float* cand, int n, const int64_t* keep, long long keep_stride, int keep_cols,
+                           const int32_t* n_keep, int b, int post_n, float* out, void* stream);
+size_t ait_roi_classify_workspace_bytes(int b, int R0, int G);
+int ait_roi_classify(const float* rois, int b, int R0, const float* gt, int G, int gt_cols, float fg_thresh,
+                     float bg_thresh_hi, float bg_thresh_lo, void* workspace, size_t workspace_bytes,
+                     float* all_rois, int64_t* assign, float* labels, int64_t* counts, int64_t* fg_members,
+                     int64_t* bg_members, void* stream);
+int ait_roi_sample_gather(const int64_t* pos, const int64_t* n_fg, int b, int P, int R, const int64_t* fg_members,
+                          const int64_t* bg_members, const float* labels, const float* all_rois,
+                          const int64_t* assign, const float* gt, int G, int gt_cols, const float* means,
+                          const float* stds, const float* inside_weights, int normalize, float* rois_b,
+                          float* labels_b, float* bbox_targets, float* inside_w, float* outside_w, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32
  * accumulate).  Replaces the ATen matmul / addmm / 1x1-conv calls behind
  *   nn.Linear w_qs/w_ks/w_vs/fc      lib/model/system/SubLayers.py:51-58,77-79,97

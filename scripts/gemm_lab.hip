@@ -7,6 +7,7 @@
 //     scripts/_gemm_lab pmc <shape> <variant> [n]   n launches of one variant (for rocprofv3 --pmc)
 // The round-1 kernel comes from the history (81edb57), extracted by the build script into
 // /tmp/ait_old_gemm_f32_impl.h with its namespace renamed; without it (-DNO_OLD) only the current one runs.
+#include <unistd.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -336,11 +337,13 @@ static void mode_interleave(int variant, int first, int last) {
     std::vector<hipEvent_t> e0(n), e1(n);
     for (int i = 0; i < n; i++) { CK(hipEventCreate(&e0[i])); CK(hipEventCreate(&e1[i])); }
     time_launches(p, variant, p.C, 8);
-    double med[3];
-    for (int mode = 0; mode < 3; mode++) {
+    double med[5];
+    for (int mode = 0; mode < 5; mode++) {
       for (int i = 0; i < n; i++) {
         if (mode == 1) hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, scratch, nscr, (unsigned)i);
-        if (mode == 2) CK(hipDeviceSynchronize());
+        if (mode >= 2) CK(hipDeviceSynchronize());
+        if (mode == 3) usleep(500);          // GPU idle for 0.5 ms / 3 ms before the launch
+        if (mode == 4) usleep(3000);
         CK(hipEventRecord(e0[i], 0));
         run(p, variant, p.C);
         CK(hipEventRecord(e1[i], 0));
@@ -351,8 +354,8 @@ static void mode_interleave(int variant, int first, int last) {
       std::sort(t.begin(), t.end());
       med[mode] = t[n / 2];
     }
-    printf("%-9s %6d %5d %6d | back-to-back %6.1f | after a 1-GiB fill %6.1f | after a host sync %6.1f  TFLOP/s (median of %d)\n",
-           p.s.name, p.s.M, p.s.N, p.s.K, med[0], med[1], med[2], n);
+    printf("%-9s %6d %5d %6d | back-to-back %6.1f | after a 1-GiB fill %6.1f | after a host sync %6.1f | after 0.5 ms idle %6.1f | after 3 ms idle %6.1f  TFLOP/s (median of %d)\n",
+           p.s.name, p.s.M, p.s.N, p.s.K, med[0], med[1], med[2], med[3], med[4], n);
     fflush(stdout);
     teardown(p);
   }

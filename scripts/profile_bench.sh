@@ -9,6 +9,7 @@ cd "$root"
 python3 scripts/trace_stats.py "$out/trace" 2 5 "$out/${tag}_timed_region_kernel_stats.csv" > /dev/null 2>&1
 python3 scripts/trace_categories.py "$out/${tag}_timed_region_kernel_stats.csv" 5 > "$out/${tag}_categories.txt" 2>&1
 python3 scripts/trace_gaps.py "$out/trace" 2 5 20 >> "$out/${tag}_categories.txt" 2>&1
+python3 scripts/trace_timeline.py "$out/trace" 2 5 > "$out/${tag}_step_timeline.txt" 2>&1
 cp $(find "$out/trace" -name "*kernel_stats.csv" | head -1) "$out/${tag}_full_run_kernel_stats.csv" 2>/dev/null
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -383,3 +383,69 @@ def test_layer4_block_on_hip_convolutions_matches_miopen():
     assert set(outs[True][2]) == set(outs[False][2]) == {"conv1.weight", "conv2.weight", "conv3.weight"}
     for k in outs[False][2]:
         assert rel(outs[True][2][k], outs[False][2][k]) < 1e-3, k
+
+
+def test_box_kernels_equal_the_tensor_expressions():
+    """ait_rpn_decode / ait_proposals_assemble / ait_roi_classify / ait_roi_sample_gather against the tensor
+    expressions they replace (ait_amd/rpn.py: the reference's formulas op by op): bit-identical boxes, scores,
+    class sizes, member lists, sampled RoIs and weights; regression targets to the last ulp of log()."""
+    from ait_amd.config import cfg
+    from ait_amd.rpn import _ProposalLayer, _ProposalTargetLayer
+    torch.manual_seed(21)
+    b, A, H, W = 3, 9, 19, 25
+    pl = _ProposalLayer(16, [8, 16, 32], [0.5, 1, 2])
+    probs = torch.softmax(torch.randn(b, 2, A * H, W, device="cuda"), 1).view(b, 2 * A, H, W)
+    deltas = (torch.randn(b, 4 * A, H, W, device="cuda") * 0.5).contiguous(memory_format=torch.channels_last)
+    info = torch.tensor([[300.0, 400.0, 1.0]] * b, device="cuda")
+    for key in ("TRAIN", "TEST"):
+        got = pl._run_hip(probs, deltas, info, key)
+        # the tensor-expression path (what _run does for non-fp32 / CPU tensors), forced on the same inputs
+        A_ = pl._num_anchors
+        import ait_amd.rpn as R
+        scores = probs[:, A_:].permute(0, 2, 3, 1).reshape(b, -1)
+        d = deltas.permute(0, 2, 3, 1).reshape(b, -1, 4)
+        boxes = R.clip_boxes(R.bbox_transform_inv(pl._grid.get(H, W, probs.device).unsqueeze(0), d), info)
+        order = torch.sort(scores, 1, True)[1][:, :cfg[key].RPN_PRE_NMS_TOP_N]
+        cand = torch.gather(boxes, 1, order.unsqueeze(2).expand(-1, -1, 4)).contiguous()
+        from ait_amd.roi_layers import nms_sorted_batched
+        keep, n_keep = nms_sorted_batched(cand, cfg[key].RPN_NMS_THRESH, cfg[key].RPN_POST_NMS_TOP_N)
+        post_n = cfg[key].RPN_POST_NMS_TOP_N
+        want = torch.zeros(b, post_n, 5, device="cuda")
+        for i in range(b):
+            k = int(n_keep[i])
+            want[i, :, 0] = i
+            want[i, :k, 1:] = cand[i, keep[i, :k]]
+        assert torch.equal(got, want), key
+
+    ptl = _ProposalTargetLayer(2)
+    R0, G = 500, 20
+    rois = torch.zeros(b, R0, 5, device="cuda")
+    xy = torch.rand(b, R0, 2, device="cuda") * 300
+    wh = torch.rand(b, R0, 2, device="cuda") * 120
+    rois[:, :, 1:3] = xy.round()
+    rois[:, :, 3:5] = (xy + wh).round()
+    rois[:, ::37, 3:5] = rois[:, ::37, 1:3]                 # zero-area RoIs (IoU -1)
+    rois[:, :, 0] = torch.arange(b, device="cuda").view(b, 1)
+    gt = torch.zeros(b, G, 5, device="cuda")                # rows past the real boxes stay zero (zero area)
+    for i in range(b):
+        n = 2 + i
+        gt[i, :n, :4] = rois[i, 5:5 + n, 1:5] + torch.tensor([3.0, -2.0, 4.0, 1.0], device="cuda")
+        gt[i, :n, 4] = 1
+    rois[:, 100, 1:5] = gt[:, 0, :4]                        # an exact hit (IoU 1) and ...
+    rois[:, 101, 1:5] = gt[:, 0, :4]                        # ... a duplicate of it
+    want = ptl._classify(rois, gt)
+    got = ptl._classify_hip(rois, gt)
+    names = ["all_rois", "assign", "labels", "counts", "fg_members", "bg_members"]
+    for nme, a, w in zip(names, got, want):
+        assert torch.equal(a, w.to(a.dtype)), nme
+    assert int(got[3][:, 0].min()) > 0
+    for P in (128, 300):
+        pos = torch.stack([torch.randint(0, int(got[3][i].min()), (P,), device="cuda") for i in range(b)])
+        n_fg = torch.tensor([32, 0, P], device="cuda")[:b]
+        w = ptl._gather(pos, n_fg, *got[4:6], got[2], got[0], got[1], gt)
+        h = ptl._gather_hip(pos, n_fg, *got[4:6], got[2], got[0], got[1], gt)
+        for nme, a, ww in zip(["rois", "labels", "targets", "inside", "outside"], h, w):
+            if nme == "targets":
+                assert torch.allclose(a, ww, rtol=2e-6, atol=1e-7), nme
+            else:
+                assert torch.equal(a, ww), nme

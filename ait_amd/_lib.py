@@ -35,6 +35,9 @@ SIGNATURES = {
     "ait_nms_batched": (_i, [_vp, _i, _i, _f, _i, _vp, _sz, _vp, _ll, _vp, _vp]),
     "ait_rpn_decode": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ait_proposals_assemble": (_i, [_vp, _i, _vp, _ll, _i, _vp, _i, _i, _vp, _vp]),
+    "ait_anchor_classify": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ait_anchor_targets": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp,
+                                _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ait_roi_classify_workspace_bytes": (_sz, [_i, _i, _i]),
     "ait_roi_classify": (_i, [_vp, _i, _i, _vp, _i, _i, _f, _f, _f, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ait_roi_sample_gather": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,

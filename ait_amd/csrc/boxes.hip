@@ -202,6 +202,154 @@ __global__ __launch_bounds__(256) void roi_sample_gather_kernel(
   }
 }
 
+// ---- anchor-target layer (lib/model/rpn/anchor_target_layer.py:55-187) ------------------------------------
+// IoU of one inside anchor against the image's gt boxes (bbox_transform.py:119-165: zero-area gt -> 0)
+__device__ __forceinline__ float anchor_iou(const float4 an, float a_area, const float* g /* x1 y1 x2 y2 area flag */) {
+  float iw = fminf(an.z, g[2]) - fmaxf(an.x, g[0]) + 1.0f;
+  float ih = fminf(an.w, g[3]) - fmaxf(an.y, g[1]) + 1.0f;
+  iw = fmaxf(iw, 0.0f); ih = fmaxf(ih, 0.0f);
+  const float inter = iw * ih;
+  float ov = inter / (a_area + g[4] - inter);
+  if (g[5] != 0.0f) ov = 0.0f;
+  return ov;
+}
+__device__ __forceinline__ void load_gts(const float* g_img, int G, int gt_cols, float* gts) {
+  for (int k = threadIdx.x; k < G; k += blockDim.x) {
+    const float x1 = g_img[k * gt_cols], y1 = g_img[k * gt_cols + 1], x2 = g_img[k * gt_cols + 2], y2 = g_img[k * gt_cols + 3];
+    const float gw = x2 - x1 + 1.0f, gh = y2 - y1 + 1.0f;
+    float* g = gts + k * 6;
+    g[0] = x1; g[1] = y1; g[2] = x2; g[3] = y2; g[4] = gw * gh; g[5] = (gw == 1.0f && gh == 1.0f) ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+}
+
+// pass 1: best gt per anchor, and the best overlap per gt box over all anchors (IoU >= 0: its fp32 bits order
+// like the values, so an integer atomicMax is the float maximum)
+__global__ __launch_bounds__(256) void anchor_iou_kernel(const float* __restrict__ anchors, int n_in, const float* __restrict__ gt,
+                                                         int G, int gt_cols, float* __restrict__ max_ov,
+                                                         int64_t* __restrict__ argmax, int* __restrict__ gt_max_bits) {
+  extern __shared__ float gts[];
+  const int img = blockIdx.y;
+  load_gts(gt + (size_t)img * G * gt_cols, G, gt_cols, gts);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_in) return;
+  const float4 an = reinterpret_cast<const float4*>(anchors)[i];
+  const float a_area = (an.z - an.x + 1.0f) * (an.w - an.y + 1.0f);
+  float best = 0.0f;
+  int arg = 0;
+  for (int k = 0; k < G; k++) {
+    const float ov = anchor_iou(an, a_area, gts + k * 6);
+    if (k == 0 || ov > best) { best = ov; arg = k; }
+    if (ov > 0.0f) atomicMax(gt_max_bits + img * G + k, __float_as_int(ov));
+  }
+  max_ov[(size_t)img * n_in + i] = best;
+  argmax[(size_t)img * n_in + i] = arg;
+}
+
+// pass 2: labels (anchor_target_layer.py:106-124) and the two class sizes per image
+__global__ __launch_bounds__(256) void anchor_label_kernel(const float* __restrict__ anchors, int n_in, const float* __restrict__ gt,
+                                                           int G, int gt_cols, const float* __restrict__ max_ov,
+                                                           const int* __restrict__ gt_max_bits, float neg_thr, float pos_thr,
+                                                           int clobber, float* __restrict__ labels, int64_t* __restrict__ counts) {
+  extern __shared__ float gts[];
+  __shared__ int n1, n0;
+  const int img = blockIdx.y;
+  if (threadIdx.x == 0) { n1 = 0; n0 = 0; }
+  load_gts(gt + (size_t)img * G * gt_cols, G, gt_cols, gts);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_in) {
+    const float4 an = reinterpret_cast<const float4*>(anchors)[i];
+    const float a_area = (an.z - an.x + 1.0f) * (an.w - an.y + 1.0f);
+    const float mo = max_ov[(size_t)img * n_in + i];
+    float lab = -1.0f;
+    if (!clobber && mo < neg_thr) lab = 0.0f;
+    bool is_best = false;
+    for (int k = 0; k < G; k++) {
+      float gm = __int_as_float(gt_max_bits[img * G + k]);
+      if (gm == 0.0f) gm = 1e-5f;
+      is_best |= (anchor_iou(an, a_area, gts + k * 6) == gm);
+    }
+    if (is_best) lab = 1.0f;
+    if (mo >= pos_thr) lab = 1.0f;
+    if (clobber && mo < neg_thr) lab = 0.0f;
+    labels[(size_t)img * n_in + i] = lab;
+    if (lab == 1.0f) atomicAdd(&n1, 1);
+    if (lab == 0.0f) atomicAdd(&n0, 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (n1) atomicAdd(reinterpret_cast<unsigned long long*>(counts + img * 2), (unsigned long long)n1);
+    if (n0) atomicAdd(reinterpret_cast<unsigned long long*>(counts + img * 2 + 1), (unsigned long long)n0);
+  }
+}
+
+// class member lists in ascending anchor order (members only; one workgroup per image)
+__global__ __launch_bounds__(kClsThreads) void anchor_members_kernel(const float* __restrict__ labels, int n_in,
+                                                                     int* __restrict__ fg_members, int* __restrict__ bg_members) {
+  __shared__ int scan[kClsThreads];
+  const int img = blockIdx.x;
+  const float* lab = labels + (size_t)img * n_in;
+  const int per = (n_in + kClsThreads - 1) / kClsThreads;
+  const int lo = min(n_in, (int)threadIdx.x * per), hi = min(n_in, lo + per);
+  int c1 = 0, c0 = 0;
+  for (int i = lo; i < hi; i++) { c1 += lab[i] == 1.0f; c0 += lab[i] == 0.0f; }
+  int t1, t0;
+  int o1 = block_exclusive_scan(c1, scan, t1);
+  int o0 = block_exclusive_scan(c0, scan, t0);
+  for (int i = lo; i < hi; i++) {
+    if (lab[i] == 1.0f) fg_members[(size_t)img * n_in + o1++] = i;
+    if (lab[i] == 0.0f) bg_members[(size_t)img * n_in + o0++] = i;
+  }
+}
+
+// the subsampling draws: label of the pos[j]-th member of the class becomes -1 (anchor_target_layer.py:131-150)
+__global__ __launch_bounds__(256) void anchor_disable_kernel(const int64_t* __restrict__ pos, const int* __restrict__ n_pos, int m,
+                                                             const int* __restrict__ members, int n_in, float* __restrict__ labels) {
+  const int img = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_pos[img]) return;
+  const int64_t p = pos[(size_t)img * m + j];
+  if (p < 0 || p >= n_in) return;
+  labels[(size_t)img * n_in + members[(size_t)img * n_in + p]] = -1.0f;
+}
+
+// regression targets, weights, and the scatter of the inside anchors back onto the [H, W, A] grid in the
+// layouts the RPN losses read (anchor_target_layer.py:152-187)
+__global__ __launch_bounds__(256) void anchor_targets_kernel(const float* __restrict__ anchors, const int* __restrict__ inside_pos,
+                                                             int n_in, int A, int H, int W, const float* __restrict__ gt, int G,
+                                                             int gt_cols, const int64_t* __restrict__ argmax,
+                                                             const float* __restrict__ labels, float inside_weight,
+                                                             float outside_weight, float* __restrict__ labels_out,
+                                                             float* __restrict__ targets, float* __restrict__ inside_w,
+                                                             float* __restrict__ outside_w) {
+  const int img = blockIdx.y;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;        // (h, w, a) order
+  const int HW = H * W;
+  if (n >= HW * A) return;
+  const int hw = n / A, a = n - hw * A, h = hw / W, w = hw - h * W;
+  const int i = inside_pos[n];
+  float lab = -1.0f, t[4] = {0.f, 0.f, 0.f, 0.f}, wi = 0.0f, wo = 0.0f;
+  if (i >= 0) {
+    lab = labels[(size_t)img * n_in + i];
+    const float4 an = reinterpret_cast<const float4*>(anchors)[i];
+    const float* gb = gt + ((size_t)img * G + argmax[(size_t)img * n_in + i]) * gt_cols;
+    const float ew = an.z - an.x + 1.0f, eh = an.w - an.y + 1.0f;
+    const float ecx = an.x + 0.5f * ew, ecy = an.y + 0.5f * eh;
+    const float gw = gb[2] - gb[0] + 1.0f, gh = gb[3] - gb[1] + 1.0f;
+    const float gcx = gb[0] + 0.5f * gw, gcy = gb[1] + 0.5f * gh;
+    t[0] = (gcx - ecx) / ew; t[1] = (gcy - ecy) / eh; t[2] = logf(gw / ew); t[3] = logf(gh / eh);
+    wi = (lab == 1.0f ? 1.0f : 0.0f) * inside_weight;
+    wo = (lab >= 0.0f ? 1.0f : 0.0f) * outside_weight;
+  }
+  labels_out[((size_t)img * A + a) * HW + hw] = lab;           // [b, 1, A*H, W]: row a*H + h, column w
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const size_t o = ((size_t)img * 4 * A + 4 * a + c) * HW + hw;   // [b, 4A, H, W]
+    targets[o] = t[c]; inside_w[o] = wi; outside_w[o] = wo;
+  }
+  (void)h; (void)w;
+}
+
 }  // namespace
 
 AIT_API int ait_rpn_decode(const float* probs, const float* deltas, const float* anchors, const float* im_info, int b,
@@ -267,6 +415,61 @@ AIT_API int ait_roi_sample_gather(const int64_t* pos, const int64_t* n_fg, int b
   hipLaunchKernelGGL(roi_sample_gather_kernel, dim3(b), dim3(256), 0, ait_stream(stream), pos, n_fg, P, R, fg_members,
                      bg_members, labels, all_rois, assign, gt, G, gt_cols, c, rois_b, labels_b, bbox_targets, inside_w,
                      outside_w);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_anchor_classify(const float* anchors_inside, int n_in, const float* gt, int b, int G, int gt_cols,
+                                float negative_overlap, float positive_overlap, int clobber_positives, float* max_ov,
+                                int64_t* argmax, int* gt_max_bits, float* labels, int64_t* counts, int* fg_members,
+                                int* bg_members, void* stream) {
+  if (b < 0 || n_in <= 0 || G <= 0 || gt_cols < 4) return AIT_EINVAL;
+  if (b == 0) return AIT_OK;
+  if (!anchors_inside || !gt || !max_ov || !argmax || !gt_max_bits || !labels || !counts || !fg_members || !bg_members)
+    return AIT_EINVAL;
+  const size_t lds = (size_t)G * 6 * sizeof(float);
+  if (lds > 48 * 1024) return AIT_EUNSUPPORTED;
+  hipStream_t s = ait_stream(stream);
+  if (hipMemsetAsync(gt_max_bits, 0, (size_t)b * G * sizeof(int), s) != hipSuccess ||
+      hipMemsetAsync(counts, 0, (size_t)b * 2 * sizeof(int64_t), s) != hipSuccess)
+    return AIT_ELAUNCH;
+  const dim3 grid((unsigned)((n_in + 255) / 256), (unsigned)b);
+  hipLaunchKernelGGL(anchor_iou_kernel, grid, dim3(256), lds, s, anchors_inside, n_in, gt, G, gt_cols, max_ov, argmax,
+                     gt_max_bits);
+  AIT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(anchor_label_kernel, grid, dim3(256), lds, s, anchors_inside, n_in, gt, G, gt_cols, max_ov,
+                     gt_max_bits, negative_overlap, positive_overlap, clobber_positives, labels, counts);
+  AIT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(anchor_members_kernel, dim3(b), dim3(kClsThreads), 0, s, labels, n_in, fg_members, bg_members);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_anchor_targets(const float* anchors_inside, const int* inside_pos, int n_in, int A, int H, int W,
+                               const float* gt, int b, int G, int gt_cols, const int64_t* argmax, float* labels,
+                               const int64_t* fg_drop, const int* n_fg_drop, int m_fg, const int* fg_members,
+                               const int64_t* bg_drop, const int* n_bg_drop, int m_bg, const int* bg_members,
+                               float inside_weight, float outside_weight, float* labels_out, float* targets,
+                               float* inside_w, float* outside_w, void* stream) {
+  if (b < 0 || n_in <= 0 || A <= 0 || H <= 0 || W <= 0 || G <= 0 || gt_cols < 4 || m_fg < 0 || m_bg < 0) return AIT_EINVAL;
+  if (b == 0) return AIT_OK;
+  if (!anchors_inside || !inside_pos || !gt || !argmax || !labels || !labels_out || !targets || !inside_w || !outside_w ||
+      (m_fg > 0 && (!fg_drop || !n_fg_drop || !fg_members)) || (m_bg > 0 && (!bg_drop || !n_bg_drop || !bg_members)))
+    return AIT_EINVAL;
+  hipStream_t s = ait_stream(stream);
+  if (m_fg > 0) {
+    hipLaunchKernelGGL(anchor_disable_kernel, dim3((unsigned)((m_fg + 255) / 256), (unsigned)b), dim3(256), 0, s, fg_drop,
+                       n_fg_drop, m_fg, fg_members, n_in, labels);
+    AIT_CHECK_LAUNCH();
+  }
+  if (m_bg > 0) {
+    hipLaunchKernelGGL(anchor_disable_kernel, dim3((unsigned)((m_bg + 255) / 256), (unsigned)b), dim3(256), 0, s, bg_drop,
+                       n_bg_drop, m_bg, bg_members, n_in, labels);
+    AIT_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(anchor_targets_kernel, dim3((unsigned)((H * W * A + 255) / 256), (unsigned)b), dim3(256), 0, s,
+                     anchors_inside, inside_pos, n_in, A, H, W, gt, G, gt_cols, argmax, labels, inside_weight,
+                     outside_weight, labels_out, targets, inside_w, outside_w);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }

@@ -22,6 +22,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .config import cfg
+import os
+
 from . import _lib
 from .roi_layers import nms_sorted_batched
 
@@ -43,6 +45,11 @@ def generate_anchors(base_size=16, ratios=(0.5, 1, 2), scales=2 ** np.arange(3, 
     ws = np.round(np.sqrt(area / ratios))
     hs = np.round(ws * ratios)
     return np.vstack([_centered(w * scales, h * scales, ctr, ctr) for w, h in zip(ws, hs)])
+
+
+# the box arithmetic of the three layers below runs on the library's kernels (csrc/boxes.hip) for fp32 tensors on
+# the GPU; AIT_BOX_TORCH=1 keeps the tensor expressions (what CPU tensors always get; the tests compare the two)
+_BOX_KERNELS = os.environ.get("AIT_BOX_TORCH", "0") != "1"
 
 
 class _AnchorGrid:
@@ -159,7 +166,7 @@ class _ProposalLayer(nn.Module):
         return self._run(probs, deltas, im_info, cfg_key)
 
     def _run(self, probs, deltas, im_info, cfg_key):
-        if probs.is_cuda and probs.dtype == torch.float32:
+        if _BOX_KERNELS and probs.is_cuda and probs.dtype == torch.float32:
             return self._run_hip(probs, deltas, im_info, cfg_key)
         A = self._num_anchors
         pre_n = cfg[cfg_key].RPN_PRE_NMS_TOP_N
@@ -264,6 +271,8 @@ class _AnchorTargetLayer(nn.Module):
                       (all_anchors[:, 2] < int(im_w) + bd) & (all_anchors[:, 3] < int(im_h) + bd))
             self._inside[key] = (torch.nonzero(inside).view(-1), (im_h, im_w))
         inds_inside, _ = self._inside[key]
+        if _BOX_KERNELS and dev.type == "cuda" and gt_boxes.dtype == torch.float32:
+            return self._prepare_hip(gt_boxes, all_anchors, inds_inside, key, H, W)
         anchors = all_anchors[inds_inside]
 
         overlaps = bbox_overlaps_batch(anchors, gt_boxes)                 # [b, n_in, G]
@@ -290,11 +299,48 @@ class _AnchorTargetLayer(nn.Module):
         return ((H, W, gt_boxes.data_ptr()), gt_boxes, inds_inside, anchors, argmax_ov, labels, host, ev,
                 all_anchors.size(0))
 
+    def _prepare_hip(self, gt_boxes, all_anchors, inds_inside, key, H, W):
+        """the device part of prepare() in three launches (ait_anchor_classify)"""
+        dev = gt_boxes.device
+        st = self.__dict__.setdefault("_static", {}).get(key)
+        if st is None:
+            anchors = all_anchors[inds_inside].float().contiguous()
+            inside_pos = torch.full((all_anchors.size(0),), -1, dtype=torch.int32, device=dev)
+            inside_pos[inds_inside] = torch.arange(inds_inside.numel(), dtype=torch.int32, device=dev)
+            st = self._static[key] = (anchors, inside_pos)
+        anchors, inside_pos = st
+        gt = gt_boxes.contiguous()
+        b, G, n_in = gt.size(0), gt.size(1), anchors.size(0)
+        max_ov = torch.empty((b, n_in), dtype=torch.float32, device=dev)
+        argmax = torch.empty((b, n_in), dtype=torch.int64, device=dev)
+        gt_max = torch.empty((b, G), dtype=torch.int32, device=dev)
+        labels = torch.empty((b, n_in), dtype=torch.float32, device=dev)
+        counts = torch.empty((b, 2), dtype=torch.int64, device=dev)
+        fg_members = torch.empty((b, n_in), dtype=torch.int32, device=dev)
+        bg_members = torch.empty((b, n_in), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().ait_anchor_classify(
+                _lib.dev_ptr(anchors), n_in, _lib.dev_ptr(gt), b, G, gt.size(2), float(cfg.TRAIN.RPN_NEGATIVE_OVERLAP),
+                float(cfg.TRAIN.RPN_POSITIVE_OVERLAP), int(bool(cfg.TRAIN.RPN_CLOBBER_POSITIVES)), _lib.dev_ptr(max_ov),
+                _lib.dev_ptr(argmax, torch.int64), _lib.dev_ptr(gt_max, torch.int32), _lib.dev_ptr(labels),
+                _lib.dev_ptr(counts, torch.int64), _lib.dev_ptr(fg_members, torch.int32),
+                _lib.dev_ptr(bg_members, torch.int32), _lib.cur_stream(dev))
+        _lib.check(rc, "ait_anchor_classify")
+        host = torch.empty((b, 2), dtype=torch.int64, pin_memory=True)
+        host.copy_(counts, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        return ((H, W, gt_boxes.data_ptr()), gt, inds_inside, anchors, argmax, labels, host, ev, all_anchors.size(0),
+                (inside_pos, fg_members, bg_members))
+
     def begin(self, gt_boxes, im_info, H, W):
         """called by the detector before the backbone is enqueued (see prepare)"""
         self._pending = self.prepare(gt_boxes, im_info, H, W)
 
     def finish(self, pending):
+        hip = None
+        if len(pending) == 10:
+            pending, hip = pending[:9], pending[9]
         (H, W, _), gt_boxes, inds_inside, anchors, argmax_ov, labels, host, ev, total = pending
         b, n_in = labels.shape
         A = self._num_anchors
@@ -323,6 +369,9 @@ class _AnchorTargetLayer(nn.Module):
         # uniform example weighting; like the reference, the count comes from the LAST image
         assert cfg.TRAIN.RPN_POSITIVE_WEIGHT < 0
         num_examples = n_fg_after[b - 1] + n_bg_after[b - 1]
+
+        if hip is not None:
+            return self._finish_hip(hip, H, W, gt_boxes, anchors, argmax_ov, labels, dis_fg, dis_bg, num_examples)
 
         def disable(lab, want, drawn):
             """lab[i, (want-th class member list)[drawn[i]]] = -1: the k-th member of a class in ascending
@@ -368,6 +417,43 @@ class _AnchorTargetLayer(nn.Module):
         return [labels, targets, spread(inside_w), spread(outside_w)]
 
 
+def _anchor_finish_hip(layer, hip, H, W, gt, anchors, argmax, labels, dis_fg, dis_bg, num_examples):
+    """finish() behind the host's draws in two or three launches (ait_anchor_targets)"""
+    inside_pos, fg_members, bg_members = hip
+    dev = gt.device
+    b, n_in = labels.shape
+    A = layer._num_anchors
+
+    def pack(drawn):
+        m = max(d.size for d in drawn)
+        pos = np.zeros((b, max(m, 1)), np.int64)
+        cnt = np.zeros((b,), np.int32)
+        for i, d in enumerate(drawn):
+            pos[i, :d.size] = d
+            cnt[i] = d.size
+        return m, torch.from_numpy(pos).to(dev, non_blocking=True), torch.from_numpy(cnt).to(dev, non_blocking=True)
+
+    m_fg, fg_pos, fg_cnt = pack(dis_fg)
+    m_bg, bg_pos, bg_cnt = pack(dis_bg)
+    out_l = torch.empty((b, 1, A * H, W), dtype=torch.float32, device=dev)
+    out_t = torch.empty((b, 4 * A, H, W), dtype=torch.float32, device=dev)
+    out_i = torch.empty_like(out_t)
+    out_o = torch.empty_like(out_t)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ait_anchor_targets(
+            _lib.dev_ptr(anchors), _lib.dev_ptr(inside_pos, torch.int32), n_in, A, H, W, _lib.dev_ptr(gt), b, gt.size(1),
+            gt.size(2), _lib.dev_ptr(argmax, torch.int64), _lib.dev_ptr(labels),
+            _lib.dev_ptr(fg_pos, torch.int64), _lib.dev_ptr(fg_cnt, torch.int32), m_fg, _lib.dev_ptr(fg_members, torch.int32),
+            _lib.dev_ptr(bg_pos, torch.int64), _lib.dev_ptr(bg_cnt, torch.int32), m_bg, _lib.dev_ptr(bg_members, torch.int32),
+            float(cfg.TRAIN.RPN_BBOX_INSIDE_WEIGHTS[0]), float(1.0 / num_examples), _lib.dev_ptr(out_l), _lib.dev_ptr(out_t),
+            _lib.dev_ptr(out_i), _lib.dev_ptr(out_o), _lib.cur_stream(dev))
+    _lib.check(rc, "ait_anchor_targets")
+    return [out_l, out_t, out_i, out_o]
+
+
+_AnchorTargetLayer._finish_hip = _anchor_finish_hip
+
+
 class _ProposalTargetLayer(nn.Module):
     """(all_rois [b,R,5], gt_boxes [b,G,5], num_boxes) -> rois [b,P,5], labels [b,P],
     bbox_targets [b,P,4], inside weights, outside weights with P = cfg.TRAIN.BATCH_SIZE."""
@@ -382,7 +468,7 @@ class _ProposalTargetLayer(nn.Module):
         P = int(cfg.TRAIN.BATCH_SIZE)
         fg_per_image = int(np.round(cfg.TRAIN.FG_FRACTION * P)) or 1
         gpu = dev.type == "cuda"
-        hip = gpu and all_rois.dtype == torch.float32 and gt_boxes.dtype == torch.float32
+        hip = _BOX_KERNELS and gpu and all_rois.dtype == torch.float32 and gt_boxes.dtype == torch.float32
         if hip:
             all_rois, assign, labels, counts, fg_members, bg_members = self._classify_hip(all_rois, gt_boxes)
         else:

@@ -149,6 +149,25 @@ int ait_rpn_decode(const float* probs, const float* deltas, const float* anchors
                    int A, int H, int W, float* boxes, float* scores, void* stream);
 int ait_proposals_assemble(const float* cand, int n, const int64_t* keep, long long keep_stride, int keep_cols,
                            const int32_t* n_keep, int b, int post_n, float* out, void* stream);
+/* Anchor-target layer (lib/model/rpn/anchor_target_layer.py:55-187) around the reference's host-side RNG draws:
+ * ait_anchor_classify  anchors_inside [n_in,4] (the anchors inside the image, ascending grid order) x gt
+ *   [b,G,gt_cols>=4] -> max_ov / argmax [b,n_in], labels [b,n_in] (-1 / 0 / 1 by the negative / positive overlap
+ *   thresholds and the best anchor of every gt box; gt_max_bits [b,G] is scratch), counts [b,2] = (#label 1,
+ *   #label 0) -- what the host's permutation draws need -- and the two class member lists (ascending, members only).
+ * ait_anchor_targets   disables the drawn members (labels -> -1; fg_drop / bg_drop [b,m] positions within the
+ *   class lists, n_*_drop [b] how many are valid), then writes the layer's four outputs on the full [H,W,A] grid in
+ *   the layouts the RPN losses read: labels_out [b,1,A*H,W], targets / inside_w / outside_w [b,4A,H,W]
+ *   (inside_pos [H*W*A]: index of each grid anchor within anchors_inside, -1 outside the image). */
+int ait_anchor_classify(const float* anchors_inside, int n_in, const float* gt, int b, int G, int gt_cols,
+                        float negative_overlap, float positive_overlap, int clobber_positives, float* max_ov,
+                        int64_t* argmax, int32_t* gt_max_bits, float* labels, int64_t* counts, int32_t* fg_members,
+                        int32_t* bg_members, void* stream);
+int ait_anchor_targets(const float* anchors_inside, const int32_t* inside_pos, int n_in, int A, int H, int W,
+                       const float* gt, int b, int G, int gt_cols, const int64_t* argmax, float* labels,
+                       const int64_t* fg_drop, const int32_t* n_fg_drop, int m_fg, const int32_t* fg_members,
+                       const int64_t* bg_drop, const int32_t* n_bg_drop, int m_bg, const int32_t* bg_members,
+                       float inside_weight, float outside_weight, float* labels_out, float* targets,
+                       float* inside_w, float* outside_w, void* stream);
 size_t ait_roi_classify_workspace_bytes(int b, int R0, int G);
 int ait_roi_classify(const float* rois, int b, int R0, const float* gt, int G, int gt_cols, float fg_thresh,
                      float bg_thresh_hi, float bg_thresh_lo, void* workspace, size_t workspace_bytes,

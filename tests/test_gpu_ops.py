@@ -449,3 +449,38 @@ def test_box_kernels_equal_the_tensor_expressions():
                 assert torch.allclose(a, ww, rtol=2e-6, atol=1e-7), nme
             else:
                 assert torch.equal(a, ww), nme
+
+
+def test_anchor_target_kernels_equal_the_tensor_expressions(monkeypatch):
+    """ait_anchor_classify / ait_anchor_targets (+ the host's RNG draws between them) against the tensor
+    expressions of the same layer under the same NumPy seed: identical labels and weights on the full anchor
+    grid, regression targets to the last ulp of log(); batches with and without over-full classes."""
+    import numpy as np
+    import ait_amd.rpn as R
+    from ait_amd.config import cfg
+    torch.manual_seed(4)
+    b, H, W, G = 3, 38, 63, 20
+    info = torch.tensor([[600.0, 1000.0, 1.0]] * b, device="cuda")
+    score = torch.zeros(b, 18, H, W, device="cuda")
+    for trial, n_gt in enumerate((1, 3, 12)):
+        gt = torch.zeros(b, G, 5, device="cuda")
+        for i in range(b):
+            xy = torch.rand(n_gt, 2, device="cuda") * torch.tensor([700.0, 350.0], device="cuda")
+            wh = 40 + torch.rand(n_gt, 2, device="cuda") * torch.tensor([280.0, 230.0], device="cuda")
+            gt[i, :n_gt, :2] = xy.round()
+            gt[i, :n_gt, 2:4] = (xy + wh).round()
+            gt[i, :n_gt, 4] = 1
+        nb = torch.full((b,), n_gt, device="cuda")
+        outs = {}
+        for hip in (True, False):
+            monkeypatch.setattr(R, "_BOX_KERNELS", hip)
+            layer = R._AnchorTargetLayer(16, [8, 16, 32], [0.5, 1, 2])
+            np.random.seed(11 + trial)
+            outs[hip] = layer((score, gt, info, nb))
+        for name, a, w in zip(["labels", "targets", "inside", "outside"], outs[True], outs[False]):
+            assert a.shape == w.shape, name
+            if name == "targets":
+                assert torch.allclose(a, w, rtol=2e-6, atol=1e-7), (name, trial)
+            else:
+                assert torch.equal(a, w.to(a.dtype)), (name, trial)
+        assert int((outs[True][0] == 1).sum()) > 0 and int((outs[True][0] == 0).sum()) > 0

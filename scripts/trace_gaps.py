@@ -4,7 +4,8 @@ usage: trace_gaps.py <dir with *_kernel_trace.csv> <warmup> <steps> [min_gap_us]
 import collections, csv, glob, sys
 d, warmup, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 min_gap = float(sys.argv[4]) if len(sys.argv) > 4 else 15.0
-f = (glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[0]
+import os
+f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getsize)   # (child processes leave small traces of their own)
 rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f)))
 gi = [i for i, r in enumerate(rows) if "gemm_f32_" in r[2]]
 per = len(gi) // (warmup + steps)

@@ -7,7 +7,8 @@ dispatch of the first timed step: bench.py issues a fixed number of gemm_f32_ker
 step, so the timed region starts at GEMM dispatch number warmup * (n_gemm / (warmup + steps))."""
 import collections, csv, glob, sys
 d, warmup, steps, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
-f = (glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[0]
+import os
+f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getsize)   # (child processes leave small traces of their own)
 rows = []
 for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))

@@ -4,7 +4,8 @@ usage: trace_timeline.py <dir with *_kernel_trace.csv> <warmup> <steps> [bin_us]
 import collections, csv, glob, re, sys
 d, warmup, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 bin_ns = int(float(sys.argv[4]) * 1000) if len(sys.argv) > 4 else 500000
-f = (glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[0]
+import os
+f = max(glob.glob(d + "/**/*kernel_trace.csv", recursive=True), key=os.path.getsize)   # (child processes leave small traces of their own)
 rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f)))
 gi = [i for i, r in enumerate(rows) if "gemm_f32_" in r[2]]
 per = len(gi) // (warmup + steps)

@@ -79,6 +79,8 @@ struct GemmArgs {
   long long sA2, sB2, sC2;     // (second batch level: the heads of an attention product)
   float* sk_ws;                // stream-K: one BM x BN partial tile per workgroup; NULL = whole tiles only
   unsigned* sk_flags;          // stream-K: one "partial published" word per workgroup (zero between launches)
+  unsigned* sched;             // dynamic tile hand-out: per XCD a ticket counter at [xcd*32] and an exit counter at
+                               // [xcd*32 + 1] (zero between launches); NULL = static lists (item j, j+W, ...)
 };
 
 enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
@@ -104,7 +106,7 @@ struct Cfg {
   static constexpr int VA = BM * BK / 4 / NT;      // float4 per thread per A slab
   static constexpr int VB = BN * BK / 4 / NT;
   static constexpr int NBUF = (MODE_ == MODE_DB) ? 2 : 3;
-  static constexpr size_t LDS = (MODE_ == MODE_DLDS) ? sizeof(float) * NS_ * BK * (BM + BN)
+  static constexpr size_t LDS = (MODE_ == MODE_DLDS) ? sizeof(float) * NS_ * BK * (BM + BN) + 64 /* ticket ring */
                                                      : sizeof(float) * NBUF * BK * (PA + PB);
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile / wave mismatch");
   static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "slab / thread mismatch");
@@ -494,21 +496,66 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       if (hi > e0) { skB_ke = (hi - e0) * BK; n_sk = 2; }
     }
   }
-  const int dp0 = sk_r + j;
-  const int n_items = n_sk + (dp0 < lim ? (lim - dp0 + W - 1) / W : 0);
-  if (n_items == 0) return;
-  // item it -> id within the chunk, K range
-  auto get_item = [&](int it, int& m0, int& n0, int& kb, int& ke) {
-    const int id = it < n_sk ? skA_tile + it : dp0 + (it - n_sk) * W;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+  // The whole items (sk_r .. lim-1 of the chunk) are handed out DYNAMICALLY when the launch has a ticket
+  // counter (g.sched): a workgroup draws its next item when it needs one, so a workgroup that becomes
+  // resident late -- the grid is sized for an empty chip; beside an RCCL kernel of a data-parallel step, or
+  // any other concurrent kernel, some workgroups start only when others exit -- finds what is left instead
+  // of a fixed share of the list (a static list would nearly double the kernel's duration then), and CUs of
+  // unequal speed balance.  Tickets are drawn in order, so neighbouring tiles still run together (operand
+  // panels shared in the XCD's L2).  One lane draws at the top of a slab
+  // iteration (for the item after the load cursor's); the ticket lands in a small LDS ring before the barrier that ends the iteration (whose
+  // vmcnt(0) wait covers it), so no wave ever waits for the counter.  The last workgroup of an XCD to exit
+  // zeroes its two counters.
+  const bool dyn = g.sched != nullptr;
+  const int lim_dp = lim - sk_r;                                   // whole items of this XCD
+  int* idq = reinterpret_cast<int*>(lds + NS * (SA + SB));         // [8] ticket ring
+  unsigned* ticket = g.sched + xcd * 32;
+  int n_fetched = 0;            // tickets in the ring so far (identical in every wave)
+  bool ended = false;           // a drawn ticket was past the end
+  if (dyn) {
+    if (threadIdx.x == 0) {
+      const unsigned t0 = atomicAdd(ticket, 1u);
+      idq[0] = (int)t0 < lim_dp ? (int)t0 : -1;
+    }
+    __syncthreads();
+    n_fetched = 1;
+    ended = idq[0] < 0;
+  }
+  // whole item k of this workgroup -> id within the chunk's whole items, or -1 past the end
+  auto dp_id = [&](int k) -> int {
+    if (dyn) return idq[k & 7];
+    const int id = j + k * W;
+    return id < lim_dp ? id : -1;
+  };
+  bool any = n_sk > 0 || dp_id(0) >= 0;
+  // item it -> tile origin, K range; false past the end of this workgroup's work
+  auto get_item = [&](int it, int& m0, int& n0, int& kb, int& ke) -> bool {
+    int id;
+    if (it < n_sk) id = skA_tile + it;
+    else {
+      id = dp_id(it - n_sk);
+      if (id < 0) return false;
+      id += sk_r;
+    }
     wmap.decode(g, base + id, BM, BN, m0, n0, kb, ke);
     if (it < n_sk) {
       kb = it == 0 ? skA_kb : 0;
       ke = it == 0 ? skA_ke : skB_ke;
     }
+    return true;
   };
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  auto leave = [&]() {          // exit protocol of the dynamic hand-out
+    if (dyn && threadIdx.x == 0) {
+      if (atomicAdd(ticket + 1, 1u) == (unsigned)W - 1u) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if (!any) { leave(); return; }
   const int wm = (wave / C::WN) * (C::TM * 32), wn = (wave % C::WN) * (C::TN * 32);
   const int li = lane & 31, lk = lane >> 5;
 
@@ -544,7 +591,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   };
   auto set_tile = [&](int it) {
     int m0, n0;
-    get_item(it, m0, n0, l_k, l_kend);
+    if (!get_item(it, m0, n0, l_k, l_kend)) { l_valid = false; return; }
     l_n0 = n0;
 #pragma unroll
     for (int i = 0; i < LA; i++) {
@@ -605,8 +652,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     l_k += BK;
     if (l_k >= l_kend) {
       l_item += 1;
-      if (l_item < n_items) set_tile(l_item);
-      else l_valid = false;
+      set_tile(l_item);          // (clears l_valid past the end)
     } else if (CONV == CONV_A) {
       if (l_k % g.conv.seg == 0) retap();      // next tap: new source rows (and, K-outer weights, new tap base)
     }
@@ -635,9 +681,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   fetch_group<BKC, C::TN, BN>(Bd, wn, li, lk, 0, xb);
   int cur = 0;
 
-  for (int item = 0; item < n_items; item++) {
+  for (int item = 0;; item++) {
     int m0, n0, kbeg, kend;
-    get_item(item, m0, n0, kbeg, kend);
+    if (!get_item(item, m0, n0, kbeg, kend)) break;
     f32x16 acc[C::TM][C::TN];
 #pragma unroll
     for (int a = 0; a < C::TM; a++)
@@ -656,6 +702,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       // at once (an LDS-DMA costs its wave 60-180 cycles of issue) with no wave left to feed the
       // matrix pipe; inside the MFMA stream the partner wave on the SIMD covers each one.
       const bool feed = l_valid;         // wave-uniform
+      // the ticket of the item AFTER the one the load cursor is in: never more than one undone ticket held
+      // (drawing further ahead starves the other workgroups when there are only a few tiles each); it is
+      // needed when the cursor leaves its item, at least two slabs from now (launch() checks the item lengths)
+      const bool draw = dyn && !ended && n_fetched - (l_item - n_sk) < 2;
+      // (inline assembly: hipcc waits vmcnt(0) right behind an atomicAdd() whose value it needs -- which here would
+      // also drain the slab in flight, once per tile; the value is read only behind the wait that ends the iteration)
+      unsigned drawn = 1u;
+      if (draw && threadIdx.x == 0)
+        asm volatile("global_atomic_add %0, %1, %0, off sc0" : "+v"(drawn) : "v"(ticket) : "memory");
       if constexpr ((C::KNOBS & KNOB_BURST) != 0) {
         if (feed) {
 #pragma unroll
@@ -717,9 +772,19 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         if (NS == 4 && feed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       };
+      auto land = [&]() {              // behind the slab wait, in front of the barrier
+        if (draw) {
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn) : : "memory");     // (the ticket: with a ring of 4 the slab wait is counted)
+          if (threadIdx.x == 0) idq[n_fetched & 7] = (int)drawn < lim_dp ? (int)drawn : -1;
+        }
+      };
+      auto landed = [&]() {            // behind the barrier: every wave learns the ticket
+        if (draw) { ended = idq[n_fetched & 7] < 0; n_fetched++; }
+      };
       if constexpr (Probe::on) {
         const unsigned long long s0 = __builtin_amdgcn_s_memtime();
         slab_wait();
+        land();
         const unsigned long long s1 = __builtin_amdgcn_s_memtime();
         ring_barrier();
         const unsigned long long s2 = __builtin_amdgcn_s_memtime();
@@ -728,8 +793,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         n_slab++;
       } else {
         slab_wait();
+        land();
         ring_barrier();
       }
+      landed();
       cur = nxt;
     }
     if constexpr (Probe::on) { c_loop += __builtin_amdgcn_s_memtime() - c0; n_tile++; }
@@ -798,6 +865,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     fetch_group<BKC, C::TN, BN>(Bd + cur * SB, wn, li, lk, 0, xb);
   }
 
+  leave();
   if constexpr (Probe::on) {
     if (threadIdx.x == 0 && g.probe) {
       unsigned long long* p = g.probe + (size_t)blockIdx.x * AIT_PROBE_WORDS;
@@ -997,7 +1065,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
 // -- launches on one stream are ordered, so they can share it; two streams never do.  Allocated on first
 // use (the only allocation this library makes; ait_gemm_workspace_release() frees it), flags zeroed once:
 // every flag a launch sets is cleared again by the workgroup that consumes it.
-struct SkWorkspace { float* ws = nullptr; unsigned* flags = nullptr; size_t bytes = 0; int nflags = 0; };
+struct SkWorkspace { float* ws = nullptr; unsigned* flags = nullptr; unsigned* sched = nullptr; size_t bytes = 0; int nflags = 0; };
 inline int& stream_k_mode() {          // 1 on, 0 off (AIT_GEMM_STREAMK=0); the lab harness flips it
   static int mode = [] { const char* e = getenv("AIT_GEMM_STREAMK"); return (e && e[0] == '0') ? 0 : 1; }();
   return mode;
@@ -1016,12 +1084,14 @@ inline int sk_workspace(hipStream_t s, size_t bytes, int nflags, SkWorkspace& ou
   if (e.bytes < bytes || e.nflags < nflags) {
     if (e.ws) (void)hipFree(e.ws);
     e = SkWorkspace();
-    const size_t fbytes = ((size_t)nflags * 4 + 255) / 256 * 256;
+    const size_t sbytes = AIT_NXCD * 32 * sizeof(unsigned);       // ticket + exit counter per XCD, a line apart
+    const size_t fbytes = ((size_t)nflags * 4 + 255) / 256 * 256 + sbytes;
     void* mem = nullptr;
     if (hipMalloc(&mem, bytes + fbytes) != hipSuccess) { (void)hipGetLastError(); return AIT_ELAUNCH; }
     if (hipMemset((char*)mem + bytes, 0, fbytes) != hipSuccess) { (void)hipFree(mem); return AIT_ELAUNCH; }
     e.ws = (float*)mem;
     e.flags = (unsigned*)((char*)mem + bytes);
+    e.sched = (unsigned*)((char*)mem + bytes + fbytes - sbytes);
     e.bytes = bytes;
     e.nflags = nflags;
   }
@@ -1053,6 +1123,7 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
   GemmArgs gl = g;
   gl.sk_ws = nullptr;
   gl.sk_flags = nullptr;
+  gl.sched = nullptr;
   WorkMap wmap;
   wmap.init(g, C::BM, C::BN);
   unsigned blocks;
@@ -1070,13 +1141,21 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
     // publishing and gathering partial tiles.
     const int wfull = max(1, slots / AIT_NXCD), rem = wmap.chunk % wfull;
     const double last_round = (rem * 2 <= wfull) ? 0.62 : 1.0;
-    const bool sk_pays = (g.K / 16) * (last_round - (double)rem / wfull) > 9.0;
-    if (EPI != EPI_ATOMIC && g.splits == 1 && g.K % 16 == 0 && rem > 0 && sk_pays && stream_k_mode() != 0) {
+    const bool sk_pays = (g.K / 16) * (last_round - (double)rem / wfull) > 12.0;
+    if (stream_k_mode() != 0) {
+      // scratch of the scheduler: ticket counters for the dynamic hand-out of whole tiles (every launch), partial
+      // tiles + flags when this launch also cuts its last round
       SkWorkspace sk;
       if (sk_workspace(s, (size_t)wfull * AIT_NXCD * C::BM * C::BN * sizeof(float), wfull * AIT_NXCD, sk) == AIT_OK) {
-        gl.sk_ws = sk.ws;
-        gl.sk_flags = sk.flags;
-        w = wfull;
+        // (a ticket lands one iteration after it is drawn, and the prologue fills the slab ring from the first
+        // item alone: every whole item must outlast both -- eight slabs is comfortably more than either)
+        const int kps = g.splits > 1 ? g.k_per_split : g.K, klast = g.K - (g.splits - 1) * kps;
+        if (kps >= 128 && klast >= 128) gl.sched = sk.sched;
+        if (EPI != EPI_ATOMIC && g.splits == 1 && g.K % 16 == 0 && rem > 0 && sk_pays) {
+          gl.sk_ws = sk.ws;
+          gl.sk_flags = sk.flags;
+          w = wfull;
+        }
       }
     }
     blocks = (unsigned)(w * AIT_NXCD);
@@ -1143,6 +1222,7 @@ inline int make_args(int trans_a, int trans_b, int M, int N, int K, float alpha,
   g.probe = nullptr;
   g.sk_ws = nullptr;
   g.sk_flags = nullptr;
+  g.sched = nullptr;
   g.conv = ConvGeom{};
   g.batch = g.batch2 = 1; g.sA = g.sB = g.sC = g.sA2 = g.sB2 = g.sC2 = 0;
   // 32-bit element offsets in the epilogue

@@ -323,6 +323,58 @@ static void mode_sustain(int variant, double seconds, int si) {
   teardown(p);
 }
 
+// A kernel on ANOTHER stream holds `hogs` CUs (96 KB of LDS each: no GEMM workgroup fits beside it) while the
+// GEMM runs -- the situation of a data-parallel step, where RCCL's all-reduce kernels share the chip with the
+// backward GEMMs.  The persistent kernel's grid is sized for an empty chip, so some of its workgroups become
+// resident only when others exit: with static work lists they then still own a full share of the tiles; with
+// the dynamic hand-out they find what is left.
+__global__ void hog_kernel(long long cycles, int* sink) {
+  extern __shared__ int hog_lds[];
+  const long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+  int x = 0;
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < cycles) { hog_lds[threadIdx.x] = x; x += hog_lds[(threadIdx.x + 1) & 63]; __builtin_amdgcn_s_sleep(8); }
+  if (x == 0x7fffffff) *sink = x;
+}
+static void mode_contend(int first, int last, int hogs) {
+  hipStream_t side;
+  CK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  CK(hipFuncSetAttribute((const void*)hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  int* sink;
+  CK(hipMalloc(&sink, 4));
+  printf("%d CUs held by another stream's kernel during the launch; TFLOP/s (and ms)\n", hogs);
+  for (int si = first; si < last; si++) {
+    Problem p;
+    setup(p, SHAPES[si]);
+    const size_t nc = (size_t)p.s.M * p.s.N;
+    CK(hipMemset(p.C, 0, nc * 4));
+    run(p, 1, p.C);
+    CK(hipDeviceSynchronize());
+    const float alone = time_launches(p, 13, p.C2, 4);
+    double res[2];
+    int okk = 1;
+    for (int k = 0; k < 2; k++) {
+      const int variant = k == 0 ? 14 : 13;       // static lists, whole tiles / dynamic hand-out + stream-K
+      std::vector<double> t;
+      for (int rep = 0; rep < 5; rep++) {
+        if (p.s.sk > 1) CK(hipMemset(p.C2, 0, nc * 4));
+        CK(hipDeviceSynchronize());
+        hipLaunchKernelGGL(hog_kernel, dim3(hogs), dim3(64), 96 * 1024, side, (long long)(alone * 4.0e-3 * 100e6), sink);   // ~4x the launch, at 100 MHz
+        usleep(200);                                // let the hogs take their CUs
+        t.push_back(time_launches(p, variant, p.C2, 1));
+        CK(hipDeviceSynchronize());
+      }
+      if (max_diff(p, 1) > 2e-5) okk = 0;
+      std::sort(t.begin(), t.end());
+      res[k] = t[2];
+    }
+    printf("%-9s %6d %5d %6d | alone %6.1f (%.3f ms) | static lists %6.1f (%.3f ms) | dynamic hand-out %6.1f (%.3f ms)%s\n", p.s.name,
+           p.s.M, p.s.N, p.s.K, tflops(p.s, alone), alone, tflops(p.s, res[0]), res[0], tflops(p.s, res[1]), res[1], okk ? "" : "  WRONG");
+    fflush(stdout);
+    teardown(p);
+  }
+  CK(hipFree(sink));
+}
+
 // Each launch timed on its own (events on the stream), (a) back to back, (b) with a memory-bound kernel
 // (a 1-GiB fill, ~0.25 ms) between the launches, (c) with a host synchronisation before every launch --
 // the three situations a GEMM meets inside the model's step.
@@ -533,6 +585,7 @@ int main(int argc, char** argv) {
   else if (!strcmp(mode, "probe")) mode_probe(first, last);
   else if (!strcmp(mode, "micro")) mode_micro();
   else if (!strcmp(mode, "sweep")) mode_sweep(argc > 2 ? atoi(argv[2]) : 5, first, last);
+  else if (!strcmp(mode, "contend")) mode_contend(first, last, argc > 2 ? atoi(argv[2]) : 64);
   else if (!strcmp(mode, "interleave")) mode_interleave(argc > 2 ? atoi(argv[2]) : 13, first, last);
   else if (!strcmp(mode, "sustain")) mode_sustain(argc > 2 ? atoi(argv[2]) : 13, argc > 3 ? atof(argv[3]) : 3.0, first);
   else if (!strcmp(mode, "pmc")) mode_pmc(atoi(argv[2]), atoi(argv[3]), argc > 4 ? atoi(argv[4]) : 10);

@@ -273,6 +273,29 @@ def test_gemm_stream_k_back_to_back_launches_reuse_the_flags():
             assert torch.equal(got, outs[i])
 
 
+def test_gemm_persistent_kernels_share_the_chip():
+    """Two streams run persistent GEMMs at the same time: neither gets the whole chip, so part of each grid
+    becomes resident only when other workgroups exit (what RCCL's kernels do to the backward GEMMs of a
+    data-parallel step).  Tiles are handed out dynamically and stream-K waits only point at higher workgroup
+    ids, so this is a speed matter, never a correctness or liveness one; each stream has its own scratch."""
+    from ait_amd import ops
+    torch.manual_seed(9)
+    shapes = [(76800, 512, 2048), (19200, 2048, 512), (58800, 1024, 512), (33000, 512, 1024)]
+    data = [(torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")) for M, N, K in shapes]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):
+        for i, (a, w) in enumerate(data):
+            with torch.cuda.stream(streams[(i + rep) % 2]):
+                outs.append((i, ops.gemm(a, w, trans_b=True)))
+    torch.cuda.synchronize()
+    for i, got in outs:
+        a, w = data[i]
+        want = a.double() @ w.double().t()
+        assert bool(((got.double() - want).abs() <= _abs_bound(a, w, False, True)).all()), shapes[i]
+
+
 def test_batched_gemm_layouts_and_autograd():
     """ait_gemm_f32_batched on the COCO co-attention shapes (blocks_coatt_transformer_sk.py:86-110: 64 query
     tokens x 2394 image tokens x 512 channels) against torch.bmm in float64, forward and through _Bmm's backward;

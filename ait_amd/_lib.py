@@ -134,7 +134,7 @@ class FfnWeights(ctypes.Structure):
 
 class ConvGeom(ctypes.Structure):
     """ait_conv_geom."""
-    _fields_ = [(n, ctypes.c_int) for n in ("n", "in_h", "in_w", "out_h", "out_w", "kh", "kw", "stride", "pad")]
+    _fields_ = [(n, ctypes.c_int) for n in ("n", "in_h", "in_w", "out_h", "out_w", "kh", "kw", "stride", "pad", "groups")]
 
 
 class TransformerWeights(ctypes.Structure):

@@ -134,8 +134,13 @@ struct ConvDims { long long rows; int taps; };
 
 inline int check_geom(const ait_conv_geom* q, int cin, int cout) {
   if (!q || q->n < 0 || q->in_h <= 0 || q->in_w <= 0 || q->out_h <= 0 || q->out_w <= 0 || q->kh <= 0 || q->kw <= 0 ||
-      q->stride <= 0 || q->pad < 0 || cin <= 0 || cout <= 0)
+      q->stride <= 0 || q->pad < 0 || cin <= 0 || cout <= 0 || q->groups < 0)
     return AIT_EINVAL;
+  if (q->groups > 1) {
+    // a 128-column (forward, data gradient) or 128-row (weight gradient) tile must lie inside one group
+    if (cin % q->groups || cout % q->groups) return AIT_EINVAL;
+    if ((cin / q->groups) % 128 || (cout / q->groups) % 128) return AIT_EUNSUPPORTED;
+  }
   if (log2_exact(q->stride) < 0) return AIT_EUNSUPPORTED;
   // every output position must see the window the geometry describes
   if ((q->out_h - 1) * q->stride - q->pad + q->kh - 1 < 0 || (q->out_w - 1) * q->stride - q->pad + q->kw - 1 < 0)
@@ -168,12 +173,14 @@ AIT_API int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_
   if (rows == 0) return AIT_OK;
   if (rows > 0x7fffffffLL / 4 || !x || !w || !y || !zeros || zeros_floats < (size_t)cin + 144) return AIT_EINVAL;
   if (flags & ~(AIT_GEMM_RELU | AIT_GEMM_MASK_POS)) return AIT_EINVAL;
-  const int taps = q->kh * q->kw;
+  const int taps = q->kh * q->kw, G = q->groups > 1 ? q->groups : 1, cing = cin / G;
   GemmArgs g;
-  AIT_TRY_RC(make_args(0, 1, (int)rows, cout, taps * cin, 1.f, x, ldx, w, taps * cin, y, ldy, bias, residual, flags, 1, 0, 0,
+  // (grouped: output channel n holds the taps * cin/G weights of its own group; the gathered rows start at the
+  // group's first channel)
+  AIT_TRY_RC(make_args(0, 1, (int)rows, cout, taps * cing, 1.f, x, ldx, w, taps * cing, y, ldy, bias, residual, flags, 1, 0, 0,
                        16, g));
-  g.conv = ConvGeom{hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cin, 0, zeros};
-  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cin, ait_stream(stream), (int)rows, cout, taps * cin, 0, 1, 1);
+  g.conv = ConvGeom{hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G};
+  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), (int)rows, cout, taps * cing, 0, 1, 1);
   return conv_dispatch<CONV_A, true, true>(g, ait_stream(stream));
 }
 
@@ -187,13 +194,14 @@ AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, con
   if (rows == 0) return AIT_OK;
   if (rows > 0x7fffffffLL / 4 || !dy || !w || !dx || !zeros || zeros_floats < (size_t)cout + 144) return AIT_EINVAL;
   if (flags & ~AIT_GEMM_MASK_POS) return AIT_EINVAL;
-  const int taps = q->kh * q->kw;
+  const int taps = q->kh * q->kw, G = q->groups > 1 ? q->groups : 1, cing = cin / G, coutg = cout / G;
   GemmArgs g;
-  // B is addressed per tap (retap): K-outer rows (t, co) at w + t*cin + co*(taps*cin)
-  AIT_TRY_RC(make_args(0, 0, (int)rows, cin, taps * cout, 1.f, dy, lddy, w, taps * cin, dx, lddx, nullptr, residual, flags, 1, 0,
-                       0, 16, g));
-  g.conv = ConvGeom{hw, ws, q->out_h, q->out_w, q->kw, 1, -1, q->pad, log2_exact(q->stride), cout, (long long)cin, zeros};
-  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cin * taps * cout, ait_stream(stream), (int)rows, cin, taps * cout, 0, 0, 1);
+  // B is addressed per tap (retap): K-outer rows (t, co) at w + t*cin/G + co*(taps*cin/G)
+  AIT_TRY_RC(make_args(0, 0, (int)rows, cin, taps * coutg, 1.f, dy, lddy, w, taps * cing, dx, lddx, nullptr, residual, flags, 1,
+                       0, 0, 16, g));
+  g.conv = ConvGeom{hw, ws, q->out_h, q->out_w, q->kw, 1, -1, q->pad, log2_exact(q->stride), coutg, (long long)cing, zeros,
+                    G > 1 ? coutg : 0, cing};
+  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cin * taps * coutg, ait_stream(stream), (int)rows, cin, taps * coutg, 0, 0, 1);
   return conv_dispatch<CONV_A, true, false>(g, ait_stream(stream));
 }
 
@@ -203,15 +211,17 @@ AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, i
   AIT_TRY_RC(check_geom(q, cin, cout));
   const int hw = log2_exact(q->out_h * q->out_w), ws = log2_exact(q->out_w);
   const long long rows = (long long)q->n * q->out_h * q->out_w;
-  if (hw < 0 || ws < 0 || (cin % 128) || (cout & 3) || (rows & 15)) return AIT_EUNSUPPORTED;
+  if (hw < 0 || ws < 0 || ((cin / (q->groups > 1 ? q->groups : 1)) % 128) || (cout & 3) || (rows & 15)) return AIT_EUNSUPPORTED;
   if (rows == 0) return AIT_OK;
   if (rows > 0x7fffffffLL / 4 || !dy || !x || !dw || !zeros || zeros_floats < (size_t)cin + 144) return AIT_EINVAL;
-  const int taps = q->kh * q->kw;
+  const int taps = q->kh * q->kw, G = q->groups > 1 ? q->groups : 1, cing = cin / G;
   GemmArgs g;
-  AIT_TRY_RC(make_args(1, 0, cout, taps * cin, (int)rows, 1.f, dy, lddy, x, ldx, dw, taps * cin, nullptr, nullptr,
+  AIT_TRY_RC(make_args(1, 0, cout, taps * cing, (int)rows, 1.f, dy, lddy, x, ldx, dw, taps * cing, nullptr, nullptr,
                        AIT_GEMM_ATOMIC, split_k < 1 ? 1 : split_k, 0, 0, 16, g));
-  g.conv = ConvGeom{hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cin, 0, zeros};
-  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cin, ait_stream(stream), cout, taps * cin, (int)rows, 1, 0,
+  g.conv = ConvGeom{hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G};
+  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), cout, taps * cing, (int)rows, 1, 0,
                       g.splits);
+  // (grouped: 128-row tiles, one group of output channels per row tile)
+  if (G > 1) return conv_launch<Tile128D, CONV_B, false, false>(g, ait_stream(stream));
   return conv_launch<Tile256D, CONV_B, false, false>(g, ait_stream(stream));
 }

@@ -45,6 +45,10 @@ struct ConvGeom {
   int seg;                              // reduction floats per tap (channels of the gathered tensor)
   long long b_tap_stride;               // CONV_A with K-outer B
   const float* zero;                    // >= max(seg, BN) + 16 floats of zeros
+  // grouped convolutions (0 = dense): the tile's columns (CONV_A) or rows (CONV_B) select the group, n_group
+  // of them per group (a tile never straddles two), and the gathered operand's channels of that group start
+  // a_group floats further per group
+  int a_group, n_group;
 };
 enum { CONV_NONE = 0, CONV_A = 1, CONV_B = 2 };
 
@@ -195,7 +199,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 // explicit instead: a slot is requested only after the barrier that retired its last reader, and
 // awaited (vmcnt) before the barrier that publishes it.
 __device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
-  const unsigned dst = (unsigned)(size_t)(lds_void*)lds_dst;      // wave-uniform LDS address
+  // wave-uniform LDS address (readfirstlane: a no-op where the compiler already knows it, the proof where it does not)
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)lds_dst);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "m0", "memory");
 }
 
@@ -522,11 +527,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     }
     __syncthreads();
     n_fetched = 1;
-    ended = idq[0] < 0;
+    ended = __builtin_amdgcn_readfirstlane(idq[0]) < 0;
   }
   // whole item k of this workgroup -> id within the chunk's whole items, or -1 past the end
   auto dp_id = [&](int k) -> int {
-    if (dyn) return idq[k & 7];
+    if (dyn) return __builtin_amdgcn_readfirstlane(idq[k & 7]);      // (every lane reads the same word: say so)
     const int id = j + k * W;
     return id < lim_dp ? id : -1;
   };
@@ -568,24 +573,29 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   const size_t step_a = AK ? 16 : (size_t)16 * g.lda;
   const size_t step_b = BKC ? 16 : (size_t)16 * g.ldb;
   int l_item = 0, l_k = 0, l_kend = 0;
-  int l_n0 = 0;                     // column origin of the load cursor's tile (CONV kernels)
+  int l_n0 = 0, l_m0 = 0;           // origin of the load cursor's tile (CONV kernels)
   int arow[LA];                     // CONV_A: this lane's (clamped) GEMM row per A transfer
   bool l_valid = true;
   // CONV_A: operand pointers at reduction index l_k = tap * seg + kin
   auto retap = [&]() {
     const int tap = l_k / g.conv.seg, kin = l_k - tap * g.conv.seg;
+    const int grp = g.conv.a_group ? l_n0 / g.conv.n_group : 0;
+    const int gch = grp * g.conv.a_group;          // first channel of the tile's group in the gathered operand
 #pragma unroll
     for (int i = 0; i < LA; i++) {
       const int row = (wave + i * NW) * 16 + (lane >> 2);
       const int chunk = (lane & 3) ^ ((row >> 2) & 3);
       const int src = conv_src_row(g.conv, arow[i], tap);
-      pa[i] = (src >= 0 ? g.A + (size_t)src * g.lda : g.conv.zero) + kin + chunk * 4;
+      pa[i] = (src >= 0 ? g.A + (size_t)src * g.lda + gch : g.conv.zero) + kin + chunk * 4;
     }
     if (!BKC) {
+      // K-outer weights [co][tap][ci]: rows = output channels (of the tile's group), columns within the tap
+      const int col0 = g.conv.a_group ? l_n0 - grp * g.conv.n_group : l_n0;
+      const int cols = g.conv.a_group ? g.conv.n_group : g.N;
 #pragma unroll
       for (int i = 0; i < LB; i++) {
         const int e = (wave + i * NW) * 256 + lane * 4;
-        pb[i] = g.B + tap * g.conv.b_tap_stride + (size_t)(kin + e / BN) * g.ldb + min(l_n0 + e % BN, g.N - 4);
+        pb[i] = g.B + tap * g.conv.b_tap_stride + (size_t)(gch + kin + e / BN) * g.ldb + min(col0 + e % BN, cols - 4);
       }
     }
   };
@@ -593,6 +603,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     int m0, n0;
     if (!get_item(it, m0, n0, l_k, l_kend)) { l_valid = false; return; }
     l_n0 = n0;
+    l_m0 = m0;
 #pragma unroll
     for (int i = 0; i < LA; i++) {
       const int q = wave + i * NW;
@@ -634,8 +645,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           // column tile) pairs with GEMM row k; nothing to pair with -> the row of zeros
           const int e = q * 256 + lane * 4;
           const int tap = l_n0 / g.conv.seg, ch0 = l_n0 - tap * g.conv.seg;
+          const int gch = g.conv.a_group ? (l_m0 / g.conv.n_group) * g.conv.a_group : 0;   // the row tile's group
           const int src = conv_src_row(g.conv, l_k + e / BN, tap);
-          glds16((src >= 0 ? g.B + (size_t)src * g.ldb + ch0 : g.conv.zero) + e % BN, Bd + slot * SB + q * 256);
+          glds16((src >= 0 ? g.B + (size_t)src * g.ldb + gch + ch0 : g.conv.zero) + e % BN, Bd + slot * SB + q * 256);
         } else {
           glds16(pb[piece - LA], Bd + slot * SB + q * 256);
         }
@@ -779,7 +791,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         }
       };
       auto landed = [&]() {            // behind the barrier: every wave learns the ticket
-        if (draw) { ended = idq[n_fetched & 7] < 0; n_fetched++; }
+        if (draw) { ended = __builtin_amdgcn_readfirstlane(idq[n_fetched & 7]) < 0; n_fetched++; }
       };
       if constexpr (Probe::on) {
         const unsigned long long s0 = __builtin_amdgcn_s_memtime();

@@ -63,6 +63,50 @@ class _SkSqSum(torch.autograd.Function):
         return ops.sk_sqsum_bwd(dy.contiguous(memory_format=_fmt(a)), a, b)
 
 
+# SK's two grouped convolutions (8 groups of 128 channels, 1x1 and 3x3) on the library's implicit-GEMM kernels:
+# with 128 channels per group a 128-column tile of the GEMM lies inside one group, so the grouped convolution is
+# the dense kernel with the gathered operand's channel offset taken from the tile's column (csrc/gemm_f32_impl.h,
+# ConvGeom::a_group).  Proposal side only (bs*64 query rows are a launch-latency problem: MIOpen).  Opt-in
+# (AIT_SK_HIP=1): built and tested, but 2.6 ms/step SLOWER than MIOpen / CK on the bench -- the block runs at
+# stride 2 (dead-position elimination), and the data gradient of a stride-2 convolution as a gather over all nine
+# taps multiplies three zero rows for every useful one (181 GFLOP executed for 45 useful).
+_SK_HIP = os.environ.get("AIT_SK_HIP", "0") == "1"
+_SK_HIP_MIN_ROWS = 4096
+
+
+class _GroupedConv(torch.autograd.Function):
+    """y = conv2d(x, w, bias, stride, padding, groups) on channels-last maps, forward and both gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, groups):
+        n, c, h, wd = x.shape
+        k = w.size(2)
+        oh, ow = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+        xr = x.permute(0, 2, 3, 1).reshape(n * h * wd, c)                 # (channels-last: a view)
+        wr = w.permute(0, 2, 3, 1).contiguous()                           # [cout, kh, kw, cin/g]
+        geom = ops.conv_geom(n, (h, wd), (oh, ow), (k, k), stride, pad, groups)
+        y = ops.conv_fwd(xr, wr, geom, bias=bias)
+        ctx.save_for_backward(xr, wr)
+        ctx.cfg = (geom, k, (n, c, h, wd), (oh, ow), bias is not None)
+        return y.view(n, oh, ow, w.size(0)).permute(0, 3, 1, 2)           # NCHW shape, channels-last memory
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        geom, k, (n, c, h, wd), (oh, ow), has_bias = ctx.cfg
+        dyr = dy.permute(0, 2, 3, 1).reshape(n * oh * ow, dy.size(1))
+        if not dyr.is_contiguous():
+            dyr = dyr.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv_bwd_data(dyr, wr, geom).view(n, h, wd, c).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_bwd_weight(dyr, xr, geom, k, k, split_k=16).permute(0, 3, 1, 2)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dyr)
+        return dx, dw, db, None, None, None
+
+
 class SKBlock(nn.Module):
     """Selective-kernel block as the reference actually computes it: two grouped conv branches
     (1x1 and 3x3, 8 groups, ReLU); the branch-attention weights `a` are computed and then NOT
@@ -86,6 +130,14 @@ class SKBlock(nn.Module):
 
     def _branch(self, i, x, stride):
         conv = self.convs[i][0]
+        k, g = conv.kernel_size[0], conv.groups
+        if (_SK_HIP and x.is_cuda and x.dtype == torch.float32 and _fmt(x) == torch.channels_last
+                and x.size(0) * x.size(2) * x.size(3) >= _SK_HIP_MIN_ROWS and conv.dilation == (1, 1)
+                and (x.size(1) // g) % 128 == 0 and (conv.out_channels // g) % 128 == 0):
+            oh = (x.size(2) + 2 * conv.padding[0] - k) // stride + 1
+            ow = (x.size(3) + 2 * conv.padding[1] - k) // stride + 1
+            if ops.conv_supported((x.size(2), x.size(3)), (oh, ow), stride, x.size(1) // g, conv.out_channels // g):
+                return _GroupedConv.apply(x, conv.weight, conv.bias, stride, conv.padding[0], g)
         if stride == 1:
             return conv(x)
         return F.conv2d(x, conv.weight, conv.bias, stride, conv.padding, conv.dilation, conv.groups)

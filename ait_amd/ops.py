@@ -410,10 +410,10 @@ def _zeros(device, n=8192):
     return _ZEROS[key]
 
 
-def conv_geom(n, in_hw, out_hw, k, stride, pad):
+def conv_geom(n, in_hw, out_hw, k, stride, pad, groups=1):
     g = _lib.ConvGeom()
     g.n, g.in_h, g.in_w, g.out_h, g.out_w = int(n), int(in_hw[0]), int(in_hw[1]), int(out_hw[0]), int(out_hw[1])
-    g.kh, g.kw, g.stride, g.pad = int(k[0]), int(k[1]), int(stride), int(pad)
+    g.kh, g.kw, g.stride, g.pad, g.groups = int(k[0]), int(k[1]), int(stride), int(pad), int(groups)
     return g
 
 
@@ -425,8 +425,8 @@ def conv_supported(in_hw, out_hw, stride, cin, cout):
 
 
 def conv_fwd(x, w, geom, bias=None, residual=None, relu=False):
-    """x [rows_in, cin] token rows of a channels-last map, w [cout, kh, kw, cin] -> y [rows_out, cout]"""
-    cout, cin = w.shape[0], w.shape[3]
+    """x [rows_in, cin] token rows of a channels-last map, w [cout, kh, kw, cin / groups] -> y [rows_out, cout]"""
+    cout, cin = w.shape[0], w.shape[3] * max(1, geom.groups)
     rows = geom.n * geom.out_h * geom.out_w
     y = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
     z = _zeros(x.device)
@@ -439,7 +439,7 @@ def conv_fwd(x, w, geom, bias=None, residual=None, relu=False):
 
 
 def conv_bwd_data(dy, w, geom, residual=None, mask_pos=False):
-    cout, cin = w.shape[0], w.shape[3]
+    cout, cin = w.shape[0], w.shape[3] * max(1, geom.groups)
     rows = geom.n * geom.in_h * geom.in_w
     dx = torch.empty((rows, cin), dtype=torch.float32, device=dy.device)
     z = _zeros(dy.device)
@@ -453,7 +453,7 @@ def conv_bwd_data(dy, w, geom, residual=None, mask_pos=False):
 
 def conv_bwd_weight(dy, x, geom, kh, kw, split_k=8):
     cout, cin = dy.shape[1], x.shape[1]
-    dw = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=dy.device)
+    dw = torch.zeros((cout, kh, kw, cin // max(1, geom.groups)), dtype=torch.float32, device=dy.device)
     z = _zeros(dy.device)
     with torch.cuda.device(dy.device):
         rc = _lib.lib().ait_conv_bwd_weight_f32(_lib.dev_ptr(dy), dy.stride(0), _lib.dev_ptr(x), x.stride(0),

@@ -275,6 +275,9 @@ int ait_sh_general_bwd(const float* du, const float* O, const float* gate, const
  * ------------------------------------------------------------------------------------- */
 typedef struct {
   int n, in_h, in_w, out_h, out_w, kh, kw, stride, pad;
+  int groups; /* 0 or 1: dense.  > 1: grouped convolution (the SK block's branches,
+                 blocks_sys_transformer_sk_dilat.py:938-947): weights [cout][kh][kw][cin/groups], cin/groups and
+                 cout/groups multiples of 128 (a 128-wide tile of the implicit GEMM lies inside one group) */
 } ait_conv_geom;
 int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_conv_geom* geom, int cin, int cout,
                      const float* bias, const float* residual, int flags, float* y, int ldy, const float* zeros,

@@ -484,3 +484,57 @@ def test_anchor_target_kernels_equal_the_tensor_expressions(monkeypatch):
             else:
                 assert torch.equal(a, w.to(a.dtype)), (name, trial)
         assert int((outs[True][0] == 1).sum()) > 0 and int((outs[True][0] == 0).sum()) > 0
+
+
+@pytest.mark.parametrize("n,k,stride,pad", [(300, 3, 2, 1), (300, 1, 2, 0), (80, 3, 1, 1)])
+def test_grouped_implicit_gemm_convolutions_vs_torch(n, k, stride, pad):
+    """The SK block's grouped convolutions (8 groups of 128 channels, blocks_sys_transformer_sk_dilat.py:938-947)
+    on the implicit-GEMM kernels -- forward with bias, data and weight gradients -- against torch's grouped
+    convolution in float64, at the bench geometry (8x8 maps evaluated at stride 2) and at stride 1."""
+    from ait_amd import ops
+    torch.manual_seed(n + k)
+    G, C, hw = 8, 1024, 8
+    oh = (hw + 2 * pad - k) // stride + 1
+    x = torch.randn(n, C, hw, hw, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.randn(C, C // G, k, k, device="cuda") * (1.0 / (C // G * k * k) ** 0.5)
+    bias = torch.randn(C, device="cuda")
+    xm = x.permute(0, 2, 3, 1).reshape(n * hw * hw, C)
+    wm = w.permute(0, 2, 3, 1).contiguous()
+    geom = ops.conv_geom(n, (hw, hw), (oh, oh), (k, k), stride, pad, groups=G)
+    y = ops.conv_fwd(xm, wm, geom, bias=bias)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), stride, pad, 1, G).permute(0, 2, 3, 1).reshape(-1, C)
+    assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+    dy = torch.randn(n * oh * oh, C, device="cuda")
+    dyn = dy.view(n, oh, oh, C).permute(0, 3, 1, 2).double()
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xd, wd, None, stride, pad, 1, G).backward(dyn)
+    dx = ops.conv_bwd_data(dy, wm, geom)
+    dx_ref = xd.grad.permute(0, 2, 3, 1).reshape(-1, C)
+    assert float((dx.double() - dx_ref).abs().max()) <= 2e-5 * float(dx_ref.abs().max()) + 1e-6
+    dw = ops.conv_bwd_weight(dy, xm, geom, k, k, split_k=16)
+    dw_ref = wd.grad.permute(0, 2, 3, 1)
+    assert float((dw.double() - dw_ref).abs().max()) <= 5e-5 * float(dw_ref.abs().max()) + 1e-6
+
+
+def test_sk_block_on_hip_grouped_convolutions_matches_miopen(monkeypatch):
+    """SKBlock with its two grouped convolutions on the library's kernels against the same block on MIOpen / CK:
+    output and every gradient (the fused ReLU / square / sum tail is common to both)."""
+    import ait_amd.faster_rcnn as fr
+    torch.manual_seed(6)
+    blk = fr.SKBlock(1024).cuda()
+    x0 = torch.randn(300, 1024, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = None
+    res = {}
+    for hip in (True, False):
+        monkeypatch.setattr(fr, "_SK_HIP", hip)
+        x = x0.clone().requires_grad_(True)
+        blk.zero_grad(set_to_none=True)
+        y = blk(x, stride=2)
+        if gy is None:
+            gy = torch.randn_like(y)
+        y.backward(gy)
+        res[hip] = [y.detach(), x.grad] + [p.grad.clone() for p in blk.convs.parameters()]
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    for a, b in zip(res[True], res[False]):
+        assert a.shape == b.shape and rel(a, b) < 2e-5

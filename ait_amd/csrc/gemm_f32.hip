@@ -148,14 +148,19 @@ inline int check_geom(const ait_conv_geom* q, int cin, int cout) {
   return AIT_OK;
 }
 
-template <class T, int CONV, bool AK, bool BKC>
+template <class T, int CONV, bool AK, bool BKC, bool GRP = false>
 int conv_launch(const GemmArgs& g, hipStream_t s) {
-  if (g.flags & AIT_GEMM_ATOMIC) return launch<T, AK, BKC, EPI_ATOMIC, NoProbe, CONV>(g, s);
+  if (g.flags & AIT_GEMM_ATOMIC) return launch<T, AK, BKC, EPI_ATOMIC, NoProbe, CONV, GRP>(g, s);
+  if (GRP) return launch<T, AK, BKC, EPI_STORE, NoProbe, CONV, GRP>(g, s);      // (grouped: bias only)
   if (g.residual) return launch<T, AK, BKC, EPI_RES, NoProbe, CONV>(g, s);
   return launch<T, AK, BKC, EPI_STORE, NoProbe, CONV>(g, s);
 }
 template <int CONV, bool AK, bool BKC>
 int conv_dispatch(const GemmArgs& g, hipStream_t s) {
+  if (g.conv.a_group) {        // grouped: separate instantiations (see glds16<FORCE_UNIFORM>)
+    if (g.residual || (g.flags & ~AIT_GEMM_RELU)) return AIT_EUNSUPPORTED;
+    return conv_launch<Tile256D, CONV, AK, BKC, true>(g, s);
+  }
   const long long tiles256 = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128) * g.splits;
   if (tiles256 >= 512 || (tiles256 >= 96 && g.K >= 512 && g.splits == 1 && !(g.flags & AIT_GEMM_ATOMIC) && stream_k_mode() != 0))
     return conv_launch<Tile256D, CONV, AK, BKC>(g, s);
@@ -222,6 +227,6 @@ AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, i
   AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), cout, taps * cing, (int)rows, 1, 0,
                       g.splits);
   // (grouped: 128-row tiles, one group of output channels per row tile)
-  if (G > 1) return conv_launch<Tile128D, CONV_B, false, false>(g, ait_stream(stream));
+  if (G > 1) return conv_launch<Tile128D, CONV_B, false, false, true>(g, ait_stream(stream));
   return conv_launch<Tile256D, CONV_B, false, false>(g, ait_stream(stream));
 }

@@ -198,9 +198,13 @@ typedef __attribute__((address_space(3))) void lds_void;
 // operand fetch, i.e. it serialises the slab's memory latency with the MFMA stream.  Ordering is
 // explicit instead: a slot is requested only after the barrier that retired its last reader, and
 // awaited (vmcnt) before the barrier that publishes it.
+template <bool FORCE_UNIFORM = false>
 __device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
-  // wave-uniform LDS address (readfirstlane: a no-op where the compiler already knows it, the proof where it does not)
-  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)lds_dst);
+  // wave-uniform LDS address.  (FORCE_UNIFORM: the grouped-convolution instantiations, where hipcc loses the proof
+  // and would hand the asm a VGPR; the readfirstlane drags the address arithmetic into vector registers, which is why
+  // it is not used for the other kernels)
+  const unsigned dst = FORCE_UNIFORM ? __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)lds_dst)
+                                     : (unsigned)(size_t)(lds_void*)lds_dst;
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "m0", "memory");
 }
 
@@ -440,7 +444,7 @@ struct WorkMap {
 // slab s+1 before that barrier, so the MFMA stream runs across it -- and across the epilogue of a
 // finished tile, whose stores are issued while the next tile's first slabs are already in LDS.
 // =========================================================================================================
-template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe, int CONV = CONV_NONE>
+template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe, int CONV = CONV_NONE, bool GRP = false>
 __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const GemmArgs g) {
   static_assert(C::MODE == MODE_DLDS && C::BK == 16 && C::BM % 16 == 0 && C::BN % 16 == 0,
                 "direct-to-LDS path needs 16-float slabs");
@@ -527,11 +531,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     }
     __syncthreads();
     n_fetched = 1;
-    ended = __builtin_amdgcn_readfirstlane(idq[0]) < 0;
+    ended = idq[0] < 0;
   }
   // whole item k of this workgroup -> id within the chunk's whole items, or -1 past the end
   auto dp_id = [&](int k) -> int {
-    if (dyn) return __builtin_amdgcn_readfirstlane(idq[k & 7]);      // (every lane reads the same word: say so)
+    if (dyn) return idq[k & 7];
     const int id = j + k * W;
     return id < lim_dp ? id : -1;
   };
@@ -579,8 +583,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // CONV_A: operand pointers at reduction index l_k = tap * seg + kin
   auto retap = [&]() {
     const int tap = l_k / g.conv.seg, kin = l_k - tap * g.conv.seg;
-    const int grp = g.conv.a_group ? l_n0 / g.conv.n_group : 0;
-    const int gch = grp * g.conv.a_group;          // first channel of the tile's group in the gathered operand
+    int grp = 0, gch = 0;                          // GRP: the tile's group, its first channel in the gathered operand
+    if constexpr (GRP) { grp = l_n0 / g.conv.n_group; gch = grp * g.conv.a_group; }
 #pragma unroll
     for (int i = 0; i < LA; i++) {
       const int row = (wave + i * NW) * 16 + (lane >> 2);
@@ -590,8 +594,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     }
     if (!BKC) {
       // K-outer weights [co][tap][ci]: rows = output channels (of the tile's group), columns within the tap
-      const int col0 = g.conv.a_group ? l_n0 - grp * g.conv.n_group : l_n0;
-      const int cols = g.conv.a_group ? g.conv.n_group : g.N;
+      const int col0 = GRP ? l_n0 - grp * g.conv.n_group : l_n0;
+      const int cols = GRP ? g.conv.n_group : g.N;
 #pragma unroll
       for (int i = 0; i < LB; i++) {
         const int e = (wave + i * NW) * 256 + lane * 4;
@@ -603,7 +607,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     int m0, n0;
     if (!get_item(it, m0, n0, l_k, l_kend)) { l_valid = false; return; }
     l_n0 = n0;
-    l_m0 = m0;
+    if constexpr (GRP) l_m0 = m0;
 #pragma unroll
     for (int i = 0; i < LA; i++) {
       const int q = wave + i * NW;
@@ -636,7 +640,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   auto issue = [&](int piece, int slot) {
     if (piece < LA) {
       const int q = wave + piece * NW;
-      if (GA % NW == 0 || q < GA) glds16(pa[piece], As + slot * SA + q * 256);
+      if (GA % NW == 0 || q < GA) glds16<GRP>(pa[piece], As + slot * SA + q * 256);
     } else {
       const int q = wave + (piece - LA) * NW;
       if (GB % NW == 0 || q < GB) {
@@ -645,11 +649,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           // column tile) pairs with GEMM row k; nothing to pair with -> the row of zeros
           const int e = q * 256 + lane * 4;
           const int tap = l_n0 / g.conv.seg, ch0 = l_n0 - tap * g.conv.seg;
-          const int gch = g.conv.a_group ? (l_m0 / g.conv.n_group) * g.conv.a_group : 0;   // the row tile's group
+          const int gch = GRP ? (l_m0 / g.conv.n_group) * g.conv.a_group : 0;   // the row tile's group
           const int src = conv_src_row(g.conv, l_k + e / BN, tap);
-          glds16((src >= 0 ? g.B + (size_t)src * g.ldb + gch + ch0 : g.conv.zero) + e % BN, Bd + slot * SB + q * 256);
+          glds16<GRP>((src >= 0 ? g.B + (size_t)src * g.ldb + gch + ch0 : g.conv.zero) + e % BN, Bd + slot * SB + q * 256);
         } else {
-          glds16(pb[piece - LA], Bd + slot * SB + q * 256);
+          glds16<GRP>(pb[piece - LA], Bd + slot * SB + q * 256);
         }
       }
     }
@@ -791,7 +795,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         }
       };
       auto landed = [&]() {            // behind the barrier: every wave learns the ticket
-        if (draw) { ended = __builtin_amdgcn_readfirstlane(idq[n_fetched & 7]) < 0; n_fetched++; }
+        if (draw) { ended = idq[n_fetched & 7] < 0; n_fetched++; }
       };
       if constexpr (Probe::on) {
         const unsigned long long s0 = __builtin_amdgcn_s_memtime();
@@ -1130,7 +1134,7 @@ inline int stream_slots() {
   return (per_cu < 1 ? 1 : per_cu) * cus;
 }
 
-template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe, int CONV = CONV_NONE>
+template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe, int CONV = CONV_NONE, bool GRP = false>
 int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
   GemmArgs gl = g;
   gl.sk_ws = nullptr;
@@ -1171,7 +1175,7 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
       }
     }
     blocks = (unsigned)(w * AIT_NXCD);
-    kern = reinterpret_cast<const void*>(gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV>);
+    kern = reinterpret_cast<const void*>(gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV, GRP>);
   } else {
     blocks = (unsigned)(wmap.chunk * AIT_NXCD);
     kern = reinterpret_cast<const void*>(gemm_f32_kernel<C, AK, BKC, EPI>);
@@ -1180,7 +1184,7 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
       hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) != hipSuccess)
     return AIT_ELAUNCH;
   if constexpr (C::MODE == MODE_DLDS)
-    hipLaunchKernelGGL((gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV>), dim3(blocks), dim3(C::NT), C::LDS, s, gl);
+    hipLaunchKernelGGL((gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV, GRP>), dim3(blocks), dim3(C::NT), C::LDS, s, gl);
   else
     hipLaunchKernelGGL((gemm_f32_kernel<C, AK, BKC, EPI>), dim3(blocks, g.batch > 1 ? g.batch : 1, g.batch2 > 1 ? g.batch2 : 1),
                        dim3(C::NT), C::LDS, s, g);

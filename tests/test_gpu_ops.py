@@ -538,3 +538,26 @@ def test_sk_block_on_hip_grouped_convolutions_matches_miopen(monkeypatch):
     rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
     for a, b in zip(res[True], res[False]):
         assert a.shape == b.shape and rel(a, b) < 2e-5
+
+
+def test_box_kernel_edge_cases():
+    """Degenerate inputs of the box kernels: a single gt box, RoIs that all miss it (no foreground: every RoI is
+    background or nothing), one image in the batch, and proposal counts that are not a multiple of the
+    workgroup's per-thread share -- against the tensor expressions."""
+    from ait_amd.rpn import _ProposalTargetLayer
+    torch.manual_seed(2)
+    ptl = _ProposalTargetLayer(2)
+    for b, R0, G in ((1, 37, 1), (2, 1, 3), (3, 2000, 20)):
+        rois = torch.zeros(b, R0, 5, device="cuda")
+        xy = torch.rand(b, R0, 2, device="cuda") * 100
+        rois[:, :, 1:3] = xy.round()
+        rois[:, :, 3:5] = (xy + 5 + torch.rand(b, R0, 2, device="cuda") * 40).round()
+        gt = torch.zeros(b, G, 5, device="cuda")
+        gt[:, 0, :4] = torch.tensor([400.0, 300.0, 480.0, 390.0], device="cuda")      # far from every RoI
+        gt[:, 0, 4] = 1
+        want = ptl._classify(rois, gt)
+        got = ptl._classify_hip(rois, gt)
+        for name, a, w in zip(["all_rois", "assign", "labels", "counts", "fg_members", "bg_members"], got, want):
+            assert torch.equal(a, w.to(a.dtype)), (name, b, R0, G)
+        # the only foreground RoI is the gt box itself (appended as a RoI: IoU 1)
+        assert bool((got[3][:, 0] == 1).all())

@@ -327,3 +327,27 @@ def test_batched_gemm_layouts_and_autograd():
     out = ops.bgemm(rho.detach(), phi.detach().contiguous(), False, True)
     ops.bgemm(rho.detach(), phi.detach(), False, True, alpha=0.5, out=out, accumulate=True)
     assert rel_err(out, 1.5 * rel_r) < 1e-6
+
+
+def test_gemm_whole_tile_mode_without_scratch():
+    """AIT_GEMM_STREAMK=0: static work lists, whole tiles only, and the library allocates nothing -- same results
+    (the switch is read once per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch\n"
+        "from ait_amd import ops, _lib\n"
+        "torch.manual_seed(3)\n"
+        "for M, N, K in ((19200, 512, 2048), (76800, 1536, 512), (33000, 512, 64)):\n"
+        "    a, w = torch.randn(M, K, device='cuda'), torch.randn(N, K, device='cuda')\n"
+        "    c = ops.gemm(a, w, trans_b=True)\n"
+        "    want = a.double() @ w.double().t()\n"
+        "    bound = 6e-7 * (a.double().abs() @ w.double().abs().t()) + 1e-6\n"
+        "    assert bool(((c.double() - want).abs() <= bound).all()), (M, N, K)\n"
+        "assert _lib.lib().ait_gemm_workspace_release() == 0\n"
+        "print('ok')\n")
+    env = dict(os.environ, AIT_GEMM_STREAMK="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -97,7 +97,7 @@ SIGNATURES = {
                           _vp, _i, _vp, _i, _vp]),
 }
 
-GEMM_RELU, GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_BIAS_ROW, GEMM_MASK_POS = 1, 2, 4, 8, 16
+GEMM_RELU, GEMM_ACCUMULATE, GEMM_ATOMIC, GEMM_BIAS_ROW, GEMM_MASK_POS, GEMM_COLSUM = 1, 2, 4, 8, 16, 32
 
 _lib = None
 

@@ -265,10 +265,11 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
   const bool interior = (m0 + wm + TM * 32 <= g.M) && (n0 + wn + TN * 32 <= g.N);   // wave-uniform
   // row r of an MFMA tile sits (r&3) + 8*(r>>2) rows below its first row
 #define AIT_ROW(r) (((r) & 3) + 8 * ((r) >> 2))
-  float bcol[TN];
+  const bool colsum = EPI != EPI_ATOMIC && (g.flags & AIT_GEMM_COLSUM) != 0;    // g.bias is then the OUTPUT
+  float bcol[TN], cs[TN];
 #pragma unroll
-  for (int b = 0; b < TN; b++) bcol[b] = 0.f;
-  if (EPI != EPI_ATOMIC && g.bias && !(g.flags & AIT_GEMM_BIAS_ROW)) {
+  for (int b = 0; b < TN; b++) { bcol[b] = 0.f; cs[b] = 0.f; }
+  if (EPI != EPI_ATOMIC && g.bias && !(g.flags & AIT_GEMM_BIAS_ROW) && !colsum) {
 #pragma unroll
     for (int b = 0; b < TN; b++) bcol[b] = g.bias[min(n0 + wn + b * 32 + li, g.N - 1)];
   }
@@ -283,6 +284,16 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
     cb[b] = g.c_colblk > 0 ? (unsigned)(colc / g.c_colblk) * (unsigned)g.c_batch + (unsigned)(colc % g.c_colblk)
                            : (unsigned)colc;
   }
+
+  // column sums of what this wave stores, added to g.bias[col] at the end (lanes l and l+32 hold the same column)
+  auto flush_colsum = [&]() {
+    if (!colsum) return;
+#pragma unroll
+    for (int b = 0; b < TN; b++) {
+      const float s = cs[b] + __shfl_xor(cs[b], 32, 64);
+      if (lk == 0 && cok[b]) unsafeAtomicAdd(const_cast<float*>(g.bias) + (n0 + wn + b * 32 + li), s);
+    }
+  };
 
   if (EPI == EPI_RES) {
     // ---- residual add / ReLU-backward gate, software-pipelined over the TM*TN MFMA tiles: the 16 loads
@@ -309,12 +320,13 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
         v = mask_pos ? (x[r] > 0.f ? v : 0.f) : v + x[r];
         if (relu) v = fmaxf(v, 0.f);
         const int row = row_of(i, r);
-        if (interior || (cok[b] && row < g.M)) g.C[cb[b] + (unsigned)row * ldc] = v;
+        if (interior || (cok[b] && row < g.M)) { g.C[cb[b] + (unsigned)row * ldc] = v; cs[b] += v; }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 16; r++) x[r] = xn[r];
     }
+    flush_colsum();
     return;
   }
 
@@ -376,15 +388,19 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
           }
           if (interior) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) g.C[obase + (unsigned)AIT_ROW(h * 8 + q) * ldc] = v[q];
+            for (int q = 0; q < 8; q++) { g.C[obase + (unsigned)AIT_ROW(h * 8 + q) * ldc] = v[q]; cs[b] += v[q]; }
           } else {
 #pragma unroll
             for (int q = 0; q < 8; q++)
-              if (cok[b] && rbase + AIT_ROW(h * 8 + q) < g.M) g.C[obase + (unsigned)AIT_ROW(h * 8 + q) * ldc] = v[q];
+              if (cok[b] && rbase + AIT_ROW(h * 8 + q) < g.M) {
+                g.C[obase + (unsigned)AIT_ROW(h * 8 + q) * ldc] = v[q];
+                cs[b] += v[q];
+              }
           }
         }
       }
     }
+  flush_colsum();
 #undef AIT_ROW
 }
 
@@ -1232,6 +1248,8 @@ inline int make_args(int trans_a, int trans_b, int M, int N, int K, float alpha,
   if ((flags & AIT_GEMM_ATOMIC) && (bias || residual || (flags & AIT_GEMM_RELU)))
     return AIT_EINVAL;
   if ((flags & AIT_GEMM_MASK_POS) && !residual) return AIT_EINVAL;
+  if ((flags & AIT_GEMM_COLSUM) && (!bias || c_colblk > 0 || (flags & (AIT_GEMM_ATOMIC | AIT_GEMM_BIAS_ROW | AIT_GEMM_ACCUMULATE))))
+    return AIT_EINVAL;
   g.A = A; g.B = B; g.C = C; g.bias = bias; g.residual = residual;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.c_colblk = c_colblk; g.c_batch = c_batch_stride; g.alpha = alpha; g.flags = flags;

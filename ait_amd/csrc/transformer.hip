@@ -54,10 +54,12 @@ inline int linear(const float* x, int M, int K, const float* w, int N, const flo
   return ait_gemm_f32(0, 1, M, N, K, 1.f, x, K, w, K, y, N, b, nullptr, relu ? AIT_GEMM_RELU : 0, 1, 0, 0, s);
 }
 // dx [M, K_in] = dy [M, N_out] . W [N_out, K_in]  (+ residual, or gated by `residual` > 0 with mask_pos)
+// `colsum` (optional): float[K_in] into which the column sums of dx are ADDED in the product's epilogue (the bias
+// gradient of the layer dx flows into)
 inline int dgrad(const float* dy, int M, int N_out, const float* w, int K_in, const float* residual, bool mask_pos,
-                 float* dx, void* s) {
-  return ait_gemm_f32(0, 0, M, K_in, N_out, 1.f, dy, N_out, w, K_in, dx, K_in, nullptr, residual,
-                      mask_pos ? AIT_GEMM_MASK_POS : 0, 1, 0, 0, s);
+                 float* dx, void* s, float* colsum = nullptr) {
+  return ait_gemm_f32(0, 0, M, K_in, N_out, 1.f, dy, N_out, w, K_in, dx, K_in, colsum, residual,
+                      (mask_pos ? AIT_GEMM_MASK_POS : 0) | (colsum ? AIT_GEMM_COLSUM : 0), 1, 0, 0, s);
 }
 // K-splits of a weight gradient [M_out, N_out] = sum over K tokens: multiples of 8 (each XCD owns whole
 // K-ranges), chosen so that tiles x splits fills the resident workgroup slots of the 256x128 kernel in
@@ -206,9 +208,8 @@ int ffn_block_bwd(const float* dy, const float* x, long long rows, const ait_ffn
   AIT_TRY(ait_ln_bwd(dy, m.f, nullptr, x, w.ln_g, m.mean, m.rstd, rows, D, T, T, 1, T, p, ait_dropout_seed(seed, 0),
                      t.df, t.dres, g.ln_g, g.ln_b, g.b2, s));
   AIT_TRY(wgrad(t.df, rows, D, m.h, DI, g.w2, s));                             // d W2 += df^T h
-  AIT_TRY(dgrad(t.df, R, D, w.w2, DI, m.h, true, t.dh, s));                    // dh = (df W2) [h > 0]
+  AIT_TRY(dgrad(t.df, R, D, w.w2, DI, m.h, true, t.dh, s, g.b1));             // dh = (df W2) [h > 0];  d b1 += column sums
   AIT_TRY(wgrad(t.dh, rows, DI, x, D, g.w1, s));                               // d W1 += dh^T x
-  if (g.b1) AIT_TRY(ait_colsum_f32(t.dh, rows, DI, DI, g.b1, s));
   return dgrad(t.dh, R, DI, w.w1, D, t.dres, false, dx, s);                    // dx = dh W1 + dres
 }
 

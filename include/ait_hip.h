@@ -212,6 +212,11 @@ int ait_roi_sample_gather(const int64_t* pos, const int64_t* n_fg, int b, int P,
 #define AIT_GEMM_BIAS_ROW 8
 #define AIT_GEMM_MASK_POS 16 /* C = (residual > 0) ? value : 0  (ReLU backward; `residual` holds
                                 the saved forward activation and is NOT added) */
+#define AIT_GEMM_COLSUM 32   /* `bias` is an OUTPUT: float[N] into which the column sums of the stored C are
+                                ADDED (fp32 atomics, one per column per tile) -- the bias gradient of the layer
+                                whose input gradient this product is (SubLayers.py:181: d b1 = sum over tokens of
+                                dh), without a second pass over C.  No bias is added; not with AIT_GEMM_ATOMIC /
+                                AIT_GEMM_BIAS_ROW / AIT_GEMM_ACCUMULATE / c_colblk. */
 int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
                  int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
                  const float* residual, int flags, int split_k, int c_colblk,

@@ -351,3 +351,34 @@ def test_gemm_whole_tile_mode_without_scratch():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("M,N,K", [(76800, 2048, 512), (19200, 512, 2048), (300, 200, 64), (33002, 520, 64)])
+def test_gemm_column_sums_in_the_epilogue(M, N, K):
+    """AIT_GEMM_COLSUM: the bias gradient of the layer an input gradient flows into (SubLayers.py:181), formed in
+    the product's epilogue -- with the ReLU-backward gate, on whole and stream-K tiles, ragged edges included --
+    equals the column sums of the stored result."""
+    import ctypes
+    from ait_amd import _lib
+    torch.manual_seed(M + K)
+    a = torch.randn(M, K, device="cuda")
+    w = torch.randn(K, N, device="cuda")
+    act = torch.randn(M, N, device="cuda")
+    out = torch.empty(M, N, device="cuda")
+    cs = torch.zeros(N, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().ait_gemm_f32(0, 0, M, N, K, 1.0, p(a), K, p(w), N, p(out), N, p(cs), p(act),
+                                     _lib.GEMM_MASK_POS | _lib.GEMM_COLSUM, 1, 0, 0, _lib.cur_stream(a.device))
+    assert rc == 0
+    want = (a.double() @ w.double()) * (act > 0)
+    assert bool(((out.double() - want).abs() <= _abs_bound(a, w, False, False)).all())
+    ref = out.double().sum(0)
+    assert float((cs.double() - ref).abs().max()) <= 1e-5 * float(out.double().abs().sum(0).max()) + 1e-4
+    # a second call ADDS
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().ait_gemm_f32(0, 0, M, N, K, 1.0, p(a), K, p(w), N, p(out), N, p(cs), None,
+                                     _lib.GEMM_COLSUM, 1, 0, 0, _lib.cur_stream(a.device))
+    assert rc == 0
+    ref2 = ref + (a.double() @ w.double()).sum(0)
+    assert float((cs.double() - ref2).abs().max()) <= 1e-5 * float((a.double().abs() @ w.double().abs()).sum(0).max()) + 1e-4

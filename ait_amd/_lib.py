@@ -18,17 +18,19 @@ _ll, _ull = ctypes.c_longlong, ctypes.c_ulonglong
 SIGNATURES = {
     "ait_abi_version": (_i, []),
     "ait_strerror": (ctypes.c_char_p, [_i]),
+    "ait_gemm_workspace_bytes": (_sz, []),
+    "ait_gemm_workspace_init": (_i, [_vp, _sz, _vp]),
     "ait_probe_create": (_vp, [_i]),
     "ait_probe_destroy": (None, [_vp]),
-    "ait_probe_attach": (None, [_vp]),
     "ait_probe_reset": (_i, [_vp]),
     "ait_probe_count": (_i, [_vp]),
+    "ait_probe_capacity": (_i, [_vp]),
     "ait_probe_get": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "ait_roi_align_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "ait_roi_align_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "ait_roi_align_nhwc_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "ait_roi_align_nhwc_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
-    "ait_roi_align_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp]),
+    "ait_roi_align_nhwc_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
+    "ait_roi_align_nhwc_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
     "ait_nms_workspace_bytes": (_sz, [_i]),
     "ait_nms": (_i, [_vp, _vp, _i, _f, _i, _vp, _sz, _vp, _vp, _vp]),
     "ait_nms_batched_workspace_bytes": (_sz, [_i, _i]),
@@ -48,27 +50,26 @@ SIGNATURES = {
     "ait_sk_sqsum_fwd": (_i, [_vp, _vp, _ll, _vp, _vp]),
     "ait_sk_sqsum_bwd": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _vp]),
     "ait_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
-                          _i, ctypes.c_longlong, _vp]),
-    "ait_gemm_workspace_release": (_i, []),
+                          _i, ctypes.c_longlong, _vp, _vp]),
     "ait_gemm_f32_batched": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _ll, _ll, _vp, _i, _ll, _ll, _vp, _i, _ll, _ll, _i, _i,
-                                  _i, _i, _vp]),
+                                  _i, _i, _vp, _vp]),
     "ait_softmax_rows_fwd": (_i, [_vp, _ll, _i, _ll, _f, _ull, _vp, _vp, _vp]),
     "ait_softmax_rows_bwd": (_i, [_vp, _vp, _ll, _i, _ll, _f, _ull, _vp, _vp]),
     "ait_sh_general_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ait_sh_general_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "ait_conv_fwd_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
-    "ait_conv_bwd_data_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
-    "ait_conv_bwd_weight_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "ait_conv_fwd_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp]),
+    "ait_conv_bwd_data_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _sz, _vp, _vp]),
+    "ait_conv_bwd_weight_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp]),
     "ait_gemm_bf16": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
-                           _i, ctypes.c_longlong, _vp]),
+                           _i, ctypes.c_longlong, _vp, _vp]),
     "ait_gemm_bf16x3": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
-                             _i, ctypes.c_longlong, _vp]),
+                             _i, ctypes.c_longlong, _vp, _vp]),
     "ait_mha_block_workspace_bytes": (_sz, [_i, _i]),
-    "ait_mha_block_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
+    "ait_mha_block_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ait_ffn_workspace_bytes": (_sz, [_ll]),
-    "ait_ffn_fwd": (_i, [_vp, _ll, _vp, _vp, _sz, _vp, _vp]),
+    "ait_ffn_fwd": (_i, [_vp, _ll, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ait_transformer_workspace_bytes": (_sz, [_i, _i, _i]),
-    "ait_transformer_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
+    "ait_transformer_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ait_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp, _vp, _vp]),
     "ait_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _ull, _vp, _vp,
                         _vp, _vp, _vp, _vp]),
@@ -76,19 +77,19 @@ SIGNATURES = {
     "ait_rep_sum_f32": (_i, [_vp, _i, _i, _ll, _vp, _vp]),
     "ait_dropout_seed": (_ull, [_ull, _i]),
     "ait_mha_block_saved_bytes": (_sz, [_i, _i]),
-    "ait_mha_block_fwd_train": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _vp]),
+    "ait_mha_block_fwd_train": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _vp, _vp]),
     "ait_mha_block_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ait_mha_block_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp,
-                               _vp, _vp]),
+                               _vp, _vp, _vp]),
     "ait_ffn_saved_bytes": (_sz, [_ll]),
-    "ait_ffn_fwd_train": (_i, [_vp, _ll, _vp, _f, _ull, _vp, _sz, _vp, _vp]),
+    "ait_ffn_fwd_train": (_i, [_vp, _ll, _vp, _f, _ull, _vp, _sz, _vp, _vp, _vp]),
     "ait_ffn_bwd_workspace_bytes": (_sz, [_ll]),
-    "ait_ffn_bwd": (_i, [_vp, _vp, _ll, _vp, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp, _vp]),
+    "ait_ffn_bwd": (_i, [_vp, _vp, _ll, _vp, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
     "ait_transformer_saved_bytes": (_sz, [_i, _i, _i]),
-    "ait_transformer_fwd_train": (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _vp]),
+    "ait_transformer_fwd_train": (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _vp, _vp]),
     "ait_transformer_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "ait_transformer_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp,
-                                 _vp, _vp]),
+                                 _vp, _vp, _vp]),
     "ait_sh_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ait_sh_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ait_attn_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp,
@@ -163,9 +164,52 @@ class TransformerGrads(ctypes.Structure):
 PROBE_GEMM, PROBE_ROI_FWD, PROBE_ROI_BWD = 1, 2, 3
 
 
+class LaunchCtx(ctypes.Structure):
+    """ait_launch_ctx of include/ait_hip.h: caller-owned scheduler scratch of the persistent GEMM + probe."""
+    _fields_ = [("sched_ws", ctypes.c_void_p), ("sched_ws_bytes", ctypes.c_size_t), ("probe", ctypes.c_void_p)]
+
+
+# ---- the host side's launch contexts: one scheduler workspace per (device, stream), allocated with torch and
+# initialised once; the probe in force (a Python-level setting of THIS host layer: the library keeps none) ----
+_SCHED = {}          # (device index, stream handle) -> (uint8 tensor, LaunchCtx without probe)
+_ACTIVE_PROBE = None
+USE_SCHED_WS = True  # test hook: False = launch without scheduler scratch (static work lists, whole tiles)
+
+
+def launch_ctx(device=None):
+    """byref(ait_launch_ctx) for a launch on the current stream of `device`"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = torch.cuda.current_stream(dev)
+    ctx = LaunchCtx()
+    if USE_SCHED_WS:
+        key = (idx, st.cuda_stream)
+        ent = _SCHED.get(key)
+        if ent is None:
+            with torch.cuda.device(dev):
+                L = lib()
+                nbytes = int(L.ait_gemm_workspace_bytes())
+                if nbytes <= 0:
+                    raise AitHipError("ait_gemm_workspace_bytes failed")
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                check(L.ait_gemm_workspace_init(ctypes.c_void_p(buf.data_ptr()), nbytes, ctypes.c_void_p(st.cuda_stream)),
+                      "ait_gemm_workspace_init")
+            ent = _SCHED[key] = (buf, nbytes)
+        ctx.sched_ws, ctx.sched_ws_bytes = ent[0].data_ptr(), ent[1]
+    pr = _ACTIVE_PROBE
+    if pr is not None and pr._p and pr.device_index == idx:
+        ctx.probe = pr._p
+    return ctypes.byref(ctx)
+
+
+def release_sched_workspaces():
+    """drop the cached scheduler workspaces (their streams must be idle)"""
+    _SCHED.clear()
+
+
 class Probe:
-    """Measurement probe of include/ait_hip.h: while attached (to the calling thread), every GEMM / RoIAlign
-    launch of the library is bracketed by HIP events on its launch stream.
+    """Measurement probe of include/ait_hip.h: while active (`with probe:`), every launch context this host layer
+    builds carries it, so the library brackets each GEMM / RoIAlign launch with HIP events on its launch stream.
 
         with Probe(20000) as pr:  ...run...
         torch.cuda.synchronize(); rows = pr.entries()   # [(kind, work, ms, dims6), ...]
@@ -173,31 +217,44 @@ class Probe:
 
     def __init__(self, capacity=65536):
         self._L = lib()
+        self.device_index = torch.cuda.current_device()
         self._p = self._L.ait_probe_create(int(capacity))
         if not self._p:
             raise AitHipError("ait_probe_create failed")
 
     def __enter__(self):
+        global _ACTIVE_PROBE
+        torch.cuda.synchronize()                 # nothing in flight holds the probe while it is reset
         self._L.ait_probe_reset(self._p)
-        self._L.ait_probe_attach(self._p)
+        _ACTIVE_PROBE = self
         return self
 
     def __exit__(self, *exc):
-        self._L.ait_probe_attach(None)
+        global _ACTIVE_PROBE
+        _ACTIVE_PROBE = None
         return False
+
+    def overflowed(self):
+        """launches the probe saw beyond its capacity (their timings were not recorded)"""
+        return max(0, self._L.ait_probe_count(self._p) - self._L.ait_probe_capacity(self._p))
 
     def entries(self):
         out = []
         kind, work, ms = ctypes.c_int(), ctypes.c_double(), ctypes.c_float()
         dims = (ctypes.c_int * 6)()
-        for i in range(self._L.ait_probe_count(self._p)):
+        n = min(self._L.ait_probe_count(self._p), self._L.ait_probe_capacity(self._p))
+        for i in range(n):
             rc = self._L.ait_probe_get(self._p, i, ctypes.byref(kind), ctypes.byref(work), ctypes.byref(ms), dims)
             check(rc, "ait_probe_get (synchronise the stream first)")
             out.append((kind.value, work.value, ms.value, tuple(dims)))
         return out
 
     def close(self):
+        global _ACTIVE_PROBE
         if self._p:
+            if _ACTIVE_PROBE is self:
+                _ACTIVE_PROBE = None
+            torch.cuda.synchronize()
             self._L.ait_probe_destroy(self._p)
             self._p = None
 

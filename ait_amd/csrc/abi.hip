@@ -1,12 +1,11 @@
 // ait_amd/csrc/abi.hip -- ABI version + error strings of libait_hip.so.
 #include "common.h"
 
-#include <atomic>
 #include <new>
 
 
 
-AIT_API int ait_abi_version(void) { return 2; }
+AIT_API int ait_abi_version(void) { return 3; }
 
 AIT_API const char* ait_strerror(int code) {
   switch (code) {
@@ -20,15 +19,14 @@ AIT_API const char* ait_strerror(int code) {
 }
 
 // ---- measurement probe --------------------------------------------------------------------------------
-namespace {
-// process-wide (not per thread): PyTorch runs the backward on its autograd engine's threads
-std::atomic<AitProbe*> g_probe{nullptr};
-}
-AitProbe* ait_probe_current() { return g_probe.load(std::memory_order_acquire); }
-
+// A probe is a caller-owned object handed to the instrumented entry points through ait_launch_ctx::probe; the
+// library holds no pointer to it between calls.  The caller synchronises the device before it resets, reads
+// or destroys a probe that launches still in flight were given.
 AIT_API void* ait_probe_create(int capacity) {
   if (capacity <= 0) return nullptr;
-  AitProbe* p = new (std::nothrow) AitProbe{capacity, 0, nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  AitProbe* p = new (std::nothrow) AitProbe{capacity, dev, 0, nullptr};
   if (!p) return nullptr;
   p->e = new (std::nothrow) AitProbeEntry[capacity];
   if (!p->e) { delete p; return nullptr; }
@@ -47,13 +45,10 @@ AIT_API void* ait_probe_create(int capacity) {
 AIT_API void ait_probe_destroy(void* probe) {
   AitProbe* p = static_cast<AitProbe*>(probe);
   if (!p) return;
-  if (g_probe.load() == p) g_probe.store(nullptr);
   for (int i = 0; i < p->cap; i++) { (void)hipEventDestroy(p->e[i].e0); (void)hipEventDestroy(p->e[i].e1); }
   delete[] p->e;
   delete p;
 }
-
-AIT_API void ait_probe_attach(void* probe) { g_probe.store(static_cast<AitProbe*>(probe), std::memory_order_release); }
 
 AIT_API int ait_probe_reset(void* probe) {
   AitProbe* p = static_cast<AitProbe*>(probe);
@@ -62,10 +57,16 @@ AIT_API int ait_probe_reset(void* probe) {
   return AIT_OK;
 }
 
+// launches the probe was handed since the last reset -- MORE than its capacity when it overflowed (only the
+// first `capacity` of them were recorded: ait_probe_get fails beyond)
 AIT_API int ait_probe_count(void* probe) {
   if (!probe) return 0;
-  const AitProbe* p = static_cast<AitProbe*>(probe);
-  return p->n < p->cap ? p->n : p->cap;
+  return static_cast<AitProbe*>(probe)->n;
+}
+
+AIT_API int ait_probe_capacity(void* probe) {
+  if (!probe) return 0;
+  return static_cast<AitProbe*>(probe)->cap;
 }
 
 AIT_API int ait_probe_get(void* probe, int i, int* kind, double* work, float* ms, int* dims6) {

@@ -195,7 +195,9 @@ __global__ __launch_bounds__(256) void roi_sample_gather_kernel(
     for (int k = 0; k < 4; k++) {
       if (c.normalize) t[k] = (t[k] - c.mean[k]) / c.stdv[k];
       const float iw = on * c.inside[k];
-      targets[((size_t)img * P + s) * 4 + k] = t[k] * on;
+      // (a select, not a product: the reference ASSIGNS targets at the foreground rows only,
+      // proposal_target_layer_cascade.py:101-107 -- a non-finite t of a degenerate box must not leak as NaN * 0)
+      targets[((size_t)img * P + s) * 4 + k] = on != 0.0f ? t[k] : 0.0f;
       inside_w[((size_t)img * P + s) * 4 + k] = iw;
       outside_w[((size_t)img * P + s) * 4 + k] = iw > 0.0f ? 1.0f : 0.0f;
     }

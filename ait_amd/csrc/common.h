@@ -21,9 +21,9 @@ static inline hipStream_t ait_stream(void* s) { return reinterpret_cast<hipStrea
     if (rc_try__ != AIT_OK) return rc_try__; \
   } while (0)
 
-// ---- measurement probe (include/ait_hip.h "Measurement"): while a probe is attached to the calling
-// thread, the instrumented entry points bracket their launches with a HIP event pair on the launch
-// stream and note the algorithmic work.  Detached (the default): one thread-local pointer test.
+// ---- measurement probe (include/ait_hip.h "Measurement"): an instrumented entry point that is handed a
+// probe (ait_launch_ctx::probe) brackets its launch with a HIP event pair on the launch stream and notes the
+// algorithmic work.  No probe (the default): one pointer test.  The library keeps no probe of its own.
 struct AitProbeEntry {
   int kind;
   double work;            // flops (AIT_PROBE_GEMM) or algorithmic bytes
@@ -32,18 +32,23 @@ struct AitProbeEntry {
 };
 struct AitProbe {
   int cap;
-  volatile int n;         // claimed with an atomic add: launches may come from several host threads
+  int device;             // the device its events belong to: launches on another device are not recorded
+  volatile int n;         // claimed with an atomic add: launches may come from several host threads; counts past
+                          // `cap` too (ait_probe_count reports the overflow)
   AitProbeEntry* e;
 };
-AitProbe* ait_probe_current();
+static inline AitProbe* ait_probe_of(const ait_launch_ctx* ctx) {
+  return ctx ? static_cast<AitProbe*>(ctx->probe) : nullptr;
+}
 struct AitProbeScope {
   AitProbeEntry* ent = nullptr;
   hipStream_t s;
-  AitProbeScope(int kind, double work, hipStream_t stream, int d0 = 0, int d1 = 0, int d2 = 0, int d3 = 0, int d4 = 0,
-                int d5 = 0)
+  AitProbeScope(AitProbe* p, int kind, double work, hipStream_t stream, int d0 = 0, int d1 = 0, int d2 = 0, int d3 = 0,
+                int d4 = 0, int d5 = 0)
       : s(stream) {
-    AitProbe* p = ait_probe_current();
     if (!p) return;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != p->device) return;
     const int slot = __atomic_fetch_add(const_cast<int*>(&p->n), 1, __ATOMIC_RELAXED);
     if (slot >= p->cap) return;
     ent = &p->e[slot];

@@ -291,14 +291,14 @@ using SplitTile = BCfg<128, 128, 2, 2, true>;     // hi+lo images: 64 KB of LDS 
 int run_gemm(bool split3, int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
              int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
              const float* residual, int flags, int split_k, int c_colblk, long long c_batch_stride,
-             void* stream) {
+             const ait_launch_ctx* ctx, void* stream) {
   if (M == 0 || N == 0) return (M < 0 || N < 0 || K < 0) ? AIT_EINVAL : AIT_OK;
   GemmArgs g;
   const int rc = make_args(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
                            flags, split_k, c_colblk, c_batch_stride, BK, g);
   if (rc != AIT_OK) return rc;
   hipStream_t s = ait_stream(stream);
-  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * M * N * K, s, M, N, K, trans_a, trans_b, g.splits);
+  AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K, s, M, N, K, trans_a, trans_b, g.splits);
   if (split3) return dispatch_bf16<SplitTile>(g, !trans_a, trans_b != 0, s);
   return dispatch_bf16<Bf16Tile>(g, !trans_a, trans_b != 0, s);
 }
@@ -308,15 +308,15 @@ int run_gemm(bool split3, int trans_a, int trans_b, int M, int N, int K, float a
 AIT_API int ait_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, float alpha,
                           const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                           const float* bias, const float* residual, int flags, int split_k,
-                          int c_colblk, long long c_batch_stride, void* stream) {
+                          int c_colblk, long long c_batch_stride, const ait_launch_ctx* ctx, void* stream) {
   return run_gemm(false, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
-                  flags, split_k, c_colblk, c_batch_stride, stream);
+                  flags, split_k, c_colblk, c_batch_stride, ctx, stream);
 }
 
 AIT_API int ait_gemm_bf16x3(int trans_a, int trans_b, int M, int N, int K, float alpha,
                             const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                             const float* bias, const float* residual, int flags, int split_k,
-                            int c_colblk, long long c_batch_stride, void* stream) {
+                            int c_colblk, long long c_batch_stride, const ait_launch_ctx* ctx, void* stream) {
   return run_gemm(true, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
-                  flags, split_k, c_colblk, c_batch_stride, stream);
+                  flags, split_k, c_colblk, c_batch_stride, ctx, stream);
 }

@@ -57,24 +57,26 @@ using Tile64 = Cfg<64, 64, 16, 2, 2, 2, MODE_DB>;
 AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha,
                          const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                          const float* bias, const float* residual, int flags, int split_k,
-                         int c_colblk, long long c_batch_stride, void* stream) {
+                         int c_colblk, long long c_batch_stride, const ait_launch_ctx* ctx, void* stream) {
   if (M == 0 || N == 0) return (M < 0 || N < 0 || K < 0) ? AIT_EINVAL : AIT_OK;
   GemmArgs g;
   const int rc = make_args(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
                            flags, split_k, c_colblk, c_batch_stride, Tile128::BK, g);
   if (rc != AIT_OK) return rc;
-  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * M * N * K, ait_stream(stream), M, N, K, trans_a, trans_b, g.splits);
+  const SchedWs ws = sched_ws_of(ctx);
+  AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K, ait_stream(stream), M, N, K, trans_a, trans_b,
+                      g.splits);
   // operand "K-contiguous" means the reduction dimension is the fast one in memory:
   //   A: !trans_a  (A is [M,K]);   B: trans_b (B is [N,K])
   const long long tiles256 = (long long)((M + 255) / 256) * ((N + 127) / 128) * g.splits;
   if (N <= 64 && (long long)((M + 255) / 256) * g.splits >= 128) return dispatch<TileN64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   const bool direct = K > 0 && (K % 16 == 0) && (!trans_a || (M % 4 == 0 && M >= 4)) && (trans_b || (N % 4 == 0 && N >= 4));
-  // with the stream-K work list the persistent tile also serves products of a few hundred tiles (their
-  // slabs are spread over all workgroups): layer4-sized and co-attention-sized products
+  // with the stream-K work list (a scheduler workspace) the persistent tile also serves products of a few hundred
+  // tiles (their slabs are spread over all workgroups): layer4-sized and co-attention-sized products
   const bool few_tiles_sk = direct && g.splits == 1 && !(flags & AIT_GEMM_ATOMIC) && K >= 512 && tiles256 >= 96 &&
-                            stream_k_mode() != 0;
+                            ws.p != nullptr;
   if (M >= 512 && (tiles256 >= 512 || few_tiles_sk)) {
-    if (direct) return dispatch<Tile256D>(g, !trans_a, trans_b != 0, ait_stream(stream));
+    if (direct) return dispatch<Tile256D>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);
     return dispatch<Tile256>(g, !trans_a, trans_b != 0, ait_stream(stream));
   }
   const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * g.splits;
@@ -82,10 +84,27 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   return dispatch<Tile128>(g, !trans_a, trans_b != 0, ait_stream(stream));
 }
 
-// Frees the stream-K scratch buffers (one per device and stream that ran a stream-K launch; see
-// gemm_f32_impl.h).  The streams must be idle.
-AIT_API int ait_gemm_workspace_release(void) {
-  sk_release();
+// Scheduler scratch of the persistent kernel (include/ait_hip.h, ait_launch_ctx): sized for the widest product tile
+// at the occupancy this device admits; the caller allocates it and has its control words zeroed once.
+AIT_API size_t ait_gemm_workspace_bytes(void) {
+  const void* k = reinterpret_cast<const void*>(gemm_f32_stream_kernel<Tile256D, true, true, EPI_STORE>);
+  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Tile256D::LDS) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  const int slots = stream_slots<Tile256D>(k);
+  // every persistent tile configuration fits: a smaller tile at a higher occupancy never needs more than
+  // (max slots) x (largest tile)
+  size_t per = (size_t)Tile256D::BM * Tile256D::BN * sizeof(float);
+  int s2 = slots;
+  const int cap = 4 * (slots / 2 > 0 ? slots / 2 : 1);         // 128x128 tiles: at most 4 per CU
+  if ((size_t)cap * 128 * 128 * sizeof(float) > (size_t)s2 * per) { per = 128 * 128 * sizeof(float); s2 = cap; }
+  return kCtlBytes + (size_t)s2 * per;
+}
+
+AIT_API int ait_gemm_workspace_init(void* sched_ws, size_t sched_ws_bytes, void* stream) {
+  if (!sched_ws || sched_ws_bytes < kCtlBytes) return AIT_EINVAL;
+  if (hipMemsetAsync(sched_ws, 0, kCtlBytes, ait_stream(stream)) != hipSuccess) return AIT_ELAUNCH;
   return AIT_OK;
 }
 
@@ -97,7 +116,7 @@ AIT_API int ait_gemm_workspace_release(void) {
 AIT_API int ait_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, int lda,
                                  long long stride_a, long long stride_a2, const float* B, int ldb, long long stride_b,
                                  long long stride_b2, float* C, int ldc, long long stride_c, long long stride_c2,
-                                 int batch, int batch2, int flags, int split_k, void* stream) {
+                                 int batch, int batch2, int flags, int split_k, const ait_launch_ctx* ctx, void* stream) {
   if (batch < 0 || batch2 < 0 || (flags & ~(AIT_GEMM_ACCUMULATE | AIT_GEMM_ATOMIC))) return AIT_EINVAL;
   if (batch == 0 || batch2 == 0 || M == 0 || N == 0) return (M < 0 || N < 0 || K < 0) ? AIT_EINVAL : AIT_OK;
   if (batch > 65535 || batch2 > 65535 || ((stride_a | stride_b | stride_a2 | stride_b2) & 3)) return AIT_EUNSUPPORTED;
@@ -107,8 +126,8 @@ AIT_API int ait_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, 
   if (rc != AIT_OK) return rc;
   g.batch = batch; g.sA = stride_a; g.sB = stride_b; g.sC = stride_c;
   g.batch2 = batch2; g.sA2 = stride_a2; g.sB2 = stride_b2; g.sC2 = stride_c2;
-  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * M * N * K * batch * batch2, ait_stream(stream), M, N, K, trans_a, trans_b,
-                      batch * batch2);
+  AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K * batch * batch2, ait_stream(stream), M, N, K,
+                      trans_a, trans_b, batch * batch2);
   const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch * batch2 * g.splits;
   if (tiles128 < 128) return dispatch<Tile64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   return dispatch<Tile128>(g, !trans_a, trans_b != 0, ait_stream(stream));
@@ -149,28 +168,28 @@ inline int check_geom(const ait_conv_geom* q, int cin, int cout) {
 }
 
 template <class T, int CONV, bool AK, bool BKC, bool GRP = false>
-int conv_launch(const GemmArgs& g, hipStream_t s) {
-  if (g.flags & AIT_GEMM_ATOMIC) return launch<T, AK, BKC, EPI_ATOMIC, NoProbe, CONV, GRP>(g, s);
-  if (GRP) return launch<T, AK, BKC, EPI_STORE, NoProbe, CONV, GRP>(g, s);      // (grouped: bias only)
-  if (g.residual) return launch<T, AK, BKC, EPI_RES, NoProbe, CONV>(g, s);
-  return launch<T, AK, BKC, EPI_STORE, NoProbe, CONV>(g, s);
+int conv_launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
+  if (g.flags & AIT_GEMM_ATOMIC) return launch<T, AK, BKC, EPI_ATOMIC, NoProbe, CONV, GRP>(g, s, ws);
+  if (GRP) return launch<T, AK, BKC, EPI_STORE, NoProbe, CONV, GRP>(g, s, ws);      // (grouped: bias only)
+  if (g.residual) return launch<T, AK, BKC, EPI_RES, NoProbe, CONV>(g, s, ws);
+  return launch<T, AK, BKC, EPI_STORE, NoProbe, CONV>(g, s, ws);
 }
 template <int CONV, bool AK, bool BKC>
-int conv_dispatch(const GemmArgs& g, hipStream_t s) {
+int conv_dispatch(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
   if (g.conv.a_group) {        // grouped: separate instantiations (see glds16<FORCE_UNIFORM>)
     if (g.residual || (g.flags & ~AIT_GEMM_RELU)) return AIT_EUNSUPPORTED;
-    return conv_launch<Tile256D, CONV, AK, BKC, true>(g, s);
+    return conv_launch<Tile256D, CONV, AK, BKC, true>(g, s, ws);
   }
   const long long tiles256 = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128) * g.splits;
-  if (tiles256 >= 512 || (tiles256 >= 96 && g.K >= 512 && g.splits == 1 && !(g.flags & AIT_GEMM_ATOMIC) && stream_k_mode() != 0))
-    return conv_launch<Tile256D, CONV, AK, BKC>(g, s);
-  return conv_launch<Tile128D, CONV, AK, BKC>(g, s);     // few tiles: 128x128, three to a CU
+  if (tiles256 >= 512 || (tiles256 >= 96 && g.K >= 512 && g.splits == 1 && !(g.flags & AIT_GEMM_ATOMIC) && ws.p != nullptr))
+    return conv_launch<Tile256D, CONV, AK, BKC>(g, s, ws);
+  return conv_launch<Tile128D, CONV, AK, BKC>(g, s, ws);     // few tiles: 128x128, three to a CU
 }
 }  // namespace
 
 AIT_API int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_conv_geom* q, int cin, int cout,
                              const float* bias, const float* residual, int flags, float* y, int ldy,
-                             const float* zeros, size_t zeros_floats, void* stream) {
+                             const float* zeros, size_t zeros_floats, const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY_RC(check_geom(q, cin, cout));
   const int hw = log2_exact(q->out_h * q->out_w), ws = log2_exact(q->out_w);
   if (hw < 0 || ws < 0 || (cin & 15) || (cout & 3)) return AIT_EUNSUPPORTED;
@@ -185,13 +204,14 @@ AIT_API int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_
   AIT_TRY_RC(make_args(0, 1, (int)rows, cout, taps * cing, 1.f, x, ldx, w, taps * cing, y, ldy, bias, residual, flags, 1, 0, 0,
                        16, g));
   g.conv = ConvGeom{hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G};
-  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), (int)rows, cout, taps * cing, 0, 1, 1);
-  return conv_dispatch<CONV_A, true, true>(g, ait_stream(stream));
+  AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), (int)rows, cout,
+                      taps * cing, 0, 1, 1);
+  return conv_dispatch<CONV_A, true, true>(g, ait_stream(stream), sched_ws_of(ctx));
 }
 
 AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, const ait_conv_geom* q, int cin, int cout,
                                   const float* residual, int flags, float* dx, int lddx, const float* zeros,
-                                  size_t zeros_floats, void* stream) {
+                                  size_t zeros_floats, const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY_RC(check_geom(q, cin, cout));
   const int hw = log2_exact(q->in_h * q->in_w), ws = log2_exact(q->in_w);
   if (hw < 0 || ws < 0 || (cout & 15) || (cin & 3)) return AIT_EUNSUPPORTED;
@@ -206,13 +226,14 @@ AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, con
                        0, 0, 16, g));
   g.conv = ConvGeom{hw, ws, q->out_h, q->out_w, q->kw, 1, -1, q->pad, log2_exact(q->stride), coutg, (long long)cing, zeros,
                     G > 1 ? coutg : 0, cing};
-  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cin * taps * coutg, ait_stream(stream), (int)rows, cin, taps * coutg, 0, 0, 1);
-  return conv_dispatch<CONV_A, true, false>(g, ait_stream(stream));
+  AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cin * taps * coutg, ait_stream(stream), (int)rows, cin,
+                      taps * coutg, 0, 0, 1);
+  return conv_dispatch<CONV_A, true, false>(g, ait_stream(stream), sched_ws_of(ctx));
 }
 
 AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, int ldx, const ait_conv_geom* q, int cin,
                                     int cout, float* dw, int split_k, const float* zeros, size_t zeros_floats,
-                                    void* stream) {
+                                    const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY_RC(check_geom(q, cin, cout));
   const int hw = log2_exact(q->out_h * q->out_w), ws = log2_exact(q->out_w);
   const long long rows = (long long)q->n * q->out_h * q->out_w;
@@ -224,9 +245,9 @@ AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, i
   AIT_TRY_RC(make_args(1, 0, cout, taps * cing, (int)rows, 1.f, dy, lddy, x, ldx, dw, taps * cing, nullptr, nullptr,
                        AIT_GEMM_ATOMIC, split_k < 1 ? 1 : split_k, 0, 0, 16, g));
   g.conv = ConvGeom{hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G};
-  AitProbeScope probe(AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), cout, taps * cing, (int)rows, 1, 0,
-                      g.splits);
+  AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), cout, taps * cing,
+                      (int)rows, 1, 0, g.splits);
   // (grouped: 128-row tiles, one group of output channels per row tile)
-  if (G > 1) return conv_launch<Tile128D, CONV_B, false, false, true>(g, ait_stream(stream));
-  return conv_launch<Tile256D, CONV_B, false, false>(g, ait_stream(stream));
+  if (G > 1) return conv_launch<Tile128D, CONV_B, false, false, true>(g, ait_stream(stream), sched_ws_of(ctx));
+  return conv_launch<Tile256D, CONV_B, false, false>(g, ait_stream(stream), sched_ws_of(ctx));
 }

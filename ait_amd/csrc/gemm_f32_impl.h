@@ -15,10 +15,7 @@
 // file; they live in the history at 81edb57 and their results in DESIGN.md section 3.1.)
 #pragma once
 #include "common.h"
-#include <cstdlib>
-#include <map>
-#include <mutex>
-#include <utility>
+#include <atomic>
 
 namespace ait_gemm {
 
@@ -497,12 +494,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // ---- work list of this workgroup: [stream-K pieces] [whole items dp0, dp0 + W, ...] ------------------
   // With a partial-tile workspace (g.sk_ws) the r = lim % W tiles that would form an under-filled last
   // round are not handed out whole: their r * K/16 slabs are cut into equal contiguous runs, one per
-  // workgroup, done FIRST.  A run covers the tail of one tile and/or the head of the next, so a
-  // workgroup has at most two pieces; the piece that starts a tile (kbeg == 0) owns it: it is that
-  // workgroup's last piece, and after it the owner adds the partial tiles the following workgroups
-  // published (fixed order: results do not depend on timing) and runs the epilogue.  A piece that does
-  // not start its tile is always its workgroup's FIRST piece, so it is published before that workgroup
-  // ever waits: waits only point at higher workgroup ids and cannot form a cycle.
+  // workgroup, done FIRST.  A run is at most one tile long and covers the tail of one tile ("piece A") and/or
+  // the head of the next ("piece B"), so a workgroup has at most two pieces.  The piece that ENDS a tile
+  // (kend == K) owns it: after it the owner adds the partial tiles that the workgroups BEFORE it published
+  // (fixed order: results do not depend on timing) and runs the epilogue.  A piece that does not end its tile
+  // is computed and published FIRST, before its workgroup ever waits.  Waits therefore point only at LOWER
+  // workgroup ids, and what they wait for is the first thing those workgroups do: with the dispatcher handing
+  // out workgroups in id order, a resident workgroup only ever waits for workgroups that are resident or done
+  // -- no cycle and no dependence on the whole grid being co-resident (a second stream's kernel, an RCCL
+  // kernel or a CU mask may hold part of the chip).
   constexpr int SK_MIN = 4;          // slabs per run at least
   int sk_r = 0, sk_total = 0, sk_w = 1, n_sk = 0;
   int skA_tile = 0, skA_kb = 0, skA_ke = 0, skB_ke = 0;
@@ -559,7 +559,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // item it -> tile origin, K range; false past the end of this workgroup's work
   auto get_item = [&](int it, int& m0, int& n0, int& kb, int& ke) -> bool {
     int id;
-    if (it < n_sk) id = skA_tile + it;
+    const bool pieceB = n_sk == 2 && it == 0;        // (two pieces: the non-owned head of the next tile goes first)
+    if (it < n_sk) id = skA_tile + (pieceB ? 1 : 0);
     else {
       id = dp_id(it - n_sk);
       if (id < 0) return false;
@@ -567,8 +568,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     }
     wmap.decode(g, base + id, BM, BN, m0, n0, kb, ke);
     if (it < n_sk) {
-      kb = it == 0 ? skA_kb : 0;
-      ke = it == 0 ? skA_ke : skB_ke;
+      kb = pieceB ? 0 : skA_kb;
+      ke = pieceB ? skB_ke : skA_ke;
     }
     return true;
   };
@@ -836,7 +837,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     if (item < n_sk && (kbeg != 0 || kend != g.K)) {
       // Inter-workgroup hand-off in the write-through form: every byte of a partial tile is stored sc1
       // and read with sc1 loads (per-XCD L2s are not coherent), the flag is an agent-scope word.
-      if (kbeg != 0) {                             // publish
+      if (kend != g.K) {                           // does not end its tile: publish
         finish = false;
         __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(
             g.sk_ws + (size_t)blockIdx.x * (BM * BN), 0, BM * BN * 4, 0x00020000);
@@ -855,10 +856,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         ring_barrier();
         if (threadIdx.x == 0)
           __hip_atomic_store(g.sk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {                                     // own: gather the runs that follow, in workgroup order
-        const int tile_end = (skA_tile + (item == 0 ? 1 : 2)) * ns;      // first slab past this tile
-        for (int jj = j + 1; jj < sk_w; jj++) {
-          if ((int)((long long)jj * sk_total / sk_w) >= tile_end) break;
+      } else {                                     // ends its tile: gather the runs before it, in workgroup order
+        const int tile_start = skA_tile * ns;      // (an owned stream-K piece is always piece A)
+        for (int jj = j - 1; jj >= 0; jj--) {
+          if ((int)((long long)(jj + 1) * sk_total / sk_w) <= tile_start) break;      // run jj ends before this tile
           const int peer = jj * AIT_NXCD + xcd;
           if (threadIdx.x == 0) {
             while (__hip_atomic_load(g.sk_flags + peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
@@ -1090,68 +1091,56 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
   epilogue<C::TM, C::TN, EPI>(acc, g, m0, n0, wm, wn, li, lk);
 }
 
-// Resident workgroup slots of the persistent kernel: as many workgroups per CU as its LDS ring allows
-// (160 KB per CU; the product tiles: 72 KB -> 2).  Queried per call (no cached global state); a failed
-// query falls back to the MI355X figure.
-// Stream-K scratch: one partial tile per workgroup + one flag word per workgroup, kept per (device, stream)
-// -- launches on one stream are ordered, so they can share it; two streams never do.  Allocated on first
-// use (the only allocation this library makes; ait_gemm_workspace_release() frees it), flags zeroed once:
-// every flag a launch sets is cleared again by the workgroup that consumes it.
-struct SkWorkspace { float* ws = nullptr; unsigned* flags = nullptr; unsigned* sched = nullptr; size_t bytes = 0; int nflags = 0; };
-inline int& stream_k_mode() {          // 1 on, 0 off (AIT_GEMM_STREAMK=0); the lab harness flips it
-  static int mode = [] { const char* e = getenv("AIT_GEMM_STREAMK"); return (e && e[0] == '0') ? 0 : 1; }();
-  return mode;
-}
-struct SkPool {
-  std::mutex mu;
-  std::map<std::pair<int, hipStream_t>, SkWorkspace> pool;
+// ---- scheduler scratch: CALLER-OWNED (include/ait_hip.h, ait_launch_ctx) ------------------------------------
+// Layout of the workspace: [0, kCtlBytes) control words -- per XCD a ticket counter and an exit counter a line apart
+// (the dynamic hand-out of whole tiles), then one "partial published" flag per workgroup -- followed by one BM x BN
+// partial tile per workgroup (stream-K).  The control words are zeroed ONCE by ait_gemm_workspace_init(); every
+// word a launch sets is cleared again by the workgroup that consumes it, so launches that are ordered on one
+// stream share a workspace.  No workspace (NULL): static work lists, whole tiles only -- nothing is allocated here.
+constexpr size_t kSchedBytes = AIT_NXCD * 32 * sizeof(unsigned);      // 1 KiB
+constexpr int kMaxSlots = 2048;                                       // workgroups of one persistent launch
+constexpr size_t kCtlBytes = 16384;                                   // >= kSchedBytes + kMaxSlots * 4
+struct SchedWs {
+  void* p = nullptr;
+  size_t bytes = 0;
+  unsigned* sched() const { return static_cast<unsigned*>(p); }
+  unsigned* flags() const { return reinterpret_cast<unsigned*>(static_cast<char*>(p) + kSchedBytes); }
+  float* partials() const { return reinterpret_cast<float*>(static_cast<char*>(p) + kCtlBytes); }
 };
-inline SkPool& sk_pool() { static SkPool p; return p; }
-inline int sk_workspace(hipStream_t s, size_t bytes, int nflags, SkWorkspace& out) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return AIT_ELAUNCH;
-  SkPool& p = sk_pool();
-  std::lock_guard<std::mutex> lock(p.mu);
-  SkWorkspace& e = p.pool[std::make_pair(dev, s)];
-  if (e.bytes < bytes || e.nflags < nflags) {
-    if (e.ws) (void)hipFree(e.ws);
-    e = SkWorkspace();
-    const size_t sbytes = AIT_NXCD * 32 * sizeof(unsigned);       // ticket + exit counter per XCD, a line apart
-    const size_t fbytes = ((size_t)nflags * 4 + 255) / 256 * 256 + sbytes;
-    void* mem = nullptr;
-    if (hipMalloc(&mem, bytes + fbytes) != hipSuccess) { (void)hipGetLastError(); return AIT_ELAUNCH; }
-    if (hipMemset((char*)mem + bytes, 0, fbytes) != hipSuccess) { (void)hipFree(mem); return AIT_ELAUNCH; }
-    e.ws = (float*)mem;
-    e.flags = (unsigned*)((char*)mem + bytes);
-    e.sched = (unsigned*)((char*)mem + bytes + fbytes - sbytes);
-    e.bytes = bytes;
-    e.nflags = nflags;
-  }
-  out = e;
-  return AIT_OK;
-}
-inline void sk_release() {
-  SkPool& p = sk_pool();
-  std::lock_guard<std::mutex> lock(p.mu);
-  for (auto& kv : p.pool) if (kv.second.ws) (void)hipFree(kv.second.ws);
-  p.pool.clear();
+inline SchedWs sched_ws_of(const ait_launch_ctx* ctx) {
+  SchedWs w;
+  if (ctx && ctx->sched_ws) { w.p = ctx->sched_ws; w.bytes = ctx->sched_ws_bytes; }
+  return w;
 }
 
+// Resident workgroup slots of the persistent kernel: what the occupancy query admits for THIS kernel (registers,
+// LDS ring, waves), not a guess from the LDS size; memoised per instantiation (a constant of the code object and
+// the device model).  A failed query falls back to the LDS-derived figure for MI355X.
 template <class C>
-inline int stream_slots() {
+inline int stream_slots(const void* kern) {
+  static std::atomic<int> memo{0};
+  int v = memo.load(std::memory_order_relaxed);
+  if (v > 0) return v;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     cus = 256;
-  int per_cu = (int)(160 * 1024 / C::LDS);
-  const int by_waves = 32 / (C::NT / 64);
-  if (per_cu > by_waves) per_cu = by_waves;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, C::NT, C::LDS) != hipSuccess || per_cu <= 0) {
+    (void)hipGetLastError();
+    per_cu = (int)(160 * 1024 / C::LDS);
+    const int by_waves = 32 / (C::NT / 64);
+    if (per_cu > by_waves) per_cu = by_waves;
+  }
   if (per_cu > 4) per_cu = 4;
-  return (per_cu < 1 ? 1 : per_cu) * cus;
+  v = (per_cu < 1 ? 1 : per_cu) * cus;
+  if (v > kMaxSlots) v = kMaxSlots;
+  memo.store(v, std::memory_order_relaxed);
+  return v;
 }
 
 template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe, int CONV = CONV_NONE, bool GRP = false>
-int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
+int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int slots = 0) {
   GemmArgs gl = g;
   gl.sk_ws = nullptr;
   gl.sk_flags = nullptr;
@@ -1161,9 +1150,13 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
   unsigned blocks;
   const void* kern;
   if constexpr (C::MODE == MODE_DLDS) {
+    kern = reinterpret_cast<const void*>(gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV, GRP>);
+    if (C::LDS > 64 * 1024 &&
+        hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) != hipSuccess)
+      return AIT_ELAUNCH;
     // persistent: W workgroups per XCD, every one of them gets work (W <= items of the smallest chunk
     // is not required: a workgroup past its chunk's end exits at once)
-    if (slots <= 0) slots = stream_slots<C>();
+    if (slots <= 0) slots = stream_slots<C>(kern);
     int w = max(1, min(wmap.chunk, slots / AIT_NXCD));
     // stream-K for the tiles of an under-filled last round (see the kernel): worth it unless that round is
     // nearly full anyway; needs whole 16-float slabs and a reduction long enough to cut
@@ -1174,31 +1167,29 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
     const int wfull = max(1, slots / AIT_NXCD), rem = wmap.chunk % wfull;
     const double last_round = (rem * 2 <= wfull) ? 0.62 : 1.0;
     const bool sk_pays = (g.K / 16) * (last_round - (double)rem / wfull) > 12.0;
-    if (stream_k_mode() != 0) {
-      // scratch of the scheduler: ticket counters for the dynamic hand-out of whole tiles (every launch), partial
-      // tiles + flags when this launch also cuts its last round
-      SkWorkspace sk;
-      if (sk_workspace(s, (size_t)wfull * AIT_NXCD * C::BM * C::BN * sizeof(float), wfull * AIT_NXCD, sk) == AIT_OK) {
-        // (a ticket lands one iteration after it is drawn, and the prologue fills the slab ring from the first
-        // item alone: every whole item must outlast both -- eight slabs is comfortably more than either)
-        const int kps = g.splits > 1 ? g.k_per_split : g.K, klast = g.K - (g.splits - 1) * kps;
-        if (kps >= 128 && klast >= 128) gl.sched = sk.sched;
-        if (EPI != EPI_ATOMIC && g.splits == 1 && g.K % 16 == 0 && rem > 0 && sk_pays) {
-          gl.sk_ws = sk.ws;
-          gl.sk_flags = sk.flags;
-          w = wfull;
-        }
+    if (ws.p) {
+      if (ws.bytes < kCtlBytes) return AIT_EWORKSPACE;
+      // ticket counters for the dynamic hand-out of whole tiles (every launch), partial tiles + flags when this
+      // launch also cuts its last round
+      // (a ticket lands one iteration after it is drawn, and the prologue fills the slab ring from the first
+      // item alone: every whole item must outlast both -- eight slabs is comfortably more than either)
+      const int kps = g.splits > 1 ? g.k_per_split : g.K, klast = g.K - (g.splits - 1) * kps;
+      if (kps >= 128 && klast >= 128) gl.sched = ws.sched();
+      if (EPI != EPI_ATOMIC && g.splits == 1 && g.K % 16 == 0 && rem > 0 && sk_pays) {
+        if (ws.bytes < kCtlBytes + (size_t)wfull * AIT_NXCD * C::BM * C::BN * sizeof(float)) return AIT_EWORKSPACE;
+        gl.sk_ws = ws.partials();
+        gl.sk_flags = ws.flags();
+        w = wfull;
       }
     }
     blocks = (unsigned)(w * AIT_NXCD);
-    kern = reinterpret_cast<const void*>(gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV, GRP>);
   } else {
     blocks = (unsigned)(wmap.chunk * AIT_NXCD);
     kern = reinterpret_cast<const void*>(gemm_f32_kernel<C, AK, BKC, EPI>);
+    if (C::LDS > 64 * 1024 &&
+        hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) != hipSuccess)
+      return AIT_ELAUNCH;
   }
-  if (C::LDS > 64 * 1024 &&
-      hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) != hipSuccess)
-    return AIT_ELAUNCH;
   if constexpr (C::MODE == MODE_DLDS)
     hipLaunchKernelGGL((gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV, GRP>), dim3(blocks), dim3(C::NT), C::LDS, s, gl);
   else
@@ -1209,21 +1200,21 @@ int launch(const GemmArgs& g, hipStream_t s, int slots = 0) {
 }
 
 template <class C, int EPI>
-int dispatch_layout(const GemmArgs& g, bool ak, bool bk, hipStream_t s) {
-  if (ak && bk) return launch<C, true, true, EPI>(g, s);
-  if (ak && !bk) return launch<C, true, false, EPI>(g, s);
-  if (!ak && bk) return launch<C, false, true, EPI>(g, s);
-  return launch<C, false, false, EPI>(g, s);
+int dispatch_layout(const GemmArgs& g, bool ak, bool bk, hipStream_t s, const SchedWs& ws) {
+  if (ak && bk) return launch<C, true, true, EPI>(g, s, ws);
+  if (ak && !bk) return launch<C, true, false, EPI>(g, s, ws);
+  if (!ak && bk) return launch<C, false, true, EPI>(g, s, ws);
+  return launch<C, false, false, EPI>(g, s, ws);
 }
 
 template <class C>
-int dispatch(const GemmArgs& g, bool ak, bool bk, hipStream_t s) {
-  if (g.flags & AIT_GEMM_ATOMIC) return dispatch_layout<C, EPI_ATOMIC>(g, ak, bk, s);
+int dispatch(const GemmArgs& g, bool ak, bool bk, hipStream_t s, const SchedWs& ws = SchedWs()) {
+  if (g.flags & AIT_GEMM_ATOMIC) return dispatch_layout<C, EPI_ATOMIC>(g, ak, bk, s, ws);
   const bool row_bias = g.bias && (g.flags & AIT_GEMM_BIAS_ROW);
-  if (g.residual && !(g.flags & AIT_GEMM_ACCUMULATE) && !row_bias) return dispatch_layout<C, EPI_RES>(g, ak, bk, s);
+  if (g.residual && !(g.flags & AIT_GEMM_ACCUMULATE) && !row_bias) return dispatch_layout<C, EPI_RES>(g, ak, bk, s, ws);
   if (g.residual || (g.flags & (AIT_GEMM_ACCUMULATE | AIT_GEMM_MASK_POS)) || row_bias)
-    return dispatch_layout<C, EPI_AUX>(g, ak, bk, s);
-  return dispatch_layout<C, EPI_STORE>(g, ak, bk, s);
+    return dispatch_layout<C, EPI_AUX>(g, ak, bk, s, ws);
+  return dispatch_layout<C, EPI_STORE>(g, ak, bk, s, ws);
 }
 
 // Validate arguments and fill GemmArgs (shared by the product entry point and the lab harness).

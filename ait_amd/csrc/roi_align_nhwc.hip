@@ -372,7 +372,8 @@ AIT_API size_t ait_roi_align_nhwc_workspace_bytes(int n_rois, int H, int W, int 
 
 AIT_API int ait_roi_align_nhwc_fwd(const float* feat, const float* rois, int n_rois, int B, int C, int H,
                                    int W, int PH, int PW, float spatial_scale, int sampling_ratio,
-                                   void* workspace, size_t workspace_bytes, float* out, void* stream) {
+                                   void* workspace, size_t workspace_bytes, float* out, const ait_launch_ctx* ctx,
+                                   void* stream) {
   if (bad(n_rois, B, C, H, W, PH, PW)) return AIT_EINVAL;
   if (unsupported(C, PH, PW)) return AIT_EUNSUPPORTED;
   if (n_rois == 0) return AIT_OK;
@@ -388,7 +389,7 @@ AIT_API int ait_roi_align_nhwc_fwd(const float* feat, const float* rois, int n_r
   if (lds > 60 * 1024) return AIT_EUNSUPPORTED;
   {
     // algorithmic bytes: the feature read once, the RoIs, the pooled tensor written once
-    AitProbeScope probe(AIT_PROBE_ROI_FWD, 4.0 * ((double)B * C * H * W + 5.0 * n_rois + (double)n_rois * PH * PW * C), s,
+    AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_ROI_FWD, 4.0 * ((double)B * C * H * W + 5.0 * n_rois + (double)n_rois * PH * PW * C), s,
                         n_rois, B, C, H, W);
     if (C % (4 * AIT_NXCD * 4) == 0 && lds_sliced <= 60 * 1024 && PH <= kThreads / 32)
       hipLaunchKernelGGL(roi_align_nhwc_fwd_sliced_kernel, dim3((unsigned)n_rois * AIT_NXCD), dim3(kThreads),
@@ -403,7 +404,8 @@ AIT_API int ait_roi_align_nhwc_fwd(const float* feat, const float* rois, int n_r
 
 AIT_API int ait_roi_align_nhwc_bwd(const float* grad_out, const float* rois, int n_rois, int B, int C,
                                    int H, int W, int PH, int PW, float spatial_scale, int sampling_ratio,
-                                   void* workspace, size_t workspace_bytes, float* grad_in, void* stream) {
+                                   void* workspace, size_t workspace_bytes, float* grad_in, const ait_launch_ctx* ctx,
+                                   void* stream) {
   if (bad(n_rois, B, C, H, W, PH, PW)) return AIT_EINVAL;
   if (unsupported(C, PH, PW)) return AIT_EUNSUPPORTED;
   if (!grad_in) return AIT_EINVAL;
@@ -417,7 +419,7 @@ AIT_API int ait_roi_align_nhwc_bwd(const float* grad_out, const float* rois, int
                              workspace_bytes, wf, wi, s);
   if (rc != AIT_OK) return rc;
   {
-    AitProbeScope probe(AIT_PROBE_ROI_BWD, 4.0 * ((double)B * C * H * W + 5.0 * n_rois + (double)n_rois * PH * PW * C), s,
+    AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_ROI_BWD, 4.0 * ((double)B * C * H * W + 5.0 * n_rois + (double)n_rois * PH * PW * C), s,
                         n_rois, B, C, H, W);
     hipLaunchKernelGGL(roi_align_nhwc_bwd_kernel, dim3(chunked_grid((long long)B * H * W)), dim3(kThreads), 0, s,
                        grad_out, rois, n_rois, B, C, H, W, PH, wf, wi, grad_in);

@@ -48,18 +48,24 @@ struct Bump {
     if (rc__ != AIT_OK) return rc__; \
   } while (0)
 
+// where a block runs: the launch stream and the caller's launch context (scheduler scratch of the GEMM, probe)
+struct Run {
+  void* stream;
+  const ait_launch_ctx* ctx;
+};
+
 // y = x W^T (+ b) (+ relu) on the fp32 matrix cores
 inline int linear(const float* x, int M, int K, const float* w, int N, const float* b, bool relu, float* y,
-                  void* s) {
-  return ait_gemm_f32(0, 1, M, N, K, 1.f, x, K, w, K, y, N, b, nullptr, relu ? AIT_GEMM_RELU : 0, 1, 0, 0, s);
+                  const Run& s) {
+  return ait_gemm_f32(0, 1, M, N, K, 1.f, x, K, w, K, y, N, b, nullptr, relu ? AIT_GEMM_RELU : 0, 1, 0, 0, s.ctx, s.stream);
 }
 // dx [M, K_in] = dy [M, N_out] . W [N_out, K_in]  (+ residual, or gated by `residual` > 0 with mask_pos)
 // `colsum` (optional): float[K_in] into which the column sums of dx are ADDED in the product's epilogue (the bias
 // gradient of the layer dx flows into)
 inline int dgrad(const float* dy, int M, int N_out, const float* w, int K_in, const float* residual, bool mask_pos,
-                 float* dx, void* s, float* colsum = nullptr) {
+                 float* dx, const Run& s, float* colsum = nullptr) {
   return ait_gemm_f32(0, 0, M, K_in, N_out, 1.f, dy, N_out, w, K_in, dx, K_in, colsum, residual,
-                      (mask_pos ? AIT_GEMM_MASK_POS : 0) | (colsum ? AIT_GEMM_COLSUM : 0), 1, 0, 0, s);
+                      (mask_pos ? AIT_GEMM_MASK_POS : 0) | (colsum ? AIT_GEMM_COLSUM : 0), 1, 0, 0, s.ctx, s.stream);
 }
 // K-splits of a weight gradient [M_out, N_out] = sum over K tokens: multiples of 8 (each XCD owns whole
 // K-ranges), chosen so that tiles x splits fills the resident workgroup slots of the 256x128 kernel in
@@ -79,11 +85,11 @@ inline int wgrad_splits(int M_out, int N_out, long long K) {
   return best;
 }
 // dW [N_out, K_in] += dy [M, N_out]^T . x [M, K_in]   (split-K, fp32 atomics: accumulates)
-inline int wgrad(const float* dy, long long M, int N_out, const float* x, int K_in, float* dw, void* s) {
+inline int wgrad(const float* dy, long long M, int N_out, const float* x, int K_in, float* dw, const Run& s) {
   if (!dw) return AIT_OK;
   const int sp = M >= 512 ? wgrad_splits(N_out, K_in, M) : 1;
   return ait_gemm_f32(1, 0, N_out, K_in, (int)M, 1.f, dy, N_out, x, K_in, dw, K_in, nullptr, nullptr, AIT_GEMM_ATOMIC,
-                      sp, 0, 0, s);
+                      sp, 0, 0, s.ctx, s.stream);
 }
 
 // buffers of one MultiHeadAttention block: scratch in eval, the saved activations in training
@@ -126,7 +132,7 @@ inline Qkv views(const MhaBuf& m, long long n, bool cross) {
 // both 0 in eval.  seed: the block's seed; its two sites derive theirs with ait_dropout_seed.
 int mha_block(const float* xq, const float* xkv, int n, int kv_rows, int mask_mode, int n_valid,
               const ait_mha_weights& w, const MhaBuf& m, float p_fc, float p_attn, unsigned long long seed,
-              float* y, void* s) {
+              float* y, const Run& s) {
   const int M = n * T;
   const bool cross = xkv != xq;
   if (!cross) {
@@ -137,11 +143,11 @@ int mha_block(const float* xq, const float* xkv, int n, int kv_rows, int mask_mo
   }
   const Qkv v = views(m, n, cross);
   AIT_TRY(ait_attn_fwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, n, H, T, DK, kv_rows, mask_mode, n_valid, 0.125f,
-                       p_attn, ait_dropout_seed(seed, 0), m.P, m.O, s));
-  AIT_TRY(ait_sh_fwd(m.O, w.sk_w, w.sk_b, n, H, T, DK, m.u, m.gate, m.s, s));
+                       p_attn, ait_dropout_seed(seed, 0), m.P, m.O, s.stream));
+  AIT_TRY(ait_sh_fwd(m.O, w.sk_w, w.sk_b, n, H, T, DK, m.u, m.gate, m.s, s.stream));
   AIT_TRY(linear(m.u, M, DK, w.fc_w, D, nullptr, false, m.f, s));
   return ait_ln_fwd(m.f, nullptr, xq, w.ln_g, w.ln_b, M, D, T, T, 1, kEps, p_fc, ait_dropout_seed(seed, 1), y, m.mean,
-                    m.rstd, s);
+                    m.rstd, s.stream);
 }
 
 // scratch of the block's backward
@@ -162,28 +168,28 @@ inline bool carve(Bump& b, MhaBwdWs& w, long long n, int kv_rows, bool cross) {
 // dxq [n*64, 512] and (cross) dxkv [n*kv_rows, 512] are WRITTEN; parameter gradients are ACCUMULATED.
 int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xkv, int n, int kv_rows,
                   const ait_mha_weights& w, const MhaBuf& m, const MhaBwdWs& t, float p_fc, float p_attn,
-                  unsigned long long seed, float* dxq, float* dxkv, const ait_mha_grads& g, void* s) {
+                  unsigned long long seed, float* dxq, float* dxkv, const ait_mha_grads& g, const Run& s) {
   const int M = n * T;
   const bool cross = xkv != xq;
   // closing LayerNorm + dropout + residual: df (at fc's output), dres (the residual branch)
   AIT_TRY(ait_ln_bwd(dy, m.f, nullptr, xq, w.ln_g, m.mean, m.rstd, M, D, T, T, 1, dy_rows, p_fc,
-                     ait_dropout_seed(seed, 1), t.df, t.dres, g.ln_g, g.ln_b, nullptr, s));
+                     ait_dropout_seed(seed, 1), t.df, t.dres, g.ln_g, g.ln_b, nullptr, s.stream));
   AIT_TRY(dgrad(t.df, M, D, w.fc_w, DK, nullptr, false, t.du, s));            // du = df fc_w
   AIT_TRY(wgrad(t.df, M, D, m.u, DK, g.fc_w, s));                            // d fc_w += df^T u
-  AIT_TRY(ait_sh_bwd(t.du, m.O, m.gate, w.sk_w, n, H, T, DK, t.dO, t.dg, s));
+  AIT_TRY(ait_sh_bwd(t.du, m.O, m.gate, w.sk_w, n, H, T, DK, t.dO, t.dg, s.stream));
   AIT_TRY(wgrad(t.dg, n, D, m.s, DK, g.sk_w, s));                            // d sk_w += dg^T s
-  if (g.sk_b) AIT_TRY(ait_colsum_f32(t.dg, n, D, D, g.sk_b, s));
+  if (g.sk_b) AIT_TRY(ait_colsum_f32(t.dg, n, D, D, g.sk_b, s.stream));
   const Qkv v = views(m, n, cross);
   float* dq = t.dqkv;
   if (!cross) {
     AIT_TRY(ait_attn_bwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
-                         ait_dropout_seed(seed, 0), dq, 3 * D, dq + D, 3 * D, dq + 2 * D, 3 * D, s));
+                         ait_dropout_seed(seed, 0), dq, 3 * D, dq + D, 3 * D, dq + 2 * D, 3 * D, s.stream));
     AIT_TRY(dgrad(dq, M, 3 * D, w.w_qkv, D, t.dres, false, dxq, s));          // dx = dqkv W_qkv + dres
     return wgrad(dq, M, 3 * D, xq, D, g.w_qkv, s);
   }
   float* dkv = t.dqkv + (size_t)M * D;
   AIT_TRY(ait_attn_bwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
-                       ait_dropout_seed(seed, 0), dq, D, dkv, 2 * D, dkv + D, 2 * D, s));
+                       ait_dropout_seed(seed, 0), dq, D, dkv, 2 * D, dkv + D, 2 * D, s.stream));
   AIT_TRY(dgrad(dq, M, D, w.w_qkv, D, t.dres, false, dxq, s));
   if (dxkv) AIT_TRY(dgrad(dkv, n * kv_rows, 2 * D, w.w_qkv + (size_t)D * D, D, nullptr, false, dxkv, s));
   AIT_TRY(wgrad(dq, M, D, xq, D, g.w_qkv, s));
@@ -194,19 +200,19 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
 // saved activations in training (with mean / rstd of the closing LayerNorm)
 struct FfnBuf { float *h, *f, *mean, *rstd; };
 int ffn_block(const float* x, long long rows, const ait_ffn_weights& w, const FfnBuf& m, float p,
-              unsigned long long seed, float* y, void* s) {
+              unsigned long long seed, float* y, const Run& s) {
   AIT_TRY(linear(x, (int)rows, D, w.w1, DI, w.b1, true, m.h, s));
   AIT_TRY(linear(m.h, (int)rows, DI, w.w2, D, w.b2, false, m.f, s));
   return ait_ln_fwd(m.f, nullptr, x, w.ln_g, w.ln_b, rows, D, T, T, 1, kEps, p, ait_dropout_seed(seed, 0), y, m.mean,
-                    m.rstd, s);
+                    m.rstd, s.stream);
 }
 struct FfnBwdWs { float *df, *dres, *dh; };
 int ffn_block_bwd(const float* dy, const float* x, long long rows, const ait_ffn_weights& w, const FfnBuf& m,
-                  const FfnBwdWs& t, float p, unsigned long long seed, float* dx, const ait_ffn_grads& g, void* s) {
+                  const FfnBwdWs& t, float p, unsigned long long seed, float* dx, const ait_ffn_grads& g, const Run& s) {
   const int R = (int)rows;
   // df at w_2's output (its column sums are d b2), dres on the residual branch
   AIT_TRY(ait_ln_bwd(dy, m.f, nullptr, x, w.ln_g, m.mean, m.rstd, rows, D, T, T, 1, T, p, ait_dropout_seed(seed, 0),
-                     t.df, t.dres, g.ln_g, g.ln_b, g.b2, s));
+                     t.df, t.dres, g.ln_g, g.ln_b, g.b2, s.stream));
   AIT_TRY(wgrad(t.df, rows, D, m.h, DI, g.w2, s));                             // d W2 += df^T h
   AIT_TRY(dgrad(t.df, R, D, w.w2, DI, m.h, true, t.dh, s, g.b1));             // dh = (df W2) [h > 0];  d b1 += column sums
   AIT_TRY(wgrad(t.dh, rows, DI, x, D, g.w1, s));                               // d W1 += dh^T x
@@ -246,7 +252,7 @@ static int check_mha(const float* xq, const float*& xkv, int n_seq, int kv_rows,
 
 AIT_API int ait_mha_block_fwd(const float* xq, const float* xkv, int n_seq, int kv_rows, int mask_mode,
                               int n_valid_keys, const ait_mha_weights* w, void* workspace, size_t workspace_bytes,
-                              float* y, void* stream) {
+                              float* y, const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY(check_mha(xq, xkv, n_seq, kv_rows, mask_mode, w));
   if (n_seq == 0) return AIT_OK;
   if (!y || !workspace) return AIT_EINVAL;
@@ -254,7 +260,7 @@ AIT_API int ait_mha_block_fwd(const float* xq, const float* xkv, int n_seq, int 
   Bump b{static_cast<char*>(workspace), workspace_bytes};
   MhaBuf m;
   if (!carve(b, m, n_seq, kv_rows, xkv != xq, false)) return AIT_EWORKSPACE;
-  return mha_block(xq, xkv, n_seq, kv_rows, mask_mode, n_valid_keys, *w, m, 0.f, 0.f, 0, y, stream);
+  return mha_block(xq, xkv, n_seq, kv_rows, mask_mode, n_valid_keys, *w, m, 0.f, 0.f, 0, y, Run{stream, ctx});
 }
 
 AIT_API size_t ait_ffn_workspace_bytes(long long rows) {
@@ -263,7 +269,7 @@ AIT_API size_t ait_ffn_workspace_bytes(long long rows) {
 }
 
 AIT_API int ait_ffn_fwd(const float* x, long long rows, const ait_ffn_weights* w, void* workspace,
-                        size_t workspace_bytes, float* y, void* stream) {
+                        size_t workspace_bytes, float* y, const ait_launch_ctx* ctx, void* stream) {
   if (rows < 0 || rows > 0x7fffffffLL || !w) return AIT_EINVAL;
   if (rows == 0) return AIT_OK;
   if (!x || !y || !workspace) return AIT_EINVAL;
@@ -271,7 +277,7 @@ AIT_API int ait_ffn_fwd(const float* x, long long rows, const ait_ffn_weights* w
   Bump b{static_cast<char*>(workspace), workspace_bytes};
   FfnBuf m{b.take((size_t)rows * DI), b.take((size_t)rows * D), nullptr, nullptr};
   if (!m.h || !m.f) return AIT_EWORKSPACE;
-  return ffn_block(x, rows, *w, m, 0.f, 0, y, stream);
+  return ffn_block(x, rows, *w, m, 0.f, 0, y, Run{stream, ctx});
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -286,7 +292,8 @@ AIT_API size_t ait_mha_block_saved_bytes(int n_seq, int kv_rows) {
 
 AIT_API int ait_mha_block_fwd_train(const float* xq, const float* xkv, int n_seq, int kv_rows, int mask_mode,
                                     int n_valid_keys, const ait_mha_weights* w, float p_drop, float p_attn_drop,
-                                    unsigned long long seed, void* saved, size_t saved_bytes, float* y, void* stream) {
+                                    unsigned long long seed, void* saved, size_t saved_bytes, float* y,
+                                    const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY(check_mha(xq, xkv, n_seq, kv_rows, mask_mode, w));
   if (bad_p(p_drop) || bad_p(p_attn_drop)) return AIT_EINVAL;
   if (n_seq == 0) return AIT_OK;
@@ -295,7 +302,7 @@ AIT_API int ait_mha_block_fwd_train(const float* xq, const float* xkv, int n_seq
   Bump b{static_cast<char*>(saved), saved_bytes};
   MhaBuf m;
   if (!carve(b, m, n_seq, kv_rows, xkv != xq, true)) return AIT_EWORKSPACE;
-  return mha_block(xq, xkv, n_seq, kv_rows, mask_mode, n_valid_keys, *w, m, p_drop, p_attn_drop, seed, y, stream);
+  return mha_block(xq, xkv, n_seq, kv_rows, mask_mode, n_valid_keys, *w, m, p_drop, p_attn_drop, seed, y, Run{stream, ctx});
 }
 
 AIT_API size_t ait_mha_block_bwd_workspace_bytes(int n_seq, int kv_rows) {
@@ -307,7 +314,7 @@ AIT_API int ait_mha_block_bwd(const float* dy, const float* xq, const float* xkv
                               int mask_mode, int n_valid_keys, const ait_mha_weights* w, float p_drop,
                               float p_attn_drop, unsigned long long seed, const void* saved, size_t saved_bytes,
                               void* workspace, size_t workspace_bytes, float* dxq, float* dxkv,
-                              const ait_mha_grads* grads, void* stream) {
+                              const ait_mha_grads* grads, const ait_launch_ctx* ctx, void* stream) {
   (void)n_valid_keys;     // masked probabilities are exactly 0 in the saved P: the backward needs no mask
   AIT_TRY(check_mha(xq, xkv, n_seq, kv_rows, mask_mode, w));
   if (bad_p(p_drop) || bad_p(p_attn_drop) || !grads) return AIT_EINVAL;
@@ -322,7 +329,8 @@ AIT_API int ait_mha_block_bwd(const float* dy, const float* xq, const float* xkv
   Bump bw{static_cast<char*>(workspace), workspace_bytes};
   MhaBwdWs t;
   if (!carve(bw, t, n_seq, kv_rows, cross)) return AIT_EWORKSPACE;
-  return mha_block_bwd(dy, T, xq, xkv, n_seq, kv_rows, *w, m, t, p_drop, p_attn_drop, seed, dxq, dxkv, *grads, stream);
+  return mha_block_bwd(dy, T, xq, xkv, n_seq, kv_rows, *w, m, t, p_drop, p_attn_drop, seed, dxq, dxkv, *grads,
+                       Run{stream, ctx});
 }
 
 AIT_API size_t ait_ffn_saved_bytes(long long rows) {
@@ -336,7 +344,8 @@ static bool carve_ffn(Bump& b, FfnBuf& m, long long rows) {
 }
 
 AIT_API int ait_ffn_fwd_train(const float* x, long long rows, const ait_ffn_weights* w, float p_drop,
-                              unsigned long long seed, void* saved, size_t saved_bytes, float* y, void* stream) {
+                              unsigned long long seed, void* saved, size_t saved_bytes, float* y,
+                              const ait_launch_ctx* ctx, void* stream) {
   if (rows < 0 || rows > 0x7fffffffLL || !w || bad_p(p_drop)) return AIT_EINVAL;
   if (rows == 0) return AIT_OK;
   if (!x || !y || !saved) return AIT_EINVAL;
@@ -344,7 +353,7 @@ AIT_API int ait_ffn_fwd_train(const float* x, long long rows, const ait_ffn_weig
   Bump b{static_cast<char*>(saved), saved_bytes};
   FfnBuf m;
   if (!carve_ffn(b, m, rows)) return AIT_EWORKSPACE;
-  return ffn_block(x, rows, *w, m, p_drop, seed, y, stream);
+  return ffn_block(x, rows, *w, m, p_drop, seed, y, Run{stream, ctx});
 }
 
 AIT_API size_t ait_ffn_bwd_workspace_bytes(long long rows) {
@@ -358,7 +367,8 @@ static bool carve_ffn_ws(Bump& b, FfnBwdWs& t, long long rows) {
 
 AIT_API int ait_ffn_bwd(const float* dy, const float* x, long long rows, const ait_ffn_weights* w, float p_drop,
                         unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
-                        size_t workspace_bytes, float* dx, const ait_ffn_grads* grads, void* stream) {
+                        size_t workspace_bytes, float* dx, const ait_ffn_grads* grads, const ait_launch_ctx* ctx,
+                        void* stream) {
   if (rows < 0 || rows > 0x7fffffffLL || !w || !grads || bad_p(p_drop)) return AIT_EINVAL;
   if (rows == 0) return AIT_OK;
   if (!dy || !x || !dx || !saved || !workspace) return AIT_EINVAL;
@@ -369,7 +379,7 @@ AIT_API int ait_ffn_bwd(const float* dy, const float* x, long long rows, const a
   Bump bw{static_cast<char*>(workspace), workspace_bytes};
   FfnBwdWs t;
   if (!carve_ffn_ws(bw, t, rows)) return AIT_EWORKSPACE;
-  return ffn_block_bwd(dy, x, rows, *w, m, t, p_drop, seed, dx, *grads, stream);
+  return ffn_block_bwd(dy, x, rows, *w, m, t, p_drop, seed, dx, *grads, Run{stream, ctx});
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -449,17 +459,18 @@ inline bool carve_eval(Bump& b, AitBufs& a, long long bp, long long bs, int ns) 
 enum { kSeedEncPro = 16, kSeedEncSlf, kSeedEncFfn, kSeedDecPro, kSeedDecSlf, kSeedDecEnc, kSeedDecFfn };
 
 int ait_forward(const float* x_props, const float* x_query, int bp, int bs, int n_src, const ait_transformer_weights* w,
-                const AitBufs& a, float p, float p_attn, unsigned long long seed, float* out, void* stream) {
+                const AitBufs& a, float p, float p_attn, unsigned long long seed, float* out, const Run& run) {
+  void* stream = run.stream;
   hipStream_t hs = ait_stream(stream);
   const int M = bp * T, P = bp / bs;
   // embeddings (1x1 convolutions on token rows)
-  AIT_TRY(linear(x_props, bp * n_src, C2, w->enc_emb_w, D, w->enc_emb_b, false, a.emb_p, stream));
-  AIT_TRY(linear(x_query, bs * T, C2, w->dec_emb_w, D, w->dec_emb_b, false, a.emb_q, stream));
+  AIT_TRY(linear(x_props, bp * n_src, C2, w->enc_emb_w, D, w->enc_emb_b, false, a.emb_p, run));
+  AIT_TRY(linear(x_query, bs * T, C2, w->dec_emb_w, D, w->dec_emb_b, false, a.emb_q, run));
   // ---- encoder (Models.py:83-111): zero-pad n_src -> 64 rows inside the LayerNorm row map --------
   AIT_TRY(ait_ln_fwd(a.emb_p, w->pos_table, nullptr, w->enc_ln_g, w->enc_ln_b, M, D, T, n_src, 1, kEps, p,
                      ait_dropout_seed(seed, kSeedEncPro), a.x0, a.mean0, a.rstd0, stream));
   AIT_TRY(mha_block(a.x0, a.x0, bp, T, /*key padding*/ 1, n_src, w->enc_slf, a.enc_slf, p, p_attn,
-                    ait_dropout_seed(seed, kSeedEncSlf), a.y1, stream));
+                    ait_dropout_seed(seed, kSeedEncSlf), a.y1, run));
   // only the n_src real rows of each sequence are read again: compact them (dead padded rows are
   // masked as keys everywhere downstream)
   if (n_src < T) {
@@ -468,17 +479,17 @@ int ait_forward(const float* x_props, const float* x_query, int bp, int bs, int 
       return AIT_ELAUNCH;
   }
   AIT_TRY(ffn_block(a.xc, (long long)bp * n_src, w->enc_ffn, a.enc_ffn, p, ait_dropout_seed(seed, kSeedEncFfn), a.mem,
-                    stream));
+                    run));
   // ---- decoder (Models.py:143-172): the query sequence of a pair repeated over its P proposals ----
   AIT_TRY(ait_ln_fwd(a.emb_q, w->pos_table, nullptr, w->dec_ln_g, w->dec_ln_b, M, D, T, T, P, kEps, p,
                      ait_dropout_seed(seed, kSeedDecPro), a.xd, a.meand, a.rstdd, stream));
   AIT_TRY(mha_block(a.xd, a.xd, bp, T, /*causal*/ 2, 0, w->dec_slf, a.dec_slf, p, p_attn,
-                    ait_dropout_seed(seed, kSeedDecSlf), a.d1, stream));
+                    ait_dropout_seed(seed, kSeedDecSlf), a.d1, run));
   AIT_TRY(mha_block(a.d1, a.mem, bp, n_src, /*none: the memory is unpadded*/ n_src < T ? 0 : 1, n_src, w->dec_enc,
-                    a.dec_enc, p, p_attn, ait_dropout_seed(seed, kSeedDecEnc), a.d2, stream));
-  AIT_TRY(ffn_block(a.d2, M, w->dec_ffn, a.dec_ffn, p, ait_dropout_seed(seed, kSeedDecFfn), a.d3, stream));
+                    a.dec_enc, p, p_attn, ait_dropout_seed(seed, kSeedDecEnc), a.d2, run));
+  AIT_TRY(ffn_block(a.d2, M, w->dec_ffn, a.dec_ffn, p, ait_dropout_seed(seed, kSeedDecFfn), a.d3, run));
   // dec_trans back to 2d channels per token
-  return linear(a.d3, M, D, w->dec_trans_w, C2, w->dec_trans_b, false, out, stream);
+  return linear(a.d3, M, D, w->dec_trans_w, C2, w->dec_trans_b, false, out, run);
 }
 
 int check_ait(int bp, int bs, int n_src, const void* w) {
@@ -496,7 +507,7 @@ AIT_API size_t ait_transformer_workspace_bytes(int bp, int bs, int n_src) {
 
 AIT_API int ait_transformer_fwd(const float* x_props, const float* x_query, int bp, int bs, int n_src,
                                 const ait_transformer_weights* w, void* workspace, size_t workspace_bytes,
-                                float* out, void* stream) {
+                                float* out, const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY(check_ait(bp, bs, n_src, w));
   if (bp == 0) return AIT_OK;
   if (!x_props || !x_query || !out || !workspace) return AIT_EINVAL;
@@ -504,7 +515,7 @@ AIT_API int ait_transformer_fwd(const float* x_props, const float* x_query, int 
   Bump b{static_cast<char*>(workspace), workspace_bytes};
   AitBufs a;
   if (!carve_eval(b, a, bp, bs, n_src)) return AIT_EWORKSPACE;
-  return ait_forward(x_props, x_query, bp, bs, n_src, w, a, 0.f, 0.f, 0, out, stream);
+  return ait_forward(x_props, x_query, bp, bs, n_src, w, a, 0.f, 0.f, 0, out, Run{stream, ctx});
 }
 
 AIT_API size_t ait_transformer_saved_bytes(int bp, int bs, int n_src) {
@@ -515,7 +526,7 @@ AIT_API size_t ait_transformer_saved_bytes(int bp, int bs, int n_src) {
 AIT_API int ait_transformer_fwd_train(const float* x_props, const float* x_query, int bp, int bs, int n_src,
                                       const ait_transformer_weights* w, float p_drop, float p_attn_drop,
                                       unsigned long long seed, void* saved, size_t saved_bytes, float* out,
-                                      void* stream) {
+                                      const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY(check_ait(bp, bs, n_src, w));
   if (bad_p(p_drop) || bad_p(p_attn_drop)) return AIT_EINVAL;
   if (bp == 0) return AIT_OK;
@@ -524,7 +535,7 @@ AIT_API int ait_transformer_fwd_train(const float* x_props, const float* x_query
   Bump b{static_cast<char*>(saved), saved_bytes};
   AitBufs a;
   if (!carve_train(b, a, bp, bs, n_src)) return AIT_EWORKSPACE;
-  return ait_forward(x_props, x_query, bp, bs, n_src, w, a, p_drop, p_attn_drop, seed, out, stream);
+  return ait_forward(x_props, x_query, bp, bs, n_src, w, a, p_drop, p_attn_drop, seed, out, Run{stream, ctx});
 }
 
 AIT_API size_t ait_transformer_bwd_workspace_bytes(int bp, int bs, int n_src) {
@@ -541,7 +552,7 @@ AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const 
                                 int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
                                 unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
                                 size_t workspace_bytes, float* d_x_props, float* d_x_query,
-                                const ait_transformer_grads* g, void* stream) {
+                                const ait_transformer_grads* g, const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY(check_ait(bp, bs, n_src, w));
   if (bad_p(p_drop) || bad_p(p_attn_drop) || !g) return AIT_EINVAL;
   if (bp == 0) return AIT_OK;
@@ -549,6 +560,7 @@ AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const 
   if (saved_bytes < ait_transformer_saved_bytes(bp, bs, n_src)) return AIT_EWORKSPACE;
   if (workspace_bytes < ait_transformer_bwd_workspace_bytes(bp, bs, n_src)) return AIT_EWORKSPACE;
   hipStream_t hs = ait_stream(stream);
+  const Run run{stream, ctx};
   const int M = bp * T, P = bp / bs, Mc = bp * n_src;
   Bump bs_{static_cast<char*>(const_cast<void*>(saved)), saved_bytes};
   AitBufs a;
@@ -564,51 +576,50 @@ AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const 
 
   // dec_trans: out = d3 W^T + b
   if (g->dec_trans_b) AIT_TRY(ait_colsum_f32(d_out, M, C2, C2, g->dec_trans_b, stream));
-  AIT_TRY(wgrad(d_out, M, C2, a.d3, D, g->dec_trans_w, stream));
-  AIT_TRY(dgrad(d_out, M, C2, w->dec_trans_w, D, nullptr, false, ga, stream));                  // ga = d d3
+  AIT_TRY(wgrad(d_out, M, C2, a.d3, D, g->dec_trans_w, run));
+  AIT_TRY(dgrad(d_out, M, C2, w->dec_trans_w, D, nullptr, false, ga, run));                  // ga = d d3
   {  // decoder feed-forward: d d3 -> d d2
     Bump bb = blk; FfnBwdWs t;
     if (!carve_ffn_ws(bb, t, M)) return AIT_EWORKSPACE;
-    AIT_TRY(ffn_block_bwd(ga, a.d2, M, w->dec_ffn, a.dec_ffn, t, p, ait_dropout_seed(seed, kSeedDecFfn), gb, g->dec_ffn,
-                          stream));
+    AIT_TRY(ffn_block_bwd(ga, a.d2, M, w->dec_ffn, a.dec_ffn, t, p, ait_dropout_seed(seed, kSeedDecFfn), gb, g->dec_ffn, run));
   }
   float* d_mem = gc;     // [Mc, 512]
   {  // decoder cross-attention: d d2 -> d d1, d mem
     Bump bb = blk; MhaBwdWs t;
     if (!carve(bb, t, bp, n_src, true)) return AIT_EWORKSPACE;
     AIT_TRY(mha_block_bwd(gb, T, a.d1, a.mem, bp, n_src, w->dec_enc, a.dec_enc, t, p, pa,
-                          ait_dropout_seed(seed, kSeedDecEnc), ga, d_mem, g->dec_enc, stream));
+                          ait_dropout_seed(seed, kSeedDecEnc), ga, d_mem, g->dec_enc, run));
   }
   {  // decoder self-attention: d d1 -> d xd
     Bump bb = blk; MhaBwdWs t;
     if (!carve(bb, t, bp, T, false)) return AIT_EWORKSPACE;
     AIT_TRY(mha_block_bwd(ga, T, a.xd, a.xd, bp, T, w->dec_slf, a.dec_slf, t, p, pa, ait_dropout_seed(seed, kSeedDecSlf),
-                          gb, nullptr, g->dec_slf, stream));
+                          gb, nullptr, g->dec_slf, run));
   }
   // decoder prologue: LayerNorm(dropout(repeat_P(emb_q) + pos)); the P copies' gradients are summed
   AIT_TRY(ait_ln_bwd(gb, a.emb_q, w->pos_table, nullptr, w->dec_ln_g, a.meand, a.rstdd, M, D, T, T, P, T, p,
                      ait_dropout_seed(seed, kSeedDecPro), ga, nullptr, g->dec_ln_g, g->dec_ln_b, g->dec_emb_b, stream));
   if (hipMemsetAsync(d_emb_q, 0, (size_t)bs * T * D * sizeof(float), hs) != hipSuccess) return AIT_ELAUNCH;
   AIT_TRY(ait_rep_sum_f32(ga, bs, P, (long long)T * D, d_emb_q, stream));
-  AIT_TRY(wgrad(d_emb_q, (long long)bs * T, D, x_query, C2, g->dec_emb_w, stream));
-  if (d_x_query) AIT_TRY(dgrad(d_emb_q, bs * T, D, w->dec_emb_w, C2, nullptr, false, d_x_query, stream));
+  AIT_TRY(wgrad(d_emb_q, (long long)bs * T, D, x_query, C2, g->dec_emb_w, run));
+  if (d_x_query) AIT_TRY(dgrad(d_emb_q, bs * T, D, w->dec_emb_w, C2, nullptr, false, d_x_query, run));
 
   {  // encoder feed-forward on the compacted rows: d mem -> d xc
     Bump bb = blk; FfnBwdWs t;
     if (!carve_ffn_ws(bb, t, Mc)) return AIT_EWORKSPACE;
     AIT_TRY(ffn_block_bwd(d_mem, a.xc, Mc, w->enc_ffn, a.enc_ffn, t, p, ait_dropout_seed(seed, kSeedEncFfn), ga,
-                          g->enc_ffn, stream));
+                          g->enc_ffn, run));
   }
   {  // encoder self-attention: its output received a gradient only on the n_src real rows of a sequence
     Bump bb = blk; MhaBwdWs t;
     if (!carve(bb, t, bp, T, false)) return AIT_EWORKSPACE;
     AIT_TRY(mha_block_bwd(ga, n_src, a.x0, a.x0, bp, T, w->enc_slf, a.enc_slf, t, p, pa,
-                          ait_dropout_seed(seed, kSeedEncSlf), gb, nullptr, g->enc_slf, stream));
+                          ait_dropout_seed(seed, kSeedEncSlf), gb, nullptr, g->enc_slf, run));
   }
   // encoder prologue: LayerNorm(dropout(pad(emb_p) + pos)); the gradient is indexed by source row
   AIT_TRY(ait_ln_bwd(gb, a.emb_p, w->pos_table, nullptr, w->enc_ln_g, a.mean0, a.rstd0, M, D, T, n_src, 1, T, p,
                      ait_dropout_seed(seed, kSeedEncPro), ga, nullptr, g->enc_ln_g, g->enc_ln_b, g->enc_emb_b, stream));
-  AIT_TRY(wgrad(ga, Mc, D, x_props, C2, g->enc_emb_w, stream));
-  if (d_x_props) AIT_TRY(dgrad(ga, Mc, D, w->enc_emb_w, C2, nullptr, false, d_x_props, stream));
+  AIT_TRY(wgrad(ga, Mc, D, x_props, C2, g->enc_emb_w, run));
+  if (d_x_props) AIT_TRY(dgrad(ga, Mc, D, w->enc_emb_w, C2, nullptr, false, d_x_props, run));
   return AIT_OK;
 }

@@ -731,7 +731,10 @@ class _fasterRCNN(nn.Module):
         if self.training and image.is_cuda:
             # the RPN's anchor targets depend only on the inputs: their device part is enqueued FIRST and the
             # two counts per image the host-side sampling needs cross PCIe while the backbone runs
-            self.RCNN_rpn.RPN_anchor_target.begin(gt_boxes, img_info, *_c4_size(image.size(2), image.size(3)))
+            # (im_hw_hint: the loader writes the padded tensor's size into im_info, roibatchLoader.py:228-255; the
+            # layer verifies the prediction on the device and redoes itself if it was wrong)
+            self.RCNN_rpn.RPN_anchor_target.begin(gt_boxes, img_info, *_c4_size(image.size(2), image.size(3)),
+                                                  im_hw_hint=(image.size(2), image.size(3)))
 
         image_feat, _ = self.RCNN_base(image)                 # [bs, 1024, H_i, W_i]
         query_feat, _ = self.RCNN_base(query)                 # [bs, 1024, 8, 8]

@@ -1,4 +1,5 @@
 """Thin tensor-level wrappers over the C ABI (no autograd here; see ait_amd/system.py)."""
+import collections
 import ctypes
 
 import torch
@@ -8,6 +9,24 @@ from . import _lib
 
 def _p(t, dtype=torch.float32):
     return None if t is None else _lib.dev_ptr(t, dtype)
+
+
+# Torch compositions that stand in for a kernel of the library exist for ONE reason: CPU tensors (the host-logic
+# tests, which run without a GPU).  Every time one runs it is counted here, by site; bench.py and the full-size GPU
+# tests assert that the count stays zero -- on a GPU box the product path is the library's kernels or an error.
+FALLBACKS = collections.Counter()
+
+
+def note_fallback(site, tensor=None):
+    FALLBACKS[site] += 1
+
+
+def fallback_count():
+    return sum(FALLBACKS.values())
+
+
+def reset_fallbacks():
+    FALLBACKS.clear()
 
 
 # "f32": exact fp32 products on v_mfma_f32_32x32x2_f32 (default, the parity / headline path).
@@ -77,7 +96,7 @@ def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, 
             int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.dev_ptr(a), lda,
             _lib.dev_ptr(b), ldb, ctypes.c_void_p(out.data_ptr()), ldc, _p(bias),
             _p(residual), flags, int(split_k), int(c_colblk), int(c_batch_stride),
-            _lib.cur_stream(a.device))
+            _lib.launch_ctx(a.device), _lib.cur_stream(a.device))
     _lib.check(rc, "ait_gemm_f32")
     return out
 
@@ -139,7 +158,7 @@ def bgemm(a, b, trans_a=False, trans_b=True, alpha=1.0, out=None, accumulate=Fal
             ctypes.c_void_p(b.data_ptr()), b.stride(-2), s1(b), s2(b), ctypes.c_void_p(out.data_ptr()), out.stride(-2),
             s1(out), s2(out), a.shape[0], a.shape[1] if nb == 2 else 1,
             _lib.GEMM_ATOMIC if split_k > 1 else (_lib.GEMM_ACCUMULATE if accumulate else 0), split_k,
-            _lib.cur_stream(a.device))
+            _lib.launch_ctx(a.device), _lib.cur_stream(a.device))
     _lib.check(rc, "ait_gemm_f32_batched")
     return out
 
@@ -210,7 +229,7 @@ def gemm_relu_bwd(dy, w, act, out=None):
         rc = _gemm_fn()(
             0, 0, M, K, N, 1.0, _lib.dev_ptr(dy), dy.stride(0), _lib.dev_ptr(w), w.stride(0),
             _lib.dev_ptr(out), out.stride(0), None, _lib.dev_ptr(act), _lib.GEMM_MASK_POS, 1, 0, 0,
-            _lib.cur_stream(dy.device))
+            _lib.launch_ctx(dy.device), _lib.cur_stream(dy.device))
     _lib.check(rc, "ait_gemm_f32(mask)")
     return out
 
@@ -433,7 +452,7 @@ def conv_fwd(x, w, geom, bias=None, residual=None, relu=False):
     with torch.cuda.device(x.device):
         rc = _lib.lib().ait_conv_fwd_f32(_lib.dev_ptr(x), x.stride(0), _lib.dev_ptr(w), ctypes.byref(geom), cin, cout,
                                          _p(bias), _p(residual), _lib.GEMM_RELU if relu else 0, _p(y), cout, _p(z),
-                                         z.numel(), _lib.cur_stream(x.device))
+                                         z.numel(), _lib.launch_ctx(x.device), _lib.cur_stream(x.device))
     _lib.check(rc, "ait_conv_fwd_f32")
     return y
 
@@ -446,7 +465,7 @@ def conv_bwd_data(dy, w, geom, residual=None, mask_pos=False):
     with torch.cuda.device(dy.device):
         rc = _lib.lib().ait_conv_bwd_data_f32(_lib.dev_ptr(dy), dy.stride(0), _lib.dev_ptr(w), ctypes.byref(geom), cin, cout,
                                               _p(residual), _lib.GEMM_MASK_POS if mask_pos else 0, _p(dx), cin, _p(z),
-                                              z.numel(), _lib.cur_stream(dy.device))
+                                              z.numel(), _lib.launch_ctx(dy.device), _lib.cur_stream(dy.device))
     _lib.check(rc, "ait_conv_bwd_data_f32")
     return dx
 
@@ -458,6 +477,6 @@ def conv_bwd_weight(dy, x, geom, kh, kw, split_k=8):
     with torch.cuda.device(dy.device):
         rc = _lib.lib().ait_conv_bwd_weight_f32(_lib.dev_ptr(dy), dy.stride(0), _lib.dev_ptr(x), x.stride(0),
                                                 ctypes.byref(geom), cin, cout, _p(dw), int(split_k), _p(z), z.numel(),
-                                                _lib.cur_stream(dy.device))
+                                                _lib.launch_ctx(dy.device), _lib.cur_stream(dy.device))
     _lib.check(rc, "ait_conv_bwd_weight_f32")
     return dw

@@ -80,7 +80,7 @@ class _ROIAlignChannelsLast(Function):
             rc = _lib.lib().ait_roi_align_nhwc_fwd(
                 _lib.dev_ptr(x, torch.float32, True), _lib.dev_ptr(roi), K, B, C, H, W, ph, pw,
                 float(spatial_scale), int(sampling_ratio), ctypes.c_void_p(ws.data_ptr()), nbytes,
-                _lib.dev_ptr(out), _lib.cur_stream(input.device))
+                _lib.dev_ptr(out), _lib.launch_ctx(input.device), _lib.cur_stream(input.device))
         _lib.check(rc, "ait_roi_align_nhwc_fwd")
         ctx.save_for_backward(roi)
         ctx.geom = (B, C, H, W, ph, pw, float(spatial_scale), int(sampling_ratio))
@@ -98,7 +98,8 @@ class _ROIAlignChannelsLast(Function):
         with torch.cuda.device(g.device):
             rc = _lib.lib().ait_roi_align_nhwc_bwd(
                 _lib.dev_ptr(g), _lib.dev_ptr(roi), K, B, C, H, W, ph, pw, scale, sr,
-                ctypes.c_void_p(ws.data_ptr()), nbytes, _lib.dev_ptr(grad_input), _lib.cur_stream(g.device))
+                ctypes.c_void_p(ws.data_ptr()), nbytes, _lib.dev_ptr(grad_input), _lib.launch_ctx(g.device),
+                _lib.cur_stream(g.device))
         _lib.check(rc, "ait_roi_align_nhwc_bwd")
         return grad_input.permute(0, 3, 1, 2), None, None, None, None
 

@@ -22,9 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .config import cfg
-import os
-
-from . import _lib
+from . import _lib, ops
 from .roi_layers import nms_sorted_batched
 
 
@@ -47,9 +45,20 @@ def generate_anchors(base_size=16, ratios=(0.5, 1, 2), scales=2 ** np.arange(3, 
     return np.vstack([_centered(w * scales, h * scales, ctr, ctr) for w, h in zip(ws, hs)])
 
 
-# the box arithmetic of the three layers below runs on the library's kernels (csrc/boxes.hip) for fp32 tensors on
-# the GPU; AIT_BOX_TORCH=1 keeps the tensor expressions (what CPU tensors always get; the tests compare the two)
-_BOX_KERNELS = os.environ.get("AIT_BOX_TORCH", "0") != "1"
+# The box arithmetic of the three layers below runs on the library's kernels (csrc/boxes.hip) for GPU tensors.
+# The tensor expressions remain for CPU tensors (the host-logic tests) and are COUNTED (ops.fallback_count);
+# a GPU tensor of the wrong dtype raises instead of silently leaving the kernels.  _BOX_KERNELS is a test hook
+# (tests/test_gpu_ops.py compares the kernels with the tensor expressions), set from Python only.
+_BOX_KERNELS = True
+
+
+def _lib_kernels(t, site="box arithmetic"):
+    if t.is_cuda and _BOX_KERNELS:
+        if t.dtype != torch.float32:
+            raise _lib.AitHipError("%s: float32 tensors expected on the GPU, got %s" % (site, t.dtype))
+        return True
+    ops.note_fallback(site, t)
+    return False
 
 
 class _AnchorGrid:
@@ -166,7 +175,7 @@ class _ProposalLayer(nn.Module):
         return self._run(probs, deltas, im_info, cfg_key)
 
     def _run(self, probs, deltas, im_info, cfg_key):
-        if _BOX_KERNELS and probs.is_cuda and probs.dtype == torch.float32:
+        if _lib_kernels(probs, "proposal_layer"):
             return self._run_hip(probs, deltas, im_info, cfg_key)
         A = self._num_anchors
         pre_n = cfg[cfg_key].RPN_PRE_NMS_TOP_N
@@ -253,26 +262,51 @@ class _AnchorTargetLayer(nn.Module):
 
     _pending = None
 
-    def prepare(self, gt_boxes, im_info, H, W):
+    def _inside_set(self, all_anchors, H, W, im_h, im_w):
+        """the anchors inside an im_h x im_w image (anchor_target_layer.py:84-90) and what derives from them,
+        cached per (H, W, im_h, im_w, device): the set depends on the IMAGE size, not only on the feature size --
+        about 16 image widths share one W"""
+        dev = all_anchors.device
+        key = (H, W, int(im_h), int(im_w), str(dev))
+        ent = self._inside.get(key)
+        if ent is None:
+            bd = self._allowed_border
+            inside = ((all_anchors[:, 0] >= -bd) & (all_anchors[:, 1] >= -bd) &
+                      (all_anchors[:, 2] < int(im_w) + bd) & (all_anchors[:, 3] < int(im_h) + bd))
+            inds = torch.nonzero(inside).view(-1)
+            if len(self._inside) >= 64:          # (bounded: a loader produces a few dozen padded sizes)
+                self._inside.pop(next(iter(self._inside)))
+            ent = self._inside[key] = {"inds": inds, "hw": torch.tensor([int(im_h), int(im_w)], device=dev)}
+        return key, ent
+
+    def prepare(self, gt_boxes, im_info, H, W, im_hw_hint=None):
         """Everything this layer computes depends only on the INPUTS (anchors, gt boxes, image size), not on
         the network: the device part (IoU, arg-max, labels) and the two per-image counts the host-side
         sampling needs are therefore enqueued at the very start of the detector's forward, and the counts
         travel to the host while the GPU runs the backbone (no GPU-idle gap at the sampler).
-        Returns the pending state consumed by finish() / forward()."""
+        Returns the pending state consumed by finish() / forward().
+
+        The inside-image anchor set is a function of im_info[0] = (im_h, im_w) (like the reference, row 0
+        decides for the batch), which lives on the device.  im_hw_hint: the host's PREDICTION of it (the
+        detector passes the image tensor's height and width, which is what the reference's loader writes
+        there, roibatchLoader.py:228-255); the set for the predicted size is used at once and a device-side
+        comparison with the real im_info travels to the host with the counts -- finish() redoes the layer on
+        a mismatch.  Without a hint im_info is read back (one host synchronisation)."""
         b = gt_boxes.size(0)
         dev = gt_boxes.device
         all_anchors = self._grid.get(H, W, dev)
-        bd = self._allowed_border
-        # (im_info rows are identical within a batch of the reference's drivers; like the reference, row 0 decides)
-        key = (H, W, str(dev))
-        if key not in self._inside:
-            im_h, im_w = float(im_info[0][0]), float(im_info[0][1])        # one tiny D2H, once per feature size
-            inside = ((all_anchors[:, 0] >= -bd) & (all_anchors[:, 1] >= -bd) &
-                      (all_anchors[:, 2] < int(im_w) + bd) & (all_anchors[:, 3] < int(im_h) + bd))
-            self._inside[key] = (torch.nonzero(inside).view(-1), (im_h, im_w))
-        inds_inside, _ = self._inside[key]
-        if _BOX_KERNELS and dev.type == "cuda" and gt_boxes.dtype == torch.float32:
-            return self._prepare_hip(gt_boxes, all_anchors, inds_inside, key, H, W)
+        if im_hw_hint is None:
+            im_h, im_w = float(im_info[0][0]), float(im_info[0][1])        # D2H: synchronises
+            key, ent = self._inside_set(all_anchors, H, W, int(im_h), int(im_w))
+            mismatch = None
+        else:
+            key, ent = self._inside_set(all_anchors, H, W, int(im_hw_hint[0]), int(im_hw_hint[1]))
+            # (int(): the reference truncates with long(), anchor_target_layer.py:86-87)
+            mismatch = (im_info[0, :2].to(torch.int64) != ent["hw"]).any().to(torch.int64).view(1)
+        inds_inside = ent["inds"]
+        redo = (gt_boxes, im_info, H, W)
+        if _lib_kernels(gt_boxes, "anchor_target_layer"):
+            return self._prepare_hip(gt_boxes, all_anchors, inds_inside, ent, H, W, mismatch, redo)
         anchors = all_anchors[inds_inside]
 
         overlaps = bbox_overlaps_batch(anchors, gt_boxes)                 # [b, n_in, G]
@@ -289,26 +323,31 @@ class _AnchorTargetLayer(nn.Module):
         if cfg.TRAIN.RPN_CLOBBER_POSITIVES:
             labels[max_ov < cfg.TRAIN.RPN_NEGATIVE_OVERLAP] = 0
         counts = torch.stack(((labels == 1).sum(1), (labels == 0).sum(1)), 1)       # [b, 2] int64
-        if dev.type == "cuda":
-            host = torch.empty((b, 2), dtype=torch.int64, pin_memory=True)
-            host.copy_(counts, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-        else:
-            host, ev = counts, None
+        host, ev = self._to_host(counts, mismatch)
         return ((H, W, gt_boxes.data_ptr()), gt_boxes, inds_inside, anchors, argmax_ov, labels, host, ev,
-                all_anchors.size(0))
+                all_anchors.size(0), None, redo)
 
-    def _prepare_hip(self, gt_boxes, all_anchors, inds_inside, key, H, W):
+    @staticmethod
+    def _to_host(counts, mismatch):
+        """the 2b class sizes (+ the image-size check) -> pinned host memory, asynchronously; an event marks arrival"""
+        flat = counts.reshape(-1) if mismatch is None else torch.cat([counts.reshape(-1), mismatch])
+        if flat.is_cuda:
+            host = torch.empty((flat.numel(),), dtype=torch.int64, pin_memory=True)
+            host.copy_(flat, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(flat.device))
+            return host, ev
+        return flat, None
+
+    def _prepare_hip(self, gt_boxes, all_anchors, inds_inside, ent, H, W, mismatch, redo):
         """the device part of prepare() in three launches (ait_anchor_classify)"""
         dev = gt_boxes.device
-        st = self.__dict__.setdefault("_static", {}).get(key)
-        if st is None:
-            anchors = all_anchors[inds_inside].float().contiguous()
+        if "anchors" not in ent:
+            ent["anchors"] = all_anchors[inds_inside].float().contiguous()
             inside_pos = torch.full((all_anchors.size(0),), -1, dtype=torch.int32, device=dev)
             inside_pos[inds_inside] = torch.arange(inds_inside.numel(), dtype=torch.int32, device=dev)
-            st = self._static[key] = (anchors, inside_pos)
-        anchors, inside_pos = st
+            ent["inside_pos"] = inside_pos
+        anchors, inside_pos = ent["anchors"], ent["inside_pos"]
         gt = gt_boxes.contiguous()
         b, G, n_in = gt.size(0), gt.size(1), anchors.size(0)
         max_ov = torch.empty((b, n_in), dtype=torch.float32, device=dev)
@@ -326,22 +365,16 @@ class _AnchorTargetLayer(nn.Module):
                 _lib.dev_ptr(counts, torch.int64), _lib.dev_ptr(fg_members, torch.int32),
                 _lib.dev_ptr(bg_members, torch.int32), _lib.cur_stream(dev))
         _lib.check(rc, "ait_anchor_classify")
-        host = torch.empty((b, 2), dtype=torch.int64, pin_memory=True)
-        host.copy_(counts, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
+        host, ev = self._to_host(counts, mismatch)
         return ((H, W, gt_boxes.data_ptr()), gt, inds_inside, anchors, argmax, labels, host, ev, all_anchors.size(0),
-                (inside_pos, fg_members, bg_members))
+                (inside_pos, fg_members, bg_members), redo)
 
-    def begin(self, gt_boxes, im_info, H, W):
+    def begin(self, gt_boxes, im_info, H, W, im_hw_hint=None):
         """called by the detector before the backbone is enqueued (see prepare)"""
-        self._pending = self.prepare(gt_boxes, im_info, H, W)
+        self._pending = self.prepare(gt_boxes, im_info, H, W, im_hw_hint)
 
     def finish(self, pending):
-        hip = None
-        if len(pending) == 10:
-            pending, hip = pending[:9], pending[9]
-        (H, W, _), gt_boxes, inds_inside, anchors, argmax_ov, labels, host, ev, total = pending
+        (H, W, _), gt_boxes, inds_inside, anchors, argmax_ov, labels, host, ev, total, hip, redo = pending
         b, n_in = labels.shape
         A = self._num_anchors
         dev = gt_boxes.device
@@ -349,7 +382,12 @@ class _AnchorTargetLayer(nn.Module):
         # counts per image; WHICH anchors the drawn positions denote is resolved on the device ----------
         if ev is not None:
             ev.synchronize()
-        cnt = host.numpy()
+        flat = host.numpy()
+        if flat.size > 2 * b and flat[2 * b] != 0:
+            # the image-size prediction was wrong (im_info[0] is not the image tensor's size): redo the layer for
+            # the real size, read back from the device.  Nothing random has been drawn yet.
+            return self.finish(self.prepare(*redo, im_hw_hint=None))
+        cnt = flat[:2 * b].reshape(b, 2)
         num_fg = int(cfg.TRAIN.RPN_FG_FRACTION * cfg.TRAIN.RPN_BATCHSIZE)
         dis_fg, dis_bg, n_fg_after, n_bg_after = [], [], [], []
         for i in range(b):
@@ -468,7 +506,9 @@ class _ProposalTargetLayer(nn.Module):
         P = int(cfg.TRAIN.BATCH_SIZE)
         fg_per_image = int(np.round(cfg.TRAIN.FG_FRACTION * P)) or 1
         gpu = dev.type == "cuda"
-        hip = _BOX_KERNELS and gpu and all_rois.dtype == torch.float32 and gt_boxes.dtype == torch.float32
+        hip = _lib_kernels(gt_boxes, "proposal_target_layer")
+        if hip and all_rois.dtype != torch.float32:
+            raise _lib.AitHipError("proposal_target_layer: float32 RoIs expected on the GPU, got %s" % all_rois.dtype)
         if hip:
             all_rois, assign, labels, counts, fg_members, bg_members = self._classify_hip(all_rois, gt_boxes)
         else:
@@ -592,7 +632,9 @@ class _ProposalTargetLayer(nn.Module):
         pos = (labels_b > 0).unsqueeze(2).to(dt)
         # an image whose sampled labels sum to zero gets no regression targets at all
         pos = pos * (labels_b.sum(1) != 0).view(b, 1, 1).to(dt)
-        bbox_targets = targets * pos
+        # (assigned at the foreground rows only, as proposal_target_layer_cascade.py:101-107: a select, so that a
+        # non-finite target of a degenerate box cannot leak as NaN * 0)
+        bbox_targets = torch.where(pos > 0, targets, torch.zeros_like(targets))
         inside_w = pos * _const(cfg.TRAIN.BBOX_INSIDE_WEIGHTS, dev, dt)
         outside_w = (inside_w > 0).to(dt)
         return rois_b, labels_b, bbox_targets, inside_w, outside_w

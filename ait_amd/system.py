@@ -347,7 +347,7 @@ class _TransformerFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = L.ait_transformer_fwd_train(_lib.dev_ptr(xp), _lib.dev_ptr(xq), bp, bs, n_s, ctypes.byref(W),
                                              float(p), float(p_attn), int(seed), ctypes.c_void_p(saved.data_ptr()),
-                                             nbytes, _lib.dev_ptr(out), _lib.cur_stream(dev))
+                                             nbytes, _lib.dev_ptr(out), _lib.launch_ctx(dev), _lib.cur_stream(dev))
         _lib.check(rc, "ait_transformer_fwd_train")
         ctx.save_for_backward(xp, xq, saved)
         ctx.W, ctx.keep = W, keep              # (keep owns the concatenated QKV matrices W points into)
@@ -392,7 +392,7 @@ class _TransformerFn(torch.autograd.Function):
                                        saved.numel(), ctypes.c_void_p(ws.data_ptr()), wbytes,
                                        None if dxp is None else _lib.dev_ptr(dxp),
                                        None if dxq is None else _lib.dev_ptr(dxq), ctypes.byref(G),
-                                       _lib.cur_stream(dev))
+                                       _lib.launch_ctx(dev), _lib.cur_stream(dev))
         _lib.check(rc, "ait_transformer_bwd")
         return (dxp, dxq, None, None, None, None, None, None, None, None) + tuple(views)
 
@@ -818,7 +818,7 @@ class Transformer(nn.Module):
         with torch.cuda.device(xp_tok.device):
             rc = L.ait_transformer_fwd(_lib.dev_ptr(xp_tok), _lib.dev_ptr(xq_tok), bp, bs, n_s,
                                        ctypes.byref(W), ctypes.c_void_p(ws.data_ptr()), nbytes,
-                                       _lib.dev_ptr(out), _lib.cur_stream(xp_tok.device))
+                                       _lib.dev_ptr(out), _lib.launch_ctx(xp_tok.device), _lib.cur_stream(xp_tok.device))
         _lib.check(rc, "ait_transformer_fwd")
         del keep
         return out

@@ -236,9 +236,13 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, device)
 
+    # on a GPU box the product path is the library's kernels: not one torch stand-in may have run
+    if ops.fallback_count() != 0:
+        raise SystemExit("bench.py: torch fallbacks ran inside the step: %r" % (dict(ops.FALLBACKS),))
     if rank != 0:
         return
     entries = probe.entries()
+    probe_overflow = probe.overflowed()
     # (flops, ms, (M, N, K, trans_a, trans_b, splits))
     prof = [(e[1], e[2], e[3]) for e in entries if e[0] == _lib.PROBE_GEMM]
     roi_prof = [(e[1], e[2], "fwd" if e[0] == _lib.PROBE_ROI_FWD else "bwd") for e in entries
@@ -289,6 +293,7 @@ def main():
                      "traffic_detail": pmc, "clock_and_mfma_util": pmc_clock_and_util() if args.dtype == "f32" else None,
                      "algorithmic_bytes_per_launch": alg,
                      "launches_per_step": len(prof) // max(1, args.steps),
+                     "probe_overflow": probe_overflow,      # launches beyond the probe's capacity (0: none truncated)
                      "gemm_ms_per_step": gemm_ms / max(1, args.steps),
                      "gemm_gflop_per_step": flops / max(1, args.steps) / 1e9,
                      # BASELINE.md 4 / SURVEY 8d: the whole AIT path end to end against the matrix peak --

@@ -3,11 +3,13 @@
  *
  * Conventions (all entry points):
  *   - extern "C", plain pointers + sizes; every pointer is DEVICE memory unless it says host.
- *   - the caller owns every buffer including workspaces; nothing is allocated inside.
+ *   - the caller owns every buffer including workspaces and scheduler scratch (ait_launch_ctx); no entry point
+ *     allocates or frees device memory (ait_probe_create allocates a HOST object and its HIP events).
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call only
  *     enqueues work on that stream and returns -- no host synchronisation.
  *   - returns AIT_OK (0) or a negative AIT_E* code; no C++ exception crosses the boundary.
- *   - re-entrant; no global mutable state; safe to call concurrently on different devices
+ *   - re-entrant; no global mutable state (what the library memoises -- the occupancy of a kernel on the
+ *     device model -- is a constant); safe to call concurrently from several threads and on different devices
  *     (the kernels run on the device that is current for the calling thread).
  *   - tensors are fp32, contiguous, row-major / NCHW unless stated.
  *
@@ -35,24 +37,56 @@ int ait_abi_version(void);
 const char* ait_strerror(int code);
 
 /* ---------------------------------------------------------------------------------------
- * Measurement (bench.py's live roofline; no reference counterpart).  While a probe is ATTACHED, the GEMM and RoIAlign entry points -- however they are reached, directly or from
- * inside ait_transformer_* -- bracket their launches with a HIP event pair on the launch stream and
- * note the launch's algorithmic work: kind AIT_PROBE_GEMM: flops = 2*M*N*K, dims = {M, N, K, trans_a,
- * trans_b, splits}; AIT_PROBE_ROI_FWD / _BWD: algorithmic bytes (feature once + RoIs + pooled
- * tensor once), dims = {n_rois, B, C, H, W, 0}.  The probe owns its events (created by
- * ait_probe_create, at most `capacity` launches are recorded); ait_probe_get reports a launch's elapsed
- * milliseconds once the stream has been synchronised.  The attached probe is process-wide (PyTorch runs
- * backward passes on its autograd engine's threads); with no probe attached (the default) the entry
- * points do nothing extra.
+ * Launch context: what a caller MAY hand to the entry points that launch the matrix-core GEMM (ait_gemm_*,
+ * ait_conv_*, ait_mha_block_*, ait_ffn_*, ait_transformer_*) and to the measured RoIAlign pair.  NULL, or a
+ * zeroed struct, is always legal.  Replaces nothing in the reference: its ATen operators take scratch from
+ * ATen's caching allocator (lib/model/csrc/cuda/ROIAlign_cuda.cu:273-299 -- outputs and temporaries are the
+ * caller's tensors); here the scratch is an explicit caller-owned buffer.
+ *
+ *   sched_ws / sched_ws_bytes   scheduler scratch of the persistent GEMM kernel, ait_gemm_workspace_bytes()
+ *       bytes of device memory, prepared ONCE with ait_gemm_workspace_init() and then reused by any number of
+ *       launches that are ORDERED on one stream (one workspace per stream that runs GEMMs concurrently).  With it
+ *       the kernel hands its output tiles out dynamically (per-XCD ticket counters: a workgroup that becomes
+ *       resident late -- beside an RCCL kernel -- finds what is left instead of a fixed share) and, when a
+ *       product's tile count leaves the last round of the persistent grid badly filled (layer4- and
+ *       co-attention-sized products), cuts the slabs of those tiles evenly over all workgroups ("stream-K"): a
+ *       workgroup that computes part of a tile it does not own publishes a partial tile (write-through stores +
+ *       an agent-scope flag), the owner adds the partials in a fixed order and runs the epilogue -- results do
+ *       not depend on timing.  Without it: static work lists, whole tiles; same mathematics, the summation
+ *       order of the affected products differs (both are deterministic).  A workspace that is too small for the
+ *       launch returns AIT_EWORKSPACE.
+ *   probe   measurement probe (below) or NULL.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  void* sched_ws;
+  size_t sched_ws_bytes;
+  void* probe;
+} ait_launch_ctx;
+size_t ait_gemm_workspace_bytes(void);   /* for the device current to the calling thread; 0 on error */
+/* zeroes the control words of a fresh workspace (enqueued on `stream`, capturable); call once after allocation */
+int ait_gemm_workspace_init(void* sched_ws, size_t sched_ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Measurement (bench.py's live roofline; no reference counterpart).  An entry point that is handed a probe
+ * through ait_launch_ctx::probe brackets its GEMM / RoIAlign launches -- however they are reached, directly or
+ * from inside ait_transformer_* -- with a HIP event pair on the launch stream and notes the launch's
+ * algorithmic work: kind AIT_PROBE_GEMM: flops = 2*M*N*K, dims = {M, N, K, trans_a, trans_b, splits};
+ * AIT_PROBE_ROI_FWD / _BWD: algorithmic bytes (feature once + RoIs + pooled tensor once), dims =
+ * {n_rois, B, C, H, W, 0}.  The probe is a caller-owned host object (created on, and only recording launches
+ * of, the device current at ait_probe_create; at most `capacity` launches are recorded, later ones are counted
+ * only); ait_probe_get reports a launch's elapsed milliseconds once the stream has been synchronised.  The
+ * library keeps no reference to a probe between calls; the caller synchronises the device before resetting,
+ * reading or destroying a probe that launches in flight were given.  Slots are claimed atomically: one probe
+ * may be handed to launches from several host threads (PyTorch runs backward passes on its autograd threads).
  * ------------------------------------------------------------------------------------- */
 #define AIT_PROBE_GEMM 1
 #define AIT_PROBE_ROI_FWD 2
 #define AIT_PROBE_ROI_BWD 3
 void* ait_probe_create(int capacity);
 void ait_probe_destroy(void* probe);
-void ait_probe_attach(void* probe);          /* NULL detaches */
 int ait_probe_reset(void* probe);
-int ait_probe_count(void* probe);
+int ait_probe_count(void* probe);      /* launches seen since the reset; > ait_probe_capacity: overflowed */
+int ait_probe_capacity(void* probe);
 int ait_probe_get(void* probe, int i, int* kind, double* work, float* ms, int* dims6);
 
 /* ---------------------------------------------------------------------------------------
@@ -84,14 +118,16 @@ int ait_roi_align_bwd(const float* grad_out, const float* rois, int n_rois, int 
  * per-axis interpolation matrices; rebuilt by every call, nothing is kept between calls).
  * The result equals the NCHW operator's up to fp32 summation order (separable weights instead of
  * per-sample sums); the backward gathers per feature cell in RoI order: no atomics, no zero-fill,
- * bitwise reproducible. */
+ * bitwise reproducible.  ctx: only its probe is used (may be NULL). */
 size_t ait_roi_align_nhwc_workspace_bytes(int n_rois, int H, int W, int PH, int PW);
 int ait_roi_align_nhwc_fwd(const float* feat, const float* rois, int n_rois, int B, int C, int H,
                            int W, int PH, int PW, float spatial_scale, int sampling_ratio,
-                           void* workspace, size_t workspace_bytes, float* out, void* stream);
+                           void* workspace, size_t workspace_bytes, float* out, const ait_launch_ctx* ctx,
+                           void* stream);
 int ait_roi_align_nhwc_bwd(const float* grad_out, const float* rois, int n_rois, int B, int C,
                            int H, int W, int PH, int PW, float spatial_scale, int sampling_ratio,
-                           void* workspace, size_t workspace_bytes, float* grad_in, void* stream);
+                           void* workspace, size_t workspace_bytes, float* grad_in, const ait_launch_ctx* ctx,
+                           void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * NMS.  Replaces model._C.nms (lib/model/csrc/vision.cpp:8, lib/model/csrc/nms.h:10-28)
@@ -220,18 +256,7 @@ int ait_roi_sample_gather(const int64_t* pos, const int64_t* n_fg, int b, int P,
 int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
                  int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
                  const float* residual, int flags, int split_k, int c_colblk,
-                 long long c_batch_stride, void* stream);
-
-/* Scratch of the persistent GEMM's stream-K scheduler.  When a product's tile count leaves the last round of
- * the persistent kernel badly filled (or is smaller than one round: layer4- and co-attention-sized
- * products), the slabs of those tiles are spread evenly over all workgroups; a workgroup that computes part
- * of a tile it does not own publishes a partial tile (write-through stores + an agent-scope flag), the
- * owner adds the partials in a fixed order and runs the epilogue -- results do not depend on timing.  That
- * needs 64 MiB + 2 KiB of device memory per (device, stream), which the library allocates on the first such
- * launch on a stream: the ONE allocation this library makes (hipMalloc, so: not while the stream is being
- * captured).  ait_gemm_workspace_release() frees all of them (streams idle); AIT_GEMM_STREAMK=0 in the
- * environment keeps the scheduler to whole tiles and the library allocation-free. */
-int ait_gemm_workspace_release(void);
+                 long long c_batch_stride, const ait_launch_ctx* ctx, void* stream);
 
 /* Batched form: batch x batch2 independent products, operand (i, j) at base + i*stride + j*stride2 (floats),
  * one launch.  Replaces the three torch.matmul of the COCO variant's image-level co-attention
@@ -244,7 +269,7 @@ int ait_gemm_workspace_release(void);
 int ait_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, int lda,
                          long long stride_a, long long stride_a2, const float* B, int ldb, long long stride_b,
                          long long stride_b2, float* C, int ldc, long long stride_c, long long stride_c2, int batch,
-                         int batch2, int flags, int split_k, void* stream);
+                         int batch2, int flags, int split_k, const ait_launch_ctx* ctx, void* stream);
 
 /* Row softmax + dropout over [rows, cols] matrices with row pitch ld (Modules.py:24 for score matrices that do
  * not fit attn.hip's 64x64 tile): y = softmax(x) per row, y_drop = dropout(y) (stateless hash of (seed, r*cols + c);
@@ -286,12 +311,13 @@ typedef struct {
 } ait_conv_geom;
 int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_conv_geom* geom, int cin, int cout,
                      const float* bias, const float* residual, int flags, float* y, int ldy, const float* zeros,
-                     size_t zeros_floats, void* stream);
+                     size_t zeros_floats, const ait_launch_ctx* ctx, void* stream);
 int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, const ait_conv_geom* geom, int cin, int cout,
                           const float* residual, int flags, float* dx, int lddx, const float* zeros,
-                          size_t zeros_floats, void* stream);
+                          size_t zeros_floats, const ait_launch_ctx* ctx, void* stream);
 int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, int ldx, const ait_conv_geom* geom, int cin,
-                            int cout, float* dw, int split_k, const float* zeros, size_t zeros_floats, void* stream);
+                            int cout, float* dw, int split_k, const float* zeros, size_t zeros_floats,
+                            const ait_launch_ctx* ctx, void* stream);
 
 /* bf16 matrix-core variant (BASELINE cfg 5): identical interface, layouts and epilogues; A and B
  * stay fp32 in memory, are rounded to bf16 (RNE) while being staged into LDS, multiplied on
@@ -299,7 +325,7 @@ int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, int ldx, 
 int ait_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
                   int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
                   const float* residual, int flags, int split_k, int c_colblk,
-                  long long c_batch_stride, void* stream);
+                  long long c_batch_stride, const ait_launch_ctx* ctx, void* stream);
 
 /* EXPERIMENTAL "bf16x3" variant: every fp32 operand is split into hi = bf16(x), lo = bf16(x - hi)
  * and each product is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the bf16 matrix cores with fp32
@@ -309,7 +335,7 @@ int ait_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, float alpha, co
 int ait_gemm_bf16x3(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
                     int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
                     const float* residual, int flags, int split_k, int c_colblk,
-                    long long c_batch_stride, void* stream);
+                    long long c_batch_stride, const ait_launch_ctx* ctx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Row kernels (d_model = 512 only; other widths return AIT_EUNSUPPORTED).
@@ -436,14 +462,14 @@ typedef struct {
 size_t ait_mha_block_workspace_bytes(int n_seq, int kv_rows);
 int ait_mha_block_fwd(const float* xq, const float* xkv, int n_seq, int kv_rows, int mask_mode,
                       int n_valid_keys, const ait_mha_weights* w, void* workspace, size_t workspace_bytes,
-                      float* y, void* stream);
+                      float* y, const ait_launch_ctx* ctx, void* stream);
 size_t ait_ffn_workspace_bytes(long long rows);
 int ait_ffn_fwd(const float* x, long long rows, const ait_ffn_weights* w, void* workspace,
-                size_t workspace_bytes, float* y, void* stream);
+                size_t workspace_bytes, float* y, const ait_launch_ctx* ctx, void* stream);
 size_t ait_transformer_workspace_bytes(int bp, int bs, int n_src);
 int ait_transformer_fwd(const float* x_props, const float* x_query, int bp, int bs, int n_src,
                         const ait_transformer_weights* w, void* workspace, size_t workspace_bytes,
-                        float* out, void* stream);
+                        float* out, const ait_launch_ctx* ctx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Training: the same blocks with dropout, a forward that SAVES what the backward needs, and the
@@ -489,33 +515,36 @@ unsigned long long ait_dropout_seed(unsigned long long base, int site);
 size_t ait_mha_block_saved_bytes(int n_seq, int kv_rows);
 int ait_mha_block_fwd_train(const float* xq, const float* xkv, int n_seq, int kv_rows, int mask_mode,
                             int n_valid_keys, const ait_mha_weights* w, float p_drop, float p_attn_drop,
-                            unsigned long long seed, void* saved, size_t saved_bytes, float* y, void* stream);
+                            unsigned long long seed, void* saved, size_t saved_bytes, float* y,
+                            const ait_launch_ctx* ctx, void* stream);
 size_t ait_mha_block_bwd_workspace_bytes(int n_seq, int kv_rows);
 int ait_mha_block_bwd(const float* dy, const float* xq, const float* xkv, int n_seq, int kv_rows,
                       int mask_mode, int n_valid_keys, const ait_mha_weights* w, float p_drop,
                       float p_attn_drop, unsigned long long seed, const void* saved, size_t saved_bytes,
                       void* workspace, size_t workspace_bytes, float* dxq, float* dxkv,
-                      const ait_mha_grads* grads, void* stream);
+                      const ait_mha_grads* grads, const ait_launch_ctx* ctx, void* stream);
 
 size_t ait_ffn_saved_bytes(long long rows);
 int ait_ffn_fwd_train(const float* x, long long rows, const ait_ffn_weights* w, float p_drop,
-                      unsigned long long seed, void* saved, size_t saved_bytes, float* y, void* stream);
+                      unsigned long long seed, void* saved, size_t saved_bytes, float* y,
+                      const ait_launch_ctx* ctx, void* stream);
 size_t ait_ffn_bwd_workspace_bytes(long long rows);
 int ait_ffn_bwd(const float* dy, const float* x, long long rows, const ait_ffn_weights* w, float p_drop,
                 unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
-                size_t workspace_bytes, float* dx, const ait_ffn_grads* grads, void* stream);
+                size_t workspace_bytes, float* dx, const ait_ffn_grads* grads, const ait_launch_ctx* ctx,
+                void* stream);
 
 size_t ait_transformer_saved_bytes(int bp, int bs, int n_src);
 int ait_transformer_fwd_train(const float* x_props, const float* x_query, int bp, int bs, int n_src,
                               const ait_transformer_weights* w, float p_drop, float p_attn_drop,
                               unsigned long long seed, void* saved, size_t saved_bytes, float* out,
-                              void* stream);
+                              const ait_launch_ctx* ctx, void* stream);
 size_t ait_transformer_bwd_workspace_bytes(int bp, int bs, int n_src);
 int ait_transformer_bwd(const float* d_out, const float* x_props, const float* x_query, int bp, int bs,
                         int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
                         unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
                         size_t workspace_bytes, float* d_x_props, float* d_x_query,
-                        const ait_transformer_grads* grads, void* stream);
+                        const ait_transformer_grads* grads, const ait_launch_ctx* ctx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Frozen batch-norm + residual + ReLU, one pass (NCHW fp32, x [n,C,HW]).

@@ -127,11 +127,22 @@ static void teardown(Problem& p) {
 }
 
 // variant 0: round-1 kernel; 1: current kernel; 2: current kernel with the stamp probe
+// the harness owns the scheduler workspace it hands to the launches (g_use_ws = false: whole tiles, static lists)
+static SchedWs g_ws;
+static bool g_use_ws = true;
+static SchedWs lab_ws() {
+  if (!g_ws.p) {
+    g_ws.bytes = kCtlBytes + (size_t)kMaxSlots * 128 * 128 * sizeof(float);      // covers every variant's tile x slots
+    CK(hipMalloc(&g_ws.p, g_ws.bytes));
+    CK(hipMemset(g_ws.p, 0, kCtlBytes));
+  }
+  return g_use_ws ? g_ws : SchedWs();
+}
 template <class T, bool AK, bool BKC, class Probe>
 static int run_epi(const GemmArgs& g, int slots) {
-  if (g.flags & AIT_GEMM_ATOMIC) return launch<T, AK, BKC, EPI_ATOMIC, Probe>(g, 0, slots);
-  if (g.residual) return launch<T, AK, BKC, EPI_RES, Probe>(g, 0, slots);
-  return launch<T, AK, BKC, EPI_STORE, Probe>(g, 0, slots);
+  if (g.flags & AIT_GEMM_ATOMIC) return launch<T, AK, BKC, EPI_ATOMIC, Probe>(g, 0, lab_ws(), slots);
+  if (g.residual) return launch<T, AK, BKC, EPI_RES, Probe>(g, 0, lab_ws(), slots);
+  return launch<T, AK, BKC, EPI_STORE, Probe>(g, 0, lab_ws(), slots);
 }
 template <class T>
 static int run_tile(const GemmArgs& g, bool ak, bool bk, int slots) {
@@ -166,9 +177,9 @@ static int run(Problem& p, int variant, float* out) {
   g.C = out;
   const bool ak = !p.s.ta, bk = p.s.tb != 0;
   if (variant == 1) {                // the reference for the sweep's result check: whole tiles only
-    stream_k_mode() = 0;
+    g_use_ws = false;
     const int rc = run_new<NoProbe>(g, ak, bk, g_slots);
-    stream_k_mode() = 1;
+    g_use_ws = true;
     return rc;
   }
   if (variant == 2) { g.probe = p.probe; return run_new<StampProbe>(g, ak, bk, g_slots); }
@@ -185,9 +196,9 @@ static int run(Problem& p, int variant, float* out) {
     case 12: return run_tile<V_sp8>(g, ak, bk, g_slots);
     case 13: return run_tile<V_sp4>(g, ak, bk, g_slots);
     case 14: {                      // the same kernel without the stream-K work list
-      stream_k_mode() = 0;
+      g_use_ws = false;
       const int rc = run_tile<V_sp4>(g, ak, bk, g_slots);
-      stream_k_mode() = 1;
+      g_use_ws = true;
       return rc;
     }
     default: break;

@@ -14,6 +14,26 @@ def _declared():
     return sorted(set(re.findall(r"\b(ait_[a-z0-9_]+)\s*\(", text)))
 
 
+def _declared_arity():
+    """name -> number of parameters of every function declared in the header"""
+    text = open(os.path.join(ROOT, "include", "ait_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(ait_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", text):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_binding_arity_matches_the_header():
+    """ctypes does not check argument counts against the C prototype: the binding table must agree with the
+    header parameter for parameter (a missing ait_launch_ctx* would shift the stream into the wrong slot)."""
+    arity = _declared_arity()
+    assert set(arity) == set(_lib.SIGNATURES)
+    for name, (_, args) in _lib.SIGNATURES.items():
+        assert len(args) == arity[name], "%s: binding has %d parameters, header %d" % (name, len(args), arity[name])
+
+
 def test_library_builds_and_exports_header_symbols():
     path = build.build()
     assert os.path.exists(path)
@@ -23,7 +43,7 @@ def test_library_builds_and_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), "libait_hip.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names, (sorted(_lib.SIGNATURES), names)
-    assert L.ait_abi_version() >= 1
+    assert L.ait_abi_version() == 3
     assert L.ait_strerror(0) == b"ok"
     assert L.ait_nms_workspace_bytes(12000) >= 12000 * 188 * 8
 

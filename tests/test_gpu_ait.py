@@ -409,7 +409,7 @@ def test_c_sublayer_blocks_match_the_modules():
         y = torch.empty(n * 64, 512, device="cuda")
         rc = L.ait_mha_block_fwd(_lib.dev_ptr(xq), None if xkv is None else _lib.dev_ptr(xkv), n, kv_rows, mode,
                                  n_valid, ctypes.byref(wstruct), ctypes.c_void_p(ws.data_ptr()), nbytes,
-                                 _lib.dev_ptr(y), _lib.cur_stream(xq.device))
+                                 _lib.dev_ptr(y), _lib.launch_ctx(xq.device), _lib.cur_stream(xq.device))
         _lib.check(rc, "ait_mha_block_fwd")
         return y.view(n, 64, 512)
 
@@ -423,13 +423,13 @@ def test_c_sublayer_blocks_match_the_modules():
         ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         y = torch.empty(rows, 512, device="cuda")
         _lib.check(L.ait_ffn_fwd(_lib.dev_ptr(x), rows, ctypes.byref(W.dec_ffn), ctypes.c_void_p(ws.data_ptr()), nbytes,
-                                 _lib.dev_ptr(y), _lib.cur_stream(x.device)), "ait_ffn_fwd")
+                                 _lib.dev_ptr(y), _lib.launch_ctx(x.device), _lib.cur_stream(x.device)), "ait_ffn_fwd")
         assert torch.equal(y.view(n, 64, 512), dec.pos_ffn(x))
     # argument checking: a workspace that is too small, an impossible memory length
     assert L.ait_ffn_fwd(_lib.dev_ptr(x), rows, ctypes.byref(W.dec_ffn), ctypes.c_void_p(ws.data_ptr()), 16,
-                         _lib.dev_ptr(y), None) == -2
+                         _lib.dev_ptr(y), None, None) == -2
     assert L.ait_mha_block_fwd(_lib.dev_ptr(x), None, n, 49, 0, 0, ctypes.byref(W.enc_slf),
-                               ctypes.c_void_p(ws.data_ptr()), nbytes, _lib.dev_ptr(y), None) == -1
+                               ctypes.c_void_p(ws.data_ptr()), nbytes, _lib.dev_ptr(y), None, None) == -1
     del keep
 
 
@@ -511,7 +511,7 @@ def test_c_training_blocks_match_the_modules():
         xkv_p = None if xkv is None else _lib.dev_ptr(xkv.detach().reshape(-1, 512))
         rc = L.ait_mha_block_fwd_train(_lib.dev_ptr(xq.detach().reshape(-1, 512)), xkv_p, n, kv_rows, mode, n_valid,
                                        ctypes.byref(wstruct), 0.1, 0.1, seed, ctypes.c_void_p(saved.data_ptr()), sb,
-                                       _lib.dev_ptr(y), None)
+                                       _lib.dev_ptr(y), _lib.launch_ctx(), None)
         _lib.check(rc, "ait_mha_block_fwd_train")
         torch.cuda.synchronize()
         assert torch.equal(y.view(n, 64, 512), y_ref.detach())
@@ -525,7 +525,8 @@ def test_c_training_blocks_match_the_modules():
         rc = L.ait_mha_block_bwd(_lib.dev_ptr(cot.reshape(-1, 512)), _lib.dev_ptr(xq.detach().reshape(-1, 512)), xkv_p, n,
                                  kv_rows, mode, n_valid, ctypes.byref(wstruct), 0.1, 0.1, seed,
                                  ctypes.c_void_p(saved.data_ptr()), sb, ctypes.c_void_p(ws.data_ptr()), wb,
-                                 _lib.dev_ptr(dxq), None if dxkv is None else _lib.dev_ptr(dxkv), ctypes.byref(G), None)
+                                 _lib.dev_ptr(dxq), None if dxkv is None else _lib.dev_ptr(dxkv), ctypes.byref(G),
+                                 _lib.launch_ctx(), None)
         _lib.check(rc, "ait_mha_block_bwd")
         torch.cuda.synchronize()
         assert _rel(dxq.view(n, 64, 512), xq.grad) < 1e-6
@@ -556,7 +557,8 @@ def test_c_training_blocks_match_the_modules():
     saved = torch.empty(sb, dtype=torch.uint8, device="cuda")
     y = torch.empty(rows, 512, device="cuda")
     _lib.check(L.ait_ffn_fwd_train(_lib.dev_ptr(x.detach().reshape(-1, 512)), rows, ctypes.byref(W.dec_ffn), 0.1, seed,
-                                   ctypes.c_void_p(saved.data_ptr()), sb, _lib.dev_ptr(y), None), "ait_ffn_fwd_train")
+                                   ctypes.c_void_p(saved.data_ptr()), sb, _lib.dev_ptr(y), _lib.launch_ctx(), None),
+               "ait_ffn_fwd_train")
     torch.cuda.synchronize()
     assert torch.equal(y.view(n, 64, 512), y_ref.detach())
     G, bufs = grads_struct(mod, _lib.FfnGrads, [("w1", "w_1.weight"), ("b1", "w_1.bias"), ("w2", "w_2.weight"),
@@ -567,7 +569,8 @@ def test_c_training_blocks_match_the_modules():
     dx = torch.empty(rows, 512, device="cuda")
     _lib.check(L.ait_ffn_bwd(_lib.dev_ptr(cot.reshape(-1, 512)), _lib.dev_ptr(x.detach().reshape(-1, 512)), rows,
                              ctypes.byref(W.dec_ffn), 0.1, seed, ctypes.c_void_p(saved.data_ptr()), sb,
-                             ctypes.c_void_p(ws.data_ptr()), wb, _lib.dev_ptr(dx), ctypes.byref(G), None), "ait_ffn_bwd")
+                             ctypes.c_void_p(ws.data_ptr()), wb, _lib.dev_ptr(dx), ctypes.byref(G), _lib.launch_ctx(), None),
+               "ait_ffn_bwd")
     torch.cuda.synchronize()
     assert _rel(dx.view(n, 64, 512), x.grad) < 1e-6
     for field, pname in (("w1", "w_1.weight"), ("b1", "w_1.bias"), ("w2", "w_2.weight"), ("b2", "w_2.bias"),
@@ -576,9 +579,9 @@ def test_c_training_blocks_match_the_modules():
     # argument checking: a saved buffer that is too small, a NULL gradient struct, a bad rate
     assert L.ait_ffn_bwd(_lib.dev_ptr(cot.reshape(-1, 512)), _lib.dev_ptr(x.detach().reshape(-1, 512)), rows,
                          ctypes.byref(W.dec_ffn), 0.1, seed, ctypes.c_void_p(saved.data_ptr()), 64,
-                         ctypes.c_void_p(ws.data_ptr()), wb, _lib.dev_ptr(dx), ctypes.byref(G), None) == -2
+                         ctypes.c_void_p(ws.data_ptr()), wb, _lib.dev_ptr(dx), ctypes.byref(G), None, None) == -2
     assert L.ait_ffn_fwd_train(_lib.dev_ptr(x.detach().reshape(-1, 512)), rows, ctypes.byref(W.dec_ffn), 1.5, seed,
-                               ctypes.c_void_p(saved.data_ptr()), sb, _lib.dev_ptr(y), None) == -1
+                               ctypes.c_void_p(saved.data_ptr()), sb, _lib.dev_ptr(y), None, None) == -1
     assert L.ait_dropout_seed(7, 3) == L.ait_dropout_seed(7, 3) != L.ait_dropout_seed(7, 4)
     del keep
 

@@ -330,27 +330,95 @@ def test_batched_gemm_layouts_and_autograd():
 
 
 def test_gemm_whole_tile_mode_without_scratch():
-    """AIT_GEMM_STREAMK=0: static work lists, whole tiles only, and the library allocates nothing -- same results
-    (the switch is read once per process, hence the subprocess)."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import torch\n"
-        "from ait_amd import ops, _lib\n"
-        "torch.manual_seed(3)\n"
-        "for M, N, K in ((19200, 512, 2048), (76800, 1536, 512), (33000, 512, 64)):\n"
-        "    a, w = torch.randn(M, K, device='cuda'), torch.randn(N, K, device='cuda')\n"
-        "    c = ops.gemm(a, w, trans_b=True)\n"
-        "    want = a.double() @ w.double().t()\n"
-        "    bound = 6e-7 * (a.double().abs() @ w.double().abs().t()) + 1e-6\n"
-        "    assert bool(((c.double() - want).abs() <= bound).all()), (M, N, K)\n"
-        "assert _lib.lib().ait_gemm_workspace_release() == 0\n"
-        "print('ok')\n")
-    env = dict(os.environ, AIT_GEMM_STREAMK="0")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    """No scheduler workspace in the launch context (ait_launch_ctx.sched_ws == NULL): static work lists, whole
+    tiles only -- the same products within the fp32 bound, and the library touches no memory but its operands."""
+    from ait_amd import _lib, ops
+    torch.manual_seed(3)
+    saved = _lib.USE_SCHED_WS
+    try:
+        for M, N, K in ((19200, 512, 2048), (76800, 1536, 512), (33000, 512, 64)):
+            a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+            _lib.USE_SCHED_WS = False
+            c0 = ops.gemm(a, w, trans_b=True)
+            _lib.USE_SCHED_WS = True
+            c1 = ops.gemm(a, w, trans_b=True)
+            want = a.double() @ w.double().t()
+            bound = 6e-7 * (a.double().abs() @ w.double().abs().t()) + 1e-6
+            for c in (c0, c1):
+                assert bool(((c.double() - want).abs() <= bound).all()), (M, N, K)
+    finally:
+        _lib.USE_SCHED_WS = saved
+
+
+def test_gemm_scheduler_workspace_contract():
+    """include/ait_hip.h, ait_launch_ctx: the scheduler scratch is the CALLER's -- sized by
+    ait_gemm_workspace_bytes(), prepared once by ait_gemm_workspace_init(), reusable by stream-ordered launches
+    (the control words are self-cleaning: a second launch on the same workspace gives the same bits), and a
+    workspace that is too small is refused with AIT_EWORKSPACE, never silently ignored."""
+    import ctypes
+    from ait_amd import _lib
+    L = _lib.lib()
+    nbytes = int(L.ait_gemm_workspace_bytes())
+    assert nbytes > 16384
+    M, N, K = 19200, 512, 2048                 # 300 tiles of 256x128: a stream-K launch
+    torch.manual_seed(11)
+    a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    ws.fill_(0xAB)                             # (a fresh allocation holds anything)
+    st = _lib.cur_stream(a.device)
+    assert L.ait_gemm_workspace_init(ctypes.c_void_p(ws.data_ptr()), nbytes, st) == 0
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def run(ctx):
+        out = torch.empty(M, N, device="cuda")
+        rc = L.ait_gemm_f32(0, 1, M, N, K, 1.0, p(a), K, p(w), K, p(out), N, None, None, 0, 1, 0, 0,
+                            None if ctx is None else ctypes.byref(ctx), st)
+        return rc, out
+
+    ctx = _lib.LaunchCtx()
+    ctx.sched_ws, ctx.sched_ws_bytes = ws.data_ptr(), nbytes
+    rc, c1 = run(ctx)
+    assert rc == 0
+    rc, c2 = run(ctx)
+    assert rc == 0 and torch.equal(c1, c2)
+    want = a.double() @ w.double().t()
+    assert bool(((c1.double() - want).abs() <= 6e-7 * (a.double().abs() @ w.double().abs().t()) + 1e-6).all())
+    rc, c0 = run(None)                          # no context at all: legal
+    assert rc == 0 and bool(((c0.double() - want).abs() <= 6e-7 * (a.double().abs() @ w.double().abs().t()) + 1e-6).all())
+    small = _lib.LaunchCtx()
+    small.sched_ws, small.sched_ws_bytes = ws.data_ptr(), 1 << 20
+    rc, _ = run(small)
+    assert rc == -2
+    assert L.ait_gemm_workspace_init(None, nbytes, st) == -1
+
+
+def test_gemm_stream_k_inside_graph_capture():
+    """A stream-K-sized product launched inside hipGraph capture: nothing in the launch path allocates,
+    memsets synchronously or synchronises (the scheduler scratch was the caller's before the capture began), and
+    the replayed graph reproduces the eager result bit for bit."""
+    from ait_amd import _lib, ops
+    M, N, K = 19200, 512, 2048
+    torch.manual_seed(12)
+    a, w = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+    out = torch.empty(M, N, device="cuda")
+    eager = ops.gemm(a, w, trans_b=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.gemm(a, w, trans_b=True, out=out)            # warm-up on the capture stream: its workspace now exists
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    out.zero_()
+    with torch.cuda.graph(g, stream=side):
+        ops.gemm(a, w, trans_b=True, out=out)
+    out.zero_()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    del g
+    _lib.release_sched_workspaces()
 
 
 @pytest.mark.parametrize("M,N,K", [(76800, 2048, 512), (19200, 512, 2048), (300, 200, 64), (33002, 520, 64)])
@@ -369,7 +437,8 @@ def test_gemm_column_sums_in_the_epilogue(M, N, K):
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     with torch.cuda.device(a.device):
         rc = _lib.lib().ait_gemm_f32(0, 0, M, N, K, 1.0, p(a), K, p(w), N, p(out), N, p(cs), p(act),
-                                     _lib.GEMM_MASK_POS | _lib.GEMM_COLSUM, 1, 0, 0, _lib.cur_stream(a.device))
+                                     _lib.GEMM_MASK_POS | _lib.GEMM_COLSUM, 1, 0, 0, _lib.launch_ctx(a.device),
+                                     _lib.cur_stream(a.device))
     assert rc == 0
     want = (a.double() @ w.double()) * (act > 0)
     assert bool(((out.double() - want).abs() <= _abs_bound(a, w, False, False)).all())
@@ -378,7 +447,7 @@ def test_gemm_column_sums_in_the_epilogue(M, N, K):
     # a second call ADDS
     with torch.cuda.device(a.device):
         rc = _lib.lib().ait_gemm_f32(0, 0, M, N, K, 1.0, p(a), K, p(w), N, p(out), N, p(cs), None,
-                                     _lib.GEMM_COLSUM, 1, 0, 0, _lib.cur_stream(a.device))
+                                     _lib.GEMM_COLSUM, 1, 0, 0, _lib.launch_ctx(a.device), _lib.cur_stream(a.device))
     assert rc == 0
     ref2 = ref + (a.double() @ w.double()).sum(0)
     assert float((cs.double() - ref2).abs().max()) <= 1e-5 * float((a.double().abs() @ w.double().abs()).sum(0).max()) + 1e-4

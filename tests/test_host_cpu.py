@@ -80,3 +80,38 @@ def test_samplers_index_parity_on_cpu_tensors(golden):
             assert np.array_equal(wi.numpy(), g["ptl%d_w_in" % P])
     finally:
         cfg.TRAIN.BATCH_SIZE = saved
+
+
+def test_anchor_target_inside_set_follows_the_image_size():
+    """anchor_target_layer.py:84-88 recomputes the inside-image anchor set from im_info on every call, and about 16
+    image widths share one feature width: one layer object fed two image sizes that map to the same (H, W) must
+    label each with ITS inside set -- also when the host's prediction of the size (im_hw_hint) is wrong, and the
+    result must equal a fresh layer's."""
+    from oracle import cases
+    from ait_amd.rpn import _AnchorTargetLayer
+    prob, _, _ = cases.rpn_case()
+    H, W = prob.shape[2], prob.shape[3]
+    gt, nb = torch.from_numpy(cases.gt_case()), torch.tensor([3, 3])
+    score = torch.from_numpy(prob)
+    sizes = [(16 * H - 1, 16 * W - 1), (16 * H - 9, 16 * W - 13), (16 * H - 1, 16 * W - 1)]
+
+    def run(layer, hw, hint):
+        np.random.seed(3)
+        info = torch.tensor([[hw[0], hw[1], 1.0]] * gt.size(0))
+        if hint is not None:
+            layer.begin(gt, info, H, W, im_hw_hint=hint)
+        return [t.clone() for t in layer((score, gt, info, nb))]
+
+    shared = _AnchorTargetLayer(16, [8, 16, 32], [0.5, 1, 2])
+    outs = []
+    for i, hw in enumerate(sizes):
+        fresh = run(_AnchorTargetLayer(16, [8, 16, 32], [0.5, 1, 2]), hw, None)
+        # the shared layer: no hint, the right hint, a WRONG hint (the previous image's size)
+        for hint in (None, hw, sizes[i - 1]):
+            got = run(shared, hw, hint)
+            for a, b in zip(got, fresh):
+                assert torch.equal(a, b), "stale inside-anchor set for image size %r (hint %r)" % (hw, hint)
+        outs.append(fresh)
+    # the two sizes really differ in their border anchors (otherwise the test pins nothing)
+    assert not torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][0], outs[2][0])

@@ -46,6 +46,26 @@ def wrap(model, local_rank, bucket_mb=25):
                static_graph=True, broadcast_buffers=False)
 
 
+def collective_description(ddp):
+    """what the gradient exchange of this run is, for the bench line: backend, bucket size, bucket count (DDP's
+    reducer rebuilds its buckets in gradient-arrival order after the first iteration) and the RCCL algorithm /
+    protocol the environment pins, if any"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return "none"
+    desc = "DDP gradient all-reduce (sum / world), backend %s" % dist.get_backend()
+    if dist.get_backend() == "nccl":
+        desc += " = RCCL over xGMI"
+    try:
+        n_buckets = len(ddp.reducer._get_zeros_like_grad_buckets())
+        desc += ", %d buckets" % n_buckets
+    except Exception:
+        pass
+    desc += ", bucket cap %d MB, overlapped with backward" % int(getattr(ddp, "bucket_bytes_cap", 25 << 20) >> 20)
+    algo, proto = os.environ.get("NCCL_ALGO"), os.environ.get("NCCL_PROTO")
+    desc += ", NCCL_ALGO=%s NCCL_PROTO=%s" % (algo or "default (RCCL tuner)", proto or "default")
+    return desc
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

@@ -75,12 +75,33 @@ def synth_batch(bs, seed, device, im_hw=(600, 1000), q=128, max_gt=20, n_gt=3):
     return [t.to(device) for t in (im, qr, info, gt, nb)]
 
 
-def build_model(P, device):
+# BASELINE.json configs the driver's command can select (bs pairs PER GPU, P proposals):
+#   cfg2 (default, the headline)  ResNet50 VOC variant, 9 anchors, MAX_NUM_GT_BOXES 20, 4 pairs x 300 proposals
+#   cfg3 / cfg4                   ResNet50 COCO variant (non-local co-attention, trainval_net_coco.py:34), 12 anchors
+#                                 (ANCHOR_SCALES [4,8,16,32], trainval_net_coco.py:196-204), 50 gt boxes, 8 pairs x 300;
+#                                 cfg3 = 2 GPUs (global batch 16), cfg4 = 8 GPUs (global batch 64): --gpus decides
+#   cfg5                          ResNet101, COCO variant, 8 pairs x 512 proposals, bf16 AIT matmuls
+CONFIGS = {
+    "cfg2": dict(variant="voc", layers=50, bs=4, proposals=300, dtype="f32",
+                 workload="ResNet50 VOC seen-classes, %(P)d proposals, bs=%(bs)d per GPU, fwd+bwd+SGD step (BASELINE.json configs[1])"),
+    "cfg3": dict(variant="coco", layers=50, bs=8, proposals=300, dtype="f32",
+                 workload="ResNet50 COCO --g 1, %(P)d proposals, bs=%(bs)d per GPU, fwd+bwd+SGD step (BASELINE.json configs[2]: bs=16 on 2 GPUs)"),
+    "cfg4": dict(variant="coco", layers=50, bs=8, proposals=300, dtype="f32",
+                 workload="ResNet50 COCO --g 0, 1000x600 targets, %(P)d proposals, bs=%(bs)d per GPU, fwd+bwd+SGD step (BASELINE.json configs[3]: bs=64 on 8 GPUs)"),
+    "cfg5": dict(variant="coco", layers=101, bs=8, proposals=512, dtype="bf16",
+                 workload="ResNet101 COCO bf16, %(P)d proposals, bs=%(bs)d per GPU, fwd+bwd+SGD step (BASELINE.json configs[4])"),
+}
+
+
+def build_model(P, device, variant="voc", layers=50):
     from ait_amd.config import cfg_from_list
-    from ait_amd.faster_rcnn import resnet
+    from ait_amd.faster_rcnn import resnet, resnet_coco
     cfg_from_list(['TRAIN.BATCH_SIZE', P])      # P RoIs per image reach RoIAlign / AIT
+    if variant == "coco":                       # trainval_net_coco.py:196-204
+        cfg_from_list(['ANCHOR_SCALES', [4, 8, 16, 32], 'MAX_NUM_GT_BOXES', 50])
     torch.manual_seed(1234)                     # identical initial weights on every rank
-    m = resnet(('__background__', 'fg'), 50, pretrained=False, class_agnostic=True, num_K=3)
+    cls = resnet_coco if variant == "coco" else resnet
+    m = cls(('__background__', 'fg'), layers, pretrained=False, class_agnostic=True, num_K=3)
     m.create_architecture()
     return m.to(device).train()
 
@@ -181,19 +202,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bs", type=int, default=4, help="pairs per GPU (BASELINE cfg2: 4)")
-    ap.add_argument("--proposals", type=int, default=300)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2",
+                    help="BASELINE.json configuration (cfg2 = configs[1], the headline; cfg3/cfg4 = the COCO-variant "
+                         "8-pairs-per-GPU workload of configs[2]/[3]; cfg5 = configs[4], ResNet101 bf16)")
+    ap.add_argument("--variant", choices=["voc", "coco"], default=None, help="override the configuration's detector variant")
+    ap.add_argument("--bs", type=int, default=None, help="pairs per GPU (override; cfg2: 4, cfg3-5: 8)")
+    ap.add_argument("--proposals", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default="f32",
-                    help="matmul arithmetic of the AIT GEMMs.  f32 (default) is the headline / parity "
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16x3"], default=None,
+                    help="matmul arithmetic of the AIT GEMMs.  f32 is the headline / parity "
                          "configuration; bf16 is the BASELINE cfg-5 arithmetic (operands rounded to bf16, "
                          "fp32 accumulate) and is reported as such, never as the headline number")
     args = ap.parse_args()
+    conf = CONFIGS[args.config]
+    args.variant = args.variant or conf["variant"]
+    args.bs = args.bs or conf["bs"]
+    args.proposals = args.proposals or conf["proposals"]
+    args.dtype = args.dtype or conf["dtype"]
 
     from ait_amd import distributed as D
     from ait_amd import _lib, ops, tuning
     rank, local_rank, world = D.init()
-    tuned = tuning.use_tuned_miopen_db(rank)      # MIOpen solver picks for the torch-side convs
+    # MIOpen solver picks for the torch-side convolutions: the committed find-db holds the cfg2 shapes (bs 4, VOC
+    # variant); any other shape would start an exhaustive search (minutes), so those run MIOpen's immediate mode
+    tuned = tuning.use_tuned_miopen_db(rank) if (args.config == "cfg2" and args.bs == 4 and args.variant == "voc") else False
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
@@ -203,11 +235,11 @@ def main():
     torch.cuda.set_device(device)
 
     ops.set_matmul_dtype(args.dtype)
-    model = build_model(args.proposals, device)
+    model = build_model(args.proposals, device, args.variant, conf["layers"])
     opt = make_optimizer(model)
     ddp = D.wrap(model, local_rank)
     np.random.seed(3 + rank)                     # reference RNG_SEED, one stream per rank
-    batch = synth_batch(args.bs, 1000 + rank, device)
+    batch = synth_batch(args.bs, 1000 + rank, device, max_gt=50 if args.variant == "coco" else 20)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -277,11 +309,13 @@ def main():
         "dtype": {"f32": "f32", "bf16": "bf16 (AIT GEMM operands; fp32 accumulate, fp32 elsewhere)",
                   "bf16x3": "f32 emulated as 3 bf16 MFMAs per product (experimental; fp32 accumulate)"}[args.dtype],
         "data": "synthetic",
-        "config": {"workload": "ResNet50 VOC seen-classes, %d proposals, bs=%d per GPU, "
-                               "fwd+bwd+SGD step (BASELINE.json configs[1])" % (args.proposals, args.bs),
-                   "variant": "voc (MultiHeadAttention co-attention, 9 anchors)",
+        "config": {"workload": conf["workload"] % {"P": args.proposals, "bs": args.bs},
+                   "name": args.config,
+                   "variant": "voc (MultiHeadAttention co-attention, 9 anchors, 20 gt boxes)" if args.variant == "voc"
+                              else "coco (non-local co-attention, 12 anchors, 50 gt boxes)",
+                   "backbone": "ResNet%d" % conf["layers"],
                    "pairs_per_gpu": args.bs, "global_batch": world * args.bs,
-                   "collective": "none" if world == 1 else "DDP gradient all-reduce over RCCL (nccl), 25 MB buckets",
+                   "collective": "none" if world == 1 else D.collective_description(ddp),
                    "proposals": args.proposals, "target": "600x1000", "query": "128x128",
                    "parallelism": "dp%d" % world, "miopen_find_db": bool(tuned)},
         "roofline": {"bound": "mfma",
@@ -317,6 +351,7 @@ def main():
             print("gemm M=%6d N=%5d K=%6d ta=%d tb=%d splits=%2d : %2d/step %8.1f us  %6.1f TF/s  %5.2f ms/step"
                   % (k + (n // args.steps, 1e3 * ms / n, fl / (ms / n) / 1e9, ms / args.steps)), file=sys.stderr)
     if world == 1 and not args.no_cpu_baseline:
+        # (the CPU port is timed on the headline workload's pair: VOC variant, ResNet50)
         line["cpu_baseline"] = cpu_baseline(args.proposals)
     print(json.dumps(line), flush=True)
 

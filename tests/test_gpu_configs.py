@@ -178,3 +178,48 @@ def test_cfg5_bf16_logits_vs_fp32_oracle_at_fixture_size():
         assert 1e-6 < rel <= 2e-2, rel
         assert float((got16[1].double().cpu() - want[1].double()).abs().max()) <= 5e-3
         assert float((got32[1].double().cpu() - want[1].double()).abs().max()) <= 1e-5
+
+
+def test_cfg2_full_size_ait_output_vs_oracle():
+    """BASELINE cfg2 size on the AIT itself: 4 pairs x 300 proposals = 1200 sequences through the product's
+    training entry point (dropout rates forced to 0, the rate parity is defined at) AND its inference entry point,
+    against the fp32 CPU oracle run ONCE on the host for one whole pair (the 300 proposals of pair 2: sequences
+    are independent) -- a VALUE comparison at the headline size, every element of that pair's
+    [300, 1024, 8, 8] output, at the AIT tolerance (1e-4 relative + 2e-5 absolute)."""
+    from oracle import ait_ref
+    from oracle.digest import seeded
+    from ait_amd import ops
+    from ait_amd.system import Transformer
+    bs, P = 4, 300
+    sd = ait_ref.make_ait_state_dict(seed=31)
+    t = Transformer(d_k=64, d_v=64, d_model=512, d_word_vec=512, d_inner=2048, n_position=64, n_layers=1, n_head=8,
+                    dropout=0.1)
+    t.load_state_dict(sd)
+    t = t.cuda()
+    xp = torch.from_numpy(seeded(311, (bs * P, 1024, 7, 7)))
+    xq = torch.from_numpy(seeded(312, (bs, 1024, 8, 8)))
+    ops.reset_fallbacks()
+    t.eval()
+    with torch.no_grad():
+        y_eval = t(x_props=xp.cuda(), x_query=xq.cuda())
+    t.train()
+    for mod in t.modules():
+        if hasattr(mod, "p") and isinstance(mod.p, float):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    y_train = t(x_props=xp.cuda().requires_grad_(True), x_query=xq.cuda())
+    assert ops.fallback_count() == 0
+    assert tuple(y_train.shape) == (bs * P, 1024, 8, 8)
+    pair = 2
+    with torch.no_grad():
+        want = ait_ref.transformer_forward(sd, xp[pair * P:(pair + 1) * P], xq[pair:pair + 1])
+    for name, y in (("eval", y_eval), ("train", y_train.detach())):
+        got = y[pair * P:(pair + 1) * P].cpu()
+        err = (got - want).abs()
+        assert bool((err <= 2e-5 + 1e-4 * want.abs()).all()), (name, float(err.max()))
+    # and the other pairs are the same function of their own inputs: batch invariance, bit for bit
+    with torch.no_grad():
+        t.eval()
+        y1 = t(x_props=xp[:P].cuda(), x_query=xq[:1].cuda())
+    assert torch.equal(y1, y_eval[:P])

@@ -123,3 +123,18 @@ def test_detector_coco_variant(golden):
     np.testing.assert_allclose(out[0].numpy(), g["train_rois"], rtol=0, atol=1e-3)
     assert np.array_equal(out[8].numpy(), g["train_labels"])
     np.testing.assert_allclose(np.array([float(x) for x in out[3:8]]), g["train_losses"], rtol=1e-4, atol=1e-6)
+
+
+def test_oracle_postprocessing_vs_reference_golden(golden):
+    """pins oracle/detector_ref.postprocess_detections (the checker of the eval post-processing, test_net_coco.py:
+    381-449) on golden g14 = the imported reference's own functions in the driver's call order"""
+    from oracle import gen_golden_post as G
+    g = golden("g14_postprocess")
+    for name, case in (("a", G.case_a), ("b", G.case_b)):
+        rois, prob, bbox, info, thresh, mpi = case()
+        got = D.postprocess_detections(D.default_config(), rois, prob, bbox, info, float(info[0, 2]),
+                                       nms_thr=float(g["nms_thr"]), thresh=thresh, max_per_image=mpi).numpy()
+        want = g[name + "_dets"]
+        assert got.shape == want.shape
+        assert np.array_equal(got[:, 4], want[:, 4])
+        np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=1e-6, atol=1e-4)

@@ -218,8 +218,9 @@ def test_cfg2_full_size_ait_output_vs_oracle():
         got = y[pair * P:(pair + 1) * P].cpu()
         err = (got - want).abs()
         assert bool((err <= 2e-5 + 1e-4 * want.abs()).all()), (name, float(err.max()))
-    # and the other pairs are the same function of their own inputs: batch invariance, bit for bit
+    # and the other pairs are the same function of their own inputs: batch invariance (to rounding: the work list of
+    # a product depends on its row count, and a tile cut between workgroups adds its partial sums in another order)
     with torch.no_grad():
         t.eval()
         y1 = t(x_props=xp[:P].cuda(), x_query=xq[:1].cuda())
-    assert torch.equal(y1, y_eval[:P])
+    assert float((y1 - y_eval[:P]).abs().max()) <= 1e-5 * float(y1.abs().max()) + 1e-6

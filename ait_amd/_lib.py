@@ -90,6 +90,10 @@ SIGNATURES = {
     "ait_transformer_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "ait_transformer_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp,
                                  _vp, _vp, _vp]),
+    "ait_tail_saved_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ait_tail_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "ait_tail_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ait_tail_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "ait_sh_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ait_sh_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ait_attn_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp,
@@ -136,6 +140,32 @@ class FfnWeights(ctypes.Structure):
 class ConvGeom(ctypes.Structure):
     """ait_conv_geom."""
     _fields_ = [(n, ctypes.c_int) for n in ("n", "in_h", "in_w", "out_h", "out_w", "kh", "kw", "stride", "pad", "groups")]
+
+
+class SkWeights(ctypes.Structure):
+    """ait_sk_weights (and ait_sk_grads: the same members)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("w1", "b1", "w3", "b3")]
+
+
+class BottleneckWeights(ctypes.Structure):
+    """ait_bottleneck_weights."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("conv1", "conv2", "conv3", "down", "bn1_scale", "bn1_shift", "bn2_scale",
+                                               "bn2_shift", "bn3_scale", "bn3_shift", "bnd_scale", "bnd_shift")]
+
+
+class BottleneckGrads(ctypes.Structure):
+    """ait_bottleneck_grads."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("conv1", "conv2", "conv3", "down")]
+
+
+class TailWeights(ctypes.Structure):
+    """ait_tail_weights."""
+    _fields_ = [("sk_props", SkWeights), ("sk_query", SkWeights), ("block", BottleneckWeights * 4)]
+
+
+class TailGrads(ctypes.Structure):
+    """ait_tail_grads."""
+    _fields_ = [("sk_props", SkWeights), ("sk_query", SkWeights), ("block", BottleneckGrads * 4)]
 
 
 class TransformerWeights(ctypes.Structure):

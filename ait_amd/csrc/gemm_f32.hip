@@ -33,6 +33,7 @@
 // tiny output): partial tiles are combined with one fp32 atomic per element, issued as whole
 // 128-B row segments straight from the accumulator layout.
 #include "gemm_f32_impl.h"
+#include "gemm_internal.h"
 
 namespace {
 using namespace ait_gemm;
@@ -54,15 +55,18 @@ using TileN64 = Cfg<256, 64, 16, 4, 1, 2, MODE_DB>;
 using Tile64 = Cfg<64, 64, 16, 2, 2, 2, MODE_DB>;
 }  // namespace
 
-AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha,
-                         const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                         const float* bias, const float* residual, int flags, int split_k,
-                         int c_colblk, long long c_batch_stride, const ait_launch_ctx* ctx, void* stream) {
+// The product entry point with everything the library's own composites may ask for (csrc/gemm_internal.h): `gate`
+// (same addressing as C; with `residual`: C = (alpha A.B + bias + residual) zeroed where gate <= 0 -- the input
+// gradient of a residual block's ReLU output, formed in the epilogue of the product that completes it).
+int ait_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                    int ldb, float* C, int ldc, const float* bias, const float* residual, const float* gate, int flags,
+                    int split_k, int c_colblk, long long c_batch_stride, const ait_launch_ctx* ctx, void* stream) {
   if (M == 0 || N == 0) return (M < 0 || N < 0 || K < 0) ? AIT_EINVAL : AIT_OK;
   GemmArgs g;
   const int rc = make_args(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
                            flags, split_k, c_colblk, c_batch_stride, Tile128::BK, g);
   if (rc != AIT_OK) return rc;
+  g.gate = gate;
   const SchedWs ws = sched_ws_of(ctx);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K, ait_stream(stream), M, N, K, trans_a, trans_b,
                       g.splits);
@@ -72,9 +76,10 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   if (N <= 64 && (long long)((M + 255) / 256) * g.splits >= 128) return dispatch<TileN64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   const bool direct = K > 0 && (K % 16 == 0) && (!trans_a || (M % 4 == 0 && M >= 4)) && (trans_b || (N % 4 == 0 && N >= 4));
   // with the stream-K work list (a scheduler workspace) the persistent tile also serves products of a few hundred
-  // tiles (their slabs are spread over all workgroups): layer4-sized and co-attention-sized products
-  const bool few_tiles_sk = direct && g.splits == 1 && !(flags & AIT_GEMM_ATOMIC) && K >= 512 && tiles256 >= 96 &&
-                            ws.p != nullptr;
+  // tiles (their slabs are spread over all workgroups): layer4-sized and co-attention-sized products; split-K
+  // launches cut their last round without any scratch
+  const bool few_tiles_sk = direct && K >= 512 && tiles256 >= 96 &&
+                            ((g.splits == 1 && !(flags & AIT_GEMM_ATOMIC) && ws.p != nullptr) || (flags & AIT_GEMM_ATOMIC));
   if (M >= 512 && (tiles256 >= 512 || few_tiles_sk)) {
     if (direct) return dispatch<Tile256D>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);
     return dispatch<Tile256>(g, !trans_a, trans_b != 0, ait_stream(stream));
@@ -82,6 +87,14 @@ AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float al
   const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * g.splits;
   if (tiles128 < 128) return dispatch<Tile64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   return dispatch<Tile128>(g, !trans_a, trans_b != 0, ait_stream(stream));
+}
+
+AIT_API int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha,
+                         const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                         const float* bias, const float* residual, int flags, int split_k,
+                         int c_colblk, long long c_batch_stride, const ait_launch_ctx* ctx, void* stream) {
+  return ait_gemm_f32_ex(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual, nullptr, flags, split_k,
+                         c_colblk, c_batch_stride, ctx, stream);
 }
 
 // Scheduler scratch of the persistent kernel (include/ait_hip.h, ait_launch_ctx): sized for the widest product tile
@@ -149,7 +162,17 @@ inline int log2_exact(int v) {
   return s;
 }
 
-struct ConvDims { long long rows; int taps; };
+// ConvGeom with the identity tap map / row map (plain convolutions); the parity-class data gradient overrides them
+inline ConvGeom make_geom(int hw_shift, int w_shift, int src_h, int src_w, int kw, int a, int b, int c, int div_shift,
+                          int seg, long long b_tap_stride, const float* zero, int a_group, int n_group) {
+  ConvGeom m{};
+  m.rows_hw_shift = hw_shift; m.rows_w_shift = w_shift; m.src_h = src_h; m.src_w = src_w; m.kw = kw;
+  m.a = a; m.b = b; m.c = c; m.cx = c; m.div_shift = div_shift; m.seg = seg; m.b_tap_stride = b_tap_stride;
+  m.zero = zero; m.a_group = a_group; m.n_group = n_group;
+  m.wt_y0 = 0; m.wt_x0 = 0; m.wt_step = 1; m.wt_kw = kw;
+  m.rowmap = 0;
+  return m;
+}
 
 inline int check_geom(const ait_conv_geom* q, int cin, int cout) {
   if (!q || q->n < 0 || q->in_h <= 0 || q->in_w <= 0 || q->out_h <= 0 || q->out_w <= 0 || q->kh <= 0 || q->kw <= 0 ||
@@ -173,6 +196,12 @@ int conv_launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
   if (GRP) return launch<T, AK, BKC, EPI_STORE, NoProbe, CONV, GRP>(g, s, ws);      // (grouped: bias only)
   if (g.residual) return launch<T, AK, BKC, EPI_RES, NoProbe, CONV>(g, s, ws);
   return launch<T, AK, BKC, EPI_STORE, NoProbe, CONV>(g, s, ws);
+}
+// one parity class of a stride-2 data gradient (K-outer weights, row-mapped result; "+ residual" with the same map)
+template <class T, bool GRP>
+int parity_launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
+  if (g.residual) return launch<T, true, false, EPI_RES, NoProbe, CONV_A, GRP, true>(g, s, ws);
+  return launch<T, true, false, EPI_STORE, NoProbe, CONV_A, GRP, true>(g, s, ws);
 }
 template <int CONV, bool AK, bool BKC>
 int conv_dispatch(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
@@ -203,11 +232,74 @@ AIT_API int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_
   // group's first channel)
   AIT_TRY_RC(make_args(0, 1, (int)rows, cout, taps * cing, 1.f, x, ldx, w, taps * cing, y, ldy, bias, residual, flags, 1, 0, 0,
                        16, g));
-  g.conv = ConvGeom{hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G};
+  g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), (int)rows, cout,
                       taps * cing, 0, 1, 1);
   return conv_dispatch<CONV_A, true, true>(g, ait_stream(stream), sched_ws_of(ctx));
 }
+
+// Data gradient of a STRIDE-2 convolution as up to four launches, one per parity class (py, px) of the input
+// positions: class rows (2ya + py, 2xa + px) are reached only by the window taps ty = (py + pad) mod 2 (+ 2, + 4 ...),
+// so a 3x3 window has 1 / 2 / 2 / 4 taps per class instead of 9 mostly-zero ones (45 GFLOP executed instead of 181 on
+// the SK block's 3x3 branch), and a 1x1 window has one tap in class (0, 0) and none elsewhere.  A class without
+// taps receives zero -- or keeps `residual` when that is dx itself (accumulating into a gradient in place).
+namespace {
+__global__ void zero_rows_kernel(float* dx, int lddx, int n_cols4, long long rows, ConvGeom cg) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * n_cols4) return;
+  const int r = (int)(i / n_cols4), c4 = (int)(i - (long long)r * n_cols4);
+  reinterpret_cast<float4*>(dx + (size_t)conv_out_row(cg, r) * lddx)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+int conv_bwd_data_stride2(const float* dy, int lddy, const float* w, const ait_conv_geom* q, int cin, int cout,
+                          const float* residual, int flags, float* dx, int lddx, const float* zeros,
+                          const ait_launch_ctx* ctx, void* stream) {
+  const int G = q->groups > 1 ? q->groups : 1, cing = cin / G, coutg = cout / G;
+  const int ch = q->in_h / 2, cw = q->in_w / 2;                 // the class grid
+  const int hw = log2_exact(ch * cw), wsft = log2_exact(cw);
+  const int img_shift = log2_exact(q->in_h * q->in_w), y_shift = log2_exact(2 * q->in_w);
+  if (hw < 0 || wsft < 0 || img_shift < 0 || y_shift < 0) return AIT_EUNSUPPORTED;
+  const long long rows = (long long)q->n * ch * cw;
+  if (rows > 0x7fffffffLL / 4) return AIT_EINVAL;
+  hipStream_t s = ait_stream(stream);
+  const SchedWs ws = sched_ws_of(ctx);
+  for (int py = 0; py < 2; py++)
+    for (int px = 0; px < 2; px++) {
+      const int ty0 = (py + q->pad) & 1, tx0 = (px + q->pad) & 1;
+      const int nty = ty0 < q->kh ? (q->kh - ty0 + 1) / 2 : 0, ntx = tx0 < q->kw ? (q->kw - tx0 + 1) / 2 : 0;
+      ConvGeom cg = make_geom(hw, wsft, q->out_h, q->out_w, ntx > 0 ? ntx : 1, 1, -1, (py + q->pad - ty0) / 2, 0, coutg,
+                              (long long)cing, zeros, G > 1 ? coutg : 0, cing);
+      cg.cx = (px + q->pad - tx0) / 2;
+      cg.wt_y0 = ty0; cg.wt_x0 = tx0; cg.wt_step = 2; cg.wt_kw = q->kw;
+      cg.rowmap = 1; cg.out_img_shift = img_shift; cg.out_y_shift = y_shift; cg.out_x_shift = 1;
+      cg.out_base = py * q->in_w + px;
+      if (nty * ntx == 0) {
+        if (residual == dx && !(flags & AIT_GEMM_MASK_POS)) continue;      // accumulating in place: nothing to add
+        if (residual && !(flags & AIT_GEMM_MASK_POS)) return AIT_EUNSUPPORTED;
+        // (no taps, or a gated zero: zero either way)
+        const long long n4 = rows * (cin / 4);
+        hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dx, lddx, cin / 4, rows, cg);
+        AIT_CHECK_LAUNCH();
+        continue;
+      }
+      GemmArgs g;
+      AIT_TRY_RC(make_args(0, 0, (int)rows, cin, nty * ntx * coutg, 1.f, dy, lddy, w, q->kh * q->kw * cing, dx, lddx, nullptr,
+                           residual, flags, 1, 0, 0, 16, g));
+      // (make_args bounds the PLAIN output extent; the row map reaches rows * 4 positions)
+      if ((unsigned long long)rows * 4ull * (unsigned long long)lddx >= (1ull << 31)) return AIT_EUNSUPPORTED;
+      g.conv = cg;
+      AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cin * nty * ntx * coutg, s, (int)rows, cin,
+                          nty * ntx * coutg, 0, 0, 1);
+      int rc;
+      const long long tiles256 = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+      if (G > 1) rc = parity_launch<Tile256D, true>(g, s, ws);
+      else if (tiles256 >= 512 || (tiles256 >= 96 && g.K >= 512 && ws.p != nullptr)) rc = parity_launch<Tile256D, false>(g, s, ws);
+      else rc = parity_launch<Tile128D, false>(g, s, ws);
+      if (rc != AIT_OK) return rc;
+    }
+  return AIT_OK;
+}
+}  // namespace
 
 AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, const ait_conv_geom* q, int cin, int cout,
                                   const float* residual, int flags, float* dx, int lddx, const float* zeros,
@@ -220,12 +312,15 @@ AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, con
   if (rows > 0x7fffffffLL / 4 || !dy || !w || !dx || !zeros || zeros_floats < (size_t)cout + 144) return AIT_EINVAL;
   if (flags & ~AIT_GEMM_MASK_POS) return AIT_EINVAL;
   const int taps = q->kh * q->kw, G = q->groups > 1 ? q->groups : 1, cing = cin / G, coutg = cout / G;
+  if (q->stride == 2 && !(q->in_h & 1) && !(q->in_w & 1) && log2_exact(q->in_h * q->in_w / 4) >= 0 &&
+      log2_exact(q->in_w / 2) >= 0)
+    return conv_bwd_data_stride2(dy, lddy, w, q, cin, cout, residual, flags, dx, lddx, zeros, ctx, stream);
   GemmArgs g;
   // B is addressed per tap (retap): K-outer rows (t, co) at w + t*cin/G + co*(taps*cin/G)
   AIT_TRY_RC(make_args(0, 0, (int)rows, cin, taps * coutg, 1.f, dy, lddy, w, taps * cing, dx, lddx, nullptr, residual, flags, 1,
                        0, 0, 16, g));
-  g.conv = ConvGeom{hw, ws, q->out_h, q->out_w, q->kw, 1, -1, q->pad, log2_exact(q->stride), coutg, (long long)cing, zeros,
-                    G > 1 ? coutg : 0, cing};
+  g.conv = make_geom(hw, ws, q->out_h, q->out_w, q->kw, 1, -1, q->pad, log2_exact(q->stride), coutg, (long long)cing, zeros,
+                     G > 1 ? coutg : 0, cing);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cin * taps * coutg, ait_stream(stream), (int)rows, cin,
                       taps * coutg, 0, 0, 1);
   return conv_dispatch<CONV_A, true, false>(g, ait_stream(stream), sched_ws_of(ctx));
@@ -244,7 +339,7 @@ AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, i
   GemmArgs g;
   AIT_TRY_RC(make_args(1, 0, cout, taps * cing, (int)rows, 1.f, dy, lddy, x, ldx, dw, taps * cing, nullptr, nullptr,
                        AIT_GEMM_ATOMIC, split_k < 1 ? 1 : split_k, 0, 0, 16, g));
-  g.conv = ConvGeom{hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G};
+  g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), cout, taps * cing,
                       (int)rows, 1, 0, g.splits);
   // (grouped: 128-row tiles, one group of output channels per row tile)

@@ -46,14 +46,30 @@ struct ConvGeom {
   // of them per group (a tile never straddles two), and the gathered operand's channels of that group start
   // a_group floats further per group
   int a_group, n_group;
+  // ---- the data gradient of a STRIDE-2 convolution, one launch per parity class (py, px) of the input positions:
+  // the GEMM rows are the positions (2ya + py, 2xa + px) of ONE class, the taps are the window taps that can reach
+  // that class (1, 2, 2 or 4 of 9 for a 3x3 window), the source position of tap (t'y, t'x) is (ya + c - t'y,
+  // xa + cx - t'x) with per-axis offsets, its weights are those of window tap (wt_y0 + 2 t'y, wt_x0 + 2 t'x), and
+  // the result row r lands on row rowmap(r) of dx.  Nothing is multiplied by a structural zero.
+  int cx;                               // `c` of the x axis (c is the y axis')
+  int wt_y0, wt_x0, wt_step, wt_kw;     // window tap of GEMM tap (t'y, t'x): (wt_y0 + wt_step t'y) * wt_kw + wt_x0 + wt_step t'x
+  int rowmap;                           // != 0: C / residual row of GEMM row r = (img, y, x) is
+  int out_img_shift, out_y_shift, out_x_shift, out_base;   //   (img << out_img_shift) + (y << out_y_shift) + (x << out_x_shift) + out_base
 };
 enum { CONV_NONE = 0, CONV_A = 1, CONV_B = 2 };
+
+// C / residual row of GEMM row r under the row map of a parity-class data gradient
+__device__ __forceinline__ unsigned conv_out_row(const ConvGeom& c, int r) {
+  const int img = r >> c.rows_hw_shift, rem = r & ((1 << c.rows_hw_shift) - 1);
+  const int y = rem >> c.rows_w_shift, x = rem & ((1 << c.rows_w_shift) - 1);
+  return (unsigned)((img << c.out_img_shift) + (y << c.out_y_shift) + (x << c.out_x_shift) + c.out_base);
+}
 
 __device__ __forceinline__ int conv_src_row(const ConvGeom& c, int r, int tap) {
   const int img = r >> c.rows_hw_shift, rem = r & ((1 << c.rows_hw_shift) - 1);
   const int y = rem >> c.rows_w_shift, x = rem & ((1 << c.rows_w_shift) - 1);
   const int ty = tap / c.kw, tx = tap - ty * c.kw;
-  const int ny = y * c.a + c.c + ty * c.b, nx = x * c.a + c.c + tx * c.b;
+  const int ny = y * c.a + c.c + ty * c.b, nx = x * c.a + c.cx + tx * c.b;
   const int sy = ny >> c.div_shift, sx = nx >> c.div_shift;
   const bool ok = ny >= 0 && nx >= 0 && ((ny | nx) & ((1 << c.div_shift) - 1)) == 0 && sy < c.src_h && sx < c.src_w;
   return ok ? (img * c.src_h + sy) * c.src_w + sx : -1;
@@ -65,6 +81,8 @@ struct GemmArgs {
   float* C;
   const float* bias;      // [N] (or [M] with AIT_GEMM_BIAS_ROW)
   const float* residual;  // same addressing as C
+  const float* gate;      // EPI_RES only, same addressing as C: the value is zeroed where gate <= 0 (after "+ residual");
+                          // NULL = no gate.  The ReLU-backward mask of the layer whose input gradient this product forms
   int M, N, K;
   int lda, ldb, ldc;
   int c_colblk;           // 0: plain row-major C.  >0: C(i,j) at (j/colblk)*c_batch + i*ldc + j%colblk
@@ -78,7 +96,8 @@ struct GemmArgs {
   int batch, batch2;           // register-staged kernels: independent problems along gridDim.y (x gridDim.z) ...
   long long sA, sB, sC;        // ... whose operands are this many floats apart
   long long sA2, sB2, sC2;     // (second batch level: the heads of an attention product)
-  float* sk_ws;                // stream-K: one BM x BN partial tile per workgroup; NULL = whole tiles only
+  int sk_on;                   // stream-K work list for the last round (set by launch())
+  float* sk_ws;                // stream-K: one BM x BN partial tile per workgroup (not needed by EPI_ATOMIC launches)
   unsigned* sk_flags;          // stream-K: one "partial published" word per workgroup (zero between launches)
   unsigned* sched;             // dynamic tile hand-out: per XCD a ticket counter at [xcd*32] and an exit counter at
                                // [xcd*32 + 1] (zero between launches); NULL = static lists (item j, j+W, ...)
@@ -231,7 +250,7 @@ __device__ __forceinline__ float4 fetch_tile(const float* __restrict__ slab, int
 //   forward  y = x W^T   : A = x [M,K] (AK), B = W [N,K] (BKC)
 //   dgrad    dx = dy W   : A = dy [M,K'] (AK), B = W [K',N] (!BKC)
 //   wgrad    dW = dy^T x : A = dy [K',M] (!AK), B = x [K',N] (!BKC)
-enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_AUX = 2, EPI_RES = 3 };
+enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_AUX = 2, EPI_RES = 3, EPI_RESG = 4 /* EPI_RES + gate (GemmArgs::gate) */ };
 
 // C/D layout of the 32x32 MFMA (any input dtype): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // EPI selects the epilogue at compile time (a run-time flag test per element makes hipcc branch
@@ -254,11 +273,16 @@ enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_AUX = 2, EPI_RES = 3 };
 //               of the current one;
 //   EPI_AUX     everything else (accumulate into C, row bias, combinations): loads in uniform-branch
 //               blocks before each half tile's stores (small / rare launches).
-template <int TM, int TN, int EPI>
+template <int TM, int TN, int EPI, bool ROWMAP = false>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& g, int m0, int n0,
                                          int wm, int wn, int li, int lk) {
   const bool relu = (g.flags & AIT_GEMM_RELU) != 0;
   const unsigned ldc = (unsigned)g.ldc;
+  // element offset of the first column of GEMM row `row` (ROWMAP: the parity-class row map of ConvGeom)
+  auto roff = [&](int row) -> unsigned {
+    if constexpr (ROWMAP) return conv_out_row(g.conv, row) * ldc;
+    else return (unsigned)row * ldc;
+  };
   const bool interior = (m0 + wm + TM * 32 <= g.M) && (n0 + wn + TN * 32 <= g.N);   // wave-uniform
   // row r of an MFMA tile sits (r&3) + 8*(r>>2) rows below its first row
 #define AIT_ROW(r) (((r) & 3) + 8 * ((r) >> 2))
@@ -292,36 +316,49 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
     }
   };
 
-  if (EPI == EPI_RES) {
+  if (EPI == EPI_RES || EPI == EPI_RESG) {
     // ---- residual add / ReLU-backward gate, software-pipelined over the TM*TN MFMA tiles: the 16 loads
     // of tile i+1 are issued BEFORE the 16 stores of tile i, so the wait for them is a counted vmcnt that
     // leaves those stores in flight, and a tile costs one load round trip (a quarter-tile pipeline, four
     // round trips per MFMA tile, measured 13 % slower on the ReLU-gated dgrad shape)
     const bool mask_pos = (g.flags & AIT_GEMM_MASK_POS) != 0;
+    constexpr bool gated = EPI == EPI_RESG;        // (its own instantiation: 32 more registers in flight)
     constexpr int NT_ = TM * TN;
-    float x[16], xn[16];
+    float x[16], xn[16], gt[gated ? 16 : 1], gn[gated ? 16 : 1];
     auto row_of = [&](int i, int r) { return m0 + wm + (i / TN) * 32 + 4 * lk + AIT_ROW(r); };
 #pragma unroll
-    for (int r = 0; r < 16; r++) x[r] = g.residual[cb[0] + (unsigned)min(row_of(0, r), g.M - 1) * ldc];
+    for (int r = 0; r < 16; r++) {
+      const unsigned o = cb[0] + roff(min(row_of(0, r), g.M - 1));
+      x[r] = g.residual[o];
+      if constexpr (gated) gt[r] = g.gate[o];
+    }
 #pragma unroll
     for (int i = 0; i < NT_; i++) {
       const int a = i / TN, b = i % TN;
       if (i + 1 < NT_) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) xn[r] = g.residual[cb[(i + 1) % TN] + (unsigned)min(row_of(i + 1, r), g.M - 1) * ldc];
+        for (int r = 0; r < 16; r++) {
+          const unsigned o = cb[(i + 1) % TN] + roff(min(row_of(i + 1, r), g.M - 1));
+          xn[r] = g.residual[o];
+          if constexpr (gated) gn[r] = g.gate[o];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         float v = g.alpha * acc[a][b][r] + bcol[b];
         v = mask_pos ? (x[r] > 0.f ? v : 0.f) : v + x[r];
+        if constexpr (gated) v = gt[r] > 0.f ? v : 0.f;
         if (relu) v = fmaxf(v, 0.f);
         const int row = row_of(i, r);
-        if (interior || (cok[b] && row < g.M)) { g.C[cb[b] + (unsigned)row * ldc] = v; cs[b] += v; }
+        if (interior || (cok[b] && row < g.M)) { g.C[cb[b] + roff(row)] = v; cs[b] += v; }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int r = 0; r < 16; r++) x[r] = xn[r];
+      for (int r = 0; r < 16; r++) {
+        x[r] = xn[r];
+        if constexpr (gated) gt[r] = gn[r];
+      }
     }
     flush_colsum();
     return;
@@ -383,7 +420,14 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
 #pragma unroll
             for (int q = 0; q < 8; q++) v[q] = fmaxf(v[q], 0.f);
           }
-          if (interior) {
+          if constexpr (ROWMAP) {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+              if (interior || (cok[b] && rbase + AIT_ROW(h * 8 + q) < g.M)) {
+                g.C[cb[b] + roff(rbase + AIT_ROW(h * 8 + q))] = v[q];
+                cs[b] += v[q];
+              }
+          } else if (interior) {
 #pragma unroll
             for (int q = 0; q < 8; q++) { g.C[obase + (unsigned)AIT_ROW(h * 8 + q) * ldc] = v[q]; cs[b] += v[q]; }
           } else {
@@ -457,7 +501,7 @@ struct WorkMap {
 // slab s+1 before that barrier, so the MFMA stream runs across it -- and across the epilogue of a
 // finished tile, whose stores are issued while the next tile's first slabs are already in LDS.
 // =========================================================================================================
-template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe, int CONV = CONV_NONE, bool GRP = false>
+template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe, int CONV = CONV_NONE, bool GRP = false, bool ROWMAP = false>
 __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const GemmArgs g) {
   static_assert(C::MODE == MODE_DLDS && C::BK == 16 && C::BM % 16 == 0 && C::BN % 16 == 0,
                 "direct-to-LDS path needs 16-float slabs");
@@ -506,8 +550,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   constexpr int SK_MIN = 4;          // slabs per run at least
   int sk_r = 0, sk_total = 0, sk_w = 1, n_sk = 0;
   int skA_tile = 0, skA_kb = 0, skA_ke = 0, skB_ke = 0;
-  const int ns = g.K / BK;
-  if (g.sk_ws != nullptr) {
+  // slabs per item: the whole reduction, or one K-split of it (split-K launches combine with atomics: their pieces
+  // need no hand-off at all -- every piece simply adds its partial tile; launch() enables the list only when all
+  // splits have the same length)
+  const int ns = (g.splits > 1 ? g.k_per_split : g.K) / BK;
+  if (g.sk_on) {
     sk_r = lim % W;
     sk_total = sk_r * ns;
     sk_w = max(1, min(W, sk_total / SK_MIN));
@@ -567,9 +614,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       id += sk_r;
     }
     wmap.decode(g, base + id, BM, BN, m0, n0, kb, ke);
-    if (it < n_sk) {
-      kb = pieceB ? 0 : skA_kb;
-      ke = pieceB ? skB_ke : skA_ke;
+    if (it < n_sk) {                      // a piece: its sub-range of the item's K range
+      ke = kb + (pieceB ? skB_ke : skA_ke);
+      kb = kb + (pieceB ? 0 : skA_kb);
     }
     return true;
   };
@@ -613,10 +660,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       // K-outer weights [co][tap][ci]: rows = output channels (of the tile's group), columns within the tap
       const int col0 = GRP ? l_n0 - grp * g.conv.n_group : l_n0;
       const int cols = GRP ? g.conv.n_group : g.N;
+      // window tap whose weights GEMM tap `tap` multiplies (identity unless this is a parity-class data gradient)
+      const int tty = tap / g.conv.kw, ttx = tap - tty * g.conv.kw;
+      const int wtap = (g.conv.wt_y0 + g.conv.wt_step * tty) * g.conv.wt_kw + g.conv.wt_x0 + g.conv.wt_step * ttx;
 #pragma unroll
       for (int i = 0; i < LB; i++) {
         const int e = (wave + i * NW) * 256 + lane * 4;
-        pb[i] = g.B + tap * g.conv.b_tap_stride + (size_t)(gch + kin + e / BN) * g.ldb + min(col0 + e % BN, cols - 4);
+        pb[i] = g.B + wtap * g.conv.b_tap_stride + (size_t)(gch + kin + e / BN) * g.ldb + min(col0 + e % BN, cols - 4);
       }
     }
   };
@@ -657,7 +707,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   auto issue = [&](int piece, int slot) {
     if (piece < LA) {
       const int q = wave + piece * NW;
-      if (GA % NW == 0 || q < GA) glds16<GRP>(pa[piece], As + slot * SA + q * 256);
+      if (GA % NW == 0 || q < GA) glds16<GRP || ROWMAP || (CONV == CONV_A && !BKC)>(pa[piece], As + slot * SA + q * 256);
     } else {
       const int q = wave + (piece - LA) * NW;
       if (GB % NW == 0 || q < GB) {
@@ -668,9 +718,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           const int tap = l_n0 / g.conv.seg, ch0 = l_n0 - tap * g.conv.seg;
           const int gch = GRP ? (l_m0 / g.conv.n_group) * g.conv.a_group : 0;   // the row tile's group
           const int src = conv_src_row(g.conv, l_k + e / BN, tap);
-          glds16<GRP>((src >= 0 ? g.B + (size_t)src * g.ldb + gch + ch0 : g.conv.zero) + e % BN, Bd + slot * SB + q * 256);
+          glds16<GRP || ROWMAP || (CONV == CONV_A && !BKC)>((src >= 0 ? g.B + (size_t)src * g.ldb + gch + ch0 : g.conv.zero) + e % BN, Bd + slot * SB + q * 256);
         } else {
-          glds16<GRP>(pb[piece - LA], Bd + slot * SB + q * 256);
+          glds16<GRP || ROWMAP || (CONV == CONV_A && !BKC)>(pb[piece - LA], Bd + slot * SB + q * 256);
         }
       }
     }
@@ -834,7 +884,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     }
     if constexpr (Probe::on) { c_loop += __builtin_amdgcn_s_memtime() - c0; n_tile++; }
     bool finish = true;          // this workgroup writes the tile
-    if (item < n_sk && (kbeg != 0 || kend != g.K)) {
+    if (EPI != EPI_ATOMIC && item < n_sk && (kbeg != 0 || kend != g.K)) {
       // Inter-workgroup hand-off in the write-through form: every byte of a partial tile is stored sc1
       // and read with sc1 loads (per-XCD L2s are not coherent), the flag is an agent-scope word.
       if (kend != g.K) {                           // does not end its tile: publish
@@ -890,7 +940,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         }
       }
     }
-    if (finish) epilogue<C::TM, C::TN, EPI>(acc, g, m0, n0, wm, wn, li, lk);
+    if (finish) epilogue<C::TM, C::TN, EPI, ROWMAP>(acc, g, m0, n0, wm, wn, li, lk);
     // (the operand quads are dead across the epilogue -- its address arithmetic needs the registers --
     // and are fetched again from the next tile's first slab, complete in LDS since the last barrier)
     __builtin_amdgcn_sched_barrier(0);
@@ -1139,9 +1189,10 @@ inline int stream_slots(const void* kern) {
   return v;
 }
 
-template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe, int CONV = CONV_NONE, bool GRP = false>
+template <class C, bool AK, bool BKC, int EPI, class Probe = NoProbe, int CONV = CONV_NONE, bool GRP = false, bool ROWMAP = false>
 int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int slots = 0) {
   GemmArgs gl = g;
+  gl.sk_on = 0;
   gl.sk_ws = nullptr;
   gl.sk_flags = nullptr;
   gl.sched = nullptr;
@@ -1150,7 +1201,7 @@ int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int 
   unsigned blocks;
   const void* kern;
   if constexpr (C::MODE == MODE_DLDS) {
-    kern = reinterpret_cast<const void*>(gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV, GRP>);
+    kern = reinterpret_cast<const void*>(gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV, GRP, ROWMAP>);
     if (C::LDS > 64 * 1024 &&
         hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS) != hipSuccess)
       return AIT_ELAUNCH;
@@ -1166,7 +1217,17 @@ int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int 
     // publishing and gathering partial tiles.
     const int wfull = max(1, slots / AIT_NXCD), rem = wmap.chunk % wfull;
     const double last_round = (rem * 2 <= wfull) ? 0.62 : 1.0;
-    const bool sk_pays = (g.K / 16) * (last_round - (double)rem / wfull) > 12.0;
+    const int item_slabs = (g.splits > 1 ? g.k_per_split : g.K) / 16;
+    if (EPI == EPI_ATOMIC) {
+      // split-K launches (weight gradients): a piece of an item just ADDS its partial tile like a whole item does --
+      // no scratch, no hand-off; costs one more atomic epilogue (~4 slab-times) per cut.  Needs equal splits.
+      const bool equal = g.K % 16 == 0 && (g.splits == 1 || (g.k_per_split % 16 == 0 && g.K == g.splits * g.k_per_split));
+      if (equal && rem > 0 && item_slabs * (last_round - (double)rem / wfull) > 6.0) {
+        gl.sk_on = 1;
+        w = wfull;
+      }
+    }
+    const bool sk_pays = item_slabs * (last_round - (double)rem / wfull) > 12.0;
     if (ws.p) {
       if (ws.bytes < kCtlBytes) return AIT_EWORKSPACE;
       // ticket counters for the dynamic hand-out of whole tiles (every launch), partial tiles + flags when this
@@ -1177,6 +1238,7 @@ int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int 
       if (kps >= 128 && klast >= 128) gl.sched = ws.sched();
       if (EPI != EPI_ATOMIC && g.splits == 1 && g.K % 16 == 0 && rem > 0 && sk_pays) {
         if (ws.bytes < kCtlBytes + (size_t)wfull * AIT_NXCD * C::BM * C::BN * sizeof(float)) return AIT_EWORKSPACE;
+        gl.sk_on = 1;
         gl.sk_ws = ws.partials();
         gl.sk_flags = ws.flags();
         w = wfull;
@@ -1191,7 +1253,7 @@ int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int 
       return AIT_ELAUNCH;
   }
   if constexpr (C::MODE == MODE_DLDS)
-    hipLaunchKernelGGL((gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV, GRP>), dim3(blocks), dim3(C::NT), C::LDS, s, gl);
+    hipLaunchKernelGGL((gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV, GRP, ROWMAP>), dim3(blocks), dim3(C::NT), C::LDS, s, gl);
   else
     hipLaunchKernelGGL((gemm_f32_kernel<C, AK, BKC, EPI>), dim3(blocks, g.batch > 1 ? g.batch : 1, g.batch2 > 1 ? g.batch2 : 1),
                        dim3(C::NT), C::LDS, s, g);
@@ -1211,6 +1273,10 @@ template <class C>
 int dispatch(const GemmArgs& g, bool ak, bool bk, hipStream_t s, const SchedWs& ws = SchedWs()) {
   if (g.flags & AIT_GEMM_ATOMIC) return dispatch_layout<C, EPI_ATOMIC>(g, ak, bk, s, ws);
   const bool row_bias = g.bias && (g.flags & AIT_GEMM_BIAS_ROW);
+  if (g.gate) {        // "+ residual", then zeroed where gate <= 0 (library-internal callers: csrc/tail.hip)
+    if (!g.residual || (g.flags & (AIT_GEMM_ACCUMULATE | AIT_GEMM_MASK_POS)) || row_bias) return AIT_EINVAL;
+    return dispatch_layout<C, EPI_RESG>(g, ak, bk, s, ws);
+  }
   if (g.residual && !(g.flags & AIT_GEMM_ACCUMULATE) && !row_bias) return dispatch_layout<C, EPI_RES>(g, ak, bk, s, ws);
   if (g.residual || (g.flags & (AIT_GEMM_ACCUMULATE | AIT_GEMM_MASK_POS)) || row_bias)
     return dispatch_layout<C, EPI_AUX>(g, ak, bk, s, ws);
@@ -1245,6 +1311,8 @@ inline int make_args(int trans_a, int trans_b, int M, int N, int K, float alpha,
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.c_colblk = c_colblk; g.c_batch = c_batch_stride; g.alpha = alpha; g.flags = flags;
   g.probe = nullptr;
+  g.gate = nullptr;
+  g.sk_on = 0;
   g.sk_ws = nullptr;
   g.sk_flags = nullptr;
   g.sched = nullptr;

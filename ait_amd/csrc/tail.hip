@@ -1,0 +1,414 @@
+// ait_amd/csrc/tail.hip -- the proposal tail behind the AIT as ONE C entry point per direction:
+//
+//   AIT output [bp, 8, 8, C] --SKBlock--> [bp, 4, 4, C] --RCNN_top (ResNet layer4)--> mean over positions --> [bp, 4*planes]
+//   query feature [bs, 8, 8, C] --its own SKBlock--> ... the same layer4 ... --> [bs, 4*planes]
+//
+// Reference: lib/model/modules/blocks_sys_transformer_sk_dilat.py:915-997 (SKBlock / SKNet: two grouped
+// convolutions -- 1x1 and 3x3, 8 groups, ReLU -- whose squares are summed; the branch-attention weights are computed
+// and NOT used, :974-981), lib/model/faster_rcnn/resnet_sys_transformer_sk_dilat.py:85-111 (Bottleneck: stride on
+// the first 1x1), :422 (RCNN_top = layer4), :482-491 (_head_to_tail = layer4 -> mean(3).mean(2)), and the call site
+// faster_rcnn_sys_transformer_sk_dilat.py:247-253.
+//
+// What is NOT computed: layer4 opens with stride-2 1x1 convolutions, so of the SK block's 8x8
+// output only the 16 even positions are ever read; the block is position-wise behind its convolutions, so it is
+// evaluated at those positions (its convolutions run at stride 2) and layer4 takes the result at stride 1.  Same
+// sums, and the skipped positions receive exactly zero gradient in the reference.
+//
+// How it runs: every convolution is a product on the matrix-core kernel of gemm_f32_impl.h -- 1x1 convolutions
+// as token-major GEMMs, 3x3 as implicit GEMMs, the SK branches as grouped implicit GEMMs -- with everything
+// elementwise in the epilogues: frozen-BN scale folded into the weight rows (one multi-tensor pass per call), BN
+// shift / residual / ReLU in the forward epilogues; in the backward the ReLU masks ride in the epilogue of the
+// product that forms each gradient (AIT_GEMM_MASK_POS; "+ residual gradient, gated by the block input's sign" for
+// the product that closes a bottleneck), so not one elementwise pass runs between two products of layer4.  The
+// stride-2 data gradients of the SK branches run per parity class of the input positions (gemm_f32.hip).  The
+// proposals' and the queries' rows go through layer4 TOGETHER (it is the same module): one set of launches, one
+// weight gradient.  Rows are padded to a multiple of 128 with zero-gradient rows so that the weight gradients'
+// K-splits are equal (their last round is then cut evenly over the workgroups without scratch).
+#include "common.h"
+#include "gemm_internal.h"
+
+namespace {
+
+constexpr int kPos = 16;          // positions per map behind the SK block (4 x 4)
+constexpr int kMaxBlocks = 4;
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Bump {
+  char* p;
+  size_t left;
+  float* take(size_t floats) {
+    const size_t bytes = align_up(floats * sizeof(float), 256);
+    if (bytes > left) return nullptr;
+    float* r = reinterpret_cast<float*>(p);
+    p += bytes;
+    left -= bytes;
+    return r;
+  }
+};
+
+#define AIT_TRY(expr)                \
+  do {                               \
+    const int rc__ = (expr);         \
+    if (rc__ != AIT_OK) return rc__; \
+  } while (0)
+
+struct Run {
+  void* stream;
+  const ait_launch_ctx* ctx;
+};
+
+// ---- small kernels -------------------------------------------------------------------------------------------
+// row-scaled copies of up to 16 matrices in one launch: out[r][c] (op)= in[r][c] * s[r]
+struct ScaleDesc { const float* in; const float* s; float* out; int rows, cols; };
+struct ScaleBatch { ScaleDesc d[16]; int n; int add; };
+__global__ __launch_bounds__(256) void scale_rows_kernel(const ScaleBatch b) {
+  const ScaleDesc d = b.d[blockIdx.y];
+  const long long n4 = (long long)d.rows * (d.cols / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int r = (int)(i / (d.cols / 4));
+    const float s = d.s ? d.s[r] : 1.f;
+    float4 v = reinterpret_cast<const float4*>(d.in)[i];
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    if (b.add) {
+      const float4 o = reinterpret_cast<const float4*>(d.out)[i];
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    reinterpret_cast<float4*>(d.out)[i] = v;
+  }
+}
+int scale_rows(const ScaleBatch& b, hipStream_t s) {
+  if (b.n == 0) return AIT_OK;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(256, (unsigned)b.n), dim3(256), 0, s, b);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+// pooled[i][c] = mean of the 16 rows of map i (mean(3).mean(2) of the reference as one reduction over equal groups)
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ o, int n_maps, int C, float* __restrict__ pooled) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n_maps * (C / 4)) return;
+  const int m = (int)(i / (C / 4)), c4 = (int)(i - (long long)m * (C / 4));
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int p = 0; p < kPos; p++) {
+    const float4 v = reinterpret_cast<const float4*>(o + ((size_t)m * kPos + p) * C)[c4];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  const float k = 1.f / kPos;
+  reinterpret_cast<float4*>(pooled + (size_t)m * C)[c4] = make_float4(acc.x * k, acc.y * k, acc.z * k, acc.w * k);
+}
+// g[r][c] = dpooled[r / 16][c] / 16 where o[r][c] > 0 (the ReLU that closes layer4), 0 elsewhere and on padding maps
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ o,
+                                                       long long rows, int n_maps, int C, float* __restrict__ g) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * (C / 4)) return;
+  const long long r = i / (C / 4);
+  const int c4 = (int)(i - r * (C / 4)), m = (int)(r / kPos);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m < n_maps) {
+    const float4 d = reinterpret_cast<const float4*>(dpooled + (size_t)m * C)[c4];
+    const float4 y = reinterpret_cast<const float4*>(o + (size_t)r * C)[c4];
+    const float k = 1.f / kPos;
+    v = make_float4(y.x > 0.f ? d.x * k : 0.f, y.y > 0.f ? d.y * k : 0.f, y.z > 0.f ? d.z * k : 0.f, y.w > 0.f ? d.w * k : 0.f);
+  }
+  reinterpret_cast<float4*>(g + (size_t)r * C)[c4] = v;
+}
+
+// ---- geometry and buffers ------------------------------------------------------------------------------------
+struct Dims {
+  int bp, bs, C, P, E;          // C = SK / layer4 input channels, P = planes, E = 4 * planes
+  int n_blocks;
+  long long Rp, Rq, R;          // rows behind the SK block: proposals, queries, padded total
+  int n_maps;                   // bp + bs
+  int n_maps_pad;               // R / 16
+};
+inline int make_dims(int bp, int bs, int C, int planes, int n_blocks, Dims& d) {
+  if (bp < 0 || bs < 0 || bp + bs <= 0 || C <= 0 || planes <= 0 || n_blocks < 1 || n_blocks > kMaxBlocks) return AIT_EINVAL;
+  if ((C % 1024) || (planes % 128)) return AIT_EUNSUPPORTED;      // 8 groups of a multiple of 128 channels; 128-wide tiles
+  d.bp = bp; d.bs = bs; d.C = C; d.P = planes; d.E = 4 * planes; d.n_blocks = n_blocks;
+  d.Rp = (long long)bp * kPos; d.Rq = (long long)bs * kPos;
+  d.R = (long long)align_up((size_t)(d.Rp + d.Rq), 128);
+  d.n_maps = bp + bs; d.n_maps_pad = (int)(d.R / kPos);
+  if (d.R * 4 > 0x7fffffffLL / 4 || (long long)bp * 64 > 0x7fffffffLL / 4) return AIT_EUNSUPPORTED;
+  return AIT_OK;
+}
+// folded weights of layer4, in launch order
+struct BlockW { float *w1, *w2, *w3, *wd; };
+inline size_t folded_floats(const Dims& d) {
+  size_t f = 0;
+  for (int k = 0; k < d.n_blocks; k++) {
+    const size_t cin = k == 0 ? d.C : d.E;
+    f += align_up((size_t)d.P * cin, 64) + align_up((size_t)d.P * 9 * d.P, 64) + align_up((size_t)d.E * d.P, 64);
+    if (k == 0) f += align_up((size_t)d.E * cin, 64);
+  }
+  return f;
+}
+inline bool carve_folded(Bump& b, const Dims& d, BlockW (&w)[kMaxBlocks]) {
+  bool ok = true;
+  for (int k = 0; k < d.n_blocks; k++) {
+    const size_t cin = k == 0 ? d.C : d.E;
+    w[k].w1 = b.take((size_t)d.P * cin);
+    w[k].w2 = b.take((size_t)d.P * 9 * d.P);
+    w[k].w3 = b.take((size_t)d.E * d.P);
+    w[k].wd = k == 0 ? b.take((size_t)d.E * cin) : nullptr;
+    ok = ok && w[k].w1 && w[k].w2 && w[k].w3 && (k != 0 || w[k].wd);
+  }
+  return ok;
+}
+struct Saved {
+  float *zeros;                       // the row of zeros an out-of-map window tap reads
+  float *f1p, *f3p, *f1q, *f3q;       // SK branches behind their ReLU, proposals / queries
+  float *xtop;                        // [R, C] layer4 input (SK outputs, padded)
+  float *a1[kMaxBlocks], *a2[kMaxBlocks], *o[kMaxBlocks];
+  BlockW wf[kMaxBlocks];
+};
+constexpr size_t kZeros = 8192;
+inline size_t saved_floats(const Dims& d) {
+  const size_t R = (size_t)d.R, slack = 64 * 64;
+  return kZeros + 2 * (size_t)(d.Rp + d.Rq) * d.C + R * d.C + (size_t)d.n_blocks * (2 * R * d.P + R * d.E) + folded_floats(d) + slack;
+}
+inline bool carve(Bump& b, const Dims& d, Saved& s) {
+  s.zeros = b.take(kZeros);
+  s.f1p = b.take((size_t)d.Rp * d.C + 4); s.f3p = b.take((size_t)d.Rp * d.C + 4);
+  s.f1q = b.take((size_t)d.Rq * d.C + 4); s.f3q = b.take((size_t)d.Rq * d.C + 4);
+  s.xtop = b.take((size_t)d.R * d.C);
+  bool ok = s.zeros && s.f1p && s.f3p && s.f1q && s.f3q && s.xtop;
+  for (int k = 0; k < d.n_blocks; k++) {
+    s.a1[k] = b.take((size_t)d.R * d.P); s.a2[k] = b.take((size_t)d.R * d.P); s.o[k] = b.take((size_t)d.R * d.E);
+    ok = ok && s.a1[k] && s.a2[k] && s.o[k];
+  }
+  return ok && carve_folded(b, d, s.wf);
+}
+
+inline ait_conv_geom sk_geom(int n, int k) { return ait_conv_geom{n, 8, 8, 4, 4, k, k, 2, k / 2, 8}; }
+inline ait_conv_geom l4_geom(int n) { return ait_conv_geom{n, 4, 4, 4, 4, 3, 3, 1, 1, 1}; }
+
+// y = relu?(x W^T + bias (+ residual))
+inline int linear(const float* x, long long M, int K, const float* w, int N, const float* bias, const float* residual,
+                  bool relu, float* y, const Run& r) {
+  return ait_gemm_f32_ex(0, 1, (int)M, N, K, 1.f, x, K, w, K, y, N, bias, residual, nullptr, relu ? AIT_GEMM_RELU : 0, 1, 0, 0,
+                         r.ctx, r.stream);
+}
+// dx = dy W  (+ residual) (gated by mask > 0: MASK_POS when there is no residual, the gate operand when there is)
+inline int dgrad(const float* dy, long long M, int N_out, const float* w, int K_in, const float* residual,
+                 const float* mask, float* dx, const Run& r) {
+  if (residual && mask)
+    return ait_gemm_f32_ex(0, 0, (int)M, K_in, N_out, 1.f, dy, N_out, w, K_in, dx, K_in, nullptr, residual, mask, 0, 1, 0, 0,
+                           r.ctx, r.stream);
+  return ait_gemm_f32_ex(0, 0, (int)M, K_in, N_out, 1.f, dy, N_out, w, K_in, dx, K_in, nullptr, mask ? mask : residual, nullptr,
+                         mask ? AIT_GEMM_MASK_POS : 0, 1, 0, 0, r.ctx, r.stream);
+}
+// dW [N_out, K_in] += dy^T x: one K-range per XCD; the persistent kernel cuts the last round evenly (equal splits)
+inline int wgrad(const float* dy, long long M, int N_out, const float* x, int K_in, float* dw, const Run& r) {
+  const int sp = M >= 4096 ? 8 : 1;
+  return ait_gemm_f32_ex(1, 0, N_out, K_in, (int)M, 1.f, dy, N_out, x, K_in, dw, K_in, nullptr, nullptr, nullptr, AIT_GEMM_ATOMIC,
+                         sp, 0, 0, r.ctx, r.stream);
+}
+
+int check_weights(const ait_tail_weights* w, const Dims& d) {
+  if (!w) return AIT_EINVAL;
+  const ait_sk_weights* sk[2] = {&w->sk_props, &w->sk_query};
+  for (int i = 0; i < 2; i++)
+    if (!sk[i]->w1 || !sk[i]->b1 || !sk[i]->w3 || !sk[i]->b3) return AIT_EINVAL;
+  for (int k = 0; k < d.n_blocks; k++) {
+    const ait_bottleneck_weights& b = w->block[k];
+    if (!b.conv1 || !b.conv2 || !b.conv3 || !b.bn1_scale || !b.bn1_shift || !b.bn2_scale || !b.bn2_shift || !b.bn3_scale ||
+        !b.bn3_shift)
+      return AIT_EINVAL;
+    if (k == 0 && (!b.down || !b.bnd_scale || !b.bnd_shift)) return AIT_EINVAL;
+  }
+  return AIT_OK;
+}
+
+// one SKBlock at stride 2: f1 = relu(conv1x1_g8(x) + b1), f3 = relu(conv3x3_g8(x) + b3), y = f1^2 + f3^2
+int sk_forward(const float* x, int n, const Dims& d, const ait_sk_weights& w, float* f1, float* f3, float* y,
+               const float* zeros, const Run& r) {
+  if (n == 0) return AIT_OK;
+  const ait_conv_geom g1 = sk_geom(n, 1), g3 = sk_geom(n, 3);
+  AIT_TRY(ait_conv_fwd_f32(x, d.C, w.w1, &g1, d.C, d.C, w.b1, nullptr, AIT_GEMM_RELU, f1, d.C, zeros, kZeros, r.ctx, r.stream));
+  AIT_TRY(ait_conv_fwd_f32(x, d.C, w.w3, &g3, d.C, d.C, w.b3, nullptr, AIT_GEMM_RELU, f3, d.C, zeros, kZeros, r.ctx, r.stream));
+  return ait_sk_sqsum_fwd(f1, f3, (long long)n * kPos * d.C, y, r.stream);
+}
+
+}  // namespace
+
+AIT_API size_t ait_tail_saved_bytes(int bp, int bs, int channels, int planes, int n_blocks) {
+  Dims d;
+  if (make_dims(bp, bs, channels, planes, n_blocks, d) != AIT_OK) return 0;
+  return saved_floats(d) * sizeof(float) + 64 * 256;
+}
+
+AIT_API int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int bs, int channels, int planes,
+                         int n_blocks, const ait_tail_weights* w, void* saved, size_t saved_bytes, float* pooled,
+                         const ait_launch_ctx* ctx, void* stream) {
+  Dims d;
+  AIT_TRY(make_dims(bp, bs, channels, planes, n_blocks, d));
+  AIT_TRY(check_weights(w, d));
+  if ((bp > 0 && !x_props) || (bs > 0 && !x_query) || !saved || !pooled) return AIT_EINVAL;
+  if (saved_bytes < ait_tail_saved_bytes(bp, bs, channels, planes, n_blocks)) return AIT_EWORKSPACE;
+  Bump b{static_cast<char*>(saved), saved_bytes};
+  Saved s;
+  if (!carve(b, d, s)) return AIT_EWORKSPACE;
+  hipStream_t hs = ait_stream(stream);
+  const Run run{stream, ctx};
+  const int C = d.C, P = d.P, E = d.E;
+  if (hipMemsetAsync(s.zeros, 0, kZeros * sizeof(float), hs) != hipSuccess) return AIT_ELAUNCH;
+  // ---- frozen-BN scales into the weight rows (resnet_sys_transformer_sk_dilat.py:435-441,474-480: every BatchNorm of
+  // RCNN_top is frozen and in eval mode): y = bn(conv(x)) = x (diag(scale) W)^T + shift
+  {
+    ScaleBatch sb{};
+    for (int k = 0; k < d.n_blocks; k++) {
+      const ait_bottleneck_weights& bw = w->block[k];
+      const int cin = k == 0 ? C : E;
+      sb.d[sb.n++] = ScaleDesc{bw.conv1, bw.bn1_scale, s.wf[k].w1, P, cin};
+      sb.d[sb.n++] = ScaleDesc{bw.conv2, bw.bn2_scale, s.wf[k].w2, P, 9 * P};
+      sb.d[sb.n++] = ScaleDesc{bw.conv3, bw.bn3_scale, s.wf[k].w3, E, P};
+      if (k == 0) sb.d[sb.n++] = ScaleDesc{bw.down, bw.bnd_scale, s.wf[k].wd, E, cin};
+    }
+    sb.add = 0;
+    AIT_TRY(scale_rows(sb, hs));
+  }
+  // ---- the two SK blocks write their halves of layer4's input; the padding rows are zero
+  AIT_TRY(sk_forward(x_props, bp, d, w->sk_props, s.f1p, s.f3p, s.xtop, s.zeros, run));
+  AIT_TRY(sk_forward(x_query, bs, d, w->sk_query, s.f1q, s.f3q, s.xtop + (size_t)d.Rp * C, s.zeros, run));
+  if (d.R > d.Rp + d.Rq &&
+      hipMemsetAsync(s.xtop + (size_t)(d.Rp + d.Rq) * C, 0, (size_t)(d.R - d.Rp - d.Rq) * C * sizeof(float), hs) != hipSuccess)
+    return AIT_ELAUNCH;
+  // ---- layer4: bottlenecks on [R, .] token rows of 4x4 maps
+  const ait_conv_geom g3 = l4_geom(d.n_maps_pad);
+  const float* xin = s.xtop;
+  for (int k = 0; k < d.n_blocks; k++) {
+    const ait_bottleneck_weights& bw = w->block[k];
+    const int cin = k == 0 ? C : E;
+    AIT_TRY(linear(xin, d.R, cin, s.wf[k].w1, P, bw.bn1_shift, nullptr, true, s.a1[k], run));
+    AIT_TRY(ait_conv_fwd_f32(s.a1[k], P, s.wf[k].w2, &g3, P, P, bw.bn2_shift, nullptr, AIT_GEMM_RELU, s.a2[k], P, s.zeros, kZeros,
+                             ctx, stream));
+    const float* idn = xin;
+    if (k == 0) {
+      // the projection shortcut; parked in the buffer of the NEXT block's output (free until then), or in the pooled
+      // staging of a one-block tail's own output buffer is impossible -> a2 of block 0 is still needed: use o[k] twice
+      float* park = d.n_blocks > 1 ? s.o[1] : nullptr;
+      if (!park) return AIT_EUNSUPPORTED;
+      AIT_TRY(linear(xin, d.R, cin, s.wf[k].wd, E, bw.bnd_shift, nullptr, false, park, run));
+      idn = park;
+    }
+    AIT_TRY(linear(s.a2[k], d.R, P, s.wf[k].w3, E, bw.bn3_shift, idn, true, s.o[k], run));
+    xin = s.o[k];
+  }
+  {
+    const long long n4 = (long long)d.n_maps * (E / 4);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, hs, s.o[d.n_blocks - 1], d.n_maps, E, pooled);
+    AIT_CHECK_LAUNCH();
+  }
+  return AIT_OK;
+}
+
+AIT_API size_t ait_tail_bwd_workspace_bytes(int bp, int bs, int channels, int planes, int n_blocks) {
+  Dims d;
+  if (make_dims(bp, bs, channels, planes, n_blocks, d) != AIT_OK) return 0;
+  const size_t R = (size_t)d.R;
+  const size_t f = 2 * R * d.E + 2 * R * d.P + R * d.C + 2 * (size_t)(d.Rp + d.Rq) * d.C + folded_floats(d) + 64 * 64;
+  return f * sizeof(float) + 64 * 256;
+}
+
+AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const float* x_query, int bp, int bs, int channels,
+                         int planes, int n_blocks, const ait_tail_weights* w, const void* saved, size_t saved_bytes,
+                         void* workspace, size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                         const ait_tail_grads* grads, const ait_launch_ctx* ctx, void* stream) {
+  Dims d;
+  AIT_TRY(make_dims(bp, bs, channels, planes, n_blocks, d));
+  AIT_TRY(check_weights(w, d));
+  if (!d_pooled || (bp > 0 && !x_props) || (bs > 0 && !x_query) || !saved || !workspace || !grads) return AIT_EINVAL;
+  if (saved_bytes < ait_tail_saved_bytes(bp, bs, channels, planes, n_blocks)) return AIT_EWORKSPACE;
+  if (workspace_bytes < ait_tail_bwd_workspace_bytes(bp, bs, channels, planes, n_blocks)) return AIT_EWORKSPACE;
+  Bump bsv{static_cast<char*>(const_cast<void*>(saved)), saved_bytes};
+  Saved s;
+  if (!carve(bsv, d, s)) return AIT_EWORKSPACE;
+  Bump b{static_cast<char*>(workspace), workspace_bytes};
+  const int C = d.C, P = d.P, E = d.E;
+  float* ga = b.take((size_t)d.R * E);
+  float* gb = b.take((size_t)d.R * E);
+  float* g2 = b.take((size_t)d.R * P);
+  float* g1 = b.take((size_t)d.R * P);
+  float* dxt = b.take((size_t)d.R * C);
+  float* df1 = b.take((size_t)(d.Rp + d.Rq) * C + 8);
+  float* df3 = b.take((size_t)(d.Rp + d.Rq) * C + 8);
+  BlockW dwf[kMaxBlocks];
+  float* dwf_base = reinterpret_cast<float*>(b.p);
+  if (!ga || !gb || !g2 || !g1 || !dxt || !df1 || !df3 || !carve_folded(b, d, dwf)) return AIT_EWORKSPACE;
+  const size_t dwf_bytes = (size_t)(b.p - reinterpret_cast<char*>(dwf_base));
+  hipStream_t hs = ait_stream(stream);
+  const Run run{stream, ctx};
+  if (hipMemsetAsync(dwf_base, 0, dwf_bytes, hs) != hipSuccess) return AIT_ELAUNCH;
+
+  // gradient at layer4's output, behind its closing ReLU
+  {
+    const long long n4 = d.R * (E / 4);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, hs, d_pooled, s.o[d.n_blocks - 1], d.R,
+                       d.n_maps, E, ga);
+    AIT_CHECK_LAUNCH();
+  }
+  const ait_conv_geom g3 = l4_geom(d.n_maps_pad);
+  float* gout = ga;        // gradient at this block's output (masked)
+  float* gnext = gb;       // where the gradient at the block's input goes
+  for (int k = d.n_blocks - 1; k >= 0; k--) {
+    const int cin = k == 0 ? C : E;
+    const float* xin = k == 0 ? s.xtop : s.o[k - 1];
+    AIT_TRY(wgrad(gout, d.R, E, s.a2[k], P, dwf[k].w3, run));                                     // d W3' += g^T a2
+    AIT_TRY(dgrad(gout, d.R, E, s.wf[k].w3, P, nullptr, s.a2[k], g2, run));                       // g2 = (g W3') [a2 > 0]
+    AIT_TRY(ait_conv_bwd_weight_f32(g2, P, s.a1[k], P, &g3, P, P, dwf[k].w2, 8, s.zeros, kZeros, ctx, stream));
+    AIT_TRY(ait_conv_bwd_data_f32(g2, P, s.wf[k].w2, &g3, P, P, s.a1[k], AIT_GEMM_MASK_POS, g1, P, s.zeros, kZeros, ctx, stream));
+    AIT_TRY(wgrad(g1, d.R, P, xin, cin, dwf[k].w1, run));                                         // d W1' += g1^T x_in
+    if (k > 0) {
+      // gradient at the previous block's output: conv1's data gradient + the identity shortcut's, behind that block's ReLU
+      AIT_TRY(dgrad(g1, d.R, P, s.wf[k].w1, cin, gout, xin, gnext, run));
+      float* t = gout; gout = gnext; gnext = t;
+    } else {
+      AIT_TRY(wgrad(gout, d.R, E, xin, cin, dwf[k].wd, run));                                     // projection shortcut
+      AIT_TRY(dgrad(gout, d.R, E, s.wf[k].wd, cin, nullptr, nullptr, dxt, run));
+      AIT_TRY(dgrad(g1, d.R, P, s.wf[k].w1, cin, dxt, nullptr, dxt, run));                        // (+=, in place)
+    }
+  }
+  // weight gradients: from the folded weights back to the parameters (d W = diag(scale) d W'), ACCUMULATED
+  {
+    ScaleBatch sb{};
+    for (int k = 0; k < d.n_blocks; k++) {
+      const ait_bottleneck_weights& bw = w->block[k];
+      const ait_bottleneck_grads& bg = grads->block[k];
+      const int cin = k == 0 ? C : E;
+      if (bg.conv1) sb.d[sb.n++] = ScaleDesc{dwf[k].w1, bw.bn1_scale, bg.conv1, P, cin};
+      if (bg.conv2) sb.d[sb.n++] = ScaleDesc{dwf[k].w2, bw.bn2_scale, bg.conv2, P, 9 * P};
+      if (bg.conv3) sb.d[sb.n++] = ScaleDesc{dwf[k].w3, bw.bn3_scale, bg.conv3, E, P};
+      if (k == 0 && bg.down) sb.d[sb.n++] = ScaleDesc{dwf[k].wd, bw.bnd_scale, bg.down, E, cin};
+    }
+    sb.add = 1;
+    AIT_TRY(scale_rows(sb, hs));
+  }
+  // ---- the two SK blocks: y = f1^2 + f3^2
+  const long long Rsk = d.Rp + d.Rq;
+  // (f1p | f1q and f3p | f3q are separate buffers: two passes each)
+  if (bp > 0) AIT_TRY(ait_sk_sqsum_bwd(dxt, s.f1p, s.f3p, d.Rp * C, df1, df3, stream));
+  if (bs > 0) AIT_TRY(ait_sk_sqsum_bwd(dxt + (size_t)d.Rp * C, s.f1q, s.f3q, d.Rq * C, df1 + (size_t)d.Rp * C, df3 + (size_t)d.Rp * C, stream));
+  (void)Rsk;
+  struct Side { const float* x; int n; long long row0; const ait_sk_weights* w; const ait_sk_grads* g; float* dx; };
+  const Side sides[2] = {{x_props, bp, 0, &w->sk_props, &grads->sk_props, d_x_props},
+                         {x_query, bs, d.Rp, &w->sk_query, &grads->sk_query, d_x_query}};
+  for (const Side& sd : sides) {
+    if (sd.n == 0) continue;
+    const float* a1 = df1 + (size_t)sd.row0 * C;
+    const float* a3 = df3 + (size_t)sd.row0 * C;
+    const long long rows = (long long)sd.n * kPos;
+    const ait_conv_geom q1 = sk_geom(sd.n, 1), q3 = sk_geom(sd.n, 3);
+    const int sp = rows >= 4096 ? 8 : 1;
+    if (sd.g->w1) AIT_TRY(ait_conv_bwd_weight_f32(a1, C, sd.x, C, &q1, C, C, sd.g->w1, sp, s.zeros, kZeros, ctx, stream));
+    if (sd.g->w3) AIT_TRY(ait_conv_bwd_weight_f32(a3, C, sd.x, C, &q3, C, C, sd.g->w3, sp, s.zeros, kZeros, ctx, stream));
+    if (sd.g->b1) AIT_TRY(ait_colsum_f32(a1, rows, C, C, sd.g->b1, stream));
+    if (sd.g->b3) AIT_TRY(ait_colsum_f32(a3, rows, C, C, sd.g->b3, stream));
+    if (sd.dx) {
+      AIT_TRY(ait_conv_bwd_data_f32(a3, C, sd.w->w3, &q3, C, C, nullptr, 0, sd.dx, C, s.zeros, kZeros, ctx, stream));
+      AIT_TRY(ait_conv_bwd_data_f32(a1, C, sd.w->w1, &q1, C, C, sd.dx, 0, sd.dx, C, s.zeros, kZeros, ctx, stream));   // += in place
+    }
+  }
+  return AIT_OK;
+}

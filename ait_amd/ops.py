@@ -457,10 +457,15 @@ def conv_fwd(x, w, geom, bias=None, residual=None, relu=False):
     return y
 
 
-def conv_bwd_data(dy, w, geom, residual=None, mask_pos=False):
+def conv_bwd_data(dy, w, geom, residual=None, mask_pos=False, out=None):
+    """dx = conv_transpose(dy, w) (+ residual, or gated by residual > 0 with mask_pos).  out: write into this
+    [rows_in, cin] tensor; with residual is out the product is ACCUMULATED into it (the second branch of a block
+    whose branches share their input: SKBlock)."""
     cout, cin = w.shape[0], w.shape[3] * max(1, geom.groups)
     rows = geom.n * geom.in_h * geom.in_w
-    dx = torch.empty((rows, cin), dtype=torch.float32, device=dy.device)
+    dx = torch.empty((rows, cin), dtype=torch.float32, device=dy.device) if out is None else out
+    if tuple(dx.shape) != (rows, cin) or not dx.is_contiguous():
+        raise _lib.AitHipError("conv_bwd_data: `out` must be a contiguous [%d, %d] tensor" % (rows, cin))
     z = _zeros(dy.device)
     with torch.cuda.device(dy.device):
         rc = _lib.lib().ait_conv_bwd_data_f32(_lib.dev_ptr(dy), dy.stride(0), _lib.dev_ptr(w), ctypes.byref(geom), cin, cout,

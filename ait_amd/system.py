@@ -29,6 +29,15 @@ from . import _lib, ops
 LN_EPS = 1e-6
 SEQ = 64          # tokens per sequence on the AIT path (8x8 query cells)
 
+# Test hooks, set from Python by the tests only (no environment switches):
+#   _PY_COMPOSE      Transformer.forward as autograd over the building blocks instead of ONE node over
+#                    ait_transformer_fwd_train / _bwd (the tests hold the C entry points against it)
+#   _COMPACT_MEMORY  False: the encoder memory keeps its 15 padded rows, as the reference computes it
+#   _COATT_TORCH     the image-level co-attention's any-length attention as torch expressions (the tests' reference)
+_PY_COMPOSE = False
+_COMPACT_MEMORY = True
+_COATT_TORCH = False
+
 
 def _rank_salt():
     """Distinct per data-parallel rank: ranks are usually seeded identically (identical initial
@@ -544,9 +553,10 @@ class MultiHeadAttention(nn.Module):
 
     def _forward_generic(self, q, k, v, mask):
         if (q.is_cuda and q.dtype == torch.float32 and mask is None and (k is v) and self.n_head == 8 and self.d_k == 64
-                and self.d_v == 64 and self.d_model == ops.D_MODEL and self.dist == 'softmax'
-                and os.environ.get("AIT_COATT_TORCH", "0") != "1"):
+                and self.d_v == 64 and self.d_model == ops.D_MODEL and self.dist == 'softmax' and not _COATT_TORCH):
             return self._forward_any_len(q, k)
+        # torch expressions: dense masks / other head geometries (never on the detector's path) and CPU tensors
+        ops.note_fallback("MultiHeadAttention generic shapes", q)
         d_k, d_v, n_head = self.d_k, self.d_v, self.n_head
         sz_b, len_q, len_k = q.size(0), q.size(1), k.size(1)
         residual = q
@@ -832,7 +842,7 @@ class Transformer(nn.Module):
         # (the C entry points multiply in exact fp32; the opt-in bf16 matmul modes of ops.set_matmul_dtype
         # go through the fine-grained composition, whose GEMM calls honour the switch)
         if (not self.training and not torch.is_grad_enabled() and len(self.encoder.layer_stack) == 1
-                and os.environ.get("AIT_COMPACT_MEMORY", "1") != "0" and ops.MATMUL_DTYPE == "f32"):
+                and _COMPACT_MEMORY and ops.MATMUL_DTYPE == "f32"):
             # inference: the whole operator is ONE call into the C ABI (ait_transformer_fwd)
             xp = x_props.reshape(bp, c2, n_s).transpose(1, 2).reshape(bp * n_s, c2).contiguous()
             xq = x_query.reshape(bs, c2, n_t).transpose(1, 2).reshape(bs * n_t, c2).contiguous()
@@ -848,8 +858,7 @@ class Transformer(nn.Module):
         p = self.encoder.p if self.training else 0.0
         p_attn = self.encoder.layer_stack[0].slf_attn.attention.dropout.p if self.training else 0.0
         base_seed = _new_seed()
-        fine = os.environ.get("AIT_PY_COMPOSE", "0") == "1" or os.environ.get("AIT_COMPACT_MEMORY", "1") == "0" \
-            or ops.MATMUL_DTYPE != "f32"
+        fine = _PY_COMPOSE or not _COMPACT_MEMORY or ops.MATMUL_DTYPE != "f32"
         if len(self.encoder.layer_stack) == 1 and len(self.decoder.layer_stack) == 1 and not fine:
             # training: the whole operator is ONE autograd node over ait_transformer_fwd_train / _bwd
             W, keep = self._c_weights_cached()
@@ -857,7 +866,7 @@ class Transformer(nn.Module):
             if self.channels_last_out:
                 return out.view(bp, hq, wq, c2).permute(0, 3, 1, 2)
             return out.view(bp, n_t, c2).transpose(1, 2).reshape(bp, c2, hq, wq)
-        # fine-grained composition (AIT_PY_COMPOSE=1): autograd over the building blocks, with the site
+        # fine-grained composition (test hook _PY_COMPOSE, and the bf16 matmul modes): autograd over the building blocks, with the site
         # seeds the C entry points derive -- same kernels, same order, same masks
         global _SEED_QUEUE
         _SEED_QUEUE = _site_seeds(base_seed)
@@ -871,7 +880,7 @@ class Transformer(nn.Module):
         emb_q = _Linear.apply(xq, self.dec_emb[0].weight.view(d, c2), self.dec_emb[0].bias)
         src_mask, trg_mask = KeyPadMask(n_s), CausalMask()
         enc = self.encoder.prologue(emb_p, bp, n_s, 1)              # zero-pads 49 -> 64 rows
-        if os.environ.get("AIT_COMPACT_MEMORY", "1") == "0":     # A/B switch: padded memory, as the reference
+        if not _COMPACT_MEMORY:                                  # test hook: padded memory, as the reference
             n_s_eff = SEQ
         else:
             n_s_eff = n_s

@@ -547,6 +547,57 @@ int ait_transformer_bwd(const float* d_out, const float* x_props, const float* x
                         const ait_transformer_grads* grads, const ait_launch_ctx* ctx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The proposal tail behind the AIT as one call per direction: both SKBlocks and RCNN_top
+ * (ResNet layer4) with the mean over positions.  Replaces, in _fasterRCNN.forward
+ * (lib/model/faster_rcnn/faster_rcnn_sys_transformer_sk_dilat.py:247-253),
+ *     props_feat, query_feat = self.sk(x_props = props_feat, x_query = non_qry)           blocks_sys_transformer_sk_dilat.py:915-997
+ *     props_feat = self._head_to_tail(props_feat) ; query_feat = self._head_to_tail(query_feat)
+ *                                                                                         resnet_sys_transformer_sk_dilat.py:482-491, :85-111
+ * and the autograd graph PyTorch builds over them.
+ *   x_props [bp*64, C]   the AIT output, token-major (= channels-last [bp, 8, 8, C]); x_query [bs*64, C] likewise
+ *   pooled  [bp + bs, 4*planes]   rows 0 .. bp-1: the proposals' pooled features, then the queries'
+ * SKBlock as the reference EXECUTES it: f_k = relu(conv_k(x)) for the 1x1 and the 3x3 grouped branch (8 groups),
+ * output sum_k f_k * f_k -- the branch-attention weights are computed by the reference and never used (:974-981).
+ * The block is evaluated only at the 16 positions layer4's stride-2 1x1 convolutions read (same sums; the others
+ * receive exactly zero gradient in the reference).
+ * Weights: plain pointers into the state_dict tensors.  Convolution weights in CHANNELS-LAST memory
+ * ([cout][kh][kw][cin / groups]); every BatchNorm of RCNN_top is frozen and in eval mode (:435-441,474-480) and is
+ * given as (scale, shift) = (gamma / sqrt(var + eps), beta - mean * scale).  C % 1024 == 0, planes % 128 == 0,
+ * 2 <= n_blocks <= 4 (block[0] is the one with the projection shortcut).
+ *   saved      caller-owned, ait_tail_saved_bytes(...): written by ait_tail_fwd, read by ait_tail_bwd (layout
+ *              private to the library; in inference it is scratch)
+ *   gradients  d_x_props / d_x_query are WRITTEN (either may be NULL); parameter gradients are ACCUMULATED into
+ *              the buffers of ait_tail_grads (same layouts as the weights; a NULL member skips that gradient)
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *w1, *b1;          /* convs.0.0: 1x1 grouped conv weight [C][C/8], bias [C] */
+  const float *w3, *b3;          /* convs.1.0: 3x3 grouped conv weight [C][3][3][C/8], bias [C] */
+} ait_sk_weights;
+typedef struct {
+  const float *conv1, *conv2, *conv3, *down;     /* [planes][cin], [planes][3][3][planes], [4 planes][planes], [4 planes][cin] or NULL */
+  const float *bn1_scale, *bn1_shift, *bn2_scale, *bn2_shift, *bn3_scale, *bn3_shift, *bnd_scale, *bnd_shift;
+} ait_bottleneck_weights;
+typedef struct {
+  ait_sk_weights sk_props, sk_query;
+  ait_bottleneck_weights block[4];
+} ait_tail_weights;
+typedef struct { float *w1, *b1, *w3, *b3; } ait_sk_grads;
+typedef struct { float *conv1, *conv2, *conv3, *down; } ait_bottleneck_grads;
+typedef struct {
+  ait_sk_grads sk_props, sk_query;
+  ait_bottleneck_grads block[4];
+} ait_tail_grads;
+size_t ait_tail_saved_bytes(int bp, int bs, int channels, int planes, int n_blocks);
+int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int bs, int channels, int planes, int n_blocks,
+                 const ait_tail_weights* w, void* saved, size_t saved_bytes, float* pooled, const ait_launch_ctx* ctx,
+                 void* stream);
+size_t ait_tail_bwd_workspace_bytes(int bp, int bs, int channels, int planes, int n_blocks);
+int ait_tail_bwd(const float* d_pooled, const float* x_props, const float* x_query, int bp, int bs, int channels,
+                 int planes, int n_blocks, const ait_tail_weights* w, const void* saved, size_t saved_bytes,
+                 void* workspace, size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                 const ait_tail_grads* grads, const ait_launch_ctx* ctx, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Frozen batch-norm + residual + ReLU, one pass (NCHW fp32, x [n,C,HW]).
  * Replaces the eval-mode BatchNorm2d / "out += residual" / ReLU chains of the ResNet bottlenecks
  * (lib/model/faster_rcnn/resnet_sys_transformer_sk_dilat.py:85-111; every BatchNorm is frozen and

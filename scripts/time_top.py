@@ -35,11 +35,17 @@ x = torch.randn(bp, 1024, 8, 8, device=dev).contiguous(memory_format=torch.chann
 q = torch.randn(4, 1024, 8, 8, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
 
 
+import ait_amd.faster_rcnn as fr
+
+
 def tail(train=True):
     def f():
-        a, b = m.sk(x_props=x, x_query=q, stride=2)
-        y = m._head_to_tail(a, subsampled=True)
-        z = m._head_to_tail(b, subsampled=True)
+        if fr._TAIL_FUSED:
+            y, z = m._tail(x, q)
+        else:
+            a, b = m.sk(x_props=x, x_query=q, stride=2)
+            y = m._head_to_tail(a, subsampled=True)
+            z = m._head_to_tail(b, subsampled=True)
         if train:
             (y.sum() + z.sum()).backward()
     return f
@@ -58,10 +64,13 @@ def l4_only():
 
 
 print("bp = %d" % bp)
-print("tail forward              %.3f ms" % timeit(tail(False)))
-print("tail forward + backward   %.3f ms" % timeit(tail(True)))
-print("  SK only   fwd + bwd     %.3f ms" % timeit(sk_only))
-print("  layer4    fwd + bwd     %.3f ms" % timeit(l4_only))
+for fused in (True, False):
+    fr._TAIL_FUSED = fused
+    print("%s: tail forward %.3f ms, forward + backward %.3f ms"
+          % ("ait_tail_* (one node)" if fused else "nn.Module composition (PyTorch-ROCm convolutions)", timeit(tail(False)), timeit(tail(True))))
+fr._TAIL_FUSED = True
+print("  module composition, SK only   fwd + bwd     %.3f ms" % timeit(sk_only))
+print("  module composition, layer4    fwd + bwd     %.3f ms" % timeit(l4_only))
 pr = _lib.Probe(4096)
 with pr:
     tail(True)()

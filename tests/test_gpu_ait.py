@@ -9,6 +9,7 @@ import torch
 
 from oracle import ait_ref
 from oracle.digest import compare, seeded
+from ait_amd import system
 
 pytestmark = pytest.mark.gpu
 
@@ -367,9 +368,9 @@ def test_transformer_c_entry_point_equals_the_autograd_composition(monkeypatch):
     xp, xq = _dev(xp0), _dev(xq0)
     with torch.enable_grad():
         y_py = t(x_props=xp.clone().requires_grad_(True), x_query=xq).detach()
-        monkeypatch.setenv("AIT_PY_COMPOSE", "1")
+        monkeypatch.setattr(system, "_PY_COMPOSE", True)
         y_fine = t(x_props=xp.clone().requires_grad_(True), x_query=xq).detach()
-        monkeypatch.setenv("AIT_PY_COMPOSE", "0")
+        monkeypatch.setattr(system, "_PY_COMPOSE", False)
     assert torch.equal(y_fine, y_py)
     with torch.no_grad():
         y_c = t(x_props=xp, x_query=xq)
@@ -441,7 +442,7 @@ def _rel(a, b):
 def test_transformer_training_c_path_equals_the_fine_grained_composition(monkeypatch, train):
     """Transformer.forward with gradients = ONE autograd node over ait_transformer_fwd_train /
     ait_transformer_bwd.  Against the fine-grained composition (autograd over the building blocks,
-    AIT_PY_COMPOSE=1), with dropout ON in train mode (both derive the ten site seeds with
+    the test hook system._PY_COMPOSE), with dropout ON in train mode (both derive the ten site seeds with
     ait_dropout_seed from the same base seed): the forward is the same kernels in the same order -> the
     same bits; input gradients likewise; parameter gradients agree to summation order (split-K atomics,
     column sums)."""
@@ -450,7 +451,7 @@ def test_transformer_training_c_path_equals_the_fine_grained_composition(monkeyp
     xp0, xq0, cot0 = seeded(301, (6, 1024, 7, 7)), seeded(302, (2, 1024, 8, 8)), seeded(303, (6, 1024, 8, 8))
 
     def run(fine):
-        monkeypatch.setenv("AIT_PY_COMPOSE", "1" if fine else "0")
+        monkeypatch.setattr(system, "_PY_COMPOSE", bool(fine))
         t.zero_grad(set_to_none=True)
         xp, xq = _dev(xp0).requires_grad_(True), _dev(xq0).requires_grad_(True)
         torch.manual_seed(11)
@@ -463,7 +464,7 @@ def test_transformer_training_c_path_equals_the_fine_grained_composition(monkeyp
     assert torch.equal(yc, yf)
     if train:                                   # dropout really was on, and really was seeded
         torch.manual_seed(12)
-        monkeypatch.setenv("AIT_PY_COMPOSE", "0")
+        monkeypatch.setattr(system, "_PY_COMPOSE", False)
         assert not torch.equal(t(x_props=_dev(xp0), x_query=_dev(xq0)), yc)
     assert _rel(gpc, gpf) < 1e-6 and _rel(gqc, gqf) < 1e-5
     assert len(gc) == 46
@@ -591,7 +592,7 @@ def test_any_length_attention_block_matches_the_torch_composition(monkeypatch, l
     """MultiHeadAttention at the image-level co-attention's shapes (faster_rcnn_sys_transformer_sk_dilat.py:31-102:
     2394 image tokens x 64 query tokens, both directions): projections, batched score / P.V products, row softmax,
     any-T selective heads and the LayerNorm tail on the library's kernels against the torch composition of the same
-    module (AIT_COATT_TORCH=1), outputs and all gradients at dropout 0; dropout statistics separately."""
+    module (test hook system._COATT_TORCH), outputs and all gradients at dropout 0; dropout statistics separately."""
     from ait_amd.system import MultiHeadAttention
     torch.manual_seed(lq + lk)
     m = MultiHeadAttention(8, 512, 64, 64, dropout=0.1).cuda().eval()
@@ -600,7 +601,7 @@ def test_any_length_attention_block_matches_the_torch_composition(monkeypatch, l
     cot = torch.randn(3, lq, 512, device="cuda")
 
     def run(torch_path):
-        monkeypatch.setenv("AIT_COATT_TORCH", "1" if torch_path else "0")
+        monkeypatch.setattr(system, "_COATT_TORCH", bool(torch_path))
         m.zero_grad(set_to_none=True)
         q, k = q0.clone().requires_grad_(True), k0.clone().requires_grad_(True)
         y, attn = m(q, k, k, mask=None)
@@ -615,7 +616,7 @@ def test_any_length_attention_block_matches_the_torch_composition(monkeypatch, l
     for n in gt:
         assert _rel(gh[n], gt[n]) < 1e-4, n
     # training mode: the probabilities' dropout keeps ~90 %, scales by 1/0.9, and is seeded
-    monkeypatch.setenv("AIT_COATT_TORCH", "0")
+    monkeypatch.setattr(system, "_COATT_TORCH", False)
     m.train()
     torch.manual_seed(3)
     y1, a1 = m(q0, k0, k0, mask=None)

@@ -203,44 +203,6 @@ def test_frozen_bn_residual_relu_matches_torch():
                     assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
 
 
-def test_conv1x1_bn_act_gemm_path_matches_torch(monkeypatch):
-    """1x1 conv + frozen BN (+ residual) (+ ReLU) on channels-last activations as ONE ait_gemm_f32
-    launch (scale folded into the weight rows, shift / residual / ReLU in the epilogue) against
-    conv2d + eval BatchNorm + add + relu in torch: forward and all gradients, 1e-5 relative."""
-    from ait_amd import faster_rcnn as fr
-    monkeypatch.setattr(fr, "_CONV1X1_GEMM", True)          # opt-in path (off by default: slower than MIOpen)
-    monkeypatch.setattr(fr, "_CONV1X1_MIN_C", 0)
-    torch.manual_seed(3)
-    # (gradients are compared on sizes where no ReLU pre-activation sits within rounding of zero:
-    # at [1200,2048,4,4] = 4e7 outputs one always does, and its mask bit moves 2e-4 of the norm)
-    for (n, cin, cout, h, w) in ((3, 64, 256, 9, 7), (2, 256, 64, 5, 6), (48, 512, 2048, 4, 4)):
-        conv = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
-        bn = torch.nn.BatchNorm2d(cout).cuda().eval()
-        with torch.no_grad():
-            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
-            bn.running_mean.uniform_(-0.5, 0.5); bn.running_var.uniform_(0.5, 1.5)
-        for p in bn.parameters():
-            p.requires_grad = False
-        for use_res in (False, True):
-            for relu in (True, False):
-                x = torch.randn(n, cin, h, w, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
-                r = torch.randn(n, cout, h, w, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True) \
-                    if use_res else None
-                y = fr.conv1x1_bn_act(x, conv, bn, residual=r, relu=relu)
-                assert y.grad_fn.__class__.__name__.startswith("_Conv1x1BnAct")
-                ref = bn(conv(x)) + (r if use_res else 0)
-                ref = torch.relu(ref) if relu else ref
-                scale = float(ref.abs().max())
-                assert float((y - ref).abs().max()) <= 1e-5 * scale
-                g = torch.randn_like(ref)
-                wrt = [x, conv.weight] + ([r] if use_res else [])
-                got = torch.autograd.grad(y, wrt, g)
-                want = torch.autograd.grad(ref, wrt, g)
-                for a, b in zip(got, want):
-                    assert a.shape == b.shape
-                    assert float((a - b).norm()) <= 1e-4 * float(b.norm()) + 1e-6
-
-
 def test_roi_align_channels_last_fuzz_vs_oracle():
     """Seeded fuzz of the channels-last RoIAlign pair against the C oracle: odd feature sizes, C not a
     multiple of the workgroup's channel span, RoIs from sub-pixel to larger than the image, explicit
@@ -347,42 +309,6 @@ def test_implicit_gemm_convolutions_vs_torch(n, cin, cout, hw, k, stride, pad):
     dw_ref = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), dyn, stride, pad).permute(0, 2, 3, 1)
     dw = ops.conv_bwd_weight(dy, xm, geom, k, k, split_k=8)
     assert float((dw.double() - dw_ref).abs().max()) <= 5e-5 * float(dw_ref.abs().max()) + 1e-6
-
-
-def test_layer4_block_on_hip_convolutions_matches_miopen():
-    """Bottleneck of RCNN_top with its convolutions on the library's kernels (1x1 as GEMMs, 3x3 as implicit
-    GEMMs, frozen BN / residual / ReLU in the epilogues) against the same block on MIOpen + bn_act: outputs
-    and every gradient."""
-    import ait_amd.faster_rcnn as fr
-    torch.manual_seed(3)
-    blk = fr.Bottleneck(2048, 512).cuda()
-    for m in blk.modules():
-        if isinstance(m, torch.nn.BatchNorm2d):
-            m.running_mean.normal_(0, 0.1)
-            m.running_var.uniform_(0.5, 1.5)
-            m.weight.data.uniform_(0.5, 1.5)
-            m.bias.data.normal_(0, 0.1)
-            m.weight.requires_grad_(False)
-            m.bias.requires_grad_(False)
-    blk.eval().to(memory_format=torch.channels_last)
-    x0 = torch.randn(300, 2048, 4, 4, device="cuda").contiguous(memory_format=torch.channels_last)
-    cot = torch.randn(300, 2048, 4, 4, device="cuda").contiguous(memory_format=torch.channels_last)
-    outs = {}
-    for hip in (False, True):
-        blk._ait_hip = hip
-        blk.zero_grad(set_to_none=True)
-        x = x0.clone().requires_grad_(True)
-        y = blk(x)
-        y.backward(cot)
-        outs[hip] = (y.detach(), x.grad, {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None})
-    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
-    assert rel(outs[True][0], outs[False][0]) < 1e-5
-    # (three ReLU masks between output and input: pre-activations within rounding of 0 flip their mask bit
-    # between two implementations -- DESIGN.md 4, item 3 -- so the gradients agree to ~3e-4, not 1e-5)
-    assert rel(outs[True][1], outs[False][1]) < 1e-3
-    assert set(outs[True][2]) == set(outs[False][2]) == {"conv1.weight", "conv2.weight", "conv3.weight"}
-    for k in outs[False][2]:
-        assert rel(outs[True][2][k], outs[False][2][k]) < 1e-3, k
 
 
 def test_box_kernels_equal_the_tensor_expressions():
@@ -515,29 +441,15 @@ def test_grouped_implicit_gemm_convolutions_vs_torch(n, k, stride, pad):
     dw = ops.conv_bwd_weight(dy, xm, geom, k, k, split_k=16)
     dw_ref = wd.grad.permute(0, 2, 3, 1)
     assert float((dw.double() - dw_ref).abs().max()) <= 5e-5 * float(dw_ref.abs().max()) + 1e-6
-
-
-def test_sk_block_on_hip_grouped_convolutions_matches_miopen(monkeypatch):
-    """SKBlock with its two grouped convolutions on the library's kernels against the same block on MIOpen / CK:
-    output and every gradient (the fused ReLU / square / sum tail is common to both)."""
-    import ait_amd.faster_rcnn as fr
-    torch.manual_seed(6)
-    blk = fr.SKBlock(1024).cuda()
-    x0 = torch.randn(300, 1024, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
-    gy = None
-    res = {}
-    for hip in (True, False):
-        monkeypatch.setattr(fr, "_SK_HIP", hip)
-        x = x0.clone().requires_grad_(True)
-        blk.zero_grad(set_to_none=True)
-        y = blk(x, stride=2)
-        if gy is None:
-            gy = torch.randn_like(y)
-        y.backward(gy)
-        res[hip] = [y.detach(), x.grad] + [p.grad.clone() for p in blk.convs.parameters()]
-    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
-    for a, b in zip(res[True], res[False]):
-        assert a.shape == b.shape and rel(a, b) < 2e-5
+    # accumulating into a gradient in place (residual is dx itself: the second branch of the SK block), and the
+    # ReLU-backward gate
+    base = torch.randn_like(dx)
+    acc = base.clone()
+    ops.conv_bwd_data(dy, wm, geom, residual=acc, out=acc)
+    assert float((acc.double() - (dx_ref + base.double())).abs().max()) <= 2e-5 * float(dx_ref.abs().max()) + 1e-5
+    gate = torch.randn_like(dx)
+    dxm = ops.conv_bwd_data(dy, wm, geom, residual=gate, mask_pos=True)
+    assert float((dxm.double() - dx_ref * (gate > 0)).abs().max()) <= 2e-5 * float(dx_ref.abs().max()) + 1e-6
 
 
 def test_box_kernel_edge_cases():
@@ -561,3 +473,56 @@ def test_box_kernel_edge_cases():
             assert torch.equal(a, w.to(a.dtype)), (name, b, R0, G)
         # the only foreground RoI is the gt box itself (appended as a RoI: IoU 1)
         assert bool((got[3][:, 0] == 1).all())
+
+
+@pytest.mark.parametrize("bp,bs", [(300, 4), (37, 2), (1200, 4)])
+def test_proposal_tail_node_matches_the_module_composition(monkeypatch, bp, bs):
+    """ait_tail_fwd / ait_tail_bwd (both SK blocks + layer4 + the mean over positions as ONE autograd node: grouped
+    implicit GEMMs at stride 2, per-parity data gradients, frozen BN folded into the weights, every ReLU mask and
+    residual add in a GEMM epilogue, proposals and queries through layer4 together) against the nn.Module
+    composition of the same parameters on PyTorch-ROCm's convolutions (test hook _TAIL_FUSED = False): pooled
+    features, both input gradients and all 18 parameter gradients."""
+    import ait_amd.faster_rcnn as fr
+    from ait_amd import ops
+    torch.manual_seed(5)
+    m = fr.resnet(('__background__', 'fg'), 50, pretrained=False, class_agnostic=True, num_K=3)
+    m.create_architecture()
+    for mod in m.RCNN_top.modules():            # non-trivial frozen statistics
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.1)
+    for blk in (m.sk.sk_props, m.sk.sk_query):
+        for c in blk.convs:
+            c[0].bias.data.normal_(0, 0.1)
+    m = m.cuda().train()
+    x0 = torch.randn(bp, 1024, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+    q0 = torch.randn(bs, 1024, 8, 8, device="cuda")
+    cot_p, cot_q = torch.randn(bp, 2048, device="cuda"), torch.randn(bs, 2048, device="cuda")
+    names = [n for n, _ in m.named_parameters() if n.startswith(("sk.sk_props.convs", "sk.sk_query.convs", "RCNN_top."))
+             and "bn" not in n and "downsample.1" not in n]
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(fr, "_TAIL_FUSED", fused)
+        m.zero_grad(set_to_none=True)
+        x, q = x0.clone().requires_grad_(True), q0.clone().requires_grad_(True)
+        ops.reset_fallbacks()
+        if m._tail_on_library(x, q, 2):
+            yp, yq = m._tail(x, q)
+        else:
+            a, b = m.sk(x_props=x, x_query=q, stride=2)
+            yp, yq = m._head_to_tail(a, subsampled=True), m._head_to_tail(b, subsampled=True)
+        assert ops.fallback_count() == 0
+        ((yp * cot_p).sum() + (yq * cot_q).sum()).backward()
+        params = dict(m.named_parameters())
+        res[fused] = [yp.detach(), yq.detach(), x.grad.clone(), q.grad.clone()] + [params[n].grad.clone() for n in names]
+    assert len(names) == 18, names
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    labels = ["pooled_props", "pooled_query", "d_x_props", "d_x_query"] + names
+    for lab, a, b in zip(labels, res[True], res[False]):
+        assert a.shape == b.shape, lab
+        # forward to rounding; gradients cross up to nine ReLU masks whose bits flip on pre-activations within
+        # rounding of zero between two implementations (DESIGN.md 4, item 3)
+        tol = 2e-5 if lab.startswith("pooled") else 2e-3
+        assert rel(a, b) < tol, (lab, rel(a, b))

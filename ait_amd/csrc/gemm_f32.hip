@@ -154,6 +154,9 @@ AIT_API int ait_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, 
 // =========================================================================================================
 namespace {
 using Tile128D = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, KNOB_SPREAD>;
+// 64 x 128, two waves: grouped convolutions over a handful of rows (the query side of the SK block: 64 output rows) --
+// a 256-row tile would multiply three quarters of padding there
+using TileS = Cfg<64, 128, 16, 1, 2, 2, MODE_DLDS, 3, KNOB_SPREAD>;
 
 inline int log2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;
@@ -167,10 +170,9 @@ inline ConvGeom make_geom(int hw_shift, int w_shift, int src_h, int src_w, int k
                           int seg, long long b_tap_stride, const float* zero, int a_group, int n_group) {
   ConvGeom m{};
   m.rows_hw_shift = hw_shift; m.rows_w_shift = w_shift; m.src_h = src_h; m.src_w = src_w; m.kw = kw;
-  m.a = a; m.b = b; m.c = c; m.cx = c; m.div_shift = div_shift; m.seg = seg; m.b_tap_stride = b_tap_stride;
+  m.a = a; m.b = b; m.c = c; m.div_shift = div_shift; m.seg = seg; m.b_tap_stride = b_tap_stride;
   m.zero = zero; m.a_group = a_group; m.n_group = n_group;
-  m.wt_y0 = 0; m.wt_x0 = 0; m.wt_step = 1; m.wt_kw = kw;
-  m.rowmap = 0;
+  m.wt_kw = kw; m.a2_class = -1;
   return m;
 }
 
@@ -193,11 +195,19 @@ inline int check_geom(const ait_conv_geom* q, int cin, int cout) {
 template <class T, int CONV, bool AK, bool BKC, bool GRP = false>
 int conv_launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
   if (g.flags & AIT_GEMM_ATOMIC) return launch<T, AK, BKC, EPI_ATOMIC, NoProbe, CONV, GRP>(g, s, ws);
-  if (GRP) return launch<T, AK, BKC, EPI_STORE, NoProbe, CONV, GRP>(g, s, ws);      // (grouped: bias only)
+  if (GRP) {
+    // grouped: bias / ReLU, and for the data-gradient layout "+ residual" / the ReLU-backward gate (the general
+    // fallback of the parity-class launch)
+    if constexpr (CONV == CONV_A && !BKC) {
+      if (g.residual) return launch<T, AK, BKC, EPI_RES, NoProbe, CONV, GRP>(g, s, ws);
+    }
+    return launch<T, AK, BKC, EPI_STORE, NoProbe, CONV, GRP>(g, s, ws);
+  }
   if (g.residual) return launch<T, AK, BKC, EPI_RES, NoProbe, CONV>(g, s, ws);
   return launch<T, AK, BKC, EPI_STORE, NoProbe, CONV>(g, s, ws);
 }
-// one parity class of a stride-2 data gradient (K-outer weights, row-mapped result; "+ residual" with the same map)
+// the parity-class data gradient of a stride-2 convolution (K-outer weights, row-mapped result; "+ residual" / the
+// ReLU-backward gate with the same map)
 template <class T, bool GRP>
 int parity_launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
   if (g.residual) return launch<T, true, false, EPI_RES, NoProbe, CONV_A, GRP, true>(g, s, ws);
@@ -206,7 +216,8 @@ int parity_launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
 template <int CONV, bool AK, bool BKC>
 int conv_dispatch(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
   if (g.conv.a_group) {        // grouped: separate instantiations (see glds16<FORCE_UNIFORM>)
-    if (g.residual || (g.flags & ~AIT_GEMM_RELU)) return AIT_EUNSUPPORTED;
+    if ((g.residual || (g.flags & ~AIT_GEMM_RELU)) && !(CONV == CONV_A && !BKC)) return AIT_EUNSUPPORTED;
+    if (g.M <= 128) return conv_launch<TileS, CONV, AK, BKC, true>(g, s, ws);
     return conv_launch<Tile256D, CONV, AK, BKC, true>(g, s, ws);
   }
   const long long tiles256 = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128) * g.splits;
@@ -238,68 +249,65 @@ AIT_API int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_
   return conv_dispatch<CONV_A, true, true>(g, ait_stream(stream), sched_ws_of(ctx));
 }
 
-// Data gradient of a STRIDE-2 convolution as up to four launches, one per parity class (py, px) of the input
-// positions: class rows (2ya + py, 2xa + px) are reached only by the window taps ty = (py + pad) mod 2 (+ 2, + 4 ...),
-// so a 3x3 window has 1 / 2 / 2 / 4 taps per class instead of 9 mostly-zero ones (45 GFLOP executed instead of 181 on
-// the SK block's 3x3 branch), and a 1x1 window has one tap in class (0, 0) and none elsewhere.  A class without
-// taps receives zero -- or keeps `residual` when that is dx itself (accumulating into a gradient in place).
-namespace {
-__global__ void zero_rows_kernel(float* dx, int lddx, int n_cols4, long long rows, ConvGeom cg) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * n_cols4) return;
-  const int r = (int)(i / n_cols4), c4 = (int)(i - (long long)r * n_cols4);
-  reinterpret_cast<float4*>(dx + (size_t)conv_out_row(cg, r) * lddx)[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-int conv_bwd_data_stride2(const float* dy, int lddy, const float* w, const ait_conv_geom* q, int cin, int cout,
-                          const float* residual, int flags, float* dx, int lddx, const float* zeros,
-                          const ait_launch_ctx* ctx, void* stream) {
+// Data gradient of a STRIDE-2 convolution by parity class of the input positions, ONE launch (ConvGeom, gemm_f32_impl.h):
+// class rows (2ya + py, 2xa + px) are reached only by the window taps ty = (py + pad) mod 2 (+ 2 ...), so a 3x3 window
+// has 1 / 2 / 2 / 4 taps per class instead of 9 mostly-zero ones (45 GFLOP executed instead of 181 on the SK block's
+// 3x3 branch).  Optionally a SECOND convolution of the same input whose stride-2 window is 1x1 (it reaches class (0, 0)
+// only) rides along as one more tap of that class: dx = conv3^T(dy) + conv1^T(dy1).  Returns AIT_EUNSUPPORTED where the
+// decomposition does not apply (a class without taps, class rows not a multiple of the tile): the caller falls back
+// to the gather over all taps.
+int ait_conv_bwd_data_s2(const float* dy, int lddy, const float* w, const ait_conv_geom* q, const float* dy1, int lddy1,
+                         const float* w1, int cin, int cout, const float* residual, int flags, float* dx, int lddx,
+                         const float* zeros, const ait_launch_ctx* ctx, void* stream) {
   const int G = q->groups > 1 ? q->groups : 1, cing = cin / G, coutg = cout / G;
+  if (q->stride != 2 || (q->in_h & 1) || (q->in_w & 1)) return AIT_EUNSUPPORTED;
   const int ch = q->in_h / 2, cw = q->in_w / 2;                 // the class grid
+  if (ch != 4 || cw != 4) return AIT_EUNSUPPORTED;              // (the epilogue's constant row offsets: 8x8 maps, the SK block's)
   const int hw = log2_exact(ch * cw), wsft = log2_exact(cw);
   const int img_shift = log2_exact(q->in_h * q->in_w), y_shift = log2_exact(2 * q->in_w);
   if (hw < 0 || wsft < 0 || img_shift < 0 || y_shift < 0) return AIT_EUNSUPPORTED;
-  const long long rows = (long long)q->n * ch * cw;
-  if (rows > 0x7fffffffLL / 4) return AIT_EINVAL;
+  const long long class_rows = (long long)q->n * ch * cw;
+  if (class_rows * 4 > 0x7fffffffLL / 4) return AIT_EINVAL;
+  const bool big = class_rows % 256 == 0 && (G > 1 || class_rows * 4 / 256 * ((cin + 127) / 128) >= 256);
+  const bool small = G > 1 && !big && class_rows % 64 == 0;            // grouped, a few rows: 64-row tiles
+  if (!big && !small && (G > 1 || class_rows % 128 != 0)) return AIT_EUNSUPPORTED;
+  ConvGeom cg = make_geom(hw, wsft, q->out_h, q->out_w, 1, 1, -1, 0, 0, coutg, (long long)cing, zeros, G > 1 ? coutg : 0, cing);
+  cg.bm_shift = big ? 8 : (small ? 6 : 7);
+  cg.wt_kw = q->kw;
+  cg.out_img_shift = img_shift; cg.out_y_shift = y_shift;
+  cg.A2 = dy1; cg.B2 = w1; cg.lda2 = lddy1; cg.ldb2 = cing; cg.a2_class = -1;
+  int kmax = 0;
+  double flops = 0.0;
+  // class order: heaviest first (odd, odd) ... lightest last (even, even): the tile list interleaves them anyway
+  const int order[4][2] = {{1, 1}, {1, 0}, {0, 1}, {0, 0}};
+  for (int c = 0; c < 4; c++) {
+    const int py = order[c][0], px = order[c][1];
+    const int ty0 = (py + q->pad) & 1, tx0 = (px + q->pad) & 1;
+    const int nty = ty0 < q->kh ? (q->kh - ty0 + 1) / 2 : 0, ntx = tx0 < q->kw ? (q->kw - tx0 + 1) / 2 : 0;
+    if (nty * ntx == 0) return AIT_EUNSUPPORTED;
+    ConvGeom::ParityClass& pc = cg.cls[c];
+    pc.cy = (py + q->pad - ty0) / 2; pc.cx = (px + q->pad - tx0) / 2;
+    pc.kw = ntx; pc.ntaps = nty * ntx; pc.wt_y0 = ty0; pc.wt_x0 = tx0;
+    pc.out_base = py * q->in_w + px;
+    pc.k_end = pc.ntaps * coutg;
+    if (dy1 && py == 0 && px == 0) { pc.k_end += coutg; cg.a2_class = c; }
+    if (pc.k_end > kmax) kmax = pc.k_end;
+    flops += 2.0 * class_rows * cin * pc.k_end;
+  }
+  if (dy1 && (!w1 || cg.a2_class < 0 || q->pad * 2 + 1 != q->kh)) return AIT_EINVAL;    // (the 1x1 sits at the window centre)
+  GemmArgs g;
+  AIT_TRY_RC(make_args(0, 0, (int)(class_rows * 4), cin, kmax, 1.f, dy, lddy, w, q->kh * q->kw * cing, dx, lddx, nullptr, residual,
+                       flags, 1, 0, 0, 16, g));
+  g.conv = cg;
   hipStream_t s = ait_stream(stream);
-  const SchedWs ws = sched_ws_of(ctx);
-  for (int py = 0; py < 2; py++)
-    for (int px = 0; px < 2; px++) {
-      const int ty0 = (py + q->pad) & 1, tx0 = (px + q->pad) & 1;
-      const int nty = ty0 < q->kh ? (q->kh - ty0 + 1) / 2 : 0, ntx = tx0 < q->kw ? (q->kw - tx0 + 1) / 2 : 0;
-      ConvGeom cg = make_geom(hw, wsft, q->out_h, q->out_w, ntx > 0 ? ntx : 1, 1, -1, (py + q->pad - ty0) / 2, 0, coutg,
-                              (long long)cing, zeros, G > 1 ? coutg : 0, cing);
-      cg.cx = (px + q->pad - tx0) / 2;
-      cg.wt_y0 = ty0; cg.wt_x0 = tx0; cg.wt_step = 2; cg.wt_kw = q->kw;
-      cg.rowmap = 1; cg.out_img_shift = img_shift; cg.out_y_shift = y_shift; cg.out_x_shift = 1;
-      cg.out_base = py * q->in_w + px;
-      if (nty * ntx == 0) {
-        if (residual == dx && !(flags & AIT_GEMM_MASK_POS)) continue;      // accumulating in place: nothing to add
-        if (residual && !(flags & AIT_GEMM_MASK_POS)) return AIT_EUNSUPPORTED;
-        // (no taps, or a gated zero: zero either way)
-        const long long n4 = rows * (cin / 4);
-        hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dx, lddx, cin / 4, rows, cg);
-        AIT_CHECK_LAUNCH();
-        continue;
-      }
-      GemmArgs g;
-      AIT_TRY_RC(make_args(0, 0, (int)rows, cin, nty * ntx * coutg, 1.f, dy, lddy, w, q->kh * q->kw * cing, dx, lddx, nullptr,
-                           residual, flags, 1, 0, 0, 16, g));
-      // (make_args bounds the PLAIN output extent; the row map reaches rows * 4 positions)
-      if ((unsigned long long)rows * 4ull * (unsigned long long)lddx >= (1ull << 31)) return AIT_EUNSUPPORTED;
-      g.conv = cg;
-      AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cin * nty * ntx * coutg, s, (int)rows, cin,
-                          nty * ntx * coutg, 0, 0, 1);
-      int rc;
-      const long long tiles256 = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128);
-      if (G > 1) rc = parity_launch<Tile256D, true>(g, s, ws);
-      else if (tiles256 >= 512 || (tiles256 >= 96 && g.K >= 512 && ws.p != nullptr)) rc = parity_launch<Tile256D, false>(g, s, ws);
-      else rc = parity_launch<Tile128D, false>(g, s, ws);
-      if (rc != AIT_OK) return rc;
-    }
-  return AIT_OK;
+  SchedWs ws = sched_ws_of(ctx);
+  AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, flops, s, (int)(class_rows * 4), cin, (int)(flops / (2.0 * class_rows * 4 * cin)),
+                      0, 0, 1);
+  if (small) return parity_launch<TileS, true>(g, s, ws);
+  if (G > 1) return parity_launch<Tile256D, true>(g, s, ws);
+  if (big) return parity_launch<Tile256D, false>(g, s, ws);
+  return parity_launch<Tile128D, false>(g, s, ws);
 }
-}  // namespace
 
 AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, const ait_conv_geom* q, int cin, int cout,
                                   const float* residual, int flags, float* dx, int lddx, const float* zeros,
@@ -312,9 +320,11 @@ AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, con
   if (rows > 0x7fffffffLL / 4 || !dy || !w || !dx || !zeros || zeros_floats < (size_t)cout + 144) return AIT_EINVAL;
   if (flags & ~AIT_GEMM_MASK_POS) return AIT_EINVAL;
   const int taps = q->kh * q->kw, G = q->groups > 1 ? q->groups : 1, cing = cin / G, coutg = cout / G;
-  if (q->stride == 2 && !(q->in_h & 1) && !(q->in_w & 1) && log2_exact(q->in_h * q->in_w / 4) >= 0 &&
-      log2_exact(q->in_w / 2) >= 0)
-    return conv_bwd_data_stride2(dy, lddy, w, q, cin, cout, residual, flags, dx, lddx, zeros, ctx, stream);
+  if (q->stride == 2) {        // by parity class of the input positions where that applies
+    const int rc2 = ait_conv_bwd_data_s2(dy, lddy, w, q, nullptr, 0, nullptr, cin, cout, residual, flags, dx, lddx, zeros, ctx,
+                                         stream);
+    if (rc2 != AIT_EUNSUPPORTED) return rc2;
+  }
   GemmArgs g;
   // B is addressed per tap (retap): K-outer rows (t, co) at w + t*cin/G + co*(taps*cin/G)
   AIT_TRY_RC(make_args(0, 0, (int)rows, cin, taps * coutg, 1.f, dy, lddy, w, taps * cing, dx, lddx, nullptr, residual, flags, 1,

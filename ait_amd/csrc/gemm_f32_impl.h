@@ -46,33 +46,72 @@ struct ConvGeom {
   // of them per group (a tile never straddles two), and the gathered operand's channels of that group start
   // a_group floats further per group
   int a_group, n_group;
-  // ---- the data gradient of a STRIDE-2 convolution, one launch per parity class (py, px) of the input positions:
-  // the GEMM rows are the positions (2ya + py, 2xa + px) of ONE class, the taps are the window taps that can reach
-  // that class (1, 2, 2 or 4 of 9 for a 3x3 window), the source position of tap (t'y, t'x) is (ya + c - t'y,
-  // xa + cx - t'x) with per-axis offsets, its weights are those of window tap (wt_y0 + 2 t'y, wt_x0 + 2 t'x), and
-  // the result row r lands on row rowmap(r) of dx.  Nothing is multiplied by a structural zero.
-  int cx;                               // `c` of the x axis (c is the y axis')
-  int wt_y0, wt_x0, wt_step, wt_kw;     // window tap of GEMM tap (t'y, t'x): (wt_y0 + wt_step t'y) * wt_kw + wt_x0 + wt_step t'x
-  int rowmap;                           // != 0: C / residual row of GEMM row r = (img, y, x) is
-  int out_img_shift, out_y_shift, out_x_shift, out_base;   //   (img << out_img_shift) + (y << out_y_shift) + (x << out_x_shift) + out_base
+  // ---- the data gradient of a STRIDE-2 convolution by parity class (py, px) of the input positions (ROWMAP kernels):
+  // a class holds the positions (2ya + py, 2xa + px); only the window taps ty = (py + pad) mod 2 (+ 2 ...) reach it
+  // (1, 2, 2 or 4 of a 3x3 window's 9), the source position of class tap (t'y, t'x) is (ya + cy - t'y, xa + cx - t'x),
+  // its weights are those of window tap (wt_y0 + 2 t'y, wt_x0 + 2 t'x), and the result lands on row
+  // (img << out_img_shift) + (ya << out_y_shift) + (xa << 1) + out_base of dx.  Nothing multiplies a structural zero.
+  // The GEMM rows interleave the classes TILE by tile (row tile tm holds class tm & 3, its rows tm >> 2 of that class),
+  // so that every XCD's share of the tile list mixes light and heavy classes; a tile's reduction length is its class's.
+  // One class (a2_class, or -1) may carry one MORE tap whose operand is a second gradient tensor at the same
+  // positions (A2) with its own K-outer weights (B2): the 1x1 branch of the SK block, whose stride-2 data gradient
+  // only reaches class (0, 0) -- both branches' input gradient in one launch.
+  struct ParityClass { int cy, cx, kw, ntaps, wt_y0, wt_x0, out_base, k_end; };
+  ParityClass cls[4];
+  int bm_shift;                         // log2(BM) of the launching tile
+  int wt_kw;                            // taps per row of the WINDOW (weights)
+  int out_img_shift, out_y_shift;
+  const float* A2;
+  const float* B2;
+  int lda2, ldb2, a2_class;
 };
-enum { CONV_NONE = 0, CONV_A = 1, CONV_B = 2 };
 
-// C / residual row of GEMM row r under the row map of a parity-class data gradient
-__device__ __forceinline__ unsigned conv_out_row(const ConvGeom& c, int r) {
-  const int img = r >> c.rows_hw_shift, rem = r & ((1 << c.rows_hw_shift) - 1);
-  const int y = rem >> c.rows_w_shift, x = rem & ((1 << c.rows_w_shift) - 1);
-  return (unsigned)((img << c.out_img_shift) + (y << c.out_y_shift) + (x << c.out_x_shift) + c.out_base);
+// class k's parameters by constant-index selects (a run-time index into the kernel-argument struct would send the whole
+// struct to scratch memory)
+__device__ __forceinline__ ConvGeom::ParityClass pick_class(const ConvGeom& c, int k) {
+#define AIT_PICK(f) (k == 0 ? c.cls[0].f : k == 1 ? c.cls[1].f : k == 2 ? c.cls[2].f : c.cls[3].f)
+  ConvGeom::ParityClass r;
+  r.cy = AIT_PICK(cy); r.cx = AIT_PICK(cx); r.kw = AIT_PICK(kw); r.ntaps = AIT_PICK(ntaps);
+  r.wt_y0 = AIT_PICK(wt_y0); r.wt_x0 = AIT_PICK(wt_x0); r.out_base = AIT_PICK(out_base); r.k_end = AIT_PICK(k_end);
+#undef AIT_PICK
+  return r;
 }
+// (class, row within the class) of GEMM row r under the tile-interleaved order
+__device__ __forceinline__ void parity_row(const ConvGeom& c, int r, int& cls, int& rr) {
+  const int tm = r >> c.bm_shift;
+  cls = tm & 3;
+  rr = ((tm >> 2) << c.bm_shift) | (r & ((1 << c.bm_shift) - 1));
+}
+// source row of class tap `tap` for class row rr (or -1), and the window tap whose weights it multiplies
+__device__ __forceinline__ int parity_src_row(const ConvGeom& c, const ConvGeom::ParityClass& pc, int rr, int tap, int& wtap) {
+  const int img = rr >> c.rows_hw_shift, rem = rr & ((1 << c.rows_hw_shift) - 1);
+  const int y = rem >> c.rows_w_shift, x = rem & ((1 << c.rows_w_shift) - 1);
+  const int ty = tap / pc.kw, tx = tap - ty * pc.kw;
+  const int sy = y + pc.cy - ty, sx = x + pc.cx - tx;
+  wtap = (pc.wt_y0 + 2 * ty) * c.wt_kw + pc.wt_x0 + 2 * tx;
+  const bool ok = sy >= 0 && sx >= 0 && sy < c.src_h && sx < c.src_w;
+  return ok ? (img * c.src_h + sy) * c.src_w + sx : -1;
+}
+enum { CONV_NONE = 0, CONV_A = 1, CONV_B = 2 };
 
 __device__ __forceinline__ int conv_src_row(const ConvGeom& c, int r, int tap) {
   const int img = r >> c.rows_hw_shift, rem = r & ((1 << c.rows_hw_shift) - 1);
   const int y = rem >> c.rows_w_shift, x = rem & ((1 << c.rows_w_shift) - 1);
   const int ty = tap / c.kw, tx = tap - ty * c.kw;
-  const int ny = y * c.a + c.c + ty * c.b, nx = x * c.a + c.cx + tx * c.b;
+  const int ny = y * c.a + c.c + ty * c.b, nx = x * c.a + c.c + tx * c.b;
   const int sy = ny >> c.div_shift, sx = nx >> c.div_shift;
   const bool ok = ny >= 0 && nx >= 0 && ((ny | nx) & ((1 << c.div_shift) - 1)) == 0 && sy < c.src_h && sx < c.src_w;
   return ok ? (img * c.src_h + sy) * c.src_w + sx : -1;
+}
+
+// C / residual row of GEMM row r of a parity-class data gradient
+__device__ __forceinline__ unsigned conv_out_row(const ConvGeom& c, int r) {
+  int cls, rr;
+  parity_row(c, r, cls, rr);
+  const int img = rr >> c.rows_hw_shift, rem = rr & ((1 << c.rows_hw_shift) - 1);
+  const int y = rem >> c.rows_w_shift, x = rem & ((1 << c.rows_w_shift) - 1);
+  const int ob = cls == 0 ? c.cls[0].out_base : cls == 1 ? c.cls[1].out_base : cls == 2 ? c.cls[2].out_base : c.cls[3].out_base;
+  return (unsigned)((img << c.out_img_shift) + (y << c.out_y_shift) + (x << 1) + ob);
 }
 
 struct GemmArgs {
@@ -115,7 +154,10 @@ enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
 //   KNOB_PRIO   the second-dispatched half of the workgroup's waves runs at s_setprio 1
 //   KNOB_SPREAD the LDS reads of the next k-step group are issued one 32-row tile at a time ahead of each
 //               MFMA step instead of all together in front of the group
-enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4 };
+//   KNOB_STAGGER the workgroup in an odd threadgroup slot of its CU (HW_ID.tg_id) starts half a tile late: the two
+//               workgroups of a CU run the same program on tiles of the same length, so without it they reach their
+//               epilogues together and the matrix pipes idle through both
+enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8 };
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int MODE_ = MODE_DB, int NS_ = 3, int KNOBS_ = 0>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_, MODE = MODE_;
@@ -214,6 +256,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 // operand fetch, i.e. it serialises the slab's memory latency with the MFMA stream.  Ordering is
 // explicit instead: a slot is requested only after the barrier that retired its last reader, and
 // awaited (vmcnt) before the barrier that publishes it.
+__device__ __forceinline__ void glds16_at(const float* src, unsigned dst) {      // dst: wave-uniform LDS byte address
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "m0", "memory");
+}
 template <bool FORCE_UNIFORM = false>
 __device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
   // wave-uniform LDS address.  (FORCE_UNIFORM: the grouped-convolution instantiations, where hipcc loses the proof
@@ -278,12 +323,20 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
                                          int wm, int wn, int li, int lk) {
   const bool relu = (g.flags & AIT_GEMM_RELU) != 0;
   const unsigned ldc = (unsigned)g.ldc;
-  // element offset of the first column of GEMM row `row` (ROWMAP: the parity-class row map of ConvGeom)
-  auto roff = [&](int row) -> unsigned {
-    if constexpr (ROWMAP) return conv_out_row(g.conv, row) * ldc;
-    else return (unsigned)row * ldc;
-  };
   const bool interior = (m0 + wm + TM * 32 <= g.M) && (n0 + wn + TN * 32 <= g.N);   // wave-uniform
+  // Element offset of the first column of the row that holds accumulator register r of an MFMA tile whose first row
+  // (for this lane) is `rb`: tile_off(rb) + reg_off(r).  Plain: rows rb + (r&3) + 8*(r>>2).  ROWMAP (parity-class
+  // data gradient on 4 x 4 class grids): rb is a multiple of 4 with y = lane half, so register r sits at x = r & 3,
+  // y + 2 * ((r >> 2) & 1), image + (r >> 3) -- constant row offsets again, one row-map evaluation per tile.
+  auto tile_off = [&](int rb) -> unsigned {
+    if constexpr (ROWMAP) return conv_out_row(g.conv, rb) * ldc;
+    else return (unsigned)rb * ldc;
+  };
+  auto reg_off = [&](int r) -> unsigned {
+    if constexpr (ROWMAP)
+      return (unsigned)(((r >> 3) << g.conv.out_img_shift) + (((r >> 2) & 1) << (g.conv.out_y_shift + 1)) + ((r & 3) << 1)) * ldc;
+    else return (unsigned)(((r) & 3) + 8 * ((r) >> 2)) * ldc;
+  };
   // row r of an MFMA tile sits (r&3) + 8*(r>>2) rows below its first row
 #define AIT_ROW(r) (((r) & 3) + 8 * ((r) >> 2))
   const bool colsum = EPI != EPI_ATOMIC && (g.flags & AIT_GEMM_COLSUM) != 0;    // g.bias is then the OUTPUT
@@ -326,9 +379,15 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
     constexpr int NT_ = TM * TN;
     float x[16], xn[16], gt[gated ? 16 : 1], gn[gated ? 16 : 1];
     auto row_of = [&](int i, int r) { return m0 + wm + (i / TN) * 32 + 4 * lk + AIT_ROW(r); };
+    // offset of register r of MFMA tile i (loads clamp to the last row at a ragged bottom edge; the parity row map
+    // never has one: its row count is a multiple of the tile)
+    auto off_of = [&](int i, int r, bool clamp) -> unsigned {
+      if constexpr (ROWMAP) return cb[i % TN] + tile_off(m0 + wm + (i / TN) * 32 + 4 * lk) + reg_off(r);
+      else return cb[i % TN] + (unsigned)(clamp ? min(row_of(i, r), g.M - 1) : row_of(i, r)) * ldc;
+    };
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const unsigned o = cb[0] + roff(min(row_of(0, r), g.M - 1));
+      const unsigned o = off_of(0, r, true);
       x[r] = g.residual[o];
       if constexpr (gated) gt[r] = g.gate[o];
     }
@@ -338,7 +397,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
       if (i + 1 < NT_) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const unsigned o = cb[(i + 1) % TN] + roff(min(row_of(i + 1, r), g.M - 1));
+          const unsigned o = off_of(i + 1, r, true);
           xn[r] = g.residual[o];
           if constexpr (gated) gn[r] = g.gate[o];
         }
@@ -351,7 +410,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
         if constexpr (gated) v = gt[r] > 0.f ? v : 0.f;
         if (relu) v = fmaxf(v, 0.f);
         const int row = row_of(i, r);
-        if (interior || (cok[b] && row < g.M)) { g.C[cb[b] + roff(row)] = v; cs[b] += v; }
+        if (interior || (cok[b] && row < g.M)) { g.C[off_of(i, r, false)] = v; cs[b] += v; }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -421,10 +480,11 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
             for (int q = 0; q < 8; q++) v[q] = fmaxf(v[q], 0.f);
           }
           if constexpr (ROWMAP) {
+            const unsigned tb = cb[b] + tile_off(rbase);
 #pragma unroll
             for (int q = 0; q < 8; q++)
-              if (interior || (cok[b] && rbase + AIT_ROW(h * 8 + q) < g.M)) {
-                g.C[cb[b] + roff(rbase + AIT_ROW(h * 8 + q))] = v[q];
+              if (interior || cok[b]) {
+                g.C[tb + reg_off(h * 8 + q)] = v[q];
                 cs[b] += v[q];
               }
           } else if (interior) {
@@ -597,14 +657,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     ended = idq[0] < 0;
   }
   // whole item k of this workgroup -> id within the chunk's whole items, or -1 past the end
-  auto dp_id = [&](int k) -> int {
+  auto dp_id = [&](int k) __attribute__((always_inline)) -> int {
     if (dyn) return idq[k & 7];
     const int id = j + k * W;
     return id < lim_dp ? id : -1;
   };
   bool any = n_sk > 0 || dp_id(0) >= 0;
   // item it -> tile origin, K range; false past the end of this workgroup's work
-  auto get_item = [&](int it, int& m0, int& n0, int& kb, int& ke) -> bool {
+  auto get_item = [&](int it, int& m0, int& n0, int& kb, int& ke) __attribute__((always_inline)) -> bool {
     int id;
     const bool pieceB = n_sk == 2 && it == 0;        // (two pieces: the non-owned head of the next tile goes first)
     if (it < n_sk) id = skA_tile + (pieceB ? 1 : 0);
@@ -614,13 +674,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       id += sk_r;
     }
     wmap.decode(g, base + id, BM, BN, m0, n0, kb, ke);
+    if constexpr (ROWMAP) { kb = 0; ke = pick_class(g.conv, (m0 >> g.conv.bm_shift) & 3).k_end; }     // (never with stream-K pieces)
     if (it < n_sk) {                      // a piece: its sub-range of the item's K range
       ke = kb + (pieceB ? skB_ke : skA_ke);
       kb = kb + (pieceB ? 0 : skA_kb);
     }
     return true;
   };
-  auto leave = [&]() {          // exit protocol of the dynamic hand-out
+  auto leave = [&]() __attribute__((always_inline)) {          // exit protocol of the dynamic hand-out
     if (dyn && threadIdx.x == 0) {
       if (atomicAdd(ticket + 1, 1u) == (unsigned)W - 1u) {
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -629,6 +690,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     }
   };
   if (!any) { leave(); return; }
+  if constexpr ((C::KNOBS & KNOB_STAGGER) != 0) {
+    const unsigned hw = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);      // HW_ID
+    if ((hw >> 16) & 1u) {
+      // one tile of `ns` slabs takes a wave ns * 64 MFMAs * 64 cycles when it has the SIMD's matrix pipe to itself,
+      // twice that beside its partner: half a shared tile = ns * 4096 cycles
+      const unsigned long long wait = (unsigned long long)ns * 4096ull, t0 = __builtin_amdgcn_s_memtime();
+      while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(64);
+    }
+  }
   const int wm = (wave / C::WN) * (C::TM * 32), wn = (wave % C::WN) * (C::TN * 32);
   const int li = lane & 31, lk = lane >> 5;
 
@@ -640,15 +710,44 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   const float* pb[LB];
   const size_t step_a = AK ? 16 : (size_t)16 * g.lda;
   const size_t step_b = BKC ? 16 : (size_t)16 * g.ldb;
+  size_t step_b_cur = step_b;       // ROWMAP: the extra tap's weights have their own row pitch
   int l_item = 0, l_k = 0, l_kend = 0;
   int l_n0 = 0, l_m0 = 0;           // origin of the load cursor's tile (CONV kernels)
   int arow[LA];                     // CONV_A: this lane's (clamped) GEMM row per A transfer
   bool l_valid = true;
   // CONV_A: operand pointers at reduction index l_k = tap * seg + kin
-  auto retap = [&]() {
+  auto retap = [&]() __attribute__((always_inline)) {
     const int tap = l_k / g.conv.seg, kin = l_k - tap * g.conv.seg;
     int grp = 0, gch = 0;                          // GRP: the tile's group, its first channel in the gathered operand
     if constexpr (GRP) { grp = l_n0 / g.conv.n_group; gch = grp * g.conv.a_group; }
+    const int col0 = GRP ? l_n0 - grp * g.conv.n_group : l_n0;
+    const int cols = GRP ? g.conv.n_group : g.N;
+    if constexpr (ROWMAP) {
+      // parity-class data gradient: the tile's class decides taps, offsets and weights; its extra tap (if any) reads
+      // the second gradient tensor at the row's own position
+      const ConvGeom::ParityClass pc = pick_class(g.conv, (l_m0 >> g.conv.bm_shift) & 3);
+      const bool extra = tap >= pc.ntaps;           // (only reached in class a2_class: k_end says so)
+      step_b_cur = extra ? (size_t)16 * g.conv.ldb2 : step_b;
+      int wtap = 0;
+#pragma unroll
+      for (int i = 0; i < LA; i++) {
+        const int row = (wave + i * NW) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        if (extra) {
+          pa[i] = g.conv.A2 + (size_t)arow[i] * g.conv.lda2 + gch + kin + chunk * 4;
+        } else {
+          const int src = parity_src_row(g.conv, pc, arow[i], tap, wtap);
+          pa[i] = (src >= 0 ? g.A + (size_t)src * g.lda + gch : g.conv.zero) + kin + chunk * 4;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < LB; i++) {
+        const int e = (wave + i * NW) * 256 + lane * 4;
+        if (extra) pb[i] = g.conv.B2 + (size_t)(gch + kin + e / BN) * g.conv.ldb2 + min(col0 + e % BN, cols - 4);
+        else pb[i] = g.B + wtap * g.conv.b_tap_stride + (size_t)(gch + kin + e / BN) * g.ldb + min(col0 + e % BN, cols - 4);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < LA; i++) {
       const int row = (wave + i * NW) * 16 + (lane >> 2);
@@ -658,30 +757,29 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     }
     if (!BKC) {
       // K-outer weights [co][tap][ci]: rows = output channels (of the tile's group), columns within the tap
-      const int col0 = GRP ? l_n0 - grp * g.conv.n_group : l_n0;
-      const int cols = GRP ? g.conv.n_group : g.N;
-      // window tap whose weights GEMM tap `tap` multiplies (identity unless this is a parity-class data gradient)
-      const int tty = tap / g.conv.kw, ttx = tap - tty * g.conv.kw;
-      const int wtap = (g.conv.wt_y0 + g.conv.wt_step * tty) * g.conv.wt_kw + g.conv.wt_x0 + g.conv.wt_step * ttx;
 #pragma unroll
       for (int i = 0; i < LB; i++) {
         const int e = (wave + i * NW) * 256 + lane * 4;
-        pb[i] = g.B + wtap * g.conv.b_tap_stride + (size_t)(gch + kin + e / BN) * g.ldb + min(col0 + e % BN, cols - 4);
+        pb[i] = g.B + tap * g.conv.b_tap_stride + (size_t)(gch + kin + e / BN) * g.ldb + min(col0 + e % BN, cols - 4);
       }
     }
   };
-  auto set_tile = [&](int it) {
+  auto set_tile = [&](int it) __attribute__((always_inline)) {
     int m0, n0;
     if (!get_item(it, m0, n0, l_k, l_kend)) { l_valid = false; return; }
     l_n0 = n0;
-    if constexpr (GRP) l_m0 = m0;
+    if constexpr (GRP || ROWMAP) l_m0 = m0;
 #pragma unroll
     for (int i = 0; i < LA; i++) {
       const int q = wave + i * NW;
       if (AK) {
         const int row = q * 16 + (lane >> 2);
         const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        if (CONV == CONV_A) arow[i] = min(m0 + row, g.M - 1);
+        if constexpr (ROWMAP) {
+          int cls_, rr_;
+          parity_row(g.conv, min(m0 + row, g.M - 1), cls_, rr_);
+          arow[i] = rr_;
+        } else if (CONV == CONV_A) arow[i] = min(m0 + row, g.M - 1);
         else pa[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + l_k + chunk * 4;
       } else {
         const int e = q * 256 + lane * 4;            // element of the [16][BM] image
@@ -703,14 +801,40 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     }
     if (CONV == CONV_A) retap();
   };
-  // one 1-KB transfer of the cursor's slab (piece < LA: operand A, else B) into ring slot `slot`
-  auto issue = [&](int piece, int slot) {
+  // one 1-KB transfer of the cursor's slab (piece < LA: operand A, else B) into ring slot `slot`.  The LDS-DMA lands
+  // at a WAVE-UNIFORM base (+ lane * 16 B); in the grouped / parity kernels hipcc keeps the slot index in a vector
+  // register and would hand the base to the asm as a VGPR, so there the two bases of a slab (this wave's first A and
+  // first B granule) are made scalar ONCE per slab (slab_bases) and the per-transfer offsets are constants --
+  // a readfirstlane in front of every transfer halves the kernel's rate
+  struct Bases { unsigned a, b; int slot; };
+  constexpr bool kScalarBases = CONV != CONV_NONE;      // (the convolution kernels: more scalar state than hipcc keeps scalar)
+  auto slab_bases = [&](int slot) __attribute__((always_inline)) -> Bases {
+    Bases r;
+    r.slot = slot;
+    r.a = r.b = 0;
+    if constexpr (kScalarBases) {
+      r.a = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)(As + slot * SA + wave * 256));
+      r.b = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)(Bd + slot * SB + wave * 256));
+    }
+    return r;
+  };
+  // (the dense kernels keep the per-transfer scalar arithmetic hipcc has always proven uniform there)
+  auto dst_a = [&](const Bases& lb, int piece) __attribute__((always_inline)) -> unsigned {
+    if constexpr (kScalarBases) return lb.a + (unsigned)(piece * NW * 1024);
+    else return (unsigned)(size_t)(lds_void*)(As + lb.slot * SA + (wave + piece * NW) * 256);
+  };
+  auto dst_b = [&](const Bases& lb, int piece) __attribute__((always_inline)) -> unsigned {
+    if constexpr (kScalarBases) return lb.b + (unsigned)(piece * NW * 1024);
+    else return (unsigned)(size_t)(lds_void*)(Bd + lb.slot * SB + (wave + piece * NW) * 256);
+  };
+  auto issue = [&](int piece, const Bases& lb) __attribute__((always_inline)) {
     if (piece < LA) {
       const int q = wave + piece * NW;
-      if (GA % NW == 0 || q < GA) glds16<GRP || ROWMAP || (CONV == CONV_A && !BKC)>(pa[piece], As + slot * SA + q * 256);
+      if (GA % NW == 0 || q < GA) glds16_at(pa[piece], dst_a(lb, piece));
     } else {
       const int q = wave + (piece - LA) * NW;
       if (GB % NW == 0 || q < GB) {
+        const unsigned dst = dst_b(lb, piece - LA);
         if (CONV == CONV_B) {
           // weight gradient: row k of the K-outer operand is the source position that tap (fixed by the
           // column tile) pairs with GEMM row k; nothing to pair with -> the row of zeros
@@ -718,19 +842,19 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           const int tap = l_n0 / g.conv.seg, ch0 = l_n0 - tap * g.conv.seg;
           const int gch = GRP ? (l_m0 / g.conv.n_group) * g.conv.a_group : 0;   // the row tile's group
           const int src = conv_src_row(g.conv, l_k + e / BN, tap);
-          glds16<GRP || ROWMAP || (CONV == CONV_A && !BKC)>((src >= 0 ? g.B + (size_t)src * g.ldb + gch + ch0 : g.conv.zero) + e % BN, Bd + slot * SB + q * 256);
+          glds16_at((src >= 0 ? g.B + (size_t)src * g.ldb + gch + ch0 : g.conv.zero) + e % BN, dst);
         } else {
-          glds16<GRP || ROWMAP || (CONV == CONV_A && !BKC)>(pb[piece - LA], Bd + slot * SB + q * 256);
+          glds16_at(pb[piece - LA], dst);
         }
       }
     }
   };
-  auto advance = [&]() {             // cursor -> next slab of the stream (possibly the next tile's first)
+  auto advance = [&]() __attribute__((always_inline)) {             // cursor -> next slab of the stream (possibly the next tile's first)
 #pragma unroll
     for (int i = 0; i < LA; i++) pa[i] += step_a;
     if (CONV != CONV_B) {
 #pragma unroll
-      for (int i = 0; i < LB; i++) pb[i] += step_b;
+      for (int i = 0; i < LB; i++) pb[i] += ROWMAP ? step_b_cur : step_b;
     }
     l_k += BK;
     if (l_k >= l_kend) {
@@ -740,9 +864,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       if (l_k % g.conv.seg == 0) retap();      // next tap: new source rows (and, K-outer weights, new tap base)
     }
   };
-  auto request = [&](int slot) {     // whole slab at once (prologue)
+  auto request = [&](int slot) __attribute__((always_inline)) {     // whole slab at once (prologue)
+    const Bases lb = slab_bases(slot);
 #pragma unroll
-    for (int i = 0; i < LA + LB; i++) issue(i, slot);
+    for (int i = 0; i < LA + LB; i++) issue(i, lb);
     advance();
   };
 
@@ -779,7 +904,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
 
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       const int nxt = (cur == NS - 1) ? 0 : cur + 1;
-      const int nxt2 = (cur == 0) ? NS - 1 : cur - 1;      // the slot iteration s-1 finished reading
+      // the slot iteration s-1 finished reading.  (Grouped / parity kernels: hipcc keeps `cur` in a vector register
+      // there and would hand the LDS-DMA's wave-uniform base to the asm as a VGPR; ONE readfirstlane per slab puts the
+      // slot back into a scalar -- forcing every transfer's address through readfirstlane halves the kernel's rate)
+      const int nxt2 = (cur == 0) ? NS - 1 : cur - 1;
+      const Bases lbase = slab_bases(nxt2);
       // The transfers of slab s+NS-1 are issued one at a time BETWEEN the MFMA steps, not in a burst at
       // the top of the iteration: right after the barrier every wave of the CU would be issuing them
       // at once (an LDS-DMA costs its wave 60-180 cycles of issue) with no wave left to feed the
@@ -797,7 +926,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       if constexpr ((C::KNOBS & KNOB_BURST) != 0) {
         if (feed) {
 #pragma unroll
-          for (int i = 0; i < NP; i++) issue(i, nxt2);
+          for (int i = 0; i < NP; i++) issue(i, lbase);
         }
       }
 #pragma unroll
@@ -836,7 +965,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           const int piece = grp * 4 + j;       // one transfer behind each of the first NP MFMA steps
           if ((C::KNOBS & KNOB_BURST) == 0 && piece < NP) {
             __builtin_amdgcn_sched_barrier(0);
-            if (feed) issue(piece, nxt2);
+            if (feed) issue(piece, lbase);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -851,17 +980,17 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       // of 3 it is the one requested in this iteration (wait for everything); with 4 it was requested one
       // iteration ago and the one requested now stays in flight (counted wait) -- unless nothing was
       // requested now (end of the stream)
-      auto slab_wait = [&]() {
+      auto slab_wait = [&]() __attribute__((always_inline)) {
         if (NS == 4 && feed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       };
-      auto land = [&]() {              // behind the slab wait, in front of the barrier
+      auto land = [&]() __attribute__((always_inline)) {              // behind the slab wait, in front of the barrier
         if (draw) {
           asm volatile("s_waitcnt vmcnt(0)" : "+v"(drawn) : : "memory");     // (the ticket: with a ring of 4 the slab wait is counted)
           if (threadIdx.x == 0) idq[n_fetched & 7] = (int)drawn < lim_dp ? (int)drawn : -1;
         }
       };
-      auto landed = [&]() {            // behind the barrier: every wave learns the ticket
+      auto landed = [&]() __attribute__((always_inline)) {            // behind the barrier: every wave learns the ticket
         if (draw) { ended = idq[n_fetched & 7] < 0; n_fetched++; }
       };
       if constexpr (Probe::on) {
@@ -1235,8 +1364,12 @@ int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int 
       // (a ticket lands one iteration after it is drawn, and the prologue fills the slab ring from the first
       // item alone: every whole item must outlast both -- eight slabs is comfortably more than either)
       const int kps = g.splits > 1 ? g.k_per_split : g.K, klast = g.K - (g.splits - 1) * kps;
-      if (kps >= 128 && klast >= 128) gl.sched = ws.sched();
-      if (EPI != EPI_ATOMIC && g.splits == 1 && g.K % 16 == 0 && rem > 0 && sk_pays) {
+      int kmin = kps < klast ? kps : klast;
+      if constexpr (ROWMAP) {
+        for (int c = 0; c < 4; c++) kmin = g.conv.cls[c].k_end < kmin ? g.conv.cls[c].k_end : kmin;
+      }
+      if (kmin >= 128) gl.sched = ws.sched();
+      if (EPI != EPI_ATOMIC && !ROWMAP && g.splits == 1 && g.K % 16 == 0 && rem > 0 && sk_pays) {
         if (ws.bytes < kCtlBytes + (size_t)wfull * AIT_NXCD * C::BM * C::BN * sizeof(float)) return AIT_EWORKSPACE;
         gl.sk_on = 1;
         gl.sk_ws = ws.partials();

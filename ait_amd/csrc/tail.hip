@@ -406,8 +406,15 @@ AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const floa
     if (sd.g->b1) AIT_TRY(ait_colsum_f32(a1, rows, C, C, sd.g->b1, stream));
     if (sd.g->b3) AIT_TRY(ait_colsum_f32(a3, rows, C, C, sd.g->b3, stream));
     if (sd.dx) {
-      AIT_TRY(ait_conv_bwd_data_f32(a3, C, sd.w->w3, &q3, C, C, nullptr, 0, sd.dx, C, s.zeros, kZeros, ctx, stream));
-      AIT_TRY(ait_conv_bwd_data_f32(a1, C, sd.w->w1, &q1, C, C, sd.dx, 0, sd.dx, C, s.zeros, kZeros, ctx, stream));   // += in place
+      // both branches' input gradient in ONE launch: by parity class of the 8x8 positions, the 1x1 branch as one more
+      // tap of class (even, even) (gemm_f32.hip); two calls (3x3, then the 1x1 accumulated in place) where that
+      // does not apply (row counts that are not a multiple of the tile)
+      int rc = ait_conv_bwd_data_s2(a3, C, sd.w->w3, &q3, a1, C, sd.w->w1, C, C, nullptr, 0, sd.dx, C, s.zeros, ctx, stream);
+      if (rc == AIT_EUNSUPPORTED) {
+        AIT_TRY(ait_conv_bwd_data_f32(a3, C, sd.w->w3, &q3, C, C, nullptr, 0, sd.dx, C, s.zeros, kZeros, ctx, stream));
+        rc = ait_conv_bwd_data_f32(a1, C, sd.w->w1, &q1, C, C, sd.dx, 0, sd.dx, C, s.zeros, kZeros, ctx, stream);     // (+= in place)
+      }
+      AIT_TRY(rc);
     }
   }
   return AIT_OK;

@@ -37,6 +37,7 @@ using V_128r4 = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, 0>;             // 64 K
 using V_sp8 = Cfg<256, 128, 16, 4, 2, 4, MODE_DLDS, 3, KNOB_SPREAD>;    // 8 waves, LDS reads spread over the MFMA steps
 using V_sp4 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD>;    // 4 waves, same
 using V_256sq = Cfg<256, 256, 16, 4, 4, 4, MODE_DLDS, 3, 0>;             // 16 waves, 96 KB: one workgroup per CU
+using V_stag = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD | KNOB_STAGGER>;   // the product tile, odd threadgroup slots start half a tile late
 #ifndef NO_OLD
 using OldD = ait_gemm_old::Cfg<256, 128, 16, 4, 2, 2, 6 + 256>;
 using OldD4 = ait_gemm_old::Cfg<256, 128, 16, 2, 2, 2, 6 + 256>;
@@ -78,6 +79,11 @@ static const Shape SHAPES[] = {
     {"l4c2  NT", 19200, 512, 4608, 0, 1, 1, AIT_GEMM_RELU},               // layer4 3x3 as a plain GEMM
     {"l4dx  NN", 19200, 2048, 512, 0, 0, 1, LAB_RES},
     {"coatt NT", 9576, 512, 1024, 0, 1, 1, 0},
+    // layer4 weight gradients at one K-range per XCD (their last round is cut evenly without scratch)
+    {"l4w2  TN", 512, 4608, 19328, 1, 0, 8, 0},
+    {"l4w3  TN", 2048, 512, 19328, 1, 0, 8, 0},
+    {"l4w1  TN", 512, 2048, 19328, 1, 0, 8, 0},
+    {"qkvw8 TN", 1536, 512, 76800, 1, 0, 8, 0},
 };
 static const int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 
@@ -152,7 +158,7 @@ static int run_tile(const GemmArgs& g, bool ak, bool bk, int slots) {
   return run_epi<T, false, true, NoProbe>(g, slots);
 }
 static const char* VNAMES[] = {"old", "new", "probe", "burst", "prio", "ring4", "ring4+burst", "4waves", "4waves+burst",
-                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK"};
+                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag"};
 template <class Probe>
 static int run_new(const GemmArgs& g, bool ak, bool bk, int slots) {
   if (!ak && !bk) return run_epi<NewD4, false, false, Probe>(g, slots);
@@ -201,6 +207,7 @@ static int run(Problem& p, int variant, float* out) {
       g_use_ws = true;
       return rc;
     }
+    case 15: return run_tile<V_stag>(g, ak, bk, g_slots);
     default: break;
   }
 #ifndef NO_OLD

@@ -412,7 +412,7 @@ def test_anchor_target_kernels_equal_the_tensor_expressions(monkeypatch):
         assert int((outs[True][0] == 1).sum()) > 0 and int((outs[True][0] == 0).sum()) > 0
 
 
-@pytest.mark.parametrize("n,k,stride,pad", [(300, 3, 2, 1), (300, 1, 2, 0), (80, 3, 1, 1)])
+@pytest.mark.parametrize("n,k,stride,pad", [(300, 3, 2, 1), (300, 1, 2, 0), (80, 3, 1, 1), (4, 3, 2, 1), (8, 1, 2, 0), (16, 3, 2, 1)])
 def test_grouped_implicit_gemm_convolutions_vs_torch(n, k, stride, pad):
     """The SK block's grouped convolutions (8 groups of 128 channels, blocks_sys_transformer_sk_dilat.py:938-947)
     on the implicit-GEMM kernels -- forward with bias, data and weight gradients -- against torch's grouped
@@ -441,8 +441,10 @@ def test_grouped_implicit_gemm_convolutions_vs_torch(n, k, stride, pad):
     dw = ops.conv_bwd_weight(dy, xm, geom, k, k, split_k=16)
     dw_ref = wd.grad.permute(0, 2, 3, 1)
     assert float((dw.double() - dw_ref).abs().max()) <= 5e-5 * float(dw_ref.abs().max()) + 1e-6
-    # accumulating into a gradient in place (residual is dx itself: the second branch of the SK block), and the
-    # ReLU-backward gate
+    if stride != 2:
+        return
+    # stride 2 (the parity-class launches): accumulating into a gradient in place (residual is dx itself: the second
+    # branch of the SK block), and the ReLU-backward gate
     base = torch.randn_like(dx)
     acc = base.clone()
     ops.conv_bwd_data(dy, wm, geom, residual=acc, out=acc)
@@ -500,7 +502,10 @@ def test_proposal_tail_node_matches_the_module_composition(monkeypatch, bp, bs):
     x0 = torch.randn(bp, 1024, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
     q0 = torch.randn(bs, 1024, 8, 8, device="cuda")
     cot_p, cot_q = torch.randn(bp, 2048, device="cuda"), torch.randn(bs, 2048, device="cuda")
-    names = [n for n, _ in m.named_parameters() if n.startswith(("sk.sk_props.convs", "sk.sk_query.convs", "RCNN_top."))
+    # (layer4 is registered twice -- RCNN_base.backbone.layer4 and RCNN_top.0 are the same modules, as in the
+    # reference -- and named_parameters() reports it under its first name)
+    names = [n for n, _ in m.named_parameters()
+             if n.startswith(("sk.sk_props.convs", "sk.sk_query.convs", "RCNN_base.backbone.layer4.", "RCNN_top."))
              and "bn" not in n and "downsample.1" not in n]
     res = {}
     for fused in (True, False):

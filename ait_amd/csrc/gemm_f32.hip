@@ -48,7 +48,8 @@ using namespace ait_gemm;
 //   Tile128    128x128 register-staged double buffer: outputs with few rows.
 //   TileN64    256x64 for the 64-column SHBlock / fc products (no dead half tile).
 //   Tile64     64x64 for few-tile problems (the bs*64-row query side): latency, not throughput.
-using Tile256D = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD>;
+using Tile256D = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT>;
+using Tile256N = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD>;      // the same tile on v_mfma_f32_32x32x2_f32 (ait_gemm_f32_products(0))
 using Tile256 = Cfg<256, 128, 16, 4, 2, 2, MODE_RING>;
 using Tile128 = Cfg<128, 128, 16, 2, 2, 2, MODE_DB>;
 using TileN64 = Cfg<256, 64, 16, 4, 1, 2, MODE_DB>;
@@ -153,10 +154,10 @@ AIT_API int ait_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, 
 // (ConvGeom, gemm_f32_impl.h); positions outside the map read a caller-provided row of zeros.
 // =========================================================================================================
 namespace {
-using Tile128D = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, KNOB_SPREAD>;
+using Tile128D = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, KNOB_SPLIT>;
 // 64 x 128, two waves: grouped convolutions over a handful of rows (the query side of the SK block: 64 output rows) --
 // a 256-row tile would multiply three quarters of padding there
-using TileS = Cfg<64, 128, 16, 1, 2, 2, MODE_DLDS, 3, KNOB_SPREAD>;
+using TileS = Cfg<64, 128, 16, 1, 2, 2, MODE_DLDS, 3, KNOB_SPLIT>;
 
 inline int log2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;

@@ -157,7 +157,7 @@ enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
 //   KNOB_STAGGER the workgroup in an odd threadgroup slot of its CU (HW_ID.tg_id) starts half a tile late: the two
 //               workgroups of a CU run the same program on tiles of the same length, so without it they reach their
 //               epilogues together and the matrix pipes idle through both
-enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8 };
+enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8, KNOB_SPLIT = 16 /* products on the bf16 matrix pipe, see split8 */ };
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int MODE_ = MODE_DB, int NS_ = 3, int KNOBS_ = 0>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_, MODE = MODE_;
@@ -505,6 +505,54 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
 #undef AIT_ROW
 }
 
+// ---- f32 products on the bf16 matrix pipe (KNOB_SPLIT) --------------------------------------------------
+// v_mfma_f32_32x32x16_bf16 retires 16x the FLOP per cycle of v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH: 32 cycles
+// for 32x32x16 against 64 for 32x32x2).  An f32 value is EXACTLY the sum of three bf16 values (24 significant bits =
+// 8 + 8 + 8: h = x truncated to bf16, m = (x - h) truncated, l = x - h - m), a product of two bf16 values is exact in
+// f32, and the MFMA accumulates in f32.  So  a*b = (ah + am + al)(bh + bm + bl)  is formed from the six terms that
+// are >= 2^-16 |a b|  --  ah bh, ah bm, am bh, ah bl, al bh, am bm  --  and the three dropped ones are <= 2^-23.9 |a b|
+// together: below the rounding of one f32 multiply-add (2^-24 of the running sum per step).  Six 32-cycle
+// instructions replace eight 64-cycle ones per 16 k-steps; the split costs 5.5 vector instructions per fetched value,
+// issued in the shadow of the MFMAs.  The operand images in LDS, the LDS-DMA stream and the epilogues are untouched:
+// a lane's eight k-values of a slab (k = 8*lk + 0..7) are exactly the 32x32x16 operand layout.
+// Non-finite inputs give NaN where the f32 instruction gives an infinity (inf - inf in the remainder).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Planes { bf16x8 h, m, l; };
+
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+  h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                      // (hi16(x1) << 16) | hi16(x0)
+  const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+  const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+  m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+__device__ __forceinline__ Planes split8(const float4& p, const float4& q) {     // k = 8*lk + 0..3 | 4..7
+  u32x4 h, m, l;
+  unsigned a, b, c;
+  split2(p.x, p.y, a, b, c); h[0] = a; m[0] = b; l[0] = c;
+  split2(p.z, p.w, a, b, c); h[1] = a; m[1] = b; l[1] = c;
+  split2(q.x, q.y, a, b, c); h[2] = a; m[2] = b; l[2] = c;
+  split2(q.z, q.w, a, b, c); h[3] = a; m[3] = b; l[3] = c;
+  Planes r;
+  r.h = __builtin_bit_cast(bf16x8, h);
+  r.m = __builtin_bit_cast(bf16x8, m);
+  r.l = __builtin_bit_cast(bf16x8, l);
+  return r;
+}
+
+__device__ __forceinline__ f32x16 mfma_split(const Planes& a, const Planes& b, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+}
+
 // one group of four k-steps: TM x TN MFMAs per step on the operand quads xa / xb
 template <int TM, int TN>
 __device__ __forceinline__ void mfma_group(f32x16 (&acc)[TM][TN], const float4 (&xa)[TM], const float4 (&xb)[TN]) {
@@ -807,7 +855,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // first B granule) are made scalar ONCE per slab (slab_bases) and the per-transfer offsets are constants --
   // a readfirstlane in front of every transfer halves the kernel's rate
   struct Bases { unsigned a, b; int slot; };
-  constexpr bool kScalarBases = CONV != CONV_NONE;      // (the convolution kernels: more scalar state than hipcc keeps scalar)
+  constexpr bool kSplit = (C::KNOBS & KNOB_SPLIT) != 0;
+  constexpr bool kScalarBases = CONV != CONV_NONE || kSplit;      // (kernels with more scalar state than hipcc keeps scalar)
   auto slab_bases = [&](int slot) __attribute__((always_inline)) -> Bases {
     Bases r;
     r.slot = slot;
@@ -885,8 +934,20 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   }
   ring_barrier();
   float4 xa[C::TM], xb[C::TN], na[C::TM], nb[C::TN];
-  fetch_group<AK, C::TM, BM>(As, wm, li, lk, 0, xa);
-  fetch_group<BKC, C::TN, BN>(Bd, wn, li, lk, 0, xb);
+  // kSplit: the slab's first A tile (both k halves) and all of its B tiles, fetched one slab ahead
+  float4 sa0, sa1, sb0[C::TN], sb1[C::TN];
+  if constexpr (kSplit) {
+    sa0 = fetch_tile<AK, BM>(As, wm, li, lk, 0, 0);
+    sa1 = fetch_tile<AK, BM>(As, wm, li, lk, 1, 0);
+#pragma unroll
+    for (int b = 0; b < C::TN; b++) {
+      sb0[b] = fetch_tile<BKC, BN>(Bd, wn, li, lk, 0, b);
+      sb1[b] = fetch_tile<BKC, BN>(Bd, wn, li, lk, 1, b);
+    }
+  } else {
+    fetch_group<AK, C::TM, BM>(As, wm, li, lk, 0, xa);
+    fetch_group<BKC, C::TN, BN>(Bd, wn, li, lk, 0, xb);
+  }
   int cur = 0;
 
   for (int item = 0;; item++) {
@@ -929,6 +990,51 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           for (int i = 0; i < NP; i++) issue(i, lbase);
         }
       }
+      if constexpr (kSplit) {
+        constexpr int kPairs = C::TM * C::TN;
+        Planes bp[C::TN];
+#pragma unroll
+        for (int b = 0; b < C::TN; b++) bp[b] = split8(sb0[b], sb1[b]);
+        float4 ca0 = sa0, ca1 = sa1;
+#pragma unroll
+        for (int a = 0; a < C::TM; a++) {
+          const Planes ap = split8(ca0, ca1);
+          // the operands of the next A tile -- or, behind the last one, of the next slab of the stream (complete in
+          // LDS since the last barrier; possibly the first slab of the next tile) -- arrive under this tile's MFMAs
+          if (a + 1 < C::TM) {
+            ca0 = fetch_tile<AK, BM>(As + cur * SA, wm, li, lk, 0, a + 1);
+            ca1 = fetch_tile<AK, BM>(As + cur * SA, wm, li, lk, 1, a + 1);
+          } else {
+            sa0 = fetch_tile<AK, BM>(As + nxt * SA, wm, li, lk, 0, 0);
+            sa1 = fetch_tile<AK, BM>(As + nxt * SA, wm, li, lk, 1, 0);
+#pragma unroll
+            for (int b = 0; b < C::TN; b++) {
+              sb0[b] = fetch_tile<BKC, BN>(Bd + nxt * SB, wn, li, lk, 0, b);
+              sb1[b] = fetch_tile<BKC, BN>(Bd + nxt * SB, wn, li, lk, 1, b);
+            }
+          }
+#pragma unroll
+          for (int b = 0; b < C::TN; b++) {
+            // The six MFMAs of a tile pair stay one uninterrupted chain on their accumulator.  (Left to itself hipcc
+            // alternates the chains of two pairs; with exactly one independent v_mfma_f32_32x32x16_bf16 between two
+            // dependent ones the later one occasionally read lanes 48-63 of its SrcC before the earlier one's last
+            // write had landed -- a handful of 16-element row segments per launch off by one term, always in the
+            // interleaved accumulator: measured with scripts/gemm_lab diffmap, ROCm 7.2.)
+            __builtin_amdgcn_sched_barrier(0);
+            acc[a][b] = mfma_split(ap, bp[b], acc[a][b]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((C::KNOBS & KNOB_BURST) == 0) {
+              const int pair = a * C::TN + b;      // the slab's NP transfers, spread over the tile pairs
+#pragma unroll
+              for (int piece = pair * NP / kPairs; piece < (pair + 1) * NP / kPairs; piece++) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (feed) issue(piece, lbase);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int grp = 0; grp < 2; grp++) {
         // next group's operands: second half of this slab, then the first half of the NEXT slab of the
@@ -973,6 +1079,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         for (int a = 0; a < C::TM; a++) xa[a] = na[a];
 #pragma unroll
         for (int b = 0; b < C::TN; b++) xb[b] = nb[b];
+      }
       }
       if (feed) advance();
       __builtin_amdgcn_sched_barrier(0);

@@ -37,6 +37,9 @@ using V_128r4 = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, 0>;             // 64 K
 using V_sp8 = Cfg<256, 128, 16, 4, 2, 4, MODE_DLDS, 3, KNOB_SPREAD>;    // 8 waves, LDS reads spread over the MFMA steps
 using V_sp4 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD>;    // 4 waves, same
 using V_256sq = Cfg<256, 256, 16, 4, 4, 4, MODE_DLDS, 3, 0>;             // 16 waves, 96 KB: one workgroup per CU
+using V_split = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT>;     // the product tile, products on the bf16 matrix pipe (3-way split, 6 terms)
+using V_split8 = Cfg<256, 128, 16, 4, 2, 4, MODE_DLDS, 3, KNOB_SPLIT>;    // 8 waves of 64x64
+using V_splitsq = Cfg<256, 256, 16, 2, 2, 1, MODE_DLDS, 3, KNOB_SPLIT>;   // 4 waves of 128x128, one workgroup per CU
 using V_stag = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD | KNOB_STAGGER>;   // the product tile, odd threadgroup slots start half a tile late
 #ifndef NO_OLD
 using OldD = ait_gemm_old::Cfg<256, 128, 16, 4, 2, 2, 6 + 256>;
@@ -158,7 +161,7 @@ static int run_tile(const GemmArgs& g, bool ak, bool bk, int slots) {
   return run_epi<T, false, true, NoProbe>(g, slots);
 }
 static const char* VNAMES[] = {"old", "new", "probe", "burst", "prio", "ring4", "ring4+burst", "4waves", "4waves+burst",
-                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag"};
+                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split 8w", "split 256sq"};
 template <class Probe>
 static int run_new(const GemmArgs& g, bool ak, bool bk, int slots) {
   if (!ak && !bk) return run_epi<NewD4, false, false, Probe>(g, slots);
@@ -188,7 +191,16 @@ static int run(Problem& p, int variant, float* out) {
     g_use_ws = true;
     return rc;
   }
-  if (variant == 2) { g.probe = p.probe; return run_new<StampProbe>(g, ak, bk, g_slots); }
+  if (variant == 2) {
+    g.probe = p.probe;
+    if (getenv("LAB_PROBE_SPLIT")) {      // the stamp probe on the split tile
+      if (!ak && !bk) return run_epi<V_split, false, false, StampProbe>(g, g_slots);
+      if (ak && bk) return run_epi<V_split, true, true, StampProbe>(g, g_slots);
+      if (ak && !bk) return run_epi<V_split, true, false, StampProbe>(g, g_slots);
+      return run_epi<V_split, false, true, StampProbe>(g, g_slots);
+    }
+    return run_new<StampProbe>(g, ak, bk, g_slots);
+  }
   switch (variant) {
     case 3: return run_tile<V_burst>(g, ak, bk, g_slots);
     case 4: return run_tile<V_prio>(g, ak, bk, g_slots);
@@ -208,6 +220,9 @@ static int run(Problem& p, int variant, float* out) {
       return rc;
     }
     case 15: return run_tile<V_stag>(g, ak, bk, g_slots);
+    case 16: return run_tile<V_split>(g, ak, bk, g_slots);
+    case 17: return run_tile<V_split8>(g, ak, bk, g_slots);
+    case 18: return run_tile<V_splitsq>(g, ak, bk, g_slots);
     default: break;
   }
 #ifndef NO_OLD
@@ -275,11 +290,11 @@ static void mode_ab(int rounds, int first, int last) {
 
 // every variant on every shape, interleaved rounds in one process; median TF/s
 static void mode_sweep(int rounds, int first, int last) {
-  int vs[16] = {0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13};
+  int vs[24] = {0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13};
   int nv = 13;
   if (const char* e = getenv("LAB_VARIANTS")) {       // e.g. LAB_VARIANTS=1,7,12,13
     nv = 0;
-    for (const char* q = e; *q && nv < 16;) { vs[nv++] = atoi(q); q = strchr(q, ','); if (!q) break; q++; }
+    for (const char* q = e; *q && nv < 24;) { vs[nv++] = atoi(q); q = strchr(q, ','); if (!q) break; q++; }
   }
   printf("%-9s %6s %5s %6s |", "shape", "M", "N", "K");
   for (int i = 0; i < nv; i++) printf(" %12s", VNAMES[vs[i]]);
@@ -296,7 +311,8 @@ static void mode_sweep(int rounds, int first, int last) {
       CK(hipMemset(p.C2, 0, nc * 4));
       const int rc = run(p, vs[i], p.C2);
       CK(hipDeviceSynchronize());
-      if (rc != 0 || max_diff(p, 1) > 2e-5) ok[i] = 0;      // stream-K and split-K change the summation order
+      const double md = rc == 0 ? max_diff(p, 1) : -1.0;
+      if (rc != 0 || md > 2e-5) { ok[i] = 0; fprintf(stderr, "  %s / %s: rc %d, max |diff| / max |ref| = %.3g\n", p.s.name, VNAMES[vs[i]], rc, md); }      // stream-K and split-K change the summation order
       if (rc == 0) time_launches(p, vs[i], p.C2, 3);
     }
     for (int r = 0; r < rounds; r++)
@@ -594,6 +610,57 @@ static void mode_pmc(int si, int variant, int n) {
   teardown(p);
 }
 
+// where a variant's result differs from the whole-tile reference: counts per 256 x 128 tile, first few elements
+static void mode_diffmap(int si, int variant) {
+  Problem p;
+  setup(p, SHAPES[si]);
+  const size_t nc = (size_t)p.s.M * p.s.N;
+  CK(hipMemset(p.C, 0, nc * 4)); CK(hipMemset(p.C2, 0, nc * 4));
+  run(p, 1, p.C);
+  if (getenv("LAB_NOWS")) g_use_ws = false;
+  run(p, variant, p.C2);
+  g_use_ws = true;
+  CK(hipDeviceSynchronize());
+  std::vector<float> a(nc), b(nc);
+  CK(hipMemcpy(a.data(), p.C, nc * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(b.data(), p.C2, nc * 4, hipMemcpyDeviceToHost));
+  double ref = 0;
+  for (size_t i = 0; i < nc; i++) ref = std::max(ref, (double)fabsf(a[i]));
+  const int tm = (p.s.M + 255) / 256, tn = (p.s.N + 127) / 128;
+  std::vector<int> cnt((size_t)tm * tn, 0);
+  int shown = 0;
+  for (int r = 0; r < p.s.M; r++)
+    for (int c = 0; c < p.s.N; c++) {
+      const size_t i = (size_t)r * p.s.N + c;
+      if (fabsf(a[i] - b[i]) > 2e-5 * ref) {
+        cnt[(size_t)(r / 256) * tn + c / 128]++;
+        if (shown++ < 12) printf("  (%d, %d) tile (%d, %d) in-tile (%d, %d): ref %.6g got %.6g\n", r, c, r / 256, c / 128, r % 256, c % 128, a[i], b[i]);
+      }
+    }
+  {   // which accumulator: wave tile 128 x 64 -> (a, b) MFMA tile, register r, lane half lk, lane quarter
+    int hist[4][2] = {}, regs[16] = {}, quarter[4] = {};
+    for (int r = 0; r < p.s.M; r++)
+      for (int c = 0; c < p.s.N; c++) {
+        const size_t i = (size_t)r * p.s.N + c;
+        if (fabsf(a[i] - b[i]) > 2e-5 * ref) {
+          const int ir = r % 128, ic = c % 64, rr = ir % 32, cc = ic % 32;
+          hist[ir / 32][ic / 32]++;
+          const int lk = (rr >> 2) & 1, reg = (rr & 3) + 4 * (rr >> 3);
+          regs[reg]++;
+          quarter[lk * 2 + cc / 16]++;
+        }
+      }
+    for (int x = 0; x < 4; x++) printf("a=%d: b=0 %d, b=1 %d\n", x, hist[x][0], hist[x][1]);
+    printf("acc register:"); for (int x = 0; x < 16; x++) printf(" %d", regs[x]); printf("\nlane quarter:");
+    for (int x = 0; x < 4; x++) printf(" %d", quarter[x]); printf("\n");
+  }
+  int bad = 0;
+  for (int t = 0; t < tm * tn; t++)
+    if (cnt[t]) { if (bad++ < 40) printf("tile %d (%d, %d): %d elements differ\n", t, t / tn, t % tn, cnt[t]); }
+  printf("%d of %d tiles differ\n", bad, tm * tn);
+  teardown(p);
+}
+
 int main(int argc, char** argv) {
   const char* mode = argc > 1 ? argv[1] : "ab";
   if (getenv("LAB_SLOTS")) g_slots = atoi(getenv("LAB_SLOTS"));
@@ -602,6 +669,7 @@ int main(int argc, char** argv) {
   if (!strcmp(mode, "ab")) mode_ab(argc > 2 ? atoi(argv[2]) : 5, first, last);
   else if (!strcmp(mode, "probe")) mode_probe(first, last);
   else if (!strcmp(mode, "micro")) mode_micro();
+  else if (!strcmp(mode, "diffmap")) mode_diffmap(atoi(argv[2]), atoi(argv[3]));
   else if (!strcmp(mode, "sweep")) mode_sweep(argc > 2 ? atoi(argv[2]) : 5, first, last);
   else if (!strcmp(mode, "contend")) mode_contend(first, last, argc > 2 ? atoi(argv[2]) : 64);
   else if (!strcmp(mode, "interleave")) mode_interleave(argc > 2 ? atoi(argv[2]) : 13, first, last);

@@ -378,3 +378,47 @@ def test_detector_full_size_step_matches_reference_work_and_is_reproducible(mode
     assert float(same.float().mean()) >= 0.98
     assert float((losses - losses_ref).abs().max()) <= 2e-4 * float(losses_ref.abs().max()) + 1e-6
     assert float((prob - prob_ref)[same].abs().max()) <= 1e-4
+
+
+def test_query_trunk_graph_replay_matches_eager_launches(model):
+    """The C4 trunk on the query patches is replayed from a forward and a backward HIP graph in training
+    (faster_rcnn._query_trunk): over three steps with fresh inputs and IN-PLACE weight updates in between, the
+    feature map and every parameter gradient equal those of the eager launches, and the gradient of the shared trunk
+    still accumulates with the target image's."""
+    import ait_amd.faster_rcnn as fr
+    model.train()
+    params = [p for k, p in model.RCNN_base.named_parameters()                  # (.backbone also owns layer4 and fc)
+              if p.requires_grad and k.startswith(("backbone.layer1.", "backbone.layer2.", "backbone.layer3."))]
+    assert len(params) > 40
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    model._query_graphs.clear()
+    try:
+        for step in range(3):
+            q = torch.randn(4, 3, 128, 128, device="cuda", generator=gen)
+            img = torch.randn(1, 3, 96, 160, device="cuda", generator=gen)
+            w = torch.randn(4, 1024, 8, 8, device="cuda", generator=gen)
+            got = {}
+            for graph in (True, False):
+                fr._QUERY_GRAPH = graph
+                for p in params:
+                    p.grad = None
+                f = model._query_trunk(q)
+                g = model.RCNN_base(img)[0]                     # the same weights, a second use in the same step
+                ((f * w).sum() + g.square().sum()).backward()
+                got[graph] = (f.detach().clone(), [p.grad.detach().clone() for p in params])
+            assert sum(k[0] != "stream" for k in model._query_graphs) == 1
+            assert float((got[True][0] - got[False][0]).abs().max()) <= 1e-5 * float(got[False][0].abs().max())
+            for a, b in zip(got[True][1], got[False][1]):
+                assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7
+            with torch.no_grad():
+                for p in params[:8]:
+                    p.mul_(1.01)                                # the optimizer's in-place update: the graph reads it
+        # evaluation and no_grad runs never touch the graphs
+        fr._QUERY_GRAPH = True
+        with torch.no_grad():
+            assert model._query_trunk(q).shape == (4, 1024, 8, 8)
+        assert sum(k[0] != "stream" for k in model._query_graphs) == 1
+    finally:
+        fr._QUERY_GRAPH = True
+        for p in params:
+            p.grad = None

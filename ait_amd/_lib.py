@@ -196,7 +196,8 @@ PROBE_GEMM, PROBE_ROI_FWD, PROBE_ROI_BWD = 1, 2, 3
 
 class LaunchCtx(ctypes.Structure):
     """ait_launch_ctx of include/ait_hip.h: caller-owned scheduler scratch of the persistent GEMM + probe."""
-    _fields_ = [("sched_ws", ctypes.c_void_p), ("sched_ws_bytes", ctypes.c_size_t), ("probe", ctypes.c_void_p)]
+    _fields_ = [("sched_ws", ctypes.c_void_p), ("sched_ws_bytes", ctypes.c_size_t), ("probe", ctypes.c_void_p),
+                ("flags", ctypes.c_uint)]
 
 
 # ---- the host side's launch contexts: one scheduler workspace per (device, stream), allocated with torch and
@@ -204,6 +205,8 @@ class LaunchCtx(ctypes.Structure):
 _SCHED = {}          # (device index, stream handle) -> (uint8 tensor, LaunchCtx without probe)
 _ACTIVE_PROBE = None
 USE_SCHED_WS = True  # test hook: False = launch without scheduler scratch (static work lists, whole tiles)
+CTX_NATIVE_F32 = 1   # ait_launch_ctx::flags
+NATIVE_F32 = False   # ops.set_matmul_dtype("f32_native"): dense products on v_mfma_f32_32x32x2_f32 (default: bf16 3-way split)
 
 
 def launch_ctx(device=None):
@@ -229,6 +232,8 @@ def launch_ctx(device=None):
     pr = _ACTIVE_PROBE
     if pr is not None and pr._p and pr.device_index == idx:
         ctx.probe = pr._p
+    if NATIVE_F32:
+        ctx.flags = CTX_NATIVE_F32
     return ctypes.byref(ctx)
 
 

@@ -44,6 +44,10 @@ using namespace ait_gemm;
 //              tile boundaries): every large product with K % 16 == 0.  Measured against the 8-wave
 //              (64x64 per wave) form of the same tile: +2..5 % on every layout (scripts/gemm_lab.hip sweep,
 //              profiles/r02_gemm_lab_sweep.txt).
+//              Products: every f32 operand value split exactly into three bf16 planes in registers, six
+//              v_mfma_f32_32x32x16_bf16 per 32x32x16 block (KNOB_SPLIT, gemm_f32_impl.h "f32 products on the bf16
+//              matrix pipe"): 185-190 TF/s on the transformer's shapes against 131-136 for the same tile on
+//              v_mfma_f32_32x32x2_f32 (Tile256N, selected by AIT_CTX_NATIVE_F32; 157.3 TF/s is that instruction's peak).
 //   Tile256    256x128, register-staged three-slab ring: large products whose K is not a multiple of 16.
 //   Tile128    128x128 register-staged double buffer: outputs with few rows.
 //   TileN64    256x64 for the 64-column SHBlock / fc products (no dead half tile).
@@ -82,7 +86,10 @@ int ait_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, float alpha, 
   const bool few_tiles_sk = direct && K >= 512 && tiles256 >= 96 &&
                             ((g.splits == 1 && !(flags & AIT_GEMM_ATOMIC) && ws.p != nullptr) || (flags & AIT_GEMM_ATOMIC));
   if (M >= 512 && (tiles256 >= 512 || few_tiles_sk)) {
-    if (direct) return dispatch<Tile256D>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);
+    if (direct) {
+      if (ctx && (ctx->flags & AIT_CTX_NATIVE_F32)) return dispatch<Tile256N>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);
+      return dispatch<Tile256D>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);
+    }
     return dispatch<Tile256>(g, !trans_a, trans_b != 0, ait_stream(stream));
   }
   const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * g.splits;

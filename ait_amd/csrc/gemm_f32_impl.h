@@ -157,7 +157,8 @@ enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
 //   KNOB_STAGGER the workgroup in an odd threadgroup slot of its CU (HW_ID.tg_id) starts half a tile late: the two
 //               workgroups of a CU run the same program on tiles of the same length, so without it they reach their
 //               epilogues together and the matrix pipes idle through both
-enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8, KNOB_SPLIT = 16 /* products on the bf16 matrix pipe, see split8 */ };
+enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8, KNOB_SPLIT = 16 /* products on the bf16 matrix pipe, see split8 */,
+       KNOB_SPLIT_SIMPLE = 32 /* lab: KNOB_SPLIT with every split in front of its tile's MFMAs instead of under the previous tile's */ };
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int MODE_ = MODE_DB, int NS_ = 3, int KNOBS_ = 0>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_, MODE = MODE_;
@@ -934,9 +935,27 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   }
   ring_barrier();
   float4 xa[C::TM], xb[C::TN], na[C::TM], nb[C::TN];
-  // kSplit: the slab's first A tile (both k halves) and all of its B tiles, fetched one slab ahead
+  // kSplit state.  Simple schedule: the slab's first A tile (both k halves) and all of its B tiles, raw, fetched one
+  // slab ahead.  Pipelined schedule: the bf16 planes of this slab's B tiles (bp) and of the A tile in work (ap), the
+  // planes being formed under the MFMAs (nap: the next A tile; nbp: the NEXT slab's B tiles) and two raw operand
+  // tiles in flight from LDS (rw): every region of six MFMAs splits what the region before it fetched.
+  constexpr bool kPipe = kSplit && (C::KNOBS & KNOB_SPLIT_SIMPLE) == 0;
+  static_assert(!kPipe || (C::TM >= 2 && C::TN >= 2 && C::TN <= C::TM && (C::TM * C::TN) % 2 == 0), "split schedule");
   float4 sa0, sa1, sb0[C::TN], sb1[C::TN];
-  if constexpr (kSplit) {
+  Planes bp[C::TN], nbp[C::TN], ap, nap;
+  float4 rw[2][2];
+  // (pipelined) everything the first region of a slab needs, from a slab that is complete in LDS
+  auto prime = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < C::TN; b++)
+      bp[b] = split8(fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 0, b), fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 1, b));
+    ap = split8(fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 0), fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 0));
+    rw[0][0] = fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 1);
+    rw[0][1] = fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 1);
+  };
+  if constexpr (kPipe) {
+    prime(0);
+  } else if constexpr (kSplit) {
     sa0 = fetch_tile<AK, BM>(As, wm, li, lk, 0, 0);
     sa1 = fetch_tile<AK, BM>(As, wm, li, lk, 1, 0);
 #pragma unroll
@@ -990,7 +1009,61 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           for (int i = 0; i < NP; i++) issue(i, lbase);
         }
       }
-      if constexpr (kSplit) {
+      if constexpr (kPipe) {
+        // Region (a, b) = the six MFMAs of tile pair (a, b), one uninterrupted chain (see the simple schedule below),
+        // with in their shadow: the split of the raw tile the PREVIOUS region fetched, and the ds_reads of the raw
+        // tile the NEXT region splits.  Splits: region (a, 0): A tile a+1 of this slab -- in the last tile: A tile 0
+        // of the next slab; region (a, 1): B tile a of the next slab (a < TN).  The next slab of the stream (possibly
+        // the first of the next tile) is complete in LDS since the last barrier.
+        constexpr int kPairs = C::TM * C::TN;
+        const float* a_cur = As + cur * SA;
+        const float* a_nxt = As + nxt * SA;
+        const float* b_nxt = Bd + nxt * SB;
+#pragma unroll
+        for (int a = 0; a < C::TM; a++) {
+#pragma unroll
+          for (int b = 0; b < C::TN; b++) {
+            const int r = a * C::TN + b, pr = r & 1, nx = pr ^ 1;
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- fetch for region r + 1 ------------------------------------------------------------------
+            if (b == 0) {                                   // next region (a, 1) splits B tile a of the next slab
+              if (a < C::TN) {
+                rw[nx][0] = fetch_tile<BKC, BN>(b_nxt, wn, li, lk, 0, a);
+                rw[nx][1] = fetch_tile<BKC, BN>(b_nxt, wn, li, lk, 1, a);
+              }
+            } else if (b == 1) {                            // next region (a + 1, 0) splits an A tile
+              if (a + 2 < C::TM) {                          // ... A tile a + 2 of this slab
+                rw[nx][0] = fetch_tile<AK, BM>(a_cur, wm, li, lk, 0, a + 2);
+                rw[nx][1] = fetch_tile<AK, BM>(a_cur, wm, li, lk, 1, a + 2);
+              } else if (a + 2 == C::TM) {                  // ... A tile 0 of the next slab
+                rw[nx][0] = fetch_tile<AK, BM>(a_nxt, wm, li, lk, 0, 0);
+                rw[nx][1] = fetch_tile<AK, BM>(a_nxt, wm, li, lk, 1, 0);
+              } else {                                      // last tile: A tile 1 of the next slab, for ITS region (0, 0)
+                rw[nx][0] = fetch_tile<AK, BM>(a_nxt, wm, li, lk, 0, 1);
+                rw[nx][1] = fetch_tile<AK, BM>(a_nxt, wm, li, lk, 1, 1);
+              }
+            }
+            // ---- the chain (nothing between its MFMAs: see the note in the simple schedule), then the split of what
+            // the previous region fetched: vector work this wave does while the SIMD's other wave has the matrix pipe
+            __builtin_amdgcn_sched_barrier(0);
+            acc[a][b] = mfma_split(ap, bp[b], acc[a][b]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (b == 0) nap = split8(rw[pr][0], rw[pr][1]);
+            else if (b == 1 && a < C::TN) nbp[a] = split8(rw[pr][0], rw[pr][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((C::KNOBS & KNOB_BURST) == 0) {
+#pragma unroll
+              for (int piece = r * NP / kPairs; piece < (r + 1) * NP / kPairs; piece++) {
+                if (feed) issue(piece, lbase);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+          ap = nap;
+        }
+#pragma unroll
+        for (int b = 0; b < C::TN; b++) bp[b] = nbp[b];
+      } else if constexpr (kSplit) {
         constexpr int kPairs = C::TM * C::TN;
         Planes bp[C::TN];
 #pragma unroll
@@ -1180,8 +1253,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     // (the operand quads are dead across the epilogue -- its address arithmetic needs the registers --
     // and are fetched again from the next tile's first slab, complete in LDS since the last barrier)
     __builtin_amdgcn_sched_barrier(0);
-    fetch_group<AK, C::TM, BM>(As + cur * SA, wm, li, lk, 0, xa);
-    fetch_group<BKC, C::TN, BN>(Bd + cur * SB, wn, li, lk, 0, xb);
+    if constexpr (kPipe) {
+      prime(cur);
+    } else if constexpr (!kSplit) {
+      fetch_group<AK, C::TM, BM>(As + cur * SA, wm, li, lk, 0, xa);
+      fetch_group<BKC, C::TN, BN>(Bd + cur * SB, wn, li, lk, 0, xb);
+    }
   }
 
   leave();

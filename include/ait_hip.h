@@ -56,11 +56,23 @@ const char* ait_strerror(int code);
  *       order of the affected products differs (both are deterministic).  A workspace that is too small for the
  *       launch returns AIT_EWORKSPACE.
  *   probe   measurement probe (below) or NULL.
+ *   flags   0, or AIT_CTX_NATIVE_F32: the dense fp32 products (ait_gemm_f32 and the products inside the
+ *       ait_mha_ / ait_ffn_ / ait_transformer_ composites) are formed by v_mfma_f32_32x32x2_f32, the instruction
+ *       that multiplies f32 operands.  Default (0): every f32 operand is split EXACTLY into three bf16 values
+ *       (24 significant bits = 8 + 8 + 8) and a product is accumulated in f32 from the six partial products that
+ *       are >= 2^-16 of it, on v_mfma_f32_32x32x16_bf16 -- 16x the FLOP per cycle of the f32 instruction, six
+ *       instead of one; the three dropped partial products sum to < 2^-23 |a b|, below the rounding of one f32
+ *       multiply-add, and the measured error against float64 equals the f32 instruction's (tests/test_gpu_gemm.py).
+ *       Same operand images, same epilogues, same summation order over k-blocks.  Non-finite inputs: NaN where
+ *       the f32 instruction gives an infinity.  The convolution composites (ait_conv_*, ait_tail_*) always use
+ *       the split form.
  * ------------------------------------------------------------------------------------- */
+#define AIT_CTX_NATIVE_F32 1u
 typedef struct {
   void* sched_ws;
   size_t sched_ws_bytes;
   void* probe;
+  unsigned flags;
 } ait_launch_ctx;
 size_t ait_gemm_workspace_bytes(void);   /* for the device current to the calling thread; 0 on error */
 /* zeroes the control words of a fresh workspace (enqueued on `stream`, capturable); call once after allocation */

@@ -38,7 +38,7 @@ using V_sp8 = Cfg<256, 128, 16, 4, 2, 4, MODE_DLDS, 3, KNOB_SPREAD>;    // 8 wav
 using V_sp4 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD>;    // 4 waves, same
 using V_256sq = Cfg<256, 256, 16, 4, 4, 4, MODE_DLDS, 3, 0>;             // 16 waves, 96 KB: one workgroup per CU
 using V_split = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT>;     // the product tile, products on the bf16 matrix pipe (3-way split, 6 terms)
-using V_split8 = Cfg<256, 128, 16, 4, 2, 4, MODE_DLDS, 3, KNOB_SPLIT>;    // 8 waves of 64x64
+using V_split8 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_SPLIT_SIMPLE>;    // every split in front of its tile's MFMAs
 using V_splitsq = Cfg<256, 256, 16, 2, 2, 1, MODE_DLDS, 3, KNOB_SPLIT>;   // 4 waves of 128x128, one workgroup per CU
 using V_stag = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD | KNOB_STAGGER>;   // the product tile, odd threadgroup slots start half a tile late
 #ifndef NO_OLD
@@ -161,7 +161,7 @@ static int run_tile(const GemmArgs& g, bool ak, bool bk, int slots) {
   return run_epi<T, false, true, NoProbe>(g, slots);
 }
 static const char* VNAMES[] = {"old", "new", "probe", "burst", "prio", "ring4", "ring4+burst", "4waves", "4waves+burst",
-                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split 8w", "split 256sq"};
+                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq"};
 template <class Probe>
 static int run_new(const GemmArgs& g, bool ak, bool bk, int slots) {
   if (!ak && !bk) return run_epi<NewD4, false, false, Probe>(g, slots);

@@ -451,3 +451,93 @@ def test_gemm_column_sums_in_the_epilogue(M, N, K):
     assert rc == 0
     ref2 = ref + (a.double() @ w.double()).sum(0)
     assert float((cs.double() - ref2).abs().max()) <= 1e-5 * float((a.double().abs() @ w.double().abs()).sum(0).max()) + 1e-4
+
+
+def _native(flag):
+    """context: dense products on v_mfma_f32_32x32x2_f32 (ait_launch_ctx::flags = AIT_CTX_NATIVE_F32)"""
+    import contextlib
+    from ait_amd import _lib
+
+    @contextlib.contextmanager
+    def cm():
+        old = _lib.NATIVE_F32
+        _lib.NATIVE_F32 = flag
+        try:
+            yield
+        finally:
+            _lib.NATIVE_F32 = old
+    return cm()
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(33000, 1536, 512, False, True), (33000, 512, 2048, False, False),
+                                         (512, 2048, 33024, True, False)])
+def test_split_bf16_products_are_as_close_to_float64_as_the_f32_instruction(M, N, K, ta, tb, record_property):
+    """The default product form (every f32 operand value = three bf16 values exactly, six bf16 MFMAs per block,
+    f32 accumulate; include/ait_hip.h ait_launch_ctx::flags) against float64, beside the same launch on
+    v_mfma_f32_32x32x2_f32: the split form's error is the f32 instruction's (the dropped partial products are
+    < 2^-23 |a b|).  Operands with a wide spread of magnitudes and signs."""
+    from ait_amd import ops
+    torch.manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), device="cuda") * torch.exp(2 * torch.randn((K, 1) if ta else (1, K), device="cuda"))
+    b = torch.randn((N, K) if tb else (K, N), device="cuda") * torch.exp(2 * torch.randn((1, K) if tb else (K, 1), device="cuda"))
+    sk = 16 if ta else 1
+    want = _ref(a, b, ta, tb)
+    mag = (a.double().abs().t() if ta else a.double().abs()) @ (b.double().abs().t() if tb else b.double().abs())
+    got = ops.gemm(a, b, trans_a=ta, trans_b=tb, split_k=sk)
+    with _native(True):
+        nat = ops.gemm(a, b, trans_a=ta, trans_b=tb, split_k=sk)
+    e_split = float(((got.double() - want).abs() / mag).max())
+    e_nat = float(((nat.double() - want).abs() / mag).max())
+    rms_split = float(((got.double() - want) / mag).square().mean().sqrt())
+    rms_nat = float(((nat.double() - want) / mag).square().mean().sqrt())
+    record_property("max_err_over_sum_abs_split", e_split)
+    record_property("max_err_over_sum_abs_f32_instruction", e_nat)
+    assert e_nat <= 6e-7 and e_split <= 6e-7            # the fence of test_gemm_layouts
+    assert e_split <= 1.5 * e_nat + 2e-8 and rms_split <= 1.25 * rms_nat + 1e-9
+    assert float((got - nat).abs().max()) <= 4e-7 * float(mag.max())
+
+
+def test_split_bf16_products_special_values():
+    """zeros, denormal-sized, huge and tiny magnitudes, exact powers of two and values with all 24 significant bits
+    set go through the 3-way split exactly; a non-finite operand gives a non-finite result"""
+    from ait_amd import ops
+    torch.manual_seed(5)
+    M, N, K = 33024, 512, 64
+    a = torch.randn(M, K, device="cuda")
+    b = torch.randn(N, K, device="cuda")
+    a[:, 0] = 0.0
+    a[:, 1] = 1e-30
+    b[:, 1] = 1e30
+    a[:, 2] = 16777215.0                 # 2^24 - 1: all significant bits set
+    b[:, 2] = 1.0 / 3.0
+    a[:, 3] = -0.5
+    a[:, 4] = 3e38
+    b[:, 4] = 1e-38
+    a[:, 5] = 1e-41                      # denormal (flushed by both forms or carried: compared with a tolerance)
+    got = ops.gemm(a, b)
+    want = a.double() @ b.double().t()
+    mag = a.double().abs() @ b.double().abs().t()
+    assert float(((got.double() - want).abs() / mag).max()) <= 6e-7
+    a[7, 9] = float("inf")
+    got = ops.gemm(a, b)
+    assert not bool(torch.isfinite(got[7]).any()) and bool(torch.isfinite(got[8]).all())
+
+
+def test_split_bf16_mfma_chains_are_not_interleaved():
+    """Regression: with one independent v_mfma_f32_32x32x16_bf16 between two dependent ones (the schedule hipcc
+    chose for the slab's first tile pairs) a few 16-element row segments per launch came out one term short --
+    only on some shapes, a handful of tiles per launch.  The chains are fenced (gemm_f32_impl.h); the launches that
+    showed it are repeated here and compared element by element with the f32 instruction's result."""
+    from ait_amd import ops
+    torch.manual_seed(2)
+    for (M, N, K) in [(19200, 2048, 512), (76800, 1024, 512), (58800, 2048, 512)]:
+        a = torch.randn(M, K, device="cuda")
+        w = torch.randn(N, K, device="cuda")
+        bias = torch.randn(N, device="cuda")
+        with _native(True):
+            nat = ops.gemm(a, w, bias=bias, relu=True)
+        scale = float(nat.abs().max())
+        for _ in range(3):
+            got = ops.gemm(a, w, bias=bias, relu=True)
+            assert float((got - nat).abs().max()) <= 2e-6 * scale
+        del a, w, nat, got

@@ -206,7 +206,9 @@ _SCHED = {}          # (device index, stream handle) -> (uint8 tensor, LaunchCtx
 _ACTIVE_PROBE = None
 USE_SCHED_WS = True  # test hook: False = launch without scheduler scratch (static work lists, whole tiles)
 CTX_NATIVE_F32 = 1   # ait_launch_ctx::flags
+CTX_BF16 = 2
 NATIVE_F32 = False   # ops.set_matmul_dtype("f32_native"): dense products on v_mfma_f32_32x32x2_f32 (default: bf16 3-way split)
+BF16_PRODUCTS = False   # ops.set_matmul_dtype("bf16"): operands rounded to bf16 in registers, one MFMA per block
 
 
 def launch_ctx(device=None):
@@ -232,7 +234,9 @@ def launch_ctx(device=None):
     pr = _ACTIVE_PROBE
     if pr is not None and pr._p and pr.device_index == idx:
         ctx.probe = pr._p
-    if NATIVE_F32:
+    if BF16_PRODUCTS:
+        ctx.flags = CTX_BF16
+    elif NATIVE_F32:
         ctx.flags = CTX_NATIVE_F32
     return ctypes.byref(ctx)
 

@@ -53,6 +53,7 @@ using namespace ait_gemm;
 //   TileN64    256x64 for the 64-column SHBlock / fc products (no dead half tile).
 //   Tile64     64x64 for few-tile problems (the bs*64-row query side): latency, not throughput.
 using Tile256D = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT>;
+using Tile256B = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BF16>;   // operands rounded to bf16, one MFMA per block (AIT_CTX_BF16)
 using Tile256N = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD>;      // the same tile on v_mfma_f32_32x32x2_f32 (ait_gemm_f32_products(0))
 using Tile256 = Cfg<256, 128, 16, 4, 2, 2, MODE_RING>;
 using Tile128 = Cfg<128, 128, 16, 2, 2, 2, MODE_DB>;
@@ -73,6 +74,19 @@ int ait_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, float alpha, 
   if (rc != AIT_OK) return rc;
   g.gate = gate;
   const SchedWs ws = sched_ws_of(ctx);
+  if (ctx && (ctx->flags & AIT_CTX_BF16)) {
+    // bf16 products: the persistent tile rounds in registers (below); products it does not take go to the kernel that
+    // rounds on the way into LDS (gemm_bf16.hip) -- except the few-tile launches with a gate / column-sum / ReLU-mask
+    // epilogue, which stay on the f32 instruction
+    const long long t256 = (long long)((M + 255) / 256) * ((N + 127) / 128) * g.splits;
+    const bool dir = K > 0 && (K % 16 == 0) && (!trans_a || (M % 4 == 0 && M >= 4)) && (trans_b || (N % 4 == 0 && N >= 4));
+    const bool sk = dir && K >= 512 && t256 >= 96 &&
+                    ((g.splits == 1 && !(flags & AIT_GEMM_ATOMIC) && ws.p != nullptr) || (flags & AIT_GEMM_ATOMIC));
+    const bool persistent = !(N <= 64 && (long long)((M + 255) / 256) * g.splits >= 128) && M >= 512 && (t256 >= 512 || sk) && dir;
+    if (!persistent && !gate && !(flags & (AIT_GEMM_COLSUM | AIT_GEMM_MASK_POS)))
+      return ait_gemm_bf16(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual, flags, split_k, c_colblk,
+                           c_batch_stride, ctx, stream);
+  }
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K, ait_stream(stream), M, N, K, trans_a, trans_b,
                       g.splits);
   // operand "K-contiguous" means the reduction dimension is the fast one in memory:
@@ -87,6 +101,7 @@ int ait_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, float alpha, 
                             ((g.splits == 1 && !(flags & AIT_GEMM_ATOMIC) && ws.p != nullptr) || (flags & AIT_GEMM_ATOMIC));
   if (M >= 512 && (tiles256 >= 512 || few_tiles_sk)) {
     if (direct) {
+      if (ctx && (ctx->flags & AIT_CTX_BF16)) return dispatch<Tile256B>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);
       if (ctx && (ctx->flags & AIT_CTX_NATIVE_F32)) return dispatch<Tile256N>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);
       return dispatch<Tile256D>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);
     }

@@ -158,6 +158,7 @@ enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
 //               workgroups of a CU run the same program on tiles of the same length, so without it they reach their
 //               epilogues together and the matrix pipes idle through both
 enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8, KNOB_SPLIT = 16 /* products on the bf16 matrix pipe, see split8 */,
+       KNOB_BF16 = 64 /* with KNOB_SPLIT: operands ROUNDED to bf16 (nearest even), one MFMA per block: bf16 products, f32 accumulate */,
        KNOB_SPLIT_SIMPLE = 32 /* lab: KNOB_SPLIT with every split in front of its tile's MFMAs instead of under the previous tile's */ };
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int MODE_ = MODE_DB, int NS_ = 3, int KNOBS_ = 0>
 struct Cfg {
@@ -531,8 +532,26 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned
   l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned round2(float x0, float x1) {         // v_cvt_pk_bf16_f32: nearest even, NaN stays NaN
+  bf16x2 t;
+  t[0] = (__bf16)x0;
+  t[1] = (__bf16)x1;
+  return __builtin_bit_cast(unsigned, t);
+}
+
+// TERMS = 6: the exact 3-way split; TERMS = 1: the operand rounded to bf16 (only plane h is formed)
+template <int TERMS = 6>
 __device__ __forceinline__ Planes split8(const float4& p, const float4& q) {     // k = 8*lk + 0..3 | 4..7
   u32x4 h, m, l;
+  if constexpr (TERMS == 1) {
+    h[0] = round2(p.x, p.y); h[1] = round2(p.z, p.w); h[2] = round2(q.x, q.y); h[3] = round2(q.z, q.w);
+    Planes r;
+    r.h = __builtin_bit_cast(bf16x8, h);
+    r.m = r.h;
+    r.l = r.h;
+    return r;
+  }
   unsigned a, b, c;
   split2(p.x, p.y, a, b, c); h[0] = a; m[0] = b; l[0] = c;
   split2(p.z, p.w, a, b, c); h[1] = a; m[1] = b; l[1] = c;
@@ -545,7 +564,9 @@ __device__ __forceinline__ Planes split8(const float4& p, const float4& q) {    
   return r;
 }
 
+template <int TERMS = 6>
 __device__ __forceinline__ f32x16 mfma_split(const Planes& a, const Planes& b, f32x16 acc) {
+  if constexpr (TERMS == 1) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
@@ -940,6 +961,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // planes being formed under the MFMAs (nap: the next A tile; nbp: the NEXT slab's B tiles) and two raw operand
   // tiles in flight from LDS (rw): every region of six MFMAs splits what the region before it fetched.
   constexpr bool kPipe = kSplit && (C::KNOBS & KNOB_SPLIT_SIMPLE) == 0;
+  constexpr int kTerms = (C::KNOBS & KNOB_BF16) != 0 ? 1 : 6;
   static_assert(!kPipe || (C::TM >= 2 && C::TN >= 2 && C::TN <= C::TM && (C::TM * C::TN) % 2 == 0), "split schedule");
   float4 sa0, sa1, sb0[C::TN], sb1[C::TN];
   Planes bp[C::TN], nbp[C::TN], ap, nap;
@@ -948,8 +970,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   auto prime = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int b = 0; b < C::TN; b++)
-      bp[b] = split8(fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 0, b), fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 1, b));
-    ap = split8(fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 0), fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 0));
+      bp[b] = split8<kTerms>(fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 0, b), fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 1, b));
+    ap = split8<kTerms>(fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 0), fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 0));
     rw[0][0] = fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 1);
     rw[0][1] = fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 1);
   };
@@ -1046,10 +1068,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
             // ---- the chain (nothing between its MFMAs: see the note in the simple schedule), then the split of what
             // the previous region fetched: vector work this wave does while the SIMD's other wave has the matrix pipe
             __builtin_amdgcn_sched_barrier(0);
-            acc[a][b] = mfma_split(ap, bp[b], acc[a][b]);
+            acc[a][b] = mfma_split<kTerms>(ap, bp[b], acc[a][b]);
             __builtin_amdgcn_sched_barrier(0);
-            if (b == 0) nap = split8(rw[pr][0], rw[pr][1]);
-            else if (b == 1 && a < C::TN) nbp[a] = split8(rw[pr][0], rw[pr][1]);
+            if (b == 0) nap = split8<kTerms>(rw[pr][0], rw[pr][1]);
+            else if (b == 1 && a < C::TN) nbp[a] = split8<kTerms>(rw[pr][0], rw[pr][1]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((C::KNOBS & KNOB_BURST) == 0) {
 #pragma unroll

@@ -768,20 +768,26 @@ class Transformer(nn.Module):
         return ps
 
     def _c_weights_cached(self):
-        """_c_weights(), rebuilt only when a parameter changed (the concatenated QKV matrices are
-        copies: an optimizer step bumps the parameters' version counters and invalidates them)."""
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """_c_weights() with the struct reused while the parameters keep their storage.  The three concatenated QKV
+        matrices are COPIES of parameters: they are refreshed on every call (three small copies per attention block)
+        rather than trusted to a version counter -- writes through `p.data` (load_state_dict of older code, the
+        reference's own init helpers) do not bump it."""
+        key = tuple(p.data_ptr() for p in self.parameters())
         c = getattr(self, "_ait_wcache", None)
         if c is None or c[0] != key:
-            W, keep = self._c_weights()
-            c = (key, W, keep)
+            W, keep, qkv = self._c_weights()
+            c = (key, W, keep, qkv)
             self._ait_wcache = c
+        else:
+            with torch.no_grad():
+                for buf, m in c[3]:
+                    torch.cat([m.w_qs.weight, m.w_ks.weight, m.w_vs.weight], 0, out=buf)
         return c[1], c[2]
 
     def _c_weights(self):
         """ait_transformer_weights (include/ait_hip.h) over this module's parameters; the returned
         keep-alive list owns the concatenated QKV matrices."""
-        keep = []
+        keep, qkv = [], []
 
         def ptr(t):
             t = t.detach()
@@ -792,7 +798,10 @@ class Transformer(nn.Module):
 
         def mha(m):
             w = _lib.MhaWeights()
-            w.w_qkv = ptr(torch.cat([m.w_qs.weight, m.w_ks.weight, m.w_vs.weight], 0))
+            with torch.no_grad():
+                cat = torch.cat([m.w_qs.weight, m.w_ks.weight, m.w_vs.weight], 0)
+            qkv.append((cat, m))
+            w.w_qkv = ptr(cat)
             w.sk_w, w.sk_b, w.fc_w = ptr(m.sh.sk.weight), ptr(m.sh.sk.bias), ptr(m.fc.weight)
             w.ln_g, w.ln_b = ptr(m.layer_norm.weight), ptr(m.layer_norm.bias)
             return w
@@ -813,7 +822,7 @@ class Transformer(nn.Module):
         enc, dec = self.encoder.layer_stack[0], self.decoder.layer_stack[0]
         W.enc_slf, W.dec_slf, W.dec_enc = mha(enc.slf_attn), mha(dec.slf_attn), mha(dec.enc_attn)
         W.enc_ffn, W.dec_ffn = ffn(enc.pos_ffn), ffn(dec.pos_ffn)
-        return W, keep
+        return W, keep, qkv
 
     def forward_tokens_c(self, xp_tok, xq_tok, bp, bs, n_s):
         """Inference through the single C entry point ait_transformer_fwd: token-major inputs
@@ -821,7 +830,7 @@ class Transformer(nn.Module):
         if len(self.encoder.layer_stack) != 1 or len(self.decoder.layer_stack) != 1:
             raise NotImplementedError("ait_transformer_fwd is built for n_layers = 1")
         L = _lib.lib()
-        W, keep = self._c_weights()
+        W, keep, _ = self._c_weights()
         nbytes = int(L.ait_transformer_workspace_bytes(bp, bs, n_s))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=xp_tok.device)
         out = torch.empty((bp * SEQ, 2 * self.channels), dtype=torch.float32, device=xp_tok.device)

@@ -402,7 +402,7 @@ def test_c_sublayer_blocks_match_the_modules():
     n = 5
     x = _dev(seeded(401, (n, 64, 512)))
     mem = _dev(seeded(402, (n, 49, 512)))
-    W, keep = t._c_weights()
+    W, keep, _ = t._c_weights()
 
     def run_mha(wstruct, xq, xkv, kv_rows, mode, n_valid):
         nbytes = int(L.ait_mha_block_workspace_bytes(n, kv_rows))
@@ -482,7 +482,7 @@ def test_c_training_blocks_match_the_modules():
     t = _transformer(3).train()
     L = _lib.lib()
     n, seed = 5, 0x1234ABCD5678
-    W, keep = t._c_weights()
+    W, keep, _ = t._c_weights()
     enc, dec = t.encoder.layer_stack[0], t.decoder.layer_stack[0]
 
     def grads_struct(mod, cls, names):
@@ -628,3 +628,28 @@ def test_any_length_attention_block_matches_the_torch_composition(monkeypatch, l
     kept = float((a1 != 0).float().mean())
     assert abs(kept - 0.9) < 0.01
     assert abs(float(a1.sum(-1).mean()) - 1.0) < 0.01         # rows of dropout(P) still sum to ~1 on average
+
+
+def test_c_weight_cache_follows_writes_through_data():
+    """The training node reads ait_transformer_weights whose QKV matrices are concatenated COPIES of three
+    parameters: a write through `.data` (which does not bump the parameter's version counter) must be seen by the
+    next forward."""
+    from ait_amd import system
+    torch.manual_seed(3)
+    t = system.Transformer(d_k=64, d_v=64, d_model=512, d_word_vec=512, d_inner=2048, n_position=64, n_layers=1,
+                           n_head=8, dropout=0.0).cuda().train()
+    xp = torch.randn(6, 1024, 7, 7, device="cuda")
+    xq = torch.randn(2, 1024, 8, 8, device="cuda")
+    y0 = t(x_props=xp, x_query=xq).detach().clone()
+    w = t.encoder.layer_stack[0].slf_attn.w_qs.weight
+    v0 = w._version
+    w.data.mul_(1.5)
+    assert w._version == v0                     # the hazard: nothing tells a version-keyed cache
+    y1 = t(x_props=xp, x_query=xq).detach().clone()
+    system._PY_COMPOSE = True
+    try:
+        y2 = t(x_props=xp, x_query=xq).detach().clone()      # op by op: reads the parameters themselves
+    finally:
+        system._PY_COMPOSE = False
+    assert float((y1 - y0).abs().max()) > 1e-4
+    assert float((y1 - y2).abs().max()) <= 2e-5 * float(y2.abs().max())

@@ -298,7 +298,7 @@ def main():
         ms = sum(p[1] for p in ev) / len(ev)
         b = sum(p[0] for p in ev) / len(ev)
         gbs = b / (ms * 1e-3) / 1e9
-        return {"kernel": "roi_align_nhwc_fwd_sliced_kernel" if tag == "fwd" else "roi_align_nhwc_bwd_kernel",
+        return {"kernel": "roi_align_nhwc_fwd_sliced_kernel" if tag == "fwd" else "roi_align_nhwc_bwd_tile_kernel",
                 "bound": "hbm", "achieved": gbs,
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "ms_per_launch": ms,
                 "algorithmic_bytes_per_launch": b, "launches_per_step": len(ev) // max(1, args.steps),

@@ -65,7 +65,7 @@ def test_roi_align_channels_last_golden_and_oracle(golden):
     rois_r = cases.random_rois(403, 64, 2)
     y3 = op(_dev(feat_r), _dev(rois_r)).cpu().numpy()
     np.testing.assert_allclose(y3, g["y_rand"], rtol=1e-5, atol=1e-6)
-    for C, n in ((1024, 300), (40, 17), (2052, 5)):
+    for C, n in ((1024, 300), (40, 17), (2052, 5), (256, 33), (96, 9)):      # (tiled backward: C % 32 == 0, C <= 1024)
         feat = seeded(7, (2, C, cases.FEAT_H, cases.FEAT_W))
         rois = cases.random_rois(8, n, 2)
         x = _dev(feat).contiguous(memory_format=torch.channels_last).requires_grad_(True)

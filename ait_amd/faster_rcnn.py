@@ -646,6 +646,16 @@ class _fasterRCNN(nn.Module):
         state["_query_graphs"] = {}          # HIP graphs do not pickle / deepcopy; they are re-captured on first use
         return state
 
+    def _query_graph_on(self, query):
+        """graph replay of the query trunk: training on the GPU, in a single-process run.  Under torch.distributed
+        (DDP over RCCL) the launches stay eager: a capture in `global` error mode is invalidated by any HIP query from
+        another thread, and the process group's watchdog thread polls its work events whenever it likes -- not
+        something a one-GPU box can test."""
+        import torch.distributed as dist
+        if not (_QUERY_GRAPH and self.training and query.is_cuda and torch.is_grad_enabled() and not query.requires_grad):
+            return False
+        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
     def _side_stream(self, device):
         key = ("stream", device.index)
         if key not in self._query_graphs:
@@ -657,8 +667,7 @@ class _fasterRCNN(nn.Module):
         cfg.TRAIN.query_size, roibatchLoader.py:287-331), so in training on the GPU the trunk's launches for them -- small kernels, bound
         by the host's issue rate, not by the GPU -- are replayed from two HIP graphs (forward, backward) captured
         on first use per (shape, parameter storage).  Same kernels, same order, same values as the eager launches."""
-        if not (_QUERY_GRAPH and self.training and query.is_cuda and torch.is_grad_enabled()
-                and not query.requires_grad):
+        if not self._query_graph_on(query):
             return self.RCNN_base(query)[0]
         key = (tuple(query.shape), query.dtype, query.device.index, _BASE_NHWC, _SK_FULL) \
             + tuple((p.data_ptr(), p.requires_grad) for p in self.RCNN_base.parameters())
@@ -680,7 +689,7 @@ class _fasterRCNN(nn.Module):
             self.RCNN_rpn.RPN_anchor_target.begin(gt_boxes, img_info, *_c4_size(image.size(2), image.size(3)),
                                                   im_hw_hint=(image.size(2), image.size(3)))
 
-        if _QUERY_GRAPH and self.training and query.is_cuda and torch.is_grad_enabled():
+        if self._query_graph_on(query):
             # the query patches' trunk is small kernels back to back (dispatch-latency bound): replayed on a second
             # HIP stream it runs in the shadow of the target image's trunk, forward and (autograd runs a node's
             # backward on the stream of its forward) backward

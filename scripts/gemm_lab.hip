@@ -39,7 +39,7 @@ using V_sp4 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD>;    // 4 wav
 using V_256sq = Cfg<256, 256, 16, 4, 4, 4, MODE_DLDS, 3, 0>;             // 16 waves, 96 KB: one workgroup per CU
 using V_split = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT>;     // the product tile, products on the bf16 matrix pipe (3-way split, 6 terms)
 using V_split8 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_SPLIT_SIMPLE>;    // every split in front of its tile's MFMAs
-using V_splitsq = Cfg<256, 256, 16, 2, 2, 1, MODE_DLDS, 3, KNOB_SPLIT>;   // 4 waves of 128x128, one workgroup per CU
+using V_splitsq = Cfg<256, 256, 16, 2, 4, 2, MODE_DLDS, 3, KNOB_SPLIT>;   // 256x256, EIGHT waves of 128x64, one workgroup per CU (98 KB)
 using V_stag = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD | KNOB_STAGGER>;   // the product tile, odd threadgroup slots start half a tile late
 #ifndef NO_OLD
 using OldD = ait_gemm_old::Cfg<256, 128, 16, 4, 2, 2, 6 + 256>;

@@ -399,7 +399,7 @@ class _TailFn(torch.autograd.Function):
         ctx.save_for_backward(xp, xq, saved)
         ctx.W, ctx.keep = W, keep
         ctx.cfg = (bp, bs, C, planes, n_blocks)
-        ctx.meta = [(tuple(t.shape), t.dim() == 4 and t.shape[2] > 1) for t in params]
+        ctx.meta = [tuple(t.shape) for t in params]
         return pooled
 
     @staticmethod
@@ -409,10 +409,10 @@ class _TailFn(torch.autograd.Function):
         bp, bs, C, planes, n_blocks = ctx.cfg
         dev = xp.device
         d_pooled = d_pooled.contiguous()
-        sizes = [int(np.prod(sh)) for sh, _ in ctx.meta]
+        sizes = [int(np.prod(sh)) for sh in ctx.meta]
         flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         views, ptrs, o = [], [], 0
-        for (sh, is_kxk), n in zip(ctx.meta, sizes):
+        for sh, n in zip(ctx.meta, sizes):
             v = flat[o:o + n]
             ptrs.append(v.data_ptr())
             if len(sh) == 4:        # [cout][kh][kw][cin/g] memory = the channels-last strides of a [cout, cin/g, kh, kw] gradient

@@ -180,6 +180,14 @@ using Tile128D = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, KNOB_SPLIT>;
 // 64 x 128, two waves: grouped convolutions over a handful of rows (the query side of the SK block: 64 output rows) --
 // a 256-row tile would multiply three quarters of padding there
 using TileS = Cfg<64, 128, 16, 1, 2, 2, MODE_DLDS, 3, KNOB_SPLIT>;
+// the same three tiles with the operands rounded to bf16 and one MFMA per block (AIT_CTX_BF16)
+struct SplitFam { using T256 = Tile256D; using T128 = Tile128D; using TS = TileS; };
+struct Bf16Fam {
+  using T256 = Tile256B;
+  using T128 = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_BF16>;
+  using TS = Cfg<64, 128, 16, 1, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BF16>;
+};
+inline bool bf16_products(const ait_launch_ctx* ctx) { return ctx && (ctx->flags & AIT_CTX_BF16); }
 
 inline int log2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;
@@ -236,17 +244,35 @@ int parity_launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
   if (g.residual) return launch<T, true, false, EPI_RES, NoProbe, CONV_A, GRP, true>(g, s, ws);
   return launch<T, true, false, EPI_STORE, NoProbe, CONV_A, GRP, true>(g, s, ws);
 }
-template <int CONV, bool AK, bool BKC>
-int conv_dispatch(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
+template <class F, int CONV, bool AK, bool BKC>
+int conv_dispatch_f(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
   if (g.conv.a_group) {        // grouped: separate instantiations (see glds16<FORCE_UNIFORM>)
     if ((g.residual || (g.flags & ~AIT_GEMM_RELU)) && !(CONV == CONV_A && !BKC)) return AIT_EUNSUPPORTED;
-    if (g.M <= 128) return conv_launch<TileS, CONV, AK, BKC, true>(g, s, ws);
-    return conv_launch<Tile256D, CONV, AK, BKC, true>(g, s, ws);
+    if (g.M <= 128) return conv_launch<typename F::TS, CONV, AK, BKC, true>(g, s, ws);
+    return conv_launch<typename F::T256, CONV, AK, BKC, true>(g, s, ws);
   }
   const long long tiles256 = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128) * g.splits;
   if (tiles256 >= 512 || (tiles256 >= 96 && g.K >= 512 && g.splits == 1 && !(g.flags & AIT_GEMM_ATOMIC) && ws.p != nullptr))
-    return conv_launch<Tile256D, CONV, AK, BKC>(g, s, ws);
-  return conv_launch<Tile128D, CONV, AK, BKC>(g, s, ws);     // few tiles: 128x128, three to a CU
+    return conv_launch<typename F::T256, CONV, AK, BKC>(g, s, ws);
+  return conv_launch<typename F::T128, CONV, AK, BKC>(g, s, ws);     // few tiles: 128x128, three to a CU
+}
+template <int CONV, bool AK, bool BKC>
+int conv_dispatch(const GemmArgs& g, hipStream_t s, const ait_launch_ctx* ctx) {
+  if (bf16_products(ctx)) return conv_dispatch_f<Bf16Fam, CONV, AK, BKC>(g, s, sched_ws_of(ctx));
+  return conv_dispatch_f<SplitFam, CONV, AK, BKC>(g, s, sched_ws_of(ctx));
+}
+template <class F>
+int parity_dispatch(const GemmArgs& g, hipStream_t s, const SchedWs& ws, bool small, bool grouped, bool big) {
+  if (small) return parity_launch<typename F::TS, true>(g, s, ws);
+  if (grouped) return parity_launch<typename F::T256, true>(g, s, ws);
+  if (big) return parity_launch<typename F::T256, false>(g, s, ws);
+  return parity_launch<typename F::T128, false>(g, s, ws);
+}
+template <class F>
+int wgrad_dispatch(const GemmArgs& g, hipStream_t s, const SchedWs& ws, bool grouped) {
+  // (grouped: 128-row tiles, one group of output channels per row tile)
+  if (grouped) return conv_launch<typename F::T128, CONV_B, false, false, true>(g, s, ws);
+  return conv_launch<typename F::T256, CONV_B, false, false>(g, s, ws);
 }
 }  // namespace
 
@@ -269,7 +295,7 @@ AIT_API int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_
   g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), (int)rows, cout,
                       taps * cing, 0, 1, 1);
-  return conv_dispatch<CONV_A, true, true>(g, ait_stream(stream), sched_ws_of(ctx));
+  return conv_dispatch<CONV_A, true, true>(g, ait_stream(stream), ctx);
 }
 
 // Data gradient of a STRIDE-2 convolution by parity class of the input positions, ONE launch (ConvGeom, gemm_f32_impl.h):
@@ -326,10 +352,8 @@ int ait_conv_bwd_data_s2(const float* dy, int lddy, const float* w, const ait_co
   SchedWs ws = sched_ws_of(ctx);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, flops, s, (int)(class_rows * 4), cin, (int)(flops / (2.0 * class_rows * 4 * cin)),
                       0, 0, 1);
-  if (small) return parity_launch<TileS, true>(g, s, ws);
-  if (G > 1) return parity_launch<Tile256D, true>(g, s, ws);
-  if (big) return parity_launch<Tile256D, false>(g, s, ws);
-  return parity_launch<Tile128D, false>(g, s, ws);
+  if (bf16_products(ctx)) return parity_dispatch<Bf16Fam>(g, s, ws, small, G > 1, big);
+  return parity_dispatch<SplitFam>(g, s, ws, small, G > 1, big);
 }
 
 AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, const ait_conv_geom* q, int cin, int cout,
@@ -356,7 +380,7 @@ AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, con
                      G > 1 ? coutg : 0, cing);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cin * taps * coutg, ait_stream(stream), (int)rows, cin,
                       taps * coutg, 0, 0, 1);
-  return conv_dispatch<CONV_A, true, false>(g, ait_stream(stream), sched_ws_of(ctx));
+  return conv_dispatch<CONV_A, true, false>(g, ait_stream(stream), ctx);
 }
 
 AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, int ldx, const ait_conv_geom* q, int cin,
@@ -375,7 +399,6 @@ AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, i
   g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), cout, taps * cing,
                       (int)rows, 1, 0, g.splits);
-  // (grouped: 128-row tiles, one group of output channels per row tile)
-  if (G > 1) return conv_launch<Tile128D, CONV_B, false, false, true>(g, ait_stream(stream), sched_ws_of(ctx));
-  return conv_launch<Tile256D, CONV_B, false, false>(g, ait_stream(stream), sched_ws_of(ctx));
+  if (bf16_products(ctx)) return wgrad_dispatch<Bf16Fam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1);
+  return wgrad_dispatch<SplitFam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1);
 }

@@ -223,9 +223,10 @@ def main():
     from ait_amd import distributed as D
     from ait_amd import _lib, ops, tuning
     rank, local_rank, world = D.init()
-    # MIOpen solver picks for the torch-side convolutions: the committed find-db holds the cfg2 shapes (bs 4, VOC
-    # variant); any other shape would start an exhaustive search (minutes), so those run MIOpen's immediate mode
-    tuned = tuning.use_tuned_miopen_db(rank) if (args.config == "cfg2" and args.bs == 4 and args.variant == "voc") else False
+    # MIOpen solver picks for the torch-side convolutions: the committed find-db holds the shapes of cfg2 .. cfg5 as
+    # configured (scripts/exp_miopen_db.py); any other batch size / variant would start a search (minutes) on the
+    # first step, so those run MIOpen's immediate mode
+    tuned = tuning.use_tuned_miopen_db(rank) if (args.bs == conf["bs"] and args.variant == conf["variant"]) else False
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():

@@ -69,7 +69,8 @@ const char* ait_strerror(int code);
  *       AIT_CTX_BF16: the same dense products with every operand value ROUNDED to bf16 (nearest even) in registers
  *       and ONE v_mfma_f32_32x32x16_bf16 per block, f32 accumulate, f32 operands and results in memory -- what
  *       torch.autocast(bfloat16) computes for a linear layer with f32 parameters (BASELINE configs[4]); NOT f32
- *       accuracy (8 significant bits per operand).
+ *       accuracy (8 significant bits per operand).  Honoured by the products, the composites and the convolutions
+ *       (ait_conv_*, ait_tail_*).
  * ------------------------------------------------------------------------------------- */
 #define AIT_CTX_NATIVE_F32 1u
 #define AIT_CTX_BF16 2u

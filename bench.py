@@ -312,7 +312,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32",
                   "f32_native": "f32",
-                  "bf16": "bf16 (AIT GEMM operands; fp32 accumulate, fp32 elsewhere)",
+                  "bf16": "bf16 products (AIT GEMMs and the proposal tail's convolutions: operands rounded to bf16 in registers, one MFMA per block, f32 accumulate); f32 storage; f32 trunk / LayerNorm / attention tiles",
                   "bf16x3": "f32 emulated as 3 bf16 MFMAs per product (experimental; fp32 accumulate)"}[args.dtype],
         "data": "synthetic",
         "config": {"workload": conf["workload"] % {"P": args.proposals, "bs": args.bs},
@@ -329,6 +329,7 @@ def main():
                                "six v_mfma_f32_32x32x16_bf16 (f32 accumulate) per 32x32x16 block = f32-equivalent products "
                                "(few-tile launches: gemm_f32_kernel on v_mfma_f32_32x32x2_f32)" if args.dtype == "f32"
                                else "gemm_f32_stream_kernel / gemm_f32_kernel (v_mfma_f32_32x32x2_f32)" if args.dtype == "f32_native"
+                               else "gemm_f32_stream_kernel with KNOB_BF16 (operands rounded to bf16 in registers, one v_mfma_f32_32x32x16_bf16 per block)" if args.dtype == "bf16"
                                else "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16%s)" % (", 3 per product" if args.dtype == "bf16x3" else ""),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak,

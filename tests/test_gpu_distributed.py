@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent("""
-    import os, sys
+    import faulthandler, os, sys
+    faulthandler.dump_traceback_later(150, exit=True)      # a rank that hangs says where (all threads), then exits
     sys.path.insert(0, %r)
     import numpy as np, torch, torch.distributed as dist
     from ait_amd import distributed as D, _lib
@@ -66,6 +67,7 @@ WORKER = textwrap.dedent("""
         dist.all_gather(mine, alone[k])
         mean = (mine[0] + mine[1]) / world
         rel = float((got[k] - mean).norm() / (mean.norm() + 1e-20))
+        print("rank", rank, k, "rel", rel, flush=True)
         # (split-K weight-gradient kernels -- MIOpen's and this library's -- sum with atomics: two runs of the
         # same step differ by ~1e-4 relative; gradients of DIFFERENT shards differ by O(1))
         assert rel < 1e-3, (k, rel)
@@ -99,10 +101,11 @@ def test_two_ranks_train_the_real_detector(tmp_path):
     outs = []
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=420)[0])
+            outs.append(p.communicate(timeout=240)[0])
         except subprocess.TimeoutExpired:
             p.kill()
             outs.append(p.communicate()[0])
+    report = "\n".join("---- rank %d (exit %s) ----\n%s" % (r, p.returncode, o[-4000:]) for r, (p, o) in enumerate(zip(procs, outs)))
     for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+        assert p.returncode == 0, "rank %d failed; both ranks' output:\n%s" % (r, report)
         assert "rank %d ok" % r in o

@@ -58,6 +58,7 @@ using Tile256N = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD>;      // 
 using Tile256 = Cfg<256, 128, 16, 4, 2, 2, MODE_RING>;
 using Tile128 = Cfg<128, 128, 16, 2, 2, 2, MODE_DB>;
 using TileN64 = Cfg<256, 64, 16, 4, 1, 2, MODE_DB>;
+using TileN64D = Cfg<256, 64, 16, 4, 1, 2, MODE_DLDS, 3, KNOB_SPLIT>;      // the same 256x64 outputs on the persistent split tile (four waves of 64x64)
 using Tile64 = Cfg<64, 64, 16, 2, 2, 2, MODE_DB>;
 }  // namespace
 
@@ -92,7 +93,12 @@ int ait_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, float alpha, 
   // operand "K-contiguous" means the reduction dimension is the fast one in memory:
   //   A: !trans_a  (A is [M,K]);   B: trans_b (B is [N,K])
   const long long tiles256 = (long long)((M + 255) / 256) * ((N + 127) / 128) * g.splits;
-  if (N <= 64 && (long long)((M + 255) / 256) * g.splits >= 128) return dispatch<TileN64>(g, !trans_a, trans_b != 0, ait_stream(stream));
+  if (N <= 64 && (long long)((M + 255) / 256) * g.splits >= 128) {
+    const bool direct64 = K > 0 && (K % 16 == 0) && N == 64 && (!trans_a || (M % 4 == 0 && M >= 4)) &&
+                          !(ctx && (ctx->flags & (AIT_CTX_NATIVE_F32 | AIT_CTX_BF16)));
+    if (direct64) return dispatch<TileN64D>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);
+    return dispatch<TileN64>(g, !trans_a, trans_b != 0, ait_stream(stream));
+  }
   const bool direct = K > 0 && (K % 16 == 0) && (!trans_a || (M % 4 == 0 && M >= 4)) && (trans_b || (N % 4 == 0 && N >= 4));
   // with the stream-K work list (a scheduler workspace) the persistent tile also serves products of a few hundred
   // tiles (their slabs are spread over all workgroups): layer4-sized and co-attention-sized products; split-K

@@ -6,6 +6,8 @@
 //   pattern 2: two independent MFMAs between dependent ones                            -- three chains rotating
 //   pattern 3: three independent MFMAs between                                        -- four chains rotating
 //   pattern 10 + n: n independent v_add_f32 between dependent MFMAs (one chain)
+//   pattern 30: one ds_read_b128 (into registers nothing else uses) between dependent MFMAs (one chain)
+//   pattern 31: the same ds_read_b128s, all issued in front of the chain
 // Operands are small integers (exact in bf16, sums exact in f32): every schedule must produce the same bits; a
 // difference is a dependent MFMA that read part of its SrcC before the predecessor's write-back landed.
 //   hipcc -O3 --offload-arch=gfx950 scripts/mfma_hazard.hip -o scripts/_mfma_hazard && scripts/_mfma_hazard
@@ -32,7 +34,15 @@ template <int PATTERN>
 __global__ __launch_bounds__(256, 2) void chain_kernel(int steps, float* __restrict__ out, float* __restrict__ sink) {
   const unsigned id = blockIdx.x * 256 + threadIdx.x;
   constexpr int NCH = PATTERN == 0 ? 1 : PATTERN <= 3 ? PATTERN + 1 : 1;
-  constexpr int NFILL = PATTERN >= 10 ? PATTERN - 10 : 0;
+  constexpr int NFILL = (PATTERN >= 10 && PATTERN < 30) ? PATTERN - 10 : 0;
+  __shared__ __attribute__((aligned(16))) float lds[256 * 4 * 6];
+  for (int i = threadIdx.x; i < 256 * 4 * 6; i += 256) lds[i] = (float)i;
+  __syncthreads();
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 dsv[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) dsv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned dsaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(lds + threadIdx.x * 4);
   f32x16 acc[4];
 #pragma unroll
   for (int c = 0; c < 4; c++)
@@ -45,18 +55,26 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(int steps, float* __restr
     // every chain receives the same operand sequence, so all chains must end with the same accumulator
     const bf16x8 a = operand(id * 2654435761u, s), b = operand(id * 40503u + 7u, s);
     SB();
+    if constexpr (PATTERN == 31) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dsv[q]) : "v"(dsaddr), "n"(0)); SB(); }
+    }
 #pragma unroll
     for (int rep = 0; rep < 6; rep++) {
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
         SB();
+        if constexpr (PATTERN == 30) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dsv[rep]) : "v"(dsaddr), "n"(0)); SB(); }
 #pragma unroll
         for (int q = 0; q < NFILL; q++) { asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(f[q])); SB(); }
       }
     }
   }
   float t = 0.f;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < 6; q++) t += dsv[q][0] * 0.f;
 #pragma unroll
   for (int q = 0; q < 12; q++) t += f[q];
   if (t == -1.f) sink[0] = t;
@@ -150,7 +168,7 @@ int main(int argc, char** argv) {
   hipMalloc(&d_sink, 4);
   std::vector<float> ref;
   run<0>(steps, blocks, ref, &ref, d_out, d_sink);
-  for (int rep = 0; rep < 1; rep++) {
+  for (int rep = 0; rep < 2; rep++) {
     run<0>(steps, blocks, ref, nullptr, d_out, d_sink);
     run<1>(steps, blocks, ref, nullptr, d_out, d_sink);
     run<2>(steps, blocks, ref, nullptr, d_out, d_sink);
@@ -160,6 +178,8 @@ int main(int argc, char** argv) {
     run<14>(steps, blocks, ref, nullptr, d_out, d_sink);
     run<17>(steps, blocks, ref, nullptr, d_out, d_sink);
     run<22>(steps, blocks, ref, nullptr, d_out, d_sink);
+    run<30>(steps, blocks, ref, nullptr, d_out, d_sink);
+    run<31>(steps, blocks, ref, nullptr, d_out, d_sink);
   }
   std::vector<float> wref;
   run_war<4, 1>(steps, blocks, &wref, wref, d_out);

@@ -207,10 +207,22 @@ inline ConvGeom make_geom(int hw_shift, int w_shift, int src_h, int src_w, int k
                           int seg, long long b_tap_stride, const float* zero, int a_group, int n_group) {
   ConvGeom m{};
   m.rows_hw_shift = hw_shift; m.rows_w_shift = w_shift; m.src_h = src_h; m.src_w = src_w; m.kw = kw;
+  m.n_rows = 0x7fffffff;
   m.a = a; m.b = b; m.c = c; m.div_shift = div_shift; m.seg = seg; m.b_tap_stride = b_tap_stride;
   m.zero = zero; m.a_group = a_group; m.n_group = n_group;
   m.wt_kw = kw; m.a2_class = -1;
   return m;
+}
+
+// maps whose sides are not powers of two: the row -> (image, y, x) decomposition by corrected f32 quotients
+// (gemm_f32_impl.h div_small; exact below 2^24 rows)
+inline bool set_general_rows(ConvGeom& m, int rows_h, int rows_w, long long n_rows) {
+  if (n_rows >= (1ll << 24) || rows_h <= 0 || rows_w <= 0) return false;
+  m.rows_hw_shift = -1; m.rows_w_shift = -1;
+  m.rows_hw = rows_h * rows_w; m.rows_w = rows_w;
+  m.inv_hw = 1.0f / (float)m.rows_hw; m.inv_w = 1.0f / (float)rows_w;
+  m.n_rows = (int)n_rows;
+  return true;
 }
 
 inline int check_geom(const ait_conv_geom* q, int cin, int cout) {
@@ -287,8 +299,10 @@ AIT_API int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_
                              const float* zeros, size_t zeros_floats, const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY_RC(check_geom(q, cin, cout));
   const int hw = log2_exact(q->out_h * q->out_w), ws = log2_exact(q->out_w);
-  if (hw < 0 || ws < 0 || (cin & 15) || (cout & 3)) return AIT_EUNSUPPORTED;
+  const bool general = hw < 0 || ws < 0;
+  if ((cin & 15) || (cout & 3)) return AIT_EUNSUPPORTED;
   const long long rows = (long long)q->n * q->out_h * q->out_w;
+  if (general && (rows >= (1ll << 24) || q->groups > 1)) return AIT_EUNSUPPORTED;
   if (rows == 0) return AIT_OK;
   if (rows > 0x7fffffffLL / 4 || !x || !w || !y || !zeros || zeros_floats < (size_t)cin + 144) return AIT_EINVAL;
   if (flags & ~(AIT_GEMM_RELU | AIT_GEMM_MASK_POS)) return AIT_EINVAL;
@@ -299,6 +313,7 @@ AIT_API int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_
   AIT_TRY_RC(make_args(0, 1, (int)rows, cout, taps * cing, 1.f, x, ldx, w, taps * cing, y, ldy, bias, residual, flags, 1, 0, 0,
                        16, g));
   g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
+  if (general) set_general_rows(g.conv, q->out_h, q->out_w, rows);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), (int)rows, cout,
                       taps * cing, 0, 1, 1);
   return conv_dispatch<CONV_A, true, true>(g, ait_stream(stream), ctx);
@@ -367,8 +382,10 @@ AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, con
                                   size_t zeros_floats, const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY_RC(check_geom(q, cin, cout));
   const int hw = log2_exact(q->in_h * q->in_w), ws = log2_exact(q->in_w);
-  if (hw < 0 || ws < 0 || (cout & 15) || (cin & 3)) return AIT_EUNSUPPORTED;
+  const bool general = hw < 0 || ws < 0;
+  if ((cout & 15) || (cin & 3)) return AIT_EUNSUPPORTED;
   const long long rows = (long long)q->n * q->in_h * q->in_w;
+  if (general && (rows >= (1ll << 24) || q->groups > 1)) return AIT_EUNSUPPORTED;
   if (rows == 0) return AIT_OK;
   if (rows > 0x7fffffffLL / 4 || !dy || !w || !dx || !zeros || zeros_floats < (size_t)cout + 144) return AIT_EINVAL;
   if (flags & ~AIT_GEMM_MASK_POS) return AIT_EINVAL;
@@ -384,6 +401,7 @@ AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, con
                        0, 0, 16, g));
   g.conv = make_geom(hw, ws, q->out_h, q->out_w, q->kw, 1, -1, q->pad, log2_exact(q->stride), coutg, (long long)cing, zeros,
                      G > 1 ? coutg : 0, cing);
+  if (general) set_general_rows(g.conv, q->in_h, q->in_w, rows);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cin * taps * coutg, ait_stream(stream), (int)rows, cin,
                       taps * coutg, 0, 0, 1);
   return conv_dispatch<CONV_A, true, false>(g, ait_stream(stream), ctx);
@@ -395,14 +413,18 @@ AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, i
   AIT_TRY_RC(check_geom(q, cin, cout));
   const int hw = log2_exact(q->out_h * q->out_w), ws = log2_exact(q->out_w);
   const long long rows = (long long)q->n * q->out_h * q->out_w;
-  if (hw < 0 || ws < 0 || ((cin / (q->groups > 1 ? q->groups : 1)) % 128) || (cout & 3) || (rows & 15)) return AIT_EUNSUPPORTED;
+  const bool general = hw < 0 || ws < 0 || (rows & 15);
+  if (((cin / (q->groups > 1 ? q->groups : 1)) % 128) || (cout & 3)) return AIT_EUNSUPPORTED;
+  if (general && (rows >= (1ll << 24) || q->groups > 1 || rows < 16)) return AIT_EUNSUPPORTED;
   if (rows == 0) return AIT_OK;
   if (rows > 0x7fffffffLL / 4 || !dy || !x || !dw || !zeros || zeros_floats < (size_t)cin + 144) return AIT_EINVAL;
   const int taps = q->kh * q->kw, G = q->groups > 1 ? q->groups : 1, cing = cin / G;
   GemmArgs g;
-  AIT_TRY_RC(make_args(1, 0, cout, taps * cing, (int)rows, 1.f, dy, lddy, x, ldx, dw, taps * cing, nullptr, nullptr,
-                       AIT_GEMM_ATOMIC, split_k < 1 ? 1 : split_k, 0, 0, 16, g));
+  // (general maps: the reduction runs over rows rounded up to a whole slab; see ConvGeom::n_rows)
+  AIT_TRY_RC(make_args(1, 0, cout, taps * cing, (int)((rows + 15) / 16 * 16), 1.f, dy, lddy, x, ldx, dw, taps * cing, nullptr,
+                       nullptr, AIT_GEMM_ATOMIC, split_k < 1 ? 1 : split_k, 0, 0, 16, g));
   g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
+  if (general) set_general_rows(g.conv, q->out_h, q->out_w, rows);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), cout, taps * cing,
                       (int)rows, 1, 0, g.splits);
   if (bf16_products(ctx)) return wgrad_dispatch<Bf16Fam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1);

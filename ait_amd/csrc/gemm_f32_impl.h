@@ -35,7 +35,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 //   CONV_B (2): weight gradient, C[cout, t*seg + ch] += sum_r A[r, cout] * src[gather(r, t), ch]: the K-outer
 //               operand B is gathered row by row, the tap is fixed per output column tile (seg % BN == 0).
 struct ConvGeom {
-  int rows_hw_shift, rows_w_shift;      // log2(rows_h * rows_w), log2(rows_w)
+  int rows_hw_shift, rows_w_shift;      // log2(rows_h * rows_w), log2(rows_w); rows_hw_shift < 0: maps of any size, below
+  int rows_hw, rows_w;                  // rows_h * rows_w, rows_w (general maps: rows < 2^24)
+  float inv_hw, inv_w;                  // their reciprocals (a quotient estimate, corrected exactly)
+  int n_rows;                           // GEMM rows that exist (CONV_B: reduction rows beyond it read the row of zeros)
   int src_h, src_w;
   int kw;                               // taps per window row
   int a, b, c, div_shift;
@@ -94,9 +97,28 @@ __device__ __forceinline__ int parity_src_row(const ConvGeom& c, const ConvGeom:
 }
 enum { CONV_NONE = 0, CONV_A = 1, CONV_B = 2 };
 
+// n / d for 0 <= n < 2^24 (exact in f32): the f32 quotient is off by at most one, corrected with the remainder
+__device__ __forceinline__ int div_small(int n, int d, float inv, int& rem) {
+  int q = (int)((float)n * inv);
+  rem = n - q * d;
+  if (rem < 0) { q--; rem += d; }
+  if (rem >= d) { q++; rem -= d; }
+  return q;
+}
+
 __device__ __forceinline__ int conv_src_row(const ConvGeom& c, int r, int tap) {
-  const int img = r >> c.rows_hw_shift, rem = r & ((1 << c.rows_hw_shift) - 1);
-  const int y = rem >> c.rows_w_shift, x = rem & ((1 << c.rows_w_shift) - 1);
+  int img, y, x;
+  if (c.rows_hw_shift >= 0) {
+    img = r >> c.rows_hw_shift;
+    const int rem = r & ((1 << c.rows_hw_shift) - 1);
+    y = rem >> c.rows_w_shift;
+    x = rem & ((1 << c.rows_w_shift) - 1);
+  } else {
+    if (r >= c.n_rows) return -1;
+    int rem;
+    img = div_small(r, c.rows_hw, c.inv_hw, rem);
+    y = div_small(rem, c.rows_w, c.inv_w, x);
+  }
   const int ty = tap / c.kw, tx = tap - ty * c.kw;
   const int ny = y * c.a + c.c + ty * c.b, nx = x * c.a + c.c + tx * c.b;
   const int sy = ny >> c.div_shift, sx = nx >> c.div_shift;
@@ -840,7 +862,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     int m0, n0;
     if (!get_item(it, m0, n0, l_k, l_kend)) { l_valid = false; return; }
     l_n0 = n0;
-    if constexpr (GRP || ROWMAP) l_m0 = m0;
+    if constexpr (GRP || ROWMAP || CONV == CONV_B) l_m0 = m0;
 #pragma unroll
     for (int i = 0; i < LA; i++) {
       const int q = wave + i * NW;
@@ -855,7 +877,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         else pa[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + l_k + chunk * 4;
       } else {
         const int e = q * 256 + lane * 4;            // element of the [16][BM] image
-        pa[i] = g.A + (size_t)(l_k + e / BM) * g.lda + min(m0 + e % BM, g.M - 4);
+        int kr = l_k + e / BM;
+        // (weight gradient over maps of any size: the reduction runs to the next multiple of 16 rows; the gathered
+        // operand reads zeros there, this one re-reads its last real row)
+        if constexpr (CONV == CONV_B) { if (g.conv.rows_hw_shift < 0) kr = min(kr, g.conv.n_rows - 1); }
+        pa[i] = g.A + (size_t)kr * g.lda + min(m0 + e % BM, g.M - 4);
       }
     }
     if (CONV == CONV_B) return;      // the gathered operand is addressed transfer by transfer (issue)
@@ -933,6 +959,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     if (l_k >= l_kend) {
       l_item += 1;
       set_tile(l_item);          // (clears l_valid past the end)
+    } else if (CONV == CONV_B && !AK) {
+      if (g.conv.rows_hw_shift < 0 && l_k + BK > g.conv.n_rows) {       // the slab that holds the last real rows
+#pragma unroll
+        for (int i = 0; i < LA; i++) {
+          const int e = (wave + i * NW) * 256 + lane * 4;
+          pa[i] = g.A + (size_t)min(l_k + e / BM, g.conv.n_rows - 1) * g.lda + min(l_m0 + e % BM, g.M - 4);
+        }
+      }
     } else if (CONV == CONV_A) {
       if (l_k % g.conv.seg == 0) retap();      // next tap: new source rows (and, K-outer weights, new tap base)
     }

@@ -652,6 +652,49 @@ def _const(values, dev, dt):
     return t
 
 
+class _Conv3x3BiasRelu(torch.autograd.Function):
+    """relu(conv3x3(x) + bias), stride 1, pad 1, on a channels-last map of ANY size as the library's implicit GEMM
+    (ait_conv_fwd_f32 / ait_conv_bwd_data_f32 / ait_conv_bwd_weight_f32: f32 products on the bf16 matrix pipe, bias +
+    ReLU in the forward epilogue).  The RPN's 1024 -> 512 convolution (lib/model/rpn/rpn.py:32,53) is 270 GFLOP per
+    bench step forward + backward: the largest single convolution outside the proposal tail."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        n, cin, h, w = x.shape
+        cout = weight.shape[0]
+        xm = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)                   # view of channels-last x
+        wm = weight.permute(0, 2, 3, 1)                                      # [cout, kh, kw, cin]: channels-last memory
+        if not wm.is_contiguous():
+            wm = wm.contiguous()
+        geom = ops.conv_geom(n, (h, w), (h, w), (3, 3), 1, 1)
+        ym = ops.conv_fwd(xm, wm, geom, bias=bias, relu=True)
+        y = ym.view(n, h, w, cout).permute(0, 3, 1, 2)
+        ctx.save_for_backward(xm, wm, y)
+        ctx.geom, ctx.xshape = geom, (n, cin, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, wm, y = ctx.saved_tensors
+        n, cin, h, w = ctx.xshape
+        cout = wm.shape[0]
+        dz = torch.where(y > 0, dy, torch.zeros((), dtype=dy.dtype, device=dy.device))
+        dzm = dz.permute(0, 2, 3, 1).reshape(n * h * w, cout)
+        if not dzm.is_contiguous():
+            dzm = dzm.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv_bwd_data(dzm, wm, ctx.geom).view(n, h, w, cin).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv_bwd_weight(dzm, xm, ctx.geom, 3, 3, split_k=8).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[2]:
+            db = ops.colsum(dzm)
+        return dx, dw, db
+
+
+_RPN_CONV_KERNEL = True     # test hook: False = PyTorch-ROCm's convolution + ReLU
+
+
 class _RPN(nn.Module):
     """Region proposal network head: 3x3 conv -> {2A objectness, 4A box deltas}."""
 
@@ -679,7 +722,13 @@ class _RPN(nn.Module):
 
     def forward(self, base_feat, im_info, gt_boxes, num_boxes):
         b = base_feat.size(0)
-        conv = F.relu(self.RPN_Conv(base_feat), inplace=True)
+        c = self.RPN_Conv
+        if (_RPN_CONV_KERNEL and base_feat.is_cuda and base_feat.dtype == torch.float32 and c.in_channels % 128 == 0
+                and c.out_channels % 16 == 0 and base_feat.is_contiguous(memory_format=torch.channels_last)
+                and base_feat.shape[0] * base_feat.shape[2] * base_feat.shape[3] >= 16):
+            conv = _Conv3x3BiasRelu.apply(base_feat, c.weight, c.bias)
+        else:
+            conv = F.relu(c(base_feat), inplace=True)
         cls_score = self.RPN_cls_score(conv)
         score_2 = self.reshape(cls_score, 2)
         cls_prob = self.reshape(F.softmax(score_2, 1), self.nc_score_out)

@@ -317,9 +317,12 @@ int ait_sh_general_bwd(const float* du, const float* O, const float* gate, const
  *   dw += dy^T (*) x     ACCUMULATED (split-K partial sums combined with fp32 atomics; caller zero-fills)
  *   zeros: caller-owned device buffer of >= max(cin, cout) + 144 floats that holds zeros (what a window
  *          position outside the map reads).
- * Requirements (else AIT_EUNSUPPORTED): the map the GEMM rows run over (out_h x out_w for forward / weight
- * gradient, in_h x in_w for the data gradient) has power-of-two width and area; stride a power of two;
- * cin % 16 == 0 (forward), cout % 16 == 0 (data gradient), cin % 128 == 0 and rows % 16 == 0 (weight gradient).
+ * Requirements (else AIT_EUNSUPPORTED): stride a power of two; cin % 16 == 0 (forward), cout % 16 == 0 (data
+ * gradient), cin % 128 == 0 (weight gradient).  The map the GEMM rows run over (out_h x out_w for forward / weight
+ * gradient, in_h x in_w for the data gradient) may have any size: power-of-two width and area decompose a row by
+ * shifts, anything else by exactly corrected f32 quotients (dense convolutions, fewer than 2^24 rows; a weight
+ * gradient over rows that are not a multiple of 16 runs its reduction to the next multiple, the gathered operand
+ * reading zeros there).  Grouped convolutions and the per-parity stride-2 data gradient need the power-of-two form.
  * ------------------------------------------------------------------------------------- */
 typedef struct {
   int n, in_h, in_w, out_h, out_w, kh, kw, stride, pad;

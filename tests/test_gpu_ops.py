@@ -529,7 +529,9 @@ def test_proposal_tail_node_matches_the_module_composition(monkeypatch, bp, bs):
         assert a.shape == b.shape, lab
         # forward to rounding; gradients cross up to nine ReLU masks whose bits flip on pre-activations within
         # rounding of zero between two implementations
-        tol = 2e-5 if lab.startswith("pooled") else 2e-3
+        # (which solver MIOpen picks for the composition differs between boxes and runs, and with it the set of
+        # flipped bits: one flip on the 4-image query side is ~1e-3 of that gradient's norm)
+        tol = 2e-5 if lab.startswith("pooled") else 5e-3
         assert rel(a, b) < tol, (lab, rel(a, b))
 
 
@@ -573,13 +575,14 @@ def test_implicit_gemm_convolutions_on_maps_of_any_size(n, h, w, cin, cout, k, p
     ya = _Conv3x3BiasRelu.apply(xa, conv.weight, conv.bias)
     g = torch.randn_like(ya)
     ya.backward(g)
-    got = (ya.detach(), xa.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
-    conv.zero_grad()
-    xb = x.clone().requires_grad_(True)
-    yb = torch.relu(conv(xb))
-    yb.backward(g)
-    # (against MIOpen's f32 kernels -- Winograd / split-K with atomics among them -- which carry their own rounding: the
-    # float64 comparisons above are the accuracy statement, this one checks the node's wiring)
-    for a, b_ in zip(got, (yb.detach(), xb.grad, conv.weight.grad, conv.bias.grad)):
-        assert tuple(a.shape) == tuple(b_.shape)
-        assert float((a - b_).abs().max()) <= 2e-3 * float(b_.abs().max()) + 1e-6
+    assert float((ya.double() - ref.view(n, h, w, cout).permute(0, 3, 1, 2)).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
+    # the node's gradients against float64 with the node's OWN ReLU mask (a second f32 implementation flips the mask
+    # bit of every pre-activation within rounding of zero, and each flip moves a gradient by a whole |g w|)
+    dz = (g * (ya > 0)).double()
+    xd2 = x.double().requires_grad_(True)
+    wd2 = wt.double().requires_grad_(True)
+    bd2 = bias.double().requires_grad_(True)
+    (torch.nn.functional.conv2d(xd2, wd2, bd2, 1, 1) * dz).sum().backward()
+    for got, want, tol in ((xa.grad, xd2.grad, 2e-5), (conv.weight.grad, wd2.grad, 5e-5), (conv.bias.grad, bd2.grad, 5e-5)):
+        assert tuple(got.shape) == tuple(want.shape)
+        assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max()) + 1e-6

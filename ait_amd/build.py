@@ -20,7 +20,14 @@ LIB = os.path.join(HERE, "libait_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 ARCH = "gfx950"
 
-COMMON = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-I", INCLUDE,
+# -fno-slp-vectorize: hipcc's SLP vectoriser packs adjacent scalar f32 operations into v_pk_fma_f32 / v_pk_add_f32.
+# In the GEMM epilogue (bias add over an accumulator register pair, the bias broadcast from the HIGH half of a register
+# pair through op_sel, right behind a v_mov_b32 into the LOW half of that pair) the packed form returned, on some
+# launches only, wrong low results in lanes 48-63 -- 16-element row segments off by the difference of two bias
+# values, always the same four accumulator registers (scripts/gemm_lab diffmap with LAB_SELF=1: a kernel against a
+# second launch of itself; ROCm 7.2, gfx950).  Without packing every kernel is reproducible launch to launch;
+# MI355X_MICROARCH.md lists packed f32 arithmetic beside MFMAs as an anti-lever anyway.
+COMMON = ["-O3", "-fno-slp-vectorize", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-I", INCLUDE,
           "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # integer/geometry kernels must reproduce the reference's fp32 operation sequence exactly
 EXACT = ["-ffp-contract=off"]

@@ -181,8 +181,6 @@ enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
 //               epilogues together and the matrix pipes idle through both
 enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8, KNOB_SPLIT = 16 /* products on the bf16 matrix pipe, see split8 */,
        KNOB_BF16 = 64 /* with KNOB_SPLIT: operands ROUNDED to bf16 (nearest even), one MFMA per block: bf16 products, f32 accumulate */,
-       KNOB_LAB_DS_IN = 128, KNOB_LAB_VALU_IN = 256 /* lab (scripts/gemm_lab diffmap): let hipcc schedule the raw-tile ds_reads / the split's
-                                                        vector instructions BETWEEN the six MFMAs of a chain -- see the note in the kernel */,
        KNOB_SPLIT_SIMPLE = 32 /* lab: KNOB_SPLIT with every split in front of its tile's MFMAs instead of under the previous tile's */ };
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int MODE_ = MODE_DB, int NS_ = 3, int KNOBS_ = 0>
 struct Cfg {
@@ -1068,8 +1066,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         }
       }
       if constexpr (kPipe) {
-        // Region (a, b) = the six MFMAs of tile pair (a, b), one uninterrupted chain (see the simple schedule below),
-        // with in their shadow: the split of the raw tile the PREVIOUS region fetched, and the ds_reads of the raw
+        // Region (a, b) = the six MFMAs of tile pair (a, b), with in their shadow: the split of the raw tile the PREVIOUS region fetched, and the ds_reads of the raw
         // tile the NEXT region splits.  Splits: region (a, 0): A tile a+1 of this slab -- in the last tile: A tile 0
         // of the next slab; region (a, 1): B tile a of the next slab (a < TN).  The next slab of the stream (possibly
         // the first of the next tile) is complete in LDS since the last barrier.
@@ -1083,7 +1080,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           for (int b = 0; b < C::TN; b++) {
             const int r = a * C::TN + b, pr = r & 1, nx = pr ^ 1;
             __builtin_amdgcn_sched_barrier(0);
-            // ---- fetch for region r + 1 ------------------------------------------------------------------
+            // ---- the raw operand tile region r + 1 splits (hipcc is free to place these reads and the split below
+            // between the region's MFMAs: measured 1-4 % faster than fencing them in front of / behind the chain)
             if (b == 0) {                                   // next region (a, 1) splits B tile a of the next slab
               if (a < C::TN) {
                 rw[nx][0] = fetch_tile<BKC, BN>(b_nxt, wn, li, lk, 0, a);
@@ -1101,11 +1099,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
                 rw[nx][1] = fetch_tile<AK, BM>(a_nxt, wm, li, lk, 1, 1);
               }
             }
-            // ---- the chain (nothing between its MFMAs: see the note in the simple schedule), then the split of what
-            // the previous region fetched: vector work this wave does while the SIMD's other wave has the matrix pipe
-            if constexpr ((C::KNOBS & KNOB_LAB_DS_IN) == 0) __builtin_amdgcn_sched_barrier(0);
+            // ---- the region's MFMAs and the split of what the previous region fetched
             acc[a][b] = mfma_split<kTerms>(ap, bp[b], acc[a][b]);
-            if constexpr ((C::KNOBS & KNOB_LAB_VALU_IN) == 0) __builtin_amdgcn_sched_barrier(0);
             if (b == 0) nap = split8<kTerms>(rw[pr][0], rw[pr][1]);
             else if (b == 1 && a < C::TN) nbp[a] = split8<kTerms>(rw[pr][0], rw[pr][1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -1146,14 +1141,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           }
 #pragma unroll
           for (int b = 0; b < C::TN; b++) {
-            // The six MFMAs of a tile pair stay one uninterrupted chain on their accumulator, with no LDS read between
-            // them.  Measured (scripts/gemm_lab diffmap, ROCm 7.2, MI355X): when hipcc is free to schedule the operand
-            // ds_read_b128s between the dependent v_mfma_f32_32x32x16_bf16 of a chain (KNOB_LAB_DS_IN; also what it did
-            // by itself for the slab's first two tile pairs), a handful of the 4800 tiles of a launch come out with
-            // 16-element row segments one partial product short -- always lanes 48-63 of even accumulator registers;
-            // vector instructions between the same MFMAs are harmless (KNOB_LAB_VALU_IN: 0 differing tiles), and
-            // scripts/mfma_hazard.hip reproduces nothing with MFMAs + ds_reads alone, so the LDS-DMA stream of the
-            // real loop is part of the trigger.  Fenced: 0 differing tiles on every lab shape and repetition.
+            // (lab form: every split in front of its tile pair's MFMAs)
             __builtin_amdgcn_sched_barrier(0);
             acc[a][b] = mfma_split(ap, bp[b], acc[a][b]);
             __builtin_amdgcn_sched_barrier(0);

@@ -10,5 +10,5 @@ if git cat-file -e 81edb57:ait_amd/csrc/gemm_f32_impl.h 2>/dev/null; then
 else
   OLD="-DNO_OLD"
 fi
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -I include $OLD scripts/gemm_lab.hip -o scripts/_gemm_lab -Wno-unused-result 2>&1 | grep -E "error:" -A5 || true
+/opt/rocm/bin/hipcc -O3 -fno-slp-vectorize $LAB_CXXFLAGS --offload-arch=gfx950 -std=c++17 -I include $OLD scripts/gemm_lab.hip -o scripts/_gemm_lab -Wno-unused-result 2>&1 | grep -E "error:" -A5 || true
 ls -la scripts/_gemm_lab

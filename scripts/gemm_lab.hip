@@ -40,9 +40,7 @@ using V_256sq = Cfg<256, 256, 16, 4, 4, 4, MODE_DLDS, 3, 0>;             // 16 w
 using V_split = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT>;     // the product tile, products on the bf16 matrix pipe (3-way split, 6 terms)
 using V_split8 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_SPLIT_SIMPLE>;    // every split in front of its tile's MFMAs
 using V_splitsq = Cfg<256, 256, 16, 2, 4, 2, MODE_DLDS, 3, KNOB_SPLIT>;   // 256x256, EIGHT waves of 128x64, one workgroup per CU (98 KB)
-using V_lab_ds = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_LAB_DS_IN>;      // ds_reads may be scheduled between a chain's MFMAs
-using V_lab_valu = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_LAB_VALU_IN>;  // the split's vector instructions may
-using V_lab_both = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_LAB_DS_IN | KNOB_LAB_VALU_IN>;
+using V_bf16 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BF16>;      // operands rounded to bf16, one MFMA per block
 using V_stag = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD | KNOB_STAGGER>;   // the product tile, odd threadgroup slots start half a tile late
 #ifndef NO_OLD
 using OldD = ait_gemm_old::Cfg<256, 128, 16, 4, 2, 2, 6 + 256>;
@@ -164,7 +162,7 @@ static int run_tile(const GemmArgs& g, bool ak, bool bk, int slots) {
   return run_epi<T, false, true, NoProbe>(g, slots);
 }
 static const char* VNAMES[] = {"old", "new", "probe", "burst", "prio", "ring4", "ring4+burst", "4waves", "4waves+burst",
-                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "lab ds in", "lab valu in", "lab both in"};
+                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "-", "-", "-", "bf16 x1"};
 template <class Probe>
 static int run_new(const GemmArgs& g, bool ak, bool bk, int slots) {
   if (!ak && !bk) return run_epi<NewD4, false, false, Probe>(g, slots);
@@ -226,9 +224,7 @@ static int run(Problem& p, int variant, float* out) {
     case 16: return run_tile<V_split>(g, ak, bk, g_slots);
     case 17: return run_tile<V_split8>(g, ak, bk, g_slots);
     case 18: return run_tile<V_splitsq>(g, ak, bk, g_slots);
-    case 19: return run_tile<V_lab_ds>(g, ak, bk, g_slots);
-    case 20: return run_tile<V_lab_valu>(g, ak, bk, g_slots);
-    case 21: return run_tile<V_lab_both>(g, ak, bk, g_slots);
+    case 22: return run_tile<V_bf16>(g, ak, bk, g_slots);
     default: break;
   }
 #ifndef NO_OLD
@@ -318,7 +314,7 @@ static void mode_sweep(int rounds, int first, int last) {
       const int rc = run(p, vs[i], p.C2);
       CK(hipDeviceSynchronize());
       const double md = rc == 0 ? max_diff(p, 1) : -1.0;
-      if (rc != 0 || md > 2e-5) { ok[i] = 0; fprintf(stderr, "  %s / %s: rc %d, max |diff| / max |ref| = %.3g\n", p.s.name, VNAMES[vs[i]], rc, md); }      // stream-K and split-K change the summation order
+      if (rc != 0 || md > (vs[i] == 22 ? 3e-2 : 2e-5)) { ok[i] = 0; fprintf(stderr, "  %s / %s: rc %d, max |diff| / max |ref| = %.3g\n", p.s.name, VNAMES[vs[i]], rc, md); }      // stream-K and split-K change the summation order
       if (rc == 0) time_launches(p, vs[i], p.C2, 3);
     }
     for (int r = 0; r < rounds; r++)
@@ -622,7 +618,7 @@ static void mode_diffmap(int si, int variant) {
   setup(p, SHAPES[si]);
   const size_t nc = (size_t)p.s.M * p.s.N;
   CK(hipMemset(p.C, 0, nc * 4)); CK(hipMemset(p.C2, 0, nc * 4));
-  run(p, 1, p.C);
+  run(p, getenv("LAB_SELF") ? variant : 1, p.C);      // LAB_SELF: the variant against a second launch of itself
   if (getenv("LAB_NOWS")) g_use_ws = false;
   run(p, variant, p.C2);
   g_use_ws = true;
@@ -638,7 +634,7 @@ static void mode_diffmap(int si, int variant) {
   for (int r = 0; r < p.s.M; r++)
     for (int c = 0; c < p.s.N; c++) {
       const size_t i = (size_t)r * p.s.N + c;
-      if (fabsf(a[i] - b[i]) > 2e-5 * ref) {
+      if (fabsf(a[i] - b[i]) > (getenv("LAB_SELF") ? 0.0 : 2e-5 * ref)) {
         cnt[(size_t)(r / 256) * tn + c / 128]++;
         if (shown++ < 12) printf("  (%d, %d) tile (%d, %d) in-tile (%d, %d): ref %.6g got %.6g\n", r, c, r / 256, c / 128, r % 256, c % 128, a[i], b[i]);
       }
@@ -648,7 +644,7 @@ static void mode_diffmap(int si, int variant) {
     for (int r = 0; r < p.s.M; r++)
       for (int c = 0; c < p.s.N; c++) {
         const size_t i = (size_t)r * p.s.N + c;
-        if (fabsf(a[i] - b[i]) > 2e-5 * ref) {
+        if (fabsf(a[i] - b[i]) > (getenv("LAB_SELF") ? 0.0 : 2e-5 * ref)) {
           const int ir = r % 128, ic = c % 64, rr = ir % 32, cc = ic % 32;
           hist[ir / 32][ic / 32]++;
           const int lk = (rr >> 2) & 1, reg = (rr & 3) + 4 * (rr >> 3);

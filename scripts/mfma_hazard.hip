@@ -1,6 +1,8 @@
 // scripts/mfma_hazard.hip -- does a DEPENDENT v_mfma_f32_32x32x16_bf16 (SrcC = the previous one's vDst) always see
 // its predecessor's complete result?  hipcc (ROCm 7.2) pads MFMA dependencies itself; this harness checks the padding
-// it chooses against the hardware, for the schedules the f32-split GEMM could use (gemm_f32_impl.h, KNOB_SPLIT):
+// it chooses against the hardware, for the schedules the f32-split GEMM could use (gemm_f32_impl.h, KNOB_SPLIT).
+// (Written while hunting non-reproducible row segments in that GEMM: every pattern here is clean -- the cause was a
+// packed v_pk_fma_f32 in the epilogue, DESIGN.md 3.1 -- and the schedules below are all safe to use.)
 //   pattern 0: the chain back to back (nothing between dependent MFMAs)
 //   pattern 1: one independent MFMA (another accumulator) between dependent ones      -- two chains alternating
 //   pattern 2: two independent MFMAs between dependent ones                            -- three chains rotating

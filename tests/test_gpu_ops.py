@@ -586,3 +586,34 @@ def test_implicit_gemm_convolutions_on_maps_of_any_size(n, h, w, cin, cout, k, p
     for got, want, tol in ((xa.grad, xd2.grad, 2e-5), (conv.weight.grad, wd2.grad, 5e-5), (conv.bias.grad, bd2.grad, 5e-5)):
         assert tuple(got.shape) == tuple(want.shape)
         assert float((got.double() - want).abs().max()) <= tol * float(want.abs().max()) + 1e-6
+
+
+def test_convolution_epilogues_are_reproducible_launch_to_launch():
+    """Every non-atomic product of the proposal tail -- forward with bias + residual + ReLU, data gradient with the
+    residual add and the ReLU gate, the per-parity stride-2 data gradient -- twice on the same inputs: bit-identical
+    (what caught the packed-epilogue bug of ait_amd/build.py on the dense products)."""
+    from ait_amd import ops
+    torch.manual_seed(9)
+    n, C, hw = 1200, 512, 4
+    x = torch.randn(n * hw * hw, C, device="cuda")
+    w = (torch.randn(C, 3, 3, C, device="cuda") / (9 * C) ** 0.5).contiguous()
+    bias = torch.randn(C, device="cuda")
+    res = torch.randn(n * hw * hw, C, device="cuda")
+    geom = ops.conv_geom(n, (hw, hw), (hw, hw), (3, 3), 1, 1)
+    y1 = ops.conv_fwd(x, w, geom, bias=bias, residual=res, relu=True)
+    y2 = ops.conv_fwd(x, w, geom, bias=bias, residual=res, relu=True)
+    assert torch.equal(y1, y2)
+    dy = torch.randn_like(y1)
+    d1 = ops.conv_bwd_data(dy, w, geom, residual=res, mask_pos=True)
+    d2 = ops.conv_bwd_data(dy, w, geom, residual=res, mask_pos=True)
+    assert torch.equal(d1, d2)
+    # the SK block's grouped 3x3 at stride 2 on 8x8 maps: parity-class launch with the in-place accumulation
+    G, Cg = 8, 1024
+    geom2 = ops.conv_geom(300, (8, 8), (4, 4), (3, 3), 2, 1, groups=G)
+    wg = (torch.randn(Cg, 3, 3, Cg // G, device="cuda") / (9 * Cg // G) ** 0.5).contiguous()
+    dyg = torch.randn(300 * 16, Cg, device="cuda")
+    base = torch.randn(300 * 64, Cg, device="cuda")
+    a1, a2 = base.clone(), base.clone()
+    ops.conv_bwd_data(dyg, wg, geom2, residual=a1, out=a1)
+    ops.conv_bwd_data(dyg, wg, geom2, residual=a2, out=a2)
+    assert torch.equal(a1, a2)

@@ -151,3 +151,26 @@ def test_graph_capture_parameter_swap_restores_the_shared_trunk():
         assert (a is None) == (b is None)
         if a is not None:
             assert torch.equal(a, b)
+
+
+def test_row_decomposition_by_corrected_f32_quotients_is_exact():
+    """gemm_f32_impl.h div_small (maps of any size in the implicit-GEMM convolutions): q = int(float(n) * (1/d)) is off
+    by at most one for 0 <= n < 2^24, and the remainder test puts it right -- restated in numpy float32 (same
+    rounding as the device: round-to-nearest multiply, truncating conversion) and checked against integer division
+    for the divisors the C4 maps produce and for adversarial ones."""
+    import numpy as np
+    rs = np.random.RandomState(4)
+    divisors = [63, 38 * 63, 125, 75 * 125, 250, 150 * 250, 3, 7, 8191, 65535, 1 << 12, (1 << 16) + 1, 9576, 16777215]
+    for d in divisors:
+        inv = np.float32(1.0) / np.float32(d)
+        n = np.concatenate([rs.randint(0, 1 << 24, 200000), np.arange(0, min(1 << 24, 40 * d), max(1, d // 7)),
+                            np.array([0, 1, d - 1, d, d + 1, (1 << 24) - 1]),
+                            (np.arange(1, 4000) * d - 1) % (1 << 24), (np.arange(1, 4000) * d) % (1 << 24)]).astype(np.int64)
+        q = (n.astype(np.float32) * inv).astype(np.int64)          # truncation: values are non-negative
+        assert np.abs(q - n // d).max() <= 1
+        rem = n - q * d
+        lo = rem < 0
+        q, rem = np.where(lo, q - 1, q), np.where(lo, rem + d, rem)
+        hi = rem >= d
+        q, rem = np.where(hi, q + 1, q), np.where(hi, rem - d, rem)
+        assert np.array_equal(q, n // d) and np.array_equal(rem, n % d), d

@@ -181,6 +181,8 @@ enum { MODE_DB = 0, MODE_RING = 1, MODE_DLDS = 2 };
 //               epilogues together and the matrix pipes idle through both
 enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8, KNOB_SPLIT = 16 /* products on the bf16 matrix pipe, see split8 */,
        KNOB_BF16 = 64 /* with KNOB_SPLIT: operands ROUNDED to bf16 (nearest even), one MFMA per block: bf16 products, f32 accumulate */,
+       KNOB_RNE = 128 /* with KNOB_SPLIT: the three planes by round-to-nearest (dropped terms <= 2^-23 |a b|) instead of by
+                         truncation (<= 2^-21): same instruction count, v_cvt_pk_bf16_f32 instead of v_perm_b32 / v_and */,
        KNOB_SPLIT_SIMPLE = 32 /* lab: KNOB_SPLIT with every split in front of its tile's MFMAs instead of under the previous tile's */ };
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int MODE_ = MODE_DB, int NS_ = 3, int KNOBS_ = 0>
 struct Cfg {
@@ -534,8 +536,8 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
 // for 32x32x16 against 64 for 32x32x2).  An f32 value is EXACTLY the sum of three bf16 values (24 significant bits =
 // 8 + 8 + 8: h = x truncated to bf16, m = (x - h) truncated, l = x - h - m), a product of two bf16 values is exact in
 // f32, and the MFMA accumulates in f32.  So  a*b = (ah + am + al)(bh + bm + bl)  is formed from the six terms that
-// are >= 2^-16 |a b|  --  ah bh, ah bm, am bh, ah bl, al bh, am bm  --  and the three dropped ones are <= 2^-23.9 |a b|
-// together: below the rounding of one f32 multiply-add (2^-24 of the running sum per step).  Six 32-cycle
+// are >= 2^-16 |a b|  --  ah bh, ah bm, am bh, ah bl, al bh, am bm  --  and the three dropped ones are <= 2^-21 |a b|
+// together (truncation; 2^-23 with KNOB_RNE): a few roundings of an f32 multiply-add chain (2^-24 of the running sum per step).  Six 32-cycle
 // instructions replace eight 64-cycle ones per 16 k-steps; the split costs 5.5 vector instructions per fetched value,
 // issued in the shadow of the MFMAs.  The operand images in LDS, the LDS-DMA stream and the epilogues are untouched:
 // a lane's eight k-values of a slab (k = 8*lk + 0..7) are exactly the 32x32x16 operand layout.
@@ -543,16 +545,6 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct Planes { bf16x8 h, m, l; };
-
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-  const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-  h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                      // (hi16(x1) << 16) | hi16(x0)
-  const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
-  const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-  m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-  const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-}
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned round2(float x0, float x1) {         // v_cvt_pk_bf16_f32: nearest even, NaN stays NaN
@@ -562,8 +554,32 @@ __device__ __forceinline__ unsigned round2(float x0, float x1) {         // v_cv
   return __builtin_bit_cast(unsigned, t);
 }
 
+// x = h + m + l exactly (the remainders are exact f32 subtractions, l needs at most 8 significant bits).
+//   RNE  : h = bf16(x), m = bf16(x - h) rounded to nearest: |m| <= 2^-8 |x|, |l| <= 2^-16 |x|; the partial products the
+//          six-term form drops (m l' + l m' + l l') are <= 2^-23 |x x'|;
+//   else : h, m by TRUNCATION (the top 16 bits): |m| < 2^-7 |x|, |l| < 2^-15 |x|, dropped terms <= 2^-21 |x x'|.
+// 11 vector instructions per two values either way (tests/test_host_cpu.py restates both in numpy).
+template <bool RNE>
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  if constexpr (RNE) {
+    h = round2(x0, x1);                                                   // (bf16(x1) << 16) | bf16(x0)
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = round2(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = round2(s0, s1);
+  } else {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                      // (hi16(x1) << 16) | hi16(x0)
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+}
+
 // TERMS = 6: the exact 3-way split; TERMS = 1: the operand rounded to bf16 (only plane h is formed)
-template <int TERMS = 6>
+template <int TERMS = 6, bool RNE = false>
 __device__ __forceinline__ Planes split8(const float4& p, const float4& q) {     // k = 8*lk + 0..3 | 4..7
   u32x4 h, m, l;
   if constexpr (TERMS == 1) {
@@ -575,10 +591,10 @@ __device__ __forceinline__ Planes split8(const float4& p, const float4& q) {    
     return r;
   }
   unsigned a, b, c;
-  split2(p.x, p.y, a, b, c); h[0] = a; m[0] = b; l[0] = c;
-  split2(p.z, p.w, a, b, c); h[1] = a; m[1] = b; l[1] = c;
-  split2(q.x, q.y, a, b, c); h[2] = a; m[2] = b; l[2] = c;
-  split2(q.z, q.w, a, b, c); h[3] = a; m[3] = b; l[3] = c;
+  split2<RNE>(p.x, p.y, a, b, c); h[0] = a; m[0] = b; l[0] = c;
+  split2<RNE>(p.z, p.w, a, b, c); h[1] = a; m[1] = b; l[1] = c;
+  split2<RNE>(q.x, q.y, a, b, c); h[2] = a; m[2] = b; l[2] = c;
+  split2<RNE>(q.z, q.w, a, b, c); h[3] = a; m[3] = b; l[3] = c;
   Planes r;
   r.h = __builtin_bit_cast(bf16x8, h);
   r.m = __builtin_bit_cast(bf16x8, m);
@@ -996,6 +1012,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // tiles in flight from LDS (rw): every region of six MFMAs splits what the region before it fetched.
   constexpr bool kPipe = kSplit && (C::KNOBS & KNOB_SPLIT_SIMPLE) == 0;
   constexpr int kTerms = (C::KNOBS & KNOB_BF16) != 0 ? 1 : 6;
+  constexpr bool kRne = (C::KNOBS & KNOB_RNE) != 0;
   static_assert(!kPipe || (C::TM >= 2 && C::TN >= 2 && C::TN <= C::TM && (C::TM * C::TN) % 2 == 0), "split schedule");
   float4 sa0, sa1, sb0[C::TN], sb1[C::TN];
   Planes bp[C::TN], nbp[C::TN], ap, nap;
@@ -1004,8 +1021,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   auto prime = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int b = 0; b < C::TN; b++)
-      bp[b] = split8<kTerms>(fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 0, b), fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 1, b));
-    ap = split8<kTerms>(fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 0), fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 0));
+      bp[b] = split8<kTerms, kRne>(fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 0, b), fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 1, b));
+    ap = split8<kTerms, kRne>(fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 0), fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 0));
     rw[0][0] = fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 1);
     rw[0][1] = fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 1);
   };
@@ -1101,8 +1118,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
             }
             // ---- the region's MFMAs and the split of what the previous region fetched
             acc[a][b] = mfma_split<kTerms>(ap, bp[b], acc[a][b]);
-            if (b == 0) nap = split8<kTerms>(rw[pr][0], rw[pr][1]);
-            else if (b == 1 && a < C::TN) nbp[a] = split8<kTerms>(rw[pr][0], rw[pr][1]);
+            if (b == 0) nap = split8<kTerms, kRne>(rw[pr][0], rw[pr][1]);
+            else if (b == 1 && a < C::TN) nbp[a] = split8<kTerms, kRne>(rw[pr][0], rw[pr][1]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((C::KNOBS & KNOB_BURST) == 0) {
 #pragma unroll

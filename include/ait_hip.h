@@ -61,7 +61,7 @@ const char* ait_strerror(int code);
  *       that multiplies f32 operands.  Default (0): every f32 operand is split EXACTLY into three bf16 values
  *       (24 significant bits = 8 + 8 + 8) and a product is accumulated in f32 from the six partial products that
  *       are >= 2^-16 of it, on v_mfma_f32_32x32x16_bf16 -- 16x the FLOP per cycle of the f32 instruction, six
- *       instead of one; the three dropped partial products sum to < 2^-23 |a b|, below the rounding of one f32
+ *       instead of one; the three dropped partial products sum to <= 2^-21 |a b| (worst case), a few roundings of an f32
  *       multiply-add, and the measured error against float64 equals the f32 instruction's (tests/test_gpu_gemm.py).
  *       Same operand images, same epilogues, same summation order over k-blocks.  Non-finite inputs: NaN where
  *       the f32 instruction gives an infinity.  The convolution composites (ait_conv_*, ait_tail_*) always use

@@ -40,6 +40,7 @@ using V_256sq = Cfg<256, 256, 16, 4, 4, 4, MODE_DLDS, 3, 0>;             // 16 w
 using V_split = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT>;     // the product tile, products on the bf16 matrix pipe (3-way split, 6 terms)
 using V_split8 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_SPLIT_SIMPLE>;    // every split in front of its tile's MFMAs
 using V_splitsq = Cfg<256, 256, 16, 2, 4, 2, MODE_DLDS, 3, KNOB_SPLIT>;   // 256x256, EIGHT waves of 128x64, one workgroup per CU (98 KB)
+using V_rne = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_RNE>;      // the product tile with the planes rounded to nearest
 using V_bf16 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BF16>;      // operands rounded to bf16, one MFMA per block
 using V_stag = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD | KNOB_STAGGER>;   // the product tile, odd threadgroup slots start half a tile late
 #ifndef NO_OLD
@@ -162,7 +163,7 @@ static int run_tile(const GemmArgs& g, bool ak, bool bk, int slots) {
   return run_epi<T, false, true, NoProbe>(g, slots);
 }
 static const char* VNAMES[] = {"old", "new", "probe", "burst", "prio", "ring4", "ring4+burst", "4waves", "4waves+burst",
-                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "-", "-", "-", "bf16 x1"};
+                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "split rne", "-", "-", "bf16 x1"};
 template <class Probe>
 static int run_new(const GemmArgs& g, bool ak, bool bk, int slots) {
   if (!ak && !bk) return run_epi<NewD4, false, false, Probe>(g, slots);
@@ -224,6 +225,7 @@ static int run(Problem& p, int variant, float* out) {
     case 16: return run_tile<V_split>(g, ak, bk, g_slots);
     case 17: return run_tile<V_split8>(g, ak, bk, g_slots);
     case 18: return run_tile<V_splitsq>(g, ak, bk, g_slots);
+    case 19: return run_tile<V_rne>(g, ak, bk, g_slots);
     case 22: return run_tile<V_bf16>(g, ak, bk, g_slots);
     default: break;
   }

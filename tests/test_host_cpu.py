@@ -174,3 +174,45 @@ def test_row_decomposition_by_corrected_f32_quotients_is_exact():
         hi = rem >= d
         q, rem = np.where(hi, q + 1, q), np.where(hi, rem - d, rem)
         assert np.array_equal(q, n // d) and np.array_equal(rem, n % d), d
+
+
+def test_three_way_bf16_split_is_exact_and_six_terms_reach_f32_accuracy():
+    """gemm_f32_impl.h split2 / mfma_split restated in numpy, both forms: planes by truncation (the product's) and by
+    round-to-nearest (KNOB_RNE).  (1) x == h + m + l exactly and every plane is a bf16 value, for random, tiny, huge
+    and all-bits-set inputs; (2) the six partial products kept (hh, hm, mh, hl, lh, mm) reproduce a * b to
+    <= 2^-21 |a b| (truncation) / <= 2^-23 |a b| (nearest)."""
+    import numpy as np
+    rs = np.random.RandomState(7)
+
+    def rne_bf16(x):
+        u = x.view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32)
+
+    def trunc_bf16(x):
+        return (x.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+
+    def split(x, to_bf16):
+        h = to_bf16(x)
+        r = (x - h).astype(np.float32)
+        m = to_bf16(r)
+        l = (r - m).astype(np.float32)
+        return h, m, l
+
+    x = np.concatenate([rs.randn(200000).astype(np.float32) * np.exp(rs.uniform(-30, 30, 200000)).astype(np.float32),
+                        np.array([0.0, 1.0, -1.0, 16777215.0, 1.0 / 3.0, 3e38, -3e38, 1e-30, 2.0 ** -100, 1.9999999],
+                                 dtype=np.float32)])
+    y = rs.permutation(x)
+    f = np.float64
+    worst = {}
+    for name, to_bf16 in (("nearest", rne_bf16), ("truncate", trunc_bf16)):
+        h, m, l = split(x, to_bf16)
+        assert np.array_equal(to_bf16(l), l)                                    # l needs no more than bf16's 8 bits
+        assert np.array_equal(h.astype(f) + m.astype(f) + l.astype(f), x.astype(f))
+        hy, my, ly = split(y, to_bf16)
+        six = h.astype(f) * hy + h.astype(f) * my + m.astype(f) * hy + h.astype(f) * ly + l.astype(f) * hy + m.astype(f) * my
+        exact = x.astype(f) * y.astype(f)
+        ok = np.isfinite(exact) & (np.abs(exact) > 1e-300) & (np.abs(exact) < 1e300)
+        worst[name] = float((np.abs(six - exact)[ok] / np.abs(exact)[ok]).max())
+    assert worst["nearest"] <= 2.0 ** -23
+    assert 2.0 ** -23 < worst["truncate"] <= 2.0 ** -21

@@ -51,6 +51,9 @@ SIGNATURES = {
     "ait_sk_sqsum_bwd": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _vp]),
     "ait_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
                           _i, ctypes.c_longlong, _vp, _vp]),
+    "ait_p3_bytes": (_sz, [_ll, _ll]),
+    "ait_p3_split": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "ait_gemm_f32_p3": (_i, [_i, _i, _i, _f, _vp, _i, _vp, _ll, _vp, _i, _vp, _vp, _i, _i, _ll, _vp, _vp]),
     "ait_gemm_f32_batched": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _ll, _ll, _vp, _i, _ll, _ll, _vp, _i, _ll, _ll, _i, _i,
                                   _i, _i, _vp, _vp]),
     "ait_softmax_rows_fwd": (_i, [_vp, _ll, _i, _ll, _f, _ull, _vp, _vp, _vp]),

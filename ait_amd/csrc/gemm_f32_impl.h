@@ -183,7 +183,10 @@ enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8, KNOB_SP
        KNOB_BF16 = 64 /* with KNOB_SPLIT: operands ROUNDED to bf16 (nearest even), one MFMA per block: bf16 products, f32 accumulate */,
        KNOB_RNE = 128 /* with KNOB_SPLIT: the three planes by round-to-nearest (dropped terms <= 2^-23 |a b|) instead of by
                          truncation (<= 2^-21): same instruction count, v_cvt_pk_bf16_f32 instead of v_perm_b32 / v_and */,
-       KNOB_SPLIT_SIMPLE = 32 /* lab: KNOB_SPLIT with every split in front of its tile's MFMAs instead of under the previous tile's */ };
+       KNOB_SPLIT_SIMPLE = 32 /* lab: KNOB_SPLIT with every split in front of its tile's MFMAs instead of under the previous tile's */,
+       KNOB_NOTICKET = 512 /* no ticket ring in LDS: static work lists only (a ring of four 40-KB slabs is all of the CU's 160 KB) */,
+       KNOB_BP3 = 256 /* with KNOB_SPLIT: operand B arrives PRE-SPLIT ("P3": the three bf16 planes of every value, interleaved in
+                         groups of eight along the reduction dimension, see p3_split_kernel); only A is split in registers */ };
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int MODE_ = MODE_DB, int NS_ = 3, int KNOBS_ = 0>
 struct Cfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_, MODE = MODE_;
@@ -194,7 +197,8 @@ struct Cfg {
   static constexpr int VA = BM * BK / 4 / NT;      // float4 per thread per A slab
   static constexpr int VB = BN * BK / 4 / NT;
   static constexpr int NBUF = (MODE_ == MODE_DB) ? 2 : 3;
-  static constexpr size_t LDS = (MODE_ == MODE_DLDS) ? sizeof(float) * NS_ * BK * (BM + BN) + 64 /* ticket ring */
+  static constexpr int BKB = (KNOBS_ & 256 /* KNOB_BP3 */) ? 24 : BK_;   // floats per row of a B slab (P3: 16 values x 6 B)
+  static constexpr size_t LDS = (MODE_ == MODE_DLDS) ? sizeof(float) * NS_ * (BK * BM + BKB * BN) + ((KNOBS_ & 512) ? 0 : 64) /* ticket ring */
                                                      : sizeof(float) * NBUF * BK * (PA + PB);
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile / wave mismatch");
   static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "slab / thread mismatch");
@@ -203,7 +207,7 @@ struct Cfg {
 // diagnostic probe: NoProbe compiles to nothing
 struct NoProbe { static constexpr bool on = false; };
 struct StampProbe { static constexpr bool on = true; };
-#define AIT_PROBE_WORDS 16   // u64 words per workgroup in GemmArgs::probe
+#define AIT_PROBE_WORDS 40   // u64 words per workgroup in GemmArgs::probe
 
 // Stage one BK x ROWS slab of an operand into registers.
 //   KCONTIG = true : element (r, k) at p[r*ld + k]   (reduction dim contiguous)
@@ -675,9 +679,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
                 "direct-to-LDS path needs 16-float slabs");
   static_assert(CONV != CONV_A || AK, "the gathered operand of CONV_A is K-contiguous");
   static_assert(CONV != CONV_B || (!AK && !BKC), "CONV_B is the weight-gradient layout");
-  static_assert((C::BM + C::BN) * 16 / 256 <= 8 * (C::NT / 64), "at most 8 transfers per wave per slab");
+  static_assert((C::BM * 16 + C::BN * C::BKB) / 256 <= 8 * (C::NT / 64), "at most 8 transfers per wave per slab");
   constexpr int BM = C::BM, BN = C::BN, BK = 16;
-  constexpr int SA = BM * 16, SB = BN * 16;          // floats per slab image
+  constexpr bool kBp3 = (C::KNOBS & KNOB_BP3) != 0;   // B pre-split: rows of 16 values x 3 planes = six 16-B chunks
+  static_assert(!kBp3 || (AK && BKC && CONV == CONV_NONE && (C::KNOBS & KNOB_SPLIT) != 0 && (C::BN * 24) % 256 == 0),
+                "pre-split B: both operands K-contiguous, dense");
+  constexpr int SA = BM * 16, SB = BN * C::BKB;      // floats per slab image
   constexpr int NW = C::NT / 64;
   constexpr int GA = SA / 256, GB = SB / 256;        // 1-KB granules per slab
   constexpr int LA = (GA + NW - 1) / NW, LB = (GB + NW - 1) / NW;   // transfers per wave per slab
@@ -817,7 +824,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   const float* pa[LA];
   const float* pb[LB];
   const size_t step_a = AK ? 16 : (size_t)16 * g.lda;
-  const size_t step_b = BKC ? 16 : (size_t)16 * g.ldb;
+  const size_t step_b = kBp3 ? 24 : BKC ? 16 : (size_t)16 * g.ldb;
   size_t step_b_cur = step_b;       // ROWMAP: the extra tap's weights have their own row pitch
   int l_item = 0, l_k = 0, l_kend = 0;
   int l_n0 = 0, l_m0 = 0;           // origin of the load cursor's tile (CONV kernels)
@@ -902,7 +909,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
 #pragma unroll
     for (int i = 0; i < LB; i++) {
       const int q = wave + i * NW;
-      if (BKC) {
+      if constexpr (kBp3) {
+        // P3 row image [row][six 16-B chunks]: LDS position p (16-B units) of the slab = row * 6 + slot; slot holds the
+        // row's chunk slot ^ ((row >> 3) & 1)  (chunk = 3 * k-half + plane: conflict-free ds_read_b128 of one plane of
+        // 32 consecutive rows).  g.ldb = floats per P3 row (1.5 per value), 16 values = 24 floats.
+        const int pos = q * 64 + lane;
+        const int row = pos / 6, slot = pos - row * 6;
+        const int chunk = slot ^ ((row >> 3) & 1);
+        pb[i] = g.B + (size_t)min(n0 + row, g.N - 1) * g.ldb + (l_k >> 3) * 12 + chunk * 4;
+      } else if (BKC) {
         const int row = q * 16 + (lane >> 2);
         const int chunk = (lane & 3) ^ ((row >> 2) & 3);
         pb[i] = g.B + (size_t)min(n0 + row, g.N - 1) * g.ldb + l_k + chunk * 4;
@@ -1010,7 +1025,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // slab ahead.  Pipelined schedule: the bf16 planes of this slab's B tiles (bp) and of the A tile in work (ap), the
   // planes being formed under the MFMAs (nap: the next A tile; nbp: the NEXT slab's B tiles) and two raw operand
   // tiles in flight from LDS (rw): every region of six MFMAs splits what the region before it fetched.
-  constexpr bool kPipe = kSplit && (C::KNOBS & KNOB_SPLIT_SIMPLE) == 0;
+  constexpr bool kPipe = kSplit && (C::KNOBS & KNOB_SPLIT_SIMPLE) == 0 && !kBp3;
   constexpr int kTerms = (C::KNOBS & KNOB_BF16) != 0 ? 1 : 6;
   constexpr bool kRne = (C::KNOBS & KNOB_RNE) != 0;
   static_assert(!kPipe || (C::TM >= 2 && C::TN >= 2 && C::TN <= C::TM && (C::TM * C::TN) % 2 == 0), "split schedule");
@@ -1026,7 +1041,21 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     rw[0][0] = fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 1);
     rw[0][1] = fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 1);
   };
-  if constexpr (kPipe) {
+  // kBp3 state: the planes of the A tile in work (ap) and of the one being formed (nap, from the raw quads rw[0]),
+  // the planes of two B tiles (bq: the one in work, the one in flight from LDS)
+  bf16x8 bq[2][3];
+  auto fetch_bplanes = [&](const float* slab, int b, bf16x8 (&d)[3]) __attribute__((always_inline)) {
+    const int row = wn + b * 32 + li, sw = (row >> 3) & 1;
+#pragma unroll
+    for (int p = 0; p < 3; p++) d[p] = *reinterpret_cast<const bf16x8*>(slab + row * 24 + (((lk * 3 + p) ^ sw) << 2));
+  };
+  auto prime3 = [&](int slot) __attribute__((always_inline)) {
+    ap = split8<6, kRne>(fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 0), fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 0));
+    fetch_bplanes(Bd + slot * SB, 0, bq[0]);
+  };
+  if constexpr (kBp3) {
+    prime3(0);
+  } else if constexpr (kPipe) {
     prime(0);
   } else if constexpr (kSplit) {
     sa0 = fetch_tile<AK, BM>(As, wm, li, lk, 0, 0);
@@ -1082,7 +1111,66 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           for (int i = 0; i < NP; i++) issue(i, lbase);
         }
       }
-      if constexpr (kPipe) {
+      if constexpr (kBp3) {
+        // Region (a, b) = the six MFMAs of tile pair (a, b).  In their shadow: the three plane reads of the NEXT region's B
+        // tile (tile 0 of the next slab behind the last region: complete in LDS since the last barrier); in region (a, 0)
+        // the raw quads of the next A tile (tile a + 1, or tile 0 of the next slab), split in regions (a, 1) and (a, 2):
+        // 88 vector instructions per 48 MFMAs against 264 when every wave splits both operands.
+        constexpr int kPairs = C::TM * C::TN;
+        static_assert(C::TN >= 3, "the A split is spread over regions (a, 1) and (a, 2)");
+        const float* a_cur = As + cur * SA;
+        const float* a_nxt = As + nxt * SA;
+        const float* b_cur = Bd + cur * SB;
+        const float* b_nxt = Bd + nxt * SB;
+        u32x4 nh, nm, nl;
+#pragma unroll
+        for (int a = 0; a < C::TM; a++) {
+#pragma unroll
+          for (int b = 0; b < C::TN; b++) {
+            const int r = a * C::TN + b, pr = r & 1, nx = pr ^ 1;
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_bplanes(r + 1 == kPairs ? b_nxt : b_cur, (b + 1) % C::TN, bq[nx]);
+            if (b == 0) {
+              const float* src = a + 1 < C::TM ? a_cur : a_nxt;
+              rw[0][0] = fetch_tile<AK, BM>(src, wm, li, lk, 0, a + 1 < C::TM ? a + 1 : 0);
+              rw[0][1] = fetch_tile<AK, BM>(src, wm, li, lk, 1, a + 1 < C::TM ? a + 1 : 0);
+            }
+            {
+              f32x16 c = acc[a][b];
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap.l, bq[pr][0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap.h, bq[pr][2], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap.m, bq[pr][1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap.m, bq[pr][0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap.h, bq[pr][1], c, 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap.h, bq[pr][0], c, 0, 0, 0);
+            }
+            if (b == 1) {
+              unsigned x, y, z;
+              split2<kRne>(rw[0][0].x, rw[0][0].y, x, y, z); nh[0] = x; nm[0] = y; nl[0] = z;
+              split2<kRne>(rw[0][0].z, rw[0][0].w, x, y, z); nh[1] = x; nm[1] = y; nl[1] = z;
+            } else if (b == 2) {
+              unsigned x, y, z;
+              split2<kRne>(rw[0][1].x, rw[0][1].y, x, y, z); nh[2] = x; nm[2] = y; nl[2] = z;
+              split2<kRne>(rw[0][1].z, rw[0][1].w, x, y, z); nh[3] = x; nm[3] = y; nl[3] = z;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // one transfer of slab s + NS - 1 behind each of the first NP regions: with one workgroup per CU nothing else
+            // covers the wait for a transfer issued late in the iteration
+            if constexpr ((C::KNOBS & KNOB_BURST) == 0) {
+              static_assert(NP <= kPairs, "one transfer per region");
+              if (r < NP) {
+                if (feed) issue(r, lbase);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+          ap.h = __builtin_bit_cast(bf16x8, nh);
+          ap.m = __builtin_bit_cast(bf16x8, nm);
+          ap.l = __builtin_bit_cast(bf16x8, nl);
+        }
+        // (kPairs is even: the planes fetched in the last region sit in bq[0], where the next slab starts)
+        static_assert(kPairs % 2 == 0, "B plane double buffer parity");
+      } else if constexpr (kPipe) {
         // Region (a, b) = the six MFMAs of tile pair (a, b), with in their shadow: the split of the raw tile the PREVIOUS region fetched, and the ds_reads of the raw
         // tile the NEXT region splits.  Splits: region (a, 0): A tile a+1 of this slab -- in the last tile: A tile 0
         // of the next slab; region (a, 1): B tile a of the next slab (a < TN).  The next slab of the stream (possibly
@@ -1319,7 +1407,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     // (the operand quads are dead across the epilogue -- its address arithmetic needs the registers --
     // and are fetched again from the next tile's first slab, complete in LDS since the last barrier)
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (kPipe) {
+    if constexpr (kBp3) {
+      prime3(cur);
+    } else if constexpr (kPipe) {
       prime(cur);
     } else if constexpr (!kSplit) {
       fetch_group<AK, C::TM, BM>(As + cur * SA, wm, li, lk, 0, xa);
@@ -1338,6 +1428,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
              (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);      // XCC_ID | HW_ID
       p[8] = c_start;
       p[9] = __builtin_amdgcn_s_memtime();
+    }
+    if (lane == 0 && g.probe && wave < 8) {      // every wave's own split of its slab loop: loop, vmcnt wait, barrier
+      unsigned long long* p = g.probe + (size_t)blockIdx.x * AIT_PROBE_WORDS + 10 + wave * 3;
+      p[0] = c_loop; p[1] = c_wait; p[2] = c_bar;
     }
   }
 }
@@ -1618,7 +1712,7 @@ int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int 
       if constexpr (ROWMAP) {
         for (int c = 0; c < 4; c++) kmin = g.conv.cls[c].k_end < kmin ? g.conv.cls[c].k_end : kmin;
       }
-      if (kmin >= 128) gl.sched = ws.sched();
+      if (kmin >= 128 && (C::KNOBS & KNOB_NOTICKET) == 0) gl.sched = ws.sched();
       if (EPI != EPI_ATOMIC && !ROWMAP && g.splits == 1 && g.K % 16 == 0 && rem > 0 && sk_pays) {
         if (ws.bytes < kCtlBytes + (size_t)wfull * AIT_NXCD * C::BM * C::BN * sizeof(float)) return AIT_EWORKSPACE;
         gl.sk_on = 1;

@@ -9,6 +9,13 @@ int ait_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, float alpha, 
                     int ldb, float* C, int ldc, const float* bias, const float* residual, const float* gate, int flags,
                     int split_k, int c_colblk, long long c_batch_stride, const ait_launch_ctx* ctx, void* stream);
 
+// Products whose weight operand is pre-split (csrc/gemm_p3.hip).  ait_gemm_p3b_takes: the shapes that path serves
+// (others stay on ait_gemm_f32_ex with the raw weight).
+bool ait_gemm_p3b_takes(int M, int N, int K, const ait_launch_ctx* ctx);
+int ait_gemm_f32_p3b(int M, int N, int K, float alpha, const float* A, int lda, const void* B_p3, long long ldb_values,
+                     float* C, int ldc, const float* bias, const float* residual, const float* gate, int flags,
+                     int c_colblk, long long c_batch_stride, const ait_launch_ctx* ctx, void* stream);
+
 // dx = conv^T(dy) (+ conv1^T(dy1): a 1x1 stride-2 convolution of the same input) (+ residual / gate) for a STRIDE-2
 // convolution, by parity class of the input positions, one launch (csrc/gemm_f32.hip).  AIT_EUNSUPPORTED: not applicable.
 int ait_conv_bwd_data_s2(const float* dy, int lddy, const float* w, const ait_conv_geom* q, const float* dy1, int lddy1,

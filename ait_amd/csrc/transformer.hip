@@ -21,6 +21,8 @@
 // gradients into the LayerNorm-backward / column-sum kernels.  The two sub-layer blocks are exported
 // the same way (ait_mha_block_*, ait_ffn_*).
 #include "common.h"
+#include "gemm_internal.h"
+#include "p3_jobs.h"
 
 namespace {
 
@@ -54,16 +56,33 @@ struct Run {
   const ait_launch_ctx* ctx;
 };
 
-// y = x W^T (+ b) (+ relu) on the fp32 matrix cores
+// A weight in its pre-split form (csrc/p3_impl.h): P3 rows starting at p, `ld` values per row (p == NULL: none -- the
+// product splits the raw weight in registers).  sub(rows, vals): the view that starts `rows` rows / `vals` reduction
+// values further.
+struct P3Ref {
+  const unsigned short* p = nullptr;
+  long long ld = 0;
+  P3Ref sub(long long rows, long long vals) const { return p ? P3Ref{p + (rows * ld + vals) * 3, ld} : P3Ref{}; }
+};
+// the two conversions of one weight W [N_out][K_in]: P3 of W (forward), P3 of W^T (input gradient; training only)
+struct P3W { P3Ref w, wt; };
+
+// y = x W^T (+ b) (+ relu) on the matrix cores
 inline int linear(const float* x, int M, int K, const float* w, int N, const float* b, bool relu, float* y,
-                  const Run& s) {
+                  const Run& s, const P3Ref& p3 = P3Ref()) {
+  if (p3.p && ait_gemm_p3b_takes(M, N, K, s.ctx))
+    return ait_gemm_f32_p3b(M, N, K, 1.f, x, K, p3.p, p3.ld, y, N, b, nullptr, nullptr, relu ? AIT_GEMM_RELU : 0, 0, 0, s.ctx,
+                            s.stream);
   return ait_gemm_f32(0, 1, M, N, K, 1.f, x, K, w, K, y, N, b, nullptr, relu ? AIT_GEMM_RELU : 0, 1, 0, 0, s.ctx, s.stream);
 }
 // dx [M, K_in] = dy [M, N_out] . W [N_out, K_in]  (+ residual, or gated by `residual` > 0 with mask_pos)
 // `colsum` (optional): float[K_in] into which the column sums of dx are ADDED in the product's epilogue (the bias
 // gradient of the layer dx flows into)
 inline int dgrad(const float* dy, int M, int N_out, const float* w, int K_in, const float* residual, bool mask_pos,
-                 float* dx, const Run& s, float* colsum = nullptr) {
+                 float* dx, const Run& s, float* colsum = nullptr, const P3Ref& p3t = P3Ref()) {
+  if (p3t.p && ait_gemm_p3b_takes(M, K_in, N_out, s.ctx))      // B = P3 of W^T: rows K_in, reduction over N_out
+    return ait_gemm_f32_p3b(M, K_in, N_out, 1.f, dy, N_out, p3t.p, p3t.ld, dx, K_in, colsum, residual, nullptr,
+                            (mask_pos ? AIT_GEMM_MASK_POS : 0) | (colsum ? AIT_GEMM_COLSUM : 0), 0, 0, s.ctx, s.stream);
   return ait_gemm_f32(0, 0, M, K_in, N_out, 1.f, dy, N_out, w, K_in, dx, K_in, colsum, residual,
                       (mask_pos ? AIT_GEMM_MASK_POS : 0) | (colsum ? AIT_GEMM_COLSUM : 0), 1, 0, 0, s.ctx, s.stream);
 }
@@ -132,14 +151,14 @@ inline Qkv views(const MhaBuf& m, long long n, bool cross) {
 // both 0 in eval.  seed: the block's seed; its two sites derive theirs with ait_dropout_seed.
 int mha_block(const float* xq, const float* xkv, int n, int kv_rows, int mask_mode, int n_valid,
               const ait_mha_weights& w, const MhaBuf& m, float p_fc, float p_attn, unsigned long long seed,
-              float* y, const Run& s) {
+              float* y, const Run& s, const P3W& pq = P3W()) {
   const int M = n * T;
   const bool cross = xkv != xq;
   if (!cross) {
-    AIT_TRY(linear(xq, M, D, w.w_qkv, 3 * D, nullptr, false, m.qkv, s));
+    AIT_TRY(linear(xq, M, D, w.w_qkv, 3 * D, nullptr, false, m.qkv, s, pq.w));
   } else {
-    AIT_TRY(linear(xq, M, D, w.w_qkv, D, nullptr, false, m.qkv, s));
-    AIT_TRY(linear(xkv, n * kv_rows, D, w.w_qkv + (size_t)D * D, 2 * D, nullptr, false, m.qkv + (size_t)M * D, s));
+    AIT_TRY(linear(xq, M, D, w.w_qkv, D, nullptr, false, m.qkv, s, pq.w));
+    AIT_TRY(linear(xkv, n * kv_rows, D, w.w_qkv + (size_t)D * D, 2 * D, nullptr, false, m.qkv + (size_t)M * D, s, pq.w.sub(D, 0)));
   }
   const Qkv v = views(m, n, cross);
   AIT_TRY(ait_attn_fwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, n, H, T, DK, kv_rows, mask_mode, n_valid, 0.125f,
@@ -168,7 +187,8 @@ inline bool carve(Bump& b, MhaBwdWs& w, long long n, int kv_rows, bool cross) {
 // dxq [n*64, 512] and (cross) dxkv [n*kv_rows, 512] are WRITTEN; parameter gradients are ACCUMULATED.
 int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xkv, int n, int kv_rows,
                   const ait_mha_weights& w, const MhaBuf& m, const MhaBwdWs& t, float p_fc, float p_attn,
-                  unsigned long long seed, float* dxq, float* dxkv, const ait_mha_grads& g, const Run& s) {
+                  unsigned long long seed, float* dxq, float* dxkv, const ait_mha_grads& g, const Run& s,
+                  const P3W& pq = P3W()) {
   const int M = n * T;
   const bool cross = xkv != xq;
   // closing LayerNorm + dropout + residual: df (at fc's output), dres (the residual branch)
@@ -184,14 +204,14 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
   if (!cross) {
     AIT_TRY(ait_attn_bwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
                          ait_dropout_seed(seed, 0), dq, 3 * D, dq + D, 3 * D, dq + 2 * D, 3 * D, s.stream));
-    AIT_TRY(dgrad(dq, M, 3 * D, w.w_qkv, D, t.dres, false, dxq, s));          // dx = dqkv W_qkv + dres
+    AIT_TRY(dgrad(dq, M, 3 * D, w.w_qkv, D, t.dres, false, dxq, s, nullptr, pq.wt));          // dx = dqkv W_qkv + dres
     return wgrad(dq, M, 3 * D, xq, D, g.w_qkv, s);
   }
   float* dkv = t.dqkv + (size_t)M * D;
   AIT_TRY(ait_attn_bwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
                        ait_dropout_seed(seed, 0), dq, D, dkv, 2 * D, dkv + D, 2 * D, s.stream));
-  AIT_TRY(dgrad(dq, M, D, w.w_qkv, D, t.dres, false, dxq, s));
-  if (dxkv) AIT_TRY(dgrad(dkv, n * kv_rows, 2 * D, w.w_qkv + (size_t)D * D, D, nullptr, false, dxkv, s));
+  AIT_TRY(dgrad(dq, M, D, w.w_qkv, D, t.dres, false, dxq, s, nullptr, pq.wt));
+  if (dxkv) AIT_TRY(dgrad(dkv, n * kv_rows, 2 * D, w.w_qkv + (size_t)D * D, D, nullptr, false, dxkv, s, nullptr, pq.wt.sub(0, D)));
   AIT_TRY(wgrad(dq, M, D, xq, D, g.w_qkv, s));
   return wgrad(dkv, (long long)n * kv_rows, 2 * D, xkv, D, g.w_qkv ? g.w_qkv + (size_t)D * D : nullptr, s);
 }
@@ -200,23 +220,24 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
 // saved activations in training (with mean / rstd of the closing LayerNorm)
 struct FfnBuf { float *h, *f, *mean, *rstd; };
 int ffn_block(const float* x, long long rows, const ait_ffn_weights& w, const FfnBuf& m, float p,
-              unsigned long long seed, float* y, const Run& s) {
-  AIT_TRY(linear(x, (int)rows, D, w.w1, DI, w.b1, true, m.h, s));
-  AIT_TRY(linear(m.h, (int)rows, DI, w.w2, D, w.b2, false, m.f, s));
+              unsigned long long seed, float* y, const Run& s, const P3W& p1 = P3W(), const P3W& p2 = P3W()) {
+  AIT_TRY(linear(x, (int)rows, D, w.w1, DI, w.b1, true, m.h, s, p1.w));
+  AIT_TRY(linear(m.h, (int)rows, DI, w.w2, D, w.b2, false, m.f, s, p2.w));
   return ait_ln_fwd(m.f, nullptr, x, w.ln_g, w.ln_b, rows, D, T, T, 1, kEps, p, ait_dropout_seed(seed, 0), y, m.mean,
                     m.rstd, s.stream);
 }
 struct FfnBwdWs { float *df, *dres, *dh; };
 int ffn_block_bwd(const float* dy, const float* x, long long rows, const ait_ffn_weights& w, const FfnBuf& m,
-                  const FfnBwdWs& t, float p, unsigned long long seed, float* dx, const ait_ffn_grads& g, const Run& s) {
+                  const FfnBwdWs& t, float p, unsigned long long seed, float* dx, const ait_ffn_grads& g, const Run& s,
+                  const P3W& p1 = P3W(), const P3W& p2 = P3W()) {
   const int R = (int)rows;
   // df at w_2's output (its column sums are d b2), dres on the residual branch
   AIT_TRY(ait_ln_bwd(dy, m.f, nullptr, x, w.ln_g, m.mean, m.rstd, rows, D, T, T, 1, T, p, ait_dropout_seed(seed, 0),
                      t.df, t.dres, g.ln_g, g.ln_b, g.b2, s.stream));
   AIT_TRY(wgrad(t.df, rows, D, m.h, DI, g.w2, s));                             // d W2 += df^T h
-  AIT_TRY(dgrad(t.df, R, D, w.w2, DI, m.h, true, t.dh, s, g.b1));             // dh = (df W2) [h > 0];  d b1 += column sums
+  AIT_TRY(dgrad(t.df, R, D, w.w2, DI, m.h, true, t.dh, s, g.b1, p2.wt));      // dh = (df W2) [h > 0];  d b1 += column sums
   AIT_TRY(wgrad(t.dh, rows, DI, x, D, g.w1, s));                               // d W1 += dh^T x
-  return dgrad(t.dh, R, DI, w.w1, D, t.dres, false, dx, s);                    // dx = dh W1 + dres
+  return dgrad(t.dh, R, DI, w.w1, D, t.dres, false, dx, s, nullptr, p1.wt);    // dx = dh W1 + dres
 }
 
 }  // namespace
@@ -401,13 +422,49 @@ struct AitBufs {
   float *d2;
   FfnBuf dec_ffn;
   float *d3;
+  // the weights of the large products, pre-split at the start of the call (forward form; in training also the
+  // transposed form for the input gradients, kept in `saved` for the backward)
+  P3W p_enc_emb, p_enc_qkv, p_dec_qkv, p_x_qkv, p_enc_w1, p_enc_w2, p_dec_w1, p_dec_w2, p_dec_trans;
 };
+// values of all pre-split weights (one conversion each)
+constexpr size_t kP3Values = (size_t)D * C2 + 3 * (size_t)3 * D * D + 4 * (size_t)DI * D + (size_t)C2 * D;
+inline size_t p3_floats(bool train) { return (train ? 2 : 1) * (kP3Values * 3 / 2) + 20 * 64; }
+inline bool carve_p3(Bump& b, AitBufs& a, bool train) {
+  bool ok = true;
+  auto one = [&](P3W& w, int n_out, int k_in) {
+    float* f = b.take((size_t)n_out * k_in * 3 / 2);
+    float* t = train ? b.take((size_t)n_out * k_in * 3 / 2) : nullptr;
+    ok = ok && f && (!train || t);
+    w.w = P3Ref{reinterpret_cast<const unsigned short*>(f), k_in};
+    w.wt = P3Ref{reinterpret_cast<const unsigned short*>(t), n_out};
+  };
+  one(a.p_enc_emb, D, C2);
+  one(a.p_enc_qkv, 3 * D, D); one(a.p_dec_qkv, 3 * D, D); one(a.p_x_qkv, 3 * D, D);
+  one(a.p_enc_w1, DI, D); one(a.p_enc_w2, D, DI); one(a.p_dec_w1, DI, D); one(a.p_dec_w2, D, DI);
+  one(a.p_dec_trans, C2, D);
+  return ok;
+}
+// the conversion pass: one launch for all of them
+inline int p3_convert(const ait_transformer_weights* w, const AitBufs& a, void* stream) {
+  ait_p3::Jobs jobs;
+  jobs.n = 0;
+  auto add = [&](const P3W& pw, const float* src, int n_out, int k_in) {
+    jobs.j[jobs.n++] = ait_p3::Job{src, const_cast<unsigned short*>(pw.w.p), n_out, k_in, k_in, 0, 0};
+    if (pw.wt.p) jobs.j[jobs.n++] = ait_p3::Job{src, const_cast<unsigned short*>(pw.wt.p), n_out, k_in, k_in, 1, 0};
+  };
+  add(a.p_enc_emb, w->enc_emb_w, D, C2);
+  add(a.p_enc_qkv, w->enc_slf.w_qkv, 3 * D, D); add(a.p_dec_qkv, w->dec_slf.w_qkv, 3 * D, D); add(a.p_x_qkv, w->dec_enc.w_qkv, 3 * D, D);
+  add(a.p_enc_w1, w->enc_ffn.w1, DI, D); add(a.p_enc_w2, w->enc_ffn.w2, D, DI);
+  add(a.p_dec_w1, w->dec_ffn.w1, DI, D); add(a.p_dec_w2, w->dec_ffn.w2, D, DI);
+  add(a.p_dec_trans, w->dec_trans_w, C2, D);
+  return ait_p3::split(jobs, ait_stream(stream));
+}
 inline size_t ait_saved_floats(long long bp, long long bs, long long ns) {
   const size_t M = (size_t)bp * T;
   return (size_t)bp * ns * D + (size_t)bs * T * D + M * D + 2 * M + mha_buf_floats(bp, T, false, true) + M * D +
          (size_t)bp * ns * D + (size_t)bp * ns * (DI + D + 2) + (size_t)bp * ns * D + M * D + 2 * M +
          mha_buf_floats(bp, T, false, true) + M * D + mha_buf_floats(bp, (int)ns, true, true) + M * D +
-         M * (DI + D + 2) + M * D + 64 * 64;
+         M * (DI + D + 2) + M * D + 64 * 64 + p3_floats(true);
 }
 inline bool carve_train(Bump& b, AitBufs& a, long long bp, long long bs, int ns) {
   const size_t M = (size_t)bp * T, Mc = (size_t)bp * ns;
@@ -425,13 +482,14 @@ inline bool carve_train(Bump& b, AitBufs& a, long long bp, long long bs, int ns)
   a.d2 = b.take(M * D);
   ok = ok && carve_ffn(b, a.dec_ffn, (long long)M);
   a.d3 = b.take(M * D);
+  ok = ok && carve_p3(b, a, true);
   return ok && a.emb_p && a.emb_q && a.x0 && a.mean0 && a.rstd0 && a.y1 && a.xc && a.mem && a.xd && a.meand &&
          a.rstdd && a.d1 && a.d2 && a.d3;
 }
 inline size_t ws_floats(long long bp, long long bs, long long ns) {
   const size_t M = (size_t)bp * T;
   return (size_t)bp * ns * D + (size_t)bs * T * D + M * D + mha_buf_floats(bp, (int)ns, true, false) + M * 2 * D +
-         M * D + (size_t)bp * ns * D + M * DI + M * D + (size_t)bp * ns * D + 3 * M * D + 32 * 64;
+         M * D + (size_t)bp * ns * D + M * DI + M * D + (size_t)bp * ns * D + 3 * M * D + 32 * 64 + p3_floats(false);
 }
 inline bool carve_eval(Bump& b, AitBufs& a, long long bp, long long bs, int ns) {
   const size_t M = (size_t)bp * T, Mc = (size_t)bp * ns;
@@ -451,6 +509,7 @@ inline bool carve_eval(Bump& b, AitBufs& a, long long bp, long long bs, int ns) 
   a.mem = b.take(Mc * D);
   a.xd = a.x0; a.meand = a.rstdd = nullptr;
   a.d1 = b.take(M * D); a.d2 = b.take(M * D); a.d3 = a.d1;
+  if (!carve_p3(b, a, false)) return false;
   return m.qkv && m.O && m.u && m.gate && m.s && m.f && a.emb_p && a.emb_q && a.x0 && a.y1 && a.xc && f.h && a.mem &&
          a.d1 && a.d2;
 }
@@ -463,14 +522,15 @@ int ait_forward(const float* x_props, const float* x_query, int bp, int bs, int 
   void* stream = run.stream;
   hipStream_t hs = ait_stream(stream);
   const int M = bp * T, P = bp / bs;
+  AIT_TRY(p3_convert(w, a, stream));     // this call's weights, pre-split (33 MB read, one launch)
   // embeddings (1x1 convolutions on token rows)
-  AIT_TRY(linear(x_props, bp * n_src, C2, w->enc_emb_w, D, w->enc_emb_b, false, a.emb_p, run));
+  AIT_TRY(linear(x_props, bp * n_src, C2, w->enc_emb_w, D, w->enc_emb_b, false, a.emb_p, run, a.p_enc_emb.w));
   AIT_TRY(linear(x_query, bs * T, C2, w->dec_emb_w, D, w->dec_emb_b, false, a.emb_q, run));
   // ---- encoder (Models.py:83-111): zero-pad n_src -> 64 rows inside the LayerNorm row map --------
   AIT_TRY(ait_ln_fwd(a.emb_p, w->pos_table, nullptr, w->enc_ln_g, w->enc_ln_b, M, D, T, n_src, 1, kEps, p,
                      ait_dropout_seed(seed, kSeedEncPro), a.x0, a.mean0, a.rstd0, stream));
   AIT_TRY(mha_block(a.x0, a.x0, bp, T, /*key padding*/ 1, n_src, w->enc_slf, a.enc_slf, p, p_attn,
-                    ait_dropout_seed(seed, kSeedEncSlf), a.y1, run));
+                    ait_dropout_seed(seed, kSeedEncSlf), a.y1, run, a.p_enc_qkv));
   // only the n_src real rows of each sequence are read again: compact them (dead padded rows are
   // masked as keys everywhere downstream)
   if (n_src < T) {
@@ -479,17 +539,17 @@ int ait_forward(const float* x_props, const float* x_query, int bp, int bs, int 
       return AIT_ELAUNCH;
   }
   AIT_TRY(ffn_block(a.xc, (long long)bp * n_src, w->enc_ffn, a.enc_ffn, p, ait_dropout_seed(seed, kSeedEncFfn), a.mem,
-                    run));
+                    run, a.p_enc_w1, a.p_enc_w2));
   // ---- decoder (Models.py:143-172): the query sequence of a pair repeated over its P proposals ----
   AIT_TRY(ait_ln_fwd(a.emb_q, w->pos_table, nullptr, w->dec_ln_g, w->dec_ln_b, M, D, T, T, P, kEps, p,
                      ait_dropout_seed(seed, kSeedDecPro), a.xd, a.meand, a.rstdd, stream));
   AIT_TRY(mha_block(a.xd, a.xd, bp, T, /*causal*/ 2, 0, w->dec_slf, a.dec_slf, p, p_attn,
-                    ait_dropout_seed(seed, kSeedDecSlf), a.d1, run));
+                    ait_dropout_seed(seed, kSeedDecSlf), a.d1, run, a.p_dec_qkv));
   AIT_TRY(mha_block(a.d1, a.mem, bp, n_src, /*none: the memory is unpadded*/ n_src < T ? 0 : 1, n_src, w->dec_enc,
-                    a.dec_enc, p, p_attn, ait_dropout_seed(seed, kSeedDecEnc), a.d2, run));
-  AIT_TRY(ffn_block(a.d2, M, w->dec_ffn, a.dec_ffn, p, ait_dropout_seed(seed, kSeedDecFfn), a.d3, run));
+                    a.dec_enc, p, p_attn, ait_dropout_seed(seed, kSeedDecEnc), a.d2, run, a.p_x_qkv));
+  AIT_TRY(ffn_block(a.d2, M, w->dec_ffn, a.dec_ffn, p, ait_dropout_seed(seed, kSeedDecFfn), a.d3, run, a.p_dec_w1, a.p_dec_w2));
   // dec_trans back to 2d channels per token
-  return linear(a.d3, M, D, w->dec_trans_w, C2, w->dec_trans_b, false, out, run);
+  return linear(a.d3, M, D, w->dec_trans_w, C2, w->dec_trans_b, false, out, run, a.p_dec_trans.w);
 }
 
 int check_ait(int bp, int bs, int n_src, const void* w) {
@@ -577,24 +637,25 @@ AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const 
   // dec_trans: out = d3 W^T + b
   if (g->dec_trans_b) AIT_TRY(ait_colsum_f32(d_out, M, C2, C2, g->dec_trans_b, stream));
   AIT_TRY(wgrad(d_out, M, C2, a.d3, D, g->dec_trans_w, run));
-  AIT_TRY(dgrad(d_out, M, C2, w->dec_trans_w, D, nullptr, false, ga, run));                  // ga = d d3
+  AIT_TRY(dgrad(d_out, M, C2, w->dec_trans_w, D, nullptr, false, ga, run, nullptr, a.p_dec_trans.wt));      // ga = d d3
   {  // decoder feed-forward: d d3 -> d d2
     Bump bb = blk; FfnBwdWs t;
     if (!carve_ffn_ws(bb, t, M)) return AIT_EWORKSPACE;
-    AIT_TRY(ffn_block_bwd(ga, a.d2, M, w->dec_ffn, a.dec_ffn, t, p, ait_dropout_seed(seed, kSeedDecFfn), gb, g->dec_ffn, run));
+    AIT_TRY(ffn_block_bwd(ga, a.d2, M, w->dec_ffn, a.dec_ffn, t, p, ait_dropout_seed(seed, kSeedDecFfn), gb, g->dec_ffn, run,
+                          a.p_dec_w1, a.p_dec_w2));
   }
   float* d_mem = gc;     // [Mc, 512]
   {  // decoder cross-attention: d d2 -> d d1, d mem
     Bump bb = blk; MhaBwdWs t;
     if (!carve(bb, t, bp, n_src, true)) return AIT_EWORKSPACE;
     AIT_TRY(mha_block_bwd(gb, T, a.d1, a.mem, bp, n_src, w->dec_enc, a.dec_enc, t, p, pa,
-                          ait_dropout_seed(seed, kSeedDecEnc), ga, d_mem, g->dec_enc, run));
+                          ait_dropout_seed(seed, kSeedDecEnc), ga, d_mem, g->dec_enc, run, a.p_x_qkv));
   }
   {  // decoder self-attention: d d1 -> d xd
     Bump bb = blk; MhaBwdWs t;
     if (!carve(bb, t, bp, T, false)) return AIT_EWORKSPACE;
     AIT_TRY(mha_block_bwd(ga, T, a.xd, a.xd, bp, T, w->dec_slf, a.dec_slf, t, p, pa, ait_dropout_seed(seed, kSeedDecSlf),
-                          gb, nullptr, g->dec_slf, run));
+                          gb, nullptr, g->dec_slf, run, a.p_dec_qkv));
   }
   // decoder prologue: LayerNorm(dropout(repeat_P(emb_q) + pos)); the P copies' gradients are summed
   AIT_TRY(ait_ln_bwd(gb, a.emb_q, w->pos_table, nullptr, w->dec_ln_g, a.meand, a.rstdd, M, D, T, T, P, T, p,
@@ -608,18 +669,18 @@ AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const 
     Bump bb = blk; FfnBwdWs t;
     if (!carve_ffn_ws(bb, t, Mc)) return AIT_EWORKSPACE;
     AIT_TRY(ffn_block_bwd(d_mem, a.xc, Mc, w->enc_ffn, a.enc_ffn, t, p, ait_dropout_seed(seed, kSeedEncFfn), ga,
-                          g->enc_ffn, run));
+                          g->enc_ffn, run, a.p_enc_w1, a.p_enc_w2));
   }
   {  // encoder self-attention: its output received a gradient only on the n_src real rows of a sequence
     Bump bb = blk; MhaBwdWs t;
     if (!carve(bb, t, bp, T, false)) return AIT_EWORKSPACE;
     AIT_TRY(mha_block_bwd(ga, n_src, a.x0, a.x0, bp, T, w->enc_slf, a.enc_slf, t, p, pa,
-                          ait_dropout_seed(seed, kSeedEncSlf), gb, nullptr, g->enc_slf, run));
+                          ait_dropout_seed(seed, kSeedEncSlf), gb, nullptr, g->enc_slf, run, a.p_enc_qkv));
   }
   // encoder prologue: LayerNorm(dropout(pad(emb_p) + pos)); the gradient is indexed by source row
   AIT_TRY(ait_ln_bwd(gb, a.emb_p, w->pos_table, nullptr, w->enc_ln_g, a.mean0, a.rstd0, M, D, T, n_src, 1, T, p,
                      ait_dropout_seed(seed, kSeedEncPro), ga, nullptr, g->enc_ln_g, g->enc_ln_b, g->enc_emb_b, stream));
   AIT_TRY(wgrad(ga, Mc, D, x_props, C2, g->enc_emb_w, run));
-  if (d_x_props) AIT_TRY(dgrad(ga, Mc, D, w->enc_emb_w, C2, nullptr, false, d_x_props, run));
+  if (d_x_props) AIT_TRY(dgrad(ga, Mc, D, w->enc_emb_w, C2, nullptr, false, d_x_props, run, nullptr, a.p_enc_emb.wt));
   return AIT_OK;
 }

@@ -243,6 +243,43 @@ def gemm_relu_bwd(dy, w, act, out=None):
     return out
 
 
+def p3_split(w, transpose=False):
+    """The pre-split form of a weight (include/ait_hip.h "P3"): w [rows, cols] f32 -> bf16 [rows, cols/8, 3, 8] (planes h,
+    m, l of every value, x = h + m + l exactly), or with transpose=True the same of w.t(): [cols, rows/8, 3, 8]."""
+    assert w.dim() == 2 and w.dtype == torch.float32
+    if w.stride(1) != 1 or w.stride(0) % 4:
+        w = w.contiguous()
+    rows, cols = w.shape
+    shape = (cols, rows // 8, 3, 8) if transpose else (rows, cols // 8, 3, 8)
+    out = torch.empty(shape, dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.lib().ait_p3_split(_lib.dev_ptr(w), rows, cols, w.stride(0), int(bool(transpose)),
+                                     ctypes.c_void_p(out.data_ptr()), _lib.cur_stream(w.device))
+    _lib.check(rc, "ait_p3_split")
+    return out
+
+
+def gemm_p3(a, w_p3, bias=None, residual=None, relu=False, mask_pos=False, colsum=None, alpha=1.0, out=None):
+    """out = alpha * a @ W^T (+bias)(+residual | masked by residual > 0)(relu), W given pre-split: w_p3 = p3_split(W)
+    ([N, K/8, 3, 8]; for the input gradient dy @ W pass p3_split(W, transpose=True)).  colsum: float[N] into which
+    the column sums of the result are added (ait_gemm_f32_p3)."""
+    M, K = a.shape
+    N = w_p3.shape[0]
+    assert w_p3.dtype == torch.bfloat16 and w_p3.shape[1] * 8 == K and w_p3.is_contiguous()
+    if a.stride(1) != 1 or a.stride(0) % 4:
+        a = a.contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_MASK_POS if mask_pos else 0) | (_lib.GEMM_COLSUM if colsum is not None else 0)
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().ait_gemm_f32_p3(M, N, K, float(alpha), _lib.dev_ptr(a), a.stride(0),
+                                        ctypes.c_void_p(w_p3.data_ptr()), K, ctypes.c_void_p(out.data_ptr()),
+                                        out.stride(0), _p(colsum if colsum is not None else bias), _p(residual), flags, 0, 0,
+                                        _lib.launch_ctx(a.device), _lib.cur_stream(a.device))
+    _lib.check(rc, "ait_gemm_f32_p3")
+    return out
+
+
 D_MODEL = 512
 
 

@@ -276,6 +276,29 @@ int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, con
                  const float* residual, int flags, int split_k, int c_colblk,
                  long long c_batch_stride, const ait_launch_ctx* ctx, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Products with a PRE-SPLIT weight operand ("P3").  No reference counterpart: how this library keeps the weight
+ * side of  y = x W^T  (lib/model/system/SubLayers.py:77-79,97,181-182; Models.py:246-247,278) and of its input
+ * gradient  dx = dy W  off the vector pipe.  P3 of an f32 matrix X [rows][K] (K = the reduction dimension of
+ * the product it enters) = its three bf16 planes h = bf16(x), m = bf16(x - h), l = x - h - m (round to nearest
+ * even; x = h + m + l exactly), interleaved in groups of eight along K:
+ *     P3[row][K / 8][h, m, l][8] bf16   -- 6 bytes per value, ait_p3_bytes(rows, K) in all, 16-byte aligned.
+ * ait_p3_split: src [rows][cols] f32 (row pitch ld floats, ld % 4 == 0, 16-byte aligned) -> P3 of src (transpose
+ *   == 0: reduction dimension = cols, cols % 8 == 0) or of its transpose (transpose != 0: P3 [cols][rows / 8][3][8],
+ *   rows % 8 == 0).  A weight is converted once per optimizer step; the ait_transformer_* composites convert their
+ *   own weights at the start of every call (33 MB, one launch).
+ * ait_gemm_f32_p3:  C [M,N] = alpha * A [M,K] (f32, row pitch lda) . X^T, X [N][K] given as B_p3 = P3 of X with
+ *   row pitch ldb_values VALUES (>= K, % 8 == 0; a K sub-range of wider rows is addressed by offsetting B_p3 by
+ *   6 bytes per value).  bias / residual / flags / c_colblk as ait_gemm_f32 (no AIT_GEMM_ATOMIC / ACCUMULATE /
+ *   BIAS_ROW); K % 16 == 0.  The same six partial products per f32 product as ait_gemm_f32's default form: A is
+ *   split in registers (truncation), B arrives split (nearest); dropped terms <= 2^-22 |a b|.
+ * ------------------------------------------------------------------------------------- */
+size_t ait_p3_bytes(long long rows, long long cols);
+int ait_p3_split(const float* src, int rows, int cols, int ld, int transpose, void* dst, void* stream);
+int ait_gemm_f32_p3(int M, int N, int K, float alpha, const float* A, int lda, const void* B_p3, long long ldb_values,
+                    float* C, int ldc, const float* bias, const float* residual, int flags, int c_colblk,
+                    long long c_batch_stride, const ait_launch_ctx* ctx, void* stream);
+
 /* Batched form: batch x batch2 independent products, operand (i, j) at base + i*stride + j*stride2 (floats),
  * one launch.  Replaces the three torch.matmul of the COCO variant's image-level co-attention
  *   (lib/model/modules/blocks_coatt_transformer_sk.py:86-110), the per-(image, head) score and P.V products of

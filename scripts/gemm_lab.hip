@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../ait_amd/csrc/gemm_f32_impl.h"
+#include "../ait_amd/csrc/p3_impl.h"
 #ifndef NO_OLD
 #include "/tmp/ait_old_gemm_f32_impl.h"
 #endif
@@ -42,6 +43,11 @@ using V_split8 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_SPLI
 using V_splitsq = Cfg<256, 256, 16, 2, 4, 2, MODE_DLDS, 3, KNOB_SPLIT>;   // 256x256, EIGHT waves of 128x64, one workgroup per CU (98 KB)
 using V_rne = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_RNE>;      // the product tile with the planes rounded to nearest
 using V_bf16 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BF16>;      // operands rounded to bf16, one MFMA per block
+using V_bp3 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3>;    // B pre-split (P3), 8 waves of 64x128, one workgroup per CU
+using V_bp3r = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3 | KNOB_BURST>;
+using V_bp3p = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3 | KNOB_PRIO>;
+using V_bp3n4 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_BP3 | KNOB_NOTICKET>;
+using V_bp3n4p = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_BP3 | KNOB_NOTICKET | KNOB_PRIO>;
 using V_stag = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD | KNOB_STAGGER>;   // the product tile, odd threadgroup slots start half a tile late
 #ifndef NO_OLD
 using OldD = ait_gemm_old::Cfg<256, 128, 16, 4, 2, 2, 6 + 256>;
@@ -107,6 +113,7 @@ __global__ void fill_kernel(float* p, size_t n, unsigned seed) {
 struct Problem {
   Shape s;
   float *A, *B, *C, *C2, *bias, *res;
+  unsigned short* Bp3;      // B as P3 [N][K / 8][3][8] (variants 20, 21)
   unsigned long long* probe;
   GemmArgs g;
 };
@@ -123,6 +130,15 @@ static void setup(Problem& p, const Shape& s) {
   fill_kernel<<<2048, 256>>>(p.B, nb, 0x89abcdeu);
   fill_kernel<<<64, 256>>>(p.bias, (size_t)s.N, 0x5555u);
   CK(hipMemset(p.C, 0, nc * 4)); CK(hipMemset(p.C2, 0, nc * 4));
+  p.Bp3 = nullptr;
+  if (!s.ta && s.K % 16 == 0) {
+    CK(hipMalloc(&p.Bp3, nb * 6));
+    ait_p3::Jobs jobs;
+    jobs.n = 1;
+    jobs.j[0] = s.tb ? ait_p3::Job{p.B, p.Bp3, s.N, s.K, s.K, 0, 0} : ait_p3::Job{p.B, p.Bp3, s.K, s.N, s.N, 1, 0};
+    const int rc = ait_p3::launch_split(jobs, 0);
+    if (rc) { printf("p3 split rc %d\n", rc); exit(1); }
+  }
   CK(hipDeviceSynchronize());
   const int lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
   const int flags = (s.flags & ~(LAB_RES | LAB_ALIAS_A | LAB_ALIAS_B)) | (s.sk > 1 ? AIT_GEMM_ATOMIC : 0);
@@ -134,6 +150,7 @@ static void setup(Problem& p, const Shape& s) {
   if (s.flags & LAB_ALIAS_B) p.g.ldb = 0;
 }
 static void teardown(Problem& p) {
+  if (p.Bp3) hipFree(p.Bp3);
   hipFree(p.A); hipFree(p.B); hipFree(p.C); hipFree(p.C2); hipFree(p.bias); hipFree(p.res); hipFree(p.probe);
 }
 
@@ -163,7 +180,7 @@ static int run_tile(const GemmArgs& g, bool ak, bool bk, int slots) {
   return run_epi<T, false, true, NoProbe>(g, slots);
 }
 static const char* VNAMES[] = {"old", "new", "probe", "burst", "prio", "ring4", "ring4+burst", "4waves", "4waves+burst",
-                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "split rne", "-", "-", "bf16 x1"};
+                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "split rne", "bp3 256sq", "bp3 burst", "bf16 x1", "bp3 prio", "bp3 ring4", "bp3 ring4 prio"};
 template <class Probe>
 static int run_new(const GemmArgs& g, bool ak, bool bk, int slots) {
   if (!ak && !bk) return run_epi<NewD4, false, false, Probe>(g, slots);
@@ -195,6 +212,12 @@ static int run(Problem& p, int variant, float* out) {
   }
   if (variant == 2) {
     g.probe = p.probe;
+    if (getenv("LAB_PROBE_BP3") && p.Bp3) {    // the stamp probe on the pre-split-B tile
+      g.B = reinterpret_cast<const float*>(p.Bp3);
+      g.ldb = p.s.K / 2 * 3;
+      if (atoi(getenv("LAB_PROBE_BP3")) == 4) return run_epi<V_bp3n4, true, true, StampProbe>(g, g_slots);
+      return run_epi<V_bp3, true, true, StampProbe>(g, g_slots);
+    }
     if (getenv("LAB_PROBE_SPLIT")) {      // the stamp probe on the split tile
       if (!ak && !bk) return run_epi<V_split, false, false, StampProbe>(g, g_slots);
       if (ak && bk) return run_epi<V_split, true, true, StampProbe>(g, g_slots);
@@ -227,6 +250,16 @@ static int run(Problem& p, int variant, float* out) {
     case 18: return run_tile<V_splitsq>(g, ak, bk, g_slots);
     case 19: return run_tile<V_rne>(g, ak, bk, g_slots);
     case 22: return run_tile<V_bf16>(g, ak, bk, g_slots);
+    case 20: case 21: case 23: case 24: case 25: {
+      if (!p.Bp3 || (p.s.flags & (LAB_ALIAS_A | LAB_ALIAS_B))) return -99;
+      g.B = reinterpret_cast<const float*>(p.Bp3);
+      g.ldb = p.s.K / 2 * 3;
+      if (variant == 21) return run_epi<V_bp3r, true, true, NoProbe>(g, g_slots);
+      if (variant == 23) return run_epi<V_bp3p, true, true, NoProbe>(g, g_slots);
+      if (variant == 24) return run_epi<V_bp3n4, true, true, NoProbe>(g, g_slots);
+      if (variant == 25) return run_epi<V_bp3n4p, true, true, NoProbe>(g, g_slots);
+      return run_epi<V_bp3, true, true, NoProbe>(g, g_slots);
+    }
     default: break;
   }
 #ifndef NO_OLD
@@ -506,6 +539,16 @@ static void mode_probe(int first, int last) {
     printf("  wave 0: %.0f cycles per slab (matrix-pipe floor %d x 64 x %d waves/SIMD = %d); vmcnt wait %.2f %%, barrier %.2f %% of the slab loop; %.1f tiles and %.0f slabs per workgroup\n",
            loop / slabs, mfma_per_slab, waves_per_simd, mfma_per_slab * 64 * waves_per_simd, 100.0 * wait / loop, 100.0 * bar / loop, tiles / ids.size(), slabs / ids.size());
     printf("  slab loop = %.1f %% of workgroup lifetime (cycles); shader clock %.2f GHz\n", 100.0 * loop / clk_c, clk_c / clk_t * 1e-9);
+    {  // per wave: share of its slab loop in the vmcnt wait / at the barrier (mean over workgroups)
+      double wl[8] = {}, ww[8] = {}, wb[8] = {};
+      for (int b : ids) {
+        const unsigned long long* q = &h[(size_t)b * AIT_PROBE_WORDS];
+        for (int w = 0; w < 8; w++) { wl[w] += q[10 + w * 3]; ww[w] += q[11 + w * 3]; wb[w] += q[12 + w * 3]; }
+      }
+      printf("  per wave (compute / vmcnt wait / barrier cycles per slab):");
+      for (int w = 0; w < 8; w++) if (wl[w] > 0) printf("  w%d %.0f/%.0f/%.0f", w, (wl[w] - ww[w] - wb[w]) / slabs, ww[w] / slabs, wb[w] / slabs);
+      printf("\n");
+    }
     {  // the two workgroups of a CU: the one that ends first ("first") and its partner ("second")
       std::map<unsigned long long, std::vector<int>> by_cu;
       for (int b : ids) {

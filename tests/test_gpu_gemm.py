@@ -551,3 +551,65 @@ def test_products_are_reproducible_launch_to_launch(mode):
             ops.set_matmul_dtype("f32")
         assert float((first - nat).abs().max()) <= (2e-6 if mode == "f32" else 2e-2) * scale
         del a, w, nat, first, again
+
+
+@pytest.mark.parametrize("rows,cols", [(512, 1024), (1536, 512), (2048, 520)])
+def test_p3_planes_are_an_exact_re_encoding(rows, cols):
+    """ait_p3_split (include/ait_hip.h "P3"): the three bf16 planes of every value sum to it EXACTLY, in the
+    group-of-eight interleaved layout, for a weight and for its transpose; wide magnitude spread, all 24
+    significant bits set, zeros."""
+    from ait_amd import ops
+    torch.manual_seed(rows + cols)
+    w = torch.randn(rows, cols, device="cuda") * torch.exp(3 * torch.randn(rows, 1, device="cuda"))
+    w[0, :8] = torch.tensor([0.0, 16777215.0, -16777215.0, 1.0, -0.5, 3e38, 1e-30, 1.0 / 3.0], device="cuda")
+    p = ops.p3_split(w)
+    assert p.shape == (rows, cols // 8, 3, 8)
+    back = p.float().sum(dim=2).reshape(rows, cols)        # h + m, then + l: every partial sum is exact in f32
+    assert torch.equal(back, w)
+    pt = ops.p3_split(w, transpose=True)
+    assert pt.shape == (cols, rows // 8, 3, 8)
+    assert torch.equal(pt.float().sum(dim=2).reshape(cols, rows), w.t())
+    # planes are ordered by magnitude: |m| <= 2^-8 |h|, |l| <= 2^-16 |h| (round to nearest)
+    h, m, l = p.float().unbind(dim=2)
+    assert bool((m.abs() <= h.abs() * 2.0 ** -8 + 1e-45).all()) and bool((l.abs() <= h.abs() * 2.0 ** -16 + 1e-45).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(76800, 1536, 512), (58800, 2048, 512), (33000, 512, 2048), (76800, 1024, 512),
+                                   (40100, 768, 1024)])
+def test_gemm_with_pre_split_weight_vs_float64(M, N, K):
+    """ait_gemm_f32_p3 (the 256x256 tile whose weight operand arrives as P3 planes; csrc/gemm_p3.hip): forward and
+    input-gradient forms, every epilogue the transformer uses on it, against float64 with the f32 error fence of the
+    other product tests; bit-identical launch to launch; and as close to float64 as the product that splits both
+    operands in registers."""
+    from ait_amd import ops
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda") * torch.exp(2 * torch.randn(1, K, device="cuda"))
+    w = torch.randn(N, K, device="cuda") * torch.exp(2 * torch.randn(1, K, device="cuda"))
+    bias = torch.randn(N, device="cuda")
+    wp = ops.p3_split(w)
+    ref = a.double() @ w.double().t()
+    mag = a.double().abs() @ w.double().abs().t()
+    bound = 3e-6 * mag + 1e-6        # (K * 2^-24 worst case of the f32 accumulation; these operands span e^+-6)
+    c = ops.gemm_p3(a, wp)
+    assert bool(((c.double() - ref).abs() <= bound).all())
+    assert torch.equal(c, ops.gemm_p3(a, wp))
+    raw = ops.gemm(a, w)
+    e_p3 = float(((c.double() - ref).abs() / mag).max())
+    e_raw = float(((raw.double() - ref).abs() / mag).max())
+    assert e_p3 <= 1.5 * e_raw + 2e-8
+    r = ops.gemm_p3(a, wp, bias=bias, relu=True)
+    assert bool(((r.double() - torch.relu(ref + bias.double())).abs() <= bound).all())
+    res = torch.randn(M, N, device="cuda")
+    r = ops.gemm_p3(a, wp, residual=res)
+    assert bool(((r.double() - ref - res.double()).abs() <= bound).all())
+    del r, raw
+    # input gradient: dy [M, N] @ W [N, K] with W^T pre-split, gated by a saved activation, column sums in the epilogue
+    dy = torch.randn(M, N, device="cuda")
+    wtp = ops.p3_split(w, transpose=True)
+    act = torch.randn(M, K, device="cuda")
+    cs = torch.zeros(K, device="cuda")
+    dx = ops.gemm_p3(dy, wtp, residual=act, mask_pos=True, colsum=cs)
+    want = (dy.double() @ w.double()) * (act > 0)
+    mag2 = dy.double().abs() @ w.double().abs()
+    assert bool(((dx.double() - want).abs() <= 3e-6 * mag2 + 1e-6).all())
+    assert torch.allclose(cs.double(), want.sum(0), rtol=1e-4, atol=1e-3 * float(want.abs().sum(0).max()))

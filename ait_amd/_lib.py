@@ -224,6 +224,12 @@ def launch_ctx(device=None):
         key = (idx, st.cuda_stream)
         ent = _SCHED.get(key)
         if ent is None:
+            if torch.cuda.is_current_stream_capturing():
+                # a first use inside a stream capture would take the workspace from the graph's private pool and CAPTURE
+                # the zeroing of its control words instead of running it: later launches would read garbage tickets
+                raise AitHipError("the GEMM scheduler workspace of this stream is created on first use, which must not happen "
+                                  "inside a stream capture: call ait_amd._lib.prewarm(stream) (or run one product on the "
+                                  "stream) before capturing")
             with torch.cuda.device(dev):
                 L = lib()
                 nbytes = int(L.ait_gemm_workspace_bytes())
@@ -242,6 +248,16 @@ def launch_ctx(device=None):
     elif NATIVE_F32:
         ctx.flags = CTX_NATIVE_F32
     return ctypes.byref(ctx)
+
+
+def prewarm(stream=None, device=None):
+    """create and initialise the scheduler workspace of `stream` (default: the current one) -- to be called before a
+    stream capture whose first product would otherwise do it inside the capture"""
+    if stream is None:
+        launch_ctx(device)
+    else:
+        with torch.cuda.stream(stream):
+            launch_ctx(device if device is not None else stream.device)
 
 
 def release_sched_workspaces():

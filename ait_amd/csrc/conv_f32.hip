@@ -6,7 +6,7 @@
 namespace {
 using namespace ait_gemm;
 // the persistent product tile of gemm_f32.hip (f32 products split onto the bf16 matrix pipe) and its bf16 form
-using Tile256D = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT>;
+using Tile256D = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_RNE>;
 using Tile256B = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BF16>;
 }  // namespace
 
@@ -17,10 +17,10 @@ using Tile256B = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BF16
 // (ConvGeom, gemm_f32_impl.h); positions outside the map read a caller-provided row of zeros.
 // =========================================================================================================
 namespace {
-using Tile128D = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, KNOB_SPLIT>;
+using Tile128D = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_RNE>;
 // 64 x 128, two waves: grouped convolutions over a handful of rows (the query side of the SK block: 64 output rows) --
 // a 256-row tile would multiply three quarters of padding there
-using TileS = Cfg<64, 128, 16, 1, 2, 2, MODE_DLDS, 3, KNOB_SPLIT>;
+using TileS = Cfg<64, 128, 16, 1, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_RNE>;
 // the same three tiles with the operands rounded to bf16 and one MFMA per block (AIT_CTX_BF16)
 struct SplitFam { using T256 = Tile256D; using T128 = Tile128D; using TS = TileS; };
 struct Bf16Fam {

@@ -52,13 +52,13 @@ using namespace ait_gemm;
 //   Tile128    128x128 register-staged double buffer: outputs with few rows.
 //   TileN64    256x64 for the 64-column SHBlock / fc products (no dead half tile).
 //   Tile64     64x64 for few-tile problems (the bs*64-row query side): latency, not throughput.
-using Tile256D = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT>;
+using Tile256D = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_RNE>;
 using Tile256B = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BF16>;   // operands rounded to bf16, one MFMA per block (AIT_CTX_BF16)
 using Tile256N = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD>;      // the same tile on v_mfma_f32_32x32x2_f32 (ait_gemm_f32_products(0))
 using Tile256 = Cfg<256, 128, 16, 4, 2, 2, MODE_RING>;
 using Tile128 = Cfg<128, 128, 16, 2, 2, 2, MODE_DB>;
 using TileN64 = Cfg<256, 64, 16, 4, 1, 2, MODE_DB>;
-using TileN64D = Cfg<256, 64, 16, 4, 1, 2, MODE_DLDS, 3, KNOB_SPLIT>;      // the same 256x64 outputs on the persistent split tile (four waves of 64x64)
+using TileN64D = Cfg<256, 64, 16, 4, 1, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_RNE>;      // the same 256x64 outputs on the persistent split tile (four waves of 64x64)
 using Tile64 = Cfg<64, 64, 16, 2, 2, 2, MODE_DB>;
 }  // namespace
 

@@ -541,7 +541,10 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
 // 8 + 8 + 8: h = x truncated to bf16, m = (x - h) truncated, l = x - h - m), a product of two bf16 values is exact in
 // f32, and the MFMA accumulates in f32.  So  a*b = (ah + am + al)(bh + bm + bl)  is formed from the six terms that
 // are >= 2^-16 |a b|  --  ah bh, ah bm, am bh, ah bl, al bh, am bm  --  and the three dropped ones are <= 2^-21 |a b|
-// together (truncation; 2^-23 with KNOB_RNE): a few roundings of an f32 multiply-add chain (2^-24 of the running sum per step).  Six 32-cycle
+// together (truncation; 2^-23 with KNOB_RNE): a few roundings of an f32 multiply-add chain (2^-24 of the running sum per step).
+// PRODUCT FORM SINCE ROUND 4: KNOB_RNE in every product tile.  Truncated planes all carry the sign of the value; on long
+// same-signed sums the bf16 pipe's accumulator alignment chops the small ones and the result drifts low by up to 1.4e-5
+// of the sum (K = 4800; profiles/r04_split_bias.txt) -- the planes rounded to nearest are zero-mean and show no drift.  Six 32-cycle
 // instructions replace eight 64-cycle ones per 16 k-steps; the split costs 5.5 vector instructions per fetched value,
 // issued in the shadow of the MFMAs.  The operand images in LDS, the LDS-DMA stream and the epilogues are untouched:
 // a lane's eight k-values of a slab (k = 8*lk + 0..7) are exactly the 32x32x16 operand layout.

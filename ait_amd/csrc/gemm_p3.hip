@@ -18,7 +18,7 @@
 
 namespace {
 using namespace ait_gemm;
-using TileP3 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3>;
+using TileP3 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3 | KNOB_RNE>;
 
 template <class C>
 int dispatch_nt(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {

@@ -124,13 +124,14 @@ struct Dims {
   int n_maps_pad;               // R / 16
 };
 inline int make_dims(int bp, int bs, int C, int planes, int n_blocks, Dims& d) {
-  if (bp < 0 || bs < 0 || bp + bs <= 0 || C <= 0 || planes <= 0 || n_blocks < 1 || n_blocks > kMaxBlocks) return AIT_EINVAL;
+  if (bp < 0 || bs < 0 || bp + bs <= 0 || C <= 0 || planes <= 0 || n_blocks < 2 || n_blocks > kMaxBlocks) return AIT_EINVAL;
   if ((C % 1024) || (planes % 128)) return AIT_EUNSUPPORTED;      // 8 groups of a multiple of 128 channels; 128-wide tiles
   d.bp = bp; d.bs = bs; d.C = C; d.P = planes; d.E = 4 * planes; d.n_blocks = n_blocks;
   d.Rp = (long long)bp * kPos; d.Rq = (long long)bs * kPos;
   d.R = (long long)align_up((size_t)(d.Rp + d.Rq), 128);
   d.n_maps = bp + bs; d.n_maps_pad = (int)(d.R / kPos);
   if (d.R * 4 > 0x7fffffffLL / 4 || (long long)bp * 64 > 0x7fffffffLL / 4) return AIT_EUNSUPPORTED;
+  if ((unsigned long long)d.R * (unsigned long long)(d.C > d.E ? d.C : d.E) >= (1ull << 32)) return AIT_EUNSUPPORTED;   // 32-bit epilogue offsets
   return AIT_OK;
 }
 // folded weights of layer4, in launch order

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib, graphs, ops, system
+from . import _lib, ops, system
 from .config import cfg
 from .roi_layers import ROIAlign
 from .rpn import _ProposalTargetLayer, _RPN, _smooth_l1_loss
@@ -40,11 +40,8 @@ from .system import MultiHeadAttention, Transformer, _Linear, _split_k, conv2d_1
 #                False = the nn.Module composition on PyTorch-ROCm convolutions, which the tests hold the node against
 #   _TOP_NHWC / _BASE_NHWC / _ROI_NHWC   channels-last activations in the proposal tail / the C4 trunk / RoIAlign (the
 #                AIT's token-major output IS channels-last); False = NCHW everywhere, the tests' reference configuration
-#   _QUERY_GRAPH the C4 trunk on the query patches (one fixed size, ~130 launches of a few microseconds: bound by the
-#                host's issue rate) replayed from a forward and a backward HIP graph in training; False = eager launches
 _SK_FULL = False
 _TAIL_FUSED = True
-_QUERY_GRAPH = True
 _TOP_NHWC = True
 _BASE_NHWC = True
 _ROI_NHWC = True
@@ -593,18 +590,6 @@ class RCNNBackbone(nn.Module):
         return run_stages([self.layer1, self.layer2, self.layer3], x), None
 
 
-class _QueryTrunk(nn.Module):
-    """RCNN_base on the query patches as the unit graphs.GraphedModule captures.  Never registered as a child of the
-    detector and never put through train()/eval(): it only borrows the shared trunk."""
-
-    def __init__(self, base):
-        super().__init__()
-        self.base = base
-
-    def forward(self, q):
-        return self.base(q)[0]
-
-
 # ------------------------------------------------------------------------------------------
 # the detector
 # ------------------------------------------------------------------------------------------
@@ -639,44 +624,6 @@ class _fasterRCNN(nn.Module):
                                        dropout=0.1)
         self.transformer.channels_last_out = _TOP_NHWC      # (only read on the GPU path)
         self.triplet_loss = torch.nn.MarginRankingLoss(margin=cfg.TRAIN.MARGIN)
-        self._query_graphs = {}
-
-    def __getstate__(self):
-        state = self.__dict__.copy()
-        state["_query_graphs"] = {}          # HIP graphs do not pickle / deepcopy; they are re-captured on first use
-        return state
-
-    def _query_graph_on(self, query):
-        """graph replay of the query trunk: training on the GPU, in a single-process run.  Under torch.distributed
-        (DDP over RCCL) the launches stay eager: a capture in `global` error mode is invalidated by any HIP query from
-        another thread, and the process group's watchdog thread polls its work events whenever it likes -- not
-        something a one-GPU box can test."""
-        import torch.distributed as dist
-        if not (_QUERY_GRAPH and self.training and query.is_cuda and torch.is_grad_enabled() and not query.requires_grad):
-            return False
-        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
-
-    def _side_stream(self, device):
-        key = ("stream", device.index)
-        if key not in self._query_graphs:
-            self._query_graphs[key] = torch.cuda.Stream(device)
-        return self._query_graphs[key]
-
-    def _query_trunk(self, query):
-        """RCNN_base(query).  The query patches have ONE size (the loader crops and resizes them to 128x128,
-        cfg.TRAIN.query_size, roibatchLoader.py:287-331), so in training on the GPU the trunk's launches for them -- small kernels, bound
-        by the host's issue rate, not by the GPU -- are replayed from two HIP graphs (forward, backward) captured
-        on first use per (shape, parameter storage).  Same kernels, same order, same values as the eager launches."""
-        if not self._query_graph_on(query):
-            return self.RCNN_base(query)[0]
-        key = (tuple(query.shape), query.dtype, query.device.index, _BASE_NHWC, _SK_FULL) \
-            + tuple((p.data_ptr(), p.requires_grad) for p in self.RCNN_base.parameters())
-        graphed = self._query_graphs.get(key)
-        if graphed is None:
-            for k in [k for k in self._query_graphs if k[0] != "stream"]:
-                del self._query_graphs[k]    # one live pair of graphs (a new key means the old one's inputs are gone)
-            graphed = self._query_graphs[key] = graphs.GraphedModule(_QueryTrunk(self.RCNN_base), query)
-        return graphed(query)
 
     def forward(self, image, query, img_info, gt_boxes, num_boxes):
         bs = image.size(0)
@@ -689,20 +636,10 @@ class _fasterRCNN(nn.Module):
             self.RCNN_rpn.RPN_anchor_target.begin(gt_boxes, img_info, *_c4_size(image.size(2), image.size(3)),
                                                   im_hw_hint=(image.size(2), image.size(3)))
 
-        if self._query_graph_on(query):
-            # the query patches' trunk is small kernels back to back (dispatch-latency bound): replayed on a second
-            # HIP stream it runs in the shadow of the target image's trunk, forward and (autograd runs a node's
-            # backward on the stream of its forward) backward
-            cur = torch.cuda.current_stream(query.device)
-            side = self._side_stream(query.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                query_feat = self._query_trunk(query)         # [bs, 1024, 8, 8]
-            image_feat, _ = self.RCNN_base(image)             # [bs, 1024, H_i, W_i]
-            cur.wait_stream(side)
-        else:
-            image_feat, _ = self.RCNN_base(image)
-            query_feat = self._query_trunk(query)
+        # (one program at every world size: the query trunk's launches are eager on the step's stream.  Round 3 replayed
+        # them from HIP graphs on a side stream at N = 1 only -- 0 ms measured un-profiled, profiles/README_r03.md)
+        image_feat, _ = self.RCNN_base(image)                 # [bs, 1024, H_i, W_i]
+        query_feat = self.RCNN_base(query)[0]                 # [bs, 1024, 8, 8]
         if self.variant == 'coco':
             non_img, non_qry = self.coattention_module(image_feat, query_feat)
         else:

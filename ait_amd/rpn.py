@@ -723,10 +723,17 @@ class _RPN(nn.Module):
     def forward(self, base_feat, im_info, gt_boxes, num_boxes):
         b = base_feat.size(0)
         c = self.RPN_Conv
-        if (_RPN_CONV_KERNEL and base_feat.is_cuda and base_feat.dtype == torch.float32 and c.in_channels % 128 == 0
-                and c.out_channels % 16 == 0 and base_feat.is_contiguous(memory_format=torch.channels_last)
-                and base_feat.shape[0] * base_feat.shape[2] * base_feat.shape[3] >= 16):
-            conv = _Conv3x3BiasRelu.apply(base_feat, c.weight, c.bias)
+        if _RPN_CONV_KERNEL and base_feat.is_cuda and base_feat.dtype == torch.float32:
+            if (c.in_channels % 128 == 0 and c.out_channels % 16 == 0
+                    and base_feat.shape[0] * base_feat.shape[2] * base_feat.shape[3] >= 16):
+                if not base_feat.is_contiguous(memory_format=torch.channels_last):
+                    base_feat = base_feat.contiguous(memory_format=torch.channels_last)    # (an NCHW caller: one re-layout, same kernel)
+                conv = _Conv3x3BiasRelu.apply(base_feat, c.weight, c.bias)
+            else:
+                # a head the implicit-GEMM kernel does not take: PyTorch-ROCm's convolution, COUNTED (bench.py refuses
+                # to print a line if any stand-in ran; DESIGN.md 1: on a GPU there is no silent fallback)
+                ops.note_fallback("rpn.RPN_Conv", base_feat)
+                conv = F.relu(c(base_feat), inplace=True)
         else:
             conv = F.relu(c(base_feat), inplace=True)
         cls_score = self.RPN_cls_score(conv)

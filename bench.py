@@ -34,13 +34,19 @@ def measured_peaks(device):
     v_mfma_f32_32x32x2_f32 loop (scripts/mfma_peak.hip, built by __graft_entry__.build(), run as a child
     process) and a 1-GiB device-to-device copy."""
     import subprocess
-    out = {"mfma_f32_tflops": None, "hbm_copy_gbs": None}
+    out = {"mfma_f32_tflops": None, "mfma_bf16_tflops": None, "hbm_copy_gbs": None}
     exe = os.path.join(ROOT, "scripts", "_mfma_peak")
     if os.path.exists(exe):
         try:
-            r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=60)
-            vals = [float(l.split("ms")[1].split("TFLOP/s")[0]) for l in r.stdout.splitlines() if "TFLOP/s" in l]
+            r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+            vals = [float(l.split("ms")[1].split("TFLOP/s")[0]) for l in r.stdout.splitlines() if "fp32 MFMA" in l]
             out["mfma_f32_tflops"] = max(vals) if vals else None
+            # the bf16 pipe UNDER LOAD: per waves-per-SIMD setting the LAST (sustained) window, random operand bits
+            per = {}
+            for l in r.stdout.splitlines():
+                if "bf16 MFMA" in l:
+                    per[l.split(":")[0]] = float(l.split("ms")[1].split("TFLOP/s")[0])
+            out["mfma_bf16_tflops"] = max(per.values()) if per else None
         except Exception:
             pass
     x = torch.empty(1 << 28, dtype=torch.float32, device=device)
@@ -209,6 +215,7 @@ def main():
     ap.add_argument("--bs", type=int, default=None, help="pairs per GPU (override; cfg2: 4, cfg3-5: 8)")
     ap.add_argument("--proposals", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ab", action="store_true", help="skip the f32_native A/B steps behind the timed region")
     ap.add_argument("--dtype", choices=["f32", "f32_native", "bf16", "bf16x3"], default=None,
                     help="matmul arithmetic of the AIT GEMMs.  f32 is the headline / parity "
                          "configuration; bf16 is the BASELINE cfg-5 arithmetic (operands rounded to bf16, "
@@ -269,6 +276,26 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, device)
 
+    # A/B beside the headline, OUTSIDE its timed region (every rank runs it: the steps hold collectives): the same step
+    # with the AIT's products on the instruction that multiplies f32 operands (v_mfma_f32_32x32x2_f32)
+    ab_native_ms = None
+    if args.dtype == "f32" and not args.no_ab:
+        ops.set_matmul_dtype("f32_native")
+        try:
+            for _ in range(2):
+                step()
+            D.barrier()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            n_ab = max(1, min(args.steps, 10))
+            for _ in range(n_ab):
+                step()
+            torch.cuda.synchronize()
+            D.barrier()
+            ab_native_ms = D.max_over_ranks(time.perf_counter() - ta, device) / n_ab * 1e3
+        finally:
+            ops.set_matmul_dtype(args.dtype)
+
     # on a GPU box the product path is the library's kernels: not one torch stand-in may have run
     if ops.fallback_count() != 0:
         raise SystemExit("bench.py: torch fallbacks ran inside the step: %r" % (dict(ops.FALLBACKS),))
@@ -310,8 +337,10 @@ def main():
         "metric": METRIC, "value": value, "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"f32": "f32",
-                  "f32_native": "f32",
+        "dtype": {"f32": "f32 (operands, results, accumulation and storage f32; products: every operand value split exactly into "
+                         "three bf16 values (round to nearest), six v_mfma_f32_32x32x16_bf16 per block, dropped terms <= 2^-23 |a b|)",
+                  "f32_native": "f32 (AIT products on v_mfma_f32_32x32x2_f32; the proposal tail's and the RPN head's convolutions "
+                                "keep the split-bf16 form)",
                   "bf16": "bf16 products (AIT GEMMs and the proposal tail's convolutions: operands rounded to bf16 in registers, one MFMA per block, f32 accumulate); f32 storage; f32 trunk / LayerNorm / attention tiles",
                   "bf16x3": "f32 emulated as 3 bf16 MFMAs per product (experimental; fp32 accumulate)"}[args.dtype],
         "data": "synthetic",
@@ -348,9 +377,14 @@ def main():
                      # BASELINE.md 4 / SURVEY 8d: the whole AIT path end to end against the matrix peak --
                      # pairs/s x 0.911 TFLOP (as-computed-by-reference FLOPs of one pair) per GPU
                      "e2e_ait_frac": value / world * AIT_TFLOP_PER_PAIR / peak if is_f32 else None,
-                     "measured_peak": peaks["mfma_f32_tflops"] if peaks else None,
-                     "frac_of_measured_peak": (achieved / peaks["mfma_f32_tflops"]) if peaks and peaks["mfma_f32_tflops"]
-                                              and is_f32 else None},
+                     # what THIS box's matrix pipe sustains for the product form in use: a register-only loop of the same
+                     # instruction on random operand bits (scripts/mfma_peak.hip), per f32-equivalent product
+                     "measured_peak": (peaks["mfma_bf16_tflops"] / 6 if args.dtype == "f32" and peaks.get("mfma_bf16_tflops")
+                                       else peaks["mfma_f32_tflops"] if args.dtype == "f32_native" else None) if peaks else None,
+                     "measured_peak_is": "register-only v_mfma_f32_32x32x16_bf16 loop on random operands, sustained, / 6"
+                                         if args.dtype == "f32" else "register-only v_mfma_f32_32x32x2_f32 loop",
+                     "measured_bf16_pipe_tflops": peaks.get("mfma_bf16_tflops") if peaks else None,
+                     "measured_f32_instruction_tflops": peaks.get("mfma_f32_tflops") if peaks else None},
         "roofline_roi_align": {"fwd": roi_entry("fwd"), "bwd": roi_entry("bwd"),
                                "measured_peak_gbs": peaks["hbm_copy_gbs"] if peaks else None},
     }
@@ -365,6 +399,12 @@ def main():
             fl = 2.0 * k[0] * k[1] * k[2]
             print("gemm M=%6d N=%5d K=%6d ta=%d tb=%d splits=%2d : %2d/step %8.1f us  %6.1f TF/s  %5.2f ms/step"
                   % (k + (n // args.steps, 1e3 * ms / n, fl / (ms / n) / 1e9, ms / args.steps)), file=sys.stderr)
+    r = line["roofline"]
+    if ab_native_ms is not None:
+        line["ab"] = {"f32_native_ms_per_step": ab_native_ms, "f32_native_pairs_per_s": world * args.bs / (ab_native_ms * 1e-3),
+                      "what": "the same step with the AIT's products formed by v_mfma_f32_32x32x2_f32 (--dtype f32_native), "
+                              "run right after the timed region; the tail's and the RPN head's convolutions keep the split form"}
+    r["frac_of_measured_peak"] = (achieved / r["measured_peak"]) if r.get("measured_peak") else None
     if world == 1 and not args.no_cpu_baseline:
         # (the CPU port is timed on the headline workload's pair: VOC variant, ResNet50)
         line["cpu_baseline"] = cpu_baseline(args.proposals)

@@ -59,10 +59,14 @@ const char* ait_strerror(int code);
  *   flags   0, or AIT_CTX_NATIVE_F32: the dense fp32 products (ait_gemm_f32 and the products inside the
  *       ait_mha_ / ait_ffn_ / ait_transformer_ composites) are formed by v_mfma_f32_32x32x2_f32, the instruction
  *       that multiplies f32 operands.  Default (0): every f32 operand is split EXACTLY into three bf16 values
- *       (24 significant bits = 8 + 8 + 8) and a product is accumulated in f32 from the six partial products that
- *       are >= 2^-16 of it, on v_mfma_f32_32x32x16_bf16 -- 16x the FLOP per cycle of the f32 instruction, six
- *       instead of one; the three dropped partial products sum to <= 2^-21 |a b| (worst case), a few roundings of an f32
- *       multiply-add, and the measured error against float64 equals the f32 instruction's (tests/test_gpu_gemm.py).
+ *       h = bf16(x), m = bf16(x - h), l = x - h - m (round to nearest even: |m| <= 2^-9 |x|, |l| <= 2^-17 |x|, both
+ *       zero-mean whatever the sign of x) and a product is accumulated in f32 from the six partial products that
+ *       are >= 2^-18 of it, on v_mfma_f32_32x32x16_bf16 -- 16x the FLOP per cycle of the f32 instruction, six
+ *       instead of one; the three dropped partial products sum to <= 2^-23 |a b|.  Tested against float64 beside the
+ *       f32 instruction (tests/test_gpu_gemm.py): on random operands the same error; on SAME-SIGNED operands over
+ *       reductions of 512 ... 76800 terms (the adversarial case: profiles/r04_split_bias.txt) mean error <= 1e-7 of
+ *       the sum, scatter below the f32 instruction's.  (Round 3 formed the planes by truncation: one-signed planes,
+ *       chopped by the pipe's accumulator alignment on long same-signed sums -- up to 1.4e-5 of the sum low.)
  *       Same operand images, same epilogues, same summation order over k-blocks.  Non-finite inputs: NaN where
  *       the f32 instruction gives an infinity.  The convolution composites (ait_conv_*, ait_tail_*) always use
  *       the split form.
@@ -291,7 +295,7 @@ int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, con
  *   row pitch ldb_values VALUES (>= K, % 8 == 0; a K sub-range of wider rows is addressed by offsetting B_p3 by
  *   6 bytes per value).  bias / residual / flags / c_colblk as ait_gemm_f32 (no AIT_GEMM_ATOMIC / ACCUMULATE /
  *   BIAS_ROW); K % 16 == 0.  The same six partial products per f32 product as ait_gemm_f32's default form: A is
- *   split in registers (truncation), B arrives split (nearest); dropped terms <= 2^-22 |a b|.
+ *   split in registers, B arrives split, both to nearest; dropped terms <= 2^-23 |a b|.
  * ------------------------------------------------------------------------------------- */
 size_t ait_p3_bytes(long long rows, long long cols);
 int ait_p3_split(const float* src, int rows, int cols, int ld, int transpose, void* dst, void* stream);

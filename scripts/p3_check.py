@@ -1,16 +1,32 @@
-import torch, sys
-sys.path.insert(0, '/root/repo')
-from ait_amd import ops
-for (M,N,K) in [(76800,1536,512),(33000,512,2048),(58800,2048,512)]:
-    for spread in (0.0, 2.0):
-        torch.manual_seed(M+N+K)
-        a = torch.randn(M, K, device="cuda") * torch.exp(spread * torch.randn(1, K, device="cuda"))
-        w = torch.randn(N, K, device="cuda") * torch.exp(spread * torch.randn(1, K, device="cuda"))
-        wp = ops.p3_split(w)
-        ref = a.double() @ w.double().t()
-        mag = a.double().abs() @ w.double().abs().t()
-        c = ops.gemm_p3(a, wp); raw = ops.gemm(a, w)
-        ep = ((c.double()-ref).abs()/mag); er = ((raw.double()-ref).abs()/mag)
-        print(M,N,K,spread, "p3 max %.3g rms %.3g | raw max %.3g rms %.3g | mean signed p3 %.3g raw %.3g" % (ep.max(), ep.square().mean().sqrt(), er.max(), er.square().mean().sqrt(), ((c.double()-ref)/mag).mean(), ((raw.double()-ref)/mag).mean()))
-        # where is the max
-        i = int(ep.argmax()); print("   argmax row %d col %d" % (i // N, i % N))
+"""diagnostic: error of the product forms on same-signed all-ones-significand operands (bias) and on random operands"""
+import torch, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ait_amd import ops, _lib
+def all_ones(shape, gen):
+    e = torch.randint(-2, 3, shape, device="cuda", generator=gen).float()
+    return (2.0 - 2.0 ** -23) * torch.exp2(e)
+for (M, N, K, ta, sk) in [(33000, 512, 64, False, 1), (33000, 512, 512, False, 1), (33000, 512, 2048, False, 1), (512, 2048, 76800, True, 16)]:
+    gen = torch.Generator(device="cuda").manual_seed(M + K)
+    for kind in ("ones", "pos_random", "random"):
+        if kind == "ones":
+            a = all_ones((K, M) if ta else (M, K), gen); b = all_ones((K, N) if ta else (N, K), gen)
+        else:
+            a = torch.rand((K, M) if ta else (M, K), device="cuda", generator=gen) + 0.5
+            b = torch.rand((K, N) if ta else (N, K), device="cuda", generator=gen) + 0.5
+            if kind == "random":
+                a = a * (torch.randint(0, 2, a.shape, device="cuda", generator=gen).float() * 2 - 1)
+                b = b * (torch.randint(0, 2, b.shape, device="cuda", generator=gen).float() * 2 - 1)
+        ref = (a.double().t() @ b.double()) if ta else (a.double() @ b.double().t())
+        mag = (a.double().abs().t() @ b.double().abs()) if ta else (a.double().abs() @ b.double().abs().t())
+        got = ops.gemm(a, b, trans_a=ta, trans_b=not ta, split_k=sk)
+        _lib.NATIVE_F32 = True
+        nat = ops.gemm(a, b, trans_a=ta, trans_b=not ta, split_k=sk)
+        _lib.NATIVE_F32 = False
+        es, en = (got.double() - ref) / mag, (nat.double() - ref) / mag
+        line = "%-10s M=%d N=%d K=%d | split: min %.3g max %.3g mean %.3g | f32 instr: min %.3g max %.3g mean %.3g" % (
+            kind, M, N, K, es.min(), es.max(), es.mean(), en.min(), en.max(), en.mean())
+        if not ta and K >= 128:
+            c = ops.gemm_p3(a, ops.p3_split(b))
+            e3 = (c.double() - ref) / mag
+            line += " | p3: min %.3g max %.3g mean %.3g" % (e3.min(), e3.max(), e3.mean())
+        print(line)

@@ -224,7 +224,16 @@ def test_detector_train_step_gradients_vs_oracle(model):
     sd = {k: v.clone() for k, v in D.make_detector_state_dict(9, D.reference_shapes()).items()}
     watch = ["transformer.encoder.layer_stack.0.slf_attn.w_qs.weight", "transformer.dec_trans.0.bias",
              "RCNN_cls_score.1.weight", "coattention.img_trans.0.weight", "RCNN_rpn.RPN_Conv.bias",
-             "RCNN_base.backbone.layer3.5.conv3.weight", "transformer.enc_emb.0.weight"]
+             "RCNN_base.backbone.layer3.5.conv3.weight", "transformer.enc_emb.0.weight",
+             # the proposal tail (ait_tail_fwd / ait_tail_bwd: both SK blocks + layer4 as one node): every convolution of
+             # the first and last bottleneck, the stride-2 shortcut, both SK branches
+             "RCNN_top.0.0.conv1.weight", "RCNN_top.0.0.conv2.weight", "RCNN_top.0.0.conv3.weight",
+             "RCNN_top.0.2.conv1.weight", "RCNN_top.0.2.conv2.weight", "RCNN_top.0.2.conv3.weight",
+             "RCNN_top.0.0.downsample.0.weight",
+             "sk.sk_props.convs.0.0.weight", "sk.sk_props.convs.0.0.bias",
+             "sk.sk_props.convs.1.0.weight", "sk.sk_props.convs.1.0.bias"]
+    watch = [k for k in watch if k in sd]
+    assert len(watch) >= 16, watch
     for k in watch:
         sd[k].requires_grad_(True)
     ins = D.synth_inputs(1, 1101)
@@ -244,7 +253,10 @@ def test_detector_train_step_gradients_vs_oracle(model):
     for i in range(3, 8):
         assert abs(float(res[i]) - float(out[i])) <= 2e-4 * abs(float(out[i])) + 2e-6
     for k in watch:
-        got, want = params[k].grad.cpu(), sd[k].grad
+        # (RCNN_top.0 IS RCNN_base.backbone.layer4 -- one module under two names, resnet_sys_transformer_sk_dilat.py:230,422;
+        # named_parameters() lists it once)
+        pk = k if k in params else "RCNN_base.backbone.layer4." + k[len("RCNN_top.0."):]
+        got, want = params[pk].grad.cpu(), sd[k].grad
         rel = float((got - want).norm() / (want.norm() + 1e-12))
         assert rel < 5e-3, (k, rel)
 
@@ -380,48 +392,3 @@ def test_detector_full_size_step_matches_reference_work_and_is_reproducible(mode
     assert float((prob - prob_ref)[same].abs().max()) <= 1e-4
 
 
-def test_query_trunk_graph_replay_matches_eager_launches(model):
-    """The C4 trunk on the query patches is replayed from a forward and a backward HIP graph in training
-    (faster_rcnn._query_trunk): over three steps with fresh inputs and IN-PLACE weight updates in between, the
-    feature map and every parameter gradient equal those of the eager launches, and the gradient of the shared trunk
-    still accumulates with the target image's."""
-    import ait_amd.faster_rcnn as fr
-    model.train()
-    params = [p for k, p in model.RCNN_base.named_parameters()                  # (.backbone also owns layer4 and fc)
-              if p.requires_grad and k.startswith(("backbone.layer1.", "backbone.layer2.", "backbone.layer3."))]
-    assert len(params) > 40
-    gen = torch.Generator(device="cuda").manual_seed(11)
-    model._query_graphs.clear()
-    try:
-        for step in range(3):
-            q = torch.randn(4, 3, 128, 128, device="cuda", generator=gen)
-            img = torch.randn(1, 3, 96, 160, device="cuda", generator=gen)
-            w = torch.randn(4, 1024, 8, 8, device="cuda", generator=gen)
-            got = {}
-            for graph in (True, False):
-                fr._QUERY_GRAPH = graph
-                for p in params:
-                    p.grad = None
-                f = model._query_trunk(q)
-                g = model.RCNN_base(img)[0]                     # the same weights, a second use in the same step
-                ((f * w).sum() + g.square().sum()).backward()
-                got[graph] = (f.detach().clone(), [p.grad.detach().clone() for p in params])
-            assert sum(k[0] != "stream" for k in model._query_graphs) == 1
-            assert float((got[True][0] - got[False][0]).abs().max()) <= 1e-5 * float(got[False][0].abs().max())
-            for a, b in zip(got[True][1], got[False][1]):
-                # (MIOpen's weight-gradient kernels accumulate with atomics, the solver it picks for a captured launch
-                # need not be the eager one, and two f32 implementations of a convolution flip the ReLU mask bit of
-                # pre-activations within rounding of zero: agreement in norm, not element by element)
-                assert float((a - b).norm()) <= 5e-3 * float(b.norm()) + 1e-7
-            with torch.no_grad():
-                for p in params[:8]:
-                    p.mul_(1.01)                                # the optimizer's in-place update: the graph reads it
-        # evaluation and no_grad runs never touch the graphs
-        fr._QUERY_GRAPH = True
-        with torch.no_grad():
-            assert model._query_trunk(q).shape == (4, 1024, 8, 8)
-        assert sum(k[0] != "stream" for k in model._query_graphs) == 1
-    finally:
-        fr._QUERY_GRAPH = True
-        for p in params:
-            p.grad = None

@@ -117,42 +117,6 @@ def test_anchor_target_inside_set_follows_the_image_size():
     assert torch.equal(outs[0][0], outs[2][0])
 
 
-def test_graph_capture_parameter_swap_restores_the_shared_trunk():
-    """graphs.GraphedModule differentiates the captured region with respect to aliases of the parameters, swapped
-    into the modules by hand: the trunk's stages are reachable under two names (RCNN_base.layer1 is
-    RCNN_base.backbone.layer1), every slot must hold the alias inside the block and the SAME Parameter objects again
-    after it (an optimizer holds them), and the gradients with respect to the aliases are the parameters' own."""
-    import torch
-    from ait_amd import graphs
-    from ait_amd.faster_rcnn import _QueryTrunk, resnet
-    torch.manual_seed(0)
-    m = resnet(('__background__', 'fg'), 50, pretrained=False, class_agnostic=True, num_K=3)
-    m.create_architecture()
-    m.train()
-    before = dict(m.named_parameters())
-    unit = _QueryTrunk(m.RCNN_base)
-    real = list(unit.parameters())
-    leaves = [p.detach().requires_grad_(p.requires_grad) for p in real]
-    by_id = {id(p): a for p, a in zip(real, leaves)}
-    x = torch.randn(1, 3, 64, 64)
-    k = "RCNN_base.backbone.layer3.5.conv3.weight"
-    with graphs._parameters_replaced(unit, by_id):
-        assert m.RCNN_base.layer3[5].conv3.weight is by_id[id(before[k])]
-        assert m.RCNN_base.backbone.layer3[5].conv3.weight is by_id[id(before[k])]
-        out = unit(x)
-    after = dict(m.named_parameters())
-    assert after.keys() == before.keys() and all(after[n] is before[n] for n in before)
-    want = [l for l in leaves if l.requires_grad]
-    g = torch.autograd.grad(out, want, torch.ones_like(out), allow_unused=True)
-    y = m.RCNN_base(x)[0]
-    gg = torch.autograd.grad(y, [p for p in real if p.requires_grad], torch.ones_like(y), allow_unused=True)
-    assert sum(t is not None for t in g) == sum(t is not None for t in gg) > 40
-    for a, b in zip(g, gg):
-        assert (a is None) == (b is None)
-        if a is not None:
-            assert torch.equal(a, b)
-
-
 def test_row_decomposition_by_corrected_f32_quotients_is_exact():
     """gemm_f32_impl.h div_small (maps of any size in the implicit-GEMM convolutions): q = int(float(n) * (1/d)) is off
     by at most one for 0 <= n < 2^24, and the remainder test puts it right -- restated in numpy float32 (same

@@ -562,18 +562,24 @@ __device__ __forceinline__ unsigned round2(float x0, float x1) {         // v_cv
 }
 
 // x = h + m + l exactly (the remainders are exact f32 subtractions, l needs at most 8 significant bits).
-//   RNE  : h = bf16(x), m = bf16(x - h) rounded to nearest: |m| <= 2^-8 |x|, |l| <= 2^-16 |x|; the partial products the
-//          six-term form drops (m l' + l m' + l l') are <= 2^-23 |x x'|;
+//   RNE  : h = bf16(x) rounded to nearest, m = the top 8 bits of the (either-signed) remainder: |m| <= 2^-9 |x|,
+//          |l| < 2^-16 |x|; the partial products the six-term form drops (m l' + l m' + l l') are <= 2^-23 |x x'|;
 //   else : h, m by TRUNCATION (the top 16 bits): |m| < 2^-7 |x|, |l| < 2^-15 |x|, dropped terms <= 2^-21 |x x'|.
 // 11 vector instructions per two values either way (tests/test_host_cpu.py restates both in numpy).
 template <bool RNE>
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
   if constexpr (RNE) {
+    // h to NEAREST (v_cvt_pk_bf16_f32); the remainder r = x - h is exact, has at most 16 significant bits and EITHER
+    // sign whatever the sign of x, so its two halves are taken by truncation (v_perm_b32: one cycle cheaper per
+    // instruction than the conversion, and the kernel that splits both operands is bound by vector issue):
+    // m = top 8 bits of r, l = r - m (exact, <= 8 bits), both with the sign of r -- zero-mean planes, no drift on
+    // same-signed data (profiles/r04_split_bias.txt), |m| <= 2^-9 |x|, |l| < 2^-16 |x|: dropped terms <= 2^-23 |x x'|.
     h = round2(x0, x1);                                                   // (bf16(x1) << 16) | bf16(x0)
     const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = round2(r0, r1);
-    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-    l = round2(s0, s1);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
   } else {
     const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
     h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                      // (hi16(x1) << 16) | hi16(x0)

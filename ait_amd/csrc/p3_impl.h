@@ -3,9 +3,9 @@
 // P3 stores an f32 matrix X [rows][K] (K = the reduction dimension of the product it will enter) as its three bf16
 // planes, interleaved in groups of eight values along K:
 //     P3[row][K / 8][plane = h, m, l][8]   (bf16)   --   48 bytes per 8 values, 6 bytes per value, row pitch 6 K bytes
-// with x = h + m + l EXACTLY (h = bf16(x), m = bf16(x - h), l = x - h - m, planes rounded to nearest even: the
-// remainders are exact f32 subtractions and l needs at most 8 significant bits): P3 is a lossless re-encoding of the
-// f32 tensor.  One 16-byte chunk is what one lane of v_mfma_f32_32x32x16_bf16 takes as its eight k-values of one
+// with x = h + m + l EXACTLY (h = bf16(x) rounded to nearest even, m = the top 8 bits of x - h, l = x - h - m: the
+// remainders are exact f32 subtractions and l needs at most 8 significant bits; gemm_f32_impl.h split2<true>): P3 is a
+// lossless re-encoding of the f32 tensor.  One 16-byte chunk is what one lane of v_mfma_f32_32x32x16_bf16 takes as its eight k-values of one
 // plane, so the GEMM moves P3 rows global -> LDS with global_load_lds_dwordx4 and fetches operands with
 // ds_read_b128 -- no vector arithmetic on that operand at all (gemm_f32_impl.h, KNOB_BP3).  Weights are converted
 // once per step (ait_p3_split / the composites' own multi-tensor pass); their 6 B/value against 4 is irrelevant

@@ -59,8 +59,8 @@ const char* ait_strerror(int code);
  *   flags   0, or AIT_CTX_NATIVE_F32: the dense fp32 products (ait_gemm_f32 and the products inside the
  *       ait_mha_ / ait_ffn_ / ait_transformer_ composites) are formed by v_mfma_f32_32x32x2_f32, the instruction
  *       that multiplies f32 operands.  Default (0): every f32 operand is split EXACTLY into three bf16 values
- *       h = bf16(x), m = bf16(x - h), l = x - h - m (round to nearest even: |m| <= 2^-9 |x|, |l| <= 2^-17 |x|, both
- *       zero-mean whatever the sign of x) and a product is accumulated in f32 from the six partial products that
+ *       h = bf16(x) rounded to nearest even, m = the top 8 bits of the exact remainder x - h, l = x - h - m
+ *       (|m| <= 2^-9 |x|, |l| < 2^-16 |x|, both zero-mean whatever the sign of x) and a product is accumulated in f32 from the six partial products that
  *       are >= 2^-18 of it, on v_mfma_f32_32x32x16_bf16 -- 16x the FLOP per cycle of the f32 instruction, six
  *       instead of one; the three dropped partial products sum to <= 2^-23 |a b|.  Tested against float64 beside the
  *       f32 instruction (tests/test_gpu_gemm.py): on random operands the same error; on SAME-SIGNED operands over
@@ -284,8 +284,8 @@ int ait_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, con
  * Products with a PRE-SPLIT weight operand ("P3").  No reference counterpart: how this library keeps the weight
  * side of  y = x W^T  (lib/model/system/SubLayers.py:77-79,97,181-182; Models.py:246-247,278) and of its input
  * gradient  dx = dy W  off the vector pipe.  P3 of an f32 matrix X [rows][K] (K = the reduction dimension of
- * the product it enters) = its three bf16 planes h = bf16(x), m = bf16(x - h), l = x - h - m (round to nearest
- * even; x = h + m + l exactly), interleaved in groups of eight along K:
+ * the product it enters) = its three bf16 planes h = bf16(x) (nearest even), m = top 8 bits of x - h, l = x - h - m
+ * (x = h + m + l exactly), interleaved in groups of eight along K:
  *     P3[row][K / 8][h, m, l][8] bf16   -- 6 bytes per value, ait_p3_bytes(rows, K) in all, 16-byte aligned.
  * ait_p3_split: src [rows][cols] f32 (row pitch ld floats, ld % 4 == 0, 16-byte aligned) -> P3 of src (transpose
  *   == 0: reduction dimension = cols, cols % 8 == 0) or of its transpose (transpose != 0: P3 [cols][rows / 8][3][8],

@@ -141,10 +141,13 @@ def test_row_decomposition_by_corrected_f32_quotients_is_exact():
 
 
 def test_three_way_bf16_split_is_exact_and_six_terms_reach_f32_accuracy():
-    """gemm_f32_impl.h split2 / mfma_split restated in numpy, both forms: planes by truncation (the product's) and by
-    round-to-nearest (KNOB_RNE).  (1) x == h + m + l exactly and every plane is a bf16 value, for random, tiny, huge
-    and all-bits-set inputs; (2) the six partial products kept (hh, hm, mh, hl, lh, mm) reproduce a * b to
-    <= 2^-21 |a b| (truncation) / <= 2^-23 |a b| (nearest)."""
+    """gemm_f32_impl.h split2 / mfma_split restated in numpy, both forms: every plane by truncation (round 3's) and the
+    product form since round 4 (KNOB_RNE): h = bf16(x) rounded to NEAREST, m = the top 8 bits of the exact remainder
+    r = x - h, l = r - m.  (1) x == h + m + l exactly and every plane is a bf16 value, for random, tiny, huge and
+    all-bits-set inputs; (2) the six partial products kept (hh, hm, mh, hl, lh, mm) reproduce a * b to
+    <= 2^-21 |a b| (truncation) / <= 2^-23 |a b| (nearest); (3) on POSITIVE inputs the truncated form's m and l planes are
+    all positive (the one-signed planes that drift on long same-signed sums, profiles/r04_split_bias.txt) while the
+    nearest form's are zero-mean."""
     import numpy as np
     rs = np.random.RandomState(7)
 
@@ -156,10 +159,10 @@ def test_three_way_bf16_split_is_exact_and_six_terms_reach_f32_accuracy():
     def trunc_bf16(x):
         return (x.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
 
-    def split(x, to_bf16):
-        h = to_bf16(x)
+    def split(x, first):
+        h = first(x)
         r = (x - h).astype(np.float32)
-        m = to_bf16(r)
+        m = trunc_bf16(r)
         l = (r - m).astype(np.float32)
         return h, m, l
 
@@ -169,14 +172,24 @@ def test_three_way_bf16_split_is_exact_and_six_terms_reach_f32_accuracy():
     y = rs.permutation(x)
     f = np.float64
     worst = {}
-    for name, to_bf16 in (("nearest", rne_bf16), ("truncate", trunc_bf16)):
-        h, m, l = split(x, to_bf16)
-        assert np.array_equal(to_bf16(l), l)                                    # l needs no more than bf16's 8 bits
+    for name, first in (("nearest", rne_bf16), ("truncate", trunc_bf16)):
+        h, m, l = split(x, first)
+        assert np.array_equal(trunc_bf16(l), l)                                 # l needs no more than bf16's 8 bits
         assert np.array_equal(h.astype(f) + m.astype(f) + l.astype(f), x.astype(f))
-        hy, my, ly = split(y, to_bf16)
+        hy, my, ly = split(y, first)
         six = h.astype(f) * hy + h.astype(f) * my + m.astype(f) * hy + h.astype(f) * ly + l.astype(f) * hy + m.astype(f) * my
         exact = x.astype(f) * y.astype(f)
         ok = np.isfinite(exact) & (np.abs(exact) > 1e-300) & (np.abs(exact) < 1e300)
         worst[name] = float((np.abs(six - exact)[ok] / np.abs(exact)[ok]).max())
+        # magnitudes of the planes
+        nz = x != 0
+        lim_m, lim_l = (2.0 ** -8, 2.0 ** -16) if name == "nearest" else (2.0 ** -7, 2.0 ** -15)
+        assert (np.abs(m[nz].astype(f)) <= lim_m * np.abs(x[nz].astype(f))).all()
+        assert (np.abs(l[nz].astype(f)) <= lim_l * np.abs(x[nz].astype(f))).all()
     assert worst["nearest"] <= 2.0 ** -23
     assert 2.0 ** -23 < worst["truncate"] <= 2.0 ** -21
+    pos = (rs.rand(200000).astype(np.float32) + 0.5)
+    _, m_t, l_t = split(pos, trunc_bf16)
+    _, m_n, l_n = split(pos, rne_bf16)
+    assert (m_t >= 0).all() and (l_t >= 0).all() and float(m_t.mean()) > 1e-3
+    assert abs(float(m_n.astype(f).mean())) < 2e-5 and 0.4 < float((m_n > 0).mean()) < 0.6 and 0.4 < float((l_n > 0).mean()) < 0.6

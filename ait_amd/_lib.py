@@ -93,6 +93,8 @@ SIGNATURES = {
     "ait_transformer_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "ait_transformer_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp,
                                  _vp, _vp, _vp]),
+    "ait_transformer_bwd_part": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp,
+                                 _vp, _vp, _vp]),
     "ait_tail_saved_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ait_tail_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ait_tail_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

@@ -608,15 +608,19 @@ AIT_API size_t ait_transformer_bwd_workspace_bytes(int bp, int bs, int n_src) {
   return (3 * M * D + (size_t)bs * T * D + blk) * sizeof(float) + 32 * 256;
 }
 
-AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const float* x_query, int bp, int bs,
-                                int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
-                                unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
-                                size_t workspace_bytes, float* d_x_props, float* d_x_query,
-                                const ait_transformer_grads* g, const ait_launch_ctx* ctx, void* stream) {
+// parts: bit 0 = decoder head (dec_trans, decoder feed-forward), bit 1 = decoder attention (cross, self, prologue,
+// dec_emb), bit 2 = encoder (feed-forward, self-attention, prologue, enc_emb).  The gradient carriers between the
+// parts live at fixed places of `workspace`: a caller that runs the parts as separate calls (in this order) hands
+// every call the same workspace.
+static int ait_backward_parts(int parts, const float* d_out, const float* x_props, const float* x_query, int bp, int bs,
+                              int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
+                              unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
+                              size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                              const ait_transformer_grads* g, const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY(check_ait(bp, bs, n_src, w));
   if (bad_p(p_drop) || bad_p(p_attn_drop) || !g) return AIT_EINVAL;
   if (bp == 0) return AIT_OK;
-  if (!d_out || !x_props || !x_query || !saved || !workspace) return AIT_EINVAL;
+  if (((parts & 1) && !d_out) || !x_props || !x_query || !saved || !workspace) return AIT_EINVAL;
   if (saved_bytes < ait_transformer_saved_bytes(bp, bs, n_src)) return AIT_EWORKSPACE;
   if (workspace_bytes < ait_transformer_bwd_workspace_bytes(bp, bs, n_src)) return AIT_EWORKSPACE;
   hipStream_t hs = ait_stream(stream);
@@ -634,6 +638,7 @@ AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const 
   const Bump blk = b;        // every block carves its scratch from the same remainder
   const float p = p_drop, pa = p_attn_drop;
 
+  if (parts & 1) {
   // dec_trans: out = d3 W^T + b
   if (g->dec_trans_b) AIT_TRY(ait_colsum_f32(d_out, M, C2, C2, g->dec_trans_b, stream));
   AIT_TRY(wgrad(d_out, M, C2, a.d3, D, g->dec_trans_w, run));
@@ -644,7 +649,9 @@ AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const 
     AIT_TRY(ffn_block_bwd(ga, a.d2, M, w->dec_ffn, a.dec_ffn, t, p, ait_dropout_seed(seed, kSeedDecFfn), gb, g->dec_ffn, run,
                           a.p_dec_w1, a.p_dec_w2));
   }
+  }
   float* d_mem = gc;     // [Mc, 512]
+  if (parts & 2) {
   {  // decoder cross-attention: d d2 -> d d1, d mem
     Bump bb = blk; MhaBwdWs t;
     if (!carve(bb, t, bp, n_src, true)) return AIT_EWORKSPACE;
@@ -664,6 +671,8 @@ AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const 
   AIT_TRY(ait_rep_sum_f32(ga, bs, P, (long long)T * D, d_emb_q, stream));
   AIT_TRY(wgrad(d_emb_q, (long long)bs * T, D, x_query, C2, g->dec_emb_w, run));
   if (d_x_query) AIT_TRY(dgrad(d_emb_q, bs * T, D, w->dec_emb_w, C2, nullptr, false, d_x_query, run));
+  }
+  if (!(parts & 4)) return AIT_OK;
 
   {  // encoder feed-forward on the compacted rows: d mem -> d xc
     Bump bb = blk; FfnBwdWs t;
@@ -683,4 +692,23 @@ AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const 
   AIT_TRY(wgrad(ga, Mc, D, x_props, C2, g->enc_emb_w, run));
   if (d_x_props) AIT_TRY(dgrad(ga, Mc, D, w->enc_emb_w, C2, nullptr, false, d_x_props, run, nullptr, a.p_enc_emb.wt));
   return AIT_OK;
+}
+
+AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const float* x_query, int bp, int bs,
+                                int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
+                                unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
+                                size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                                const ait_transformer_grads* g, const ait_launch_ctx* ctx, void* stream) {
+  return ait_backward_parts(7, d_out, x_props, x_query, bp, bs, n_src, w, p_drop, p_attn_drop, seed, saved, saved_bytes,
+                            workspace, workspace_bytes, d_x_props, d_x_query, g, ctx, stream);
+}
+
+AIT_API int ait_transformer_bwd_part(int part, const float* d_out, const float* x_props, const float* x_query, int bp,
+                                     int bs, int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
+                                     unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
+                                     size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                                     const ait_transformer_grads* g, const ait_launch_ctx* ctx, void* stream) {
+  if (part < 0 || part > 2) return AIT_EINVAL;
+  return ait_backward_parts(1 << part, d_out, x_props, x_query, bp, bs, n_src, w, p_drop, p_attn_drop, seed, saved,
+                            saved_bytes, workspace, workspace_bytes, d_x_props, d_x_query, g, ctx, stream);
 }

@@ -66,6 +66,33 @@ def collective_description(ddp):
     return desc
 
 
+class BucketClock:
+    """When does the reducer hand its buckets to the all-reduce?  A comm hook (the default all-reduce, plus a note of the
+    host clock) over a DDP-wrapped model: `start()` before backward(), then `first_ms` / `last_ms` / `count` say when
+    the first and the last bucket of that backward became ready, relative to start.  Host clock: when the reducer
+    ENQUEUED the exchange (it then waits for the gradients' stream on the device)."""
+
+    def __init__(self, ddp):
+        import time
+        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        self._time, self.t0, self.stamps = time, None, []
+
+        def hook(state, bucket):
+            if self.t0 is not None:
+                self.stamps.append((self._time.perf_counter() - self.t0) * 1e3)
+            return default_hooks.allreduce_hook(None, bucket)
+        ddp.register_comm_hook(None, hook)
+
+    def start(self):
+        self.t0, self.stamps = self._time.perf_counter(), []
+
+    def summary(self):
+        if not self.stamps:
+            return None
+        return {"buckets": len(self.stamps), "first_ready_ms": self.stamps[0], "last_ready_ms": self.stamps[-1],
+                "clock": "host, from the call of backward()"}
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

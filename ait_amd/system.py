@@ -339,71 +339,139 @@ class _ToNCHW(torch.autograd.Function):
         return dx, dw, ops.colsum(dyt.contiguous()), None, None
 
 
-class _TransformerFn(torch.autograd.Function):
-    """The whole AIT operator in training: ait_transformer_fwd_train / ait_transformer_bwd
-    (include/ait_hip.h).  One autograd node: the forward saves its activations into ONE buffer the
-    library lays out, the backward writes both input gradients and accumulates the 46 parameter
-    gradients into one zero-filled buffer whose views are handed to autograd."""
+# The AIT operator in training: ait_transformer_fwd_train, and its backward in THREE bursts (ait_transformer_bwd_part,
+# include/ait_hip.h) as three chained autograd nodes -- the forward saves its activations into ONE buffer the library
+# lays out; every backward part accumulates the parameter gradients of its own layers into a zero-filled buffer whose
+# views are handed to autograd.  Under DistributedDataParallel the reducer's hooks therefore see the decoder head's
+# gradients while the decoder attention's backward is being enqueued, and so on: its buckets are handed to RCCL
+# during the 15 ms of AIT backward instead of after it.  Index of every parameter in _param_list():
+_PART_PARAMS = (
+    [4, 5] + list(range(40, 46)),                                     # part 0: dec_trans, decoder feed-forward
+    list(range(26, 34)) + list(range(18, 26)) + [8, 9, 2, 3],         # part 1: dec_enc, dec_slf, decoder prologue, dec_emb
+    list(range(34, 40)) + list(range(10, 18)) + [6, 7, 0, 1],         # part 2: enc_ffn, enc_slf, encoder prologue, enc_emb
+)
+
+
+class _AitState:
+    """what the three backward parts of one forward share (plain Python object: not a tensor, not saved by autograd)"""
+    __slots__ = ("xp", "xq", "saved", "ws", "W", "keep", "cfg", "shapes", "_dxq")
+
+
+def _grads_struct(views_by_index):
+    """ait_transformer_grads with the members of the given {param index: tensor} set, the others NULL"""
+    G = _lib.TransformerGrads()
+    ptr = lambda i: views_by_index[i].data_ptr() if i in views_by_index else None
+    G.enc_emb_w, G.enc_emb_b, G.dec_emb_w, G.dec_emb_b = ptr(0), ptr(1), ptr(2), ptr(3)
+    G.dec_trans_w, G.dec_trans_b = ptr(4), ptr(5)
+    G.enc_ln_g, G.enc_ln_b, G.dec_ln_g, G.dec_ln_b = ptr(6), ptr(7), ptr(8), ptr(9)
+    for j, name in enumerate(("enc_slf", "dec_slf", "dec_enc")):
+        b = 10 + 8 * j       # w_qs, w_ks, w_vs (contiguous = the [1536, 512] layout of w_qkv), sk.w, sk.b, fc, ln
+        g = getattr(G, name)
+        g.w_qkv, g.sk_w, g.sk_b, g.fc_w, g.ln_g, g.ln_b = ptr(b), ptr(b + 3), ptr(b + 4), ptr(b + 5), ptr(b + 6), ptr(b + 7)
+    for j, name in enumerate(("enc_ffn", "dec_ffn")):
+        b = 34 + 6 * j
+        g = getattr(G, name)
+        g.w1, g.b1, g.w2, g.b2, g.ln_g, g.ln_b = (ptr(b + i) for i in range(6))
+    return G
+
+
+PART_TRACE = None      # test hook: a list that receives ("ait_part", k) when part k of an AIT backward is enqueued
+
+
+def _ait_backward_part(st, part, d_out, want_dxp=False, want_dxq=False):
+    """run one part; returns (views of this part's parameter gradients in _PART_PARAMS[part] order, dxp, dxq)"""
+    if PART_TRACE is not None:
+        PART_TRACE.append(("ait_part", part))
+    L = _lib.lib()
+    bp, bs, n_s, p, p_attn, seed = st.cfg
+    dev = st.xp.device
+    idx = _PART_PARAMS[part]
+    sizes = [int(np.prod(st.shapes[i])) for i in idx]
+    # (the three w_qs / w_ks / w_vs gradients of a block are ONE [1536, 512] matrix for the library: their views must be
+    # adjacent, which the index lists above guarantee)
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    views, o = {}, 0
+    for i, n in zip(idx, sizes):
+        views[i] = flat[o:o + n].view(st.shapes[i])
+        o += n
+    G = _grads_struct(views)
+    if st.ws is None:
+        wbytes = int(L.ait_transformer_bwd_workspace_bytes(bp, bs, n_s))
+        st.ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    dxp = torch.empty_like(st.xp) if want_dxp else None
+    dxq = torch.empty_like(st.xq) if want_dxq else None
+    with torch.cuda.device(dev):
+        rc = L.ait_transformer_bwd_part(part, None if d_out is None else _lib.dev_ptr(d_out), _lib.dev_ptr(st.xp),
+                                        _lib.dev_ptr(st.xq), bp, bs, n_s, ctypes.byref(st.W), p, p_attn, seed,
+                                        ctypes.c_void_p(st.saved.data_ptr()), st.saved.numel(),
+                                        ctypes.c_void_p(st.ws.data_ptr()), st.ws.numel(),
+                                        None if dxp is None else _lib.dev_ptr(dxp),
+                                        None if dxq is None else _lib.dev_ptr(dxq), ctypes.byref(G),
+                                        _lib.launch_ctx(dev), _lib.cur_stream(dev))
+    _lib.check(rc, "ait_transformer_bwd_part(%d)" % part)
+    return [views[i] for i in idx], dxp, dxq
+
+
+class _AitCore(torch.autograd.Function):
+    """forward: the whole operator; backward: part 2 (the encoder; writes d x_props) -- runs LAST"""
 
     @staticmethod
-    def forward(ctx, xp, xq, bp, bs, n_s, p, p_attn, seed, W, keep, *params):
+    def forward(ctx, xp, xq, st, *params2):
         L = _lib.lib()
         dev = xp.device
-        xp, xq = xp.contiguous(), xq.contiguous()
+        bp, bs, n_s, p, p_attn, seed = st.cfg
+        st.xp, st.xq = xp.contiguous(), xq.contiguous()
         nbytes = int(L.ait_transformer_saved_bytes(bp, bs, n_s))
-        saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        st.saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         out = torch.empty((bp * SEQ, xp.shape[1]), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = L.ait_transformer_fwd_train(_lib.dev_ptr(xp), _lib.dev_ptr(xq), bp, bs, n_s, ctypes.byref(W),
-                                             float(p), float(p_attn), int(seed), ctypes.c_void_p(saved.data_ptr()),
+            rc = L.ait_transformer_fwd_train(_lib.dev_ptr(st.xp), _lib.dev_ptr(st.xq), bp, bs, n_s, ctypes.byref(st.W),
+                                             float(p), float(p_attn), int(seed), ctypes.c_void_p(st.saved.data_ptr()),
                                              nbytes, _lib.dev_ptr(out), _lib.launch_ctx(dev), _lib.cur_stream(dev))
         _lib.check(rc, "ait_transformer_fwd_train")
-        ctx.save_for_backward(xp, xq, saved)
-        ctx.W, ctx.keep = W, keep              # (keep owns the concatenated QKV matrices W points into)
-        ctx.cfg = (bp, bs, n_s, float(p), float(p_attn), int(seed))
-        ctx.shapes = [tuple(t.shape) for t in params]
+        ctx.st = st
         return out
 
     @staticmethod
-    def backward(ctx, d_out):
-        L = _lib.lib()
-        xp, xq, saved = ctx.saved_tensors
-        bp, bs, n_s, p, p_attn, seed = ctx.cfg
-        dev = xp.device
-        d_out = d_out.contiguous()
-        # one zero-filled buffer for every parameter gradient (they are ACCUMULATED by the library)
-        sizes = [int(np.prod(sh)) for sh in ctx.shapes]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-        views, o = [], 0
-        for sh, n in zip(ctx.shapes, sizes):
-            views.append(flat[o:o + n].view(sh))
-            o += n
-        G = _lib.TransformerGrads()
-        ptr = lambda i: views[i].data_ptr()
-        G.enc_emb_w, G.enc_emb_b, G.dec_emb_w, G.dec_emb_b = ptr(0), ptr(1), ptr(2), ptr(3)
-        G.dec_trans_w, G.dec_trans_b = ptr(4), ptr(5)
-        G.enc_ln_g, G.enc_ln_b, G.dec_ln_g, G.dec_ln_b = ptr(6), ptr(7), ptr(8), ptr(9)
-        for j, name in enumerate(("enc_slf", "dec_slf", "dec_enc")):
-            b = 10 + 8 * j       # w_qs, w_ks, w_vs (contiguous = the [1536, 512] layout of w_qkv), sk.w, sk.b, fc, ln
-            g = getattr(G, name)
-            g.w_qkv, g.sk_w, g.sk_b, g.fc_w, g.ln_g, g.ln_b = ptr(b), ptr(b + 3), ptr(b + 4), ptr(b + 5), ptr(b + 6), ptr(b + 7)
-        for j, name in enumerate(("enc_ffn", "dec_ffn")):
-            b = 34 + 6 * j
-            g = getattr(G, name)
-            g.w1, g.b1, g.w2, g.b2, g.ln_g, g.ln_b = (ptr(b + i) for i in range(6))
-        dxp = torch.empty_like(xp) if ctx.needs_input_grad[0] else None
-        dxq = torch.empty_like(xq) if ctx.needs_input_grad[1] else None
-        wbytes = int(L.ait_transformer_bwd_workspace_bytes(bp, bs, n_s))
-        ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            rc = L.ait_transformer_bwd(_lib.dev_ptr(d_out), _lib.dev_ptr(xp), _lib.dev_ptr(xq), bp, bs, n_s,
-                                       ctypes.byref(ctx.W), p, p_attn, seed, ctypes.c_void_p(saved.data_ptr()),
-                                       saved.numel(), ctypes.c_void_p(ws.data_ptr()), wbytes,
-                                       None if dxp is None else _lib.dev_ptr(dxp),
-                                       None if dxq is None else _lib.dev_ptr(dxq), ctypes.byref(G),
-                                       _lib.launch_ctx(dev), _lib.cur_stream(dev))
-        _lib.check(rc, "ait_transformer_bwd")
-        return (dxp, dxq, None, None, None, None, None, None, None, None) + tuple(views)
+    def backward(ctx, _token):
+        st = ctx.st
+        grads, dxp, _ = _ait_backward_part(st, 2, None, want_dxp=ctx.needs_input_grad[0])
+        dxq = getattr(st, "_dxq", None)
+        st.ws = None        # the workspace goes back to the allocator here (`saved` lives as long as the graph: a second
+                            # backward over a retained graph runs the three parts again)
+        return (dxp, dxq, None) + tuple(grads)
+
+
+class _AitStage(torch.autograd.Function):
+    """forward: identity; backward: part `part` of the operator's backward (0 runs first, then 1).  The gradient it hands
+    on is only a token that orders the parts: the real carriers live in the shared workspace."""
+
+    @staticmethod
+    def forward(ctx, y, st, part, *params):
+        ctx.st, ctx.part = st, part
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, d):
+        st, part = ctx.st, ctx.part
+        if part == 0:
+            grads, _, _ = _ait_backward_part(st, 0, d.contiguous())
+        else:
+            grads, _, dxq = _ait_backward_part(st, 1, None, want_dxq=True)
+            st._dxq = dxq                           # (returned by _AitCore.backward, the node that owns x_query)
+        return (d, None, None) + tuple(grads)
+
+
+def _transformer_train(xp, xq, bp, bs, n_s, p, p_attn, seed, W, keep, params):
+    st = _AitState.__new__(_AitState)
+    st.ws = st.saved = st._dxq = None
+    st.W, st.keep = W, keep                        # (keep owns the concatenated QKV matrices W points into)
+    st.cfg = (bp, bs, n_s, float(p), float(p_attn), int(seed))
+    st.shapes = [tuple(t.shape) for t in params]
+    pick = lambda part: [params[i] for i in _PART_PARAMS[part]]
+    y = _AitCore.apply(xp, xq, st, *pick(2))
+    y = _AitStage.apply(y, st, 1, *pick(1))
+    return _AitStage.apply(y, st, 0, *pick(0))
 
 
 # ------------------------------------------------------------------------------------------
@@ -755,7 +823,7 @@ class Transformer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def _param_list(self):
-        """the 46 parameters in the order of ait_transformer_grads (_TransformerFn.backward)"""
+        """the 46 parameters in the order of ait_transformer_grads (_grads_struct)"""
         enc, dec = self.encoder.layer_stack[0], self.decoder.layer_stack[0]
         ps = [self.enc_emb[0].weight, self.enc_emb[0].bias, self.dec_emb[0].weight, self.dec_emb[0].bias,
               self.dec_trans[0].weight, self.dec_trans[0].bias, self.encoder.layer_norm.weight,
@@ -869,9 +937,9 @@ class Transformer(nn.Module):
         base_seed = _new_seed()
         fine = _PY_COMPOSE or not _COMPACT_MEMORY or ops.MATMUL_DTYPE != "f32"
         if len(self.encoder.layer_stack) == 1 and len(self.decoder.layer_stack) == 1 and not fine:
-            # training: the whole operator is ONE autograd node over ait_transformer_fwd_train / _bwd
+            # training: ait_transformer_fwd_train, and its backward as three chained autograd nodes (_transformer_train)
             W, keep = self._c_weights_cached()
-            out = _TransformerFn.apply(xp, xq, bp, bs, n_s, p, p_attn, base_seed, W, keep, *self._param_list())
+            out = _transformer_train(xp, xq, bp, bs, n_s, p, p_attn, base_seed, W, keep, self._param_list())
             if self.channels_last_out:
                 return out.view(bp, hq, wq, c2).permute(0, 3, 1, 2)
             return out.view(bp, n_t, c2).transpose(1, 2).reshape(bp, c2, hq, wq)

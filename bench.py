@@ -249,10 +249,15 @@ def main():
     np.random.seed(3 + rank)                     # reference RNG_SEED, one stream per rank
     batch = synth_batch(args.bs, 1000 + rank, device, max_gt=50 if args.variant == "coco" else 20)
 
+    clock = D.BucketClock(ddp) if world > 1 else None      # (N > 1: when the gradient buckets reach the all-reduce)
+
     def step():
         opt.zero_grad(set_to_none=True)
         out = ddp(*batch)
-        total_cost(out).backward()
+        cost = total_cost(out)
+        if clock is not None:
+            clock.start()
+        cost.backward()
         opt.step()
 
     peaks = measured_peaks(device) if rank == 0 else None
@@ -351,6 +356,7 @@ def main():
                    "backbone": "ResNet%d" % conf["layers"],
                    "pairs_per_gpu": args.bs, "global_batch": world * args.bs,
                    "collective": "none" if world == 1 else D.collective_description(ddp),
+                   "gradient_buckets": clock.summary() if clock is not None else None,
                    "proposals": args.proposals, "target": "600x1000", "query": "128x128",
                    "parallelism": "dp%d" % world, "miopen_find_db": bool(tuned)},
         "roofline": {"bound": "mfma",

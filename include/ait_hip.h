@@ -593,6 +593,18 @@ int ait_transformer_bwd(const float* d_out, const float* x_props, const float* x
                         unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
                         size_t workspace_bytes, float* d_x_props, float* d_x_query,
                         const ait_transformer_grads* grads, const ait_launch_ctx* ctx, void* stream);
+/* The same backward in THREE calls, for a data-parallel caller that wants the parameter gradients in bursts it can
+ * hand to the gradient all-reduce while the rest of the backward still runs (trainval_net_voc.py:321-326,391-395:
+ * the reference's DataParallel reduces after the whole backward; SURVEY 8e: buckets launched as backward produces
+ * them).  part 0: dec_trans + decoder feed-forward (reads d_out); part 1: decoder cross- and self-attention,
+ * decoder prologue, dec_emb (writes d_x_query); part 2: the encoder, enc_emb (writes d_x_props).  Called in this
+ * order with the SAME workspace (the gradient carriers between the parts live in it) and the same other arguments;
+ * a part only touches the `grads` members of its own layers (the others may be NULL). */
+int ait_transformer_bwd_part(int part, const float* d_out, const float* x_props, const float* x_query, int bp, int bs,
+                             int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
+                             unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
+                             size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                             const ait_transformer_grads* grads, const ait_launch_ctx* ctx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * The proposal tail behind the AIT as one call per direction: both SKBlocks and RCNN_top

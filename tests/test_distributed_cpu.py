@@ -25,13 +25,18 @@ WORKER = textwrap.dedent("""
     torch.manual_seed(0)
     net = Net()
     ddp = D.wrap(net, local_rank)
+    clock = D.BucketClock(ddp)                   # (bench.py's note of when the buckets reach the all-reduce)
     lo, hi = D.shard_slice(6, rank, world)
     assert (lo, hi) == ((0, 3) if rank == 0 else (3, 6))
     torch.manual_seed(100)
     x = torch.randn(6, 8)[lo:hi]
     for _ in range(3):                          # static_graph needs >1 iteration to settle
         net.zero_grad()
-        ddp(x).sum().backward()
+        loss = ddp(x).sum()
+        clock.start()
+        loss.backward()
+    s = clock.summary()
+    assert s["buckets"] >= 1 and 0 <= s["first_ready_ms"] <= s["last_ready_ms"]
     g = net.a.weight.grad.clone()
     ref = [torch.zeros_like(g) for _ in range(world)]
     torch.distributed.all_gather(ref, g)

@@ -54,10 +54,34 @@ WORKER = textwrap.dedent("""
         return {k: params[k].grad.detach().clone() for k in watch}
 
     alone = step(m)                                # this rank's own gradient, no exchange
-    ddp = D.wrap(m, local_rank)
+    ddp = D.wrap(m, local_rank, bucket_mb=8)
     assert ddp is not m
-    for _ in range(2):                             # static_graph settles after the first iteration
+    # ---- when do the reducer's buckets become ready?  (SURVEY 8e: buckets launched as backward produces them.)  A
+    # comm hook notes every bucket the reducer hands to the all-reduce, the AIT notes its three backward parts, a
+    # gradient hook on the LAST convolution of the trunk (the first trunk layer the backward reaches) notes when the
+    # trunk's backward has started.
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    from ait_amd import system
+    events = []
+    system.PART_TRACE = events
+    def hook(state, bucket):
+        events.append(("bucket", bucket.index()))
+        return default_hooks.allreduce_hook(None, bucket)
+    ddp.register_comm_hook(None, hook)
+    params["RCNN_base.backbone.layer3.5.conv3.weight"].register_post_accumulate_grad_hook(lambda p_: events.append(("trunk",)))
+    for _ in range(3):                             # static_graph settles (and rebuilds its buckets) in the first iterations
+        del events[:]
         got = step(ddp)
+    kinds = [e[0] for e in events]
+    first_trunk = kinds.index("trunk")
+    n_before = sum(k == "bucket" for k in kinds[:first_trunk])
+    print("rank", rank, "buckets ready before the trunk backward:", n_before, "of", kinds.count("bucket"), flush=True)
+    assert n_before >= 4, events
+    # the AIT's gradients arrive in three bursts, and the reducer launches buckets BETWEEN them (while the rest of the
+    # AIT backward is still being enqueued), not only after the whole operator's backward
+    p0, p2 = events.index(("ait_part", 0)), events.index(("ait_part", 2))
+    assert events.index(("ait_part", 1)) in range(p0, p2)
+    assert any(k == "bucket" for k in kinds[p0:p2]), events
     assert params["RCNN_base.backbone.fc.weight"].grad is None      # never used: dropped from the buckets
     for k in watch:
         both = [torch.zeros_like(got[k]) for _ in range(world)]

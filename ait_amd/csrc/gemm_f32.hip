@@ -60,7 +60,19 @@ using Tile128 = Cfg<128, 128, 16, 2, 2, 2, MODE_DB>;
 using TileN64 = Cfg<256, 64, 16, 4, 1, 2, MODE_DB>;
 using TileN64D = Cfg<256, 64, 16, 4, 1, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_RNE>;      // the same 256x64 outputs on the persistent split tile (four waves of 64x64)
 using Tile64 = Cfg<64, 64, 16, 2, 2, 2, MODE_DB>;
+//   TileCoop   256x256, eight waves of 64x128, one workgroup per CU, every operand value split ONCE per workgroup into an LDS
+//              plane image (KNOB_COOP): 88 vector instructions per 48 MFMAs against 264.  The weight-gradient products (both
+//              operands are activations, K-outer: nothing to pre-split): 203-204 TF/s against 185 for Tile256D on the
+//              transformer's shapes (profiles/r04_gemm_lab_coop.txt).  Static work lists (its LDS is the CU's 160 KB).
+using TileCoop = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_COOP | KNOB_NOTICKET | KNOB_RNE>;
 }  // namespace
+
+// the weight-gradient launches the cooperative-split tile takes (csrc/transformer.hip sizes its K-splits for the tile)
+bool ait_gemm_coop_takes(int trans_a, int trans_b, int M, int N, int K, int flags, const ait_launch_ctx* ctx) {
+  if (ctx && (ctx->flags & (AIT_CTX_NATIVE_F32 | AIT_CTX_BF16))) return false;
+  return trans_a && !trans_b && (flags & AIT_GEMM_ATOMIC) && M >= 256 && N >= 256 && (M % 4) == 0 && (N % 4) == 0 &&
+         K >= 4096 && (K % 16) == 0;
+}
 
 // The product entry point with everything the library's own composites may ask for (csrc/gemm_internal.h): `gate`
 // (same addressing as C; with `residual`: C = (alpha A.B + bias + residual) zeroed where gate <= 0 -- the input
@@ -105,6 +117,9 @@ int ait_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, float alpha, 
   // launches cut their last round without any scratch
   const bool few_tiles_sk = direct && K >= 512 && tiles256 >= 96 &&
                             ((g.splits == 1 && !(flags & AIT_GEMM_ATOMIC) && ws.p != nullptr) || (flags & AIT_GEMM_ATOMIC));
+  if (direct && ait_gemm_coop_takes(trans_a, trans_b, M, N, K, flags, ctx) &&
+      (long long)((M + 255) / 256) * ((N + 255) / 256) * g.splits >= 128)
+    return launch<TileCoop, false, false, EPI_ATOMIC>(g, ait_stream(stream), ws);
   if (M >= 512 && (tiles256 >= 512 || few_tiles_sk)) {
     if (direct) {
       if (ctx && (ctx->flags & AIT_CTX_BF16)) return dispatch<Tile256B>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);

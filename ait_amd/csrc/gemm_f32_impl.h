@@ -183,6 +183,10 @@ enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8, KNOB_SP
        KNOB_RNE = 128 /* with KNOB_SPLIT: the three planes by round-to-nearest (dropped terms <= 2^-23 |a b|) instead of by
                          truncation (<= 2^-21): same instruction count, v_cvt_pk_bf16_f32 instead of v_perm_b32 / v_and */,
        KNOB_SPLIT_SIMPLE = 32 /* lab: KNOB_SPLIT with every split in front of its tile's MFMAs instead of under the previous tile's */,
+       KNOB_COOP = 1024 /* with KNOB_SPLIT: every operand value is split ONCE per workgroup -- the raw slab lands in a two-slot ring,
+                         each of the NT threads splits one operand row of the NEXT slab (16 values) and writes its planes into an
+                         LDS image in the P3 row format, and the MFMAs of the current slab fetch ready planes (no vector work on
+                         the matrix side).  One main loop for every operand layout: only the split stage looks at the raw image */,
        KNOB_NOTICKET = 512 /* no ticket ring in LDS: static work lists only (a ring of four 40-KB slabs is all of the CU's 160 KB) */,
        KNOB_BP3 = 256 /* with KNOB_SPLIT: operand B arrives PRE-SPLIT ("P3": the three bf16 planes of every value, interleaved in
                          groups of eight along the reduction dimension, see p3_split_kernel); only A is split in registers */ };
@@ -197,7 +201,9 @@ struct Cfg {
   static constexpr int VB = BN * BK / 4 / NT;
   static constexpr int NBUF = (MODE_ == MODE_DB) ? 2 : 3;
   static constexpr int BKB = (KNOBS_ & 256 /* KNOB_BP3 */) ? 24 : BK_;   // floats per row of a B slab (P3: 16 values x 6 B)
-  static constexpr size_t LDS = (MODE_ == MODE_DLDS) ? sizeof(float) * NS_ * (BK * BM + BKB * BN) + ((KNOBS_ & 512) ? 0 : 64) /* ticket ring */
+  static constexpr size_t LDS = (MODE_ == MODE_DLDS && (KNOBS_ & 1024 /* KNOB_COOP */))
+                                    ? sizeof(float) * 2 * (BK + 24) * (BM + BN) + ((KNOBS_ & 512) ? 0 : 64)   // raw ring of two + two plane images
+                                : (MODE_ == MODE_DLDS) ? sizeof(float) * NS_ * (BK * BM + BKB * BN) + ((KNOBS_ & 512) ? 0 : 64) /* ticket ring */
                                                      : sizeof(float) * NBUF * BK * (PA + PB);
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile / wave mismatch");
   static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "slab / thread mismatch");
@@ -624,10 +630,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NS = C::NS;
   constexpr int NP = LA + LB;     // transfers per wave per slab
+  constexpr bool kCoop = (C::KNOBS & KNOB_COOP) != 0;
+  static_assert(!kCoop || ((C::KNOBS & KNOB_SPLIT) != 0 && !kBp3 && C::NT == BM + BN), "cooperative split: one thread per operand row");
   static_assert(NS == 3 || NS == 4, "ring of 3 or 4 slabs");
   static_assert(NS == 3 || (GA % NW == 0 && GB % NW == 0), "counted waits need the same transfer count in every wave");
-  float* As = lds;                // [NS][SA]
-  float* Bd = lds + NS * SA;      // [NS][SB]
+  constexpr int NSR = kCoop ? 2 : NS;      // slots of the raw slab ring
+  float* As = lds;                // [NSR][SA]
+  float* Bd = lds + NSR * SA;     // [NSR][SB]
+  float* Pa = lds + NSR * (SA + SB);       // kCoop: [2][BM * 24] plane image of A (P3 rows, p3_impl.h), then of B
+  float* Pb = Pa + 2 * BM * 24;
 
   // raw barrier: __syncthreads() is a fence + barrier, and the fence makes hipcc drain vmcnt(0) whenever it
   // has stores of its own outstanding (the epilogue's), which would also drain the slab kept in flight
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // zeroes its two counters.
   const bool dyn = g.sched != nullptr;
   const int lim_dp = lim - sk_r;                                   // whole items of this XCD
-  int* idq = reinterpret_cast<int*>(lds + NS * (SA + SB));         // [8] ticket ring
+  int* idq = reinterpret_cast<int*>(lds + NSR * (SA + SB) + (kCoop ? 2 * 24 * (BM + BN) : 0));         // [8] ticket ring
   unsigned* ticket = g.sched + xcd * 32;
   int n_fetched = 0;            // tickets in the ring so far (identical in every wave)
   bool ended = false;           // a drawn ticket was past the end
@@ -958,7 +969,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // slab ahead.  Pipelined schedule: the bf16 planes of this slab's B tiles (bp) and of the A tile in work (ap), the
   // planes being formed under the MFMAs (nap: the next A tile; nbp: the NEXT slab's B tiles) and two raw operand
   // tiles in flight from LDS (rw): every region of six MFMAs splits what the region before it fetched.
-  constexpr bool kPipe = kSplit && (C::KNOBS & KNOB_SPLIT_SIMPLE) == 0 && !kBp3;
+  constexpr bool kPipe = kSplit && (C::KNOBS & KNOB_SPLIT_SIMPLE) == 0 && !kBp3 && !kCoop;
   constexpr int kTerms = (C::KNOBS & KNOB_BF16) != 0 ? 1 : 6;
   constexpr bool kRne = (C::KNOBS & KNOB_RNE) != 0;
   static_assert(!kPipe || (C::TM >= 2 && C::TN >= 2 && C::TN <= C::TM && (C::TM * C::TN) % 2 == 0), "split schedule");
@@ -986,7 +997,51 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     ap = split8<6, kRne>(fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 0), fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 0));
     fetch_bplanes(Bd + slot * SB, 0, bq[0]);
   };
-  if constexpr (kBp3) {
+  // kCoop: thread t owns operand row t of every slab (t < BM: row t of A, else row t - BM of B): it reads the row's 16
+  // raw values, splits them and writes the six 16-B plane chunks of the row into the plane image `pslot`.
+  //   raw image, reduction dim contiguous: the row's four swizzled 16-B chunks (rowimg_off);
+  //   raw image K-major [16][ROWS]: sixteen ds_read_b32 a row pitch apart (consecutive lanes, consecutive rows)
+  auto coop_read = [&](int rslot, float4 (&q)[4]) __attribute__((always_inline)) {
+    const bool isA = threadIdx.x < BM;                   // (wave-uniform: BM is a multiple of 64)
+    const int r = isA ? (int)threadIdx.x : (int)threadIdx.x - BM;
+    const float* raw = isA ? As + rslot * SA : Bd + rslot * SB;
+    const bool kcontig = isA ? AK : BKC;
+    const int rows = isA ? BM : BN;
+    if (kcontig) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) q[c] = *reinterpret_cast<const float4*>(raw + rowimg_off(r, c));
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const float* p = raw + (4 * c) * rows + r;
+        q[c] = make_float4(p[0], p[rows], p[2 * rows], p[3 * rows]);
+      }
+    }
+  };
+  auto coop_write = [&](int pslot, const Planes& lo, const Planes& hi) __attribute__((always_inline)) {
+    const bool isA = threadIdx.x < BM;
+    const int r = isA ? (int)threadIdx.x : (int)threadIdx.x - BM;
+    float* d = (isA ? Pa + pslot * (BM * 24) : Pb + pslot * (BN * 24)) + r * 24;
+    const int sw = (r >> 3) & 1;
+    *reinterpret_cast<bf16x8*>(d + ((0 ^ sw) << 2)) = lo.h;
+    *reinterpret_cast<bf16x8*>(d + ((1 ^ sw) << 2)) = lo.m;
+    *reinterpret_cast<bf16x8*>(d + ((2 ^ sw) << 2)) = lo.l;
+    *reinterpret_cast<bf16x8*>(d + ((3 ^ sw) << 2)) = hi.h;
+    *reinterpret_cast<bf16x8*>(d + ((4 ^ sw) << 2)) = hi.m;
+    *reinterpret_cast<bf16x8*>(d + ((5 ^ sw) << 2)) = hi.l;
+  };
+  // planes of 32-row tile t (rows row0 + 32 t + li) of a plane image
+  auto fetch_planes = [&](const float* img, int row0, int t, bf16x8 (&d)[3]) __attribute__((always_inline)) {
+    const int row = row0 + t * 32 + li, sw = (row >> 3) & 1;
+#pragma unroll
+    for (int p = 0; p < 3; p++) d[p] = *reinterpret_cast<const bf16x8*>(img + row * 24 + (((lk * 3 + p) ^ sw) << 2));
+  };
+  if constexpr (kCoop) {
+    float4 q[4];
+    coop_read(0, q);
+    coop_write(0, split8<6, kRne>(q[0], q[1]), split8<6, kRne>(q[2], q[3]));
+    ring_barrier();          // plane image 0 complete; raw slot 0 free for slab 2
+  } else if constexpr (kBp3) {
     prime3(0);
   } else if constexpr (kPipe) {
     prime(0);
@@ -1018,11 +1073,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     if constexpr (Probe::on) c0 = __builtin_amdgcn_s_memtime();
 
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      const int nxt = (cur == NS - 1) ? 0 : cur + 1;
+      const int nxt = (cur == NSR - 1) ? 0 : cur + 1;
       // the slot iteration s-1 finished reading.  (Grouped / parity kernels: hipcc keeps `cur` in a vector register
       // there and would hand the LDS-DMA's wave-uniform base to the asm as a VGPR; ONE readfirstlane per slab puts the
       // slot back into a scalar -- forcing every transfer's address through readfirstlane halves the kernel's rate)
-      const int nxt2 = (cur == 0) ? NS - 1 : cur - 1;
+      // (kCoop: slab s + 2 goes where slab s was: its raw values were split during the previous iteration)
+      const int nxt2 = kCoop ? cur : (cur == 0) ? NS - 1 : cur - 1;
       const Bases lbase = slab_bases(nxt2);
       // The transfers of slab s+NS-1 are issued one at a time BETWEEN the MFMA steps, not in a burst at
       // the top of the iteration: right after the barrier every wave of the CU would be issuing them
@@ -1044,7 +1100,48 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           for (int i = 0; i < NP; i++) issue(i, lbase);
         }
       }
-      if constexpr (kBp3) {
+      if constexpr (kCoop) {
+        // Region (a, b) = the six MFMAs of tile pair (a, b) on planes fetched from image `cur`.  In their shadow: the B
+        // planes of the next region; this thread's row of the NEXT slab -- raw reads in region 0, the two halves of the
+        // split in regions 1..4, the six plane stores in regions 5 and 6 (image `nxt`); one LDS-DMA transfer of slab
+        // s + 2 behind each of the first NP regions.
+        constexpr int kPairs = C::TM * C::TN;
+        static_assert(kPairs >= 8 && kPairs % 2 == 0 && NP <= kPairs, "cooperative split schedule");
+        const float* pa_img = Pa + cur * (BM * 24);
+        const float* pb_img = Pb + cur * (BN * 24);
+        bf16x8 pA[3], pB[2][3];
+        float4 q[4];
+        Planes slo, shi;
+        fetch_planes(pb_img, wn, 0, pB[0]);
+#pragma unroll
+        for (int a = 0; a < C::TM; a++) {
+          fetch_planes(pa_img, wm, a, pA);
+#pragma unroll
+          for (int b = 0; b < C::TN; b++) {
+            const int r = a * C::TN + b, pr = r & 1, nx = pr ^ 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (r + 1 < kPairs) fetch_planes(pb_img, wn, (b + 1) % C::TN, pB[nx]);
+            if (r == 0) coop_read(nxt, q);
+            {
+              f32x16 c = acc[a][b];
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[2], pB[pr][0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[0], pB[pr][2], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[1], pB[pr][1], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[1], pB[pr][0], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[0], pB[pr][1], c, 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[0], pB[pr][0], c, 0, 0, 0);
+            }
+            if (r == 1) slo = split8<6, kRne>(q[0], q[1]);
+            if (r == 3) shi = split8<6, kRne>(q[2], q[3]);
+            if (r == 5) coop_write(nxt, slo, shi);
+            __builtin_amdgcn_sched_barrier(0);
+            if (r < NP) {
+              if (feed) issue(r, lbase);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      } else if constexpr (kBp3) {
         // Region (a, b) = the six MFMAs of tile pair (a, b).  In their shadow: the three plane reads of the NEXT region's B
         // tile (tile 0 of the next slab behind the last region: complete in LDS since the last barrier); in region (a, 0)
         // the raw quads of the next A tile (tile a + 1, or tile 0 of the next slab), split in regions (a, 1) and (a, 2):
@@ -1340,7 +1437,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     // (the operand quads are dead across the epilogue -- its address arithmetic needs the registers --
     // and are fetched again from the next tile's first slab, complete in LDS since the last barrier)
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (kBp3) {
+    if constexpr (kCoop) {
+      // (operands are fetched from the plane image at the top of every iteration: nothing to re-fetch)
+    } else if constexpr (kBp3) {
       prime3(cur);
     } else if constexpr (kPipe) {
       prime(cur);

@@ -9,6 +9,9 @@ int ait_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, float alpha, 
                     int ldb, float* C, int ldc, const float* bias, const float* residual, const float* gate, int flags,
                     int split_k, int c_colblk, long long c_batch_stride, const ait_launch_ctx* ctx, void* stream);
 
+// the weight-gradient launches that run on the cooperative-split 256 x 256 tile (csrc/gemm_f32.hip)
+bool ait_gemm_coop_takes(int trans_a, int trans_b, int M, int N, int K, int flags, const ait_launch_ctx* ctx);
+
 // Products whose weight operand is pre-split (csrc/gemm_p3.hip).  ait_gemm_p3b_takes: the shapes that path serves
 // (others stay on ait_gemm_f32_ex with the raw weight).
 bool ait_gemm_p3b_takes(int M, int N, int K, const ait_launch_ctx* ctx);

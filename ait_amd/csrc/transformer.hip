@@ -89,9 +89,10 @@ inline int dgrad(const float* dy, int M, int N_out, const float* w, int K_in, co
 // K-splits of a weight gradient [M_out, N_out] = sum over K tokens: multiples of 8 (each XCD owns whole
 // K-ranges), chosen so that tiles x splits fills the resident workgroup slots of the 256x128 kernel in
 // whole rounds with at least 256 tokens per split (the heuristic ait_amd/system.py used in round 1).
-inline int wgrad_splits(int M_out, int N_out, long long K) {
+inline int wgrad_splits(int M_out, int N_out, long long K, bool coop) {
   long long tiles, slots;
-  if (M_out >= 512) { tiles = (long long)((M_out + 255) / 256) * ((N_out + 127) / 128); slots = 512; }
+  if (coop) { tiles = (long long)((M_out + 255) / 256) * ((N_out + 255) / 256); slots = 256; }      // the 256 x 256 tile, one per CU
+  else if (M_out >= 512) { tiles = (long long)((M_out + 255) / 256) * ((N_out + 127) / 128); slots = 512; }
   else { tiles = (long long)((M_out + 127) / 128) * ((N_out + 127) / 128); slots = 1024; }
   int best = 8;
   double best_eff = -1.0;
@@ -106,7 +107,8 @@ inline int wgrad_splits(int M_out, int N_out, long long K) {
 // dW [N_out, K_in] += dy [M, N_out]^T . x [M, K_in]   (split-K, fp32 atomics: accumulates)
 inline int wgrad(const float* dy, long long M, int N_out, const float* x, int K_in, float* dw, const Run& s) {
   if (!dw) return AIT_OK;
-  const int sp = M >= 512 ? wgrad_splits(N_out, K_in, M) : 1;
+  const bool coop = M >= 512 && ait_gemm_coop_takes(1, 0, N_out, K_in, (int)M, AIT_GEMM_ATOMIC, s.ctx);
+  const int sp = M >= 512 ? wgrad_splits(N_out, K_in, M, coop) : 1;
   return ait_gemm_f32(1, 0, N_out, K_in, (int)M, 1.f, dy, N_out, x, K_in, dw, K_in, nullptr, nullptr, AIT_GEMM_ATOMIC,
                       sp, 0, 0, s.ctx, s.stream);
 }

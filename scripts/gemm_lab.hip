@@ -45,7 +45,7 @@ using V_rne = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_RNE>;  
 using V_bf16 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BF16>;      // operands rounded to bf16, one MFMA per block
 using V_bp3 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3>;    // B pre-split (P3), 8 waves of 64x128, one workgroup per CU
 using V_bp3r = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3 | KNOB_RNE>;
-using V_bp3p = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3 | KNOB_PRIO>;
+using V_bp3p = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_COOP | KNOB_NOTICKET | KNOB_RNE>;     // every value split once per workgroup (LDS plane image)
 using V_bp3n4 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_BP3 | KNOB_NOTICKET>;
 using V_bp3n4p = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_BP3 | KNOB_NOTICKET | KNOB_PRIO>;
 using V_stag = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD | KNOB_STAGGER>;   // the product tile, odd threadgroup slots start half a tile late
@@ -180,7 +180,7 @@ static int run_tile(const GemmArgs& g, bool ak, bool bk, int slots) {
   return run_epi<T, false, true, NoProbe>(g, slots);
 }
 static const char* VNAMES[] = {"old", "new", "probe", "burst", "prio", "ring4", "ring4+burst", "4waves", "4waves+burst",
-                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "split rne", "bp3 256sq", "bp3 rne", "bf16 x1", "bp3 prio", "bp3 ring4", "bp3 ring4 prio"};
+                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "split rne", "bp3 256sq", "bp3 rne", "bf16 x1", "coop 256sq", "bp3 ring4", "bp3 ring4 prio"};
 template <class Probe>
 static int run_new(const GemmArgs& g, bool ak, bool bk, int slots) {
   if (!ak && !bk) return run_epi<NewD4, false, false, Probe>(g, slots);
@@ -212,6 +212,12 @@ static int run(Problem& p, int variant, float* out) {
   }
   if (variant == 2) {
     g.probe = p.probe;
+    if (getenv("LAB_PROBE_COOP")) {           // the stamp probe on the cooperative-split tile
+      if (!ak && !bk) return run_epi<V_bp3p, false, false, StampProbe>(g, g_slots);
+      if (ak && bk) return run_epi<V_bp3p, true, true, StampProbe>(g, g_slots);
+      if (ak && !bk) return run_epi<V_bp3p, true, false, StampProbe>(g, g_slots);
+      return run_epi<V_bp3p, false, true, StampProbe>(g, g_slots);
+    }
     if (getenv("LAB_PROBE_BP3") && p.Bp3) {    // the stamp probe on the pre-split-B tile
       g.B = reinterpret_cast<const float*>(p.Bp3);
       g.ldb = p.s.K / 2 * 3;
@@ -250,12 +256,13 @@ static int run(Problem& p, int variant, float* out) {
     case 18: return run_tile<V_splitsq>(g, ak, bk, g_slots);
     case 19: return run_tile<V_rne>(g, ak, bk, g_slots);
     case 22: return run_tile<V_bf16>(g, ak, bk, g_slots);
-    case 20: case 21: case 23: case 24: case 25: {
+    case 23: return run_tile<V_bp3p>(g, ak, bk, g_slots);
+    case 20: case 21: case 24: case 25: {
       if (!p.Bp3 || (p.s.flags & (LAB_ALIAS_A | LAB_ALIAS_B))) return -99;
       g.B = reinterpret_cast<const float*>(p.Bp3);
       g.ldb = p.s.K / 2 * 3;
       if (variant == 21) return run_epi<V_bp3r, true, true, NoProbe>(g, g_slots);
-      if (variant == 23) return run_epi<V_bp3p, true, true, NoProbe>(g, g_slots);
+      if (variant == 23) return -99;
       if (variant == 24) return run_epi<V_bp3n4, true, true, NoProbe>(g, g_slots);
       if (variant == 25) return run_epi<V_bp3n4p, true, true, NoProbe>(g, g_slots);
       return run_epi<V_bp3, true, true, NoProbe>(g, g_slots);

@@ -2,6 +2,7 @@
 // (a translation unit of its own: the instantiations compile beside those of gemm_f32.hip).
 #include "gemm_f32_impl.h"
 #include "gemm_internal.h"
+#include <type_traits>
 
 namespace {
 using namespace ait_gemm;
@@ -22,6 +23,9 @@ using Tile128D = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_RNE>
 // a 256-row tile would multiply three quarters of padding there
 using TileS = Cfg<64, 128, 16, 1, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_RNE>;
 // the same three tiles with the operands rounded to bf16 and one MFMA per block (AIT_CTX_BF16)
+// 256 x 256, every operand value split once per workgroup (gemm_f32.hip TileCoop): long reductions (3x3 windows, 2048-channel
+// 1x1) -- +8..12 % there, a loss on the 512-deep ones (profiles/r04_gemm_lab_coop.txt)
+using TileCoop = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_COOP | KNOB_NOTICKET | KNOB_RNE>;
 struct SplitFam { using T256 = Tile256D; using T128 = Tile128D; using TS = TileS; };
 struct Bf16Fam {
   using T256 = Tile256B;
@@ -103,6 +107,12 @@ int conv_dispatch_f(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
     if ((g.residual || (g.flags & ~AIT_GEMM_RELU)) && !(CONV == CONV_A && !BKC)) return AIT_EUNSUPPORTED;
     if (g.M <= 128) return conv_launch<typename F::TS, CONV, AK, BKC, true>(g, s, ws);
     return conv_launch<typename F::T256, CONV, AK, BKC, true>(g, s, ws);
+  }
+  if constexpr (std::is_same<F, SplitFam>::value && CONV == CONV_A) {      // (the gathered weight-gradient layout measured slower on it)
+    const long long tiles_sq = (long long)((g.M + 255) / 256) * ((g.N + 255) / 256) * g.splits;
+    if (g.K >= 2048 && g.M >= 256 && g.N >= 256 && (g.M % 4) == 0 && (g.N % 4) == 0 && tiles_sq >= 96 &&
+        ((g.flags & AIT_GEMM_ATOMIC) || ws.p != nullptr))
+      return conv_launch<TileCoop, CONV, AK, BKC>(g, s, ws);
   }
   const long long tiles256 = (long long)((g.M + 255) / 256) * ((g.N + 127) / 128) * g.splits;
   if (tiles256 >= 512 || (tiles256 >= 96 && g.K >= 512 && g.splits == 1 && !(g.flags & AIT_GEMM_ATOMIC) && ws.p != nullptr))

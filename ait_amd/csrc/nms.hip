@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(
       // waves 1..7: the previous block's survivors -> removed[w] for w >= rb + 1 (its word for block
       // rb itself was the critical column wave 0 handled one iteration ago).  Thread = (row group g
       // of 7, word lane): a word lane walks the column words (coalesced 512-B row segments per wave),
-      // a row group takes every 7th surviving row, four per step with independent loads in flight.
+      // a row group takes every 7th surviving row, ten per step with independent loads in flight.
       const int prev = cur ^ 1;
       const int kc = __popcll(kept_bits[prev]);
       const int t = tid - kTile, g = t >> 6, wl = t & 63;
@@ -169,13 +169,14 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(
       const unsigned long long* __restrict__ mrow = mask + (size_t)(base - kTile) * nb;
       for (int w = rb + 1 + wl; w < nb; w += kTile) {
         unsigned long long acc = 0ull;
-        for (int j = g; j < kc; j += 4 * G) {
-          const int r0 = kept_rows[prev][j];
-          const int r1 = kept_rows[prev][min(j + G, kc - 1)], r2 = kept_rows[prev][min(j + 2 * G, kc - 1)],
-                    r3 = kept_rows[prev][min(j + 3 * G, kc - 1)];   // clamped duplicates OR harmlessly
-          const unsigned long long a0 = mrow[(size_t)r0 * nb + w], a1 = mrow[(size_t)r1 * nb + w],
-                                   a2 = mrow[(size_t)r2 * nb + w], a3 = mrow[(size_t)r3 * nb + w];
-          acc |= a0 | a1 | a2 | a3;
+        // (ten loads in flight per thread: 70 rows per pass, so a block's <= 64 survivors take ONE memory round trip --
+        // this phase, not wave 0's chain, is what a block costs: 441 -> see profiles/r04_categories.txt)
+        for (int j = g; j < kc; j += 10 * G) {
+          unsigned long long a[10];
+#pragma unroll
+          for (int u = 0; u < 10; u++) a[u] = mrow[(size_t)kept_rows[prev][min(j + u * G, kc - 1)] * nb + w];   // clamped duplicates OR harmlessly
+#pragma unroll
+          for (int u = 0; u < 10; u++) acc |= a[u];
         }
         if (acc) atomicOr(&removed[w], acc);
       }

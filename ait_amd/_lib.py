@@ -74,6 +74,7 @@ SIGNATURES = {
     "ait_transformer_workspace_bytes": (_sz, [_i, _i, _i]),
     "ait_transformer_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ait_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp, _vp, _vp]),
+    "ait_ln_fwd_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp, _vp, _vp]),
     "ait_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _i, _i, _f, _ull, _vp, _vp,
                         _vp, _vp, _vp, _vp]),
     "ait_colsum_f32": (_i, [_vp, _ll, _i, _ll, _vp, _vp]),

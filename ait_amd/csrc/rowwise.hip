@@ -36,6 +36,8 @@ __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned lo
 struct RowMap {
   int seq_len, src_rows, rep;
   int dy_rows;     // backward only: rows per sequence that `dy` holds (compacted gradient); == seq_len: all
+  int out_rows;    // forward only: rows per sequence that `y` holds (row (q, t) at y[q * out_rows + t], t >= out_rows
+                   // not written); == seq_len: all
 };
 // out row r=(q,t) -> source row of `a`, or -1 for a zero (padding) row
 __device__ __forceinline__ long long src_row(const RowMap m, long long r) {
@@ -116,7 +118,13 @@ __global__ __launch_bounds__(kThreads) void ln_fwd_kernel(
     float o[kVec];
 #pragma unroll
     for (int i = 0; i < kVec; i++) o[i] = (z[i] - mu) * rs * g[i] + b[i];
-    store8(y + (size_t)r * kD + c0, o);
+    if (m.out_rows == m.seq_len) {
+      store8(y + (size_t)r * kD + c0, o);
+    } else {      // compacted output: only the first out_rows rows of a sequence are read again
+      const long long q = r / m.seq_len;
+      const int t = (int)(r - q * m.seq_len);
+      if (t < m.out_rows) store8(y + (size_t)(q * m.out_rows + t) * kD + c0, o);
+    }
     if (lane == 0) {
       if (mean) mean[r] = mu;
       if (rstd) rstd[r] = rs;
@@ -551,22 +559,31 @@ inline unsigned ln_grid(long long rows) {
 
 }  // namespace
 
+AIT_API int ait_ln_fwd_rows(const float* a, const float* pos, const float* residual,
+                            const float* gamma, const float* beta, long long rows, int d, int seq_len,
+                            int src_rows_per_seq, int rep, int out_rows_per_seq, float eps, float p_drop,
+                            unsigned long long seed, float* y, float* mean, float* rstd,
+                            void* stream) {
+  if (rows < 0 || seq_len <= 0 || src_rows_per_seq <= 0 || src_rows_per_seq > seq_len ||
+      rep < 1 || p_drop < 0.f || p_drop >= 1.f || out_rows_per_seq <= 0 || out_rows_per_seq > seq_len)
+    return AIT_EINVAL;
+  if (d != kD) return AIT_EUNSUPPORTED;
+  if (rows == 0) return AIT_OK;
+  if (!a || !gamma || !beta || !y) return AIT_EINVAL;
+  RowMap m{seq_len, src_rows_per_seq, rep, seq_len, out_rows_per_seq};
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(rows)), dim3(kThreads), 0, ait_stream(stream), a,
+                     pos, residual, gamma, beta, rows, m, eps, p_drop, seed, y, mean, rstd);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
 AIT_API int ait_ln_fwd(const float* a, const float* pos, const float* residual,
                        const float* gamma, const float* beta, long long rows, int d, int seq_len,
                        int src_rows_per_seq, int rep, float eps, float p_drop,
                        unsigned long long seed, float* y, float* mean, float* rstd,
                        void* stream) {
-  if (rows < 0 || seq_len <= 0 || src_rows_per_seq <= 0 || src_rows_per_seq > seq_len ||
-      rep < 1 || p_drop < 0.f || p_drop >= 1.f)
-    return AIT_EINVAL;
-  if (d != kD) return AIT_EUNSUPPORTED;
-  if (rows == 0) return AIT_OK;
-  if (!a || !gamma || !beta || !y) return AIT_EINVAL;
-  RowMap m{seq_len, src_rows_per_seq, rep, seq_len};
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ln_grid(rows)), dim3(kThreads), 0, ait_stream(stream), a,
-                     pos, residual, gamma, beta, rows, m, eps, p_drop, seed, y, mean, rstd);
-  AIT_CHECK_LAUNCH();
-  return AIT_OK;
+  return ait_ln_fwd_rows(a, pos, residual, gamma, beta, rows, d, seq_len, src_rows_per_seq, rep, seq_len, eps, p_drop, seed, y,
+                         mean, rstd, stream);
 }
 
 AIT_API int ait_ln_bwd(const float* dy, const float* a, const float* pos, const float* residual,
@@ -581,7 +598,7 @@ AIT_API int ait_ln_bwd(const float* dy, const float* a, const float* pos, const 
   if (rows == 0) return AIT_OK;
   if (!dy || !a || !gamma || !mean || !rstd) return AIT_EINVAL;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return AIT_EINVAL;
-  RowMap m{seq_len, src_rows_per_seq, rep, dy_rows_per_seq};
+  RowMap m{seq_len, src_rows_per_seq, rep, dy_rows_per_seq, seq_len};
   // fewer, fatter blocks: each block issues 2*512 atomics for the affine gradients
   long long b = (rows + 63) / 64;
   unsigned grid = (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));

@@ -153,7 +153,7 @@ inline Qkv views(const MhaBuf& m, long long n, bool cross) {
 // both 0 in eval.  seed: the block's seed; its two sites derive theirs with ait_dropout_seed.
 int mha_block(const float* xq, const float* xkv, int n, int kv_rows, int mask_mode, int n_valid,
               const ait_mha_weights& w, const MhaBuf& m, float p_fc, float p_attn, unsigned long long seed,
-              float* y, const Run& s, const P3W& pq = P3W()) {
+              float* y, const Run& s, const P3W& pq = P3W(), int out_rows = T) {
   const int M = n * T;
   const bool cross = xkv != xq;
   if (!cross) {
@@ -167,8 +167,10 @@ int mha_block(const float* xq, const float* xkv, int n, int kv_rows, int mask_mo
                        p_attn, ait_dropout_seed(seed, 0), m.P, m.O, s.stream));
   AIT_TRY(ait_sh_fwd(m.O, w.sk_w, w.sk_b, n, H, T, DK, m.u, m.gate, m.s, s.stream));
   AIT_TRY(linear(m.u, M, DK, w.fc_w, D, nullptr, false, m.f, s));
-  return ait_ln_fwd(m.f, nullptr, xq, w.ln_g, w.ln_b, M, D, T, T, 1, kEps, p_fc, ait_dropout_seed(seed, 1), y, m.mean,
-                    m.rstd, s.stream);
+  // (out_rows < 64: only the first out_rows rows of every sequence are written, compacted -- the encoder, whose padded
+  // rows are never read again)
+  return ait_ln_fwd_rows(m.f, nullptr, xq, w.ln_g, w.ln_b, M, D, T, T, 1, out_rows, kEps, p_fc, ait_dropout_seed(seed, 1), y,
+                         m.mean, m.rstd, s.stream);
 }
 
 // scratch of the block's backward
@@ -522,7 +524,6 @@ enum { kSeedEncPro = 16, kSeedEncSlf, kSeedEncFfn, kSeedDecPro, kSeedDecSlf, kSe
 int ait_forward(const float* x_props, const float* x_query, int bp, int bs, int n_src, const ait_transformer_weights* w,
                 const AitBufs& a, float p, float p_attn, unsigned long long seed, float* out, const Run& run) {
   void* stream = run.stream;
-  hipStream_t hs = ait_stream(stream);
   const int M = bp * T, P = bp / bs;
   AIT_TRY(p3_convert(w, a, stream));     // this call's weights, pre-split (33 MB read, one launch)
   // embeddings (1x1 convolutions on token rows)
@@ -531,15 +532,10 @@ int ait_forward(const float* x_props, const float* x_query, int bp, int bs, int 
   // ---- encoder (Models.py:83-111): zero-pad n_src -> 64 rows inside the LayerNorm row map --------
   AIT_TRY(ait_ln_fwd(a.emb_p, w->pos_table, nullptr, w->enc_ln_g, w->enc_ln_b, M, D, T, n_src, 1, kEps, p,
                      ait_dropout_seed(seed, kSeedEncPro), a.x0, a.mean0, a.rstd0, stream));
+  // only the n_src real rows of each sequence are read again (dead padded rows are masked as keys everywhere
+  // downstream): the block's closing LayerNorm writes them compacted, straight into xc
   AIT_TRY(mha_block(a.x0, a.x0, bp, T, /*key padding*/ 1, n_src, w->enc_slf, a.enc_slf, p, p_attn,
-                    ait_dropout_seed(seed, kSeedEncSlf), a.y1, run, a.p_enc_qkv));
-  // only the n_src real rows of each sequence are read again: compact them (dead padded rows are
-  // masked as keys everywhere downstream)
-  if (n_src < T) {
-    if (hipMemcpy2DAsync(a.xc, (size_t)n_src * D * sizeof(float), a.y1, (size_t)T * D * sizeof(float),
-                         (size_t)n_src * D * sizeof(float), bp, hipMemcpyDeviceToDevice, hs) != hipSuccess)
-      return AIT_ELAUNCH;
-  }
+                    ait_dropout_seed(seed, kSeedEncSlf), a.xc, run, a.p_enc_qkv, n_src));
   AIT_TRY(ffn_block(a.xc, (long long)bp * n_src, w->enc_ffn, a.enc_ffn, p, ait_dropout_seed(seed, kSeedEncFfn), a.mem,
                     run, a.p_enc_w1, a.p_enc_w2));
   // ---- decoder (Models.py:143-172): the query sequence of a pair repeated over its P proposals ----

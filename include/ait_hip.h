@@ -420,6 +420,14 @@ int ait_ln_fwd(const float* a, const float* pos, const float* residual, const fl
                const float* beta, long long rows, int d, int seq_len, int src_rows_per_seq,
                int rep, float eps, float p_drop, unsigned long long seed, float* y, float* mean,
                float* rstd, void* stream);
+/* the same with a COMPACTED output: of every sequence only the first out_rows_per_seq rows are written, row (q, t)
+ * at y[q * out_rows_per_seq + t] -- the encoder's self-attention block, of whose 64 rows only the n_src real ones
+ * are read again (Models.py:269-270 pads, the masks of :258-260 ignore the padding ever after); statistics are
+ * saved for every row. */
+int ait_ln_fwd_rows(const float* a, const float* pos, const float* residual, const float* gamma,
+                    const float* beta, long long rows, int d, int seq_len, int src_rows_per_seq,
+                    int rep, int out_rows_per_seq, float eps, float p_drop, unsigned long long seed, float* y,
+                    float* mean, float* rstd, void* stream);
 int ait_ln_bwd(const float* dy, const float* a, const float* pos, const float* residual,
                const float* gamma, const float* mean, const float* rstd, long long rows, int d,
                int seq_len, int src_rows_per_seq, int rep, int dy_rows_per_seq, float p_drop,

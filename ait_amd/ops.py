@@ -29,9 +29,8 @@ def reset_fallbacks():
     FALLBACKS.clear()
 
 
-# "f32": exact fp32 products on v_mfma_f32_32x32x2_f32 (default, the parity / headline path).
-# "bf16": operands rounded to bf16 on the fly, v_mfma_f32_32x32x16_bf16 (BASELINE cfg 5 arithmetic).
-# "bf16x3": experimental split-bf16 emulation of fp32 products (3 bf16 MFMAs per product).
+# the product form of the dense contractions; see set_matmul_dtype for what each name means.  "f32" (the default, the
+# parity / headline path) is f32 in and out with the products formed on the bf16 pipe from an exact three-way split.
 MATMUL_DTYPE = "f32"
 
 
@@ -483,9 +482,11 @@ def conv_geom(n, in_hw, out_hw, k, stride, pad, groups=1):
 
 
 def conv_supported(in_hw, out_hw, stride, cin, cout):
-    """what ait_conv_*_f32 take (forward, data and weight gradient all together)"""
-    p2 = lambda v: v > 0 and (v & (v - 1)) == 0
-    return (p2(in_hw[1]) and p2(in_hw[0] * in_hw[1]) and p2(out_hw[1]) and p2(out_hw[0] * out_hw[1]) and p2(stride)
+    """what ait_conv_*_f32 take (forward, data and weight gradient all together): maps of any size (csrc/conv_f32.hip
+    decomposes a row index by shifts for power-of-two maps and by exactly corrected f32 quotients otherwise), stride 1
+    or 2, channel counts the 16-value slabs and the 128-channel groups divide.  (Maps whose sides are not powers of two:
+    ungrouped only and fewer than 2^24 output rows -- the library returns AIT_EUNSUPPORTED otherwise.)"""
+    return (min(in_hw) > 0 and min(out_hw) > 0 and stride in (1, 2)
             and cin % 128 == 0 and cout % 16 == 0 and max(cin, cout) + 144 <= 8192)
 
 

@@ -17,6 +17,17 @@ struct Jobs {
   int n;
 };
 
+// a P3 operand as a product sees it: planes of a [rows][ld values] matrix (6 bytes per value; gemm_p3.hip).  A null
+// Ref means "not pre-split" (the product splits the raw weight in registers).  sub(rows, vals): the view that starts
+// `rows` rows / `vals` reduction values further.
+struct Ref {
+  const unsigned short* p = nullptr;
+  long long ld = 0;
+  Ref sub(long long rows, long long vals) const { return p ? Ref{p + (rows * ld + vals) * 3, ld} : Ref{}; }
+};
+// the two conversions of one weight W [N_out][K_in]: P3 of W (forward), P3 of W^T (input gradient; training only)
+struct Pair { Ref w, wt; };
+
 // enqueue the conversion of jobs.n matrices, one launch (csrc/gemm_p3.hip)
 int split(Jobs& jobs, hipStream_t s);
 

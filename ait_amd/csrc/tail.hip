@@ -26,6 +26,7 @@
 // K-splits are equal (their last round is then cut evenly over the workgroups without scratch).
 #include "common.h"
 #include "gemm_internal.h"
+#include "p3_jobs.h"
 
 namespace {
 
@@ -136,6 +137,34 @@ inline int make_dims(int bp, int bs, int C, int planes, int n_blocks, Dims& d) {
 }
 // folded weights of layer4, in launch order
 struct BlockW { float *w1, *w2, *w3, *wd; };
+// the folded 1x1 weights once more in the pre-split operand format (csrc/p3_jobs.h): planes of W' for the forward
+// product, of W'^T for the data gradient -- the 256 x 256 tile of gemm_p3.hip takes them
+struct BlockP3 { ait_p3::Pair w1, w3, wd; };
+inline size_t p3_floats(const Dims& d) {
+  size_t v = 0;
+  for (int k = 0; k < d.n_blocks; k++) {
+    const size_t cin = k == 0 ? d.C : d.E;
+    v += (size_t)d.P * cin + (size_t)d.E * d.P + (k == 0 ? (size_t)d.E * cin : 0);
+  }
+  return 2 * (v * 3 / 2) + 16 * 64;
+}
+inline bool carve_p3(Bump& b, const Dims& d, BlockP3 (&p)[kMaxBlocks]) {
+  bool ok = true;
+  auto one = [&](ait_p3::Pair& w, size_t n_out, size_t k_in) {
+    float* f = b.take(n_out * k_in * 3 / 2);
+    float* t = b.take(n_out * k_in * 3 / 2);
+    ok = ok && f && t;
+    w.w = ait_p3::Ref{reinterpret_cast<const unsigned short*>(f), (long long)k_in};
+    w.wt = ait_p3::Ref{reinterpret_cast<const unsigned short*>(t), (long long)n_out};
+  };
+  for (int k = 0; k < d.n_blocks; k++) {
+    const size_t cin = k == 0 ? d.C : d.E;
+    one(p[k].w1, d.P, cin);
+    one(p[k].w3, d.E, d.P);
+    if (k == 0) one(p[k].wd, d.E, cin);
+  }
+  return ok;
+}
 inline size_t folded_floats(const Dims& d) {
   size_t f = 0;
   for (int k = 0; k < d.n_blocks; k++) {
@@ -163,11 +192,12 @@ struct Saved {
   float *xtop;                        // [R, C] layer4 input (SK outputs, padded)
   float *a1[kMaxBlocks], *a2[kMaxBlocks], *o[kMaxBlocks];
   BlockW wf[kMaxBlocks];
+  BlockP3 p3[kMaxBlocks];
 };
 constexpr size_t kZeros = 8192;
 inline size_t saved_floats(const Dims& d) {
   const size_t R = (size_t)d.R, slack = 64 * 64;
-  return kZeros + 2 * (size_t)(d.Rp + d.Rq) * d.C + R * d.C + (size_t)d.n_blocks * (2 * R * d.P + R * d.E) + folded_floats(d) + slack;
+  return kZeros + 2 * (size_t)(d.Rp + d.Rq) * d.C + R * d.C + (size_t)d.n_blocks * (2 * R * d.P + R * d.E) + folded_floats(d) + p3_floats(d) + slack;
 }
 inline bool carve(Bump& b, const Dims& d, Saved& s) {
   s.zeros = b.take(kZeros);
@@ -179,7 +209,7 @@ inline bool carve(Bump& b, const Dims& d, Saved& s) {
     s.a1[k] = b.take((size_t)d.R * d.P); s.a2[k] = b.take((size_t)d.R * d.P); s.o[k] = b.take((size_t)d.R * d.E);
     ok = ok && s.a1[k] && s.a2[k] && s.o[k];
   }
-  return ok && carve_folded(b, d, s.wf);
+  return ok && carve_folded(b, d, s.wf) && carve_p3(b, d, s.p3);
 }
 
 inline ait_conv_geom sk_geom(int n, int k) { return ait_conv_geom{n, 8, 8, 4, 4, k, k, 2, k / 2, 8}; }
@@ -187,13 +217,21 @@ inline ait_conv_geom l4_geom(int n) { return ait_conv_geom{n, 4, 4, 4, 4, 3, 3, 
 
 // y = relu?(x W^T + bias (+ residual))
 inline int linear(const float* x, long long M, int K, const float* w, int N, const float* bias, const float* residual,
-                  bool relu, float* y, const Run& r) {
+                  bool relu, float* y, const Run& r, const ait_p3::Ref& p3 = ait_p3::Ref()) {
+  if (p3.p && ait_gemm_p3b_takes((int)M, N, K, r.ctx))
+    return ait_gemm_f32_p3b((int)M, N, K, 1.f, x, K, p3.p, p3.ld, y, N, bias, residual, nullptr, relu ? AIT_GEMM_RELU : 0, 0, 0,
+                            r.ctx, r.stream);
   return ait_gemm_f32_ex(0, 1, (int)M, N, K, 1.f, x, K, w, K, y, N, bias, residual, nullptr, relu ? AIT_GEMM_RELU : 0, 1, 0, 0,
                          r.ctx, r.stream);
 }
 // dx = dy W  (+ residual) (gated by mask > 0: MASK_POS when there is no residual, the gate operand when there is)
 inline int dgrad(const float* dy, long long M, int N_out, const float* w, int K_in, const float* residual,
-                 const float* mask, float* dx, const Run& r) {
+                 const float* mask, float* dx, const Run& r, const ait_p3::Ref& p3t = ait_p3::Ref()) {
+  if (p3t.p && ait_gemm_p3b_takes((int)M, K_in, N_out, r.ctx)) {      // B = planes of W'^T: rows K_in, reduction over N_out
+    const bool both = residual && mask;
+    return ait_gemm_f32_p3b((int)M, K_in, N_out, 1.f, dy, N_out, p3t.p, p3t.ld, dx, K_in, nullptr, both ? residual : (mask ? mask : residual),
+                            both ? mask : nullptr, (!both && mask) ? AIT_GEMM_MASK_POS : 0, 0, 0, r.ctx, r.stream);
+  }
   if (residual && mask)
     return ait_gemm_f32_ex(0, 0, (int)M, K_in, N_out, 1.f, dy, N_out, w, K_in, dx, K_in, nullptr, residual, mask, 0, 1, 0, 0,
                            r.ctx, r.stream);
@@ -269,6 +307,20 @@ AIT_API int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int
     }
     sb.add = 0;
     AIT_TRY(scale_rows(sb, hs));
+    // ... and the folded 1x1 weights once more as bf16 planes, both orientations (one launch)
+    ait_p3::Jobs jobs;
+    jobs.n = 0;
+    auto add = [&](const ait_p3::Pair& pw, const float* src, int n_out, int k_in) {
+      jobs.j[jobs.n++] = ait_p3::Job{src, const_cast<unsigned short*>(pw.w.p), n_out, k_in, k_in, 0, 0};
+      jobs.j[jobs.n++] = ait_p3::Job{src, const_cast<unsigned short*>(pw.wt.p), n_out, k_in, k_in, 1, 0};
+    };
+    for (int k = 0; k < d.n_blocks; k++) {
+      const int cin = k == 0 ? C : E;
+      add(s.p3[k].w1, s.wf[k].w1, P, cin);
+      add(s.p3[k].w3, s.wf[k].w3, E, P);
+      if (k == 0) add(s.p3[k].wd, s.wf[k].wd, E, cin);
+    }
+    AIT_TRY(ait_p3::split(jobs, hs));
   }
   // ---- the two SK blocks write their halves of layer4's input; the padding rows are zero
   AIT_TRY(sk_forward(x_props, bp, d, w->sk_props, s.f1p, s.f3p, s.xtop, s.zeros, run));
@@ -282,7 +334,7 @@ AIT_API int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int
   for (int k = 0; k < d.n_blocks; k++) {
     const ait_bottleneck_weights& bw = w->block[k];
     const int cin = k == 0 ? C : E;
-    AIT_TRY(linear(xin, d.R, cin, s.wf[k].w1, P, bw.bn1_shift, nullptr, true, s.a1[k], run));
+    AIT_TRY(linear(xin, d.R, cin, s.wf[k].w1, P, bw.bn1_shift, nullptr, true, s.a1[k], run, s.p3[k].w1.w));
     AIT_TRY(ait_conv_fwd_f32(s.a1[k], P, s.wf[k].w2, &g3, P, P, bw.bn2_shift, nullptr, AIT_GEMM_RELU, s.a2[k], P, s.zeros, kZeros,
                              ctx, stream));
     const float* idn = xin;
@@ -291,10 +343,10 @@ AIT_API int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int
       // staging of a one-block tail's own output buffer is impossible -> a2 of block 0 is still needed: use o[k] twice
       float* park = d.n_blocks > 1 ? s.o[1] : nullptr;
       if (!park) return AIT_EUNSUPPORTED;
-      AIT_TRY(linear(xin, d.R, cin, s.wf[k].wd, E, bw.bnd_shift, nullptr, false, park, run));
+      AIT_TRY(linear(xin, d.R, cin, s.wf[k].wd, E, bw.bnd_shift, nullptr, false, park, run, s.p3[k].wd.w));
       idn = park;
     }
-    AIT_TRY(linear(s.a2[k], d.R, P, s.wf[k].w3, E, bw.bn3_shift, idn, true, s.o[k], run));
+    AIT_TRY(linear(s.a2[k], d.R, P, s.wf[k].w3, E, bw.bn3_shift, idn, true, s.o[k], run, s.p3[k].w3.w));
     xin = s.o[k];
   }
   {
@@ -357,18 +409,18 @@ AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const floa
     const int cin = k == 0 ? C : E;
     const float* xin = k == 0 ? s.xtop : s.o[k - 1];
     AIT_TRY(wgrad(gout, d.R, E, s.a2[k], P, dwf[k].w3, run));                                     // d W3' += g^T a2
-    AIT_TRY(dgrad(gout, d.R, E, s.wf[k].w3, P, nullptr, s.a2[k], g2, run));                       // g2 = (g W3') [a2 > 0]
+    AIT_TRY(dgrad(gout, d.R, E, s.wf[k].w3, P, nullptr, s.a2[k], g2, run, s.p3[k].w3.wt));                      // g2 = (g W3') [a2 > 0]
     AIT_TRY(ait_conv_bwd_weight_f32(g2, P, s.a1[k], P, &g3, P, P, dwf[k].w2, 8, s.zeros, kZeros, ctx, stream));
     AIT_TRY(ait_conv_bwd_data_f32(g2, P, s.wf[k].w2, &g3, P, P, s.a1[k], AIT_GEMM_MASK_POS, g1, P, s.zeros, kZeros, ctx, stream));
     AIT_TRY(wgrad(g1, d.R, P, xin, cin, dwf[k].w1, run));                                         // d W1' += g1^T x_in
     if (k > 0) {
       // gradient at the previous block's output: conv1's data gradient + the identity shortcut's, behind that block's ReLU
-      AIT_TRY(dgrad(g1, d.R, P, s.wf[k].w1, cin, gout, xin, gnext, run));
+      AIT_TRY(dgrad(g1, d.R, P, s.wf[k].w1, cin, gout, xin, gnext, run, s.p3[k].w1.wt));
       float* t = gout; gout = gnext; gnext = t;
     } else {
       AIT_TRY(wgrad(gout, d.R, E, xin, cin, dwf[k].wd, run));                                     // projection shortcut
-      AIT_TRY(dgrad(gout, d.R, E, s.wf[k].wd, cin, nullptr, nullptr, dxt, run));
-      AIT_TRY(dgrad(g1, d.R, P, s.wf[k].w1, cin, dxt, nullptr, dxt, run));                        // (+=, in place)
+      AIT_TRY(dgrad(gout, d.R, E, s.wf[k].wd, cin, nullptr, nullptr, dxt, run, s.p3[k].wd.wt));
+      AIT_TRY(dgrad(g1, d.R, P, s.wf[k].w1, cin, dxt, nullptr, dxt, run, s.p3[k].w1.wt));                      // (+=, in place)
     }
   }
   // weight gradients: from the folded weights back to the parameters (d W = diag(scale) d W'), ACCUMULATED

@@ -56,16 +56,9 @@ struct Run {
   const ait_launch_ctx* ctx;
 };
 
-// A weight in its pre-split form (csrc/p3_impl.h): P3 rows starting at p, `ld` values per row (p == NULL: none -- the
-// product splits the raw weight in registers).  sub(rows, vals): the view that starts `rows` rows / `vals` reduction
-// values further.
-struct P3Ref {
-  const unsigned short* p = nullptr;
-  long long ld = 0;
-  P3Ref sub(long long rows, long long vals) const { return p ? P3Ref{p + (rows * ld + vals) * 3, ld} : P3Ref{}; }
-};
-// the two conversions of one weight W [N_out][K_in]: P3 of W (forward), P3 of W^T (input gradient; training only)
-struct P3W { P3Ref w, wt; };
+// a weight in its pre-split form, and the forward / transposed pair of one weight (csrc/p3_jobs.h)
+using P3Ref = ait_p3::Ref;
+using P3W = ait_p3::Pair;
 
 // y = x W^T (+ b) (+ relu) on the matrix cores
 inline int linear(const float* x, int M, int K, const float* w, int N, const float* b, bool relu, float* y,

@@ -216,6 +216,8 @@ def main():
     ap.add_argument("--proposals", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ab", action="store_true", help="skip the f32_native A/B steps behind the timed region")
+    ap.add_argument("--gemm-table", default=None, metavar="PATH",
+                    help="also write the timed region's GEMM launches grouped by shape (launches/step, ms/step, TFLOP/s)")
     ap.add_argument("--dtype", choices=["f32", "f32_native", "bf16", "bf16x3"], default=None,
                     help="matmul arithmetic of the AIT GEMMs.  f32 is the headline / parity "
                          "configuration; bf16 is the BASELINE cfg-5 arithmetic (operands rounded to bf16, "
@@ -314,6 +316,17 @@ def main():
                 if e[0] in (_lib.PROBE_ROI_FWD, _lib.PROBE_ROI_BWD)]
     flops = sum(p[0] for p in prof)
     gemm_ms = sum(p[1] for p in prof)
+    if args.gemm_table:
+        by = {}
+        for f, ms, dims in prof:
+            a = by.setdefault(tuple(dims), [0, 0.0, 0.0])
+            a[0] += 1; a[1] += ms; a[2] += f
+        with open(args.gemm_table, "w") as fh:
+            fh.write("# GEMM launches of the timed region by shape (M, N, K, trans_a, trans_b, splits); convolutions as their implicit GEMM\n")
+            fh.write("# %8s %6s %7s ta tb spl | launches/step   ms/step   TFLOP/s\n" % ("M", "N", "K"))
+            for dims, (n, ms, f) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                fh.write("%10d %6d %7d %2d %2d %3d | %13.1f %9.3f %9.1f\n" % (dims + (n / args.steps, ms / args.steps, f / (ms * 1e-3) / 1e12)))
+            fh.write("# total %.3f ms/step, %.1f TFLOP/s\n" % (gemm_ms / args.steps, flops / (gemm_ms * 1e-3) / 1e12))
     achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     pairs = world * args.bs * args.steps
     # dense MFMA peak for the arithmetic: fp32, bf16, or bf16 / 3 MFMAs per product

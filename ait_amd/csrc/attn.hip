@@ -35,8 +35,8 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const AttnArgs g,
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       float m = half_max(fmaxf(acc[a][0][r], acc[a][1][r]));
-      float e0 = expf(acc[a][0][r] - m), e1 = expf(acc[a][1][r] - m);
-      float inv = 1.f / half_sum(e0 + e1);
+      float e0 = exp_neg(acc[a][0][r] - m), e1 = exp_neg(acc[a][1][r] - m);
+      float inv = __builtin_amdgcn_rcpf(half_sum(e0 + e1));      // (1 ulp; a full-precision divide is ten instructions)
       acc[a][0][r] = e0 * inv;
       acc[a][1][r] = e1 * inv;
     }

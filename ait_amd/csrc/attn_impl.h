@@ -221,16 +221,46 @@ __device__ __forceinline__ int acc_row(int a, int r, int lane) {
 }
 __device__ __forceinline__ int acc_col(int b, int lane) { return b * 32 + (lane & 31); }
 
-// reductions across the 32 lanes that hold one accumulator row (same lane>>5)
+// reductions across the 32 lanes that hold one accumulator row (same lane>>5), result in every lane -- on the vector
+// pipe only: four DPP steps inside a row of 16 lanes (quad_perm 1032 / 2301, then row_half_mirror / row_mirror, which
+// pair equal-valued groups exactly as xor 4 / xor 8 would), and gfx950's v_permlane16_swap_b32 for the step between the
+// two rows.  (__shfl_xor compiles to ds_bpermute_b32: an LDS-pipe round trip per step -- the 320 of them in the softmax
+// were 45 % of the attention tile's time.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// v of lane ^ 16 beside the lane's own: a = b = v, then rows 1 / 3 of a swap with rows 0 / 2 of b
+__device__ __forceinline__ void swap16(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);     // row_half_mirror
+  v += dpp_f<0x140>(v);     // row_mirror
+  float w = v;
+  swap16(v, w);
+  return v + w;
 }
 __device__ __forceinline__ float half_max(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  float w = v;
+  swap16(v, w);
+  return fmaxf(v, w);
+}
+
+// e^x for x <= 0 (softmax arguments) in six vector instructions: v_exp_f32 of x log2(e), the product carried in two
+// floats (t + lo) so that the result is as close as expf's (|rel| < 2e-7) -- libm's expf is ~20 instructions of range
+// and denormal handling the softmax does not need (masked scores, -1e9, underflow to exactly 0 either way).
+__device__ __forceinline__ float exp_neg(float x) {
+  const float t = x * 1.44269504f;
+  const float lo = fmaf(x, 1.44269504f, -t) + x * 1.92596303e-8f;      // rounding of the product + log2(e) - float(log2(e))
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, lo * 0.693147182f, e);
 }
 
 template <typename F>

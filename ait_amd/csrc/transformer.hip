@@ -156,14 +156,16 @@ int mha_block(const float* xq, const float* xkv, int n, int kv_rows, int mask_mo
     AIT_TRY(linear(xkv, n * kv_rows, D, w.w_qkv + (size_t)D * D, 2 * D, nullptr, false, m.qkv + (size_t)M * D, s, pq.w.sub(D, 0)));
   }
   const Qkv v = views(m, n, cross);
-  AIT_TRY(ait_attn_fwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, n, H, T, DK, kv_rows, mask_mode, n_valid, 0.125f,
-                       p_attn, ait_dropout_seed(seed, 0), m.P, m.O, s.stream));
-  AIT_TRY(ait_sh_fwd(m.O, w.sk_w, w.sk_b, n, H, T, DK, m.u, m.gate, m.s, s.stream));
-  AIT_TRY(linear(m.u, M, DK, w.fc_w, D, nullptr, false, m.f, s));
+  // attention tiles, selective heads, fc, dropout, residual and the closing LayerNorm: one kernel, all eight heads of a
+  // sequence resident (csrc/mha_fused.hip).  Training saves what the backward reads; inference writes nothing but y.
   // (out_rows < 64: only the first out_rows rows of every sequence are written, compacted -- the encoder, whose padded
   // rows are never read again)
-  return ait_ln_fwd_rows(m.f, nullptr, xq, w.ln_g, w.ln_b, M, D, T, T, 1, out_rows, kEps, p_fc, ait_dropout_seed(seed, 1), y,
-                         m.mean, m.rstd, s.stream);
+  const bool train = m.mean != nullptr;
+  return ait_mha_core_fwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, n, kv_rows, mask_mode, n_valid, 0.125f, p_attn,
+                          ait_dropout_seed(seed, 0), w.sk_w, w.sk_b, w.fc_w, xq, w.ln_g, w.ln_b, kEps, p_fc,
+                          ait_dropout_seed(seed, 1), out_rows, train ? m.P : nullptr, train ? m.O : nullptr,
+                          train ? m.u : nullptr, train ? m.gate : nullptr, train ? m.s : nullptr, train ? m.f : nullptr, y,
+                          m.mean, m.rstd, s.stream);
 }
 
 // scratch of the block's backward

@@ -386,6 +386,26 @@ def attn_fwd(q, qoff, k, koff, v, voff, n_seq, H, T, d, mask_mode, n_valid, scal
     return O, P
 
 
+def mha_core_fwd(q, qoff, k, koff, v, voff, n_seq, mask_mode, n_valid, p_attn, seed_attn, sk_w, sk_b, fc_w, residual,
+                 ln_g, ln_b, eps, p_fc, seed_fc, kv_rows=64, out_rows=64, save=True):
+    """ait_mha_core_fwd: attention tiles + selective heads + fc + dropout + residual + LayerNorm of one
+    MultiHeadAttention block in one launch.  Returns y and, with save=True, the dict of tensors the backward reads."""
+    dev = q.device
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    y = e(n_seq * out_rows, D_MODEL)
+    sv = dict(P=e(n_seq, 8, 64, 64), O=e(n_seq, 8, 64, 64), u=e(n_seq * 64, 64), gate=e(n_seq, D_MODEL), s=e(n_seq, 64),
+              f=e(n_seq * 64, D_MODEL), mean=e(n_seq * 64), rstd=e(n_seq * 64)) if save else {}
+    g = lambda name: _p(sv.get(name))
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ait_mha_core_fwd(_col(q, qoff), q.stride(0), _col(k, koff), k.stride(0), _col(v, voff), v.stride(0),
+                                         n_seq, int(kv_rows), mask_mode, n_valid, 0.125, float(p_attn), int(seed_attn),
+                                         _p(sk_w), _p(sk_b), _p(fc_w), _p(residual), _p(ln_g), _p(ln_b), float(eps),
+                                         float(p_fc), int(seed_fc), int(out_rows), g("P"), g("O"), g("u"), g("gate"), g("s"),
+                                         g("f"), _p(y), g("mean"), g("rstd"), _lib.cur_stream(dev))
+    _lib.check(rc, "ait_mha_core_fwd")
+    return y, sv
+
+
 def attn_bwd(q, qoff, k, koff, v, voff, P, dO, n_seq, H, T, d, scale, p, seed, dq, dqoff, dk,
              dkoff, dv, dvoff, kv_rows=None):
     dev = q.device

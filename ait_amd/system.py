@@ -37,6 +37,7 @@ SEQ = 64          # tokens per sequence on the AIT path (8x8 query cells)
 _PY_COMPOSE = False
 _COMPACT_MEMORY = True
 _COATT_TORCH = False
+_FUSED_BLOCK = True         # test hook: False = the attention block op by op (four launches) in the fine-grained composition
 
 
 def _rank_salt():
@@ -259,6 +260,49 @@ class _SelectiveHeads(torch.autograd.Function):
         dw = ops.gemm(dg, s, trans_a=True, trans_b=False,
                       split_k=8 if dg.shape[0] >= 512 else 1)       # [H*dv, dv] = dg^T s
         return dO, dw, ops.colsum(dg)
+
+
+class _MhaCore(torch.autograd.Function):
+    """Everything of MultiHeadAttention.forward behind the projections in ONE launch (ops.mha_core_fwd, csrc/mha_fused.hip):
+    attention tiles, selective heads, fc, dropout, residual, LayerNorm.  qt: the fused projections [M, 1536] (self-attention)
+    or the query projection [M, 512] with kvt [n*kv_rows, 1024] (cross-attention).  The backward is the four op-by-op
+    backward kernels on what the forward saved."""
+
+    @staticmethod
+    def forward(ctx, qt, kvt, n_seq, mode, n_valid, p_attn, seed_a, sk_w, sk_b, fc_w, residual, ln_g, ln_b, p_fc, seed_f):
+        hd = 512
+        if kvt is None:
+            q, qo, k, ko, v, vo, kv_rows = qt, 0, qt, hd, qt, 2 * hd, SEQ
+        else:
+            q, qo, k, ko, v, vo, kv_rows = qt, 0, kvt, 0, kvt, hd, kvt.shape[0] // n_seq
+        y, sv = ops.mha_core_fwd(q, qo, k, ko, v, vo, n_seq, mode, n_valid, p_attn, seed_a, sk_w, sk_b, fc_w, residual,
+                                 ln_g, ln_b, LN_EPS, p_fc, seed_f, kv_rows=kv_rows, save=True)
+        ctx.save_for_backward(qt, kvt, sk_w, fc_w, residual, ln_g, sv["P"], sv["O"], sv["u"], sv["gate"], sv["s"], sv["f"],
+                              sv["mean"], sv["rstd"])
+        ctx.cfg = (n_seq, p_attn, seed_a, p_fc, seed_f, kv_rows)
+        ctx.mark_non_differentiable(sv["P"])
+        return y, sv["P"]
+
+    @staticmethod
+    def backward(ctx, dy, _dP):
+        qt, kvt, sk_w, fc_w, residual, ln_g, P, O, u, gate, s, f, mean, rstd = ctx.saved_tensors
+        n_seq, p_attn, seed_a, p_fc, seed_f, kv_rows = ctx.cfg
+        M, hd, d = n_seq * SEQ, 512, 64
+        df, dres, dgam, dbet = ops.ln_bwd(dy.contiguous(), f, None, residual, ln_g, mean, rstd, M, SEQ, SEQ, 1, p_fc, seed_f,
+                                          need_da=True, need_dres=True)
+        du = ops.gemm(df, fc_w, trans_b=False)
+        dfc = _wgrad(df, u)
+        dO, dg = ops.sh_bwd(du, O, gate, sk_w)
+        dskw = ops.gemm(dg, s, trans_a=True, trans_b=False, split_k=8 if dg.shape[0] >= 512 else 1)
+        dskb = ops.colsum(dg)
+        if kvt is None:
+            dqt, dkvt = torch.empty_like(qt), None
+            ops.attn_bwd(qt, 0, qt, hd, qt, 2 * hd, P, dO, n_seq, 8, SEQ, d, 0.125, p_attn, seed_a, dqt, 0, dqt, hd, dqt, 2 * hd)
+        else:
+            dqt, dkvt = torch.empty_like(qt), torch.empty_like(kvt)
+            ops.attn_bwd(qt, 0, kvt, 0, kvt, hd, P, dO, n_seq, 8, SEQ, d, 0.125, p_attn, seed_a, dqt, 0, dkvt, 0, dkvt, hd,
+                         kv_rows=kv_rows)
+        return dqt, dkvt, None, None, None, None, None, dskw, dskb, dfc, dres, dgam, dbet, None, None
 
 
 class _SelectiveHeadsAnyT(torch.autograd.Function):
@@ -570,15 +614,21 @@ class MultiHeadAttention(nn.Module):
         xq = x_q.reshape(n_seq * SEQ, self.d_model)
         if x_kv is x_q:
             w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight], 0)
-            qkv = _Linear.apply(xq, w, None)
-            O, attn = _AttnSelf.apply(qkv, n_seq, H, d, mode, n_valid, 1.0 / self.d_k ** 0.5, p_attn,
-                                      _new_seed())
+            qt, kvt = _Linear.apply(xq, w, None), None
         else:
             xkv = x_kv.reshape(n_seq * x_kv.size(1), self.d_model)
-            qp = _Linear.apply(xq, self.w_qs.weight, None)
-            kv = _Linear.apply(xkv, torch.cat([self.w_ks.weight, self.w_vs.weight], 0), None)
-            O, attn = _AttnCross.apply(qp, kv, n_seq, H, d, mode, n_valid, 1.0 / self.d_k ** 0.5,
-                                       p_attn, _new_seed())
+            qt = _Linear.apply(xq, self.w_qs.weight, None)
+            kvt = _Linear.apply(xkv, torch.cat([self.w_ks.weight, self.w_vs.weight], 0), None)
+        seed_a = _new_seed()
+        if _FUSED_BLOCK and qt.is_cuda:
+            # one launch, as the C entry points run the block (csrc/mha_fused.hip)
+            y, attn = _MhaCore.apply(qt, kvt, n_seq, mode, n_valid, p_attn, seed_a, self.sh.sk.weight, self.sh.sk.bias,
+                                     self.fc.weight, xq, self.layer_norm.weight, self.layer_norm.bias, p, _new_seed())
+            return y.view(n_seq, SEQ, self.d_model), attn
+        if kvt is None:
+            O, attn = _AttnSelf.apply(qt, n_seq, H, d, mode, n_valid, 1.0 / self.d_k ** 0.5, p_attn, seed_a)
+        else:
+            O, attn = _AttnCross.apply(qt, kvt, n_seq, H, d, mode, n_valid, 1.0 / self.d_k ** 0.5, p_attn, seed_a)
         u = _SelectiveHeads.apply(O, self.sh.sk.weight, self.sh.sk.bias)      # [n, T, dv]
         f = _Linear.apply(u.view(n_seq * SEQ, d), self.fc.weight, None)
         y = _DropResLN.apply(f, None, xq, self.layer_norm.weight, self.layer_norm.bias,

@@ -475,6 +475,27 @@ int ait_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* 
                  float* dv, int lddv, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Everything of MultiHeadAttention.forward behind the Q / K / V projections as ONE kernel, one workgroup per
+ * sequence with its eight heads resident (lib/model/system/SubLayers.py:82-100 with Modules.py:16-29 and SHBlock,
+ * SubLayers.py:22-39): attention tiles, selective heads, the head sum, fc, dropout, residual, LayerNorm
+ *     y = LayerNorm_eps( dropout_{p_fc}( (sum_h gate_h * (dropout_{p_attn}(softmax(mask(q k^T * scale))) v)_h) fc_w^T ) + residual )
+ * = ait_attn_fwd -> ait_sh_fwd -> ait_gemm_f32 (fc) -> ait_ln_fwd_rows in one launch, with the same dropout masks for
+ * the same seeds.  H = 8, T = 64, d = 64, model width 512 only.  q / k / v / kv_rows / mask_mode / n_valid_keys /
+ * scale as ait_attn_fwd; sk_w [512,64], sk_b [512] (SHBlock.sk), fc_w [512,64] (MultiHeadAttention.fc, no bias),
+ * residual [n_seq*64, 512] (the block's input), ln_g / ln_b [512]; y [n_seq*out_rows, 512]: rows t >= out_rows of a
+ * sequence are not written (out_rows = 64: all).
+ * Saved for the backward, each optional (NULL: not written; inference passes NULL for all of them and nothing but y
+ * leaves the chip): P [n_seq,8,64,64] probabilities before dropout, O [n_seq,8,64,64], u [n_seq*64,64] the gated head
+ * sum, gate [n_seq,512], s [n_seq,64], f [n_seq*64,512] fc's output before dropout, mean / rstd [n_seq*64].
+ * ------------------------------------------------------------------------------------- */
+int ait_mha_core_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int n_seq,
+                     int kv_rows, int mask_mode, int n_valid_keys, float scale, float p_attn,
+                     unsigned long long seed_attn, const float* sk_w, const float* sk_b, const float* fc_w,
+                     const float* residual, const float* ln_g, const float* ln_b, float eps, float p_fc,
+                     unsigned long long seed_fc, int out_rows, float* P, float* O, float* u, float* gate, float* s,
+                     float* f, float* y, float* mean, float* rstd, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * The whole AIT forward as one call: Transformer.forward in eval mode
  * (lib/model/system/Models.py:231-280, n_layers = 1, d_model = 512, 8 heads of 64, d_inner = 2048:
  * the configuration of faster_rcnn_sys_transformer_sk_dilat.py:148-158).  Composes the entry

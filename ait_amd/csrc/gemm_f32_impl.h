@@ -188,6 +188,8 @@ enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8, KNOB_SP
                          LDS image in the P3 row format, and the MFMAs of the current slab fetch ready planes (no vector work on
                          the matrix side).  One main loop for every operand layout: only the split stage looks at the raw image */,
        KNOB_NOTICKET = 512 /* no ticket ring in LDS: static work lists only (a ring of four 40-KB slabs is all of the CU's 160 KB) */,
+       KNOB_AP3 = 2048 /* with KNOB_BP3: operand A arrives pre-split as well (an activation whose producer wrote the P3 form
+                          beside the f32 one): no vector work at all on the matrix side, planes of both operands by LDS-DMA */,
        KNOB_BP3 = 256 /* with KNOB_SPLIT: operand B arrives PRE-SPLIT ("P3": the three bf16 planes of every value, interleaved in
                          groups of eight along the reduction dimension, see p3_split_kernel); only A is split in registers */ };
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_, int MODE_ = MODE_DB, int NS_ = 3, int KNOBS_ = 0>
@@ -201,9 +203,10 @@ struct Cfg {
   static constexpr int VB = BN * BK / 4 / NT;
   static constexpr int NBUF = (MODE_ == MODE_DB) ? 2 : 3;
   static constexpr int BKB = (KNOBS_ & 256 /* KNOB_BP3 */) ? 24 : BK_;   // floats per row of a B slab (P3: 16 values x 6 B)
+  static constexpr int BKA = (KNOBS_ & 2048 /* KNOB_AP3 */) ? 24 : BK_;  // ... of an A slab
   static constexpr size_t LDS = (MODE_ == MODE_DLDS && (KNOBS_ & 1024 /* KNOB_COOP */))
                                     ? sizeof(float) * 2 * (BK + 24) * (BM + BN) + ((KNOBS_ & 512) ? 0 : 64)   // raw ring of two + two plane images
-                                : (MODE_ == MODE_DLDS) ? sizeof(float) * NS_ * (BK * BM + BKB * BN) + ((KNOBS_ & 512) ? 0 : 64) /* ticket ring */
+                                : (MODE_ == MODE_DLDS) ? sizeof(float) * NS_ * (BKA * BM + BKB * BN) + ((KNOBS_ & 512) ? 0 : 64) /* ticket ring */
                                                      : sizeof(float) * NBUF * BK * (PA + PB);
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile / wave mismatch");
   static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "slab / thread mismatch");
@@ -618,12 +621,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
                 "direct-to-LDS path needs 16-float slabs");
   static_assert(CONV != CONV_A || AK, "the gathered operand of CONV_A is K-contiguous");
   static_assert(CONV != CONV_B || (!AK && !BKC), "CONV_B is the weight-gradient layout");
-  static_assert((C::BM * 16 + C::BN * C::BKB) / 256 <= 8 * (C::NT / 64), "at most 8 transfers per wave per slab");
+  static_assert((C::BM * C::BKA + C::BN * C::BKB) / 256 <= 8 * (C::NT / 64), "at most 8 transfers per wave per slab");
   constexpr int BM = C::BM, BN = C::BN, BK = 16;
   constexpr bool kBp3 = (C::KNOBS & KNOB_BP3) != 0;   // B pre-split: rows of 16 values x 3 planes = six 16-B chunks
   static_assert(!kBp3 || (AK && BKC && CONV == CONV_NONE && (C::KNOBS & KNOB_SPLIT) != 0 && (C::BN * 24) % 256 == 0),
                 "pre-split B: both operands K-contiguous, dense");
-  constexpr int SA = BM * 16, SB = BN * C::BKB;      // floats per slab image
+  constexpr bool kAp3 = (C::KNOBS & KNOB_AP3) != 0;   // A pre-split too
+  static_assert(!kAp3 || (kBp3 && (C::BM * 24) % 256 == 0 && !ROWMAP && !GRP), "pre-split A: on top of pre-split B");
+  constexpr int SA = BM * C::BKA, SB = BN * C::BKB;      // floats per slab image
   constexpr int NW = C::NT / 64;
   constexpr int GA = SA / 256, GB = SB / 256;        // 1-KB granules per slab
   constexpr int LA = (GA + NW - 1) / NW, LB = (GB + NW - 1) / NW;   // transfers per wave per slab
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // ---- load cursor: runs two slabs ahead of the multiply ----------------------------------------
   const float* pa[LA];
   const float* pb[LB];
-  const size_t step_a = AK ? 16 : (size_t)16 * g.lda;
+  const size_t step_a = kAp3 ? 24 : AK ? 16 : (size_t)16 * g.lda;
   const size_t step_b = kBp3 ? 24 : BKC ? 16 : (size_t)16 * g.ldb;
   size_t step_b_cur = step_b;       // ROWMAP: the extra tap's weights have their own row pitch
   int l_item = 0, l_k = 0, l_kend = 0;
@@ -831,7 +836,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
 #pragma unroll
     for (int i = 0; i < LA; i++) {
       const int q = wave + i * NW;
-      if (AK) {
+      if constexpr (kAp3) {        // P3 row image, as operand B below (g.lda = floats per P3 row)
+        const int pos = q * 64 + lane;
+        const int row = pos / 6, slot = pos - row * 6;
+        const int chunk = slot ^ ((row >> 3) & 1);
+        pa[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + (l_k >> 3) * 12 + chunk * 4;
+      } else if (AK) {
         const int row = q * 16 + (lane >> 2);
         const int chunk = (lane & 3) ^ ((row >> 2) & 3);
         if constexpr (ROWMAP) {
@@ -993,8 +1003,20 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
 #pragma unroll
     for (int p = 0; p < 3; p++) d[p] = *reinterpret_cast<const bf16x8*>(slab + row * 24 + (((lk * 3 + p) ^ sw) << 2));
   };
+  // planes of 32-row tile t (rows row0 + 32 t + li) of a plane image
+  auto fetch_planes = [&](const float* img, int row0, int t, bf16x8 (&d)[3]) __attribute__((always_inline)) {
+    const int row = row0 + t * 32 + li, sw = (row >> 3) & 1;
+#pragma unroll
+    for (int p = 0; p < 3; p++) d[p] = *reinterpret_cast<const bf16x8*>(img + row * 24 + (((lk * 3 + p) ^ sw) << 2));
+  };
   auto prime3 = [&](int slot) __attribute__((always_inline)) {
-    ap = split8<6, kRne>(fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 0), fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 0));
+    if constexpr (kAp3) {
+      bf16x8 t[3];
+      fetch_planes(As + slot * SA, wm, 0, t);
+      ap.h = t[0]; ap.m = t[1]; ap.l = t[2];
+    } else {
+      ap = split8<6, kRne>(fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 0), fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 0));
+    }
     fetch_bplanes(Bd + slot * SB, 0, bq[0]);
   };
   // kCoop: thread t owns operand row t of every slab (t < BM: row t of A, else row t - BM of B): it reads the row's 16
@@ -1029,12 +1051,6 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     *reinterpret_cast<bf16x8*>(d + ((3 ^ sw) << 2)) = hi.h;
     *reinterpret_cast<bf16x8*>(d + ((4 ^ sw) << 2)) = hi.m;
     *reinterpret_cast<bf16x8*>(d + ((5 ^ sw) << 2)) = hi.l;
-  };
-  // planes of 32-row tile t (rows row0 + 32 t + li) of a plane image
-  auto fetch_planes = [&](const float* img, int row0, int t, bf16x8 (&d)[3]) __attribute__((always_inline)) {
-    const int row = row0 + t * 32 + li, sw = (row >> 3) & 1;
-#pragma unroll
-    for (int p = 0; p < 3; p++) d[p] = *reinterpret_cast<const bf16x8*>(img + row * 24 + (((lk * 3 + p) ^ sw) << 2));
   };
   if constexpr (kCoop) {
     float4 q[4];
@@ -1153,6 +1169,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         const float* b_cur = Bd + cur * SB;
         const float* b_nxt = Bd + nxt * SB;
         u32x4 nh, nm, nl;
+        bf16x8 naq[3];            // kAp3: the next A tile's planes, fetched ready-made
 #pragma unroll
         for (int a = 0; a < C::TM; a++) {
 #pragma unroll
@@ -1162,8 +1179,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
             fetch_bplanes(r + 1 == kPairs ? b_nxt : b_cur, (b + 1) % C::TN, bq[nx]);
             if (b == 0) {
               const float* src = a + 1 < C::TM ? a_cur : a_nxt;
-              rw[0][0] = fetch_tile<AK, BM>(src, wm, li, lk, 0, a + 1 < C::TM ? a + 1 : 0);
-              rw[0][1] = fetch_tile<AK, BM>(src, wm, li, lk, 1, a + 1 < C::TM ? a + 1 : 0);
+              if constexpr (kAp3) {
+                fetch_planes(src, wm, a + 1 < C::TM ? a + 1 : 0, naq);
+              } else {
+                rw[0][0] = fetch_tile<AK, BM>(src, wm, li, lk, 0, a + 1 < C::TM ? a + 1 : 0);
+                rw[0][1] = fetch_tile<AK, BM>(src, wm, li, lk, 1, a + 1 < C::TM ? a + 1 : 0);
+              }
             }
             {
               f32x16 c = acc[a][b];
@@ -1174,7 +1195,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
               c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap.h, bq[pr][1], c, 0, 0, 0);
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap.h, bq[pr][0], c, 0, 0, 0);
             }
-            if (b == 1) {
+            if constexpr (kAp3) {
+            } else if (b == 1) {
               unsigned x, y, z;
               split2<kRne>(rw[0][0].x, rw[0][0].y, x, y, z); nh[0] = x; nm[0] = y; nl[0] = z;
               split2<kRne>(rw[0][0].z, rw[0][0].w, x, y, z); nh[1] = x; nm[1] = y; nl[1] = z;
@@ -1194,9 +1216,13 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
               }
             }
           }
-          ap.h = __builtin_bit_cast(bf16x8, nh);
-          ap.m = __builtin_bit_cast(bf16x8, nm);
-          ap.l = __builtin_bit_cast(bf16x8, nl);
+          if constexpr (kAp3) {
+            ap.h = naq[0]; ap.m = naq[1]; ap.l = naq[2];
+          } else {
+            ap.h = __builtin_bit_cast(bf16x8, nh);
+            ap.m = __builtin_bit_cast(bf16x8, nm);
+            ap.l = __builtin_bit_cast(bf16x8, nl);
+          }
         }
         // (kPairs is even: the planes fetched in the last region sit in bq[0], where the next slab starts)
         static_assert(kPairs % 2 == 0, "B plane double buffer parity");

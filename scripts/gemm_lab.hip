@@ -45,6 +45,7 @@ using V_rne = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_RNE>;  
 using V_bf16 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BF16>;      // operands rounded to bf16, one MFMA per block
 using V_bp3 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3>;    // B pre-split (P3), 8 waves of 64x128, one workgroup per CU
 using V_bp3r = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3 | KNOB_RNE>;
+using V_ab3 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3 | KNOB_AP3 | KNOB_RNE>;   // both operands pre-split: no vector work
 using V_bp3p = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_COOP | KNOB_NOTICKET | KNOB_RNE>;     // every value split once per workgroup (LDS plane image)
 using V_bp3n4 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_BP3 | KNOB_NOTICKET>;
 using V_bp3n4p = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_BP3 | KNOB_NOTICKET | KNOB_PRIO>;
@@ -114,6 +115,7 @@ struct Problem {
   Shape s;
   float *A, *B, *C, *C2, *bias, *res;
   unsigned short* Bp3;      // B as P3 [N][K / 8][3][8] (variants 20, 21)
+  unsigned short* Ap3;      // A as P3 [M][K / 8][3][8] (variant 26)
   unsigned long long* probe;
   GemmArgs g;
 };
@@ -131,13 +133,18 @@ static void setup(Problem& p, const Shape& s) {
   fill_kernel<<<64, 256>>>(p.bias, (size_t)s.N, 0x5555u);
   CK(hipMemset(p.C, 0, nc * 4)); CK(hipMemset(p.C2, 0, nc * 4));
   p.Bp3 = nullptr;
+  p.Ap3 = nullptr;
   if (!s.ta && s.K % 16 == 0) {
     CK(hipMalloc(&p.Bp3, nb * 6));
     ait_p3::Jobs jobs;
     jobs.n = 1;
     jobs.j[0] = s.tb ? ait_p3::Job{p.B, p.Bp3, s.N, s.K, s.K, 0, 0} : ait_p3::Job{p.B, p.Bp3, s.K, s.N, s.N, 1, 0};
-    const int rc = ait_p3::launch_split(jobs, 0);
+    int rc = ait_p3::launch_split(jobs, 0);
     if (rc) { printf("p3 split rc %d\n", rc); exit(1); }
+    CK(hipMalloc(&p.Ap3, na * 6));
+    jobs.j[0] = ait_p3::Job{p.A, p.Ap3, s.M, s.K, s.K, 0, 0};
+    rc = ait_p3::launch_split(jobs, 0);
+    if (rc) { printf("p3 split (A) rc %d\n", rc); exit(1); }
   }
   CK(hipDeviceSynchronize());
   const int lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
@@ -151,6 +158,7 @@ static void setup(Problem& p, const Shape& s) {
 }
 static void teardown(Problem& p) {
   if (p.Bp3) hipFree(p.Bp3);
+  if (p.Ap3) hipFree(p.Ap3);
   hipFree(p.A); hipFree(p.B); hipFree(p.C); hipFree(p.C2); hipFree(p.bias); hipFree(p.res); hipFree(p.probe);
 }
 
@@ -180,7 +188,7 @@ static int run_tile(const GemmArgs& g, bool ak, bool bk, int slots) {
   return run_epi<T, false, true, NoProbe>(g, slots);
 }
 static const char* VNAMES[] = {"old", "new", "probe", "burst", "prio", "ring4", "ring4+burst", "4waves", "4waves+burst",
-                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "split rne", "bp3 256sq", "bp3 rne", "bf16 x1", "coop 256sq", "bp3 ring4", "bp3 ring4 prio"};
+                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "split rne", "bp3 256sq", "bp3 rne", "bf16 x1", "coop 256sq", "bp3 ring4", "bp3 ring4 prio", "ap3+bp3"};
 template <class Probe>
 static int run_new(const GemmArgs& g, bool ak, bool bk, int slots) {
   if (!ak && !bk) return run_epi<NewD4, false, false, Probe>(g, slots);
@@ -221,6 +229,12 @@ static int run(Problem& p, int variant, float* out) {
     if (getenv("LAB_PROBE_BP3") && p.Bp3) {    // the stamp probe on the pre-split-B tile
       g.B = reinterpret_cast<const float*>(p.Bp3);
       g.ldb = p.s.K / 2 * 3;
+      if (atoi(getenv("LAB_PROBE_BP3")) == 26) {
+        g.A = reinterpret_cast<const float*>(p.Ap3);
+        g.lda = p.s.K / 2 * 3;
+        return run_epi<V_ab3, true, true, StampProbe>(g, g_slots);
+      }
+      if (atoi(getenv("LAB_PROBE_BP3")) == 21) return run_epi<V_bp3r, true, true, StampProbe>(g, g_slots);
       if (atoi(getenv("LAB_PROBE_BP3")) == 4) return run_epi<V_bp3n4, true, true, StampProbe>(g, g_slots);
       return run_epi<V_bp3, true, true, StampProbe>(g, g_slots);
     }
@@ -257,10 +271,15 @@ static int run(Problem& p, int variant, float* out) {
     case 19: return run_tile<V_rne>(g, ak, bk, g_slots);
     case 22: return run_tile<V_bf16>(g, ak, bk, g_slots);
     case 23: return run_tile<V_bp3p>(g, ak, bk, g_slots);
-    case 20: case 21: case 24: case 25: {
+    case 20: case 21: case 24: case 25: case 26: {
       if (!p.Bp3 || (p.s.flags & (LAB_ALIAS_A | LAB_ALIAS_B))) return -99;
       g.B = reinterpret_cast<const float*>(p.Bp3);
       g.ldb = p.s.K / 2 * 3;
+      if (variant == 26) {
+        g.A = reinterpret_cast<const float*>(p.Ap3);
+        g.lda = p.s.K / 2 * 3;
+        return run_epi<V_ab3, true, true, NoProbe>(g, g_slots);
+      }
       if (variant == 21) return run_epi<V_bp3r, true, true, NoProbe>(g, g_slots);
       if (variant == 23) return -99;
       if (variant == 24) return run_epi<V_bp3n4, true, true, NoProbe>(g, g_slots);

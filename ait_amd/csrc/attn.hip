@@ -7,7 +7,7 @@ using namespace ait_attn;
 __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const AttnArgs g, float* __restrict__ P,
                                                                float* __restrict__ O) {
   __shared__ __attribute__((aligned(16))) float lds[kWaves * kPanel];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (uniform: unit bases in SGPRs)
   const long long unit = (long long)blockIdx.x * kWaves + wave;  // (sequence, head)
   if (unit >= (long long)g.n_seq * g.H) return;
   const int n = (int)(unit / g.H), h = (int)(unit % g.H);
@@ -44,9 +44,8 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const AttnArgs g,
   if (P) acc_to_global(acc, P + pbase, T, lane, 1.f);
   if (g.p > 0.f) {
     const float inv_keep = 1.f / (1.f - g.p);
-    for_acc(acc, lane, [&](float x, int row, int col) {
-      return x * drop_scale(g.seed, pbase + (size_t)row * T + col, g.p, inv_keep);
-    });
+    const DropBlock db(g.seed, pbase);
+    for_acc(acc, lane, [&](float x, int row, int col) { return x * db.scale(row * T + col, g.p, inv_keep); });
   }
   acc_to_lds(acc, s0, lane);  // P_drop over the K panel (this wave's reads of it are done)
   zero(acc);

@@ -18,13 +18,14 @@ struct AttnBwdArgs {
 // 0.48 ms (an extra product and an exp pass in front of everything else).
 __global__ __launch_bounds__(kThreads, 2) void attn_bwd_kernel(const AttnBwdArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[kWaves * kPanel];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (uniform: unit bases in SGPRs)
   const long long unit = (long long)blockIdx.x * kWaves + wave;
   if (unit >= (long long)g.f.n_seq * g.f.H) return;
   const int n = (int)(unit / g.f.H), h = (int)(unit % g.f.H);
   float* s0 = lds + wave * kPanel;
   const size_t pbase = (size_t)unit * T * T;
   const float p = g.f.p, inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  const DropBlock db(g.f.seed, pbase);
   const float* __restrict__ dO = g.dO + (size_t)unit * T * D;
   const float* __restrict__ Vg = g.f.v + ((size_t)n * g.f.kv_rows) * g.f.ldv + h * D;
   const float* __restrict__ Kg = g.f.k + ((size_t)n * g.f.kv_rows) * g.f.ldk + h * D;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_kernel(const AttnBwdArgs
         for (int r = 0; r < 16; r++) {
           const int row = acc_row(a, r, lane), col = acc_col(b, lane);
           // branch-free: at p = 0 the hash test u >= p always passes and inv_keep is 1
-          pd[a][b][r] = Pu[row * T + col] * drop_scale(g.f.seed, pbase + (size_t)row * T + col, p, inv_keep);
+          pd[a][b][r] = Pu[(unsigned)(row * T + col)] * db.scale(row * T + col, p, inv_keep);
         }
     acc_to_lds(pd, s0, lane);
   }
@@ -76,9 +77,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_bwd_kernel(const AttnBwdArgs
     for (int r = 0; r < 16; r++) {
       if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // four rows' shuffle chains at a time
       const int row = acc_row(a, r, lane);
-      const float p0 = Pu[row * T + acc_col(0, lane)], p1 = Pu[row * T + acc_col(1, lane)];
-      const float d0 = acc[a][0][r] * drop_scale(g.f.seed, pbase + (size_t)row * T + acc_col(0, lane), p, inv_keep);
-      const float d1 = acc[a][1][r] * drop_scale(g.f.seed, pbase + (size_t)row * T + acc_col(1, lane), p, inv_keep);
+      const float p0 = Pu[(unsigned)(row * T + acc_col(0, lane))], p1 = Pu[(unsigned)(row * T + acc_col(1, lane))];
+      const float d0 = acc[a][0][r] * db.scale(row * T + acc_col(0, lane), p, inv_keep);
+      const float d1 = acc[a][1][r] * db.scale(row * T + acc_col(1, lane), p, inv_keep);
       const float dot = half_sum(d0 * p0 + d1 * p1);
       acc[a][0][r] = p0 * (d0 - dot) * g.f.scale;
       acc[a][1][r] = p1 * (d1 - dot) * g.f.scale;

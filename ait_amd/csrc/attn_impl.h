@@ -57,6 +57,21 @@ __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned lo
   return u >= p ? inv_keep : 0.f;
 }
 
+// The same decision for element base + off of a block whose base is wave-uniform and a multiple of a power of two > off
+// (a unit's 4096 probabilities, a sequence's 32768 fc outputs): the high word of the index and everything that depends
+// on it are computed once per block on the scalar side -- 9 vector instructions per element instead of 17, two of them
+// the quarter-rate v_mul_lo_u32 either way.  Bit-identical to drop_scale(seed, base + off, ...).
+struct DropBlock {
+  unsigned lo0, key;
+  __device__ __forceinline__ DropBlock(unsigned long long seed, unsigned long long base)
+      : lo0((unsigned)base), key(mix32((unsigned)(base >> 32) + (unsigned)seed) ^ (unsigned)(seed >> 32) * 0x9e3779b9u) {}
+  __device__ __forceinline__ float scale(unsigned off, float p, float inv_keep) const {
+    const unsigned h = mix32((lo0 + off) ^ key);
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.f;
+  }
+};
+
 // One 64x64 operand panel on its way global -> registers -> LDS [64][65].  All 16 loads of a lane
 // (16 B each: lane = (row & 3, 16-B column chunk), 4 rows per wave-wide load) are issued back to
 // back, so a panel costs ONE memory round trip, and they can be issued long before the panel is
@@ -71,7 +86,7 @@ struct Stage {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int r = min(i * 4 + r0, rows - 1);
-      v[i] = *reinterpret_cast<const float4*>(g + (r * ld + c));      // 32-bit offset off a wave-uniform base
+      v[i] = *reinterpret_cast<const float4*>(g + (unsigned)(r * ld + c));      // unsigned 32-bit offset off a wave-uniform (SGPR) base: saddr + voffset addressing
     }
   }
   __device__ __forceinline__ void store(float* __restrict__ s, int lane, int rows = T) const {
@@ -129,7 +144,7 @@ __device__ __forceinline__ void breg_load(OpRegs& b, const float* __restrict__ g
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int k = 16 * kb + 8 * lk + j;
-      const int off = min(k, rows - 1) * ld + li;          // 32-bit offset off a wave-uniform base
+      const unsigned off = (unsigned)(min(k, rows - 1) * ld + li);          // unsigned 32-bit offset off a wave-uniform base
       const float x0 = g[off], x1 = g[off + 32];
       b.v[0][kb][j] = k < rows ? x0 : 0.f;
       b.v[1][kb][j] = k < rows ? x1 : 0.f;
@@ -282,7 +297,7 @@ __device__ __forceinline__ void acc_to_global(const f32x16 (&acc)[2][2], float* 
     for (int b = 0; b < 2; b++)
 #pragma unroll
       for (int r = 0; r < 16; r++)
-        g[acc_row(a, r, lane) * ld + acc_col(b, lane)] = acc[a][b][r] * mul;
+        g[(unsigned)(acc_row(a, r, lane) * ld + acc_col(b, lane))] = acc[a][b][r] * mul;
 }
 __device__ __forceinline__ void acc_to_global_rows(const f32x16 (&acc)[2][2], float* __restrict__ g,
                                                    int ld, int lane, int rows) {
@@ -293,7 +308,7 @@ __device__ __forceinline__ void acc_to_global_rows(const f32x16 (&acc)[2][2], fl
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int row = acc_row(a, r, lane);
-        if (row < rows) g[row * ld + acc_col(b, lane)] = acc[a][b][r];
+        if (row < rows) g[(unsigned)(row * ld + acc_col(b, lane))] = acc[a][b][r];
       }
 }
 __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[2][2], float* __restrict__ s,

@@ -118,9 +118,8 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   if (c.P) acc_to_global(acc, c.P + pbase, T, lane, 1.f);
   if (g.p > 0.f) {
     const float inv_keep = 1.f / (1.f - g.p);
-    for_acc(acc, lane, [&](float x, int row, int col) {
-      return x * drop_scale(g.seed, pbase + (size_t)row * T + col, g.p, inv_keep);
-    });
+    const DropBlock db(g.seed, pbase);
+    for_acc(acc, lane, [&](float x, int row, int col) { return x * db.scale(row * T + col, g.p, inv_keep); });
   }
   STAMP(2)
   acc_to_lds(acc, s0, lane);
@@ -233,6 +232,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   // ---- phase E: z = dropout(f) + residual ; LayerNorm over the 512 columns of every token row ------------------
   {
     const float inv_keep = c.p_fc > 0.f ? 1.f / (1.f - c.p_fc) : 1.f;
+    const DropBlock db(c.seed_fc, row0 * kDm);
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
         for (int r = 0; r < 16; r++) {
           const size_t idx = (row0 + acc_row(a, r, lane)) * kDm + col0 + acc_col(b, lane);
           float z = acc[a][b][r];
-          if (c.p_fc > 0.f) z *= drop_scale(c.seed_fc, idx, c.p_fc, inv_keep);
+          if (c.p_fc > 0.f) z *= db.scale((unsigned)(acc_row(a, r, lane) * kDm + col0 + acc_col(b, lane)), c.p_fc, inv_keep);
           acc[a][b][r] = z + c.residual[idx];
         }
   }

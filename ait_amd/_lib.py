@@ -103,7 +103,7 @@ SIGNATURES = {
     "ait_sh_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ait_sh_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ait_mha_core_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f,
-                               _ull, _i] + [_vp] * 10),
+                               _ull, _i, _i] + [_vp] * 10),
     "ait_attn_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp,
                           _vp]),
     "ait_attn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _i,

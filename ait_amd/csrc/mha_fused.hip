@@ -32,7 +32,7 @@ struct CoreArgs {
   float eps, p_fc;
   unsigned long long seed_fc;
   int out_rows;
-  int round;       // workgroups resident at once (= CUs)
+  int q_rep;       // sequence n takes its queries and its residual from sequence n / q_rep of q / residual
   float *P, *O, *u, *gate, *s, *f, *y, *mean, *rstd;
   unsigned long long* prof;
 };
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   // lane-dependent address computations of the body out of it and keeps them live across it (1.9 KB of scratch per lane,
   // 2.4x the time; hiding the lane id and the induction variable from it still left 200 B and 1.3x).
   const int n = blockIdx.x;
+  const int nq = c.q_rep > 1 ? n / c.q_rep : n;      // (inference: the decoder's query side is one sequence per PAIR)
   const long long unit = (long long)n * kHeads + h;
 #ifdef AIT_MHA_PROF
   unsigned long long t_last = clock64();
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   OpRegs op;
   {
     Stage sq, sk;
-    sq.load(g.q + ((size_t)n * T) * g.ldq + h * D, g.ldq, lane);
+    sq.load(g.q + ((size_t)nq * T) * g.ldq + h * D, g.ldq, lane);
     sk.load(g.k + ((size_t)n * g.kv_rows) * g.ldk + h * D, g.ldk, lane, g.kv_rows);
     sq.store(s0, lane);
     areg_from_lds(op, s0, lane);
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
           const size_t idx = (row0 + acc_row(a, r, lane)) * kDm + col0 + acc_col(b, lane);
           float z = acc[a][b][r];
           if (c.p_fc > 0.f) z *= db.scale((unsigned)(acc_row(a, r, lane) * kDm + col0 + acc_col(b, lane)), c.p_fc, inv_keep);
-          acc[a][b][r] = z + c.residual[idx];
+          acc[a][b][r] = z + c.residual[idx - (size_t)(n - nq) * T * kDm];
         }
   }
   STAMP(9)
@@ -326,21 +327,18 @@ AIT_API int ait_mha_core_fwd(const float* q, int ldq, const float* k, int ldk, c
                              int kv_rows, int mask_mode, int n_valid_keys, float scale, float p_attn,
                              unsigned long long seed_attn, const float* sk_w, const float* sk_b, const float* fc_w,
                              const float* residual, const float* ln_g, const float* ln_b, float eps, float p_fc,
-                             unsigned long long seed_fc, int out_rows, float* P, float* O, float* u, float* gate, float* s,
-                             float* f, float* y, float* mean, float* rstd, void* stream) {
+                             unsigned long long seed_fc, int out_rows, int q_rep, float* P, float* O, float* u, float* gate,
+                             float* s, float* f, float* y, float* mean, float* rstd, void* stream) {
   if (bad(n_seq, kHeads, T, D, mask_mode, n_valid_keys, p_attn) || p_fc < 0.f || p_fc >= 1.f) return AIT_EINVAL;
   if (n_seq == 0) return AIT_OK;
   if (!q || !k || !v || !sk_w || !sk_b || !fc_w || !residual || !ln_g || !ln_b || !y) return AIT_EINVAL;
-  if (kv_rows <= 0 || kv_rows > T || out_rows <= 0 || out_rows > T) return AIT_EINVAL;
+  if (kv_rows <= 0 || kv_rows > T || out_rows <= 0 || out_rows > T || q_rep < 1) return AIT_EINVAL;
   if ((long long)n_seq * T * kDm > 0x7fffffffLL * 4) return AIT_EUNSUPPORTED;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(mha_core_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kFusedLds) != hipSuccess)
     return AIT_ELAUNCH;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    return AIT_ELAUNCH;
   CoreArgs c{AttnArgs{q, k, v, ldq, ldk, ldv, n_seq, kHeads, mask_mode, n_valid_keys, kv_rows, scale, p_attn, seed_attn},
-             sk_w, sk_b, fc_w, residual, ln_g, ln_b, eps, p_fc, seed_fc, out_rows, cus, P, O, u, gate, s, f, y, mean, rstd, g_prof};
+             sk_w, sk_b, fc_w, residual, ln_g, ln_b, eps, p_fc, seed_fc, out_rows, q_rep, P, O, u, gate, s, f, y, mean, rstd, g_prof};
   hipLaunchKernelGGL(mha_core_fwd_kernel, dim3((unsigned)n_seq), dim3(kFusedThreads), kFusedLds, ait_stream(stream), c);
   AIT_CHECK_LAUNCH();
   return AIT_OK;

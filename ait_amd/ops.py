@@ -387,7 +387,7 @@ def attn_fwd(q, qoff, k, koff, v, voff, n_seq, H, T, d, mask_mode, n_valid, scal
 
 
 def mha_core_fwd(q, qoff, k, koff, v, voff, n_seq, mask_mode, n_valid, p_attn, seed_attn, sk_w, sk_b, fc_w, residual,
-                 ln_g, ln_b, eps, p_fc, seed_fc, kv_rows=64, out_rows=64, save=True):
+                 ln_g, ln_b, eps, p_fc, seed_fc, kv_rows=64, out_rows=64, save=True, q_rep=1):
     """ait_mha_core_fwd: attention tiles + selective heads + fc + dropout + residual + LayerNorm of one
     MultiHeadAttention block in one launch.  Returns y and, with save=True, the dict of tensors the backward reads."""
     dev = q.device
@@ -400,7 +400,7 @@ def mha_core_fwd(q, qoff, k, koff, v, voff, n_seq, mask_mode, n_valid, p_attn, s
         rc = _lib.lib().ait_mha_core_fwd(_col(q, qoff), q.stride(0), _col(k, koff), k.stride(0), _col(v, voff), v.stride(0),
                                          n_seq, int(kv_rows), mask_mode, n_valid, 0.125, float(p_attn), int(seed_attn),
                                          _p(sk_w), _p(sk_b), _p(fc_w), _p(residual), _p(ln_g), _p(ln_b), float(eps),
-                                         float(p_fc), int(seed_fc), int(out_rows), g("P"), g("O"), g("u"), g("gate"), g("s"),
+                                         float(p_fc), int(seed_fc), int(out_rows), int(q_rep), g("P"), g("O"), g("u"), g("gate"), g("s"),
                                          g("f"), _p(y), g("mean"), g("rstd"), _lib.cur_stream(dev))
     _lib.check(rc, "ait_mha_core_fwd")
     return y, sv

@@ -483,7 +483,9 @@ int ait_attn_bwd(const float* q, int ldq, const float* k, int ldk, const float* 
  * the same seeds.  H = 8, T = 64, d = 64, model width 512 only.  q / k / v / kv_rows / mask_mode / n_valid_keys /
  * scale as ait_attn_fwd; sk_w [512,64], sk_b [512] (SHBlock.sk), fc_w [512,64] (MultiHeadAttention.fc, no bias),
  * residual [n_seq*64, 512] (the block's input), ln_g / ln_b [512]; y [n_seq*out_rows, 512]: rows t >= out_rows of a
- * sequence are not written (out_rows = 64: all).
+ * sequence are not written (out_rows = 64: all).  q_rep >= 1: sequence n takes its queries AND its residual from
+ * sequence n / q_rep of q / residual ([n_seq / q_rep * 64, .]) -- inference, where the decoder's query side is the same
+ * for the q_rep proposals of a pair (Models.py:250 repeats it; without dropout the repeats are equal).
  * Saved for the backward, each optional (NULL: not written; inference passes NULL for all of them and nothing but y
  * leaves the chip): P [n_seq,8,64,64] probabilities before dropout, O [n_seq,8,64,64], u [n_seq*64,64] the gated head
  * sum, gate [n_seq,512], s [n_seq,64], f [n_seq*64,512] fc's output before dropout, mean / rstd [n_seq*64].
@@ -492,8 +494,8 @@ int ait_mha_core_fwd(const float* q, int ldq, const float* k, int ldk, const flo
                      int kv_rows, int mask_mode, int n_valid_keys, float scale, float p_attn,
                      unsigned long long seed_attn, const float* sk_w, const float* sk_b, const float* fc_w,
                      const float* residual, const float* ln_g, const float* ln_b, float eps, float p_fc,
-                     unsigned long long seed_fc, int out_rows, float* P, float* O, float* u, float* gate, float* s,
-                     float* f, float* y, float* mean, float* rstd, void* stream);
+                     unsigned long long seed_fc, int out_rows, int q_rep, float* P, float* O, float* u, float* gate,
+                     float* s, float* f, float* y, float* mean, float* rstd, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * The whole AIT forward as one call: Transformer.forward in eval mode

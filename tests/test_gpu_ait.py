@@ -384,8 +384,11 @@ def test_transformer_c_entry_point_equals_the_autograd_composition(monkeypatch):
         t.channels_last_out = True
         y_c_cl = t(x_props=xp, x_query=xq)
         t.channels_last_out = False
-    assert torch.equal(y_c, y_py)
-    assert torch.equal(y_c_cl, y_py) and y_c_cl.permute(0, 2, 3, 1).is_contiguous()
+    # (the inference entry point runs the decoder's query side -- prologue, self-attention block, the cross-attention's
+    # query projection -- once per PAIR instead of once per proposal: the same kernels on fewer rows, where the
+    # projections pick other tiles; equal to rounding)
+    assert float((y_c - y_py).abs().max()) <= 1e-5 * float(y_py.abs().max())
+    assert torch.equal(y_c_cl, y_c) and y_c_cl.permute(0, 2, 3, 1).is_contiguous()
     ref = ait_ref.transformer_forward(ait_ref.make_ait_state_dict(seed=3), torch.from_numpy(xp0), torch.from_numpy(xq0))
     assert float((y_c.cpu() - ref).norm() / ref.norm()) < 1e-5
     # a padded (64-token) proposal memory and a wrong pairing are handled / rejected

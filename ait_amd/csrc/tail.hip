@@ -227,8 +227,11 @@ inline int linear(const float* x, long long M, int K, const float* w, int N, con
 // dx = dy W  (+ residual) (gated by mask > 0: MASK_POS when there is no residual, the gate operand when there is)
 inline int dgrad(const float* dy, long long M, int N_out, const float* w, int K_in, const float* residual,
                  const float* mask, float* dx, const Run& r, const ait_p3::Ref& p3t = ait_p3::Ref()) {
-  if (p3t.p && ait_gemm_p3b_takes((int)M, K_in, N_out, r.ctx)) {      // B = planes of W'^T: rows K_in, reduction over N_out
-    const bool both = residual && mask;
+  // (the residual + gate epilogue reads two more tensors per output: on these short reductions the 256 x 256 tile's
+  // epilogue then weighs more than the pre-split planes save -- 35 % against 39 % of the matrix pipe -- so it stays on
+  // the 256 x 128 tile)
+  if (p3t.p && !(residual && mask) && ait_gemm_p3b_takes((int)M, K_in, N_out, r.ctx)) {      // B = planes of W'^T: rows K_in, reduction over N_out
+    const bool both = false;
     return ait_gemm_f32_p3b((int)M, K_in, N_out, 1.f, dy, N_out, p3t.p, p3t.ld, dx, K_in, nullptr, both ? residual : (mask ? mask : residual),
                             both ? mask : nullptr, (!both && mask) ? AIT_GEMM_MASK_POS : 0, 0, 0, r.ctx, r.stream);
   }

@@ -14,6 +14,7 @@ def c(n):
     if 'naive_conv' in n or 'miopen' in n.lower() or 'gridwise' in n.lower(): return 'miopen other'
     if 'at::native' in n or 'rocprim' in n or 'at::cuda' in n: return 'torch elementwise / reduce / index'
     if 'anonymous' in n:
+        if 'mha_core' in n: return 'ait fused attention block (fwd: tiles + selective heads + fc + LayerNorm)'
         for k in ('roi_align', 'attn', 'bn_act', 'ln_', 'sh_', 'nms', 'sk_', 'colsum', 'rep_sum'):
             if k in n: return 'ait ' + k.strip('_')
         return 'ait other'

@@ -79,6 +79,8 @@ static const Shape SHAPES[] = {
     {"dhmsk NN", 76800, 2048, 512, 0, 0, 1, LAB_RES | AIT_GEMM_MASK_POS},  // dgrad gated by the saved ReLU
     {"fc    NT", 76800, 512, 64, 0, 1, 1, 0},                              // K = 64: four slabs per tile
     {"trans NT", 76800, 1024, 512, 0, 1, 1, AIT_GEMM_RELU},                // dec_trans shape (+ bias)
+    {"xq    NT", 76800, 512, 512, 0, 1, 1, 0},                             // cross-attention query projection: 600 tiles of 32 slabs
+    {"l4c3r NT", 19328, 2048, 512, 0, 1, 1, AIT_GEMM_RELU | LAB_RES},      // layer4 conv3 + shift + shortcut + ReLU
     // timing-only experiments (results meaningless): operand rows aliased onto one row (row pitch 0), so that
     // the loads are served from L1 / L2 whatever the tile -- what the kernel does with the memory system taken away
     {"qkv aA NT", 76800, 1536, 512, 0, 1, 1, LAB_ALIAS_A},

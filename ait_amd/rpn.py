@@ -692,7 +692,42 @@ class _Conv3x3BiasRelu(torch.autograd.Function):
         return dx, dw, db
 
 
+class _Heads1x1(torch.autograd.Function):
+    """The RPN's two 1x1 heads (lib/model/rpn/rpn.py:34-43: 512 -> 2A objectness scores, 512 -> 4A box deltas) as ONE
+    product on the library's GEMM: the two weight matrices stacked and padded to 64 rows, y [tokens, 64] = x W^T + b on the
+    token rows of the channels-last feature; the two results are its column ranges.  Backward: the stacked gradient
+    [tokens, 64] -> dx = dy W, dW = dy^T x (split-K), db = column sums.  (MIOpen runs each head as its own rocBLAS call
+    with N = 18 / 36.)"""
+
+    @staticmethod
+    def forward(ctx, xm, w1, b1, w2, b2):
+        n1, n2, k = w1.shape[0], w2.shape[0], xm.shape[1]
+        W = torch.zeros((64, k), dtype=torch.float32, device=xm.device)
+        W[:n1] = w1.reshape(n1, k)
+        W[n1:n1 + n2] = w2.reshape(n2, k)
+        bias = torch.zeros((64,), dtype=torch.float32, device=xm.device)
+        bias[:n1] = b1
+        bias[n1:n1 + n2] = b2
+        y = ops.gemm(xm, W, bias=bias)
+        ctx.save_for_backward(xm, W)
+        ctx.sizes = (n1, n2, tuple(w1.shape), tuple(w2.shape))
+        return y[:, :n1], y[:, n1:n1 + n2]
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        xm, W = ctx.saved_tensors
+        n1, n2, s1, s2 = ctx.sizes
+        dy = torch.zeros((xm.shape[0], 64), dtype=torch.float32, device=xm.device)
+        dy[:, :n1] = d1
+        dy[:, n1:n1 + n2] = d2
+        dx = ops.gemm(dy, W, trans_b=False) if ctx.needs_input_grad[0] else None
+        dW = ops.gemm(dy, xm, trans_a=True, trans_b=False, split_k=8 if xm.shape[0] >= 2048 else 1)
+        db = ops.colsum(dy)
+        return dx, dW[:n1].reshape(s1), db[:n1], dW[n1:n1 + n2].reshape(s2), db[n1:n1 + n2]
+
+
 _RPN_CONV_KERNEL = True     # test hook: False = PyTorch-ROCm's convolution + ReLU
+_RPN_HEADS_KERNEL = True    # test hook: False = the two 1x1 heads as PyTorch-ROCm convolutions
 
 
 class _RPN(nn.Module):
@@ -736,10 +771,22 @@ class _RPN(nn.Module):
                 conv = F.relu(c(base_feat), inplace=True)
         else:
             conv = F.relu(c(base_feat), inplace=True)
-        cls_score = self.RPN_cls_score(conv)
+        n_out = self.nc_score_out + self.nc_bbox_out
+        if (_RPN_HEADS_KERNEL and conv.is_cuda and conv.dtype == torch.float32 and n_out <= 64 and conv.shape[1] % 16 == 0
+                and conv.is_contiguous(memory_format=torch.channels_last)):
+            n, ch, fh, fw = conv.shape
+            ys, yb = _Heads1x1.apply(conv.permute(0, 2, 3, 1).reshape(n * fh * fw, ch), self.RPN_cls_score.weight,
+                                     self.RPN_cls_score.bias, self.RPN_bbox_pred.weight, self.RPN_bbox_pred.bias)
+            # (the proposal layer's decode kernel and the losses read the reference's NCHW layout)
+            cls_score = ys.reshape(n, fh, fw, self.nc_score_out).permute(0, 3, 1, 2).contiguous()
+            bbox_pred = yb.reshape(n, fh, fw, self.nc_bbox_out).permute(0, 3, 1, 2).contiguous()
+        else:
+            if conv.is_cuda and _RPN_HEADS_KERNEL:       # heads the stacked product does not take: COUNTED
+                ops.note_fallback("rpn.heads", conv)
+            cls_score = self.RPN_cls_score(conv)
+            bbox_pred = self.RPN_bbox_pred(conv)
         score_2 = self.reshape(cls_score, 2)
         cls_prob = self.reshape(F.softmax(score_2, 1), self.nc_score_out)
-        bbox_pred = self.RPN_bbox_pred(conv)
         rois = self.RPN_proposal((cls_prob.data, bbox_pred.data, im_info,
                                   'TRAIN' if self.training else 'TEST'))
         self.rpn_loss_cls = 0

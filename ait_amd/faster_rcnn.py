@@ -397,6 +397,8 @@ class _TailFn(torch.autograd.Function):
         ctx.W, ctx.keep = W, keep
         ctx.cfg = (bp, bs, C, planes, n_blocks)
         ctx.meta = [tuple(t.shape) for t in params]
+        ctx.strides = [tuple(t.stride()) for t in params]
+        assert all(t.dim() != 4 or t.is_contiguous(memory_format=torch.channels_last) for t in params)
         return pooled
 
     @staticmethod
@@ -409,11 +411,13 @@ class _TailFn(torch.autograd.Function):
         sizes = [int(np.prod(sh)) for sh in ctx.meta]
         flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
         views, ptrs, o = [], [], 0
-        for sh, n in zip(ctx.meta, sizes):
+        for sh, st, n in zip(ctx.meta, ctx.strides, sizes):
             v = flat[o:o + n]
             ptrs.append(v.data_ptr())
             if len(sh) == 4:        # [cout][kh][kw][cin/g] memory = the channels-last strides of a [cout, cin/g, kh, kw] gradient
-                v = v.view(sh[0], sh[2], sh[3], sh[1]).permute(0, 3, 1, 2)
+                # (spelled with the PARAMETER's own strides: for 1x1 kernels plain and channels-last strides describe the
+                # same memory, and DDP's reducer aliases a gradient into its bucket only if the strides match literally)
+                v = v.as_strided(sh, st)
             else:
                 v = v.view(sh)
             views.append(v)
@@ -723,6 +727,10 @@ class _fasterRCNN(nn.Module):
         if _TOP_NHWC:
             self.RCNN_top.to(memory_format=torch.channels_last)
             self.sk.to(memory_format=torch.channels_last)
+        if _BASE_NHWC and self.variant == 'voc':
+            # (the co-attention's query embedding is a MIOpen convolution on a channels-last feature: its weight gradient
+            # comes back with channels-last strides, which DDP's reducer aliases only into a parameter spelled the same way)
+            self.coattention.qry_emb.to(memory_format=torch.channels_last)
 
 
 class resnet(_fasterRCNN):

@@ -713,3 +713,24 @@ def test_fused_attention_block_equals_the_four_launches(mask_mode, n_valid, kv_r
     y2, _ = ops.mha_core_fwd(q, qoff, k, koff, v, voff, n, mask_mode, n_valid, p, sa, sk_w, sk_b, fc_w, res, g, b, 1e-6,
                              p, sf, kv_rows=kv_rows, out_rows=out_rows, save=False)
     assert torch.equal(y2, y)
+
+
+@pytest.mark.gpu
+def test_fused_attention_block_query_side_per_pair_equals_the_repeated_one():
+    """q_rep of ait_mha_core_fwd (inference: the decoder's query side once per pair, every proposal's sequence reads the
+    queries and the residual of sequence n / q_rep) against the same call on explicitly repeated tensors: the same bits."""
+    from ait_amd import ops
+    torch.manual_seed(3)
+    pairs, P, kv_rows, dev = 3, 5, 49, "cuda"
+    n = pairs * P
+    q1 = torch.randn(pairs * 64, 512, device=dev)
+    res1 = torch.randn(pairs * 64, 512, device=dev)
+    kv = torch.randn(n * kv_rows, 1024, device=dev)
+    sk_w, sk_b = torch.randn(512, 64, device=dev) * 0.3, torch.randn(512, device=dev) * 0.1
+    fc_w = torch.randn(512, 64, device=dev) * 0.125
+    g, b = torch.rand(512, device=dev) + 0.5, torch.randn(512, device=dev) * 0.1
+    rep = lambda t: t.view(pairs, 1, 64, 512).expand(pairs, P, 64, 512).reshape(n * 64, 512).contiguous()
+    args = (n, 0, kv_rows, 0.0, 0, sk_w, sk_b, fc_w)
+    y_rep, _ = ops.mha_core_fwd(rep(q1), 0, kv, 0, kv, 512, *args, rep(res1), g, b, 1e-6, 0.0, 0, kv_rows=kv_rows, save=False)
+    y_one, _ = ops.mha_core_fwd(q1, 0, kv, 0, kv, 512, *args, res1, g, b, 1e-6, 0.0, 0, kv_rows=kv_rows, save=False, q_rep=P)
+    assert torch.equal(y_one, y_rep)

@@ -131,10 +131,21 @@ int parity_dispatch(const GemmArgs& g, hipStream_t s, const SchedWs& ws, bool sm
   if (big) return parity_launch<typename F::T256, false>(g, s, ws);
   return parity_launch<typename F::T128, false>(g, s, ws);
 }
+// does the weight gradient run on the one-per-CU 256 x 256 tile (every value split once per workgroup)?  Where its
+// tiles x splits make about ONE round of the 256 slots: layer4's 3x3 (36 tiles x 8: 186 against 175 TFLOP/s on the
+// 256 x 128 tile, lab); at 2.25 rounds (the RPN's 1024 -> 512 3x3) the 256 x 128 tile's finer units win (158 against 152).
+inline bool coop_wgrad_takes(int M, int N, long long rows, int splits) {
+  if (M < 256 || N < 256 || (M & 3) || (N & 3) || rows < 4096) return false;
+  const long long units = (long long)((M + 255) / 256) * ((N + 255) / 256) * splits;
+  return units >= 128 && units <= 320;
+}
 template <class F>
-int wgrad_dispatch(const GemmArgs& g, hipStream_t s, const SchedWs& ws, bool grouped) {
+int wgrad_dispatch(const GemmArgs& g, hipStream_t s, const SchedWs& ws, bool grouped, bool coop) {
   // (grouped: 128-row tiles, one group of output channels per row tile)
   if (grouped) return conv_launch<typename F::T128, CONV_B, false, false, true>(g, s, ws);
+  if constexpr (std::is_same<F, SplitFam>::value) {
+    if (coop) return conv_launch<TileCoop, CONV_B, false, false>(g, s, ws);
+  }
   return conv_launch<typename F::T256, CONV_B, false, false>(g, s, ws);
 }
 }  // namespace
@@ -266,12 +277,13 @@ AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, i
   const int taps = q->kh * q->kw, G = q->groups > 1 ? q->groups : 1, cing = cin / G;
   GemmArgs g;
   // (general maps: the reduction runs over rows rounded up to a whole slab; see ConvGeom::n_rows)
+  const bool sp_coop = G == 1 && !bf16_products(ctx) && coop_wgrad_takes(cout, taps * cing, rows, split_k < 1 ? 1 : split_k);
   AIT_TRY_RC(make_args(1, 0, cout, taps * cing, (int)((rows + 15) / 16 * 16), 1.f, dy, lddy, x, ldx, dw, taps * cing, nullptr,
                        nullptr, AIT_GEMM_ATOMIC, split_k < 1 ? 1 : split_k, 0, 0, 16, g));
   g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
   if (general) set_general_rows(g.conv, q->out_h, q->out_w, rows);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), cout, taps * cing,
                       (int)rows, 1, 0, g.splits);
-  if (bf16_products(ctx)) return wgrad_dispatch<Bf16Fam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1);
-  return wgrad_dispatch<SplitFam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1);
+  if (bf16_products(ctx)) return wgrad_dispatch<Bf16Fam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1, false);
+  return wgrad_dispatch<SplitFam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1, sp_coop);
 }

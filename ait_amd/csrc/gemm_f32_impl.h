@@ -124,6 +124,26 @@ __device__ __forceinline__ int conv_src_row(const ConvGeom& c, int r, int tap) {
   const bool ok = ny >= 0 && nx >= 0 && ((ny | nx) & ((1 << c.div_shift) - 1)) == 0 && sy < c.src_h && sx < c.src_w;
   return ok ? (img * c.src_h + sy) * c.src_w + sx : -1;
 }
+// the same with the tap already decomposed (ty, tx): the weight gradient's tap is fixed per column tile, and tap / kw is
+// a ~35-instruction runtime division the transfers of every slab would repeat
+__device__ __forceinline__ int conv_src_row_t(const ConvGeom& c, int r, int ty, int tx) {
+  int img, y, x;
+  if (c.rows_hw_shift >= 0) {
+    img = r >> c.rows_hw_shift;
+    const int rem = r & ((1 << c.rows_hw_shift) - 1);
+    y = rem >> c.rows_w_shift;
+    x = rem & ((1 << c.rows_w_shift) - 1);
+  } else {
+    if (r >= c.n_rows) return -1;
+    int rem;
+    img = div_small(r, c.rows_hw, c.inv_hw, rem);
+    y = div_small(rem, c.rows_w, c.inv_w, x);
+  }
+  const int ny = y * c.a + c.c + ty * c.b, nx = x * c.a + c.c + tx * c.b;
+  const int sy = ny >> c.div_shift, sx = nx >> c.div_shift;
+  const bool ok = ny >= 0 && nx >= 0 && ((ny | nx) & ((1 << c.div_shift) - 1)) == 0 && sy < c.src_h && sx < c.src_w;
+  return ok ? (img * c.src_h + sy) * c.src_w + sx : -1;
+}
 
 // C / residual row of GEMM row r of a parity-class data gradient
 __device__ __forceinline__ unsigned conv_out_row(const ConvGeom& c, int r) {
@@ -777,6 +797,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   size_t step_b_cur = step_b;       // ROWMAP: the extra tap's weights have their own row pitch
   int l_item = 0, l_k = 0, l_kend = 0;
   int l_n0 = 0, l_m0 = 0;           // origin of the load cursor's tile (CONV kernels)
+  int l_ty = 0, l_tx = 0, l_ch0 = 0;   // CONV_B: the column tile's tap (row, column of the window) and first source channel (+ group offset)
   int arow[LA];                     // CONV_A: this lane's (clamped) GEMM row per A transfer
   bool l_valid = true;
   // CONV_A: operand pointers at reduction index l_k = tap * seg + kin
@@ -833,6 +854,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     if (!get_item(it, m0, n0, l_k, l_kend)) { l_valid = false; return; }
     l_n0 = n0;
     if constexpr (GRP || ROWMAP || CONV == CONV_B) l_m0 = m0;
+    if constexpr (CONV == CONV_B) {
+      const int tap = n0 / g.conv.seg;
+      l_ty = tap / g.conv.kw;
+      l_tx = tap - l_ty * g.conv.kw;
+      l_ch0 = n0 - tap * g.conv.seg + (GRP ? (m0 / g.conv.n_group) * g.conv.a_group : 0);
+    }
 #pragma unroll
     for (int i = 0; i < LA; i++) {
       const int q = wave + i * NW;
@@ -920,11 +947,10 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         if (CONV == CONV_B) {
           // weight gradient: row k of the K-outer operand is the source position that tap (fixed by the
           // column tile) pairs with GEMM row k; nothing to pair with -> the row of zeros
+          // (tap, channel offset and group of the column / row tile: l_ty, l_tx, l_ch0 -- set once per tile in set_tile)
           const int e = q * 256 + lane * 4;
-          const int tap = l_n0 / g.conv.seg, ch0 = l_n0 - tap * g.conv.seg;
-          const int gch = GRP ? (l_m0 / g.conv.n_group) * g.conv.a_group : 0;   // the row tile's group
-          const int src = conv_src_row(g.conv, l_k + e / BN, tap);
-          glds16_at((src >= 0 ? g.B + (size_t)src * g.ldb + gch + ch0 : g.conv.zero) + e % BN, dst);
+          const int src = conv_src_row_t(g.conv, l_k + e / BN, l_ty, l_tx);
+          glds16_at((src >= 0 ? g.B + (size_t)src * g.ldb + l_ch0 : g.conv.zero) + e % BN, dst);
         } else {
           glds16_at(pb[piece - LA], dst);
         }

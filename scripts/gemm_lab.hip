@@ -81,6 +81,9 @@ static const Shape SHAPES[] = {
     {"trans NT", 76800, 1024, 512, 0, 1, 1, AIT_GEMM_RELU},                // dec_trans shape (+ bias)
     {"xq    NT", 76800, 512, 512, 0, 1, 1, 0},                             // cross-attention query projection: 600 tiles of 32 slabs
     {"l4c3r NT", 19328, 2048, 512, 0, 1, 1, AIT_GEMM_RELU | LAB_RES},      // layer4 conv3 + shift + shortcut + ReLU
+    {"l4w2  TN", 512, 4608, 19328, 1, 0, 7, 0},                            // layer4 conv2's weight gradient as a plain product
+    {"l4w2  TN", 512, 4608, 19328, 1, 0, 8, 0},
+    {"rpnw  TN", 512, 9216, 9576, 1, 0, 8, 0},                             // the RPN convolution's weight gradient as a plain product
     // timing-only experiments (results meaningless): operand rows aliased onto one row (row pitch 0), so that
     // the loads are served from L1 / L2 whatever the tile -- what the kernel does with the memory system taken away
     {"qkv aA NT", 76800, 1536, 512, 0, 1, 1, LAB_ALIAS_A},
@@ -95,6 +98,7 @@ static const Shape SHAPES[] = {
     {"coatt NT", 9576, 512, 1024, 0, 1, 1, 0},
     // layer4 weight gradients at one K-range per XCD (their last round is cut evenly without scratch)
     {"l4w2  TN", 512, 4608, 19328, 1, 0, 8, 0},
+    {"rpnw  TN", 512, 9216, 9576, 1, 0, 8, 0},                             // the RPN convolution's weight gradient as a plain product
     {"l4w3  TN", 2048, 512, 19328, 1, 0, 8, 0},
     {"l4w1  TN", 512, 2048, 19328, 1, 0, 8, 0},
     {"qkvw8 TN", 1536, 512, 76800, 1, 0, 8, 0},

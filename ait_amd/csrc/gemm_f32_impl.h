@@ -797,12 +797,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   size_t step_b_cur = step_b;       // ROWMAP: the extra tap's weights have their own row pitch
   int l_item = 0, l_k = 0, l_kend = 0;
   int l_n0 = 0, l_m0 = 0;           // origin of the load cursor's tile (CONV kernels)
+  int l_kin = 0;                    // CONV_A: reduction index within the current tap (retap() sets it; no per-slab modulo)
   int l_ty = 0, l_tx = 0, l_ch0 = 0;   // CONV_B: the column tile's tap (row, column of the window) and first source channel (+ group offset)
   int arow[LA];                     // CONV_A: this lane's (clamped) GEMM row per A transfer
   bool l_valid = true;
   // CONV_A: operand pointers at reduction index l_k = tap * seg + kin
   auto retap = [&]() __attribute__((always_inline)) {
     const int tap = l_k / g.conv.seg, kin = l_k - tap * g.conv.seg;
+    l_kin = kin;
     int grp = 0, gch = 0;                          // GRP: the tile's group, its first channel in the gathered operand
     if constexpr (GRP) { grp = l_n0 / g.conv.n_group; gch = grp * g.conv.a_group; }
     const int col0 = GRP ? l_n0 - grp * g.conv.n_group : l_n0;
@@ -977,7 +979,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         }
       }
     } else if (CONV == CONV_A) {
-      if (l_k % g.conv.seg == 0) retap();      // next tap: new source rows (and, K-outer weights, new tap base)
+      l_kin += BK;
+      if (l_kin >= g.conv.seg) retap();        // next tap: new source rows (and, K-outer weights, new tap base)
     }
   };
   auto request = [&](int slot) __attribute__((always_inline)) {     // whole slab at once (prologue)

@@ -37,3 +37,9 @@ p = torch.randn(1200, 1024, 7, 7, device=dev, requires_grad=True); qq = torch.ra
 m.train()
 print("AIT transformer fwd       %.2f ms" % timeit(lambda: m.transformer(x_props=p, x_query=qq)))
 print("AIT transformer fwd+bwd   %.2f ms" % timeit(lambda: m.transformer(x_props=p, x_query=qq).sum().backward()))
+fi = torch.randn(4, 1024, 38, 63, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+fq = torch.randn(4, 1024, 8, 8, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+def coatt():
+    a, b = m.coattention(x_img=fi, x_qry=fq)
+    (a.sum() + b.sum()).backward()
+print("image-level co-attention fwd+bwd  %.2f ms" % timeit(coatt))

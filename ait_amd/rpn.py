@@ -694,18 +694,19 @@ class _Conv3x3BiasRelu(torch.autograd.Function):
 
 class _Heads1x1(torch.autograd.Function):
     """The RPN's two 1x1 heads (lib/model/rpn/rpn.py:34-43: 512 -> 2A objectness scores, 512 -> 4A box deltas) as ONE
-    product on the library's GEMM: the two weight matrices stacked and padded to 64 rows, y [tokens, 64] = x W^T + b on the
-    token rows of the channels-last feature; the two results are its column ranges.  Backward: the stacked gradient
-    [tokens, 64] -> dx = dy W, dW = dy^T x (split-K), db = column sums.  (MIOpen runs each head as its own rocBLAS call
+    product on the library's GEMM: the two weight matrices stacked and padded to a multiple of 64 rows (64 for 9 anchors,
+    128 for the COCO variant's 12), y [tokens, 64 | 128] = x W^T + b on the token rows of the channels-last feature; the two
+    results are its column ranges.  Backward: the stacked gradient -> dx = dy W, dW = dy^T x (split-K), db = column sums.  (MIOpen runs each head as its own rocBLAS call
     with N = 18 / 36.)"""
 
     @staticmethod
     def forward(ctx, xm, w1, b1, w2, b2):
         n1, n2, k = w1.shape[0], w2.shape[0], xm.shape[1]
-        W = torch.zeros((64, k), dtype=torch.float32, device=xm.device)
+        npad = (n1 + n2 + 63) // 64 * 64
+        W = torch.zeros((npad, k), dtype=torch.float32, device=xm.device)
         W[:n1] = w1.reshape(n1, k)
         W[n1:n1 + n2] = w2.reshape(n2, k)
-        bias = torch.zeros((64,), dtype=torch.float32, device=xm.device)
+        bias = torch.zeros((npad,), dtype=torch.float32, device=xm.device)
         bias[:n1] = b1
         bias[n1:n1 + n2] = b2
         y = ops.gemm(xm, W, bias=bias)
@@ -717,7 +718,7 @@ class _Heads1x1(torch.autograd.Function):
     def backward(ctx, d1, d2):
         xm, W = ctx.saved_tensors
         n1, n2, s1, s2 = ctx.sizes
-        dy = torch.zeros((xm.shape[0], 64), dtype=torch.float32, device=xm.device)
+        dy = torch.zeros((xm.shape[0], W.shape[0]), dtype=torch.float32, device=xm.device)
         dy[:, :n1] = d1
         dy[:, n1:n1 + n2] = d2
         dx = ops.gemm(dy, W, trans_b=False) if ctx.needs_input_grad[0] else None
@@ -772,7 +773,7 @@ class _RPN(nn.Module):
         else:
             conv = F.relu(c(base_feat), inplace=True)
         n_out = self.nc_score_out + self.nc_bbox_out
-        if (_RPN_HEADS_KERNEL and conv.is_cuda and conv.dtype == torch.float32 and n_out <= 64 and conv.shape[1] % 16 == 0
+        if (_RPN_HEADS_KERNEL and conv.is_cuda and conv.dtype == torch.float32 and n_out <= 256 and conv.shape[1] % 16 == 0
                 and conv.is_contiguous(memory_format=torch.channels_last)):
             n, ch, fh, fw = conv.shape
             ys, yb = _Heads1x1.apply(conv.permute(0, 2, 3, 1).reshape(n * fh * fw, ch), self.RPN_cls_score.weight,

@@ -82,7 +82,12 @@ def test_cfg34_coco_variant_8_pairs_300_proposals():
         for mod in m.modules():
             if hasattr(mod, "p") and isinstance(mod.p, float):
                 mod.p = 0.0
+        from ait_amd import ops
+        ops.reset_fallbacks()
         out, l1, g1 = _train_step(m, ins)
+        # (on a GPU the product path is the library's kernels: not one counted torch stand-in in the COCO variant either --
+        # e.g. its 12-anchor RPN heads, 24 + 48 outputs, on the stacked product)
+        assert ops.fallback_count() == 0, dict(ops.FALLBACKS)
         assert tuple(out[0].shape) == (8, 300, 5) and tuple(out[8].shape) == (8 * 300,)
         assert bool(torch.isfinite(l1).all())
         assert all(bool(torch.isfinite(g).all()) for g in g1.values())

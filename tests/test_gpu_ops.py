@@ -620,20 +620,22 @@ def test_convolution_epilogues_are_reproducible_launch_to_launch():
 
 
 @pytest.mark.gpu
-def test_rpn_heads_as_one_product_match_the_two_convolutions():
+@pytest.mark.parametrize("A", [9, 12])
+def test_rpn_heads_as_one_product_match_the_two_convolutions(A):
     """rpn._Heads1x1 (the RPN's objectness and box-delta 1x1 heads stacked into one 64-row product on the library's
     GEMM, lib/model/rpn/rpn.py:34-43) against the two convolutions in float64: outputs and every gradient, on a map
-    whose side is not a power of two."""
+    whose side is not a power of two; 9 anchors (VOC: 18 + 36 outputs in 64 rows) and 12 (COCO: 24 + 48 in 128)."""
     from ait_amd import rpn
     torch.manual_seed(5)
     n, c, h, w = 2, 512, 38, 63
     x = torch.randn(n, c, h, w, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    w1, b1 = (torch.randn(18, c, 1, 1, device="cuda") * 0.05).requires_grad_(True), torch.randn(18, device="cuda").requires_grad_(True)
-    w2, b2 = (torch.randn(36, c, 1, 1, device="cuda") * 0.05).requires_grad_(True), torch.randn(36, device="cuda").requires_grad_(True)
+    n1, n2 = 2 * A, 4 * A
+    w1, b1 = (torch.randn(n1, c, 1, 1, device="cuda") * 0.05).requires_grad_(True), torch.randn(n1, device="cuda").requires_grad_(True)
+    w2, b2 = (torch.randn(n2, c, 1, 1, device="cuda") * 0.05).requires_grad_(True), torch.randn(n2, device="cuda").requires_grad_(True)
     ys, yb = rpn._Heads1x1.apply(x.permute(0, 2, 3, 1).reshape(n * h * w, c), w1, b1, w2, b2)
-    ys = ys.reshape(n, h, w, 18).permute(0, 3, 1, 2)
-    yb = yb.reshape(n, h, w, 36).permute(0, 3, 1, 2)
-    g1, g2 = torch.randn(n, 18, h, w, device="cuda"), torch.randn(n, 36, h, w, device="cuda")
+    ys = ys.reshape(n, h, w, n1).permute(0, 3, 1, 2)
+    yb = yb.reshape(n, h, w, n2).permute(0, 3, 1, 2)
+    g1, g2 = torch.randn(n, n1, h, w, device="cuda"), torch.randn(n, n2, h, w, device="cuda")
     grads = torch.autograd.grad([ys, yb], [x, w1, b1, w2, b2], [g1, g2])
     xd, w1d, b1d, w2d, b2d = (t.detach().double().requires_grad_(True) for t in (x, w1, b1, w2, b2))
     rs, rb = torch.nn.functional.conv2d(xd, w1d, b1d), torch.nn.functional.conv2d(xd, w2d, b2d)

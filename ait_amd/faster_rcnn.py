@@ -41,6 +41,21 @@ from .system import MultiHeadAttention, Transformer, _Linear, _split_k, conv2d_1
 #   _TOP_NHWC / _BASE_NHWC / _ROI_NHWC   channels-last activations in the proposal tail / the C4 trunk / RoIAlign (the
 #                AIT's token-major output IS channels-last); False = NCHW everywhere, the tests' reference configuration
 _SK_FULL = False
+_QUERY_SIDE_STREAM = True   # test hook: False = the query trunk on the step's own stream, behind the image's
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        # (the trunk's parameters receive gradients from both streams: intended, not a stale graph)
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
+    return st
+
 _TAIL_FUSED = True
 _TOP_NHWC = True
 _BASE_NHWC = True
@@ -642,8 +657,21 @@ class _fasterRCNN(nn.Module):
 
         # (one program at every world size: the query trunk's launches are eager on the step's stream.  Round 3 replayed
         # them from HIP graphs on a side stream at N = 1 only -- 0 ms measured un-profiled, profiles/README_r03.md)
-        image_feat, _ = self.RCNN_base(image)                 # [bs, 1024, H_i, W_i]
-        query_feat = self.RCNN_base(query)[0]                 # [bs, 1024, 8, 8]
+        if _QUERY_SIDE_STREAM and image.is_cuda:
+            # the query patches' trip through the trunk is ~130 launches of a few microseconds each on 1/40 of the image's
+            # pixels: on a second stream it runs in the shadow of the image's (autograd replays each node's backward on
+            # the stream of its forward, so the backward overlaps the same way)
+            cur = torch.cuda.current_stream(image.device)
+            side = _side_stream(image.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                query_feat = self.RCNN_base(query)[0]             # [bs, 1024, 8, 8]
+            image_feat, _ = self.RCNN_base(image)                 # [bs, 1024, H_i, W_i]
+            cur.wait_stream(side)
+            query_feat.record_stream(cur)
+        else:
+            image_feat, _ = self.RCNN_base(image)                 # [bs, 1024, H_i, W_i]
+            query_feat = self.RCNN_base(query)[0]                 # [bs, 1024, 8, 8]
         if self.variant == 'coco':
             non_img, non_qry = self.coattention_module(image_feat, query_feat)
         else:

@@ -124,11 +124,14 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(
         if (rb + 2 < nb) next_crit = r[1];
       }
       unsigned long long cw = 0ull;      // what this block's survivors suppress in block rb + 1
-      for (int i = 0; i < cnt; i++) {
-        if (!((word >> i) & 1ull)) {       // uniform branch: row i survives
-          word |= readlane64(diag, i);
-          cw |= readlane64(crit, i);
-        }
+      // one step per SURVIVOR, not per row (a block keeps ~10 of its 64): the lowest row still alive survives, its
+      // diagonal word removes rows above it (s_ff1 on the scalar side finds the next one)
+      for (unsigned long long todo = ~word; todo;) {
+        const int i = __builtin_ctzll(todo);
+        const unsigned long long d = readlane64(diag, i);
+        word |= d;
+        cw |= readlane64(crit, i);
+        todo = (todo & (todo - 1ull)) & ~d;
       }
       diag = next_diag;
       crit = next_crit;

@@ -4,12 +4,12 @@
 out=$1; tag=$2; root=$(pwd)
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/trace" --output-format csv -- python3 "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-ab > "$root/$out/bench_under_prof.json" 2> "$root/$out/trace.err"
+timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/trace" --output-format csv -- python3 "$root/bench.py" --steps 10 --warmup 5 --no-cpu-baseline --no-ab > "$root/$out/bench_under_prof.json" 2> "$root/$out/trace.err"
 cd "$root"
-python3 scripts/trace_stats.py "$out/trace" 2 5 "$out/${tag}_timed_region_kernel_stats.csv" > /dev/null 2>&1
-python3 scripts/trace_categories.py "$out/${tag}_timed_region_kernel_stats.csv" 5 > "$out/${tag}_categories.txt" 2>&1
-python3 scripts/trace_gaps.py "$out/trace" 2 5 20 >> "$out/${tag}_categories.txt" 2>&1
-python3 scripts/trace_timeline.py "$out/trace" 2 5 > "$out/${tag}_step_timeline.txt" 2>&1
+python3 scripts/trace_stats.py "$out/trace" 5 10 "$out/${tag}_timed_region_kernel_stats.csv" > /dev/null 2>&1
+python3 scripts/trace_categories.py "$out/${tag}_timed_region_kernel_stats.csv" 10 > "$out/${tag}_categories.txt" 2>&1
+python3 scripts/trace_gaps.py "$out/trace" 5 10 20 >> "$out/${tag}_categories.txt" 2>&1
+python3 scripts/trace_timeline.py "$out/trace" 5 10 > "$out/${tag}_step_timeline.txt" 2>&1
 cp "$(find "$out/trace" -name "*kernel_stats.csv" -printf "%s %p\n" | sort -rn | head -1 | cut -d" " -f2-)" "$out/${tag}_full_run_kernel_stats.csv" 2>/dev/null   # the largest: bench.py's own process, not the mfma_peak child
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do

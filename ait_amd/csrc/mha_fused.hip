@@ -317,7 +317,11 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
 
 constexpr size_t kFusedLds = (size_t)(kHeads * kPanel + kPanel + kHeads * 64 + kDm + 64 + 128 + 64) * sizeof(float);
 
-unsigned long long* g_prof = nullptr;
+#ifdef AIT_MHA_PROF
+unsigned long long* g_prof = nullptr;      // lab builds only (-DAIT_MHA_PROF: phase stamps, profiles/r04_mha_fused.txt)
+#else
+constexpr unsigned long long* g_prof = nullptr;
+#endif
 }  // namespace
 #ifdef AIT_MHA_PROF
 AIT_API void ait_mha_core_set_prof(unsigned long long* p) { g_prof = p; }

@@ -208,6 +208,7 @@ enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8, KNOB_SP
                          LDS image in the P3 row format, and the MFMAs of the current slab fetch ready planes (no vector work on
                          the matrix side).  One main loop for every operand layout: only the split stage looks at the raw image */,
        KNOB_NOTICKET = 512 /* no ticket ring in LDS: static work lists only (a ring of four 40-KB slabs is all of the CU's 160 KB) */,
+       KNOB_F16X2 = 4096 /* LAB ONLY, with KNOB_SPLIT: two fp16 planes per value, three f16 MFMAs per block (split_planes.h) */,
        KNOB_AP3 = 2048 /* with KNOB_BP3: operand A arrives pre-split as well (an activation whose producer wrote the P3 form
                           beside the f32 one): no vector work at all on the matrix side, planes of both operands by LDS-DMA */,
        KNOB_BP3 = 256 /* with KNOB_SPLIT: operand B arrives PRE-SPLIT ("P3": the three bf16 planes of every value, interleaved in
@@ -1009,7 +1010,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // planes being formed under the MFMAs (nap: the next A tile; nbp: the NEXT slab's B tiles) and two raw operand
   // tiles in flight from LDS (rw): every region of six MFMAs splits what the region before it fetched.
   constexpr bool kPipe = kSplit && (C::KNOBS & KNOB_SPLIT_SIMPLE) == 0 && !kBp3 && !kCoop;
-  constexpr int kTerms = (C::KNOBS & KNOB_BF16) != 0 ? 1 : 6;
+  constexpr int kTerms = (C::KNOBS & KNOB_BF16) != 0 ? 1 : (C::KNOBS & KNOB_F16X2) != 0 ? 3 : 6;
   constexpr bool kRne = (C::KNOBS & KNOB_RNE) != 0;
   static_assert(!kPipe || (C::TM >= 2 && C::TN >= 2 && C::TN <= C::TM && (C::TM * C::TN) % 2 == 0), "split schedule");
   float4 sa0, sa1, sb0[C::TN], sb1[C::TN];
@@ -1084,7 +1085,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   if constexpr (kCoop) {
     float4 q[4];
     coop_read(0, q);
-    coop_write(0, split8<6, kRne>(q[0], q[1]), split8<6, kRne>(q[2], q[3]));
+    coop_write(0, split8<kTerms == 3 ? 3 : 6, kRne>(q[0], q[1]), split8<kTerms == 3 ? 3 : 6, kRne>(q[2], q[3]));
     ring_barrier();          // plane image 0 complete; raw slot 0 free for slab 2
   } else if constexpr (kBp3) {
     prime3(0);
@@ -1167,7 +1168,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
             __builtin_amdgcn_sched_barrier(0);
             if (r + 1 < kPairs) fetch_planes(pb_img, wn, (b + 1) % C::TN, pB[nx]);
             if (r == 0) coop_read(nxt, q);
-            {
+            if constexpr (kTerms == 3) {        // LAB (KNOB_F16X2): planes 0 / 1 hold fp16 h / l
+              Planes x, y;
+              x.h = pA[0]; x.m = pA[1]; x.l = pA[1];
+              y.h = pB[pr][0]; y.m = pB[pr][1]; y.l = pB[pr][1];
+              acc[a][b] = mfma_split<3>(x, y, acc[a][b]);
+            } else {
               f32x16 c = acc[a][b];
               c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[2], pB[pr][0], c, 0, 0, 0);
               c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[0], pB[pr][2], c, 0, 0, 0);
@@ -1176,8 +1182,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
               c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[0], pB[pr][1], c, 0, 0, 0);
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[0], pB[pr][0], c, 0, 0, 0);
             }
-            if (r == 1) slo = split8<6, kRne>(q[0], q[1]);
-            if (r == 3) shi = split8<6, kRne>(q[2], q[3]);
+            if (r == 1) slo = split8<kTerms == 3 ? 3 : 6, kRne>(q[0], q[1]);
+            if (r == 3) shi = split8<kTerms == 3 ? 3 : 6, kRne>(q[2], q[3]);
             if (r == 5) coop_write(nxt, slo, shi);
             __builtin_amdgcn_sched_barrier(0);
             if (r < NP) {

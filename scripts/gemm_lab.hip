@@ -46,6 +46,8 @@ using V_bf16 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BF16>;
 using V_bp3 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3>;    // B pre-split (P3), 8 waves of 64x128, one workgroup per CU
 using V_bp3r = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3 | KNOB_RNE>;
 using V_ab3 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3 | KNOB_AP3 | KNOB_RNE>;   // both operands pre-split: no vector work
+using V_f16x2 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD | KNOB_SPLIT | KNOB_F16X2>;   // two fp16 planes, three MFMAs per block (LAB)
+using V_f16x2c = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_COOP | KNOB_NOTICKET | KNOB_F16X2>;   // ... on the cooperative tile (LAB)
 using V_bp3p = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_COOP | KNOB_NOTICKET | KNOB_RNE>;     // every value split once per workgroup (LDS plane image)
 using V_bp3n4 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_BP3 | KNOB_NOTICKET>;
 using V_bp3n4p = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_BP3 | KNOB_NOTICKET | KNOB_PRIO>;
@@ -105,6 +107,10 @@ static const Shape SHAPES[] = {
 };
 static const int NSHAPES = sizeof(SHAPES) / sizeof(SHAPES[0]);
 
+__global__ void scale_kernel(float* p, size_t n, float s) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] *= s;
+}
 __global__ void fill_kernel(float* p, size_t n, unsigned seed) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -137,6 +143,11 @@ static void setup(Problem& p, const Shape& s) {
   fill_kernel<<<2048, 256>>>(p.A, na, 0x1234567u);
   fill_kernel<<<2048, 256>>>(p.B, nb, 0x89abcdeu);
   fill_kernel<<<64, 256>>>(p.bias, (size_t)s.N, 0x5555u);
+  if (const char* e = getenv("LAB_DATA_SCALE")) {      // operands multiplied by 2^-e: how the lab fp16 form behaves on small values
+    const float sc = ldexpf(1.f, -atoi(e));
+    scale_kernel<<<2048, 256>>>(p.A, na, sc);
+    scale_kernel<<<2048, 256>>>(p.B, nb, sc);
+  }
   CK(hipMemset(p.C, 0, nc * 4)); CK(hipMemset(p.C2, 0, nc * 4));
   p.Bp3 = nullptr;
   p.Ap3 = nullptr;
@@ -194,7 +205,7 @@ static int run_tile(const GemmArgs& g, bool ak, bool bk, int slots) {
   return run_epi<T, false, true, NoProbe>(g, slots);
 }
 static const char* VNAMES[] = {"old", "new", "probe", "burst", "prio", "ring4", "ring4+burst", "4waves", "4waves+burst",
-                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "split rne", "bp3 256sq", "bp3 rne", "bf16 x1", "coop 256sq", "bp3 ring4", "bp3 ring4 prio", "ap3+bp3"};
+                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "split rne", "bp3 256sq", "bp3 rne", "bf16 x1", "coop 256sq", "bp3 ring4", "bp3 ring4 prio", "ap3+bp3", "f16x2 4w", "f16x2 coop"};
 template <class Probe>
 static int run_new(const GemmArgs& g, bool ak, bool bk, int slots) {
   if (!ak && !bk) return run_epi<NewD4, false, false, Probe>(g, slots);
@@ -277,6 +288,8 @@ static int run(Problem& p, int variant, float* out) {
     case 19: return run_tile<V_rne>(g, ak, bk, g_slots);
     case 22: return run_tile<V_bf16>(g, ak, bk, g_slots);
     case 23: return run_tile<V_bp3p>(g, ak, bk, g_slots);
+    case 27: return run_tile<V_f16x2>(g, ak, bk, g_slots);
+    case 28: return run_tile<V_f16x2c>(g, ak, bk, g_slots);
     case 20: case 21: case 24: case 25: case 26: {
       if (!p.Bp3 || (p.s.flags & (LAB_ALIAS_A | LAB_ALIAS_B))) return -99;
       g.B = reinterpret_cast<const float*>(p.Bp3);
@@ -381,6 +394,7 @@ static void mode_sweep(int rounds, int first, int last) {
       const int rc = run(p, vs[i], p.C2);
       CK(hipDeviceSynchronize());
       const double md = rc == 0 ? max_diff(p, 1) : -1.0;
+      if (getenv("LAB_PRINT_DIFF")) fprintf(stderr, "  %s / %s: max |diff| / max |ref| = %.3g\n", p.s.name, VNAMES[vs[i]], md);
       if (rc != 0 || md > (vs[i] == 22 ? 3e-2 : 2e-5)) { ok[i] = 0; fprintf(stderr, "  %s / %s: rc %d, max |diff| / max |ref| = %.3g\n", p.s.name, VNAMES[vs[i]], rc, md); }      // stream-K and split-K change the summation order
       if (rc == 0) time_launches(p, vs[i], p.C2, 3);
     }

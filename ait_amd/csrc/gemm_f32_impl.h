@@ -105,6 +105,14 @@ __device__ __forceinline__ int div_small(int n, int d, float inv, int& rem) {
   return q;
 }
 
+// KNOB_F16X2: the power of two that brings a tensor of maximum magnitude m into [2^13, 2^14) (fp16: 65504 at most)
+__device__ __forceinline__ float f16_scale_for(float m) {
+  const unsigned e = (__float_as_uint(m) >> 23) & 0xffu;       // biased exponent of the maximum
+  if (e == 0u || e == 0xffu) return 1.f;                        // zero / denormal / inf-nan tensors: left alone
+  const int se = 127 + 13 - ((int)e - 127);
+  return __uint_as_float((unsigned)min(max(se, 1), 254) << 23);
+}
+
 __device__ __forceinline__ int conv_src_row(const ConvGeom& c, int r, int tap) {
   int img, y, x;
   if (c.rows_hw_shift >= 0) {
@@ -172,6 +180,8 @@ struct GemmArgs {
   int k_per_split;
   int splits;
   unsigned long long* probe;   // diagnostic stamps (scripts/gemm_lab.hip); NULL in the product
+  const float* absmax_a;       // KNOB_F16X2: max |A|, max |B| (device scalars written by ait_absmax_f32; NULL = operands already
+  const float* absmax_b;       //   in fp16's range).  Each operand is multiplied by the power of two that brings its maximum to [2^13, 2^14)
   ConvGeom conv;               // CONV != 0 kernels only
   int batch, batch2;           // register-staged kernels: independent problems along gridDim.y (x gridDim.z) ...
   long long sA, sB, sC;        // ... whose operands are this many floats apart
@@ -1012,6 +1022,21 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   constexpr bool kPipe = kSplit && (C::KNOBS & KNOB_SPLIT_SIMPLE) == 0 && !kBp3 && !kCoop;
   constexpr int kTerms = (C::KNOBS & KNOB_BF16) != 0 ? 1 : (C::KNOBS & KNOB_F16X2) != 0 ? 3 : 6;
   constexpr bool kRne = (C::KNOBS & KNOB_RNE) != 0;
+  // KNOB_F16X2: power-of-two operand scales from the tensors' maxima, and the inverse of their product for the result
+  float f16_sa = 1.f, f16_sb = 1.f, f16_inv = 1.f;
+  if constexpr (kTerms == 3) {
+    f16_sa = g.absmax_a ? f16_scale_for(*g.absmax_a) : 1.f;
+    f16_sb = g.absmax_b ? f16_scale_for(*g.absmax_b) : 1.f;
+    f16_inv = 1.f / (f16_sa * f16_sb);          // (powers of two: exact)
+  }
+  auto split_a = [&](float4 p, float4 q) __attribute__((always_inline)) -> Planes {
+    if constexpr (kTerms == 3) { p.x *= f16_sa; p.y *= f16_sa; p.z *= f16_sa; p.w *= f16_sa; q.x *= f16_sa; q.y *= f16_sa; q.z *= f16_sa; q.w *= f16_sa; }
+    return split8<kTerms, kRne>(p, q);
+  };
+  auto split_b = [&](float4 p, float4 q) __attribute__((always_inline)) -> Planes {
+    if constexpr (kTerms == 3) { p.x *= f16_sb; p.y *= f16_sb; p.z *= f16_sb; p.w *= f16_sb; q.x *= f16_sb; q.y *= f16_sb; q.z *= f16_sb; q.w *= f16_sb; }
+    return split8<kTerms, kRne>(p, q);
+  };
   static_assert(!kPipe || (C::TM >= 2 && C::TN >= 2 && C::TN <= C::TM && (C::TM * C::TN) % 2 == 0), "split schedule");
   float4 sa0, sa1, sb0[C::TN], sb1[C::TN];
   Planes bp[C::TN], nbp[C::TN], ap, nap;
@@ -1020,8 +1045,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   auto prime = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
     for (int b = 0; b < C::TN; b++)
-      bp[b] = split8<kTerms, kRne>(fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 0, b), fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 1, b));
-    ap = split8<kTerms, kRne>(fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 0), fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 0));
+      bp[b] = split_b(fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 0, b), fetch_tile<BKC, BN>(Bd + slot * SB, wn, li, lk, 1, b));
+    ap = split_a(fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 0), fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 0));
     rw[0][0] = fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 0, 1);
     rw[0][1] = fetch_tile<AK, BM>(As + slot * SA, wm, li, lk, 1, 1);
   };
@@ -1297,8 +1322,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
             }
             // ---- the region's MFMAs and the split of what the previous region fetched
             acc[a][b] = mfma_split<kTerms>(ap, bp[b], acc[a][b]);
-            if (b == 0) nap = split8<kTerms, kRne>(rw[pr][0], rw[pr][1]);
-            else if (b == 1 && a < C::TN) nbp[a] = split8<kTerms, kRne>(rw[pr][0], rw[pr][1]);
+            if (b == 0) nap = split_a(rw[pr][0], rw[pr][1]);
+            else if (b == 1 && a < C::TN) nbp[a] = split_b(rw[pr][0], rw[pr][1]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr ((C::KNOBS & KNOB_BURST) == 0) {
 #pragma unroll
@@ -1437,6 +1462,14 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       cur = nxt;
     }
     if constexpr (Probe::on) { c_loop += __builtin_amdgcn_s_memtime() - c0; n_tile++; }
+    if constexpr (kTerms == 3) {     // the product of the operand scales out of the sums (before any hand-off of partial tiles)
+#pragma unroll
+      for (int a = 0; a < C::TM; a++)
+#pragma unroll
+        for (int b = 0; b < C::TN; b++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[a][b][r] *= f16_inv;
+    }
     bool finish = true;          // this workgroup writes the tile
     if (EPI != EPI_ATOMIC && item < n_sk && (kbeg != 0 || kend != g.K)) {
       // Inter-workgroup hand-off in the write-through form: every byte of a partial tile is stored sc1
@@ -1881,6 +1914,7 @@ inline int make_args(int trans_a, int trans_b, int M, int N, int K, float alpha,
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.c_colblk = c_colblk; g.c_batch = c_batch_stride; g.alpha = alpha; g.flags = flags;
   g.probe = nullptr;
+  g.absmax_a = g.absmax_b = nullptr;
   g.gate = nullptr;
   g.sk_on = 0;
   g.sk_ws = nullptr;

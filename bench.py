@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--no-ab", action="store_true", help="skip the f32_native A/B steps behind the timed region")
     ap.add_argument("--gemm-table", default=None, metavar="PATH",
                     help="also write the timed region's GEMM launches grouped by shape (launches/step, ms/step, TFLOP/s)")
-    ap.add_argument("--dtype", choices=["f32", "f32_native", "bf16", "bf16x3"], default=None,
+    ap.add_argument("--dtype", choices=["f32", "f32_native", "f32_f16x2", "bf16", "bf16x3"], default=None,
                     help="matmul arithmetic of the AIT GEMMs.  f32 is the headline / parity "
                          "configuration; bf16 is the BASELINE cfg-5 arithmetic (operands rounded to bf16, "
                          "fp32 accumulate) and is reported as such, never as the headline number")
@@ -285,9 +285,10 @@ def main():
 
     # A/B beside the headline, OUTSIDE its timed region (every rank runs it: the steps hold collectives): the same step
     # with the AIT's products on the instruction that multiplies f32 operands (v_mfma_f32_32x32x2_f32)
-    ab_native_ms = None
-    if args.dtype == "f32" and not args.no_ab:
-        ops.set_matmul_dtype("f32_native")
+    ab_native_ms = ab_f16x2_ms = None
+
+    def ab_run(mode):
+        ops.set_matmul_dtype(mode)
         try:
             for _ in range(2):
                 step()
@@ -299,9 +300,15 @@ def main():
                 step()
             torch.cuda.synchronize()
             D.barrier()
-            ab_native_ms = D.max_over_ranks(time.perf_counter() - ta, device) / n_ab * 1e3
+            return D.max_over_ranks(time.perf_counter() - ta, device) / n_ab * 1e3
         finally:
             ops.set_matmul_dtype(args.dtype)
+
+    if args.dtype == "f32" and not args.no_ab:
+        ab_native_ms = ab_run("f32_native")
+        # ... and with the AIT's dense products in the EXPERIMENTAL two-scaled-fp16-planes form (three MFMAs per block,
+        # two extra max-reduction passes per product; opt-in, NOT the headline: profiles/r04_gemm_lab_f16x2.txt)
+        ab_f16x2_ms = ab_run("f32_f16x2")
 
     # on a GPU box the product path is the library's kernels: not one torch stand-in may have run
     if ops.fallback_count() != 0:
@@ -332,8 +339,8 @@ def main():
     # dense MFMA peak for the arithmetic: fp32, bf16, or bf16 / 3 MFMAs per product
     # (f32: the bf16 pipe's dense peak over the SIX MFMAs an f32 block product costs on it -- the ceiling of the split
     # form; the f32 instruction's own peak is reported beside it)
-    peak = {"f32": 2500.0 / 6, "f32_native": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.dtype]
-    is_f32 = args.dtype in ("f32", "f32_native")
+    peak = {"f32": 2500.0 / 6, "f32_native": PEAK_F32_MFMA_TFLOPS, "f32_f16x2": 2500.0 / 3, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.dtype]
+    is_f32 = args.dtype in ("f32", "f32_native", "f32_f16x2")
     pmc = pmc_traffic_per_launch() if is_f32 else None
     # algorithmic bytes of the same launches: each operand read once, the output written once
     alg = sum(4.0 * (p[2][0] * p[2][2] + p[2][1] * p[2][2] + p[2][0] * p[2][1]) for p in prof) / max(1, len(prof))
@@ -359,6 +366,8 @@ def main():
                          "three bf16 values (round to nearest), six v_mfma_f32_32x32x16_bf16 per block, dropped terms <= 2^-23 |a b|)",
                   "f32_native": "f32 (AIT products on v_mfma_f32_32x32x2_f32; the proposal tail's and the RPN head's convolutions "
                                 "keep the split-bf16 form)",
+                  "f32_f16x2": "EXPERIMENTAL (not the headline): f32 tensors, the AIT's dense products from two fp16 planes per value under a "
+                               "power-of-two scale per tensor, three v_mfma_f32_32x32x16_f16 per block (22 bits, not an exact split)",
                   "bf16": "bf16 products (AIT GEMMs and the proposal tail's convolutions: operands rounded to bf16 in registers, one MFMA per block, f32 accumulate); f32 storage; f32 trunk / LayerNorm / attention tiles",
                   "bf16x3": "f32 emulated as 3 bf16 MFMAs per product (experimental; fp32 accumulate)"}[args.dtype],
         "data": "synthetic",
@@ -382,7 +391,7 @@ def main():
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak,
                      "peak_is": {"f32": "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per f32 block product",
-                                 "f32_native": "v_mfma_f32_32x32x2_f32 dense peak", "bf16": "dense bf16 MFMA",
+                                 "f32_native": "v_mfma_f32_32x32x2_f32 dense peak", "f32_f16x2": "2500 TFLOP/s dense f16 MFMA / 3 MFMAs per block product", "bf16": "dense bf16 MFMA",
                                  "bf16x3": "dense bf16 MFMA / 3"}[args.dtype],
                      "f32_instruction_peak": PEAK_F32_MFMA_TFLOPS,
                      "achieved_over_f32_instruction_peak": achieved / PEAK_F32_MFMA_TFLOPS if is_f32 else None,
@@ -420,7 +429,11 @@ def main():
                   % (k + (n // args.steps, 1e3 * ms / n, fl / (ms / n) / 1e9, ms / args.steps)), file=sys.stderr)
     r = line["roofline"]
     if ab_native_ms is not None:
-        line["ab"] = {"f32_native_ms_per_step": ab_native_ms, "f32_native_pairs_per_s": world * args.bs / (ab_native_ms * 1e-3),
+        line["ab"] = {"f32_f16x2_experimental_ms_per_step": ab_f16x2_ms,
+                      "f32_f16x2_what": "EXPERIMENTAL opt-in form, not the headline: the AIT's dense products (not the convolutions) from two "
+                                        "fp16 planes per value under a power-of-two scale per tensor, three MFMAs per block, max-reductions "
+                                        "of both operands in front of every product (ops.set_matmul_dtype('f32_f16x2'))",
+                      "f32_native_ms_per_step": ab_native_ms, "f32_native_pairs_per_s": world * args.bs / (ab_native_ms * 1e-3),
                       "what": "the same step with the AIT's products formed by v_mfma_f32_32x32x2_f32 (--dtype f32_native), "
                               "run right after the timed region; the tail's and the RPN head's convolutions keep the split form"}
     r["frac_of_measured_peak"] = (achieved / r["measured_peak"]) if r.get("measured_peak") else None

@@ -78,6 +78,12 @@ const char* ait_strerror(int code);
  * ------------------------------------------------------------------------------------- */
 #define AIT_CTX_NATIVE_F32 1u
 #define AIT_CTX_BF16 2u
+/* EXPERIMENTAL, opt-in: the dense f32 products (ait_gemm_f32 and the composites built on it; not the convolutions) from TWO
+ * fp16 planes per operand value under a power-of-two scale per tensor -- three v_mfma_f32_32x32x16_f16 per block instead of the
+ * six bf16 ones of the default form.  Each product first reduces max |A| and max |B| (two extra passes over the operands)
+ * and scales them to [2^13, 2^14).  NOT an exact split: 22 significant bits for values within 2^-17 of their tensor's
+ * maximum, an absolute error of 2^-39 max|x| below that (profiles/r04_gemm_lab_f16x2.txt).  Needs sched_ws. */
+#define AIT_CTX_F16X2 4u
 typedef struct {
   void* sched_ws;
   size_t sched_ws_bytes;

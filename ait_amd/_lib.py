@@ -215,8 +215,6 @@ _ACTIVE_PROBE = None
 USE_SCHED_WS = True  # test hook: False = launch without scheduler scratch (static work lists, whole tiles)
 CTX_NATIVE_F32 = 1   # ait_launch_ctx::flags
 CTX_BF16 = 2
-CTX_F16X2 = 4
-F16X2 = False   # ops.set_matmul_dtype("f32_f16x2"): EXPERIMENTAL two scaled fp16 planes, three MFMAs per block
 NATIVE_F32 = False   # ops.set_matmul_dtype("f32_native"): dense products on v_mfma_f32_32x32x2_f32 (default: bf16 3-way split)
 BF16_PRODUCTS = False   # ops.set_matmul_dtype("bf16"): operands rounded to bf16 in registers, one MFMA per block
 
@@ -252,8 +250,6 @@ def launch_ctx(device=None):
         ctx.probe = pr._p
     if BF16_PRODUCTS:
         ctx.flags = CTX_BF16
-    elif F16X2:
-        ctx.flags = CTX_F16X2
     elif NATIVE_F32:
         ctx.flags = CTX_NATIVE_F32
     return ctypes.byref(ctx)

@@ -5,7 +5,7 @@
 
 
 
-AIT_API int ait_abi_version(void) { return 5; }
+AIT_API int ait_abi_version(void) { return 6; }
 
 AIT_API const char* ait_strerror(int code) {
   switch (code) {

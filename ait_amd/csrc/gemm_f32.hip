@@ -65,50 +65,11 @@ using Tile64 = Cfg<64, 64, 16, 2, 2, 2, MODE_DB>;
 //              operands are activations, K-outer: nothing to pre-split): 203-204 TF/s against 185 for Tile256D on the
 //              transformer's shapes (profiles/r04_gemm_lab_coop.txt).  Static work lists (its LDS is the CU's 160 KB).
 using TileCoop = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_COOP | KNOB_NOTICKET | KNOB_RNE>;
-//   Tile256F   EXPERIMENTAL, opt-in (AIT_CTX_F16X2): every operand value as TWO fp16 planes under a power-of-two scale per
-//              tensor, three v_mfma_f32_32x32x16_f16 per block instead of six bf16 ones (profiles/r04_gemm_lab_f16x2.txt:
-//              246-276 TFLOP/s on this tile).  Not an exact split: x 2^s = h + l to 22 bits for values within 2^-17 of the
-//              tensor's maximum, an absolute error of 2^-39 max|x| below that.
-using Tile256F = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD | KNOB_SPLIT | KNOB_F16X2>;
-
-// max |x| over a [rows, cols] matrix (row pitch ld), as the bits of a non-negative float (which order like unsigned
-// integers): one atomicMax per wave into *out (zeroed by the caller)
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long rows, int cols, long long ld,
-                                                     unsigned* __restrict__ out) {
-  // a wave per group of four rows (four independent row segments in flight per lane), lanes along the row in 16-B steps
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c4 = cols / 4;
-  unsigned m = 0u;
-  for (long long r0 = ((long long)blockIdx.x * 4 + wave) * 4; r0 < rows; r0 += (long long)gridDim.x * 16) {
-    for (int j = lane; j < c4; j += 64) {
-      float4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const long long r = r0 + u < rows ? r0 + u : rows - 1;
-        v[u] = *reinterpret_cast<const float4*>(x + r * ld + 4 * j);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-        m = max(max(m, __float_as_uint(fabsf(v[u].x))),
-                max(__float_as_uint(fabsf(v[u].y)), max(__float_as_uint(fabsf(v[u].z)), __float_as_uint(fabsf(v[u].w)))));
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-  if (lane == 0 && m) atomicMax(out, m);
-}
-int absmax(const float* x, long long rows, int cols, long long ld, float* out, hipStream_t s) {
-  const long long want = (rows + 15) / 16;
-  const unsigned blocks = (unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096);
-  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, rows, cols, ld, reinterpret_cast<unsigned*>(out));
-  AIT_CHECK_LAUNCH();
-  return AIT_OK;
-}
 }  // namespace
 
 // the weight-gradient launches the cooperative-split tile takes (csrc/transformer.hip sizes its K-splits for the tile)
 bool ait_gemm_coop_takes(int trans_a, int trans_b, int M, int N, int K, int flags, const ait_launch_ctx* ctx) {
-  if (ctx && (ctx->flags & (AIT_CTX_NATIVE_F32 | AIT_CTX_BF16 | AIT_CTX_F16X2))) return false;
+  if (ctx && (ctx->flags & (AIT_CTX_NATIVE_F32 | AIT_CTX_BF16))) return false;
   return trans_a && !trans_b && (flags & AIT_GEMM_ATOMIC) && M >= 256 && N >= 256 && (M % 4) == 0 && (N % 4) == 0 &&
          K >= 4096 && (K % 16) == 0;
 }
@@ -160,18 +121,6 @@ int ait_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, float alpha, 
       (long long)((M + 255) / 256) * ((N + 255) / 256) * g.splits >= 128)
     return launch<TileCoop, false, false, EPI_ATOMIC>(g, ait_stream(stream), ws);
   if (M >= 512 && (tiles256 >= 512 || few_tiles_sk)) {
-    if (direct && ctx && (ctx->flags & AIT_CTX_F16X2) && ws.p && (M % 4) == 0 && (N % 4) == 0 && (K % 4) == 0) {
-      // EXPERIMENTAL: two scaled fp16 planes per value.  The two maxima land in the control area of the caller's
-      // scheduler scratch (launches on one stream are ordered, so every product reuses the same two words)
-      float* mx = reinterpret_cast<float*>(static_cast<char*>(ws.p) + kCtlBytes - 64);
-      hipStream_t hs = ait_stream(stream);
-      if (hipMemsetAsync(mx, 0, 8, hs) != hipSuccess) return AIT_ELAUNCH;
-      if (absmax(A, trans_a ? K : M, trans_a ? M : K, lda, mx, hs) != AIT_OK) return AIT_ELAUNCH;
-      if (absmax(B, trans_b ? N : K, trans_b ? K : N, ldb, mx + 1, hs) != AIT_OK) return AIT_ELAUNCH;
-      g.absmax_a = mx;
-      g.absmax_b = mx + 1;
-      return dispatch<Tile256F>(g, !trans_a, trans_b != 0, hs, ws);
-    }
     if (direct) {
       if (ctx && (ctx->flags & AIT_CTX_BF16)) return dispatch<Tile256B>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);
       if (ctx && (ctx->flags & AIT_CTX_NATIVE_F32)) return dispatch<Tile256N>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);

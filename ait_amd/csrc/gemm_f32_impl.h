@@ -105,14 +105,6 @@ __device__ __forceinline__ int div_small(int n, int d, float inv, int& rem) {
   return q;
 }
 
-// KNOB_F16X2: the power of two that brings a tensor of maximum magnitude m into [2^13, 2^14) (fp16: 65504 at most)
-__device__ __forceinline__ float f16_scale_for(float m) {
-  const unsigned e = (__float_as_uint(m) >> 23) & 0xffu;       // biased exponent of the maximum
-  if (e == 0u || e == 0xffu) return 1.f;                        // zero / denormal / inf-nan tensors: left alone
-  const int se = 127 + 13 - ((int)e - 127);
-  return __uint_as_float((unsigned)min(max(se, 1), 254) << 23);
-}
-
 __device__ __forceinline__ int conv_src_row(const ConvGeom& c, int r, int tap) {
   int img, y, x;
   if (c.rows_hw_shift >= 0) {
@@ -180,8 +172,6 @@ struct GemmArgs {
   int k_per_split;
   int splits;
   unsigned long long* probe;   // diagnostic stamps (scripts/gemm_lab.hip); NULL in the product
-  const float* absmax_a;       // KNOB_F16X2: max |A|, max |B| (device scalars written by ait_absmax_f32; NULL = operands already
-  const float* absmax_b;       //   in fp16's range).  Each operand is multiplied by the power of two that brings its maximum to [2^13, 2^14)
   ConvGeom conv;               // CONV != 0 kernels only
   int batch, batch2;           // register-staged kernels: independent problems along gridDim.y (x gridDim.z) ...
   long long sA, sB, sC;        // ... whose operands are this many floats apart
@@ -218,7 +208,6 @@ enum { KNOB_BURST = 1, KNOB_PRIO = 2, KNOB_SPREAD = 4, KNOB_STAGGER = 8, KNOB_SP
                          LDS image in the P3 row format, and the MFMAs of the current slab fetch ready planes (no vector work on
                          the matrix side).  One main loop for every operand layout: only the split stage looks at the raw image */,
        KNOB_NOTICKET = 512 /* no ticket ring in LDS: static work lists only (a ring of four 40-KB slabs is all of the CU's 160 KB) */,
-       KNOB_F16X2 = 4096 /* LAB ONLY, with KNOB_SPLIT: two fp16 planes per value, three f16 MFMAs per block (split_planes.h) */,
        KNOB_AP3 = 2048 /* with KNOB_BP3: operand A arrives pre-split as well (an activation whose producer wrote the P3 form
                           beside the f32 one): no vector work at all on the matrix side, planes of both operands by LDS-DMA */,
        KNOB_BP3 = 256 /* with KNOB_SPLIT: operand B arrives PRE-SPLIT ("P3": the three bf16 planes of every value, interleaved in
@@ -1020,21 +1009,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // planes being formed under the MFMAs (nap: the next A tile; nbp: the NEXT slab's B tiles) and two raw operand
   // tiles in flight from LDS (rw): every region of six MFMAs splits what the region before it fetched.
   constexpr bool kPipe = kSplit && (C::KNOBS & KNOB_SPLIT_SIMPLE) == 0 && !kBp3 && !kCoop;
-  constexpr int kTerms = (C::KNOBS & KNOB_BF16) != 0 ? 1 : (C::KNOBS & KNOB_F16X2) != 0 ? 3 : 6;
+  constexpr int kTerms = (C::KNOBS & KNOB_BF16) != 0 ? 1 : 6;
   constexpr bool kRne = (C::KNOBS & KNOB_RNE) != 0;
-  // KNOB_F16X2: power-of-two operand scales from the tensors' maxima, and the inverse of their product for the result
-  float f16_sa = 1.f, f16_sb = 1.f, f16_inv = 1.f;
-  if constexpr (kTerms == 3) {
-    f16_sa = g.absmax_a ? f16_scale_for(*g.absmax_a) : 1.f;
-    f16_sb = g.absmax_b ? f16_scale_for(*g.absmax_b) : 1.f;
-    f16_inv = 1.f / (f16_sa * f16_sb);          // (powers of two: exact)
-  }
   auto split_a = [&](float4 p, float4 q) __attribute__((always_inline)) -> Planes {
-    if constexpr (kTerms == 3) { p.x *= f16_sa; p.y *= f16_sa; p.z *= f16_sa; p.w *= f16_sa; q.x *= f16_sa; q.y *= f16_sa; q.z *= f16_sa; q.w *= f16_sa; }
     return split8<kTerms, kRne>(p, q);
   };
   auto split_b = [&](float4 p, float4 q) __attribute__((always_inline)) -> Planes {
-    if constexpr (kTerms == 3) { p.x *= f16_sb; p.y *= f16_sb; p.z *= f16_sb; p.w *= f16_sb; q.x *= f16_sb; q.y *= f16_sb; q.z *= f16_sb; q.w *= f16_sb; }
     return split8<kTerms, kRne>(p, q);
   };
   static_assert(!kPipe || (C::TM >= 2 && C::TN >= 2 && C::TN <= C::TM && (C::TM * C::TN) % 2 == 0), "split schedule");
@@ -1110,7 +1090,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   if constexpr (kCoop) {
     float4 q[4];
     coop_read(0, q);
-    coop_write(0, split8<kTerms == 3 ? 3 : 6, kRne>(q[0], q[1]), split8<kTerms == 3 ? 3 : 6, kRne>(q[2], q[3]));
+    coop_write(0, split8<6, kRne>(q[0], q[1]), split8<6, kRne>(q[2], q[3]));
     ring_barrier();          // plane image 0 complete; raw slot 0 free for slab 2
   } else if constexpr (kBp3) {
     prime3(0);
@@ -1193,12 +1173,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
             __builtin_amdgcn_sched_barrier(0);
             if (r + 1 < kPairs) fetch_planes(pb_img, wn, (b + 1) % C::TN, pB[nx]);
             if (r == 0) coop_read(nxt, q);
-            if constexpr (kTerms == 3) {        // LAB (KNOB_F16X2): planes 0 / 1 hold fp16 h / l
-              Planes x, y;
-              x.h = pA[0]; x.m = pA[1]; x.l = pA[1];
-              y.h = pB[pr][0]; y.m = pB[pr][1]; y.l = pB[pr][1];
-              acc[a][b] = mfma_split<3>(x, y, acc[a][b]);
-            } else {
+            {
               f32x16 c = acc[a][b];
               c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[2], pB[pr][0], c, 0, 0, 0);
               c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[0], pB[pr][2], c, 0, 0, 0);
@@ -1207,8 +1182,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
               c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[0], pB[pr][1], c, 0, 0, 0);
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pA[0], pB[pr][0], c, 0, 0, 0);
             }
-            if (r == 1) slo = split8<kTerms == 3 ? 3 : 6, kRne>(q[0], q[1]);
-            if (r == 3) shi = split8<kTerms == 3 ? 3 : 6, kRne>(q[2], q[3]);
+            if (r == 1) slo = split8<6, kRne>(q[0], q[1]);
+            if (r == 3) shi = split8<6, kRne>(q[2], q[3]);
             if (r == 5) coop_write(nxt, slo, shi);
             __builtin_amdgcn_sched_barrier(0);
             if (r < NP) {
@@ -1462,14 +1437,6 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       cur = nxt;
     }
     if constexpr (Probe::on) { c_loop += __builtin_amdgcn_s_memtime() - c0; n_tile++; }
-    if constexpr (kTerms == 3) {     // the product of the operand scales out of the sums (before any hand-off of partial tiles)
-#pragma unroll
-      for (int a = 0; a < C::TM; a++)
-#pragma unroll
-        for (int b = 0; b < C::TN; b++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) acc[a][b][r] *= f16_inv;
-    }
     bool finish = true;          // this workgroup writes the tile
     if (EPI != EPI_ATOMIC && item < n_sk && (kbeg != 0 || kend != g.K)) {
       // Inter-workgroup hand-off in the write-through form: every byte of a partial tile is stored sc1
@@ -1914,7 +1881,6 @@ inline int make_args(int trans_a, int trans_b, int M, int N, int K, float alpha,
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.c_colblk = c_colblk; g.c_batch = c_batch_stride; g.alpha = alpha; g.flags = flags;
   g.probe = nullptr;
-  g.absmax_a = g.absmax_b = nullptr;
   g.gate = nullptr;
   g.sk_on = 0;
   g.sk_ws = nullptr;

@@ -34,7 +34,7 @@ int dispatch_nt(const GemmArgs& g, hipStream_t s, const SchedWs& ws) {
 }  // namespace
 
 bool ait_gemm_p3b_takes(int M, int N, int K, const ait_launch_ctx* ctx) {
-  if (ctx && (ctx->flags & (AIT_CTX_NATIVE_F32 | AIT_CTX_BF16 | AIT_CTX_F16X2))) return false;
+  if (ctx && (ctx->flags & (AIT_CTX_NATIVE_F32 | AIT_CTX_BF16))) return false;
   if (!ctx || !ctx->sched_ws) return false;         // (the 256 x 256 tile list needs the stream-K cut of its last round)
   const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
   return M >= 512 && N >= 256 && K >= 128 && (K % 16) == 0 && tiles >= 128;

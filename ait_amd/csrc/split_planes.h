@@ -49,35 +49,10 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned
   }
 }
 
-// LAB ONLY (scripts/gemm_lab.hip, KNOB_F16X2): x as TWO fp16 planes, h = fp16(x) to nearest, l = fp16(x - h): 11 + 11
-// significant bits where x and x - h sit in fp16's normal range (a product kernel would scale every tensor by a power of
-// two first); three v_mfma_f32_32x32x16_f16 per block (h h', h l', l h') instead of six bf16 ones.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split2_f16(float x0, float x1, unsigned& h, unsigned& l) {
-  f16x2 a, b;
-  a[0] = (_Float16)x0; a[1] = (_Float16)x1;
-  b[0] = (_Float16)(x0 - (float)a[0]); b[1] = (_Float16)(x1 - (float)a[1]);
-  h = __builtin_bit_cast(unsigned, a);
-  l = __builtin_bit_cast(unsigned, b);
-}
-
 // TERMS = 6: the exact 3-way split; TERMS = 1: the operand rounded to bf16 (only plane h is formed)
 template <int TERMS = 6, bool RNE = false>
 __device__ __forceinline__ Planes split8(const float4& p, const float4& q) {     // k = 8*lk + 0..3 | 4..7
   u32x4 h, m, l;
-  if constexpr (TERMS == 3) {        // LAB: two fp16 planes (x = h + l to 22 bits for |x| in fp16's normal range), see mfma_split<3>
-    unsigned a, b;
-    split2_f16(p.x, p.y, a, b); h[0] = a; m[0] = b;
-    split2_f16(p.z, p.w, a, b); h[1] = a; m[1] = b;
-    split2_f16(q.x, q.y, a, b); h[2] = a; m[2] = b;
-    split2_f16(q.z, q.w, a, b); h[3] = a; m[3] = b;
-    Planes r;
-    r.h = __builtin_bit_cast(bf16x8, h);
-    r.m = __builtin_bit_cast(bf16x8, m);
-    r.l = r.m;
-    return r;
-  }
   if constexpr (TERMS == 1) {
     h[0] = round2(p.x, p.y); h[1] = round2(p.z, p.w); h[2] = round2(q.x, q.y); h[3] = round2(q.z, q.w);
     Planes r;
@@ -100,13 +75,6 @@ __device__ __forceinline__ Planes split8(const float4& p, const float4& q) {    
 
 template <int TERMS = 6>
 __device__ __forceinline__ f32x16 mfma_split(const Planes& a, const Planes& b, f32x16 acc) {
-  if constexpr (TERMS == 3) {        // LAB: planes h / m hold fp16 values (split8<3>)
-    const f16x8 ah = __builtin_bit_cast(f16x8, a.h), al = __builtin_bit_cast(f16x8, a.m);
-    const f16x8 bh = __builtin_bit_cast(f16x8, b.h), bl = __builtin_bit_cast(f16x8, b.m);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-  }
   if constexpr (TERMS == 1) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);

@@ -125,7 +125,8 @@ struct Dims {
   int n_maps_pad;               // R / 16
 };
 inline int make_dims(int bp, int bs, int C, int planes, int n_blocks, Dims& d) {
-  if (bp < 0 || bs < 0 || bp + bs <= 0 || C <= 0 || planes <= 0 || n_blocks < 2 || n_blocks > kMaxBlocks) return AIT_EINVAL;
+  if (bp < 0 || bs < 0 || bp + bs <= 0 || C <= 0 || planes <= 0 || n_blocks < 1 || n_blocks > kMaxBlocks) return AIT_EINVAL;
+  if (n_blocks < 2) return AIT_EUNSUPPORTED;      // a one-block tail has nowhere to park its shortcut (ait_hip.h: 2 <= n_blocks)
   if ((C % 1024) || (planes % 128)) return AIT_EUNSUPPORTED;      // 8 groups of a multiple of 128 channels; 128-wide tiles
   d.bp = bp; d.bs = bs; d.C = C; d.P = planes; d.E = 4 * planes; d.n_blocks = n_blocks;
   d.Rp = (long long)bp * kPos; d.Rq = (long long)bs * kPos;

@@ -663,6 +663,16 @@ class _fasterRCNN(nn.Module):
             # the stream of its forward, so the backward overlaps the same way)
             cur = torch.cuda.current_stream(image.device)
             side = _side_stream(image.device)
+            # the trunk's lazily filled device caches (the frozen BatchNorms' scale / shift) are filled HERE, on the
+            # step's stream, in front of the fork: filled by the query pass on the side stream they would be read by
+            # the image pass on `cur` with nothing ordering the reads behind the writes (first forward, and after any
+            # change of a BatchNorm buffer such as load_state_dict)
+            bns = self.__dict__.get("_trunk_bns")
+            if bns is None:
+                bns = self.__dict__["_trunk_bns"] = [m for m in self.RCNN_base.modules() if isinstance(m, nn.BatchNorm2d)]
+            for m in bns:
+                if _bn_frozen(m):
+                    _bn_affine(m)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 query_feat = self.RCNN_base(query)[0]             # [bs, 1024, 8, 8]

@@ -38,19 +38,16 @@ def set_matmul_dtype(dtype):
     """"f32" (default): f32 operands, f32 results; products formed on the bf16 matrix pipe from an exact 3-way bf16
     split of every operand value (include/ait_hip.h, ait_launch_ctx::flags) -- f32-equivalent accuracy.
     "f32_native": the same kernels on v_mfma_f32_32x32x2_f32 (the A/B for the above).
-    "f32_f16x2": EXPERIMENTAL -- two fp16 planes per value under a power-of-two scale per tensor, three MFMAs per block
-    (include/ait_hip.h AIT_CTX_F16X2; profiles/r04_gemm_lab_f16x2.txt).
     "bf16": the same kernels with every operand value rounded to bf16 in registers, one MFMA per block, f32
     accumulate, f32 tensors in memory (torch.autocast semantics; BASELINE configs[4]) -- NOT f32 accuracy.
     "bf16_lds" / "bf16x3": the round-1 bf16 kernel (operands converted on their way into LDS; x3: hi + lo, three
     products)."""
     global MATMUL_DTYPE
-    if dtype not in ("f32", "f32_native", "f32_f16x2", "bf16", "bf16_lds", "bf16x3"):
+    if dtype not in ("f32", "f32_native", "bf16", "bf16_lds", "bf16x3"):
         raise ValueError(dtype)
     _lib.NATIVE_F32 = dtype == "f32_native"
-    _lib.F16X2 = dtype == "f32_f16x2"
     _lib.BF16_PRODUCTS = dtype == "bf16"
-    MATMUL_DTYPE = {"f32_native": "f32", "f32_f16x2": "f32", "bf16": "f32", "bf16_lds": "bf16"}.get(dtype, dtype)
+    MATMUL_DTYPE = {"f32_native": "f32", "bf16": "f32", "bf16_lds": "bf16"}.get(dtype, dtype)
 
 
 def _gemm_fn(exact=False):

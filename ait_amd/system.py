@@ -398,7 +398,7 @@ _PART_PARAMS = (
 
 class _AitState:
     """what the three backward parts of one forward share (plain Python object: not a tensor, not saved by autograd)"""
-    __slots__ = ("xp", "xq", "saved", "ws", "W", "keep", "cfg", "shapes", "_dxq")
+    __slots__ = ("fw", "ws", "W", "keep", "cfg", "shapes", "_dxq")
 
 
 def _grads_struct(views_by_index):
@@ -422,13 +422,15 @@ def _grads_struct(views_by_index):
 PART_TRACE = None      # test hook: a list that receives ("ait_part", k) when part k of an AIT backward is enqueued
 
 
-def _ait_backward_part(st, part, d_out, want_dxp=False, want_dxq=False):
-    """run one part; returns (views of this part's parameter gradients in _PART_PARAMS[part] order, dxp, dxq)"""
+def _ait_backward_part(st, part, d_out, kept, want_dxp=False, want_dxq=False):
+    """run one part; returns (views of this part's parameter gradients in _PART_PARAMS[part] order, dxp, dxq).
+    `kept` = (x_props, x_query, saved activations): the calling node's saved tensors."""
+    xp, xq, saved = kept
     if PART_TRACE is not None:
         PART_TRACE.append(("ait_part", part))
     L = _lib.lib()
     bp, bs, n_s, p, p_attn, seed = st.cfg
-    dev = st.xp.device
+    dev = xp.device
     idx = _PART_PARAMS[part]
     sizes = [int(np.prod(st.shapes[i])) for i in idx]
     # (the three w_qs / w_ks / w_vs gradients of a block are ONE [1536, 512] matrix for the library: their views must be
@@ -442,12 +444,12 @@ def _ait_backward_part(st, part, d_out, want_dxp=False, want_dxq=False):
     if st.ws is None:
         wbytes = int(L.ait_transformer_bwd_workspace_bytes(bp, bs, n_s))
         st.ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-    dxp = torch.empty_like(st.xp) if want_dxp else None
-    dxq = torch.empty_like(st.xq) if want_dxq else None
+    dxp = torch.empty_like(xp) if want_dxp else None
+    dxq = torch.empty_like(xq) if want_dxq else None
     with torch.cuda.device(dev):
-        rc = L.ait_transformer_bwd_part(part, None if d_out is None else _lib.dev_ptr(d_out), _lib.dev_ptr(st.xp),
-                                        _lib.dev_ptr(st.xq), bp, bs, n_s, ctypes.byref(st.W), p, p_attn, seed,
-                                        ctypes.c_void_p(st.saved.data_ptr()), st.saved.numel(),
+        rc = L.ait_transformer_bwd_part(part, None if d_out is None else _lib.dev_ptr(d_out), _lib.dev_ptr(xp),
+                                        _lib.dev_ptr(xq), bp, bs, n_s, ctypes.byref(st.W), p, p_attn, seed,
+                                        ctypes.c_void_p(saved.data_ptr()), saved.numel(),
                                         ctypes.c_void_p(st.ws.data_ptr()), st.ws.numel(),
                                         None if dxp is None else _lib.dev_ptr(dxp),
                                         None if dxq is None else _lib.dev_ptr(dxq), ctypes.byref(G),
@@ -464,25 +466,29 @@ class _AitCore(torch.autograd.Function):
         L = _lib.lib()
         dev = xp.device
         bp, bs, n_s, p, p_attn, seed = st.cfg
-        st.xp, st.xq = xp.contiguous(), xq.contiguous()
+        xp, xq = xp.contiguous(), xq.contiguous()
         nbytes = int(L.ait_transformer_saved_bytes(bp, bs, n_s))
-        st.saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         out = torch.empty((bp * SEQ, xp.shape[1]), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = L.ait_transformer_fwd_train(_lib.dev_ptr(st.xp), _lib.dev_ptr(st.xq), bp, bs, n_s, ctypes.byref(st.W),
-                                             float(p), float(p_attn), int(seed), ctypes.c_void_p(st.saved.data_ptr()),
+            rc = L.ait_transformer_fwd_train(_lib.dev_ptr(xp), _lib.dev_ptr(xq), bp, bs, n_s, ctypes.byref(st.W),
+                                             float(p), float(p_attn), int(seed), ctypes.c_void_p(saved.data_ptr()),
                                              nbytes, _lib.dev_ptr(out), _lib.launch_ctx(dev), _lib.cur_stream(dev))
         _lib.check(rc, "ait_transformer_fwd_train")
+        # the multi-GB activation buffer and the two inputs are the NODES' saved tensors (all three nodes save the same
+        # storages): autograd frees them when the graph is freed -- not when the Python state object dies -- and an
+        # in-place change of x_props / x_query between forward and backward is detected
+        st.fw = (xp, xq, saved)          # (only until the two stage nodes have saved them too: _transformer_train)
+        ctx.save_for_backward(xp, xq, saved)
         ctx.st = st
         return out
 
     @staticmethod
     def backward(ctx, _token):
         st = ctx.st
-        grads, dxp, _ = _ait_backward_part(st, 2, None, want_dxp=ctx.needs_input_grad[0])
-        dxq = getattr(st, "_dxq", None)
-        st.ws = None        # the workspace goes back to the allocator here (`saved` lives as long as the graph: a second
-                            # backward over a retained graph runs the three parts again)
+        grads, dxp, _ = _ait_backward_part(st, 2, None, ctx.saved_tensors, want_dxp=ctx.needs_input_grad[0])
+        dxq, st._dxq = st._dxq, None
+        st.ws = None        # the workspace goes back to the allocator here (this part runs last)
         return (dxp, dxq, None) + tuple(grads)
 
 
@@ -493,29 +499,32 @@ class _AitStage(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, st, part, *params):
         ctx.st, ctx.part = st, part
+        ctx.save_for_backward(*st.fw)
         return y.view_as(y)
 
     @staticmethod
     def backward(ctx, d):
         st, part = ctx.st, ctx.part
         if part == 0:
-            grads, _, _ = _ait_backward_part(st, 0, d.contiguous())
+            grads, _, _ = _ait_backward_part(st, 0, d.contiguous(), ctx.saved_tensors)
         else:
-            grads, _, dxq = _ait_backward_part(st, 1, None, want_dxq=True)
+            grads, _, dxq = _ait_backward_part(st, 1, None, ctx.saved_tensors, want_dxq=True)
             st._dxq = dxq                           # (returned by _AitCore.backward, the node that owns x_query)
         return (d, None, None) + tuple(grads)
 
 
 def _transformer_train(xp, xq, bp, bs, n_s, p, p_attn, seed, W, keep, params):
     st = _AitState.__new__(_AitState)
-    st.ws = st.saved = st._dxq = None
+    st.ws = st.fw = st._dxq = None
     st.W, st.keep = W, keep                        # (keep owns the concatenated QKV matrices W points into)
     st.cfg = (bp, bs, n_s, float(p), float(p_attn), int(seed))
     st.shapes = [tuple(t.shape) for t in params]
     pick = lambda part: [params[i] for i in _PART_PARAMS[part]]
     y = _AitCore.apply(xp, xq, st, *pick(2))
     y = _AitStage.apply(y, st, 1, *pick(1))
-    return _AitStage.apply(y, st, 0, *pick(0))
+    y = _AitStage.apply(y, st, 0, *pick(0))
+    st.fw = None
+    return y
 
 
 # ------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 """bench.py -- (target, query) pairs/sec, fwd+bwd+SGD step, ResNet50, 300 proposals, on N MI355X.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks, one child process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -203,6 +204,54 @@ def pmc_traffic_per_launch(kernel_prefix="gemm_f32_"):
             "source": "profiles/%s + profiles/%s" % (out["fetch"][1], out["write"][1])}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside a torch.distributed.run environment: this parent starts N fresh child
+    processes of this same script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torchrun would:
+    the reference's `python trainval_net_voc.py --mGPUs`, trainval_net_voc.py:83,321-326, is one command too),
+    relays rank 0's JSON line and returns non-zero if any rank fails.  The parent never initialises the GPU
+    (torch.cuda.device_count() only) and nothing is exec'ed."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    gloo = os.environ.get("AIT_DIST_BACKEND") == "gloo"          # test hook: N ranks share the GPUs there are
+    if have < n and not gloo:
+        sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible\n" % (n, have))
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            if gloo:
+                env.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # a rank that dies leaves the others inside a collective: stop them (by their exact PIDs) instead of waiting
+        # for the collective's timeout
+        failed = None
+        while any(p.poll() is None for p in procs):
+            bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            if bad and failed is None:
+                failed = bad[0]
+                time.sleep(2.0)
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+            time.sleep(0.05)
+        codes = [p.wait() for p in procs]
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
+    if any(codes):
+        sys.stderr.write("bench.py: rank exit codes %r%s\n" % (codes, "" if failed is None else " (rank %d failed first)" % failed))
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,7 +267,7 @@ def main():
     ap.add_argument("--no-ab", action="store_true", help="skip the f32_native A/B steps behind the timed region")
     ap.add_argument("--gemm-table", default=None, metavar="PATH",
                     help="also write the timed region's GEMM launches grouped by shape (launches/step, ms/step, TFLOP/s)")
-    ap.add_argument("--dtype", choices=["f32", "f32_native", "f32_f16x2", "bf16", "bf16x3"], default=None,
+    ap.add_argument("--dtype", choices=["f32", "f32_native", "bf16", "bf16x3"], default=None,
                     help="matmul arithmetic of the AIT GEMMs.  f32 is the headline / parity "
                          "configuration; bf16 is the BASELINE cfg-5 arithmetic (operands rounded to bf16, "
                          "fp32 accumulate) and is reported as such, never as the headline number")
@@ -229,6 +278,9 @@ def main():
     args.proposals = args.proposals or conf["proposals"]
     args.dtype = args.dtype or conf["dtype"]
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     from ait_amd import distributed as D
     from ait_amd import _lib, ops, tuning
     rank, local_rank, world = D.init()
@@ -236,8 +288,9 @@ def main():
     # configured (scripts/exp_miopen_db.py); any other batch size / variant would start a search (minutes) on the
     # first step, so those run MIOpen's immediate mode
     tuned = tuning.use_tuned_miopen_db(rank) if (args.bs == conf["bs"] and args.variant == conf["variant"]) else False
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d: refusing to report a line for another job size"
+                         % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     _lib.lib()                                   # fail loudly if libait_hip.so is missing
@@ -285,10 +338,9 @@ def main():
 
     # A/B beside the headline, OUTSIDE its timed region (every rank runs it: the steps hold collectives): the same step
     # with the AIT's products on the instruction that multiplies f32 operands (v_mfma_f32_32x32x2_f32)
-    ab_native_ms = ab_f16x2_ms = None
-
-    def ab_run(mode):
-        ops.set_matmul_dtype(mode)
+    ab_native_ms = None
+    if args.dtype == "f32" and not args.no_ab:
+        ops.set_matmul_dtype("f32_native")
         try:
             for _ in range(2):
                 step()
@@ -300,19 +352,9 @@ def main():
                 step()
             torch.cuda.synchronize()
             D.barrier()
-            return D.max_over_ranks(time.perf_counter() - ta, device) / n_ab * 1e3
+            ab_native_ms = D.max_over_ranks(time.perf_counter() - ta, device) / n_ab * 1e3
         finally:
             ops.set_matmul_dtype(args.dtype)
-
-    if args.dtype == "f32" and not args.no_ab:
-        ab_native_ms = ab_run("f32_native")
-        # ... and with the AIT's dense products in the EXPERIMENTAL two-scaled-fp16-planes form (three MFMAs per block,
-        # two extra max-reduction passes per product; opt-in, NOT the headline: profiles/r04_gemm_lab_f16x2.txt)
-        try:
-            ab_f16x2_ms = ab_run("f32_f16x2")
-        except Exception as e:          # an experiment beside the headline must never cost the headline its line
-            sys.stderr.write("bench.py: the experimental f32_f16x2 A/B failed: %r\n" % (e,))
-            ab_f16x2_ms = None
 
     # on a GPU box the product path is the library's kernels: not one torch stand-in may have run
     if ops.fallback_count() != 0:
@@ -343,8 +385,8 @@ def main():
     # dense MFMA peak for the arithmetic: fp32, bf16, or bf16 / 3 MFMAs per product
     # (f32: the bf16 pipe's dense peak over the SIX MFMAs an f32 block product costs on it -- the ceiling of the split
     # form; the f32 instruction's own peak is reported beside it)
-    peak = {"f32": 2500.0 / 6, "f32_native": PEAK_F32_MFMA_TFLOPS, "f32_f16x2": 2500.0 / 3, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.dtype]
-    is_f32 = args.dtype in ("f32", "f32_native", "f32_f16x2")
+    peak = {"f32": 2500.0 / 6, "f32_native": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.dtype]
+    is_f32 = args.dtype in ("f32", "f32_native")
     pmc = pmc_traffic_per_launch() if is_f32 else None
     # algorithmic bytes of the same launches: each operand read once, the output written once
     alg = sum(4.0 * (p[2][0] * p[2][2] + p[2][1] * p[2][2] + p[2][0] * p[2][1]) for p in prof) / max(1, len(prof))
@@ -370,8 +412,6 @@ def main():
                          "three bf16 values (round to nearest), six v_mfma_f32_32x32x16_bf16 per block, dropped terms <= 2^-23 |a b|)",
                   "f32_native": "f32 (AIT products on v_mfma_f32_32x32x2_f32; the proposal tail's and the RPN head's convolutions "
                                 "keep the split-bf16 form)",
-                  "f32_f16x2": "EXPERIMENTAL (not the headline): f32 tensors, the AIT's dense products from two fp16 planes per value under a "
-                               "power-of-two scale per tensor, three v_mfma_f32_32x32x16_f16 per block (22 bits, not an exact split)",
                   "bf16": "bf16 products (AIT GEMMs and the proposal tail's convolutions: operands rounded to bf16 in registers, one MFMA per block, f32 accumulate); f32 storage; f32 trunk / LayerNorm / attention tiles",
                   "bf16x3": "f32 emulated as 3 bf16 MFMAs per product (experimental; fp32 accumulate)"}[args.dtype],
         "data": "synthetic",
@@ -395,7 +435,7 @@ def main():
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak,
                      "peak_is": {"f32": "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per f32 block product",
-                                 "f32_native": "v_mfma_f32_32x32x2_f32 dense peak", "f32_f16x2": "2500 TFLOP/s dense f16 MFMA / 3 MFMAs per block product", "bf16": "dense bf16 MFMA",
+                                 "f32_native": "v_mfma_f32_32x32x2_f32 dense peak", "bf16": "dense bf16 MFMA",
                                  "bf16x3": "dense bf16 MFMA / 3"}[args.dtype],
                      "f32_instruction_peak": PEAK_F32_MFMA_TFLOPS,
                      "achieved_over_f32_instruction_peak": achieved / PEAK_F32_MFMA_TFLOPS if is_f32 else None,
@@ -433,11 +473,7 @@ def main():
                   % (k + (n // args.steps, 1e3 * ms / n, fl / (ms / n) / 1e9, ms / args.steps)), file=sys.stderr)
     r = line["roofline"]
     if ab_native_ms is not None:
-        line["ab"] = {"f32_f16x2_experimental_ms_per_step": ab_f16x2_ms,
-                      "f32_f16x2_what": "EXPERIMENTAL opt-in form, not the headline: the AIT's dense products (not the convolutions) from two "
-                                        "fp16 planes per value under a power-of-two scale per tensor, three MFMAs per block, max-reductions "
-                                        "of both operands in front of every product (ops.set_matmul_dtype('f32_f16x2'))",
-                      "f32_native_ms_per_step": ab_native_ms, "f32_native_pairs_per_s": world * args.bs / (ab_native_ms * 1e-3),
+        line["ab"] = {"f32_native_ms_per_step": ab_native_ms, "f32_native_pairs_per_s": world * args.bs / (ab_native_ms * 1e-3),
                       "what": "the same step with the AIT's products formed by v_mfma_f32_32x32x2_f32 (--dtype f32_native), "
                               "run right after the timed region; the tail's and the RPN head's convolutions keep the split form"}
     r["frac_of_measured_peak"] = (achieved / r["measured_peak"]) if r.get("measured_peak") else None

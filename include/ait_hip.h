@@ -78,12 +78,6 @@ const char* ait_strerror(int code);
  * ------------------------------------------------------------------------------------- */
 #define AIT_CTX_NATIVE_F32 1u
 #define AIT_CTX_BF16 2u
-/* EXPERIMENTAL, opt-in: the dense f32 products (ait_gemm_f32 and the composites built on it; not the convolutions) from TWO
- * fp16 planes per operand value under a power-of-two scale per tensor -- three v_mfma_f32_32x32x16_f16 per block instead of the
- * six bf16 ones of the default form.  Each product first reduces max |A| and max |B| (two extra passes over the operands)
- * and scales them to [2^13, 2^14).  NOT an exact split: 22 significant bits for values within 2^-17 of their tensor's
- * maximum, an absolute error of 2^-39 max|x| below that (profiles/r04_gemm_lab_f16x2.txt).  Needs sched_ws. */
-#define AIT_CTX_F16X2 4u
 typedef struct {
   void* sched_ws;
   size_t sched_ws_bytes;
@@ -660,7 +654,8 @@ int ait_transformer_bwd_part(int part, const float* d_out, const float* x_props,
  * Weights: plain pointers into the state_dict tensors.  Convolution weights in CHANNELS-LAST memory
  * ([cout][kh][kw][cin / groups]); every BatchNorm of RCNN_top is frozen and in eval mode (:435-441,474-480) and is
  * given as (scale, shift) = (gamma / sqrt(var + eps), beta - mean * scale).  C % 1024 == 0, planes % 128 == 0,
- * 2 <= n_blocks <= 4 (block[0] is the one with the projection shortcut).
+ * 2 <= n_blocks <= 4 (block[0] is the one with the projection shortcut); n_blocks == 1 returns AIT_EUNSUPPORTED (the
+ * caller's cue to run that tail block by block), anything else outside the range AIT_EINVAL.
  *   saved      caller-owned, ait_tail_saved_bytes(...): written by ait_tail_fwd, read by ait_tail_bwd (layout
  *              private to the library; in inference it is scratch)
  *   gradients  d_x_props / d_x_query are WRITTEN (either may be NULL); parameter gradients are ACCUMULATED into

@@ -537,9 +537,10 @@ def reference_shapes(n_layers=50, A=9, variant="voc"):
     return s
 
 
-def time_train_step(P=300, cores=1, seconds_budget=25.0, seed=5):
+def time_train_step(P=300, cores=1, seconds_budget=25.0, seed=5, timed=5):
     """cpu_baseline leg of bench.py: forward + backward of ONE (target, query) pair per
-    iteration (600x1000 target, 128x128 query, P proposals) until the budget is spent."""
+    iteration (600x1000 target, 128x128 query, P proposals): one warm-up iteration, then `timed` (>= 5)
+    timed ones whatever the budget says; further ones while the budget lasts, eight at most."""
     cfgd = default_config()
     cfgd["TRAIN"]["BATCH_SIZE"] = P
     sd = make_detector_state_dict(seed, reference_shapes())
@@ -562,16 +563,17 @@ def time_train_step(P=300, cores=1, seconds_budget=25.0, seed=5):
         for v in sd.values():
             v.grad = None
         it += 1
-        if time.perf_counter() - t_start > seconds_budget or it >= 8:
+        if it >= 1 + timed and (time.perf_counter() - t_start > seconds_budget or it >= 8):
             break
     best = float(np.median(times[1:])) if len(times) > 1 else times[0]
     return {"value": 1.0 / best, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d single-pair train iterations (fwd+bwd, 600x1000 target, P=%d) of "
+            "sample": "1 warm-up + %d timed single-pair train iterations (fwd+bwd, 600x1000 target, P=%d) of "
                       "oracle/detector_ref.py with torch.set_num_threads(%d); RoIAlign/NMS from "
-                      "oracle/native.c run single-threaded; median of all but the first" % (it, P, cores)}
+                      "oracle/native.c run single-threaded; median of the %d timed ones" % (it - 1, P, cores, it - 1),
+            "timed_iterations": it - 1, "seconds_each": [round(t, 3) for t in times[1:]]}
 
 
-def time_eval_forward(P=300, cores=1, seconds_budget=8.0, seed=5):
+def time_eval_forward(P=300, cores=1, seconds_budget=8.0, seed=5, timed=5):
     """cpu_baseline figure (i) of SURVEY 8d: full eval forward of ONE pair (600x1000 target, P proposals)."""
     cfgd = default_config()
     cfgd["TEST"]["RPN_POST_NMS_TOP_N"] = P
@@ -584,14 +586,14 @@ def time_eval_forward(P=300, cores=1, seconds_budget=8.0, seed=5):
             detector_forward(sd, cfgd, *ins, False)
         times.append(time.perf_counter() - t0)
         it += 1
-        if time.perf_counter() - t_start > seconds_budget or it >= 5:
+        if it >= 1 + timed:
             break
     best = float(np.median(times[1:])) if len(times) > 1 else times[0]
     return {"value": 1.0 / best, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d single-pair eval forwards (600x1000 target, P=%d), median of all but the first" % (it, P)}
+            "sample": "1 warm-up + %d timed single-pair eval forwards (600x1000 target, P=%d), median of the timed ones" % (it - 1, P)}
 
 
-def time_ait_only(P=300, cores=1, seconds_budget=8.0, seed=5):
+def time_ait_only(P=300, cores=1, seconds_budget=8.0, seed=5, timed=5):
     """cpu_baseline figure (iii) of SURVEY 8d: the AIT alone, forward + backward, for ONE pair's P proposals
     (oracle/ait_ref.transformer_forward on [P,1024,7,7] / [1,1024,8,8])."""
     from . import ait_ref as A
@@ -611,11 +613,11 @@ def time_ait_only(P=300, cores=1, seconds_budget=8.0, seed=5):
         for v in list(sd.values()) + [xp, xq]:
             v.grad = None
         it += 1
-        if time.perf_counter() - t_start > seconds_budget or it >= 5:
+        if it >= 1 + timed:
             break
     best = float(np.median(times[1:])) if len(times) > 1 else times[0]
     return {"value": 1.0 / best, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d AIT-only fwd+bwd iterations for one pair's %d proposals, median of all but the first" % (it, P)}
+            "sample": "1 warm-up + %d timed AIT-only fwd+bwd iterations for one pair's %d proposals, median of the timed ones" % (it - 1, P)}
 
 
 def postprocess_detections(cfgd, rois, cls_prob, bbox_pred, im_info, im_scale, nms_thr=0.3, thresh=0.0,

@@ -46,8 +46,8 @@ using V_bf16 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BF16>;
 using V_bp3 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3>;    // B pre-split (P3), 8 waves of 64x128, one workgroup per CU
 using V_bp3r = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3 | KNOB_RNE>;
 using V_ab3 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_BP3 | KNOB_AP3 | KNOB_RNE>;   // both operands pre-split: no vector work
-using V_f16x2 = Cfg<256, 128, 16, 2, 2, 2, MODE_DLDS, 3, KNOB_SPREAD | KNOB_SPLIT | KNOB_F16X2>;   // two fp16 planes, three MFMAs per block (LAB)
-using V_f16x2c = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_COOP | KNOB_NOTICKET | KNOB_F16X2>;   // ... on the cooperative tile (LAB)
+// (variants 27 / 28, two scaled fp16 planes per value and three MFMAs per block, were measured in round 4 --
+//  profiles/r04_gemm_lab_f16x2.txt -- and removed with the knob in round 5: 22 bits under a tensor scale is not an f32 product)
 using V_bp3p = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_COOP | KNOB_NOTICKET | KNOB_RNE>;     // every value split once per workgroup (LDS plane image)
 using V_bp3n4 = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_BP3 | KNOB_NOTICKET>;
 using V_bp3n4p = Cfg<256, 256, 16, 4, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_BP3 | KNOB_NOTICKET | KNOB_PRIO>;
@@ -205,7 +205,7 @@ static int run_tile(const GemmArgs& g, bool ak, bool bk, int slots) {
   return run_epi<T, false, true, NoProbe>(g, slots);
 }
 static const char* VNAMES[] = {"old", "new", "probe", "burst", "prio", "ring4", "ring4+burst", "4waves", "4waves+burst",
-                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "split rne", "bp3 256sq", "bp3 rne", "bf16 x1", "coop 256sq", "bp3 ring4", "bp3 ring4 prio", "ap3+bp3", "f16x2 4w", "f16x2 coop"};
+                               "128sq", "128sq ring4", "256sq 16w", "8w spread", "4w spread", "4w spr noSK", "4w spr stag", "split 4w", "split simple", "split 256sq", "split rne", "bp3 256sq", "bp3 rne", "bf16 x1", "coop 256sq", "bp3 ring4", "bp3 ring4 prio", "ap3+bp3"};
 template <class Probe>
 static int run_new(const GemmArgs& g, bool ak, bool bk, int slots) {
   if (!ak && !bk) return run_epi<NewD4, false, false, Probe>(g, slots);
@@ -288,8 +288,6 @@ static int run(Problem& p, int variant, float* out) {
     case 19: return run_tile<V_rne>(g, ak, bk, g_slots);
     case 22: return run_tile<V_bf16>(g, ak, bk, g_slots);
     case 23: return run_tile<V_bp3p>(g, ak, bk, g_slots);
-    case 27: return run_tile<V_f16x2>(g, ak, bk, g_slots);
-    case 28: return run_tile<V_f16x2c>(g, ak, bk, g_slots);
     case 20: case 21: case 24: case 25: case 26: {
       if (!p.Bp3 || (p.s.flags & (LAB_ALIAS_A | LAB_ALIAS_B))) return -99;
       g.B = reinterpret_cast<const float*>(p.Bp3);

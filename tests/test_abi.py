@@ -43,7 +43,7 @@ def test_library_builds_and_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), "libait_hip.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names, (sorted(_lib.SIGNATURES), names)
-    assert L.ait_abi_version() == 5
+    assert L.ait_abi_version() == 6
     assert L.ait_strerror(0) == b"ok"
     assert L.ait_nms_workspace_bytes(12000) >= 12000 * 188 * 8
 

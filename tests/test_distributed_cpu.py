@@ -88,3 +88,23 @@ def test_shard_slice_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _bench(args, extra_env, drop=("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_bench_gpus_n_spawns_ranks_and_refuses_a_mismatch():
+    """bench.py --gpus N on a GPU-less host: (1) without enough GPUs the parent refuses before starting anything;
+    (2) with the gloo test hook it starts N children, each of which refuses to run without a GPU -- the parent reports
+    the failure with a non-zero exit and no JSON line; (3) inside a rank environment whose WORLD_SIZE is not --gpus the
+    rank refuses instead of printing a line for another job size."""
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr and r.stdout.strip() == ""
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"AIT_DIST_BACKEND": "gloo", "GLOO_SOCKET_IFNAME": "lo"})
+    assert r.returncode == 1 and "rank exit codes" in r.stderr and "{" not in r.stdout
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert r.returncode != 0 and "refusing" in r.stderr

@@ -734,38 +734,3 @@ def test_fused_attention_block_query_side_per_pair_equals_the_repeated_one():
     y_rep, _ = ops.mha_core_fwd(rep(q1), 0, kv, 0, kv, 512, *args, rep(res1), g, b, 1e-6, 0.0, 0, kv_rows=kv_rows, save=False)
     y_one, _ = ops.mha_core_fwd(q1, 0, kv, 0, kv, 512, *args, res1, g, b, 1e-6, 0.0, 0, kv_rows=kv_rows, save=False, q_rep=P)
     assert torch.equal(y_one, y_rep)
-
-
-@pytest.mark.gpu
-def test_transformer_experimental_f16x2_mode_vs_fp32_oracle():
-    """The AIT forward and backward with its dense products in the EXPERIMENTAL two-scaled-fp16-planes form
-    (ops.set_matmul_dtype("f32_f16x2"), opt-in; profiles/r04_gemm_lab_f16x2.txt) against the fp32 CPU oracle, at a size
-    where the products do take that tile (2 pairs x 64 proposals: 8192 token rows): the same bars the default form is
-    held to (output and input gradients, relative L2), printed beside the default's."""
-    from ait_amd import ops
-    sd = ait_ref.make_ait_state_dict(seed=3)
-    t = _transformer(3).eval()
-    xp0, xq0, cot0 = seeded(311, (128, 1024, 7, 7)), seeded(312, (2, 1024, 8, 8)), seeded(313, (128, 1024, 8, 8))
-    a = torch.from_numpy(xp0).requires_grad_(True)
-    b = torch.from_numpy(xq0).requires_grad_(True)
-    ref = ait_ref.transformer_forward(sd, a, b)
-    ga, gb = torch.autograd.grad(ref, [a, b], torch.from_numpy(cot0))
-    rel = lambda got, want: float((got.detach().cpu() - want.detach()).norm() / want.detach().norm())
-    errs, outs = {}, {}
-    for mode in ("f32", "f32_f16x2"):
-        ops.set_matmul_dtype(mode)
-        try:
-            A, B = _dev(xp0).requires_grad_(True), _dev(xq0).requires_grad_(True)
-            y = t(x_props=A, x_query=B)
-            GA, GB = torch.autograd.grad(y, [A, B], _dev(cot0))
-        finally:
-            ops.set_matmul_dtype("f32")
-        errs[mode] = (rel(y, ref), rel(GA, ga), rel(GB, gb))
-        outs[mode] = y.detach()
-    print("relative L2 errors (y, d x_props, d x_query):", errs)
-    assert not torch.equal(outs["f32"], outs["f32_f16x2"])         # the mode really took other kernels
-    # (at this size a few tokens of BOTH forms sit on the other side of a ReLU from the float64-free oracle -- a
-    # pre-activation within rounding of zero flips its mask and rewrites that token's gradient, see the bf16x3 test --
-    # so the gradients are held to "no worse than the default form", the forward to the absolute bar)
-    assert errs["f32_f16x2"][0] < 1e-5, errs
-    assert errs["f32_f16x2"][1] <= max(1e-4, 1.5 * errs["f32"][1]) and errs["f32_f16x2"][2] <= max(1e-4, 1.5 * errs["f32"][2]), errs

@@ -133,3 +133,23 @@ def test_two_ranks_train_the_real_detector(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed; both ranks' output:\n%s" % (r, report)
         assert "rank %d ok" % r in o
+
+
+def test_bench_gpus_2_starts_its_own_two_ranks():
+    """`python bench.py --gpus 2` outside a torchrun environment is ONE command that runs two ranks (the reference's
+    `trainval_net_voc.py --mGPUs`, trainval_net_voc.py:83,321-326): the parent starts two fresh children before any
+    GPU call and relays rank 0's line.  Here the two ranks share the box's one GPU over gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AIT_DIST_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-ab"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp2"
+    assert "gloo" in line["config"]["collective"]
+    assert line["config"]["gradient_buckets"]["buckets"] >= 4
+    assert line["value"] > 0 and line["roofline"]["achieved"] > 0

@@ -700,39 +700,3 @@ def test_every_epilogue_and_tile_family_the_step_launches_is_reproducible():
             if nat is not None:
                 assert float((first - nat).abs().max()) <= 3e-6 * float(nat.abs().max()) + 1e-6, (M, N, K, name)
         del a, w, res, forms
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["random", "tiny", "huge", "positive", "wide_rows"])
-def test_experimental_f16x2_products_against_float64(kind):
-    """ops.set_matmul_dtype("f32_f16x2") (AIT_CTX_F16X2, EXPERIMENTAL, opt-in): two fp16 planes per value under a
-    power-of-two scale per tensor, three MFMAs per block.  Against float64: the error relative to sum |a||b| stays in the
-    class of the default form's for operands of any magnitude (the scale), on same-signed data, and -- the stated
-    weakness -- degrades gracefully for rows far below their tensor's maximum."""
-    from ait_amd import ops
-    torch.manual_seed(17)
-    M, N, K = 4096, 1024, 1024
-    a = torch.randn(M, K, device="cuda")
-    b = torch.randn(N, K, device="cuda")
-    bound = 3e-6
-    if kind == "tiny":
-        a, b = a * 1e-9, b * 1e-7
-    elif kind == "huge":
-        a, b = a * 3e8, b * 1e5
-    elif kind == "positive":
-        a, b = a.abs() + 0.5, b.abs() + 0.5
-    elif kind == "wide_rows":          # half of A's rows are 2^-20 of the others: their 22 bits shrink to ~13
-        a[::2] *= 2.0 ** -20
-        bound = 2e-4
-    ref = a.double() @ b.double().t()
-    mag = a.double().abs() @ b.double().abs().t()
-    ops.set_matmul_dtype("f32_f16x2")
-    try:
-        y = ops.gemm(a, b)
-    finally:
-        ops.set_matmul_dtype("f32")
-    y0 = ops.gemm(a, b)
-    err = float(((y.double() - ref).abs() / mag).max())
-    err0 = float(((y0.double() - ref).abs() / mag).max())
-    print(kind, "f16x2 max err / sum|a||b| = %.3g, default form %.3g" % (err, err0))
-    assert bool(torch.isfinite(y).all()) and err <= bound, (kind, err, err0)

@@ -80,6 +80,7 @@ SIGNATURES = {
     "ait_colsum_f32": (_i, [_vp, _ll, _i, _ll, _vp, _vp]),
     "ait_rep_sum_f32": (_i, [_vp, _i, _i, _ll, _vp, _vp]),
     "ait_dropout_seed": (_ull, [_ull, _i]),
+    "ait_dropout_mask": (_i, [_ull, _ull, _ll, _f, _vp, _vp]),
     "ait_mha_block_saved_bytes": (_sz, [_i, _i]),
     "ait_mha_block_fwd_train": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _vp, _vp]),
     "ait_mha_block_bwd_workspace_bytes": (_sz, [_i, _i]),

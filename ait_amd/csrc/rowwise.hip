@@ -557,6 +557,15 @@ inline unsigned ln_grid(long long rows) {
   return (unsigned)(b < 4096 ? (b > 0 ? b : 1) : 4096);
 }
 
+// the keep / scale decisions of one dropout site, written out (ait_dropout_mask): element j of `out` is what the kernels
+// multiply element first + j of that site's tensor by -- 1 / (1 - p) or 0
+__global__ __launch_bounds__(256) void dropout_mask_kernel(unsigned long long seed, unsigned long long first, long long count,
+                                                           float p, float* __restrict__ out) {
+  const float inv_keep = 1.f / (1.f - p);
+  for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < count; j += (long long)gridDim.x * 256)
+    out[j] = p > 0.f ? drop_scale(seed, first + (unsigned long long)j, p, inv_keep) : 1.f;
+}
+
 }  // namespace
 
 AIT_API int ait_ln_fwd_rows(const float* a, const float* pos, const float* residual,
@@ -651,6 +660,18 @@ AIT_API int ait_sh_bwd(const float* du, const float* O, const float* gate, const
   if (!du || !O || !gate || !sk_w || !dO || !dg) return AIT_EINVAL;
   hipLaunchKernelGGL(sh_bwd_kernel, dim3(n_seq), dim3(kThreads), 0, ait_stream(stream), du, O, gate,
                      sk_w, dO, dg);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_dropout_mask(unsigned long long site_seed, unsigned long long first_index, long long count, float p_drop,
+                             float* scale, void* stream) {
+  if (count < 0 || p_drop < 0.f || p_drop >= 1.f) return AIT_EINVAL;
+  if (count == 0) return AIT_OK;
+  if (!scale) return AIT_EINVAL;
+  const long long b = (count + 255) / 256;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)(b > 16384 ? 16384 : b)), dim3(256), 0, ait_stream(stream), site_seed,
+                     first_index, count, p_drop, scale);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }

@@ -342,6 +342,15 @@ def dropout_seed(base, site):
     return int(_lib.lib().ait_dropout_seed(int(base), int(site)))
 
 
+def dropout_mask(site_seed, first_index, count, p, device):
+    """ait_dropout_mask: the factors (1 / (1 - p) or 0) the kernels apply to elements first_index .. + count of a site"""
+    out = torch.empty(int(count), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().ait_dropout_mask(int(site_seed), int(first_index), int(count), float(p), _lib.dev_ptr(out),
+                                               _lib.cur_stream(device)), "ait_dropout_mask")
+    return out
+
+
 def sh_fwd(O, sk_w, sk_b):
     n, H, T, dv = O.shape
     u = torch.empty((n, T, dv), dtype=torch.float32, device=O.device)

@@ -76,6 +76,28 @@ def _site_seeds(base):
     return out
 
 
+def transformer_dropout_masks(base_seed, bp, n_s, p, p_attn, device):
+    """The factors (1 / (1 - p) or 0) that ait_transformer_fwd_train(seed = base_seed) applies at its ten dropout sites,
+    read back through ait_dropout_mask and laid out as the reference's tensors see them (Models.py:98,155,
+    SubLayers.py:98,184, Modules.py:24): {site: [bp, 64, 512]} for the prologue / fc / feed-forward sites,
+    {site: [bp, 8, 64, 64]} for the probabilities.  Keys in the reference's order of reaching the sites.  The
+    encoder's feed-forward runs on the n_s compacted rows of a sequence: rows n_s .. 63, which the reference
+    computes and nothing reads, get factor 1."""
+    names = ("enc_pro", "enc_slf_attn", "enc_slf_fc", "enc_ffn", "dec_pro", "dec_slf_attn", "dec_slf_fc", "dec_enc_attn",
+             "dec_enc_fc", "dec_ffn")
+    out = {}
+    for name, seed in zip(names, _site_seeds(base_seed)):
+        if name.endswith("_attn"):
+            out[name] = ops.dropout_mask(seed, 0, bp * 8 * SEQ * SEQ, p_attn, device).view(bp, 8, SEQ, SEQ)
+        elif name == "enc_ffn" and n_s < SEQ:
+            m = torch.ones((bp, SEQ, ops.D_MODEL), dtype=torch.float32, device=device)
+            m[:, :n_s] = ops.dropout_mask(seed, 0, bp * n_s * ops.D_MODEL, p, device).view(bp, n_s, ops.D_MODEL)
+            out[name] = m
+        else:
+            out[name] = ops.dropout_mask(seed, 0, bp * SEQ * ops.D_MODEL, p, device).view(bp, SEQ, ops.D_MODEL)
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # masks: the AIT path only ever uses these two predicates (SURVEY.md 8a row a4)
 # ------------------------------------------------------------------------------------------

@@ -590,6 +590,20 @@ typedef struct {
 
 /* seed of dropout site `site` under base seed `base` (pure function, splitmix64 finaliser) */
 unsigned long long ait_dropout_seed(unsigned long long base, int site);
+/* The decisions of ONE dropout site, written out: scale[j] = what the kernels multiply element first_index + j of the
+ * site's tensor by, 1 / (1 - p_drop) or 0 (nn.Dropout's train-mode factor: lib/model/system/Modules.py:24,
+ * SubLayers.py:98,184, Models.py:98,155).  A mask is a stateless hash of (site seed, element index), so this entry runs
+ * the same device function on the same arguments as the operators do; it exists so that a checker can hand the product's
+ * masks to a CPU reference and compare VALUES at p > 0 (tests/test_gpu_ait.py), and for debugging.  Site seeds and
+ * element indices of ait_transformer_fwd_train(seed): block seed b = ait_dropout_seed(seed, k) with k = 16 encoder
+ * prologue, 17 encoder self-attention, 18 encoder feed-forward, 19 decoder prologue, 20 decoder self-attention,
+ * 21 decoder cross-attention, 22 decoder feed-forward; a prologue's site seed is b itself, an attention block's are
+ * ait_dropout_seed(b, 0) (probabilities, element index = flat index of [n_seq, 8, 64, 64]) and ait_dropout_seed(b, 1)
+ * (fc output, flat index of [n_seq * 64, 512]), a feed-forward's is ait_dropout_seed(b, 0) (flat index of
+ * [rows, 512], rows as the block sees them: the encoder's run on the n_src compacted rows per sequence); prologues:
+ * flat index of [n_seq * 64, 512]. */
+int ait_dropout_mask(unsigned long long site_seed, unsigned long long first_index, long long count, float p_drop,
+                     float* scale, void* stream);
 
 size_t ait_mha_block_saved_bytes(int n_seq, int kv_rows);
 int ait_mha_block_fwd_train(const float* xq, const float* xkv, int n_seq, int kv_rows, int mask_mode,

@@ -16,6 +16,8 @@ Groups:
   g5  model._C.nms kept indices (csrc/cpu/nms_cpu.cpp), incl. exact ovr == thr ties
   g6  generate_anchors tables + shifted-grid checksum (rpn/generate_anchors.py)
   g7+ detector-level groups are appended by oracle/gen_golden_detector.py
+  g15 Transformer in train() mode (dropout p = 0.1 ON) at (1,2): the keep decisions its ten nn.Dropout modules drew
+      (recorded by forward hooks, bit-packed), output, grads wrt inputs and all 46 params
 """
 import os
 import sys
@@ -181,6 +183,77 @@ def g3():
     _save("g3_transformer", out)
 
 
+# reference module path of each dropout site -> key of oracle.ait_ref.DROPOUT_SITES
+_DROPOUT_MODULES = {
+    "encoder.dropout": "enc_pro",                                          # Models.py:98
+    "encoder.layer_stack.0.slf_attn.attention.dropout": "enc_slf_attn",    # Modules.py:24
+    "encoder.layer_stack.0.slf_attn.dropout": "enc_slf_fc",                # SubLayers.py:98
+    "encoder.layer_stack.0.pos_ffn.dropout": "enc_ffn",                    # SubLayers.py:184
+    "decoder.dropout": "dec_pro",                                          # Models.py:155
+    "decoder.layer_stack.0.slf_attn.attention.dropout": "dec_slf_attn",
+    "decoder.layer_stack.0.slf_attn.dropout": "dec_slf_fc",
+    "decoder.layer_stack.0.enc_attn.attention.dropout": "dec_enc_attn",
+    "decoder.layer_stack.0.enc_attn.dropout": "dec_enc_fc",
+    "decoder.layer_stack.0.pos_ffn.dropout": "dec_ffn",
+}
+
+
+def g15():
+    """The reference in TRAIN mode (its ten nn.Dropout modules at p = 0.1 active, torch's own generator), with a forward
+    hook on every one of them noting which elements it kept: the fixture that pins oracle/ait_ref.transformer_forward's
+    `masks` argument -- placement of the ten sites and the 1 / (1 - p) factor -- to the reference's own arithmetic.
+    (An element whose input is exactly 0 -- a masked probability -- reads as kept; its decision cannot matter.)
+    Same ReLU-margin seed search as g3."""
+    out = {}
+    sd = ait_ref.make_ait_state_dict(seed=3)
+    t = _ref_transformer(sd).train()
+    mods = dict(t.named_modules())
+    assert all(isinstance(mods[k], torch.nn.Dropout) and mods[k].p == 0.1 for k in _DROPOUT_MODULES)
+    assert sum(isinstance(m, torch.nn.Dropout) for m in mods.values()) == len(_DROPOUT_MODULES)
+    keeps, pre_min = {}, []
+
+    def note(key):
+        def hook(mod, inp, o):
+            assert key not in keeps, key
+            keeps[key] = ((o != 0) | (inp[0] == 0)).detach()
+        return hook
+    hooks = [mods[k].register_forward_hook(note(v)) for k, v in _DROPOUT_MODULES.items()]
+    hooks += [m.register_forward_hook(lambda mod, i, o: pre_min.append(float(o.abs().min())))
+              for m in (t.encoder.layer_stack[0].pos_ffn.w_1, t.decoder.layer_stack[0].pos_ffn.w_1)]
+    bs, P = 1, 2
+    for seed in range(15200, 15400):
+        del pre_min[:]
+        keeps.clear()
+        xp = torch.from_numpy(seeded(seed, (bs * P, 1024, 7, 7))).requires_grad_(True)
+        xq = torch.from_numpy(seeded(seed + 1000, (bs, 1024, 8, 8))).requires_grad_(True)
+        torch.manual_seed(seed)
+        y = t(x_props=xp, x_query=xq)
+        if min(pre_min) >= 5e-6:
+            break
+    else:
+        raise RuntimeError("no seed with a safe ReLU margin found")
+    for h in hooks:
+        h.remove()
+    print("g15 fixture: seed", seed, "min |pre-activation|", min(pre_min))
+    out["seed"] = np.asarray(seed)
+    out["p"] = np.asarray(0.1)
+    out["relu_margin"] = np.asarray(min(pre_min))
+    for k in ait_ref.DROPOUT_SITES:
+        m = keeps[k].numpy()
+        out["keep/%s/shape" % k] = np.asarray(m.shape)
+        out["keep/%s/bits" % k] = np.packbits(m.reshape(-1))
+        out["keep/%s/kept_fraction" % k] = np.asarray(m.mean())
+    cot = torch.from_numpy(seeded(1503, tuple(y.shape)))
+    params = dict(t.named_parameters())
+    gs = _grads(y, [xp, xq] + list(params.values()), cot)
+    pack("y", y, out)
+    pack("g_x_props", gs[0], out)
+    pack("g_x_query", gs[1], out)
+    for (pn, _), g in zip(params.items(), gs[2:]):
+        pack("g_" + pn, g, out)
+    _save("g15_transformer_dropout", out)
+
+
 def g4():
     import model
     feat, rois = cases.roi_align_case()
@@ -234,7 +307,7 @@ def g6():
     _save("g6_anchors", out)
 
 
-GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6}
+GROUPS = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g15": g15}
 
 
 def main(argv):

@@ -179,6 +179,79 @@ def test_transformer_vs_reference_golden(golden):
         _check("t12/g_" + pn, gr, g, GRTOL, GATOL)
 
 
+def _train_mode_product_vs_oracle(t, sd, xp0, xq0, cot0, torch_seed):
+    """one train-mode (dropout ON) forward + backward of the product, and the oracle fed the product's own masks"""
+    from ait_amd import system
+    bp, bs = xp0.shape[0], xq0.shape[0]
+    torch.manual_seed(torch_seed)
+    base = system._new_seed()                  # the seed Transformer.forward is about to draw from torch's generator
+    torch.manual_seed(torch_seed)
+    A, B = _dev(xp0).requires_grad_(True), _dev(xq0).requires_grad_(True)
+    y = t(x_props=A, x_query=B)
+    params = dict(t.named_parameters())
+    gs = torch.autograd.grad(y, [A, B] + list(params.values()), _dev(cot0))
+    p = t.encoder.p
+    p_attn = t.encoder.layer_stack[0].slf_attn.attention.dropout.p
+    masks = {k: v.cpu() for k, v in system.transformer_dropout_masks(base, bp, 49, p, p_attn, "cuda").items()}
+    sdr = {k: (v.clone().requires_grad_(True) if "pos_table" not in k else v) for k, v in sd.items()}
+    a, b = torch.from_numpy(xp0).requires_grad_(True), torch.from_numpy(xq0).requires_grad_(True)
+    ref, inter = ait_ref.transformer_forward(sdr, a, b, masks=masks, return_intermediates=True)
+    names = [k for k in sdr if "pos_table" not in k]
+    assert names == list(params)
+    rg = torch.autograd.grad(ref, [a, b] + [sdr[n] for n in names], torch.from_numpy(cot0))
+    return y, gs, ref, rg, names, masks, inter["relu_margin"]
+
+
+def test_transformer_train_mode_dropout_values_vs_oracle():
+    """VALUE parity with dropout ON -- what the timed region runs (p = 0.1 at ten sites: Modules.py:24,
+    SubLayers.py:98,184, Models.py:98,155).  The product's ten masks (a stateless hash of seed and element index) are
+    read back through ait_dropout_mask, handed to the CPU oracle -- whose `masks` argument is pinned to the reference's
+    own train-mode arithmetic by g15 -- and output, input gradients and all 46 parameter gradients are compared element
+    by element at 1e-4, as at p = 0.  Inputs are searched for a safe ReLU margin in the ORACLE's forward (gen_golden g3)."""
+    sd = ait_ref.make_ait_state_dict(seed=3)
+    t = _transformer(3).train()
+    for seed in range(15500, 15560):
+        xp0, xq0 = seeded(seed, (2, 1024, 7, 7)), seeded(seed + 1000, (1, 1024, 8, 8))
+        cot0 = seeded(1503, (2, 1024, 8, 8))
+        y, gs, ref, rg, names, masks, margin = _train_mode_product_vs_oracle(t, sd, xp0, xq0, cot0, seed)
+        if margin >= 5e-6:
+            break
+    else:
+        raise AssertionError("no input seed with a safe ReLU margin")
+    for k, m in masks.items():                 # a real p = 0.1 draw at every site, two values only
+        kept = float((m != 0).float().mean())
+        assert 0.88 < kept < 0.92, (k, kept)
+        assert set(torch.unique(m).tolist()) <= {0.0, float(np.float32(1.0) / np.float32(0.9))}, k
+    with torch.no_grad():                      # ... and they matter: the eval-mode oracle is far away
+        assert float((ait_ref.transformer_forward(sd, torch.from_numpy(xp0), torch.from_numpy(xq0)) - ref).abs().max()) > 1e-2
+
+    def close(name, got, want, rtol, atol):
+        err = (got.detach().cpu() - want.detach()).abs()
+        assert bool((err <= atol + rtol * want.detach().abs()).all()), (name, float(err.max()), float(want.abs().max()))
+    close("y", y, ref, RTOL, ATOL)
+    close("g_x_props", gs[0], rg[0], GRTOL, GATOL)
+    close("g_x_query", gs[1], rg[1], GRTOL, GATOL)
+    for n, got, want in zip(names, gs[2:], rg[2:]):
+        close("g_" + n, got, want, GRTOL, GATOL)
+
+
+def test_transformer_train_mode_dropout_multi_pair_vs_oracle():
+    """(bs, P) = (2, 3) with dropout ON: the P repeats of a pair's query sequence draw DIFFERENT masks in the decoder
+    prologue (Models.py:155 drops the repeated tensor), and their gradients are summed back: product against the oracle
+    with the product's masks, forward element by element, gradients in relative L2 (a ReLU-boundary flip is possible at
+    this size, see gen_golden g3)."""
+    sd = ait_ref.make_ait_state_dict(seed=3)
+    t = _transformer(3).train()
+    xp0, xq0, cot0 = seeded(1531, (6, 1024, 7, 7)), seeded(1532, (2, 1024, 8, 8)), seeded(1533, (6, 1024, 8, 8))
+    y, gs, ref, rg, names, masks, _ = _train_mode_product_vs_oracle(t, sd, xp0, xq0, cot0, 77)
+    assert not torch.equal(masks["dec_pro"][0], masks["dec_pro"][1])
+    err = (y.detach().cpu() - ref.detach()).abs()
+    assert bool((err <= ATOL + RTOL * ref.detach().abs()).all()), float(err.max())
+    for n, got, want in zip(["x_props", "x_query"] + names, gs, rg):
+        rel = float((got.detach().cpu() - want).norm() / (want.norm() + 1e-30))
+        assert rel < 2e-3, (n, rel)
+
+
 def test_transformer_grads_vs_oracle_multi_pair():
     """(bs,P)=(2,3): repeat-over-proposals and its gradient reduction, against the oracle run on
     this box's host CPU (same inputs); a single ReLU-boundary flip is tolerated by comparing in

@@ -190,7 +190,8 @@ def test_cfg2_full_size_ait_output_vs_oracle():
     training entry point (dropout rates forced to 0, the rate parity is defined at) AND its inference entry point,
     against the fp32 CPU oracle run ONCE on the host for one whole pair (the 300 proposals of pair 2: sequences
     are independent) -- a VALUE comparison at the headline size, every element of that pair's
-    [300, 1024, 8, 8] output, at the AIT tolerance (1e-4 relative + 2e-5 absolute)."""
+    [300, 1024, 8, 8] output, at the AIT tolerance (1e-4 relative + 2e-5 absolute).  Then the backward: input
+    gradients and all 46 parameter gradients of the 1200-sequence step against the oracle's."""
     from oracle import ait_ref
     from oracle.digest import seeded
     from ait_amd import ops
@@ -213,9 +214,37 @@ def test_cfg2_full_size_ait_output_vs_oracle():
             mod.p = 0.0
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
-    y_train = t(x_props=xp.cuda().requires_grad_(True), x_query=xq.cuda())
+    xp_d, xq_d = xp.cuda().requires_grad_(True), xq.cuda().requires_grad_(True)
+    y_train = t(x_props=xp_d, x_query=xq_d)
     assert ops.fallback_count() == 0
     assert tuple(y_train.shape) == (bs * P, 1024, 8, 8)
+    # ---- GRADIENTS at the headline size: the training entry point's backward over all 1200
+    # sequences against the oracle's, pair by pair on the host (pairs are independent: d x_props / d x_query of a pair are
+    # its own, parameter gradients are the sum over the four pairs).  At this size (3e8 ReLU pre-activations) a few sit
+    # within rounding of zero on either side, so the bar is relative L2 per tensor plus a bound on the share of
+    # elements outside the 1e-4 band, not every element (oracle/gen_golden.py g3).
+    cot = torch.from_numpy(seeded(313, (bs * P, 1024, 8, 8)))
+    params = dict(t.named_parameters())
+    got = torch.autograd.grad(y_train, [xp_d, xq_d] + list(params.values()), cot.cuda())
+    sdr = {k: (v.clone().requires_grad_(True) if "pos_table" not in k else v) for k, v in sd.items()}
+    names = [k for k in sdr if "pos_table" not in k]
+    assert names == list(params)
+    want_p = [torch.zeros_like(sdr[n]) for n in names]
+    want_xp, want_xq = [], []
+    for b in range(bs):
+        a = xp[b * P:(b + 1) * P].clone().requires_grad_(True)
+        q = xq[b:b + 1].clone().requires_grad_(True)
+        yb = ait_ref.transformer_forward(sdr, a, q)
+        gb = torch.autograd.grad(yb, [a, q] + [sdr[n] for n in names], cot[b * P:(b + 1) * P])
+        want_xp.append(gb[0]); want_xq.append(gb[1])
+        for acc, g_ in zip(want_p, gb[2:]):
+            acc += g_
+    wants = [torch.cat(want_xp), torch.cat(want_xq)] + want_p
+    for n, g_, w_ in zip(["x_props", "x_query"] + names, got, wants):
+        g_ = g_.cpu()
+        rel = float((g_ - w_).norm() / (w_.norm() + 1e-30))
+        out = float(((g_ - w_).abs() > 2e-4 + 1e-4 * w_.abs()).float().mean())
+        assert rel < 1e-3 and out < 2e-3, (n, rel, out)
     pair = 2
     with torch.no_grad():
         want = ait_ref.transformer_forward(sd, xp[pair * P:(pair + 1) * P], xq[pair:pair + 1])

@@ -127,6 +127,47 @@ def test_transformer_forward_and_grads(golden):
         _check("t12/g_" + n, gr, g, GRTOL, GATOL)
 
 
+def golden_dropout_masks(g):
+    """the reference's own keep decisions of g15 as the oracle's factor tensors"""
+    inv = np.float32(1.0) / (np.float32(1.0) - np.float32(float(g["p"])))
+    masks = {}
+    for k in ait_ref.DROPOUT_SITES:
+        shape = tuple(int(v) for v in g["keep/%s/shape" % k])
+        keep = np.unpackbits(g["keep/%s/bits" % k])[:int(np.prod(shape))].reshape(shape)
+        masks[k] = torch.from_numpy(keep.astype(np.float32) * inv)
+    return masks
+
+
+def test_transformer_train_mode_dropout_masks_vs_reference(golden):
+    """Dropout ON (p = 0.1 at all ten sites, Modules.py:24, SubLayers.py:98,184, Models.py:98,155): the oracle, given
+    the decisions the reference's own nn.Dropout modules drew in train() mode (g15, recorded by forward hooks), reproduces
+    the reference's output and every gradient -- which pins WHERE the ten sites sit and the 1 / (1 - p) factor."""
+    g = golden("g15_transformer_dropout")
+    assert float(g["relu_margin"]) >= 5e-6
+    masks = golden_dropout_masks(g)
+    for k in ait_ref.DROPOUT_SITES:           # the fixture really is a p = 0.1 draw at every site
+        frac = float(g["keep/%s/kept_fraction" % k])
+        assert 0.88 < frac < 0.97, (k, frac)       # (attention sites: masked probabilities read as kept)
+    sd = {k: (v.clone().requires_grad_(True) if "pos_table" not in k else v)
+          for k, v in ait_ref.make_ait_state_dict(seed=3).items()}
+    seed = int(g["seed"])
+    xp = torch.from_numpy(seeded(seed, (2, 1024, 7, 7))).requires_grad_(True)
+    xq = torch.from_numpy(seeded(seed + 1000, (1, 1024, 8, 8))).requires_grad_(True)
+    y = ait_ref.transformer_forward(sd, xp, xq, masks=masks)
+    cot = torch.from_numpy(seeded(1503, tuple(y.shape)))
+    names = [k for k in sd if "pos_table" not in k]
+    gs = torch.autograd.grad(y, [xp, xq] + [sd[n] for n in names], cot)
+    _check("y", y, g)
+    _check("g_x_props", gs[0], g, GRTOL, GATOL)
+    _check("g_x_query", gs[1], g, GRTOL, GATOL)
+    for n, gr in zip(names, gs[2:]):
+        _check("g_" + n, gr, g, GRTOL, GATOL)
+    # and the masks matter: without them the same inputs give another output
+    with torch.no_grad():
+        y0 = ait_ref.transformer_forward(sd, xp, xq)
+    assert float((y0 - y).abs().max()) > 1e-2
+
+
 def test_transformer_cfg1_shape(golden):
     """cfg1 of BASELINE.json: one pair, 128 proposals, CPU forward."""
     g = golden("g3_transformer")

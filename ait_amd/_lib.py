@@ -51,6 +51,8 @@ SIGNATURES = {
     "ait_sk_sqsum_bwd": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _vp]),
     "ait_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
                           _i, ctypes.c_longlong, _vp, _vp]),
+    "ait_gemm_bf16s": (_i, [_i, _i, _i, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _ll, _i, _vp, _vp]),
+    "ait_f32_to_bf16": (_i, [_vp, _ll, _i, _ll, _vp, _ll, _i, _vp]),
     "ait_p3_bytes": (_sz, [_ll, _ll]),
     "ait_p3_split": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "ait_gemm_f32_p3": (_i, [_i, _i, _i, _f, _vp, _i, _vp, _ll, _vp, _i, _vp, _vp, _i, _i, _ll, _vp, _vp]),
@@ -101,6 +103,9 @@ SIGNATURES = {
     "ait_tail_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ait_tail_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ait_tail_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "ait_heads_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ait_heads_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "ait_heads_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz] + [_vp] * 8 + [_vp]),
     "ait_sh_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ait_sh_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ait_mha_core_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f,

@@ -57,6 +57,7 @@ def _side_stream(device):
     return st
 
 _TAIL_FUSED = True
+_HEADS_KERNEL = True          # test hook: False = the two heads as torch nn.Linear calls (vendor GEMM)
 _TOP_NHWC = True
 _BASE_NHWC = True
 _ROI_NHWC = True
@@ -388,6 +389,28 @@ def _channels_last_weight(p):
     return p
 
 
+class _HeadsFn(torch.autograd.Function):
+    """(pooled proposal features [R, F], pooled query features [bs, F]) -> (bbox_pred [R, n_bbox], score [R, 2]) through
+    ait_heads_fwd / ait_heads_bwd: RCNN_bbox_pred and the two Linears of RCNN_cls_score on the concatenation the
+    reference builds (faster_rcnn_sys_transformer_sk_dilat.py:283-288), in the library (csrc/heads.hip)."""
+
+    @staticmethod
+    def forward(ctx, props, query, w_bbox, b_bbox, w1, b1, w2, b2):
+        props, query = props.contiguous(), query.contiguous()
+        bbox, hidden, score = ops.heads_fwd(props, query, w_bbox, b_bbox, w1, b1, w2, b2)
+        ctx.save_for_backward(props, query, w_bbox, w1, w2, hidden)
+        return bbox, score
+
+    @staticmethod
+    def backward(ctx, d_bbox, d_score):
+        props, query, w_bbox, w1, w2, hidden = ctx.saved_tensors
+        d_bbox = None if d_bbox is None else d_bbox.contiguous()
+        d_score = None if d_score is None else d_score.contiguous()
+        d_props, d_query, g = ops.heads_bwd(d_bbox, d_score, props, query, w_bbox, w1, w2, hidden,
+                                            ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return (d_props, d_query, g[0].view_as(w_bbox), g[1], g[2].view_as(w1), g[3], g[4].view_as(w2), g[5])
+
+
 class _TailFn(torch.autograd.Function):
     """(AIT output tokens [bp*64, C], query tokens [bs*64, C]) -> pooled [bp + bs, 2048] through ait_tail_fwd; the
     backward (ait_tail_bwd) writes both input gradients and accumulates the 18 parameter gradients into one
@@ -717,10 +740,28 @@ class _fasterRCNN(nn.Module):
             props_feat = self._head_to_tail(props_feat, subsampled=sk_stride != 1)   # [bs*P, 2048]
             query_feat = self._head_to_tail(query_feat, subsampled=sk_stride != 1)   # [bs, 2048]
 
-        bbox_pred = self.RCNN_bbox_pred(props_feat)
-        stack_feat = torch.cat((props_feat.view(bs, num_props, -1),
-                                query_feat.unsqueeze(1).expand(-1, num_props, -1)), dim=2).reshape(-1, 4096)
-        score = self.RCNN_cls_score(stack_feat)                              # similarity logits
+        if props_feat.is_cuda and props_feat.dtype == torch.float32 and _HEADS_KERNEL and self.RCNN_bbox_pred.out_features <= 8:
+            # both heads in the library (csrc/heads.hip): no [bs*P, 4096] concatenation, no vendor GEMM under the logits
+            bbox_pred, score = _HeadsFn.apply(props_feat, query_feat, self.RCNN_bbox_pred.weight, self.RCNN_bbox_pred.bias,
+                                              self.RCNN_cls_score[0].weight, self.RCNN_cls_score[0].bias,
+                                              self.RCNN_cls_score[1].weight, self.RCNN_cls_score[1].bias)
+            # forward hooks registered on the two head modules still see their outputs (the reference's users read the
+            # logits through a hook on RCNN_cls_score); the concatenated input does not exist here: args = ()
+            for mod, name in ((self.RCNN_bbox_pred, "bbox"), (self.RCNN_cls_score, "score")):
+                for hook in list(mod._forward_hooks.values()):
+                    r = hook(mod, (), bbox_pred if name == "bbox" else score)
+                    if r is not None:
+                        if name == "bbox":
+                            bbox_pred = r
+                        else:
+                            score = r
+        else:
+            if props_feat.is_cuda and _HEADS_KERNEL:
+                ops.note_fallback("heads", props_feat)
+            bbox_pred = self.RCNN_bbox_pred(props_feat)
+            stack_feat = torch.cat((props_feat.view(bs, num_props, -1),
+                                    query_feat.unsqueeze(1).expand(-1, num_props, -1)), dim=2).reshape(-1, 4096)
+            score = self.RCNN_cls_score(stack_feat)                          # similarity logits
         score_prob = F.softmax(score, 1)[:, 1]
 
         RCNN_loss_cls = 0

@@ -242,6 +242,48 @@ def gemm_relu_bwd(dy, w, act, out=None):
     return out
 
 
+def to_bf16(x, transpose=False, out=None):
+    """ait_f32_to_bf16: x [rows, cols] f32 -> bf16 [rows, cols], or with transpose=True [cols, rows]"""
+    assert x.dim() == 2 and x.dtype == torch.float32
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((cols, rows) if transpose else (rows, cols), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().ait_f32_to_bf16(_lib.dev_ptr(x) if x.is_contiguous() else ctypes.c_void_p(x.data_ptr()), rows, cols,
+                                        x.stride(0), ctypes.c_void_p(out.data_ptr()), out.stride(0), int(bool(transpose)),
+                                        _lib.cur_stream(x.device))
+    _lib.check(rc, "ait_f32_to_bf16")
+    return out
+
+
+def gemm_bf16s(a16, b16, bias=None, residual=None, gate16=None, relu=False, mask_pos=False, out32=None, out16=None,
+               want32=True, want16=False):
+    """ait_gemm_bf16s: (f32 and / or bf16) = a16 [M, K] @ b16 [N, K]^T (+bias)(+residual | gated)(relu), bf16 operands
+    stored in memory.  Returns (out32 or None, out16 or None)."""
+    assert a16.dtype == torch.bfloat16 and b16.dtype == torch.bfloat16 and a16.dim() == 2 and b16.dim() == 2
+    assert a16.stride(1) == 1 and b16.stride(1) == 1
+    M, K = a16.shape
+    N = b16.shape[0]
+    assert b16.shape[1] == K
+    dev = a16.device
+    if out32 is None and want32:
+        out32 = torch.empty((M, N), dtype=torch.float32, device=dev)
+    if out16 is None and want16:
+        out16 = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    g = gate16 if gate16 is not None else residual
+    flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_MASK_POS if mask_pos else 0)
+    vp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ait_gemm_bf16s(M, N, K, vp(a16), a16.stride(0), vp(b16), b16.stride(0), vp(out32),
+                                       0 if out32 is None else out32.stride(0), vp(out16), 0 if out16 is None else out16.stride(0),
+                                       _p(bias), _p(residual), vp(gate16), 0 if g is None else g.stride(0), flags,
+                                       _lib.launch_ctx(dev), _lib.cur_stream(dev))
+    _lib.check(rc, "ait_gemm_bf16s")
+    return out32, out16
+
+
 def p3_split(w, transpose=False):
     """The pre-split form of a weight (include/ait_hip.h "P3"): w [rows, cols] f32 -> bf16 [rows, cols/8, 3, 8] (planes h,
     m, l of every value, x = h + m + l exactly), or with transpose=True the same of w.t(): [cols, rows/8, 3, 8]."""
@@ -349,6 +391,46 @@ def dropout_mask(site_seed, first_index, count, p, device):
         _lib.check(_lib.lib().ait_dropout_mask(int(site_seed), int(first_index), int(count), float(p), _lib.dev_ptr(out),
                                                _lib.cur_stream(device)), "ait_dropout_mask")
     return out
+
+
+def heads_fwd(props, query, w_bbox, b_bbox, w1, b1, w2, b2):
+    """ait_heads_fwd: bbox_pred [R, n_bbox], hidden [R, 8], score [R, 2] of the detector's two heads"""
+    R, F = props.shape
+    bs = query.shape[0]
+    nb = w_bbox.shape[0]
+    dev = props.device
+    bbox = torch.empty((R, nb), dtype=torch.float32, device=dev)
+    hidden = torch.empty((R, 8), dtype=torch.float32, device=dev)
+    score = torch.empty((R, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ait_heads_fwd(_p(props), _p(query), R, bs, F, _p(w_bbox), _p(b_bbox), nb, _p(w1), _p(b1), _p(w2),
+                                      _p(b2), _p(bbox), _p(hidden), _p(score), _lib.cur_stream(dev))
+    _lib.check(rc, "ait_heads_fwd")
+    return bbox, hidden, score
+
+
+def heads_bwd(d_bbox, d_score, props, query, w_bbox, w1, w2, hidden, need_props=True, need_query=True):
+    """ait_heads_bwd: (d_props, d_query, one zero-filled flat buffer holding d w_bbox | d b_bbox | d w1 | d b1 | d w2 | d b2)"""
+    R, F = props.shape
+    bs = query.shape[0]
+    nb = w_bbox.shape[0]
+    dev = props.device
+    L = _lib.lib()
+    sizes = [nb * F, nb, 8 * 2 * F, 8, 16, 2]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    parts, o = [], 0
+    for n in sizes:
+        parts.append(flat[o:o + n])
+        o += n
+    ws = torch.empty(int(L.ait_heads_bwd_workspace_bytes(R, bs)), dtype=torch.uint8, device=dev)
+    d_props = torch.empty_like(props) if need_props else None
+    d_query = torch.empty_like(query) if need_query else None
+    with torch.cuda.device(dev):
+        rc = L.ait_heads_bwd(_p(d_bbox), _p(d_score), _p(props), _p(query), R, bs, F, _p(w_bbox), nb, _p(w1), _p(w2), _p(hidden),
+                             ctypes.c_void_p(ws.data_ptr()), ws.numel(), _p(d_props), _p(d_query), *[_p(t) for t in parts],
+                             _lib.cur_stream(dev))
+    _lib.check(rc, "ait_heads_bwd")
+    return d_props, d_query, parts
 
 
 def sh_fwd(O, sk_w, sk_b):

@@ -375,6 +375,24 @@ int ait_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, float alpha, co
                   const float* residual, int flags, int split_k, int c_colblk,
                   long long c_batch_stride, const ait_launch_ctx* ctx, void* stream);
 
+/* bf16 STORAGE (BASELINE configs[4]; /root/reference/cfgs/res101.yml:1-18 names the configuration, the reference has no
+ * bf16 path of its own): C[M, N] = A[M, K] . B[N, K]^T with A and B held in memory as bf16 (K contiguous, row pitches lda /
+ * ldb in ELEMENTS, multiples of 8, bases 16-byte aligned), one v_mfma_f32_32x32x16_bf16 per block, f32 accumulate.
+ * K % 32 == 0, N % 128 == 0, any M.  Epilogue: + bias[N] (f32, may be NULL); then EITHER + residual[M, N] (f32, pitch ldr)
+ * OR with AIT_GEMM_MASK_POS the value is kept where the gate is > 0 and zeroed elsewhere -- the gate is `gate16` (a bf16
+ * [M, N] tensor, pitch ldr: the STORED ReLU output of the forward) if given, else `residual`; then ReLU with AIT_GEMM_RELU.
+ * The result is written as f32 into C32 (pitch ldc32) and / or rounded to bf16 (nearest even) into C16 (pitch ldc16):
+ * either may be NULL, not both.  The linears of the AIT in the bf16-storage mode: Models.py:246-247,278,
+ * SubLayers.py:77-79,97,181-183 and their input gradients (B = the transposed weight copy). */
+int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, float* C32,
+                   long long ldc32, void* C16, long long ldc16, const float* bias, const float* residual,
+                   const void* gate16, long long ldr, int flags, const ait_launch_ctx* ctx, void* stream);
+/* f32 [rows, cols] (pitch ld_src) -> bf16, nearest even: dst[r, c] (pitch ld_dst >= cols; cols, pitches % 4 == 0), or with
+ * transpose != 0 dst[c, r] (pitch ld_dst >= rows, even).  The per-step weight copies (and their transposes, the B operand of
+ * the input-gradient products) and the activations whose producer is not one of this library's bf16-emitting kernels. */
+int ait_f32_to_bf16(const float* src, long long rows, int cols, long long ld_src, void* dst, long long ld_dst,
+                    int transpose, void* stream);
+
 /* EXPERIMENTAL "bf16x3" variant: every fp32 operand is split into hi = bf16(x), lo = bf16(x - hi)
  * and each product is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the bf16 matrix cores with fp32
  * accumulation (<= ~3*2^-18 relative per product): fp32-class accuracy at 3/16 of the fp32 MFMA
@@ -702,6 +720,27 @@ int ait_tail_bwd(const float* d_pooled, const float* x_props, const float* x_que
                  int planes, int n_blocks, const ait_tail_weights* w, const void* saved, size_t saved_bytes,
                  void* workspace, size_t workspace_bytes, float* d_x_props, float* d_x_query,
                  const ait_tail_grads* grads, const ait_launch_ctx* ctx, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The detector's two heads behind the proposal tail (lib/model/faster_rcnn/faster_rcnn_sys_transformer_sk_dilat.py:
+ * 283-290; modules resnet_sys_transformer_sk_dilat.py:425-433): the box regressor nn.Linear(F, n_bbox) on the pooled
+ * proposal features, and the similarity classifier nn.Sequential(nn.Linear(2F, 8), nn.Linear(8, 2)) on
+ * cat(props, query repeated over the R / bs proposals of its pair) -- whose output `score` [R, 2] is the per-proposal
+ * similarity logit pair (:288).  Replaces three ATen addmm calls (vendor GEMM) and the [R, 2F] concatenation.
+ *   props [R, F], query [bs, F] (R % bs == 0, F % 4 == 0, n_bbox <= 8); weights in nn.Linear layout: w_bbox [n_bbox, F],
+ *   w1 [8, 2F] (columns [0, F) meet props, [F, 2F) the query), w2 [2, 8]; outputs bbox_pred [R, n_bbox], hidden [R, 8]
+ *   (the first layer's output: saved for the backward), score [R, 2].
+ *   backward: d_bbox / d_score may be NULL (no gradient from that head); d_props / d_query are WRITTEN (either may be
+ *   NULL); parameter gradients are ACCUMULATED with fp32 atomics (a NULL member skips that gradient).
+ * ------------------------------------------------------------------------------------- */
+int ait_heads_fwd(const float* props, const float* query, int R, int bs, int F, const float* w_bbox,
+                  const float* b_bbox, int n_bbox, const float* w1, const float* b1, const float* w2, const float* b2,
+                  float* bbox_pred, float* hidden, float* score, void* stream);
+size_t ait_heads_bwd_workspace_bytes(int R, int bs);
+int ait_heads_bwd(const float* d_bbox, const float* d_score, const float* props, const float* query, int R, int bs,
+                  int F, const float* w_bbox, int n_bbox, const float* w1, const float* w2, const float* hidden,
+                  void* workspace, size_t workspace_bytes, float* d_props, float* d_query, float* d_w_bbox,
+                  float* d_b_bbox, float* d_w1, float* d_b1, float* d_w2, float* d_b2, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Frozen batch-norm + residual + ReLU, one pass (NCHW fp32, x [n,C,HW]).

@@ -644,3 +644,56 @@ def test_rpn_heads_as_one_product_match_the_two_convolutions(A):
     assert rel(ys, rs) < 1e-5 and rel(yb, rb) < 1e-5
     for got, want, name in zip(grads, ref, ("dx", "dw1", "db1", "dw2", "db2")):
         assert rel(got, want) < 2e-5, name
+
+
+@pytest.mark.parametrize("bs,P,F,nb", [(1, 1, 2048, 4), (4, 300, 2048, 4), (2, 37, 512, 8), (3, 64, 2048, 0)])
+def test_heads_kernel_vs_float64_linear_layers(bs, P, F, nb):
+    """ait_heads_fwd / ait_heads_bwd (csrc/heads.hip) against the reference's composition in float64:
+    bbox_pred = Linear(F, nb)(props); score = Linear(8, 2)(Linear(2F, 8)(cat(props, repeat_P(query))))
+    (faster_rcnn_sys_transformer_sk_dilat.py:283-288) -- outputs, input gradients and all six parameter gradients.
+    Weights at the reference's init scale (N(0, 0.01) / N(0, 0.001)), where the logits are small sums of many terms."""
+    from ait_amd import ops
+    torch.manual_seed(5 + P)
+    R = bs * P
+    props, query = torch.randn(R, F, device="cuda").relu_(), torch.randn(bs, F, device="cuda").relu_()
+    wb, bb = torch.randn(nb, F, device="cuda") * 1e-3, torch.randn(nb, device="cuda") * 0.1
+    w1, b1 = torch.randn(8, 2 * F, device="cuda") * 1e-2, torch.randn(8, device="cuda") * 0.1
+    w2, b2 = torch.randn(2, 8, device="cuda") * 1e-2, torch.randn(2, device="cuda") * 0.1
+    d_bbox, d_score = torch.randn(R, nb, device="cuda"), torch.randn(R, 2, device="cuda")
+    bbox, hidden, score = ops.heads_fwd(props, query, wb, bb, w1, b1, w2, b2)
+    dp, dq, g = ops.heads_bwd(d_bbox if nb else None, d_score, props, query, wb, w1, w2, hidden)
+    leaves = [t.double().requires_grad_(True) for t in (props, query, wb, bb, w1, b1, w2, b2)]
+    p64, q64, wb64, bb64, w164, b164, w264, b264 = leaves
+    stack = torch.cat((p64.view(bs, P, F), q64.unsqueeze(1).expand(-1, P, -1)), 2).reshape(R, 2 * F)
+    h64 = torch.nn.functional.linear(stack, w164, b164)
+    s64 = torch.nn.functional.linear(h64, w264, b264)
+    bx64 = torch.nn.functional.linear(p64, wb64, bb64)
+    want = torch.autograd.grad([s64, bx64], leaves, [d_score.double(), d_bbox.double()], allow_unused=True)
+
+    def close(name, got, ref, rtol=1e-4):
+        if ref is None or ref.numel() == 0:
+            return
+        err = float((got.double() - ref).abs().max())
+        assert err <= rtol * float(ref.abs().max()) + 1e-9, (name, err, float(ref.abs().max()))
+    close("score", score, s64.detach(), 1e-5)
+    close("hidden", hidden, h64.detach(), 1e-5)
+    close("bbox", bbox, bx64.detach(), 1e-5)
+    close("d_props", dp, want[0])
+    close("d_query", dq, want[1])
+    for name, got, ref in zip(("d_w_bbox", "d_b_bbox", "d_w1", "d_b1", "d_w2", "d_b2"), g, want[2:]):
+        close(name, got.view(ref.shape) if ref is not None else got, ref)
+
+
+def test_detector_heads_run_in_the_library_and_keep_module_hooks():
+    """the detector's forward takes both heads through _HeadsFn (no torch Linear under the logits) and a forward hook on
+    RCNN_cls_score -- how the reference's users (and g9) read the logits -- still sees them"""
+    from ait_amd import faster_rcnn as FR
+    props, query = torch.randn(6, 2048, device="cuda"), torch.randn(2, 2048, device="cuda")
+    lin_b = torch.nn.Linear(2048, 4).cuda()
+    lin_s = torch.nn.Sequential(torch.nn.Linear(4096, 8), torch.nn.Linear(8, 2)).cuda()
+    bbox, score = FR._HeadsFn.apply(props, query, lin_b.weight, lin_b.bias, lin_s[0].weight, lin_s[0].bias, lin_s[1].weight,
+                                    lin_s[1].bias)
+    stack = torch.cat((props.view(2, 3, -1), query.unsqueeze(1).expand(-1, 3, -1)), 2).reshape(-1, 4096)
+    assert torch.allclose(score, lin_s(stack), rtol=1e-4, atol=1e-5) and torch.allclose(bbox, lin_b(props), rtol=1e-4, atol=1e-5)
+    (score.sum() + bbox.sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in list(lin_b.parameters()) + list(lin_s.parameters()))

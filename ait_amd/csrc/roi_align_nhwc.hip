@@ -29,6 +29,15 @@
 namespace {
 
 constexpr int kPW = 7;          // pooled width/height this file is specialised for (cfg.POOLING_SIZE)
+#ifndef AIT_ROI_CELLS           // lab knob: cells of a feature row a lane keeps in flight in the separable forward
+#define AIT_ROI_CELLS 4
+#endif
+constexpr int kCellsInFlight = AIT_ROI_CELLS;
+#ifndef AIT_ROI_FWD_SLICED      // lab knob (scripts/ab_roi.sh builds a second library with it): the round-4 forward
+constexpr bool kFwdSeparable = true;
+#else
+constexpr bool kFwdSeparable = false;
+#endif
 constexpr int kThreads = 256;
 
 struct Geom {
@@ -258,6 +267,94 @@ __global__ __launch_bounds__(kThreads) void roi_align_nhwc_fwd_sliced_kernel(
     }
 #pragma unroll
     for (int p = 0; p < PW; p++) o[(size_t)p * C4 + c4] = acc[p];
+  }
+}
+
+// Forward, channel-sliced AND separable in two stages (round 5; profiles/r05_roi_align_sep.txt).  The sliced kernel
+// above walks, per bin row ph, its band of feature rows, and per row every bin's band of cells: a cell under two bins is
+// loaded twice, a row under two bin rows twice more (2-4x redundant loads, each behind its own address computation --
+// the PMC pass of round 4 found the waves 0.83 of their cycles in s_waitcnt).  Here every cell of the RoI's window is
+// loaded ONCE: workgroup = (RoI, 128-channel slice) as before; the window's rows are taken eight at a time, group g
+// reduces row y0 + g along x into the PW partial sums T[g][pw] = sum_x Wx[pw][x] F[y0 + g][x] with four cells in flight
+// per lane (weights wave-uniform: a zero weight is skipped on the scalar side), the partials go through LDS (28 KB),
+// and group ph < PH folds them into its bin row with Wy[ph][y].  Same factorisation and the same order of additions as
+// the sliced kernel: results are bit-identical to it.
+__global__ __launch_bounds__(kThreads) void roi_align_nhwc_fwd_sep_kernel(
+    const float* __restrict__ feat, const float* __restrict__ rois, int n_rois, int B, int C, int H, int W,
+    int PH, const float* __restrict__ wf, const int* __restrict__ wi, float* __restrict__ out) {
+  constexpr int PW = kPW;
+  constexpr int kRows = kThreads / 32;                  // feature rows per chunk: one per group
+  const int slice = blockIdx.x % AIT_NXCD, n = blockIdx.x / AIT_NXCD;
+  if (n >= n_rois) return;
+  const int C4 = C >> 2, S4 = C4 / AIT_NXCD;
+  const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;        // (two groups per wave)
+  const int* __restrict__ ti = wi + (size_t)n * tab_ints(PH, PW);
+  const int* lim = ti + 2 * PH + 2 * PW;
+  const int ymin = lim[0], ymax = lim[1], xmin = lim[2], xmax = lim[3];
+  const int b = (int)rois[5 * n];
+  const bool dead = xmax < xmin || ymax < ymin || b < 0 || b >= B;
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // T[kRows][PW][32] float4 | wy[PH][H] | wx[PW][W]
+  float4* s_t = reinterpret_cast<float4*>(sm);
+  float* s_wy = sm + kRows * PW * 32 * 4;
+  float* s_wx = s_wy + (size_t)PH * H;
+  const float* __restrict__ gw = wf + (size_t)n * tab_floats(H, W, PH, PW);
+  if (!dead) {
+    for (int i = threadIdx.x; i < PH * H + PW * W; i += kThreads) s_wy[i] = gw[i];
+  }
+  const int ph = grp;
+  const int ylo = ph < PH ? ti[2 * ph] : 1, yhi = ph < PH ? ti[2 * ph + 1] : 0;
+  __syncthreads();
+  float4* __restrict__ o = reinterpret_cast<float4*>(out) + ((size_t)n * PH + (ph < PH ? ph : 0)) * PW * C4 + slice * S4;
+  const float4* __restrict__ f0 = reinterpret_cast<const float4*>(feat) + (size_t)(dead ? 0 : b) * H * W * C4 + slice * S4;
+  for (int c4 = l; c4 < S4; c4 += 32) {
+    float4 acc[PW];
+#pragma unroll
+    for (int p = 0; p < PW; p++) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!dead) {
+      for (int y0 = ymin; y0 <= ymax; y0 += kRows) {
+        // ---- stage 1: row y0 + grp reduced along x into PW partial sums ----
+        const int y = y0 + grp;
+        if (y <= ymax) {
+          float4 t[PW];
+#pragma unroll
+          for (int p = 0; p < PW; p++) t[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4* __restrict__ frow = f0 + (size_t)y * W * C4 + c4;
+          for (int x = xmin; x <= xmax; x += kCellsInFlight) {
+            float4 v[kCellsInFlight];
+#pragma unroll
+            for (int i = 0; i < kCellsInFlight; i++) v[i] = frow[(size_t)min(x + i, xmax) * C4];
+#pragma unroll
+            for (int i = 0; i < kCellsInFlight; i++) {
+              if (x + i <= xmax) {
+#pragma unroll
+                for (int p = 0; p < PW; p++) {
+                  const float w = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_wx[p * W + x + i])));
+                  if (w != 0.f) t[p] = fma4(w, v[i], t[p]);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int p = 0; p < PW; p++) s_t[(grp * PW + p) * 32 + l] = t[p];
+        }
+        __syncthreads();
+        // ---- stage 2: bin row ph folds the rows of this chunk that lie in its band ----
+        if (ph < PH) {
+          const int ya = max(ylo, y0), yb = min(yhi, min(ymax, y0 + kRows - 1));
+          for (int yy = ya; yy <= yb; yy++) {
+            const float wyv = s_wy[ph * H + yy];
+            if (wyv == 0.f) continue;
+#pragma unroll
+            for (int p = 0; p < PW; p++) acc[p] = fma4(wyv, s_t[((yy - y0) * PW + p) * 32 + l], acc[p]);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (ph < PH) {
+#pragma unroll
+      for (int p = 0; p < PW; p++) o[(size_t)p * C4 + c4] = acc[p];
+    }
   }
 }
 
@@ -522,7 +619,11 @@ AIT_API int ait_roi_align_nhwc_fwd(const float* feat, const float* rois, int n_r
     // algorithmic bytes: the feature read once, the RoIs, the pooled tensor written once
     AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_ROI_FWD, 4.0 * ((double)B * C * H * W + 5.0 * n_rois + (double)n_rois * PH * PW * C), s,
                         n_rois, B, C, H, W);
-    if (C % (4 * AIT_NXCD * 4) == 0 && lds_sliced <= 60 * 1024 && PH <= kThreads / 32)
+    const size_t lds_sep = lds_sliced + (size_t)(kThreads / 32) * kPW * 32 * sizeof(float4);
+    if (C % (4 * AIT_NXCD * 32) == 0 && lds_sep <= 60 * 1024 && PH < kThreads / 32 && kFwdSeparable)
+      hipLaunchKernelGGL(roi_align_nhwc_fwd_sep_kernel, dim3((unsigned)n_rois * AIT_NXCD), dim3(kThreads), lds_sep, s, feat, rois,
+                         n_rois, B, C, H, W, PH, wf, wi, out);
+    else if (C % (4 * AIT_NXCD * 4) == 0 && lds_sliced <= 60 * 1024 && PH <= kThreads / 32)
       hipLaunchKernelGGL(roi_align_nhwc_fwd_sliced_kernel, dim3((unsigned)n_rois * AIT_NXCD), dim3(kThreads),
                          lds_sliced, s, feat, rois, n_rois, B, C, H, W, PH, wf, wi, out);
     else

@@ -1,7 +1,9 @@
 """RoIAlign fwd/bwd micro-benchmark on the bench shapes (GPU box)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
+import _lab_lib  # noqa: F401  (AIT_LAB_LIB=<name>: a lab build of the library)
 from ait_amd.roi_layers import roi_align
 bs, P, C = 4, 300, 1024
 feat = torch.randn(bs, C, 38, 63, device="cuda", requires_grad=True)

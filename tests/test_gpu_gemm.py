@@ -700,3 +700,34 @@ def test_every_epilogue_and_tile_family_the_step_launches_is_reproducible():
             if nat is not None:
                 assert float((first - nat).abs().max()) <= 3e-6 * float(nat.abs().max()) + 1e-6, (M, N, K, name)
         del a, w, res, forms
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (1000, 256, 64), (4097, 512, 512), (19200, 2048, 512), (777, 1536, 2048)])
+def test_bf16_storage_gemm_against_float64(M, N, K):
+    """ait_gemm_bf16s (csrc/gemm_bf16s.hip): bf16 operands stored in memory, f32 accumulate; against the float64 product of
+    the SAME bf16 values (the only error left is the f32 accumulation), every epilogue: bias, ReLU, residual, the two
+    gates, f32 and bf16 outputs; ragged M (rows past M are neither read as results nor written)."""
+    from ait_amd import ops
+    torch.manual_seed(M + N + K)
+    a, b = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda")
+    a16, b16 = ops.to_bf16(a), ops.to_bf16(b)
+    assert torch.equal(a16, a.to(torch.bfloat16)) and torch.equal(ops.to_bf16(b, transpose=True), b.t().contiguous().to(torch.bfloat16))
+    bias, res = torch.randn(N, device="cuda"), torch.randn(M, N, device="cuda")
+    ref = a16.double() @ b16.double().t()
+    mag = a16.double().abs() @ b16.double().abs().t()
+    guard = torch.full((M + 3, N), 7.0, device="cuda")                      # rows past M must stay untouched
+    y32, y16 = ops.gemm_bf16s(a16, b16, out32=guard[:M], want16=True)
+    assert float(((y32.double() - ref).abs() / mag).max()) < 2e-6 and bool((guard[M:] == 7.0).all())
+    assert torch.equal(y16, y32.to(torch.bfloat16))
+    y, _ = ops.gemm_bf16s(a16, b16, bias=bias, relu=True)
+    assert float(((y.double() - (ref + bias.double()).clamp_min(0)).abs() / (mag + 1)).max()) < 2e-6
+    y, _ = ops.gemm_bf16s(a16, b16, bias=bias, residual=res)
+    assert float(((y.double() - (ref + bias.double() + res.double())).abs() / (mag + 1)).max()) < 2e-6
+    y, _ = ops.gemm_bf16s(a16, b16, residual=res, mask_pos=True)
+    assert float(((y.double() - ref * (res > 0)).abs() / mag).max()) < 2e-6
+    g16 = res.to(torch.bfloat16)
+    _, y = ops.gemm_bf16s(a16, b16, gate16=g16, mask_pos=True, want32=False, want16=True)
+    want = (ref * (g16.float() > 0)).float().to(torch.bfloat16)
+    assert float((y.float() - want.float()).abs().max()) <= 2.0 ** -7 * float(want.float().abs().max())
+    assert bool(((y.float() == 0) == ((g16.float() <= 0) | (want.float() == 0))).all())

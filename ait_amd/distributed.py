@@ -67,30 +67,58 @@ def collective_description(ddp):
 
 
 class BucketClock:
-    """When does the reducer hand its buckets to the all-reduce?  A comm hook (the default all-reduce, plus a note of the
-    host clock) over a DDP-wrapped model: `start()` before backward(), then `first_ms` / `last_ms` / `count` say when
-    the first and the last bucket of that backward became ready, relative to start.  Host clock: when the reducer
-    ENQUEUED the exchange (it then waits for the gradients' stream on the device)."""
+    """When does the reducer hand its buckets to the all-reduce?  A comm hook (the default all-reduce, plus two notes per
+    bucket) over a DDP-wrapped model: `start()` before backward(), `stop()` behind it, then `summary()` says when the
+    first and the last bucket of that backward became ready, relative to start --
+      * on the HOST clock: when the reducer ENQUEUED the exchange, and
+      * on the DEVICE: an event recorded on the gradients' stream at that moment, i.e. behind the kernels that produced
+        the bucket and in front of everything the backward enqueues later; against the event `stop()` records at the end
+        of the backward this shows how much of the backward's device time was still ahead when the bucket could go
+        (CUDA tensors only; needs a synchronize before summary(), which bench.py's timed region ends with)."""
 
     def __init__(self, ddp):
         import time
         from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-        self._time, self.t0, self.stamps = time, None, []
+        self._time, self.t0, self.stamps, self.events = time, None, [], []
+        self.ev0 = self.ev1 = None
+        self._cuda = next(ddp.parameters()).is_cuda
 
         def hook(state, bucket):
             if self.t0 is not None:
                 self.stamps.append((self._time.perf_counter() - self.t0) * 1e3)
+                if self._cuda:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    self.events.append(ev)
             return default_hooks.allreduce_hook(None, bucket)
         ddp.register_comm_hook(None, hook)
 
     def start(self):
-        self.t0, self.stamps = self._time.perf_counter(), []
+        self.t0, self.stamps, self.events, self.ev1 = self._time.perf_counter(), [], [], None
+        if self._cuda:
+            self.ev0 = torch.cuda.Event(enable_timing=True)
+            self.ev0.record()
+
+    def stop(self):
+        if self._cuda and self.ev0 is not None:
+            self.ev1 = torch.cuda.Event(enable_timing=True)
+            self.ev1.record()
 
     def summary(self):
         if not self.stamps:
             return None
-        return {"buckets": len(self.stamps), "first_ready_ms": self.stamps[0], "last_ready_ms": self.stamps[-1],
-                "clock": "host, from the call of backward()"}
+        out = {"buckets": len(self.stamps), "first_ready_ms": self.stamps[0], "last_ready_ms": self.stamps[-1],
+               "clock": "host, from the call of backward()"}
+        if self._cuda and self.events and self.ev1 is not None:
+            try:
+                self.ev1.synchronize()
+                out["device"] = {"first_ready_ms": self.ev0.elapsed_time(self.events[0]),
+                                 "last_ready_ms": self.ev0.elapsed_time(self.events[-1]),
+                                 "backward_end_ms": self.ev0.elapsed_time(self.ev1),
+                                 "clock": "device events on the gradients' stream, from the start of backward()"}
+            except RuntimeError:
+                pass
+        return out
 
 
 def barrier():

@@ -313,6 +313,8 @@ def main():
         if clock is not None:
             clock.start()
         cost.backward()
+        if clock is not None:
+            clock.stop()
         opt.step()
 
     peaks = measured_peaks(device) if rank == 0 else None
@@ -439,8 +441,13 @@ def main():
                                  "bf16x3": "dense bf16 MFMA / 3"}[args.dtype],
                      "f32_instruction_peak": PEAK_F32_MFMA_TFLOPS,
                      "achieved_over_f32_instruction_peak": achieved / PEAK_F32_MFMA_TFLOPS if is_f32 else None,
+                     # PMC counters cannot be read from inside this process: `traffic` (HBM bytes per launch of the dominant
+                     # kernel) comes from the COMMITTED rocprofv3 passes of this same command, taken on another box at the
+                     # end of the round (profiles/README_r05.md); everything else in this object is measured live in this run
                      "traffic": pmc["bytes_per_launch"] if pmc else None,
-                     "traffic_detail": pmc, "clock_and_mfma_util": pmc_clock_and_util() if is_f32 else None,
+                     "from_committed_profile": {"traffic_detail": pmc,
+                                                "clock_and_mfma_util": pmc_clock_and_util() if is_f32 else None,
+                                                "note": "not measured by this run: parsed from profiles/*, boxes differ by ~3 %"},
                      "algorithmic_bytes_per_launch": alg,
                      "launches_per_step": len(prof) // max(1, args.steps),
                      "probe_overflow": probe_overflow,      # launches beyond the probe's capacity (0: none truncated)

@@ -68,7 +68,9 @@ const char* ait_strerror(int code);
  *       the sum, scatter below the f32 instruction's.  (Round 3 formed the planes by truncation: one-signed planes,
  *       chopped by the pipe's accumulator alignment on long same-signed sums -- up to 1.4e-5 of the sum low.)
  *       Same operand images, same epilogues, same summation order over k-blocks.  Non-finite inputs: NaN where
- *       the f32 instruction gives an infinity.  The convolution composites (ait_conv_*, ait_tail_*) always use
+ *       the f32 instruction gives an infinity; finite operands whose magnitude exceeds the largest bf16 value
+ *       (3.3895e38 < |x| <= 3.4028e38: the nearest-rounded high plane is an infinity) likewise -- every other finite,
+ *       overflow-free product stays finite (tested at +-3e38 and at the bf16 maximum).  The convolution composites (ait_conv_*, ait_tail_*) always use
  *       the split form.
  *       AIT_CTX_BF16: the same dense products with every operand value ROUNDED to bf16 (nearest even) in registers
  *       and ONE v_mfma_f32_32x32x16_bf16 per block, f32 accumulate, f32 operands and results in memory -- what

@@ -151,5 +151,10 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp2"
     assert "gloo" in line["config"]["collective"]
-    assert line["config"]["gradient_buckets"]["buckets"] >= 4
+    gb = line["config"]["gradient_buckets"]
+    assert gb["buckets"] >= 4
+    # on the DEVICE (events on the gradients' stream): the first bucket is ready with most of the backward still ahead
+    dev = gb["device"]
+    assert 0 <= dev["first_ready_ms"] <= dev["last_ready_ms"] <= dev["backward_end_ms"] + 1e-3
+    assert dev["first_ready_ms"] < 0.6 * dev["backward_end_ms"], dev
     assert line["value"] > 0 and line["roofline"]["achieved"] > 0

@@ -519,6 +519,17 @@ def test_split_bf16_products_special_values():
     want = a.double() @ b.double().t()
     mag = a.double().abs() @ b.double().abs().t()
     assert float(((got.double() - want).abs() / mag).max()) <= 6e-7
+    # a FINITE, overflow-free product never becomes NaN / inf: operands of either sign up to the largest bf16 value
+    # (3.3895e38: the nearest-rounded high plane of anything larger would be an infinity -- the documented limit of the
+    # split form, include/ait_hip.h) against operands that keep every partial product and the sum in range
+    a2 = torch.randn(512, 64, device="cuda")
+    b2 = torch.randn(512, 64, device="cuda") * 1e-3
+    a2[:, 0], a2[:, 1], a2[:, 2] = 3e38, -3e38, 3.3895e38
+    b2[:, 0], b2[:, 1], b2[:, 2] = 1e-38, 1e-38, -2.5e-39
+    got2 = ops.gemm(a2, b2)
+    want2 = a2.double() @ b2.double().t()
+    assert bool(torch.isfinite(got2).all())
+    assert float(((got2.double() - want2).abs() / (a2.double().abs() @ b2.double().abs().t())).max()) <= 6e-7
     a[7, 9] = float("inf")
     got = ops.gemm(a, b)
     assert not bool(torch.isfinite(got[7]).any()) and bool(torch.isfinite(got[8]).all())

@@ -1782,7 +1782,14 @@ int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int 
     // workgroup alone on its CU runs faster -- stream-K costs rem/W of a tile plus ~9 slab-times of
     // publishing and gathering partial tiles.
     const int wfull = max(1, slots / AIT_NXCD), rem = wmap.chunk % wfull;
+    // (the 0.62 holds for tiles of which a CU holds two or more: the lone workgroup of an under-filled round has the
+    // CU to itself.  A tile that fills the CU alone -- the 256 x 256 ones, > 80 KB of LDS -- gains nothing from idle
+    // neighbours: its last round costs a whole tile however few workgroups are in it)
+#ifndef AIT_LAB_OLD_LAST_ROUND
+    const double last_round = (rem * 2 <= wfull && C::LDS <= 80 * 1024) ? 0.62 : 1.0;
+#else
     const double last_round = (rem * 2 <= wfull) ? 0.62 : 1.0;
+#endif
     const int item_slabs = (g.splits > 1 ? g.k_per_split : g.K) / 16;
     if (EPI == EPI_ATOMIC) {
       // split-K launches (weight gradients): a piece of an item just ADDS its partial tile like a whole item does --

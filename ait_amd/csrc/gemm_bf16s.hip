@@ -23,15 +23,32 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-constexpr int BM = 256, BN = 128, BK = 32, NT = 256, NS = 3;
-constexpr int ROWB = BK * 2;                       // bytes per operand row of a slab (64)
-constexpr int STAGE = (BM + BN) * ROWB;            // 24 KB
-constexpr int GRAN = 16 * ROWB;                    // one LDS-DMA instruction: 16 rows x 64 B = 1 KB
-constexpr int GA = BM / 16, GB = BN / 16;          // granules per slab: 16 + 8
+// Tile families (every wave owns 128 x 64 outputs = 4 x 2 MFMA blocks, 128 accumulator registers):
+//   Small  256 x 128 x 32, 4 waves, three 24-KB stages: two workgroups per CU -- one's epilogue under the other's MFMAs.
+//          The 512-deep products of the AIT (an output tile per 16 slabs).
+//   Big    256 x 256 x 64, 8 waves, two 64-KB stages: one workgroup per CU, half the operand traffic per product and a
+//          barrier per 32 MFMAs of a wave instead of 16.  Long reductions: K >= 1024, and the weight gradients.
+template <int BM_, int BN_, int BK_, int NS_, int WM_, int WN_>
+struct TileCfg {
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, NS = NS_, WM = WM_, WN = WN_;
+  static constexpr int NW = WM * WN, NT = 64 * NW;
+  static constexpr int ROWB = BK * 2;                  // bytes per operand row of a K-contiguous slab
+  static constexpr int CH = ROWB / 16;                 // 16-B chunks per such row (4 or 8)
+  static constexpr int RG = 64 / CH;                   // rows per 1-KB LDS-DMA granule
+  static constexpr int STAGE = (BM + BN) * ROWB;
+  static constexpr int LDS = NS * STAGE;
+  static constexpr int GRANULES = STAGE / 1024;
+  static constexpr int LPW = GRANULES / NW;            // LDS-DMA instructions per wave and slab
+  static_assert(BM / WM == 128 && BN / WN == 64, "a wave owns 128 x 64 outputs");
+  static_assert(GRANULES % NW == 0 && (CH == 4 || CH == 8) && BK % 16 == 0, "tile");
+};
+using Small = TileCfg<256, 128, 32, 3, 2, 2>;
+using Big = TileCfg<256, 256, 64, 2, 2, 4>;
 
 struct Args {
   const unsigned short* A;
@@ -57,10 +74,23 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {         // v_cvt_p
   t[1] = (__bf16)b;
   return __builtin_bit_cast(unsigned, t);
 }
+// wait until at most `n` of this wave's memory operations are outstanding (n: compile-time)
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else static_assert(N == 0, "add the immediate");
+}
+// position swizzle of a K-contiguous slab row: chunk c of row r is stored at c ^ swz(r) (conflict-free ds_read_b128 of 32
+// consecutive rows: 64-B rows need the row's bits 2-3, 128-B rows its bits 0-2)
+template <int CH>
+__device__ __forceinline__ int swz(int r) { return CH == 4 ? (r >> 2) & 3 : r & 7; }
 
-template <int EPI>
-__global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(const Args g) {
+template <class T, int EPI>
+__global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {      // (two waves per SIMD: <= 256 VGPRs)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NS = T::NS, ROWB = T::ROWB, CH = T::CH, RG = T::RG, STAGE = T::STAGE;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tiles_n = g.N / BN, tiles_m = (g.M + BM - 1) / BM, tiles = tiles_m * tiles_n;
   const int per = (tiles + AIT_NXCD - 1) / AIT_NXCD, wg_per_xcd = gridDim.x / AIT_NXCD;
@@ -68,36 +98,34 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(const Args g) {
   const int chunk_end = min(per, tiles - xcd * per);
   const int mine = j < chunk_end ? (chunk_end - j + wg_per_xcd - 1) / wg_per_xcd : 0;
   if (mine <= 0) return;
-  const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
+  const int wm = (wave / T::WN) * 128, wn = (wave % T::WN) * 64;
   const int li = lane & 31, lk = lane >> 5;
   const int slabs = g.K / BK, total = mine * slabs;
-  const int rr = lane >> 2, pos = lane & 3;                        // row within a granule, chunk POSITION in LDS
-  const int cfetch = pos ^ ((rr >> 2) & 3);                          // the 16-B chunk of the row that lands there
+  const int rr = lane / CH, pos = lane % CH;                          // row within a granule, chunk POSITION in LDS
+  const int cfetch = pos ^ swz<CH>(rr);                               // the 16-B chunk of the row that lands there
   const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
   auto tile_origin = [&](int i, int& m0, int& n0) __attribute__((always_inline)) {
     const int t = xcd * per + j + i * wg_per_xcd;
     m0 = (t / tiles_n) * BM;
     n0 = (t % tiles_n) * BN;
   };
-  // loader: 24 granules per slab, six per wave (A granules 0..15: waves take q = wave, wave + 4, ...; then B's eight)
+  // loader: granule q of a slab is RG operand rows (A's BM / RG granules first, then B's); wave w takes q = w, w + NW, ...
   auto issue = [&](int s, int stage) __attribute__((always_inline)) {
     int m0, n0;
     tile_origin(s / slabs, m0, n0);
     const int k0 = (s % slabs) * BK;
 #pragma unroll
-    for (int i = 0; i < GA / 4; i++) {
-      const int q = wave + i * 4;
-      int row = m0 + q * 16 + rr;
-      row = row < g.M ? row : g.M - 1;                               // (rows past M: any finite data, never stored)
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE + q * GRAN);
-      glds16(g.A + (size_t)row * g.lda + k0 + cfetch * 8, dst);
-    }
-#pragma unroll
-    for (int i = 0; i < GB / 4; i++) {
-      const int q = wave + i * 4;
-      const int row = n0 + q * 16 + rr;
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE + BM * ROWB + q * GRAN);
-      glds16(g.B + (size_t)row * g.ldb + k0 + cfetch * 8, dst);
+    for (int i = 0; i < T::LPW; i++) {
+      const int q = wave + i * T::NW;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE + q * 1024);
+      if (q < BM / RG) {
+        int row = m0 + q * RG + rr;
+        row = row < g.M ? row : g.M - 1;                             // (rows past M: any finite data, never stored)
+        glds16(g.A + (size_t)row * g.lda + k0 + cfetch * 8, dst);
+      } else {
+        const int row = n0 + (q - BM / RG) * RG + rr;
+        glds16(g.B + (size_t)row * g.ldb + k0 + cfetch * 8, dst);
+      }
     }
   };
   f32x16 acc[4][2];
@@ -107,18 +135,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(const Args g) {
     for (int b = 0; b < 2; b++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
-  issue(0, 0);
-  if (total > 1) issue(1, 1);
+#pragma unroll
+  for (int i = 0; i < NS - 1; i++)
+    if (i < total) issue(i, i);
   int done = 0, ti = 0, stage = 0;
   bool stores_pending = false;
   for (int s = 0; s < total; s++) {
-    // slab s must have landed: everything but the six loads of slab s + 1 (loads complete in order; stores of an
-    // epilogue may overtake loads in the counter, so after one everything is awaited)
-    if (stores_pending || s + 1 >= total) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // slab s must have landed: everything but the loads of the NS - 2 slabs behind it (loads complete in order; the stores
+    // of an epilogue may overtake loads in the counter, so after one -- and at the tail -- everything is awaited)
+    if (stores_pending || s + NS - 1 > total) wait_vm<0>();
+    else wait_vm<(NS - 2) * T::LPW>();
     stores_pending = false;
     __builtin_amdgcn_s_barrier();                                    // ... for every wave; and all are done with slab s - 1
-    if (s + 2 < total) issue(s + 2, (stage + 2) % NS);
+    if (s + NS - 1 < total) issue(s + NS - 1, (stage + NS - 1) % NS);
     const unsigned char* sa = lds + stage * STAGE;
     const unsigned char* sb = sa + BM * ROWB;
 #pragma unroll
@@ -128,12 +157,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(const Args g) {
 #pragma unroll
       for (int a = 0; a < 4; a++) {
         const int row = wm + a * 32 + li;
-        fa[a] = *reinterpret_cast<const bf16x8*>(sa + row * ROWB + ((c ^ ((row >> 2) & 3)) << 4));
+        fa[a] = *reinterpret_cast<const bf16x8*>(sa + row * ROWB + ((c ^ swz<CH>(row)) << 4));
       }
 #pragma unroll
       for (int b = 0; b < 2; b++) {
         const int row = wn + b * 32 + li;
-        fb[b] = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((c ^ ((row >> 2) & 3)) << 4));
+        fb[b] = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((c ^ swz<CH>(row)) << 4));
       }
       // operands swapped: D^T = B A^T, lane (li, lk) holds row m = li, columns 8 q + 4 lk + (r & 3), q = r >> 2
 #pragma unroll
@@ -191,6 +220,145 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16s_kernel(const Args g) {
   }
 }
 
+// ---- weight gradients: C[Mo, No] (f32) += sum_r A[r, m] B[r, n], both operands bf16 [R, features] row-major -----------
+// The reduction index is the OUTER dimension of both operands (token rows): a slab is BK rows x BM (A) / BN (B) feature
+// columns, moved global -> LDS as it lies (LDS-DMA, 16-B chunks along the features), and the MFMA operand -- eight
+// consecutive reduction indices of one feature per lane -- is gathered by ds_read_b64_tr_b16, gfx950's transposing LDS read
+// (per 16 lanes a 4-row x 16-column block, delivered column-major): two reads per operand block, no register shuffles.
+// 16-B chunk c of slab row k is stored at chunk position c ^ (4 (k & 3)): the four rows of a transposed read, 512 (256) B
+// apart, land on four different quarter-sets of the 64 banks.  Split-K over the rows; partial tiles are added with f32
+// atomics (like the f32-storage weight-gradient launches).
+struct TnArgs {
+  const unsigned short* A;      // [R, Mo] (pitch lda)
+  const unsigned short* B;      // [R, No] (pitch ldb)
+  float* C;                     // [Mo, No] (pitch ldc), accumulated
+  int Mo, No, R, splits, k_per_split;
+  long long lda, ldb, ldc;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off_lo, int off_hi) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + off_hi));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <class T>
+__global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NS = T::NS, STAGE = T::STAGE;
+  constexpr int ROWA = BM * 2, ROWB_ = BN * 2;                // bytes per slab row (512 / 256 or 512)
+  constexpr int SLAB_A = BK * ROWA;
+  constexpr int GA = SLAB_A / 1024;                            // granules of the A slab (the B slab's follow)
+  constexpr int LPRA = ROWA / 16, LPRB = ROWB_ / 16;           // lanes (16-B chunks) per slab row
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tiles_n = g.No / BN, tiles = (g.Mo / BM) * tiles_n, items = tiles * g.splits;
+  const int wm = (wave / T::WN) * 128, wn = (wave % T::WN) * 64;
+  const int li = lane & 31, lk = lane >> 5;
+  const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
+  const int slabs = g.k_per_split / BK;
+  // this workgroup's items: i = blockIdx.x, + gridDim.x, ...  (item = split-major: the tiles of one split are neighbours,
+  // so concurrently running workgroups read the same token rows: one pass of the operands through L2)
+  const int mine = (int)blockIdx.x < items ? (items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  if (mine <= 0) return;
+  const int total = mine * slabs;
+  auto item_of = [&](int i, int& m0, int& n0, int& k0) __attribute__((always_inline)) {
+    const int it = (int)blockIdx.x + i * (int)gridDim.x;
+    const int split = it / tiles, t = it % tiles;
+    m0 = (t / tiles_n) * BM;
+    n0 = (t % tiles_n) * BN;
+    k0 = split * g.k_per_split;
+  };
+  auto issue = [&](int s, int stage) __attribute__((always_inline)) {
+    int m0, n0, k0;
+    item_of(s / slabs, m0, n0, k0);
+    k0 += (s % slabs) * BK;
+#pragma unroll
+    for (int i = 0; i < T::LPW; i++) {
+      const int q = wave + i * T::NW;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE + q * 1024);
+      if (q < GA) {
+        const int row = q * (64 / LPRA) + lane / LPRA, pos = lane % LPRA;
+        glds16(g.A + (size_t)(k0 + row) * g.lda + m0 + (pos ^ (4 * (row & 3))) * 8, dst);
+      } else {
+        const int row = (q - GA) * (64 / LPRB) + lane / LPRB, pos = lane % LPRB;
+        glds16(g.B + (size_t)(k0 + row) * g.ldb + n0 + (pos ^ (4 * (row & 3))) * 8, dst);
+      }
+    }
+  };
+  // transposed-read addresses of this lane (bytes from the slab's operand base), for k-step 0 / read 0; k-step ks adds
+  // 16 ks rows, the second read 4 rows.  Group gq = lane >> 4: features +16 (gq & 1), reduction rows +8 (gq >> 1).
+  const int gq = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  const int krow = 8 * (gq >> 1) + tq;                       // (k & 3) == tq for every read: block rows start at multiples of 4
+  int offA[4], offB[2];
+#pragma unroll
+  for (int a = 0; a < 4; a++) {
+    const int c = (wm + 32 * a) / 8 + 2 * (gq & 1) + (tp >> 1);
+    offA[a] = krow * ROWA + ((c ^ (4 * tq)) << 4) + 8 * (tp & 1);
+  }
+#pragma unroll
+  for (int b = 0; b < 2; b++) {
+    const int c = (wn + 32 * b) / 8 + 2 * (gq & 1) + (tp >> 1);
+    offB[b] = krow * ROWB_ + ((c ^ (4 * tq)) << 4) + 8 * (tp & 1);
+  }
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NS - 1; i++)
+    if (i < total) issue(i, i);
+  int done = 0, ti = 0, stage = 0;
+  for (int s = 0; s < total; s++) {
+    if (s + NS - 1 > total) wait_vm<0>();
+    else wait_vm<(NS - 2) * T::LPW>();
+    __builtin_amdgcn_s_barrier();
+    if (s + NS - 1 < total) issue(s + NS - 1, (stage + NS - 1) % NS);
+    const unsigned char* sa = lds + stage * STAGE;
+    const unsigned char* sb = sa + SLAB_A;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ks++) {
+      bf16x8 fa[4], fb[2];
+#pragma unroll
+      for (int a = 0; a < 4; a++) fa[a] = tr_frag(sa, offA[a] + 16 * ks * ROWA, offA[a] + (16 * ks + 4) * ROWA);
+#pragma unroll
+      for (int b = 0; b < 2; b++) fb[b] = tr_frag(sb, offB[b] + 16 * ks * ROWB_, offB[b] + (16 * ks + 4) * ROWB_);
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
+    }
+    stage = stage + 1 == NS ? 0 : stage + 1;
+    if (++done == slabs) {
+      int m0, n0, k0;
+      item_of(ti, m0, n0, k0);
+#pragma unroll
+      for (int a = 0; a < 4; a++) {
+        const int row = m0 + wm + a * 32 + li;
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float* dst = g.C + (size_t)row * g.ldc + n0 + wn + b * 32 + 8 * q + 4 * lk;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              unsafeAtomicAdd(dst + r, acc[a][b][4 * q + r]);
+              acc[a][b][4 * q + r] = 0.f;
+            }
+          }
+      }
+      done = 0;
+      ti++;
+      wait_vm<0>();       // (the atomics count like stores and may overtake the loads already requested: wait for everything once)
+    }
+  }
+}
+
 // f32 [rows, cols] (row pitch ld_src) -> bf16 [rows, cols] (row pitch ld_dst), nearest even; 16 B in, 8 B out per lane
 __global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ src, long long rows, int cols, long long ld_src,
                                                       unsigned short* __restrict__ dst, long long ld_dst) {
@@ -225,34 +393,87 @@ __global__ __launch_bounds__(256) void to_bf16_t_kernel(const float* __restrict_
   }
 }
 
-template <int EPI>
-int launch(const Args& g, hipStream_t s) {
-  const void* kern = reinterpret_cast<const void*>(gemm_bf16s_kernel<EPI>);
-  constexpr int kLds = NS * STAGE;
-  static int slots = 0;           // (a constant of the code object and the device model)
-  if (slots == 0) {
-    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess) return AIT_ELAUNCH;
-    int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus <= 0)
-      cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, kLds) != hipSuccess || per_cu <= 0) {
-      (void)hipGetLastError();
-      per_cu = 2;
+// out[c] += sum_r x[r, c] over a bf16 [rows, cols] matrix (the bias gradient of a layer whose output gradient is stored
+// in bf16): a thread per column quad (8-B loads), a block a band of 128 rows, one f32 atomic per column and block
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* __restrict__ x, long long rows, int cols,
+                                                          long long ld, float* __restrict__ out) {
+  const long long r0 = (long long)blockIdx.x * 128;
+  const long long r1 = r0 + 128 < rows ? r0 + 128 : rows;
+  for (int c4 = threadIdx.x + blockIdx.y * blockDim.x; c4 < cols / 4; c4 += blockDim.x * gridDim.y) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned short* __restrict__ p = x + r0 * ld + 4 * c4;
+#pragma unroll 8
+    for (long long r = r0; r < r1; r++, p += ld) {
+      const uint2 v = *reinterpret_cast<const uint2*>(p);
+      acc.x += __uint_as_float(v.x << 16); acc.y += __uint_as_float(v.x & 0xffff0000u);
+      acc.z += __uint_as_float(v.y << 16); acc.w += __uint_as_float(v.y & 0xffff0000u);
     }
-    slots = (per_cu > 2 ? 2 : per_cu) * cus;
+    unsafeAtomicAdd(out + 4 * c4 + 0, acc.x);
+    unsafeAtomicAdd(out + 4 * c4 + 1, acc.y);
+    unsafeAtomicAdd(out + 4 * c4 + 2, acc.z);
+    unsafeAtomicAdd(out + 4 * c4 + 3, acc.w);
   }
-  const int tiles = ((g.M + BM - 1) / BM) * (g.N / BN);
+}
+
+// resident workgroup slots of a kernel (a constant of the code object and the device model); also raises its LDS limit
+template <class T>
+inline int slots_of(const void* kern, int& memo) {
+  if (memo > 0) return memo;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS) != hipSuccess) return -1;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      cus <= 0)
+    cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, T::NT, T::LDS) != hipSuccess || per_cu <= 0) {
+    (void)hipGetLastError();
+    per_cu = T::LDS > 80 * 1024 ? 1 : 2;
+  }
+  memo = (per_cu > 2 ? 2 : per_cu) * cus;
+  return memo;
+}
+
+template <class T, int EPI>
+int launch(const Args& g, hipStream_t s) {
+  const void* kern = reinterpret_cast<const void*>(gemm_bf16s_kernel<T, EPI>);
+  static int memo = 0;
+  const int slots = slots_of<T>(kern, memo);
+  if (slots <= 0) return AIT_ELAUNCH;
+  const int tiles = ((g.M + T::BM - 1) / T::BM) * (g.N / T::BN);
   const int per = (tiles + AIT_NXCD - 1) / AIT_NXCD;
   int w = slots / AIT_NXCD;
   if (w > per) w = per;
   if (w < 1) w = 1;
-  hipLaunchKernelGGL(gemm_bf16s_kernel<EPI>, dim3(w * AIT_NXCD), dim3(NT), kLds, s, g);
+  hipLaunchKernelGGL((gemm_bf16s_kernel<T, EPI>), dim3(w * AIT_NXCD), dim3(T::NT), T::LDS, s, g);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+template <class T>
+int launch_epi(const Args& g, bool gate, hipStream_t s) {
+  if (gate) return launch<T, EPI_GATE>(g, s);
+  if (g.residual) return launch<T, EPI_RES>(g, s);
+  return launch<T, EPI_PLAIN>(g, s);
+}
+template <class T>
+int launch_tn(const TnArgs& g, hipStream_t s) {
+  const void* kern = reinterpret_cast<const void*>(gemm_bf16s_tn_kernel<T>);
+  static int memo = 0;
+  const int slots = slots_of<T>(kern, memo);
+  if (slots <= 0) return AIT_ELAUNCH;
+  const long long items = (long long)(g.Mo / T::BM) * (g.No / T::BN) * g.splits;
+  const int grid = (int)(items < slots ? items : slots);
+  hipLaunchKernelGGL((gemm_bf16s_tn_kernel<T>), dim3(grid), dim3(T::NT), T::LDS, s, g);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }
 
 }  // namespace
+
+// lab knob (scripts/build_variant.py): -DAIT_LAB_BF16S_SMALL_ONLY keeps every product on the 256 x 128 x 32 tile
+#ifndef AIT_LAB_BF16S_SMALL_ONLY
+constexpr bool kUseBig = true;
+#else
+constexpr bool kUseBig = false;
+#endif
 
 AIT_API int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, float* C32,
                            long long ldc32, void* C16, long long ldc16, const float* bias, const float* residual,
@@ -260,8 +481,9 @@ AIT_API int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, co
   if (M < 0 || N < 0 || K < 0) return AIT_EINVAL;
   if (M == 0 || N == 0) return AIT_OK;
   if (!A || !B || (!C32 && !C16)) return AIT_EINVAL;
-  if (K == 0 || (K % BK) || (N % BN) || (lda % 8) || (ldb % 8) || lda < K || ldb < K ||
-      (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15))
+  if (K == 0 || (K % Small::BK) || (N % Small::BN) || (lda % 8) || (ldb % 8) || lda < K || ldb < K ||
+      (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
+      (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
     return AIT_EUNSUPPORTED;
   if ((C32 && ((ldc32 % 4) || ldc32 < N || (reinterpret_cast<uintptr_t>(C32) & 15))) ||
       (C16 && ((ldc16 % 4) || ldc16 < N || (reinterpret_cast<uintptr_t>(C16) & 7))))
@@ -279,9 +501,44 @@ AIT_API int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, co
   g.relu = (flags & AIT_GEMM_RELU) ? 1 : 0;
   hipStream_t s = ait_stream(stream);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K, s, M, N, K, 0, 1, 1);
-  if (gate) return launch<EPI_GATE>(g, s);
-  if (residual) return launch<EPI_RES>(g, s);
-  return launch<EPI_PLAIN>(g, s);
+  // long reductions on the 256 x 256 x 64 tile (at least a round of them), the 512-deep products on the 256 x 128 x 32 one
+  const long long big_tiles = (long long)((M + Big::BM - 1) / Big::BM) * (N / Big::BN);
+  if (kUseBig && K >= 1024 && (K % Big::BK) == 0 && (N % Big::BN) == 0 && big_tiles >= 192) return launch_epi<Big>(g, gate, s);
+  return launch_epi<Small>(g, gate, s);
+}
+
+AIT_API int ait_gemm_bf16s_tn(int Mo, int No, int R, const void* A, long long lda, const void* B, long long ldb, float* C,
+                              long long ldc, int split_k, const ait_launch_ctx* ctx, void* stream) {
+  if (Mo < 0 || No < 0 || R < 0) return AIT_EINVAL;
+  if (Mo == 0 || No == 0 || R == 0) return AIT_OK;
+  if (!A || !B || !C) return AIT_EINVAL;
+  if ((Mo % Small::BM) || (No % Small::BN) || (lda % 8) || (ldb % 8) || lda < Mo || ldb < No || (ldc % 4) || ldc < No ||
+      (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15))
+    return AIT_EUNSUPPORTED;
+  if (split_k < 1) split_k = 1;
+  if ((R % split_k) || ((R / split_k) % Small::BK)) return AIT_EUNSUPPORTED;      // whole 32-row slabs per split
+  TnArgs g;
+  g.A = static_cast<const unsigned short*>(A); g.B = static_cast<const unsigned short*>(B); g.C = C;
+  g.Mo = Mo; g.No = No; g.R = R; g.splits = split_k; g.k_per_split = R / split_k;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  hipStream_t s = ait_stream(stream);
+  AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * Mo * No * R, s, Mo, No, R, 1, 0, split_k);
+  if (kUseBig && (No % Big::BN) == 0 && (g.k_per_split % Big::BK) == 0 &&
+      (long long)(Mo / Big::BM) * (No / Big::BN) * split_k >= 192)
+    return launch_tn<Big>(g, s);
+  return launch_tn<Small>(g, s);
+}
+
+AIT_API int ait_colsum_bf16(const void* x, long long rows, int cols, long long ld, float* out, void* stream) {
+  if (rows < 0 || cols < 0 || (cols & 3) || ld < cols || (ld & 3)) return AIT_EINVAL;
+  if (rows == 0 || cols == 0) return AIT_OK;
+  if (!x || !out || (reinterpret_cast<uintptr_t>(x) & 7)) return AIT_EINVAL;
+  const int threads = cols / 4 >= 256 ? 256 : (cols / 4 > 64 ? 128 : 64);
+  const unsigned gy = (unsigned)((cols / 4 + threads - 1) / threads);
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)((rows + 127) / 128), gy), dim3(threads), 0, ait_stream(stream),
+                     static_cast<const unsigned short*>(x), rows, cols, ld, out);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
 }
 
 AIT_API int ait_f32_to_bf16(const float* src, long long rows, int cols, long long ld_src, void* dst, long long ld_dst,

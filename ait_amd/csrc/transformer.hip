@@ -220,10 +220,59 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
 // PositionwiseFeedForward (SubLayers.py:177-187) on `rows` token rows; h / f are scratch in eval and the
 // saved activations in training (with mean / rstd of the closing LayerNorm)
 struct FfnBuf { float *h, *f, *mean, *rstd; };
+
+// ---- the feed-forward block with its 2048-wide tensors STORED in bf16 (AIT_CTX_BF16; BASELINE configs[4]) ------------
+// h = relu(x W1^T + b1) and dh exist only as bf16 (in the first half of the f32 buffers the block owns anyway), the two
+// 512-wide operands x and df are converted on the way in (a sixth of the bytes of h), the weights and their transposes are
+// converted once per forward into the block's pre-split-weight scratch (unused in this mode); all six products run on
+// ait_gemm_bf16s / ait_gemm_bf16s_tn (csrc/gemm_bf16s.hip): bf16 operands from memory, f32 accumulate.  Same products as
+// the f32-storage bf16 mode (which rounds the same values in registers); the summation order differs.
+// Taken when the scratch is there and the shapes fit the bf16 kernels (whole 32-row slabs per split).
+struct Bf16Ffn {
+  bool on = false;
+  int split = 1;
+  unsigned short *w1, *w1t, *w2, *w2t;     // [DI, D], [D, DI], [D, DI], [DI, D]
+};
+inline Bf16Ffn bf16_ffn_plan(long long rows, const Run& s, const P3W& p1, const P3W& p2) {
+  Bf16Ffn b;
+#ifdef AIT_LAB_NO_BF16_FFN      // lab knob (scripts/build_variant.py): the f32-storage feed-forward in the bf16 mode, for A/Bs
+  return b;
+#endif
+  if (!s.ctx || !(s.ctx->flags & AIT_CTX_BF16) || !p1.w.p || !p2.w.p || rows < 256 || rows > 0x7fffffffLL / DI) return b;
+  // split-K of the two weight gradients (32 tiles each): 16 ranges = one round of the 512 resident workgroups; more ranges
+  // only add atomic traffic to a 4-MB result (64: 250 TFLOP/s against 570-590, profiles/r05_bf16_storage_ffn.txt)
+  for (int sp : {16, 8, 4, 2, 1}) {
+    if (rows % sp == 0 && (rows / sp) % 32 == 0 && (rows / sp >= 512 || sp == 1)) { b.split = sp; b.on = true; break; }
+  }
+  if (!b.on) return b;
+  b.w1 = const_cast<unsigned short*>(p1.w.p); b.w1t = b.w1 + (size_t)DI * D;      // (6 bytes per value are carved: 4 used)
+  b.w2 = const_cast<unsigned short*>(p2.w.p); b.w2t = b.w2 + (size_t)DI * D;
+  return b;
+}
+
+// PositionwiseFeedForward (SubLayers.py:177-187) on `rows` token rows; h / f are scratch in eval and the
+// saved activations in training (with mean / rstd of the closing LayerNorm)
 int ffn_block(const float* x, long long rows, const ait_ffn_weights& w, const FfnBuf& m, float p,
               unsigned long long seed, float* y, const Run& s, const P3W& p1 = P3W(), const P3W& p2 = P3W()) {
-  AIT_TRY(linear(x, (int)rows, D, w.w1, DI, w.b1, true, m.h, s, p1.w));
-  AIT_TRY(linear(m.h, (int)rows, DI, w.w2, D, w.b2, false, m.f, s, p2.w));
+  const Bf16Ffn b = bf16_ffn_plan(rows, s, p1, p2);
+  if (b.on) {
+    unsigned short* h16 = reinterpret_cast<unsigned short*>(m.h);                 // [rows, DI] bf16: the first half of m.h
+    unsigned short* x16 = h16 + (size_t)rows * DI;                                // [rows, D] bf16, in the second half
+    AIT_TRY(ait_f32_to_bf16(w.w1, DI, D, D, b.w1, D, 0, s.stream));
+    AIT_TRY(ait_f32_to_bf16(w.w2, D, DI, DI, b.w2, DI, 0, s.stream));
+    if (p1.wt.p) {          // training: the transposes the backward multiplies by
+      AIT_TRY(ait_f32_to_bf16(w.w1, DI, D, D, b.w1t, DI, 1, s.stream));
+      AIT_TRY(ait_f32_to_bf16(w.w2, D, DI, DI, b.w2t, D, 1, s.stream));
+    }
+    AIT_TRY(ait_f32_to_bf16(x, rows, D, D, x16, D, 0, s.stream));
+    AIT_TRY(ait_gemm_bf16s((int)rows, DI, D, x16, D, b.w1, D, nullptr, 0, h16, DI, w.b1, nullptr, nullptr, 0, AIT_GEMM_RELU,
+                           s.ctx, s.stream));
+    AIT_TRY(ait_gemm_bf16s((int)rows, D, DI, h16, DI, b.w2, DI, m.f, D, nullptr, 0, w.b2, nullptr, nullptr, 0, 0, s.ctx,
+                           s.stream));
+  } else {
+    AIT_TRY(linear(x, (int)rows, D, w.w1, DI, w.b1, true, m.h, s, p1.w));
+    AIT_TRY(linear(m.h, (int)rows, DI, w.w2, D, w.b2, false, m.f, s, p2.w));
+  }
   return ait_ln_fwd(m.f, nullptr, x, w.ln_g, w.ln_b, rows, D, T, T, 1, kEps, p, ait_dropout_seed(seed, 0), y, m.mean,
                     m.rstd, s.stream);
 }
@@ -235,6 +284,23 @@ int ffn_block_bwd(const float* dy, const float* x, long long rows, const ait_ffn
   // df at w_2's output (its column sums are d b2), dres on the residual branch
   AIT_TRY(ait_ln_bwd(dy, m.f, nullptr, x, w.ln_g, m.mean, m.rstd, rows, D, T, T, 1, T, p, ait_dropout_seed(seed, 0),
                      t.df, t.dres, g.ln_g, g.ln_b, g.b2, s.stream));
+  const Bf16Ffn b = bf16_ffn_plan(rows, s, p1, p2);
+  if (b.on && p1.wt.p) {
+    // (the forward of this step stored h and the weight copies in bf16: same plan, same predicate)
+    const unsigned short* h16 = reinterpret_cast<const unsigned short*>(m.h);
+    unsigned short* dh16 = reinterpret_cast<unsigned short*>(t.dh);               // [rows, DI] bf16: first half of t.dh
+    unsigned short* df16 = dh16 + (size_t)rows * DI;                              // [rows, D], [rows, D]: in the second half
+    unsigned short* x16 = df16 + (size_t)rows * D;
+    AIT_TRY(ait_f32_to_bf16(t.df, rows, D, D, df16, D, 0, s.stream));
+    if (g.w2) AIT_TRY(ait_gemm_bf16s_tn(D, DI, R, df16, D, h16, DI, g.w2, DI, b.split, s.ctx, s.stream));      // d W2 += df^T h
+    AIT_TRY(ait_gemm_bf16s(R, DI, D, df16, D, b.w2t, D, nullptr, 0, dh16, DI, nullptr, nullptr, h16, DI, AIT_GEMM_MASK_POS,
+                           s.ctx, s.stream));                                                                   // dh = (df W2) [h > 0]
+    if (g.b1) AIT_TRY(ait_colsum_bf16(dh16, rows, DI, DI, g.b1, s.stream));                                    // d b1
+    AIT_TRY(ait_f32_to_bf16(x, rows, D, D, x16, D, 0, s.stream));
+    if (g.w1) AIT_TRY(ait_gemm_bf16s_tn(DI, D, R, dh16, DI, x16, D, g.w1, D, b.split, s.ctx, s.stream));       // d W1 += dh^T x
+    return ait_gemm_bf16s(R, D, DI, dh16, DI, b.w1t, DI, dx, D, nullptr, 0, nullptr, t.dres, nullptr, D, 0, s.ctx,
+                          s.stream);                                                                            // dx = dh W1 + dres
+  }
   AIT_TRY(wgrad(t.df, rows, D, m.h, DI, g.w2, s));                             // d W2 += df^T h
   AIT_TRY(dgrad(t.df, R, D, w.w2, DI, m.h, true, t.dh, s, g.b1, p2.wt));      // dh = (df W2) [h > 0];  d b1 += column sums
   AIT_TRY(wgrad(t.dh, rows, DI, x, D, g.w1, s));                               // d W1 += dh^T x

@@ -284,6 +284,28 @@ def gemm_bf16s(a16, b16, bias=None, residual=None, gate16=None, relu=False, mask
     return out32, out16
 
 
+def gemm_bf16s_tn(dy16, x16, out=None, split_k=None):
+    """ait_gemm_bf16s_tn: out [Mo, No] f32 (+)= dy16^T @ x16 over the R token rows, bf16 operands [R, Mo] / [R, No]"""
+    assert dy16.dtype == torch.bfloat16 and x16.dtype == torch.bfloat16 and dy16.shape[0] == x16.shape[0]
+    R, Mo = dy16.shape
+    No = x16.shape[1]
+    if split_k is None:
+        split_k = 1
+        tiles = max(1, (Mo // 256) * (No // 128))
+        for cand in (64, 32, 16, 8, 4, 2):
+            if R % cand == 0 and (R // cand) % 32 == 0 and R // cand >= 512 and tiles * cand <= 2048:
+                split_k = cand
+                break
+    if out is None:
+        out = torch.zeros((Mo, No), dtype=torch.float32, device=dy16.device)
+    with torch.cuda.device(dy16.device):
+        rc = _lib.lib().ait_gemm_bf16s_tn(Mo, No, R, ctypes.c_void_p(dy16.data_ptr()), dy16.stride(0),
+                                          ctypes.c_void_p(x16.data_ptr()), x16.stride(0), _p(out), out.stride(0), int(split_k),
+                                          _lib.launch_ctx(dy16.device), _lib.cur_stream(dy16.device))
+    _lib.check(rc, "ait_gemm_bf16s_tn")
+    return out
+
+
 def p3_split(w, transpose=False):
     """The pre-split form of a weight (include/ait_hip.h "P3"): w [rows, cols] f32 -> bf16 [rows, cols/8, 3, 8] (planes h,
     m, l of every value, x = h + m + l exactly), or with transpose=True the same of w.t(): [cols, rows/8, 3, 8]."""

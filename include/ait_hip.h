@@ -389,6 +389,15 @@ int ait_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, float alpha, co
 int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, float* C32,
                    long long ldc32, void* C16, long long ldc16, const float* bias, const float* residual,
                    const void* gate16, long long ldr, int flags, const ait_launch_ctx* ctx, void* stream);
+/* ... and the weight-gradient product of that mode: C[Mo, No] (f32, pitch ldc) += sum over the R token rows of
+ * A[r, m] * B[r, n], A = bf16 [R, Mo] (the output gradient), B = bf16 [R, No] (the layer's input), both row-major with
+ * the REDUCTION index outermost (pitches in elements, multiples of 8).  Mo % 256 == 0, No % 128 == 0; the rows are cut into
+ * split_k equal ranges of whole 32-row slabs (R % split_k == 0, (R / split_k) % 32 == 0: pad the operands with zero rows)
+ * whose partial tiles are ADDED to C with f32 atomics -- zero C for a plain gradient (SubLayers.py:181-183's weights). */
+int ait_gemm_bf16s_tn(int Mo, int No, int R, const void* A, long long lda, const void* B, long long ldb, float* C,
+                      long long ldc, int split_k, const ait_launch_ctx* ctx, void* stream);
+/* out[c] += sum_r x[r * ld + c] over a bf16 matrix (cols, ld % 4 == 0): ait_colsum_f32 for a gradient stored in bf16 */
+int ait_colsum_bf16(const void* x, long long rows, int cols, long long ld, float* out, void* stream);
 /* f32 [rows, cols] (pitch ld_src) -> bf16, nearest even: dst[r, c] (pitch ld_dst >= cols; cols, pitches % 4 == 0), or with
  * transpose != 0 dst[c, r] (pitch ld_dst >= rows, even).  The per-step weight copies (and their transposes, the B operand of
  * the input-gradient products) and the activations whose producer is not one of this library's bf16-emitting kernels. */

@@ -35,3 +35,23 @@ for M in (int(sys.argv[1]) if len(sys.argv) > 1 else 262144, 76800):
               "convert A %.3f ms (%.0f GB/s)" % (name, M, N, K, fl / t32 / 1e9, fl / t16 / 1e9, fl / tb / 1e9, fl / told / 1e9, tc,
                                                  M * K * 6 / tc / 1e6), flush=True)
         del a, b, a16, b16, o32, o16
+
+print("weight-gradient products (bf16 operands, reduction outermost, split-K atomics) vs the f32-storage kernels in bf16-products mode")
+from ait_amd.system import _wgrad
+for R in (262144, 76800):
+    for name, Mo, No in (("dW2", 512, 2048), ("dW1", 2048, 512), ("dWqkv", 1536, 512)):
+        dy, x = torch.randn(R, Mo, device="cuda"), torch.randn(R, No, device="cuda")
+        dy16, x16 = dy.to(torch.bfloat16), x.to(torch.bfloat16)
+        out = torch.zeros(Mo, No, device="cuda")
+        fl = 2.0 * R * Mo * No
+        best = None
+        for sk in (8, 16, 32, 64):
+            if R % sk or (R // sk) % 32:
+                continue
+            t = timeit(lambda: ops.gemm_bf16s_tn(dy16, x16, out=out, split_k=sk))
+            best = (t, sk) if best is None or t < best[0] else best
+        ops.set_matmul_dtype("bf16")
+        told = timeit(lambda: _wgrad(dy, x))
+        ops.set_matmul_dtype("f32")
+        print("%-6s R=%6d %4d x %4d | bf16s-tn %6.1f TF/s (split %d) | f32-storage bf16 products %6.1f" %
+              (name, R, Mo, No, fl / best[0] / 1e9, best[1], fl / told / 1e9), flush=True)

@@ -714,7 +714,8 @@ def test_every_epilogue_and_tile_family_the_step_launches_is_reproducible():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (1000, 256, 64), (4097, 512, 512), (19200, 2048, 512), (777, 1536, 2048)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (1000, 256, 64), (4097, 512, 512), (19200, 2048, 512), (777, 1536, 2048),
+                                   (12290, 1024, 1024), (50000, 512, 2048)])       # (the last two: the 256 x 256 x 64 tile)
 def test_bf16_storage_gemm_against_float64(M, N, K):
     """ait_gemm_bf16s (csrc/gemm_bf16s.hip): bf16 operands stored in memory, f32 accumulate; against the float64 product of
     the SAME bf16 values (the only error left is the f32 accumulation), every epilogue: bias, ReLU, residual, the two
@@ -742,3 +743,22 @@ def test_bf16_storage_gemm_against_float64(M, N, K):
     want = (ref * (g16.float() > 0)).float().to(torch.bfloat16)
     assert float((y.float() - want.float()).abs().max()) <= 2.0 ** -7 * float(want.float().abs().max())
     assert bool(((y.float() == 0) == ((g16.float() <= 0) | (want.float() == 0))).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,Mo,No,sk", [(64, 256, 128, 1), (2048, 512, 2048, 4), (4800, 2048, 512, 5), (76800, 512, 2048, 16)])
+def test_bf16_storage_weight_gradient_product_against_float64(R, Mo, No, sk):
+    """ait_gemm_bf16s_tn: dW[Mo, No] += dy^T x over the token rows, bf16 operands row-major with the reduction index
+    outermost (the transposing LDS read ds_read_b64_tr_b16 builds the MFMA operands); split-K partials added with f32
+    atomics: against the float64 product of the same bf16 values, and accumulation into a non-zero destination."""
+    from ait_amd import ops
+    torch.manual_seed(R + Mo)
+    dy16 = torch.randn(R, Mo, device="cuda").to(torch.bfloat16)
+    x16 = torch.randn(R, No, device="cuda").to(torch.bfloat16)
+    ref = dy16.double().t() @ x16.double()
+    mag = dy16.double().abs().t() @ x16.double().abs()
+    got = ops.gemm_bf16s_tn(dy16, x16, split_k=sk)
+    assert float(((got.double() - ref).abs() / mag).max()) < 4e-6, float(((got.double() - ref).abs() / mag).max())
+    base = torch.randn(Mo, No, device="cuda")
+    got2 = ops.gemm_bf16s_tn(dy16, x16, out=base.clone(), split_k=sk)
+    assert float(((got2.double() - ref - base.double()).abs() / (mag + 1)).max()) < 4e-6

@@ -288,15 +288,14 @@ int ffn_block_bwd(const float* dy, const float* x, long long rows, const ait_ffn
   if (b.on && p1.wt.p) {
     // (the forward of this step stored h and the weight copies in bf16: same plan, same predicate)
     const unsigned short* h16 = reinterpret_cast<const unsigned short*>(m.h);
+    const unsigned short* x16 = h16 + (size_t)rows * DI;                          // the forward's bf16 copy of x, still there
     unsigned short* dh16 = reinterpret_cast<unsigned short*>(t.dh);               // [rows, DI] bf16: first half of t.dh
-    unsigned short* df16 = dh16 + (size_t)rows * DI;                              // [rows, D], [rows, D]: in the second half
-    unsigned short* x16 = df16 + (size_t)rows * D;
+    unsigned short* df16 = dh16 + (size_t)rows * DI;                              // [rows, D]: in the second half
     AIT_TRY(ait_f32_to_bf16(t.df, rows, D, D, df16, D, 0, s.stream));
     if (g.w2) AIT_TRY(ait_gemm_bf16s_tn(D, DI, R, df16, D, h16, DI, g.w2, DI, b.split, s.ctx, s.stream));      // d W2 += df^T h
     AIT_TRY(ait_gemm_bf16s(R, DI, D, df16, D, b.w2t, D, nullptr, 0, dh16, DI, nullptr, nullptr, h16, DI, AIT_GEMM_MASK_POS,
                            s.ctx, s.stream));                                                                   // dh = (df W2) [h > 0]
     if (g.b1) AIT_TRY(ait_colsum_bf16(dh16, rows, DI, DI, g.b1, s.stream));                                    // d b1
-    AIT_TRY(ait_f32_to_bf16(x, rows, D, D, x16, D, 0, s.stream));
     if (g.w1) AIT_TRY(ait_gemm_bf16s_tn(DI, D, R, dh16, DI, x16, D, g.w1, D, b.split, s.ctx, s.stream));       // d W1 += dh^T x
     return ait_gemm_bf16s(R, D, DI, dh16, DI, b.w1t, DI, dx, D, nullptr, 0, nullptr, t.dres, nullptr, D, 0, s.ctx,
                           s.stream);                                                                            // dx = dh W1 + dres

@@ -227,8 +227,15 @@ NATIVE_F32 = False   # ops.set_matmul_dtype("f32_native"): dense products on v_m
 BF16_PRODUCTS = False   # ops.set_matmul_dtype("bf16"): operands rounded to bf16 in registers, one MFMA per block
 
 
-def launch_ctx(device=None):
-    """byref(ait_launch_ctx) for a launch on the current stream of `device`"""
+def current_flags():
+    """ait_launch_ctx::flags of the product form in force (ops.set_matmul_dtype)"""
+    return CTX_BF16 if BF16_PRODUCTS else (CTX_NATIVE_F32 if NATIVE_F32 else 0)
+
+
+def launch_ctx(device=None, flags=None):
+    """byref(ait_launch_ctx) for a launch on the current stream of `device`.  flags: None = the product form in force;
+    an int = exactly these flags (a backward pass gives the flags of ITS forward: the saved activations of the bf16-storage
+    feed-forward are bf16 only if the forward ran in that mode)"""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     st = torch.cuda.current_stream(dev)
@@ -256,10 +263,7 @@ def launch_ctx(device=None):
     pr = _ACTIVE_PROBE
     if pr is not None and pr._p and pr.device_index == idx:
         ctx.probe = pr._p
-    if BF16_PRODUCTS:
-        ctx.flags = CTX_BF16
-    elif NATIVE_F32:
-        ctx.flags = CTX_NATIVE_F32
+    ctx.flags = current_flags() if flags is None else int(flags)
     return ctypes.byref(ctx)
 
 

@@ -420,7 +420,7 @@ _PART_PARAMS = (
 
 class _AitState:
     """what the three backward parts of one forward share (plain Python object: not a tensor, not saved by autograd)"""
-    __slots__ = ("fw", "ws", "W", "keep", "cfg", "shapes", "_dxq")
+    __slots__ = ("fw", "ws", "W", "keep", "cfg", "shapes", "_dxq", "flags")
 
 
 def _grads_struct(views_by_index):
@@ -475,7 +475,7 @@ def _ait_backward_part(st, part, d_out, kept, want_dxp=False, want_dxq=False):
                                         ctypes.c_void_p(st.ws.data_ptr()), st.ws.numel(),
                                         None if dxp is None else _lib.dev_ptr(dxp),
                                         None if dxq is None else _lib.dev_ptr(dxq), ctypes.byref(G),
-                                        _lib.launch_ctx(dev), _lib.cur_stream(dev))
+                                        _lib.launch_ctx(dev, flags=st.flags), _lib.cur_stream(dev))
     _lib.check(rc, "ait_transformer_bwd_part(%d)" % part)
     return [views[i] for i in idx], dxp, dxq
 
@@ -493,9 +493,11 @@ class _AitCore(torch.autograd.Function):
         saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         out = torch.empty((bp * SEQ, xp.shape[1]), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
+            st.flags = _lib.current_flags()      # the backward parts run in the product form of this forward
             rc = L.ait_transformer_fwd_train(_lib.dev_ptr(xp), _lib.dev_ptr(xq), bp, bs, n_s, ctypes.byref(st.W),
                                              float(p), float(p_attn), int(seed), ctypes.c_void_p(saved.data_ptr()),
-                                             nbytes, _lib.dev_ptr(out), _lib.launch_ctx(dev), _lib.cur_stream(dev))
+                                             nbytes, _lib.dev_ptr(out), _lib.launch_ctx(dev, flags=st.flags),
+                                             _lib.cur_stream(dev))
         _lib.check(rc, "ait_transformer_fwd_train")
         # the multi-GB activation buffer and the two inputs are the NODES' saved tensors (all three nodes save the same
         # storages): autograd frees them when the graph is freed -- not when the Python state object dies -- and an
@@ -538,6 +540,7 @@ class _AitStage(torch.autograd.Function):
 def _transformer_train(xp, xq, bp, bs, n_s, p, p_attn, seed, W, keep, params):
     st = _AitState.__new__(_AitState)
     st.ws = st.fw = st._dxq = None
+    st.flags = 0
     st.W, st.keep = W, keep                        # (keep owns the concatenated QKV matrices W points into)
     st.cfg = (bp, bs, n_s, float(p), float(p_attn), int(seed))
     st.shapes = [tuple(t.shape) for t in params]

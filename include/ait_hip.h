@@ -76,7 +76,10 @@ const char* ait_strerror(int code);
  *       and ONE v_mfma_f32_32x32x16_bf16 per block, f32 accumulate, f32 operands and results in memory -- what
  *       torch.autocast(bfloat16) computes for a linear layer with f32 parameters (BASELINE configs[4]); NOT f32
  *       accuracy (8 significant bits per operand).  Honoured by the products, the composites and the convolutions
- *       (ait_conv_*, ait_tail_*).
+ *       (ait_conv_*, ait_tail_*).  Inside ait_transformer_fwd_train / ait_transformer_bwd_part the feed-forward blocks
+ *       additionally STORE their 2048-wide tensors (the ReLU output h, its gradient) in bf16 and multiply bf16 operands
+ *       from memory (ait_gemm_bf16s, ait_gemm_bf16s_tn; shapes permitting): the `saved` buffer of such a forward holds
+ *       bf16 where an f32 forward holds f32, so THE BACKWARD MUST BE GIVEN THE FLAGS OF ITS FORWARD.
  * ------------------------------------------------------------------------------------- */
 #define AIT_CTX_NATIVE_F32 1u
 #define AIT_CTX_BF16 2u

@@ -31,16 +31,9 @@ struct HeadsArgs {
   int R, bs, P, F, n_bbox;
 };
 
-// dot of this lane's strided share of two F-vectors (float4 index = lane + 64 j)
-__device__ __forceinline__ float dot_share(const float4* __restrict__ a, const float4* __restrict__ b, int n4, int lane) {
-  float s = 0.f;
-  for (int j = lane; j < n4; j += 64) {
-    const float4 x = a[j], y = b[j];
-    s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-  }
-  return s;
-}
-
+// PER = float4 per lane of an F-vector (F = 256 PER): the row's and the pair's query share are fetched ONCE into registers
+// (2 PER independent 16-B loads in flight), then every weight row is PER more independent loads against them.
+template <int PER>
 __global__ __launch_bounds__(64 * kRowsPerBlock) void heads_fwd_kernel(const HeadsArgs g, float* __restrict__ bbox,
                                                                        float* __restrict__ hidden, float* __restrict__ score) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -49,15 +42,29 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void heads_fwd_kernel(const Hea
   const int n4 = g.F / 4;
   const float4* x = reinterpret_cast<const float4*>(g.props + (size_t)r * g.F);
   const float4* q = reinterpret_cast<const float4*>(g.query + (size_t)(r / g.P) * g.F);
-  // (the row's 8 KB are re-read per dot product from L1; HBM sees them once)
+  float4 xs[PER], qs[PER];
+#pragma unroll
+  for (int i = 0; i < PER; i++) {
+    xs[i] = x[lane + 64 * i];
+    qs[i] = q[lane + 64 * i];
+  }
+  auto dot = [&](const float4 (&v)[PER], const float4* __restrict__ w) __attribute__((always_inline)) -> float {
+    float4 wv[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) wv[i] = w[lane + 64 * i];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++) s += v[i].x * wv[i].x + v[i].y * wv[i].y + v[i].z * wv[i].z + v[i].w * wv[i].w;
+    return s;
+  };
   float hb[kMaxBox], hh[kHid];
 #pragma unroll
   for (int k = 0; k < kMaxBox; k++)
-    hb[k] = k < g.n_bbox ? dot_share(x, reinterpret_cast<const float4*>(g.w_bbox + (size_t)k * g.F), n4, lane) : 0.f;
+    hb[k] = k < g.n_bbox ? dot(xs, reinterpret_cast<const float4*>(g.w_bbox + (size_t)k * g.F)) : 0.f;
 #pragma unroll
   for (int j = 0; j < kHid; j++) {
     const float4* wp = reinterpret_cast<const float4*>(g.w1 + (size_t)j * 2 * g.F);
-    hh[j] = dot_share(x, wp, n4, lane) + dot_share(q, wp + n4, n4, lane);
+    hh[j] = dot(xs, wp) + dot(qs, wp + n4);
   }
 #pragma unroll
   for (int k = 0; k < kMaxBox; k++) hb[k] = wave_sum(hb[k]);
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(256) void heads_bwd_wide_kernel(const HeadsArgs g, 
 inline int check_args(int R, int bs, int F, int n_bbox) {
   if (R < 0 || bs <= 0 || F <= 0 || n_bbox < 0) return AIT_EINVAL;
   if (R % bs) return AIT_EINVAL;
-  if ((F % 4) || n_bbox > kMaxBox) return AIT_EUNSUPPORTED;
+  if ((F % 256) || F > 4096 || n_bbox > kMaxBox) return AIT_EUNSUPPORTED;      // a lane owns F / 256 float4 of a row
   return AIT_OK;
 }
 
@@ -246,8 +253,15 @@ AIT_API int ait_heads_fwd(const float* props, const float* query, int R, int bs,
   if (!props || !query || !w1 || !b1 || !w2 || !b2 || !hidden || !score || (n_bbox > 0 && (!w_bbox || !b_bbox || !bbox_pred)))
     return AIT_EINVAL;
   HeadsArgs g{props, query, w_bbox, b_bbox, w1, b1, w2, b2, R, bs, R / bs, F, n_bbox};
-  hipLaunchKernelGGL(heads_fwd_kernel, dim3((R + kRowsPerBlock - 1) / kRowsPerBlock), dim3(64 * kRowsPerBlock), 0,
-                     ait_stream(stream), g, bbox_pred, hidden, score);
+  const dim3 grid((R + kRowsPerBlock - 1) / kRowsPerBlock), block(64 * kRowsPerBlock);
+  switch (F / 256) {
+    case 1: hipLaunchKernelGGL(heads_fwd_kernel<1>, grid, block, 0, ait_stream(stream), g, bbox_pred, hidden, score); break;
+    case 2: hipLaunchKernelGGL(heads_fwd_kernel<2>, grid, block, 0, ait_stream(stream), g, bbox_pred, hidden, score); break;
+    case 4: hipLaunchKernelGGL(heads_fwd_kernel<4>, grid, block, 0, ait_stream(stream), g, bbox_pred, hidden, score); break;
+    case 8: hipLaunchKernelGGL(heads_fwd_kernel<8>, grid, block, 0, ait_stream(stream), g, bbox_pred, hidden, score); break;
+    case 16: hipLaunchKernelGGL(heads_fwd_kernel<16>, grid, block, 0, ait_stream(stream), g, bbox_pred, hidden, score); break;
+    default: return AIT_EUNSUPPORTED;
+  }
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }

@@ -740,7 +740,8 @@ class _fasterRCNN(nn.Module):
             props_feat = self._head_to_tail(props_feat, subsampled=sk_stride != 1)   # [bs*P, 2048]
             query_feat = self._head_to_tail(query_feat, subsampled=sk_stride != 1)   # [bs, 2048]
 
-        if props_feat.is_cuda and props_feat.dtype == torch.float32 and _HEADS_KERNEL and self.RCNN_bbox_pred.out_features <= 8:
+        if (props_feat.is_cuda and props_feat.dtype == torch.float32 and _HEADS_KERNEL and self.RCNN_bbox_pred.out_features <= 8
+                and props_feat.shape[1] in (256, 512, 1024, 2048, 4096)):
             # both heads in the library (csrc/heads.hip): no [bs*P, 4096] concatenation, no vendor GEMM under the logits
             bbox_pred, score = _HeadsFn.apply(props_feat, query_feat, self.RCNN_bbox_pred.weight, self.RCNN_bbox_pred.bias,
                                               self.RCNN_cls_score[0].weight, self.RCNN_cls_score[0].bias,

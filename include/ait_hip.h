@@ -741,7 +741,7 @@ int ait_tail_bwd(const float* d_pooled, const float* x_props, const float* x_que
  * proposal features, and the similarity classifier nn.Sequential(nn.Linear(2F, 8), nn.Linear(8, 2)) on
  * cat(props, query repeated over the R / bs proposals of its pair) -- whose output `score` [R, 2] is the per-proposal
  * similarity logit pair (:288).  Replaces three ATen addmm calls (vendor GEMM) and the [R, 2F] concatenation.
- *   props [R, F], query [bs, F] (R % bs == 0, F % 4 == 0, n_bbox <= 8); weights in nn.Linear layout: w_bbox [n_bbox, F],
+ *   props [R, F], query [bs, F] (R % bs == 0, F in {256, 512, 1024, 2048, 4096}, n_bbox <= 8); weights in nn.Linear layout: w_bbox [n_bbox, F],
  *   w1 [8, 2F] (columns [0, F) meet props, [F, 2F) the query), w2 [2, 8]; outputs bbox_pred [R, n_bbox], hidden [R, 8]
  *   (the first layer's output: saved for the backward), score [R, 2].
  *   backward: d_bbox / d_score may be NULL (no gradient from that head); d_props / d_query are WRITTEN (either may be

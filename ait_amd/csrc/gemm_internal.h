@@ -24,3 +24,8 @@ int ait_gemm_f32_p3b(int M, int N, int K, float alpha, const float* A, int lda, 
 int ait_conv_bwd_data_s2(const float* dy, int lddy, const float* w, const ait_conv_geom* q, const float* dy1, int lddy1,
                          const float* w1, int cin, int cout, const float* residual, int flags, float* dx, int lddx,
                          const float* zeros, const ait_launch_ctx* ctx, void* stream);
+
+// ait_attn_bwd with the three gradients written as bf16 (out_bf16 != 0; pitches in elements) -- csrc/attn_bwd.hip
+int ait_attn_bwd_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* P, const float* dO,
+                    int n_seq, int H, int T, int d, int kv_rows, float scale, float p_drop, unsigned long long seed, void* dq,
+                    int lddq, void* dk, int lddk, void* dv, int lddv, int out_bf16, void* stream);

@@ -106,6 +106,16 @@ inline int wgrad(const float* dy, long long M, int N_out, const float* x, int K_
                       sp, 0, 0, s.ctx, s.stream);
 }
 
+// K-ranges of a bf16 weight-gradient product over R token rows (ait_gemm_bf16s_tn): 16 where the rows allow -- the
+// partial tiles are added with f32 atomics, and their traffic is what more ranges buy: measured on cfg5's shapes
+// (profiles/r05_bf16_storage_ffn.txt) 16 ranges 528-613 TFLOP/s, 32 ranges 328-377, 64 ranges 234-265 -- in whole 32-row
+// slabs per range.  0: none fits.  (Results of fewer than 24 tiles of 256 x 128 -- the cross-attention block's two
+// projections -- stay on the f32-storage kernels: 16 ranges leave the chip half empty there, 254-370 against 410-464.)
+inline int bf16_tn_split(long long R) {
+  for (int sp = 16; sp >= 1; sp /= 2)
+    if (R > 0 && R % sp == 0 && (R / sp) % 32 == 0 && (R / sp >= 512 || sp == 1)) return sp;
+  return 0;
+}
 // buffers of one MultiHeadAttention block: scratch in eval, the saved activations in training
 struct MhaBuf {
   float *qkv;          // self: [M, 1536];  cross: q [M, 512] then kv [n*kv_rows, 1024]
@@ -202,6 +212,53 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
   if (g.sk_b) AIT_TRY(ait_colsum_f32(t.dg, n, D, D, g.sk_b, s.stream));
   const Qkv v = views(m, n, cross);
   float* dq = t.dqkv;
+  // ---- bf16 storage of the attention gradients (AIT_CTX_BF16, round 5): dq / dk / dv leave the attention kernel as bf16
+  // (their only consumers are the two products below), the block's input and the transposed projection weight are
+  // converted once, and the input gradient / weight gradient run on the bf16-operand kernels (csrc/gemm_bf16s.hip).
+  // Shapes permitting (whole 32-row slabs per K-range of the weight gradients), else the f32-storage products below.
+  {
+    const long long R2 = (long long)n * kv_rows;
+    int sp = 0, sp2 = 0;
+#ifndef AIT_LAB_NO_BF16_ATTN      // lab knob: the f32-storage projection backward in the bf16 mode, for A/Bs
+    if (s.ctx && (s.ctx->flags & AIT_CTX_BF16) && pq.w.p && M >= 256) {
+#else
+    if (false) {
+#endif
+      if (!cross) sp = bf16_tn_split(M);          // self-attention blocks only (see bf16_tn_split)
+    }
+    if (sp && (!cross || sp2)) {
+      unsigned short* wt16 = const_cast<unsigned short*>(pq.w.p);              // W_qkv^T as bf16 [D, 3D] (2 of the 6 carved bytes per value)
+      unsigned short* g16 = reinterpret_cast<unsigned short*>(t.dqkv);          // the gradients, bf16, in the first half of t.dqkv
+      AIT_TRY(ait_f32_to_bf16(w.w_qkv, 3 * D, D, D, wt16, 3 * D, 1, s.stream));
+      if (!cross) {
+        unsigned short* x16 = g16 + (size_t)M * 3 * D;                          // [M, D] in the second half
+        AIT_TRY(ait_attn_bwd_ex(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
+                                ait_dropout_seed(seed, 0), g16, 3 * D, g16 + D, 3 * D, g16 + 2 * D, 3 * D, 1, s.stream));
+        AIT_TRY(ait_f32_to_bf16(xq, M, D, D, x16, D, 0, s.stream));
+        AIT_TRY(ait_gemm_bf16s(M, D, 3 * D, g16, 3 * D, wt16, 3 * D, dxq, D, nullptr, 0, nullptr, t.dres, nullptr, D, 0, s.ctx,
+                               s.stream));                                                                   // dx = dqkv W_qkv + dres
+        if (g.w_qkv) AIT_TRY(ait_gemm_bf16s_tn(3 * D, D, M, g16, 3 * D, x16, D, g.w_qkv, D, sp, s.ctx, s.stream));
+        return AIT_OK;
+      }
+      unsigned short* dq16 = g16;                                               // [M, D]
+      unsigned short* dkv16 = dq16 + (size_t)M * D;                             // [R2, 2D]
+      unsigned short* x16 = dkv16 + (size_t)R2 * 2 * D;                         // [M, D]
+      unsigned short* xkv16 = x16 + (size_t)M * D;                              // [R2, D]
+      AIT_TRY(ait_attn_bwd_ex(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
+                              ait_dropout_seed(seed, 0), dq16, D, dkv16, 2 * D, dkv16 + D, 2 * D, 1, s.stream));
+      AIT_TRY(ait_f32_to_bf16(xq, M, D, D, x16, D, 0, s.stream));
+      AIT_TRY(ait_f32_to_bf16(xkv, R2, D, D, xkv16, D, 0, s.stream));
+      AIT_TRY(ait_gemm_bf16s(M, D, D, dq16, D, wt16, 3 * D, dxq, D, nullptr, 0, nullptr, t.dres, nullptr, D, 0, s.ctx, s.stream));
+      if (dxkv)
+        AIT_TRY(ait_gemm_bf16s((int)R2, D, 2 * D, dkv16, 2 * D, wt16 + D, 3 * D, dxkv, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0,
+                               s.ctx, s.stream));
+      if (g.w_qkv) {
+        AIT_TRY(ait_gemm_bf16s_tn(D, D, M, dq16, D, x16, D, g.w_qkv, D, sp, s.ctx, s.stream));
+        AIT_TRY(ait_gemm_bf16s_tn(2 * D, D, (int)R2, dkv16, 2 * D, xkv16, D, g.w_qkv + (size_t)D * D, D, sp2, s.ctx, s.stream));
+      }
+      return AIT_OK;
+    }
+  }
   if (!cross) {
     AIT_TRY(ait_attn_bwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
                          ait_dropout_seed(seed, 0), dq, 3 * D, dq + D, 3 * D, dq + 2 * D, 3 * D, s.stream));
@@ -239,11 +296,8 @@ inline Bf16Ffn bf16_ffn_plan(long long rows, const Run& s, const P3W& p1, const 
   return b;
 #endif
   if (!s.ctx || !(s.ctx->flags & AIT_CTX_BF16) || !p1.w.p || !p2.w.p || rows < 256 || rows > 0x7fffffffLL / DI) return b;
-  // split-K of the two weight gradients (32 tiles each): 16 ranges = one round of the 512 resident workgroups; more ranges
-  // only add atomic traffic to a 4-MB result (64: 250 TFLOP/s against 570-590, profiles/r05_bf16_storage_ffn.txt)
-  for (int sp : {16, 8, 4, 2, 1}) {
-    if (rows % sp == 0 && (rows / sp) % 32 == 0 && (rows / sp >= 512 || sp == 1)) { b.split = sp; b.on = true; break; }
-  }
+  b.split = bf16_tn_split(rows);
+  b.on = b.split > 0;
   if (!b.on) return b;
   b.w1 = const_cast<unsigned short*>(p1.w.p); b.w1t = b.w1 + (size_t)DI * D;      // (6 bytes per value are carved: 4 used)
   b.w2 = const_cast<unsigned short*>(p2.w.p); b.w2t = b.w2 + (size_t)DI * D;

@@ -29,3 +29,9 @@ int ait_conv_bwd_data_s2(const float* dy, int lddy, const float* w, const ait_co
 int ait_attn_bwd_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* P, const float* dO,
                     int n_seq, int H, int T, int d, int kv_rows, float scale, float p_drop, unsigned long long seed, void* dq,
                     int lddq, void* dk, int lddk, void* dv, int lddv, int out_bf16, void* stream);
+
+// ait_ln_bwd with the gradient `da` also / instead written as bf16 (da16: [rows, 512] bf16 or NULL) -- csrc/rowwise.hip
+int ait_ln_bwd_ex(const float* dy, const float* a, const float* pos, const float* residual, const float* gamma,
+                  const float* mean, const float* rstd, long long rows, int d, int seq_len, int src_rows_per_seq, int rep,
+                  int dy_rows_per_seq, float p_drop, unsigned long long seed, float* da, float* dres, float* dgamma,
+                  float* dbeta, float* dcolsum, void* da16, void* stream);

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
     const float* __restrict__ res, const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, long long rows, RowMap m, float p, unsigned long long seed,
     float* __restrict__ da, float* __restrict__ dres, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, float* __restrict__ dcolsum) {
+    float* __restrict__ dbeta, float* __restrict__ dcolsum, unsigned short* __restrict__ da16) {
   __shared__ float red[3][kRowsPerBlock][kD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c0 = lane * kVec;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < kVec; i++) dz[i] = (wd[i] - s1 - xh[i] * s2) * rs;
     if (dres) store8(dres + (size_t)r * kD + c0, dz);
-    if (da || dcolsum) {
+    if (da || da16 || dcolsum) {
       const long long sr = src_row(m, r);      // padded rows have no source: no gradient, no column sum
       if (sr >= 0) {
 #pragma unroll
@@ -189,6 +189,12 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
           dc[i] += dz[i];
         }
         if (da) store8(da + (size_t)(m.rep == 1 ? sr : r) * kD + c0, dz);   // rep == 1: source indexing
+        if (da16) {      // the same gradient rounded to bf16 (nearest even): the bf16-storage feed-forward's operand
+          typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+          auto pk = [](float x0, float x1) { bf16x2_ t; t[0] = (__bf16)x0; t[1] = (__bf16)x1; return __builtin_bit_cast(unsigned, t); };
+          *reinterpret_cast<uint4*>(da16 + (size_t)(m.rep == 1 ? sr : r) * kD + c0) =
+              make_uint4(pk(dz[0], dz[1]), pk(dz[2], dz[3]), pk(dz[4], dz[5]), pk(dz[6], dz[7]));
+        }
       }
     }
   }
@@ -595,11 +601,12 @@ AIT_API int ait_ln_fwd(const float* a, const float* pos, const float* residual,
                          mean, rstd, stream);
 }
 
-AIT_API int ait_ln_bwd(const float* dy, const float* a, const float* pos, const float* residual,
-                       const float* gamma, const float* mean, const float* rstd, long long rows,
-                       int d, int seq_len, int src_rows_per_seq, int rep, int dy_rows_per_seq,
-                       float p_drop, unsigned long long seed, float* da, float* dres, float* dgamma,
-                       float* dbeta, float* dcolsum, void* stream) {
+// da16 (library-internal, csrc/transformer.hip): the gradient `da` ALSO / INSTEAD written as bf16 [rows, 512]
+int ait_ln_bwd_ex(const float* dy, const float* a, const float* pos, const float* residual,
+                  const float* gamma, const float* mean, const float* rstd, long long rows,
+                  int d, int seq_len, int src_rows_per_seq, int rep, int dy_rows_per_seq,
+                  float p_drop, unsigned long long seed, float* da, float* dres, float* dgamma,
+                  float* dbeta, float* dcolsum, void* da16, void* stream) {
   if (rows < 0 || seq_len <= 0 || src_rows_per_seq <= 0 || src_rows_per_seq > seq_len ||
       rep < 1 || p_drop < 0.f || p_drop >= 1.f || dy_rows_per_seq <= 0 || dy_rows_per_seq > seq_len)
     return AIT_EINVAL;
@@ -612,9 +619,19 @@ AIT_API int ait_ln_bwd(const float* dy, const float* a, const float* pos, const 
   long long b = (rows + 63) / 64;
   unsigned grid = (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(kThreads), 0, ait_stream(stream), dy, a, pos,
-                     residual, gamma, mean, rstd, rows, m, p_drop, seed, da, dres, dgamma, dbeta, dcolsum);
+                     residual, gamma, mean, rstd, rows, m, p_drop, seed, da, dres, dgamma, dbeta, dcolsum,
+                     static_cast<unsigned short*>(da16));
   AIT_CHECK_LAUNCH();
   return AIT_OK;
+}
+
+AIT_API int ait_ln_bwd(const float* dy, const float* a, const float* pos, const float* residual,
+                       const float* gamma, const float* mean, const float* rstd, long long rows,
+                       int d, int seq_len, int src_rows_per_seq, int rep, int dy_rows_per_seq,
+                       float p_drop, unsigned long long seed, float* da, float* dres, float* dgamma,
+                       float* dbeta, float* dcolsum, void* stream) {
+  return ait_ln_bwd_ex(dy, a, pos, residual, gamma, mean, rstd, rows, d, seq_len, src_rows_per_seq, rep, dy_rows_per_seq, p_drop,
+                       seed, da, dres, dgamma, dbeta, dcolsum, nullptr, stream);
 }
 
 AIT_API int ait_colsum_f32(const float* x, long long rows, int cols, long long ld, float* out, void* stream) {

@@ -335,17 +335,19 @@ int ffn_block_bwd(const float* dy, const float* x, long long rows, const ait_ffn
                   const FfnBwdWs& t, float p, unsigned long long seed, float* dx, const ait_ffn_grads& g, const Run& s,
                   const P3W& p1 = P3W(), const P3W& p2 = P3W()) {
   const int R = (int)rows;
-  // df at w_2's output (its column sums are d b2), dres on the residual branch
-  AIT_TRY(ait_ln_bwd(dy, m.f, nullptr, x, w.ln_g, m.mean, m.rstd, rows, D, T, T, 1, T, p, ait_dropout_seed(seed, 0),
-                     t.df, t.dres, g.ln_g, g.ln_b, g.b2, s.stream));
   const Bf16Ffn b = bf16_ffn_plan(rows, s, p1, p2);
-  if (b.on && p1.wt.p) {
+  const bool b16 = b.on && p1.wt.p;
+  // df at w_2's output (its column sums are d b2), dres on the residual branch; in the bf16-storage mode df is written
+  // as bf16 only (its consumers are the two bf16 products below)
+  unsigned short* df16_ = b16 ? reinterpret_cast<unsigned short*>(t.dh) + (size_t)rows * DI : nullptr;
+  AIT_TRY(ait_ln_bwd_ex(dy, m.f, nullptr, x, w.ln_g, m.mean, m.rstd, rows, D, T, T, 1, T, p, ait_dropout_seed(seed, 0),
+                        b16 ? nullptr : t.df, t.dres, g.ln_g, g.ln_b, g.b2, df16_, s.stream));
+  if (b16) {
     // (the forward of this step stored h and the weight copies in bf16: same plan, same predicate)
     const unsigned short* h16 = reinterpret_cast<const unsigned short*>(m.h);
     const unsigned short* x16 = h16 + (size_t)rows * DI;                          // the forward's bf16 copy of x, still there
     unsigned short* dh16 = reinterpret_cast<unsigned short*>(t.dh);               // [rows, DI] bf16: first half of t.dh
-    unsigned short* df16 = dh16 + (size_t)rows * DI;                              // [rows, D]: in the second half
-    AIT_TRY(ait_f32_to_bf16(t.df, rows, D, D, df16, D, 0, s.stream));
+    const unsigned short* df16 = df16_;                                           // [rows, D]: in the second half of t.dh
     if (g.w2) AIT_TRY(ait_gemm_bf16s_tn(D, DI, R, df16, D, h16, DI, g.w2, DI, b.split, s.ctx, s.stream));      // d W2 += df^T h
     AIT_TRY(ait_gemm_bf16s(R, DI, D, df16, D, b.w2t, D, nullptr, 0, dh16, DI, nullptr, nullptr, h16, DI, AIT_GEMM_MASK_POS,
                            s.ctx, s.stream));                                                                   // dh = (df W2) [h > 0]

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_nhwc_fwd_sliced_kernel(
   }
 }
 
-// Forward, channel-sliced AND separable in two stages (round 5; profiles/r05_roi_align_sep.txt).  The sliced kernel
+// Forward, channel-sliced AND separable in two stages (round 5; LAB: built with -DAIT_ROI_FWD_SEPARABLE, see kFwdSeparable; profiles/r05_roi_align_sep.txt).  The sliced kernel
 // above walks, per bin row ph, its band of feature rows, and per row every bin's band of cells: a cell under two bins is
 // loaded twice, a row under two bin rows twice more (2-4x redundant loads, each behind its own address computation --
 // the PMC pass of round 4 found the waves 0.83 of their cycles in s_waitcnt).  Here every cell of the RoI's window is

@@ -30,9 +30,13 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // Tile families (every wave owns 128 x 64 outputs = 4 x 2 MFMA blocks, 128 accumulator registers):
 //   Small  256 x 128 x 32, 4 waves, three 24-KB stages: two workgroups per CU -- one's epilogue under the other's MFMAs.
-//          The 512-deep products of the AIT (an output tile per 16 slabs).
-//   Big    256 x 256 x 64, 8 waves, two 64-KB stages: one workgroup per CU, half the operand traffic per product and a
-//          barrier per 32 MFMAs of a wave instead of 16.  Long reductions: K >= 1024, and the weight gradients.
+//          Outputs narrower than 256 columns or too few tiles for the other.
+//   Big    256 x 256 x 64, 8 waves, two 64-KB stages: one workgroup per CU.  A third less operand traffic per product
+//          (128 against 85 FLOP per byte fetched into LDS) in whole 128-B lines instead of 64-B halves, a barrier per 32
+//          MFMAs of a wave instead of 16.  These kernels are bound by L2 -> LDS bandwidth (at the pipe's ~2000 TFLOP/s the
+//          small tile would pull 24 TB/s), which is why the big tile wins even on the 512-deep products whose epilogue it
+//          cannot hide: 510-560 against 410-460 TFLOP/s with an f32 result, 610-665 against 520-555 with a bf16 one
+//          (profiles/r05_bf16_storage_gemm_product_kernel.txt).  K >= 512, and the weight gradients.
 template <int BM_, int BN_, int BK_, int NS_, int WM_, int WN_>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, NS = NS_, WM = WM_, WN = WN_;
@@ -503,7 +507,11 @@ AIT_API int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, co
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K, s, M, N, K, 0, 1, 1);
   // long reductions on the 256 x 256 x 64 tile (at least a round of them), the 512-deep products on the 256 x 128 x 32 one
   const long long big_tiles = (long long)((M + Big::BM - 1) / Big::BM) * (N / Big::BN);
-  if (kUseBig && K >= 1024 && (K % Big::BK) == 0 && (N % Big::BN) == 0 && big_tiles >= 192) return launch_epi<Big>(g, gate, s);
+#ifndef AIT_LAB_BF16S_BIG_MINK
+#define AIT_LAB_BF16S_BIG_MINK 512       // lab knob: the shortest reduction the 256 x 256 x 64 tile takes
+#endif
+  if (kUseBig && K >= AIT_LAB_BF16S_BIG_MINK && (K % Big::BK) == 0 && (N % Big::BN) == 0 && big_tiles >= 192)
+    return launch_epi<Big>(g, gate, s);
   return launch_epi<Small>(g, gate, s);
 }
 

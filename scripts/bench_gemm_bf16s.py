@@ -2,7 +2,9 @@
 bf16 outputs, against the f32-storage kernels in their bf16-products mode (ops.set_matmul_dtype('bf16')): TFLOP/s."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
+import _lab_lib  # noqa: F401  (AIT_LAB_LIB=<name>: a lab build of the library)
 from ait_amd import ops
 
 

@@ -389,10 +389,13 @@ __global__ __launch_bounds__(256) void to_bf16_t_kernel(const float* __restrict_
   for (int i = threadIdx.x; i < 64 * 32; i += 256) {
     const int c = i >> 5, r = (i & 31) * 2;
     if (c0 + c < cols && r0 + r < rows) {
-      if (r0 + r + 1 < rows)
-        *reinterpret_cast<unsigned*>(dst + (long long)(c0 + c) * ld_dst + r0 + r) = pack2(tile[r][c], tile[r + 1][c]);
-      else
-        dst[(long long)(c0 + c) * ld_dst + r0 + r] = (unsigned short)(pack2(tile[r][c], 0.f) & 0xffffu);
+      const unsigned v = pack2(tile[r][c], tile[r + 1][c]);
+      unsigned short* d = dst + (long long)(c0 + c) * ld_dst + r0 + r;
+      if (r0 + r + 1 < rows && !(ld_dst & 1)) *reinterpret_cast<unsigned*>(d) = v;      // (even pitch: 4-byte aligned pairs)
+      else {
+        d[0] = (unsigned short)(v & 0xffffu);
+        if (r0 + r + 1 < rows) d[1] = (unsigned short)(v >> 16);
+      }
     }
   }
 }
@@ -556,7 +559,7 @@ AIT_API int ait_f32_to_bf16(const float* src, long long rows, int cols, long lon
   if (!src || !dst || ld_src < cols) return AIT_EINVAL;
   hipStream_t s = ait_stream(stream);
   if (transpose) {
-    if (ld_dst < rows || (ld_dst % 2) || (reinterpret_cast<uintptr_t>(dst) & 3)) return AIT_EUNSUPPORTED;
+    if (ld_dst < rows || (reinterpret_cast<uintptr_t>(dst) & 3)) return AIT_EUNSUPPORTED;
     const long long bx = (rows + 63) / 64;
     if (bx > 0x7fffffffLL || (cols + 63) / 64 > 65535) return AIT_EUNSUPPORTED;
     hipLaunchKernelGGL(to_bf16_t_kernel, dim3((unsigned)bx, (unsigned)((cols + 63) / 64)), dim3(256), 0, s, src, rows, cols, ld_src,

@@ -402,7 +402,7 @@ int ait_gemm_bf16s_tn(int Mo, int No, int R, const void* A, long long lda, const
 /* out[c] += sum_r x[r * ld + c] over a bf16 matrix (cols, ld % 4 == 0): ait_colsum_f32 for a gradient stored in bf16 */
 int ait_colsum_bf16(const void* x, long long rows, int cols, long long ld, float* out, void* stream);
 /* f32 [rows, cols] (pitch ld_src) -> bf16, nearest even: dst[r, c] (pitch ld_dst >= cols; cols, pitches % 4 == 0), or with
- * transpose != 0 dst[c, r] (pitch ld_dst >= rows, even).  The per-step weight copies (and their transposes, the B operand of
+ * transpose != 0 dst[c, r] (pitch ld_dst >= rows; any shape).  The per-step weight copies (and their transposes, the B operand of
  * the input-gradient products) and the activations whose producer is not one of this library's bf16-emitting kernels. */
 int ait_f32_to_bf16(const float* src, long long rows, int cols, long long ld_src, void* dst, long long ld_dst,
                     int transpose, void* stream);

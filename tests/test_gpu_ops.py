@@ -697,3 +697,43 @@ def test_detector_heads_run_in_the_library_and_keep_module_hooks():
     assert torch.allclose(score, lin_s(stack), rtol=1e-4, atol=1e-5) and torch.allclose(bbox, lin_b(props), rtol=1e-4, atol=1e-5)
     (score.sum() + bbox.sum()).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in list(lin_b.parameters()) + list(lin_s.parameters()))
+
+
+def test_round5_entry_points_check_their_arguments():
+    """ABI v6 additions refuse what they do not support with the documented codes (include/ait_hip.h) instead of
+    launching: the bf16-storage products, the conversions, the heads, the dropout-mask read-back."""
+    import ctypes
+    from ait_amd import _lib, ops
+    L = _lib.lib()
+    st = _lib.cur_stream(torch.device("cuda"))
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    OK, EINVAL, EUNSUPPORTED = 0, -1, -4                 # include/ait_hip.h
+    a16 = torch.zeros(64, 64, device="cuda", dtype=torch.bfloat16)
+    c32 = torch.zeros(256, 256, device="cuda")
+    # weight-gradient product: rows must split into whole 32-row slabs; outputs in whole 256 x 128 tiles
+    big = torch.zeros(96, 256, device="cuda", dtype=torch.bfloat16)
+    assert L.ait_gemm_bf16s_tn(256, 256, 96, vp(big), 256, vp(big), 256, vp(c32), 256, 2, None, st) == EUNSUPPORTED
+    assert L.ait_gemm_bf16s_tn(200, 256, 96, vp(big), 256, vp(big), 256, vp(c32), 256, 1, None, st) == EUNSUPPORTED
+    assert L.ait_gemm_bf16s_tn(256, 256, 96, vp(big), 256, vp(big), 256, vp(c32), 256, 1, None, st) == OK
+    # NT product: N in whole 128-column tiles, K in whole 32-deep slabs, at least one result
+    assert L.ait_gemm_bf16s(64, 64, 64, vp(a16), 64, vp(a16), 64, vp(c32), 64, None, 0, None, None, None, 0, 0, None, st) == EUNSUPPORTED
+    w16 = torch.zeros(128, 64, device="cuda", dtype=torch.bfloat16)
+    assert L.ait_gemm_bf16s(64, 128, 64, vp(a16), 64, vp(w16), 64, None, 0, None, 0, None, None, None, 0, 0, None, st) == EINVAL
+    assert L.ait_gemm_bf16s(0, 128, 64, vp(a16), 64, vp(w16), 64, vp(c32), 128, None, 0, None, None, None, 0, 0, None, st) == OK
+    # conversions: odd shapes through the transposing form are fine, the straight form wants columns % 4 == 0
+    x = torch.randn(37, 10, device="cuda")
+    assert torch.equal(ops.to_bf16(x, transpose=True), x.t().contiguous().to(torch.bfloat16))
+    dst = torch.zeros(37, 12, device="cuda", dtype=torch.bfloat16)
+    assert L.ait_f32_to_bf16(vp(x), 37, 10, 10, vp(dst), 12, 0, st) == EUNSUPPORTED
+    # heads: feature width must be one of the register-resident sizes
+    p = torch.zeros(4, 100, device="cuda")
+    z = torch.zeros(8, 200, device="cuda")
+    o = torch.zeros(4, 8, device="cuda")
+    assert L.ait_heads_fwd(vp(p), vp(p), 4, 2, 100, vp(p), vp(p), 4, vp(z), vp(z), vp(z), vp(z), vp(o), vp(o), vp(o), st) == EUNSUPPORTED
+    assert L.ait_heads_fwd(vp(p), vp(p), 0, 2, 256, vp(p), vp(p), 4, vp(z), vp(z), vp(z), vp(z), vp(o), vp(o), vp(o), st) == OK
+    # dropout mask: p = 0 keeps everything at factor 1; p outside [0, 1) is refused
+    assert bool((ops.dropout_mask(123, 0, 1000, 0.0, "cuda") == 1).all())
+    m = ops.dropout_mask(123, 5, 4096, 0.25, "cuda")
+    assert set(torch.unique(m).tolist()) <= {0.0, float(np.float32(1) / np.float32(0.75))} and 0.70 < float((m != 0).float().mean()) < 0.80
+    assert torch.equal(m[7:100], ops.dropout_mask(123, 12, 93, 0.25, "cuda"))            # a function of (seed, absolute index)
+    assert L.ait_dropout_mask(1, 0, 10, ctypes.c_float(1.0), vp(o), st) == EINVAL

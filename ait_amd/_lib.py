@@ -52,7 +52,7 @@ SIGNATURES = {
     "ait_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
                           _i, ctypes.c_longlong, _vp, _vp]),
     "ait_gemm_bf16s": (_i, [_i, _i, _i, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _ll, _i, _vp, _vp]),
-    "ait_gemm_bf16s_tn": (_i, [_i, _i, _i, _vp, _ll, _vp, _ll, _vp, _ll, _i, _vp, _vp]),
+    "ait_gemm_bf16s_tn": (_i, [_i, _i, _i, _vp, _ll, _vp, _ll, _vp, _ll, _i, _vp, _sz, _vp, _vp]),
     "ait_colsum_bf16": (_i, [_vp, _ll, _i, _ll, _vp, _vp]),
     "ait_f32_to_bf16": (_i, [_vp, _ll, _i, _ll, _vp, _ll, _i, _vp]),
     "ait_p3_bytes": (_sz, [_ll, _ll]),

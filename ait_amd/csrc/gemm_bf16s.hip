@@ -236,6 +236,7 @@ struct TnArgs {
   const unsigned short* A;      // [R, Mo] (pitch lda)
   const unsigned short* B;      // [R, No] (pitch ldb)
   float* C;                     // [Mo, No] (pitch ldc), accumulated
+  float* partials;              // PARTIAL: [splits][Mo][No] scratch, every element written once (no atomics); reduced afterwards
   int Mo, No, R, splits, k_per_split;
   long long lda, ldb, ldc;
 };
@@ -249,7 +250,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off_lo,
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <class T>
+template <class T, bool PARTIAL>
 __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NS = T::NS, STAGE = T::STAGE;
@@ -348,12 +349,18 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g)
         for (int b = 0; b < 2; b++)
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            float* dst = g.C + (size_t)row * g.ldc + n0 + wn + b * 32 + 8 * q + 4 * lk;
+            const int col = n0 + wn + b * 32 + 8 * q + 4 * lk;
+            if constexpr (PARTIAL) {      // this K-range's tile, stored once (16-B stores); tn_reduce_kernel adds the ranges
+              float* dst = g.partials + ((size_t)(k0 / g.k_per_split) * g.Mo + row) * g.No + col;
+              *reinterpret_cast<float4*>(dst) =
+                  make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+            } else {
+              float* dst = g.C + (size_t)row * g.ldc + col;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-              unsafeAtomicAdd(dst + r, acc[a][b][4 * q + r]);
-              acc[a][b][4 * q + r] = 0.f;
+              for (int r = 0; r < 4; r++) unsafeAtomicAdd(dst + r, acc[a][b][4 * q + r]);
             }
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[a][b][4 * q + r] = 0.f;
           }
       }
       done = 0;
@@ -460,16 +467,39 @@ int launch_epi(const Args& g, bool gate, hipStream_t s) {
   if (g.residual) return launch<T, EPI_RES>(g, s);
   return launch<T, EPI_PLAIN>(g, s);
 }
-template <class T>
+// C[m, n] += sum over the K-ranges of partials[s][m][n]  (16-B loads; in range order: reproducible)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partials, int splits, int Mo, int No,
+                                                        float* __restrict__ C, long long ldc) {
+  const long long n4 = (long long)Mo * (No / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long m = i / (No / 4);
+    const int c = (int)(i - m * (No / 4)) * 4;
+    float4* dst = reinterpret_cast<float4*>(C + m * ldc + c);
+    float4 acc = *dst;
+    for (int sp = 0; sp < splits; sp++) {
+      const float4 v = *reinterpret_cast<const float4*>(partials + ((size_t)sp * Mo + m) * No + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *dst = acc;
+  }
+}
+
+template <class T, bool PARTIAL>
 int launch_tn(const TnArgs& g, hipStream_t s) {
-  const void* kern = reinterpret_cast<const void*>(gemm_bf16s_tn_kernel<T>);
+  const void* kern = reinterpret_cast<const void*>(gemm_bf16s_tn_kernel<T, PARTIAL>);
   static int memo = 0;
   const int slots = slots_of<T>(kern, memo);
   if (slots <= 0) return AIT_ELAUNCH;
   const long long items = (long long)(g.Mo / T::BM) * (g.No / T::BN) * g.splits;
   const int grid = (int)(items < slots ? items : slots);
-  hipLaunchKernelGGL((gemm_bf16s_tn_kernel<T>), dim3(grid), dim3(T::NT), T::LDS, s, g);
+  hipLaunchKernelGGL((gemm_bf16s_tn_kernel<T, PARTIAL>), dim3(grid), dim3(T::NT), T::LDS, s, g);
   AIT_CHECK_LAUNCH();
+  if (PARTIAL) {
+    const long long want = ((long long)g.Mo * (g.No / 4) + 255) / 256;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(want > 4096 ? 4096 : want)), dim3(256), 0, s, g.partials, g.splits, g.Mo,
+                       g.No, g.C, g.ldc);
+    AIT_CHECK_LAUNCH();
+  }
   return AIT_OK;
 }
 
@@ -519,12 +549,13 @@ AIT_API int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, co
 }
 
 AIT_API int ait_gemm_bf16s_tn(int Mo, int No, int R, const void* A, long long lda, const void* B, long long ldb, float* C,
-                              long long ldc, int split_k, const ait_launch_ctx* ctx, void* stream) {
+                              long long ldc, int split_k, void* partials, size_t partials_bytes, const ait_launch_ctx* ctx,
+                              void* stream) {
   if (Mo < 0 || No < 0 || R < 0) return AIT_EINVAL;
   if (Mo == 0 || No == 0 || R == 0) return AIT_OK;
   if (!A || !B || !C) return AIT_EINVAL;
   if ((Mo % Small::BM) || (No % Small::BN) || (lda % 8) || (ldb % 8) || lda < Mo || ldb < No || (ldc % 4) || ldc < No ||
-      (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15))
+      (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (reinterpret_cast<uintptr_t>(C) & 15))
     return AIT_EUNSUPPORTED;
   if (split_k < 1) split_k = 1;
   if ((R % split_k) || ((R / split_k) % Small::BK)) return AIT_EUNSUPPORTED;      // whole 32-row slabs per split
@@ -532,12 +563,22 @@ AIT_API int ait_gemm_bf16s_tn(int Mo, int No, int R, const void* A, long long ld
   g.A = static_cast<const unsigned short*>(A); g.B = static_cast<const unsigned short*>(B); g.C = C;
   g.Mo = Mo; g.No = No; g.R = R; g.splits = split_k; g.k_per_split = R / split_k;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  // with scratch for one partial tile set per K-range the ranges are stored once and added by a second small launch
+  // (in range order: reproducible); without it they are added to C with f32 atomics -- a third of the product's time at 16
+  // ranges (profiles/r05_bf16_storage_ffn.txt)
+  const size_t need = (size_t)split_k * Mo * No * sizeof(float);
+#ifndef AIT_LAB_TN_ATOMICS      // lab knob: always the atomic form
+  const bool use_partials = split_k > 1 && partials && partials_bytes >= need && !(reinterpret_cast<uintptr_t>(partials) & 15);
+#else
+  const bool use_partials = false && need;
+#endif
+  g.partials = use_partials ? static_cast<float*>(partials) : nullptr;
   hipStream_t s = ait_stream(stream);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * Mo * No * R, s, Mo, No, R, 1, 0, split_k);
-  if (kUseBig && (No % Big::BN) == 0 && (g.k_per_split % Big::BK) == 0 &&
-      (long long)(Mo / Big::BM) * (No / Big::BN) * split_k >= 192)
-    return launch_tn<Big>(g, s);
-  return launch_tn<Small>(g, s);
+  const bool big = kUseBig && (No % Big::BN) == 0 && (g.k_per_split % Big::BK) == 0 &&
+                   (long long)(Mo / Big::BM) * (No / Big::BN) * split_k >= 192;
+  if (use_partials) return big ? launch_tn<Big, true>(g, s) : launch_tn<Small, true>(g, s);
+  return big ? launch_tn<Big, false>(g, s) : launch_tn<Small, false>(g, s);
 }
 
 AIT_API int ait_colsum_bf16(const void* x, long long rows, int cols, long long ld, float* out, void* stream) {

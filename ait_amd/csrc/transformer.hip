@@ -106,14 +106,22 @@ inline int wgrad(const float* dy, long long M, int N_out, const float* x, int K_
                       sp, 0, 0, s.ctx, s.stream);
 }
 
-// K-ranges of a bf16 weight-gradient product over R token rows (ait_gemm_bf16s_tn): 16 where the rows allow -- the
-// partial tiles are added with f32 atomics, and their traffic is what more ranges buy: measured on cfg5's shapes
-// (profiles/r05_bf16_storage_ffn.txt) 16 ranges 528-613 TFLOP/s, 32 ranges 328-377, 64 ranges 234-265 -- in whole 32-row
-// slabs per range.  0: none fits.  (Results of fewer than 24 tiles of 256 x 128 -- the cross-attention block's two
-// projections -- stay on the f32-storage kernels: 16 ranges leave the chip half empty there, 254-370 against 410-464.)
-inline int bf16_tn_split(long long R) {
-  for (int sp = 16; sp >= 1; sp /= 2)
-    if (R > 0 && R % sp == 0 && (R / sp) % 32 == 0 && (R / sp >= 512 || sp == 1)) return sp;
+// K-ranges of a bf16 weight-gradient product [Mo, No] over R token rows (ait_gemm_bf16s_tn): enough that tiles x ranges
+// fill the chip's 256 workgroup slots of the 256 x 256 tile in whole rounds (64 at most), in whole 32-row slabs per range,
+// and -- decisive -- only as many as `scratch_bytes` holds partial tiles for: stored once and reduced by a second launch the
+// ranges cost next to nothing (866-906 TFLOP/s on cfg5's feed-forward gradients), added with f32 atomics they cost a third
+// of the product at 16 ranges and more beyond (590 / 350 / 250 TFLOP/s at 16 / 32 / 64: profiles/r05_bf16_storage_ffn.txt).
+// 0: no split fits the rows.
+inline int bf16_tn_split(int Mo, int No, long long R, size_t scratch_bytes) {
+  const long long tiles = (long long)(Mo / 256) * (No % 256 == 0 ? No / 256 : No / 128);
+  if (tiles <= 0 || R <= 0) return 0;
+  int want = 1;
+  while (want < 64 && tiles * want < 256) want *= 2;
+  for (int sp = want; sp >= 1; sp /= 2) {
+    if (R % sp || (R / sp) % 32 || (R / sp < 512 && sp > 1)) continue;
+    if (sp > 16 && (size_t)sp * Mo * No * sizeof(float) > scratch_bytes) continue;      // (beyond 16 only without atomics)
+    return sp;
+  }
   return 0;
 }
 // buffers of one MultiHeadAttention block: scratch in eval, the saved activations in training
@@ -224,7 +232,11 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
 #else
     if (false) {
 #endif
-      if (!cross) sp = bf16_tn_split(M);          // self-attention blocks only (see bf16_tn_split)
+      if (!cross) sp = bf16_tn_split(3 * D, D, M, (size_t)M * 2 * D * 2);
+      else {
+        sp = bf16_tn_split(D, D, M, (size_t)R2 * 2 * D);
+        sp2 = bf16_tn_split(2 * D, D, R2, (size_t)R2 * 2 * D);
+      }
     }
     if (sp && (!cross || sp2)) {
       unsigned short* wt16 = const_cast<unsigned short*>(pq.w.p);              // W_qkv^T as bf16 [D, 3D] (2 of the 6 carved bytes per value)
@@ -237,7 +249,10 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
         AIT_TRY(ait_f32_to_bf16(xq, M, D, D, x16, D, 0, s.stream));
         AIT_TRY(ait_gemm_bf16s(M, D, 3 * D, g16, 3 * D, wt16, 3 * D, dxq, D, nullptr, 0, nullptr, t.dres, nullptr, D, 0, s.ctx,
                                s.stream));                                                                   // dx = dqkv W_qkv + dres
-        if (g.w_qkv) AIT_TRY(ait_gemm_bf16s_tn(3 * D, D, M, g16, 3 * D, x16, D, g.w_qkv, D, sp, s.ctx, s.stream));
+        // (scratch for the K-ranges' partial tiles: what is left of t.dqkv's second half behind x16)
+        if (g.w_qkv)
+          AIT_TRY(ait_gemm_bf16s_tn(3 * D, D, M, g16, 3 * D, x16, D, g.w_qkv, D, sp, x16 + (size_t)M * D, (size_t)M * 2 * D * 2,
+                                    s.ctx, s.stream));
         return AIT_OK;
       }
       unsigned short* dq16 = g16;                                               // [M, D]
@@ -253,8 +268,12 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
         AIT_TRY(ait_gemm_bf16s((int)R2, D, 2 * D, dkv16, 2 * D, wt16 + D, 3 * D, dxkv, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0,
                                s.ctx, s.stream));
       if (g.w_qkv) {
-        AIT_TRY(ait_gemm_bf16s_tn(D, D, M, dq16, D, x16, D, g.w_qkv, D, sp, s.ctx, s.stream));
-        AIT_TRY(ait_gemm_bf16s_tn(2 * D, D, (int)R2, dkv16, 2 * D, xkv16, D, g.w_qkv + (size_t)D * D, D, sp2, s.ctx, s.stream));
+        // (scratch for the partial tiles: the R2 * 2D bytes of t.dqkv behind the four bf16 tensors)
+        void* part = xkv16 + (size_t)R2 * D;
+        const size_t part_bytes = (size_t)R2 * 2 * D;
+        AIT_TRY(ait_gemm_bf16s_tn(D, D, M, dq16, D, x16, D, g.w_qkv, D, sp, part, part_bytes, s.ctx, s.stream));
+        AIT_TRY(ait_gemm_bf16s_tn(2 * D, D, (int)R2, dkv16, 2 * D, xkv16, D, g.w_qkv + (size_t)D * D, D, sp2, part, part_bytes,
+                                  s.ctx, s.stream));
       }
       return AIT_OK;
     }
@@ -296,7 +315,7 @@ inline Bf16Ffn bf16_ffn_plan(long long rows, const Run& s, const P3W& p1, const 
   return b;
 #endif
   if (!s.ctx || !(s.ctx->flags & AIT_CTX_BF16) || !p1.w.p || !p2.w.p || rows < 256 || rows > 0x7fffffffLL / DI) return b;
-  b.split = bf16_tn_split(rows);
+  b.split = bf16_tn_split(D, DI, rows, (size_t)rows * (DI - D) * 2);      // (both weight gradients: 16 tiles of 256 x 256)
   b.on = b.split > 0;
   if (!b.on) return b;
   b.w1 = const_cast<unsigned short*>(p1.w.p); b.w1t = b.w1 + (size_t)DI * D;      // (6 bytes per value are carved: 4 used)
@@ -348,11 +367,14 @@ int ffn_block_bwd(const float* dy, const float* x, long long rows, const ait_ffn
     const unsigned short* x16 = h16 + (size_t)rows * DI;                          // the forward's bf16 copy of x, still there
     unsigned short* dh16 = reinterpret_cast<unsigned short*>(t.dh);               // [rows, DI] bf16: first half of t.dh
     const unsigned short* df16 = df16_;                                           // [rows, D]: in the second half of t.dh
-    if (g.w2) AIT_TRY(ait_gemm_bf16s_tn(D, DI, R, df16, D, h16, DI, g.w2, DI, b.split, s.ctx, s.stream));      // d W2 += df^T h
+    // (scratch for the K-ranges' partial tiles of the two weight gradients: t.dh's second half behind df16)
+    void* part = const_cast<unsigned short*>(df16) + (size_t)rows * D;
+    const size_t part_bytes = (size_t)rows * (DI - D) * 2;
+    if (g.w2) AIT_TRY(ait_gemm_bf16s_tn(D, DI, R, df16, D, h16, DI, g.w2, DI, b.split, part, part_bytes, s.ctx, s.stream));   // d W2 += df^T h
     AIT_TRY(ait_gemm_bf16s(R, DI, D, df16, D, b.w2t, D, nullptr, 0, dh16, DI, nullptr, nullptr, h16, DI, AIT_GEMM_MASK_POS,
                            s.ctx, s.stream));                                                                   // dh = (df W2) [h > 0]
     if (g.b1) AIT_TRY(ait_colsum_bf16(dh16, rows, DI, DI, g.b1, s.stream));                                    // d b1
-    if (g.w1) AIT_TRY(ait_gemm_bf16s_tn(DI, D, R, dh16, DI, x16, D, g.w1, D, b.split, s.ctx, s.stream));       // d W1 += dh^T x
+    if (g.w1) AIT_TRY(ait_gemm_bf16s_tn(DI, D, R, dh16, DI, x16, D, g.w1, D, b.split, part, part_bytes, s.ctx, s.stream));    // d W1 += dh^T x
     return ait_gemm_bf16s(R, D, DI, dh16, DI, b.w1t, DI, dx, D, nullptr, 0, nullptr, t.dres, nullptr, D, 0, s.ctx,
                           s.stream);                                                                            // dx = dh W1 + dres
   }

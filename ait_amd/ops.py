@@ -284,7 +284,7 @@ def gemm_bf16s(a16, b16, bias=None, residual=None, gate16=None, relu=False, mask
     return out32, out16
 
 
-def gemm_bf16s_tn(dy16, x16, out=None, split_k=None):
+def gemm_bf16s_tn(dy16, x16, out=None, split_k=None, partials=True):
     """ait_gemm_bf16s_tn: out [Mo, No] f32 (+)= dy16^T @ x16 over the R token rows, bf16 operands [R, Mo] / [R, No]"""
     assert dy16.dtype == torch.bfloat16 and x16.dtype == torch.bfloat16 and dy16.shape[0] == x16.shape[0]
     R, Mo = dy16.shape
@@ -298,9 +298,11 @@ def gemm_bf16s_tn(dy16, x16, out=None, split_k=None):
                 break
     if out is None:
         out = torch.zeros((Mo, No), dtype=torch.float32, device=dy16.device)
+    ws = torch.empty(int(split_k) * Mo * No, dtype=torch.float32, device=dy16.device) if (partials and split_k > 1) else None
     with torch.cuda.device(dy16.device):
         rc = _lib.lib().ait_gemm_bf16s_tn(Mo, No, R, ctypes.c_void_p(dy16.data_ptr()), dy16.stride(0),
                                           ctypes.c_void_p(x16.data_ptr()), x16.stride(0), _p(out), out.stride(0), int(split_k),
+                                          None if ws is None else ctypes.c_void_p(ws.data_ptr()), 0 if ws is None else ws.numel() * 4,
                                           _lib.launch_ctx(dy16.device), _lib.cur_stream(dy16.device))
     _lib.check(rc, "ait_gemm_bf16s_tn")
     return out

@@ -396,9 +396,12 @@ int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, const void
  * A[r, m] * B[r, n], A = bf16 [R, Mo] (the output gradient), B = bf16 [R, No] (the layer's input), both row-major with
  * the REDUCTION index outermost (pitches in elements, multiples of 8).  Mo % 256 == 0, No % 128 == 0; the rows are cut into
  * split_k equal ranges of whole 32-row slabs (R % split_k == 0, (R / split_k) % 32 == 0: pad the operands with zero rows)
- * whose partial tiles are ADDED to C with f32 atomics -- zero C for a plain gradient (SubLayers.py:181-183's weights). */
+ * whose partial tiles are ADDED to C -- zero C for a plain gradient (SubLayers.py:181-183's weights).  `partials`
+ * (optional, caller-owned, split_k * Mo * No floats, 16-byte aligned): the ranges' tiles are stored there once and added to
+ * C in range order by a second small launch (bit-reproducible); NULL or too small: f32 atomics (order-dependent rounding). */
 int ait_gemm_bf16s_tn(int Mo, int No, int R, const void* A, long long lda, const void* B, long long ldb, float* C,
-                      long long ldc, int split_k, const ait_launch_ctx* ctx, void* stream);
+                      long long ldc, int split_k, void* partials, size_t partials_bytes, const ait_launch_ctx* ctx,
+                      void* stream);
 /* out[c] += sum_r x[r * ld + c] over a bf16 matrix (cols, ld % 4 == 0): ait_colsum_f32 for a gradient stored in bf16 */
 int ait_colsum_bf16(const void* x, long long rows, int cols, long long ld, float* out, void* stream);
 /* f32 [rows, cols] (pitch ld_src) -> bf16, nearest even: dst[r, c] (pitch ld_dst >= cols; cols, pitches % 4 == 0), or with

@@ -757,8 +757,11 @@ def test_bf16_storage_weight_gradient_product_against_float64(R, Mo, No, sk):
     x16 = torch.randn(R, No, device="cuda").to(torch.bfloat16)
     ref = dy16.double().t() @ x16.double()
     mag = dy16.double().abs().t() @ x16.double().abs()
-    got = ops.gemm_bf16s_tn(dy16, x16, split_k=sk)
+    got = ops.gemm_bf16s_tn(dy16, x16, split_k=sk)                          # K-ranges stored as partial tiles, then reduced
     assert float(((got.double() - ref).abs() / mag).max()) < 4e-6, float(((got.double() - ref).abs() / mag).max())
+    assert torch.equal(got, ops.gemm_bf16s_tn(dy16, x16, split_k=sk))       # ... in range order: bit-reproducible
+    got_a = ops.gemm_bf16s_tn(dy16, x16, split_k=sk, partials=False)        # no scratch: f32 atomics
+    assert float(((got_a.double() - ref).abs() / mag).max()) < 4e-6
     base = torch.randn(Mo, No, device="cuda")
     got2 = ops.gemm_bf16s_tn(dy16, x16, out=base.clone(), split_k=sk)
     assert float(((got2.double() - ref - base.double()).abs() / (mag + 1)).max()) < 4e-6

@@ -1800,7 +1800,10 @@ int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int 
         w = wfull;
       }
     }
-    const bool sk_pays = item_slabs * (last_round - (double)rem / wfull) > 12.0;
+#ifndef AIT_LAB_SK_PAYS
+#define AIT_LAB_SK_PAYS 12.0      // lab knob: slab-times a stream-K cut of the last round must save
+#endif
+    const bool sk_pays = item_slabs * (last_round - (double)rem / wfull) > AIT_LAB_SK_PAYS;
     if (ws.p) {
       if (ws.bytes < kCtlBytes) return AIT_EWORKSPACE;
       // ticket counters for the dynamic hand-out of whole tiles (every launch), partial tiles + flags when this

@@ -99,6 +99,68 @@ __global__ __launch_bounds__(kThreads) void bn_act_bwd_kernel(
   }
 }
 
+// ---- bf16 tensors (the C4 trunk of the bf16 configuration, BASELINE configs[4]): channels-last rows, eight values
+// (16 B) per lane, f32 arithmetic, nearest-even rounding on the way out --------------------------------------------------
+__device__ __forceinline__ void unpack8(const uint4 v, float (&o)[8]) {
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+  o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 t;
+  t[0] = (__bf16)a;
+  t[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+  return make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+}
+__global__ __launch_bounds__(kThreads) void bn_act_fwd16_kernel(const unsigned short* __restrict__ x, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const unsigned short* __restrict__ res,
+                                                                int relu, long long total, int C, unsigned short* __restrict__ y) {
+  const long long stride = (long long)gridDim.x * kThreads * 8;
+  for (long long i = ((long long)blockIdx.x * kThreads + threadIdx.x) * 8; i < total; i += stride) {
+    float v[8], r[8], s[8], t[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + i), v);
+    if (res) unpack8(*reinterpret_cast<const uint4*>(res + i), r);
+    const int c = (int)(i % C);
+    *reinterpret_cast<float4*>(s) = *reinterpret_cast<const float4*>(scale + c);
+    *reinterpret_cast<float4*>(s + 4) = *reinterpret_cast<const float4*>(scale + c + 4);
+    *reinterpret_cast<float4*>(t) = *reinterpret_cast<const float4*>(shift + c);
+    *reinterpret_cast<float4*>(t + 4) = *reinterpret_cast<const float4*>(shift + c + 4);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      v[k] = v[k] * s[k] + t[k] + (res ? r[k] : 0.f);
+      if (relu) v[k] = fmaxf(v[k], 0.f);
+    }
+    *reinterpret_cast<uint4*>(y + i) = pack8(v);
+  }
+}
+__global__ __launch_bounds__(kThreads) void bn_act_bwd16_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y,
+                                                                const float* __restrict__ scale, int relu, long long total, int C,
+                                                                unsigned short* __restrict__ dx, unsigned short* __restrict__ dres) {
+  const long long stride = (long long)gridDim.x * kThreads * 8;
+  for (long long i = ((long long)blockIdx.x * kThreads + threadIdx.x) * 8; i < total; i += stride) {
+    float g[8], o[8], s[8];
+    const uint4 graw = *reinterpret_cast<const uint4*>(dy + i);
+    unpack8(graw, g);
+    if (relu) {
+      unpack8(*reinterpret_cast<const uint4*>(y + i), o);
+#pragma unroll
+      for (int k = 0; k < 8; k++) g[k] = o[k] > 0.f ? g[k] : 0.f;
+    }
+    if (dres) *reinterpret_cast<uint4*>(dres + i) = pack8(g);       // (a masked copy of bf16 values: exact)
+    const int c = (int)(i % C);
+    *reinterpret_cast<float4*>(s) = *reinterpret_cast<const float4*>(scale + c);
+    *reinterpret_cast<float4*>(s + 4) = *reinterpret_cast<const float4*>(scale + c + 4);
+#pragma unroll
+    for (int k = 0; k < 8; k++) g[k] *= s[k];
+    *reinterpret_cast<uint4*>(dx + i) = pack8(g);
+  }
+}
+
 inline unsigned grid_for(long long total) {
   long long b = (total / 4 + kThreads - 1) / kThreads;
   return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -145,6 +207,38 @@ AIT_API int ait_bn_act_bwd(const float* dy, const float* y, const float* scale, 
   else
     hipLaunchKernelGGL(bn_act_bwd_kernel<0>, dim3(grid_for(total)), dim3(kThreads), 0,
                        ait_stream(stream), dy, y, scale, relu, total, C, HW, dx, dres);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_bn_act_fwd_bf16(const void* x, const float* scale, const float* shift, const void* residual, int relu,
+                                long long rows, int C, void* y, void* stream) {
+  if (rows < 0 || C <= 0) return AIT_EINVAL;
+  const long long total = rows * C;
+  if (total == 0) return AIT_OK;
+  if (!x || !scale || !shift || !y) return AIT_EINVAL;
+  if ((C % 8) || !aligned16(x) || !aligned16(y) || (residual && !aligned16(residual)) || !aligned16(scale) || !aligned16(shift))
+    return AIT_EUNSUPPORTED;
+  long long b = (total / 8 + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(bn_act_fwd16_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(kThreads), 0, ait_stream(stream),
+                     static_cast<const unsigned short*>(x), scale, shift, static_cast<const unsigned short*>(residual), relu, total, C,
+                     static_cast<unsigned short*>(y));
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_bn_act_bwd_bf16(const void* dy, const void* y, const float* scale, int relu, long long rows, int C, void* dx,
+                                void* dres, void* stream) {
+  if (rows < 0 || C <= 0) return AIT_EINVAL;
+  const long long total = rows * C;
+  if (total == 0) return AIT_OK;
+  if (!dy || !scale || !dx || (relu && !y)) return AIT_EINVAL;
+  if ((C % 8) || !aligned16(dy) || !aligned16(dx) || (relu && !aligned16(y)) || (dres && !aligned16(dres)) || !aligned16(scale))
+    return AIT_EUNSUPPORTED;
+  long long b = (total / 8 + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(bn_act_bwd16_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(kThreads), 0, ait_stream(stream),
+                     static_cast<const unsigned short*>(dy), static_cast<const unsigned short*>(y), scale, relu, total, C,
+                     static_cast<unsigned short*>(dx), static_cast<unsigned short*>(dres));
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }

@@ -58,6 +58,7 @@ def _side_stream(device):
 
 _TAIL_FUSED = True
 _HEADS_KERNEL = True          # test hook: False = the two heads as torch nn.Linear calls (vendor GEMM)
+_TRUNK_BF16 = True            # test hook: False = the C4 trunk in f32 also in the bf16 configuration (round 4's cfg5)
 _TOP_NHWC = True
 _BASE_NHWC = True
 _ROI_NHWC = True
@@ -354,9 +355,34 @@ def _bn_affine(bn):
     return cache[1], cache[2], cache[3]
 
 
+class _BnAct16(torch.autograd.Function):
+    """_BnAct over bf16 channels-last tensors (the C4 trunk of the bf16 configuration)"""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, relu):
+        y = ops.bn_act_fwd_bf16(x, scale, shift, residual, relu)
+        ctx.save_for_backward(y if relu else None, scale)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, scale = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx, dres = ops.bn_act_bwd_bf16(dy, y, scale, ctx.relu, ctx.has_res and ctx.needs_input_grad[3])
+        return dx, None, None, dres, None
+
+
 def bn_act(x, bn, residual=None, relu=True):
     """relu(bn(x) + residual) for a FROZEN BatchNorm2d in eval mode (the only state the reference
     ever runs its BatchNorms in); anything else goes through torch."""
+    if _bn_frozen(bn) and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0:
+        scale, shift, _ = _bn_affine(bn)
+        x = x.contiguous(memory_format=torch.channels_last)
+        if residual is not None:
+            residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        return _BnAct16.apply(x, scale, shift, residual, relu)
     if not (_bn_frozen(bn) and x.is_cuda and x.dtype == torch.float32):
         y = bn(x)
         if residual is not None:
@@ -626,6 +652,15 @@ class RCNNBackbone(nn.Module):
     def forward(self, x):
         if _BASE_NHWC and x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
+        if _TRUNK_BF16 and _BASE_NHWC and x.is_cuda and _lib.BF16_PRODUCTS:
+            # the bf16 configuration (BASELINE configs[4], ops.set_matmul_dtype("bf16")): the trunk's convolutions run on
+            # MIOpen with bf16 tensors (f32 accumulate; autocast casts the f32 master weights per call), the frozen-BN /
+            # residual / ReLU passes between them read and write bf16 (ait_bn_act_*_bf16); the C4 feature goes back to f32
+            # for the co-attention, the RPN and RoIAlign.  3-4x faster convolutions (profiles/r05_trunk_bf16.txt)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                x = self.stem[3](bn_act(self.stem[0](x), self.stem[1]))
+                y = run_stages([self.layer1, self.layer2, self.layer3], x)
+            return y.float(), None
         x = self.stem[3](bn_act(self.stem[0](x), self.stem[1]))        # conv1, bn1+relu, maxpool
         # (a channels-last trunk hands its feature on channels-last: the co-attention reads token rows,
         # the RPN convolutions and the RoIAlign used here take either format)

@@ -576,6 +576,41 @@ def bn_act_bwd(dy, y, scale, relu, need_dres):
     return dx, dres
 
 
+def _cl_rows(x):
+    """(rows, C) of a 4-d bf16 tensor in channels-last memory"""
+    if not (x.dim() == 4 and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.AitHipError("bf16 bn_act: a 4-d bfloat16 tensor in channels-last memory expected")
+    return x.numel() // x.shape[1], x.shape[1]
+
+
+def bn_act_fwd_bf16(x, scale, shift, residual, relu):
+    """ait_bn_act_fwd_bf16: relu(x * scale[c] + shift[c] + residual) over bf16 channels-last tensors"""
+    rows, C = _cl_rows(x)
+    if residual is not None:
+        _cl_rows(residual)
+    y = torch.empty_like(x)
+    _same_format(x, residual, y)
+    vp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().ait_bn_act_fwd_bf16(vp(x), _p(scale), _p(shift), vp(residual), int(relu), rows, C, vp(y),
+                                            _lib.cur_stream(x.device))
+    _lib.check(rc, "ait_bn_act_fwd_bf16")
+    return y
+
+
+def bn_act_bwd_bf16(dy, y, scale, relu, need_dres):
+    rows, C = _cl_rows(dy)
+    dx = torch.empty_like(dy)
+    dres = torch.empty_like(dy) if need_dres else None
+    _same_format(dy, y, dx, dres)
+    vp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    with torch.cuda.device(dy.device):
+        rc = _lib.lib().ait_bn_act_bwd_bf16(vp(dy), vp(y), _p(scale), int(relu), rows, C, vp(dx), vp(dres),
+                                            _lib.cur_stream(dy.device))
+    _lib.check(rc, "ait_bn_act_bwd_bf16")
+    return dx, dres
+
+
 def sk_sqsum_fwd(a, b):
     y = torch.empty_like(a)
     _same_format(a, b, y)

@@ -774,6 +774,14 @@ int ait_bn_act_fwd(const float* x, const float* scale, const float* shift, const
 int ait_bn_act_bwd(const float* dy, const float* y, const float* scale, int relu, long long n,
                    int C, int HW, float* dx, float* dres, void* stream);
 
+/* The same pass over bf16 tensors in channels-last memory ([rows, C] rows of C channels, C % 8 == 0; scale / shift f32):
+ * the C4 trunk of the bf16 configuration (BASELINE configs[4]: its convolutions run on MIOpen in bf16, this is the
+ * frozen-BN / residual / ReLU pass between them).  f32 arithmetic, nearest-even rounding on the way out. */
+int ait_bn_act_fwd_bf16(const void* x, const float* scale, const float* shift, const void* residual, int relu,
+                        long long rows, int C, void* y, void* stream);
+int ait_bn_act_bwd_bf16(const void* dy, const void* y, const float* scale, int relu, long long rows, int C, void* dx,
+                        void* dres, void* stream);
+
 /* SKBlock tail as the reference executes it (blocks_sys_transformer_sk_dilat.py:966-981: two
  * conv+ReLU branches, `v = f * f`, summed): y = relu(a)^2 + relu(b)^2 over n fp32 elements
  * (n % 4 == 0, 16-byte aligned), and da = 2*relu(a)*dy, db = 2*relu(b)*dy. */

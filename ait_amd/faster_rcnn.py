@@ -59,6 +59,7 @@ def _side_stream(device):
 _TAIL_FUSED = True
 _HEADS_KERNEL = True          # test hook: False = the two heads as torch nn.Linear calls (vendor GEMM)
 _TRUNK_BF16 = True            # test hook: False = the C4 trunk in f32 also in the bf16 configuration (round 4's cfg5)
+_TAIL_BF16_MIOPEN = True      # test hook: False = the library's (f32-storage) tail node also in the bf16 configuration
 _TOP_NHWC = True
 _BASE_NHWC = True
 _ROI_NHWC = True
@@ -768,7 +769,18 @@ class _fasterRCNN(nn.Module):
         # reference), 3/4 of the SK work not done.  AIT_SK_FULL=1 keeps the dead positions.
         sk_stride = 1 if _SK_FULL else self._top_stride()
         c_att = None
-        if self._tail_on_library(props_feat, non_qry, sk_stride):
+        if _TAIL_BF16_MIOPEN and _lib.BF16_PRODUCTS and props_feat.is_cuda and sk_stride == 2:
+            # the bf16 configuration (BASELINE configs[4]): the proposal tail as the module composition on MIOpen with bf16
+            # tensors, like the trunk (frozen-BN passes: ait_bn_act_*_bf16) -- the library's tail node (ait_tail_*) stores
+            # f32 and multiplies bf16-rounded operands at 250-430 TFLOP/s; MIOpen's bf16 convolutions are 4.6 ms/step faster
+            # at cfg5 (77.0 -> 72.5 ms, profiles/r05_trunk_bf16.txt).  The f32 configurations keep the library's node.
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                xp = props_feat.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                xq = non_qry.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+                p16, q16 = self.sk(x_props=xp, x_query=xq, stride=sk_stride)
+                props_feat = self._head_to_tail(p16, subsampled=True).float()
+                query_feat = self._head_to_tail(q16, subsampled=True).float()
+        elif self._tail_on_library(props_feat, non_qry, sk_stride):
             props_feat, query_feat = self._tail(props_feat, non_qry)                 # [bs*P, 2048], [bs, 2048]
         else:
             props_feat, query_feat = self.sk(x_props=props_feat, x_query=non_qry, stride=sk_stride)

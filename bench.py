@@ -414,7 +414,10 @@ def main():
                          "three bf16 values (round to nearest), six v_mfma_f32_32x32x16_bf16 per block, dropped terms <= 2^-23 |a b|)",
                   "f32_native": "f32 (AIT products on v_mfma_f32_32x32x2_f32; the proposal tail's and the RPN head's convolutions "
                                 "keep the split-bf16 form)",
-                  "bf16": "bf16 products (AIT GEMMs and the proposal tail's convolutions: operands rounded to bf16 in registers, one MFMA per block, f32 accumulate); f32 storage; f32 trunk / LayerNorm / attention tiles",
+                  "bf16": "bf16 (BASELINE configs[4]): C4 trunk and proposal tail on MIOpen with bf16 tensors (f32 master weights, f32 accumulate, "
+                          "frozen-BN passes on bf16); AIT: every product on v_mfma_f32_32x32x16_bf16 with f32 accumulate -- feed-forward "
+                          "hidden tensors and the attention blocks' gradients STORED in bf16 (bf16 operands from memory), the other "
+                          "linears' operands rounded to bf16 in registers; f32 residual stream, LayerNorm, attention tiles, RPN, losses",
                   "bf16x3": "f32 emulated as 3 bf16 MFMAs per product (experimental; fp32 accumulate)"}[args.dtype],
         "data": "synthetic",
         "config": {"workload": conf["workload"] % {"P": args.proposals, "bs": args.bs},
@@ -432,7 +435,7 @@ def main():
                                "six v_mfma_f32_32x32x16_bf16 (f32 accumulate) per 32x32x16 block = f32-equivalent products "
                                "(few-tile launches: gemm_f32_kernel on v_mfma_f32_32x32x2_f32)" if args.dtype == "f32"
                                else "gemm_f32_stream_kernel / gemm_f32_kernel (v_mfma_f32_32x32x2_f32)" if args.dtype == "f32_native"
-                               else "gemm_f32_stream_kernel with KNOB_BF16 (operands rounded to bf16 in registers, one v_mfma_f32_32x32x16_bf16 per block)" if args.dtype == "bf16"
+                               else "the AIT's products: gemm_bf16s_kernel / gemm_bf16s_tn_kernel (bf16 operands stored in memory) and gemm_f32_stream_kernel with KNOB_BF16 (f32 operands rounded to bf16 in registers), one v_mfma_f32_32x32x16_bf16 per block" if args.dtype == "bf16"
                                else "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16%s)" % (", 3 per product" if args.dtype == "bf16x3" else ""),
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak,

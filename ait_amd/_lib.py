@@ -114,6 +114,8 @@ SIGNATURES = {
     "ait_sh_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ait_mha_core_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f,
                                _ull, _i, _i] + [_vp] * 10),
+    "ait_mha_core_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _f, _f, _ull, _vp, _i, _vp, _i,
+                               _vp, _i, _vp, _vp]),
     "ait_attn_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _vp,
                           _vp]),
     "ait_attn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _ull, _vp, _i,

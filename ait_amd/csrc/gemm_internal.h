@@ -30,6 +30,12 @@ int ait_attn_bwd_ex(const float* q, int ldq, const float* k, int ldk, const floa
                     int n_seq, int H, int T, int d, int kv_rows, float scale, float p_drop, unsigned long long seed, void* dq,
                     int lddq, void* dk, int lddk, void* dv, int lddv, int out_bf16, void* stream);
 
+// ait_mha_core_bwd with the three gradients written as bf16 (out_bf16 != 0; pitches in elements) -- csrc/mha_fused_bwd.hip
+int ait_mha_core_bwd_ex(const float* df, const float* fc_w, const float* O, const float* gate, const float* sk_w, const float* q,
+                        int ldq, const float* k, int ldk, const float* v, int ldv, const float* P, int n_seq, int kv_rows,
+                        float scale, float p_attn, unsigned long long seed_attn, void* dq, int lddq, void* dk, int lddk, void* dv,
+                        int lddv, float* dg, int out_bf16, void* stream);
+
 // ait_ln_bwd with the gradient `da` also / instead written as bf16 (da16: [rows, 512] bf16 or NULL) -- csrc/rowwise.hip
 int ait_ln_bwd_ex(const float* dy, const float* a, const float* pos, const float* residual, const float* gamma,
                   const float* mean, const float* rstd, long long rows, int d, int seq_len, int src_rows_per_seq, int rep,

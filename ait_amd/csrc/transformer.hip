@@ -213,12 +213,24 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
   // closing LayerNorm + dropout + residual: df (at fc's output), dres (the residual branch)
   AIT_TRY(ait_ln_bwd(dy, m.f, nullptr, xq, w.ln_g, m.mean, m.rstd, M, D, T, T, 1, dy_rows, p_fc,
                      ait_dropout_seed(seed, 1), t.df, t.dres, g.ln_g, g.ln_b, nullptr, s.stream));
-  AIT_TRY(dgrad(t.df, M, D, w.fc_w, DK, nullptr, false, t.du, s));            // du = df fc_w
   AIT_TRY(wgrad(t.df, M, D, m.u, DK, g.fc_w, s));                            // d fc_w += df^T u
-  AIT_TRY(ait_sh_bwd(t.du, m.O, m.gate, w.sk_w, n, H, T, DK, t.dO, t.dg, s.stream));
-  AIT_TRY(wgrad(t.dg, n, D, m.s, DK, g.sk_w, s));                            // d sk_w += dg^T s
-  if (g.sk_b) AIT_TRY(ait_colsum_f32(t.dg, n, D, D, g.sk_b, s.stream));
   const Qkv v = views(m, n, cross);
+  // fc's input gradient, the selective heads and the attention tiles backwards: one kernel per sequence
+  // (csrc/mha_fused_bwd.hip; du and dO stay on the chip), or -- lab builds, for A/Bs -- the three launches it replaces
+  auto attn_back = [&](void* dq_, int lddq, void* dk_, int lddk, void* dv_, int lddv, int out16) -> int {
+#ifndef AIT_LAB_NO_FUSED_BWD
+    AIT_TRY(ait_mha_core_bwd_ex(t.df, w.fc_w, m.O, m.gate, w.sk_w, v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, n, kv_rows, 0.125f,
+                                p_attn, ait_dropout_seed(seed, 0), dq_, lddq, dk_, lddk, dv_, lddv, t.dg, out16, s.stream));
+#else
+    AIT_TRY(dgrad(t.df, M, D, w.fc_w, DK, nullptr, false, t.du, s));            // du = df fc_w
+    AIT_TRY(ait_sh_bwd(t.du, m.O, m.gate, w.sk_w, n, H, T, DK, t.dO, t.dg, s.stream));
+    AIT_TRY(ait_attn_bwd_ex(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
+                            ait_dropout_seed(seed, 0), dq_, lddq, dk_, lddk, dv_, lddv, out16, s.stream));
+#endif
+    AIT_TRY(wgrad(t.dg, n, D, m.s, DK, g.sk_w, s));                            // d sk_w += dg^T s
+    if (g.sk_b) AIT_TRY(ait_colsum_f32(t.dg, n, D, D, g.sk_b, s.stream));
+    return AIT_OK;
+  };
   float* dq = t.dqkv;
   // ---- bf16 storage of the attention gradients (AIT_CTX_BF16, round 5): dq / dk / dv leave the attention kernel as bf16
   // (their only consumers are the two products below), the block's input and the transposed projection weight are
@@ -244,8 +256,7 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
       AIT_TRY(ait_f32_to_bf16(w.w_qkv, 3 * D, D, D, wt16, 3 * D, 1, s.stream));
       if (!cross) {
         unsigned short* x16 = g16 + (size_t)M * 3 * D;                          // [M, D] in the second half
-        AIT_TRY(ait_attn_bwd_ex(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
-                                ait_dropout_seed(seed, 0), g16, 3 * D, g16 + D, 3 * D, g16 + 2 * D, 3 * D, 1, s.stream));
+        AIT_TRY(attn_back(g16, 3 * D, g16 + D, 3 * D, g16 + 2 * D, 3 * D, 1));
         AIT_TRY(ait_f32_to_bf16(xq, M, D, D, x16, D, 0, s.stream));
         AIT_TRY(ait_gemm_bf16s(M, D, 3 * D, g16, 3 * D, wt16, 3 * D, dxq, D, nullptr, 0, nullptr, t.dres, nullptr, D, 0, s.ctx,
                                s.stream));                                                                   // dx = dqkv W_qkv + dres
@@ -259,8 +270,7 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
       unsigned short* dkv16 = dq16 + (size_t)M * D;                             // [R2, 2D]
       unsigned short* x16 = dkv16 + (size_t)R2 * 2 * D;                         // [M, D]
       unsigned short* xkv16 = x16 + (size_t)M * D;                              // [R2, D]
-      AIT_TRY(ait_attn_bwd_ex(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
-                              ait_dropout_seed(seed, 0), dq16, D, dkv16, 2 * D, dkv16 + D, 2 * D, 1, s.stream));
+      AIT_TRY(attn_back(dq16, D, dkv16, 2 * D, dkv16 + D, 2 * D, 1));
       AIT_TRY(ait_f32_to_bf16(xq, M, D, D, x16, D, 0, s.stream));
       AIT_TRY(ait_f32_to_bf16(xkv, R2, D, D, xkv16, D, 0, s.stream));
       AIT_TRY(ait_gemm_bf16s(M, D, D, dq16, D, wt16, 3 * D, dxq, D, nullptr, 0, nullptr, t.dres, nullptr, D, 0, s.ctx, s.stream));
@@ -279,14 +289,12 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
     }
   }
   if (!cross) {
-    AIT_TRY(ait_attn_bwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
-                         ait_dropout_seed(seed, 0), dq, 3 * D, dq + D, 3 * D, dq + 2 * D, 3 * D, s.stream));
+    AIT_TRY(attn_back(dq, 3 * D, dq + D, 3 * D, dq + 2 * D, 3 * D, 0));
     AIT_TRY(dgrad(dq, M, 3 * D, w.w_qkv, D, t.dres, false, dxq, s, nullptr, pq.wt));          // dx = dqkv W_qkv + dres
     return wgrad(dq, M, 3 * D, xq, D, g.w_qkv, s);
   }
   float* dkv = t.dqkv + (size_t)M * D;
-  AIT_TRY(ait_attn_bwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
-                       ait_dropout_seed(seed, 0), dq, D, dkv, 2 * D, dkv + D, 2 * D, s.stream));
+  AIT_TRY(attn_back(dq, D, dkv, 2 * D, dkv + D, 2 * D, 0));
   AIT_TRY(dgrad(dq, M, D, w.w_qkv, D, t.dres, false, dxq, s, nullptr, pq.wt));
   if (dxkv) AIT_TRY(dgrad(dkv, n * kv_rows, 2 * D, w.w_qkv + (size_t)D * D, D, nullptr, false, dxkv, s, nullptr, pq.wt.sub(0, D)));
   AIT_TRY(wgrad(dq, M, D, xq, D, g.w_qkv, s));

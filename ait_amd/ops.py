@@ -521,6 +521,21 @@ def mha_core_fwd(q, qoff, k, koff, v, voff, n_seq, mask_mode, n_valid, p_attn, s
     return y, sv
 
 
+def mha_core_bwd(df, fc_w, O, gate, sk_w, q, qoff, k, koff, v, voff, P, n_seq, p_attn, seed_attn, dq, dqoff, dk, dkoff,
+                 dv, dvoff, kv_rows=64):
+    """ait_mha_core_bwd: fc's input gradient + selective heads + attention tiles backwards, one launch.  Writes dq / dk / dv
+    (columns dqoff / dkoff / dvoff .. + 512 of the given tensors) and returns dg [n_seq, 512]."""
+    dev = q.device
+    dg = torch.empty(n_seq, D_MODEL, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ait_mha_core_bwd(_p(df), _p(fc_w), _p(O), _p(gate), _p(sk_w), _col(q, qoff), q.stride(0), _col(k, koff),
+                                         k.stride(0), _col(v, voff), v.stride(0), _p(P), n_seq, int(kv_rows), 0.125,
+                                         float(p_attn), int(seed_attn), _col(dq, dqoff), dq.stride(0), _col(dk, dkoff),
+                                         dk.stride(0), _col(dv, dvoff), dv.stride(0), _p(dg), _lib.cur_stream(dev))
+    _lib.check(rc, "ait_mha_core_bwd")
+    return dg
+
+
 def attn_bwd(q, qoff, k, koff, v, voff, P, dO, n_seq, H, T, d, scale, p, seed, dq, dqoff, dk,
              dkoff, dv, dvoff, kv_rows=None):
     dev = q.device

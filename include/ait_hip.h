@@ -533,6 +533,22 @@ int ait_mha_core_fwd(const float* q, int ldq, const float* k, int ldk, const flo
                      float* s, float* f, float* y, float* mean, float* rstd, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The backward of ait_mha_core_fwd between the closing LayerNorm and the Q / K / V projections as ONE kernel, one
+ * workgroup per sequence with its eight heads resident (SubLayers.py:82-100 backwards; SHBlock :22-39; Modules.py:16-29):
+ *     du = df fc_w ;  (dO, dg) = SHBlock'(du, O, gate, sk_w) ;  (dq, dk, dv) = attention'(q, k, v, P, dO)
+ * = ait_gemm_f32 (fc's input gradient) -> ait_sh_bwd -> ait_attn_bwd in one launch; du and dO never leave the chip.
+ * H = 8, T = 64, d = 64.  df [n_seq*64, 512]: the gradient at fc's output (ait_ln_bwd's `da`); fc_w [512,64];
+ * O [n_seq,8,64,64], gate [n_seq,512], P [n_seq,8,64,64]: what ait_mha_core_fwd saved; sk_w [512,64]; q / k / v / kv_rows /
+ * scale / p_attn / seed_attn as given to the forward.  Written: dq / dk / dv with the addressing of q / k / v (pitches
+ * lddq / lddk / lddv; rows >= kv_rows of dk / dv are not written), dg [n_seq,512] the gradient at SHBlock.sk's output
+ * (d sk_w = dg^T s, d sk_b = column sums of dg: the caller's M-deep products, like d fc_w = df^T u).
+ * ------------------------------------------------------------------------------------- */
+int ait_mha_core_bwd(const float* df, const float* fc_w, const float* O, const float* gate, const float* sk_w,
+                     const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* P, int n_seq,
+                     int kv_rows, float scale, float p_attn, unsigned long long seed_attn, float* dq, int lddq, float* dk,
+                     int lddk, float* dv, int lddv, float* dg, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * The whole AIT forward as one call: Transformer.forward in eval mode
  * (lib/model/system/Models.py:231-280, n_layers = 1, d_model = 512, 8 heads of 64, d_inner = 2048:
  * the configuration of faster_rcnn_sys_transformer_sk_dilat.py:148-158).  Composes the entry

@@ -795,6 +795,58 @@ def test_fused_attention_block_equals_the_four_launches(mask_mode, n_valid, kv_r
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mask_mode,n_valid,kv_rows,cross", [(1, 49, 64, False), (2, 0, 64, False), (0, 49, 49, True)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_fused_attention_block_backward_equals_the_three_launches(mask_mode, n_valid, kv_rows, cross, p):
+    """ait_mha_core_bwd (fc's input gradient + selective heads + attention tiles backwards in one kernel, all heads of a
+    sequence resident; du and dO never written) against ait_gemm_f32 -> ait_sh_bwd -> ait_attn_bwd on the same saved
+    tensors and seeds: dq, dk, dv (rows >= kv_rows untouched) and dg.  The three blocks of the AIT, as in the forward's
+    test; the products of both sides are f32 (the fused kernel's fc product on the f32 instruction, the library's GEMM in
+    its split form), so the bound is a few f32 roundings of a 512-deep sum."""
+    from ait_amd import ops
+    torch.manual_seed(23 + mask_mode)
+    n, dev = 37, "cuda"
+    if cross:
+        qm = torch.randn(n * 64, 512, device=dev)
+        kvm = torch.randn(n * kv_rows, 1024, device=dev)
+        q, qoff, k, koff, v, voff = qm, 0, kvm, 0, kvm, 512
+    else:
+        qkv = torch.randn(n * 64, 1536, device=dev)
+        q, qoff, k, koff, v, voff = qkv, 0, qkv, 512, qkv, 1024
+    sk_w = torch.randn(512, 64, device=dev) * 0.3
+    sk_b = torch.randn(512, device=dev) * 0.1
+    fc_w = torch.randn(512, 64, device=dev) * 0.125
+    sa = ops.dropout_seed(77, 0)
+    O, P = ops.attn_fwd(q, qoff, k, koff, v, voff, n, 8, 64, 64, mask_mode, n_valid, 0.125, p, sa, kv_rows=kv_rows)
+    _, gate, _ = ops.sh_fwd(O, sk_w, sk_b)
+    df = torch.randn(n * 64, 512, device=dev)
+
+    def grads_like():
+        if cross:
+            return torch.full_like(qm, 7.0), torch.full_like(kvm, 7.0)
+        t = torch.full_like(qkv, 7.0)
+        return t, t
+
+    # the three launches
+    du = ops.gemm(df, fc_w, trans_b=False)
+    dO, dg_ref = ops.sh_bwd(du.reshape(n, 64, 64), O, gate, sk_w)
+    rq, rkv = grads_like()
+    ops.attn_bwd(q, qoff, k, koff, v, voff, P, dO, n, 8, 64, 64, 0.125, p, sa, rq, qoff, rkv, koff, rkv, voff, kv_rows=kv_rows)
+    # one launch
+    gq, gkv = grads_like()
+    dg = ops.mha_core_bwd(df, fc_w, O, gate, sk_w, q, qoff, k, koff, v, voff, P, n, p, sa, gq, qoff, gkv, koff, gkv, voff,
+                          kv_rows=kv_rows)
+    for name, got, ref in (("dg", dg, dg_ref), ("dq", gq, rq), ("dkv", gkv, rkv)):
+        err = float((got - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 2e-5, (name, err)
+    # launch to launch the kernel is bit-reproducible (fixed summation order over the heads)
+    gq2, gkv2 = grads_like()
+    dg2 = ops.mha_core_bwd(df, fc_w, O, gate, sk_w, q, qoff, k, koff, v, voff, P, n, p, sa, gq2, qoff, gkv2, koff, gkv2, voff,
+                           kv_rows=kv_rows)
+    assert torch.equal(dg2, dg) and torch.equal(gq2, gq) and torch.equal(gkv2, gkv)
+
+
+@pytest.mark.gpu
 def test_fused_attention_block_query_side_per_pair_equals_the_repeated_one():
     """q_rep of ait_mha_core_fwd (inference: the decoder's query side once per pair, every proposal's sequence reads the
     queries and the residual of sequence n / q_rep) against the same call on explicitly repeated tensors: the same bits."""

@@ -104,6 +104,37 @@ struct Stage {
   }
 };
 
+// The same panel from a bf16 tensor (the bf16-storage mode's q / k / v, csrc/transformer.hip): 16 B = eight values per
+// lane and load (lane = (row & 7, 16-B chunk): eight rows per wave-wide load, eight loads per panel), the values widened
+// to f32 on their way into the (f32) panel, so every product downstream is unchanged -- and exact for these operands, whose
+// two lower planes are zero.  LDS writes: (row & 7) + 8 * chunk + j covers all 64 banks exactly once.
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+struct Stage16 {
+  uint4 v[8];
+  __device__ __forceinline__ void load(const unsigned short* __restrict__ g, int ld, int lane, int rows = T) {
+    const int c = (lane & 7) * 8, r0 = lane >> 3;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int r = min(i * 8 + r0, rows - 1);
+      v[i] = *reinterpret_cast<const uint4*>(g + (unsigned)(r * ld + c));
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ s, int lane, int rows = T) const {
+    const int c = (lane & 7) * 8, r0 = lane >> 3;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int r = i * 8 + r0;
+      const bool live = r < rows;
+      float* __restrict__ d = s + r * PITCH + c;
+      d[0] = live ? bf16_lo(v[i].x) : 0.f; d[1] = live ? bf16_hi(v[i].x) : 0.f;
+      d[2] = live ? bf16_lo(v[i].y) : 0.f; d[3] = live ? bf16_hi(v[i].y) : 0.f;
+      d[4] = live ? bf16_lo(v[i].z) : 0.f; d[5] = live ? bf16_hi(v[i].z) : 0.f;
+      d[6] = live ? bf16_lo(v[i].w) : 0.f; d[7] = live ? bf16_hi(v[i].w) : 0.f;
+    }
+  }
+};
+
 // ---- operand fragments ---------------------------------------------------------------------------------------
 // A 64x64x64 product runs as four k-blocks of 16; in block kb lane (li, lk) holds, for each of its two 32-row (or
 // 32-column) tiles t, the eight values k = 16 kb + 8 lk + 0..7 of row / column 32 t + li -- the operand layout of
@@ -148,6 +179,24 @@ __device__ __forceinline__ void breg_load(OpRegs& b, const float* __restrict__ g
       const float x0 = g[off], x1 = g[off + 32];
       b.v[0][kb][j] = k < rows ? x0 : 0.f;
       b.v[1][kb][j] = k < rows ? x1 : 0.f;
+    }
+}
+
+// The same from a bf16 tensor, with the COLUMNS PAIRED: lane li loads ONE dword of row k -- columns 2 li and 2 li + 1, a
+// whole 128-B row per half-wave -- and takes the low half as its column of tile 0, the high half as its column of tile 1:
+// B's column of (tile t, lane li) is 2 li + t, not 32 t + li.  A permutation of B's columns is the same permutation of
+// the product's: whoever reads the accumulators of such a product addresses columns with acc_col_of<true>.  32 loads
+// instead of the 64 two-byte loads the unpaired layout would take.
+__device__ __forceinline__ void breg_load_pairs(OpRegs& b, const unsigned short* __restrict__ g, int ld, int lane, int rows = T) {
+  const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = 16 * kb + 8 * lk + j;
+      const unsigned w = *reinterpret_cast<const unsigned*>(g + (unsigned)(min(k, rows - 1) * ld + 2 * li));
+      b.v[0][kb][j] = k < rows ? bf16_lo(w) : 0.f;
+      b.v[1][kb][j] = k < rows ? bf16_hi(w) : 0.f;
     }
 }
 
@@ -235,6 +284,9 @@ __device__ __forceinline__ int acc_row(int a, int r, int lane) {
   return a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 }
 __device__ __forceinline__ int acc_col(int b, int lane) { return b * 32 + (lane & 31); }
+// ... of a product whose right operand came from breg_load_pairs (PAIRED), or not
+template <bool PAIRED>
+__device__ __forceinline__ int acc_col_of(int b, int lane) { return PAIRED ? 2 * (lane & 31) + b : b * 32 + (lane & 31); }
 
 // reductions across the 32 lanes that hold one accumulator row (same lane>>5), result in every lane -- on the vector
 // pipe only: four DPP steps inside a row of 16 lanes (quad_perm 1032 / 2301, then row_half_mirror / row_mirror, which

@@ -30,11 +30,19 @@ int ait_attn_bwd_ex(const float* q, int ldq, const float* k, int ldk, const floa
                     int n_seq, int H, int T, int d, int kv_rows, float scale, float p_drop, unsigned long long seed, void* dq,
                     int lddq, void* dk, int lddk, void* dv, int lddv, int out_bf16, void* stream);
 
-// ait_mha_core_bwd with the three gradients written as bf16 (out_bf16 != 0; pitches in elements) -- csrc/mha_fused_bwd.hip
-int ait_mha_core_bwd_ex(const float* df, const float* fc_w, const float* O, const float* gate, const float* sk_w, const float* q,
-                        int ldq, const float* k, int ldk, const float* v, int ldv, const float* P, int n_seq, int kv_rows,
+// ait_mha_core_fwd reading q / k / v from bf16 tensors (qkv_bf16 != 0; pitches in elements) -- csrc/mha_fused.hip
+int ait_mha_core_fwd_ex(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int n_seq, int kv_rows,
+                        int mask_mode, int n_valid_keys, float scale, float p_attn, unsigned long long seed_attn, const float* sk_w,
+                        const float* sk_b, const float* fc_w, const float* residual, const float* ln_g, const float* ln_b, float eps,
+                        float p_fc, unsigned long long seed_fc, int out_rows, int q_rep, float* P, float* O, float* u, float* gate,
+                        float* s, float* f, float* y, float* mean, float* rstd, int qkv_bf16, void* stream);
+
+// ait_mha_core_bwd with the three gradients written as bf16 (out_bf16 != 0) and / or q / k / v read from bf16 tensors
+// (qkv_bf16 != 0); pitches in elements -- csrc/mha_fused_bwd.hip
+int ait_mha_core_bwd_ex(const float* df, const float* fc_w, const float* O, const float* gate, const float* sk_w, const void* q,
+                        int ldq, const void* k, int ldk, const void* v, int ldv, const float* P, int n_seq, int kv_rows,
                         float scale, float p_attn, unsigned long long seed_attn, void* dq, int lddq, void* dk, int lddk, void* dv,
-                        int lddv, float* dg, int out_bf16, void* stream);
+                        int lddv, float* dg, int out_bf16, int qkv_bf16, void* stream);
 
 // ait_ln_bwd with the gradient `da` also / instead written as bf16 (da16: [rows, 512] bf16 or NULL) -- csrc/rowwise.hip
 int ait_ln_bwd_ex(const float* dy, const float* a, const float* pos, const float* residual, const float* gamma,

@@ -18,6 +18,7 @@
 //
 // LDS: eight 64 x 65 panels (133 KB) + u (16.6 KB) + 9 KB of vectors -> one workgroup (8 waves, 2 per SIMD) per CU.
 #include "attn_impl.h"
+#include "gemm_internal.h"
 
 namespace {
 using namespace ait_attn;
@@ -65,6 +66,8 @@ __device__ __forceinline__ void wg_barrier() {
 #define STAMP(i)
 #endif
 
+// IN16: q / k / v are bf16 tensors behind the float pointers (pitches in elements either way)
+template <bool IN16>
 __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const CoreArgs c) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const U = lds + kHeads * kPanel;          // [64][65]
@@ -88,7 +91,14 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
 #endif
   // ---- phase A: the attention tile of head h (attn.hip) -----------------------------------------------------
   OpRegs op;
-  {
+  if constexpr (IN16) {
+    Stage16 sq, sk;
+    sq.load(reinterpret_cast<const unsigned short*>(g.q) + ((size_t)nq * T) * g.ldq + h * D, g.ldq, lane);
+    sk.load(reinterpret_cast<const unsigned short*>(g.k) + ((size_t)n * g.kv_rows) * g.ldk + h * D, g.ldk, lane, g.kv_rows);
+    sq.store(s0, lane);
+    areg_from_lds(op, s0, lane);
+    sk.store(s0, lane, g.kv_rows);
+  } else {
     Stage sq, sk;
     sq.load(g.q + ((size_t)nq * T) * g.ldq + h * D, g.ldq, lane);
     sk.load(g.k + ((size_t)n * g.kv_rows) * g.ldk + h * D, g.ldk, lane, g.kv_rows);
@@ -103,7 +113,10 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   mm_areg_bldsT(op, s0, acc, lane);       // S = Q K^T
   STAMP(1)
   __builtin_amdgcn_sched_barrier(0);
-  breg_load(op, g.v + ((size_t)n * g.kv_rows) * g.ldv + h * D, g.ldv, lane, g.kv_rows);
+  if constexpr (IN16)      // (column-paired: O_h's columns below are acc_col_of<IN16>)
+    breg_load_pairs(op, reinterpret_cast<const unsigned short*>(g.v) + ((size_t)n * g.kv_rows) * g.ldv + h * D, g.ldv, lane, g.kv_rows);
+  else
+    breg_load(op, g.v + ((size_t)n * g.kv_rows) * g.ldv + h * D, g.ldv, lane, g.kv_rows);
   scale_mask(acc, lane, g);
 #pragma unroll
   for (int a = 0; a < 2; a++)
@@ -128,7 +141,21 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   mm_alds_breg<false>(s0, op, acc, lane);  // O_h = P V, kept in acc
   STAMP(3)
   __builtin_amdgcn_sched_barrier(0);
-  if (c.O) acc_to_global(acc, c.O + (size_t)unit * T * D, D, lane, 1.f);
+  if (c.O) {
+    float* __restrict__ og = c.O + (size_t)unit * T * D;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int row = acc_row(a, r, lane);
+        if constexpr (IN16) {      // columns 2 li and 2 li + 1: one 8-byte store
+          *reinterpret_cast<float2*>(og + (unsigned)(row * D + 2 * li)) = make_float2(acc[a][0][r], acc[a][1][r]);
+        } else {
+          og[(unsigned)(row * D + li)] = acc[a][0][r];
+          og[(unsigned)(row * D + 32 + li)] = acc[a][1][r];
+        }
+      }
+  }
   // ---- phase B: s = mean over tokens of the head sum; gate = softmax over heads of sk_w s + sk_b ----------------
   // rows 64 h .. 64 h + 63 of sk_w (this wave's 64 gate logits) go through the wave's own panel, whose P the product
   // above has read: coalesced loads, conflict-free row reads, and nothing here waits for another wave
@@ -143,7 +170,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
 #pragma unroll
         for (int r = 0; r < 16; r++) cs += acc[a][b][r];
       cs += __shfl_xor(cs, 32, 64);
-      if (lk == 0) part[h * 64 + b * 32 + li] = cs;
+      if (lk == 0) part[h * 64 + acc_col_of<IN16>(b, lane)] = cs;
     }
     sw.store(s0, lane);
   }
@@ -190,15 +217,23 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   STAMP(5)
   // ---- phase C: u = sum_h gate_h * O_h through the panels, heads in fixed order ---------------------------------
   {
-    const float gx = __shfl_xor(gj, 32, 64);
-    const float g0 = lk ? gx : gj, g1 = lk ? gj : gx;      // gates of channels li and 32 + li
+    float g0, g1;                                           // gates of the lane's two channels
+    if constexpr (IN16) {
+      g0 = __shfl(gj, 2 * li, 64);
+      g1 = __shfl(gj, 2 * li + 1, 64);
+    } else {
+      const float gx = __shfl_xor(gj, 32, 64);
+      g0 = lk ? gx : gj;                                    // channels li and 32 + li
+      g1 = lk ? gj : gx;
+    }
+    const int c0 = acc_col_of<IN16>(0, lane), c1 = acc_col_of<IN16>(1, lane);
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int row = acc_row(a, r, lane);
-        s0[row * PITCH + li] = acc[a][0][r] * g0;
-        s0[row * PITCH + 32 + li] = acc[a][1][r] * g1;
+        s0[row * PITCH + c0] = acc[a][0][r] * g0;
+        s0[row * PITCH + c1] = acc[a][1][r] * g1;
       }
   }
   wg_barrier();
@@ -327,23 +362,38 @@ constexpr unsigned long long* g_prof = nullptr;
 AIT_API void ait_mha_core_set_prof(unsigned long long* p) { g_prof = p; }
 #endif
 
+// qkv_bf16 != 0: q / k / v point at bf16 tensors (library-internal: csrc/transformer.hip's bf16-storage mode)
+int ait_mha_core_fwd_ex(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int n_seq, int kv_rows,
+                        int mask_mode, int n_valid_keys, float scale, float p_attn, unsigned long long seed_attn, const float* sk_w,
+                        const float* sk_b, const float* fc_w, const float* residual, const float* ln_g, const float* ln_b, float eps,
+                        float p_fc, unsigned long long seed_fc, int out_rows, int q_rep, float* P, float* O, float* u, float* gate,
+                        float* s, float* f, float* y, float* mean, float* rstd, int qkv_bf16, void* stream) {
+  if (bad(n_seq, kHeads, T, D, mask_mode, n_valid_keys, p_attn) || p_fc < 0.f || p_fc >= 1.f) return AIT_EINVAL;
+  if (n_seq == 0) return AIT_OK;
+  if (!q || !k || !v || !sk_w || !sk_b || !fc_w || !residual || !ln_g || !ln_b || !y) return AIT_EINVAL;
+  if (kv_rows <= 0 || kv_rows > T || out_rows <= 0 || out_rows > T || q_rep < 1) return AIT_EINVAL;
+  if ((long long)n_seq * T * kDm > 0x7fffffffLL * 4) return AIT_EUNSUPPORTED;
+  const void* fn = qkv_bf16 ? reinterpret_cast<const void*>(mha_core_fwd_kernel<true>)
+                            : reinterpret_cast<const void*>(mha_core_fwd_kernel<false>);
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds) != hipSuccess) return AIT_ELAUNCH;
+  CoreArgs c{AttnArgs{static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v), ldq, ldk, ldv, n_seq,
+                      kHeads, mask_mode, n_valid_keys, kv_rows, scale, p_attn, seed_attn},
+             sk_w, sk_b, fc_w, residual, ln_g, ln_b, eps, p_fc, seed_fc, out_rows, q_rep, P, O, u, gate, s, f, y, mean, rstd, g_prof};
+  if (qkv_bf16)
+    hipLaunchKernelGGL(mha_core_fwd_kernel<true>, dim3((unsigned)n_seq), dim3(kFusedThreads), kFusedLds, ait_stream(stream), c);
+  else
+    hipLaunchKernelGGL(mha_core_fwd_kernel<false>, dim3((unsigned)n_seq), dim3(kFusedThreads), kFusedLds, ait_stream(stream), c);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
 AIT_API int ait_mha_core_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int n_seq,
                              int kv_rows, int mask_mode, int n_valid_keys, float scale, float p_attn,
                              unsigned long long seed_attn, const float* sk_w, const float* sk_b, const float* fc_w,
                              const float* residual, const float* ln_g, const float* ln_b, float eps, float p_fc,
                              unsigned long long seed_fc, int out_rows, int q_rep, float* P, float* O, float* u, float* gate,
                              float* s, float* f, float* y, float* mean, float* rstd, void* stream) {
-  if (bad(n_seq, kHeads, T, D, mask_mode, n_valid_keys, p_attn) || p_fc < 0.f || p_fc >= 1.f) return AIT_EINVAL;
-  if (n_seq == 0) return AIT_OK;
-  if (!q || !k || !v || !sk_w || !sk_b || !fc_w || !residual || !ln_g || !ln_b || !y) return AIT_EINVAL;
-  if (kv_rows <= 0 || kv_rows > T || out_rows <= 0 || out_rows > T || q_rep < 1) return AIT_EINVAL;
-  if ((long long)n_seq * T * kDm > 0x7fffffffLL * 4) return AIT_EUNSUPPORTED;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(mha_core_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)kFusedLds) != hipSuccess)
-    return AIT_ELAUNCH;
-  CoreArgs c{AttnArgs{q, k, v, ldq, ldk, ldv, n_seq, kHeads, mask_mode, n_valid_keys, kv_rows, scale, p_attn, seed_attn},
-             sk_w, sk_b, fc_w, residual, ln_g, ln_b, eps, p_fc, seed_fc, out_rows, q_rep, P, O, u, gate, s, f, y, mean, rstd, g_prof};
-  hipLaunchKernelGGL(mha_core_fwd_kernel, dim3((unsigned)n_seq), dim3(kFusedThreads), kFusedLds, ait_stream(stream), c);
-  AIT_CHECK_LAUNCH();
-  return AIT_OK;
+  return ait_mha_core_fwd_ex(q, ldq, k, ldk, v, ldv, n_seq, kv_rows, mask_mode, n_valid_keys, scale, p_attn, seed_attn, sk_w, sk_b,
+                             fc_w, residual, ln_g, ln_b, eps, p_fc, seed_fc, out_rows, q_rep, P, O, u, gate, s, f, y, mean, rstd, 0,
+                             stream);
 }

@@ -22,6 +22,7 @@
 // LDS: eight 64 x 65 panels (133 KB) + du (16.6 KB) + 8 KB of vectors -> one workgroup (8 waves, 2 per SIMD) per CU.
 #include "attn_impl.h"
 #include "gemm_internal.h"
+#include <type_traits>
 
 namespace {
 using namespace ait_attn;
@@ -63,27 +64,37 @@ __device__ __forceinline__ unsigned short bf16_bits(float x) {
   return __builtin_bit_cast(unsigned short, b);
 }
 // the accumulator tile to rows < `rows` of a tensor whose first element of this unit is `first` ELEMENTS behind `base`
-// (OUT16: bf16 elements, nearest even)
-template <bool OUT16>
+// (OUT16: bf16 elements, nearest even).  PAIRED: the product's right operand came from breg_load_pairs -- the lane's two
+// values of a row are neighbouring columns and leave as one store.
+template <bool OUT16, bool PAIRED>
 __device__ __forceinline__ void store_rows(const f32x16 (&acc)[2][2], float* base, size_t first, int ld, int lane, int rows) {
   float* __restrict__ g32 = base + first;
   unsigned short* __restrict__ g16 = reinterpret_cast<unsigned short*>(base) + first;
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++)
+    for (int r = 0; r < 16; r++) {
+      const int row = acc_row(a, r, lane);
+      if (row >= rows) continue;
+      if constexpr (PAIRED) {
+        const unsigned off = (unsigned)(row * ld + 2 * (lane & 31));
+        if constexpr (OUT16)
+          *reinterpret_cast<unsigned*>(g16 + off) = (unsigned)bf16_bits(acc[a][0][r]) | ((unsigned)bf16_bits(acc[a][1][r]) << 16);
+        else
+          *reinterpret_cast<float2*>(g32 + off) = make_float2(acc[a][0][r], acc[a][1][r]);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = acc_row(a, r, lane);
-        const unsigned off = (unsigned)(row * ld + acc_col(b, lane));
-        if (row < rows) {
+        for (int b = 0; b < 2; b++) {
+          const unsigned off = (unsigned)(row * ld + acc_col(b, lane));
           if constexpr (OUT16) g16[off] = bf16_bits(acc[a][b][r]);
           else g32[off] = acc[a][b][r];
         }
       }
+    }
 }
 
-template <bool OUT16>
+// OUT16: dq / dk / dv are written as bf16;  IN16: q / k / v are bf16 tensors behind the float pointers
+template <bool OUT16, bool IN16>
 __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_bwd_kernel(const CoreBwdArgs c) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const U = lds + kHeads * kPanel;          // [64][65]   du, shared by the eight heads
@@ -177,9 +188,11 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_bwd_kernel(const Co
   const size_t pbase = (size_t)unit * T * T;
   const float p = g.p, inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   const DropBlock db(g.seed, pbase);
-  const float* __restrict__ Vg = g.v + ((size_t)n * g.kv_rows) * g.ldv + h * D;
-  const float* __restrict__ Kg = g.k + ((size_t)n * g.kv_rows) * g.ldk + h * D;
-  const float* __restrict__ Qg = g.q + ((size_t)n * T) * g.ldq + h * D;
+  using In = typename std::conditional<IN16, unsigned short, float>::type;
+  using StageIn = typename std::conditional<IN16, Stage16, Stage>::type;
+  const In* __restrict__ Vg = reinterpret_cast<const In*>(g.v) + ((size_t)n * g.kv_rows) * g.ldv + h * D;
+  const In* __restrict__ Kg = reinterpret_cast<const In*>(g.k) + ((size_t)n * g.kv_rows) * g.ldk + h * D;
+  const In* __restrict__ Qg = reinterpret_cast<const In*>(g.q) + ((size_t)n * T) * g.ldq + h * D;
   const float* __restrict__ Pu = c.P + pbase;
   // dV = dropout(P)^T dO : dO as the register right operand, R(k, j) = dO(k, j)
   {
@@ -209,11 +222,11 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_bwd_kernel(const Co
   __builtin_amdgcn_sched_barrier(0);
   zero(acc);
   mm_alds_breg<true, (kSplitMask & 1) != 0>(s0, op, acc, lane);
-  store_rows<OUT16>(acc, c.dv, ((size_t)n * g.kv_rows) * c.lddv + h * D, c.lddv, opaque(lane), g.kv_rows);
+  store_rows<OUT16, false>(acc, c.dv, ((size_t)n * g.kv_rows) * c.lddv + h * D, c.lddv, opaque(lane), g.kv_rows);
   __builtin_amdgcn_sched_barrier(0);
   // dPd = dO V^T : dO as the register left operand, L(i, k) = dO(i, k); the panel holds V
   {
-    Stage st;
+    StageIn st;
     st.load(Vg, g.ldv, lane, g.kv_rows);
 #pragma unroll
     for (int kb = 0; kb < 4; kb++)
@@ -246,43 +259,45 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_bwd_kernel(const Co
       acc[a][1][r] = p1 * (d1 - dot) * g.scale;
     }
   __builtin_amdgcn_sched_barrier(0);
-  breg_load(op, Kg, g.ldk, lane, g.kv_rows);
+  if constexpr (IN16) breg_load_pairs(op, Kg, g.ldk, lane, g.kv_rows);      // (column-paired: so are dQ's columns)
+  else breg_load(op, Kg, g.ldk, lane, g.kv_rows);
   acc_to_lds(acc, s0, lane);
   zero(acc);
   mm_alds_breg<false, (kSplitMask & 4) != 0>(s0, op, acc, lane);      // dQ = dS K
   __builtin_amdgcn_sched_barrier(0);
-  breg_load(op, Qg, g.ldq, lane);
-  store_rows<OUT16>(acc, c.dq, ((size_t)n * T) * c.lddq + h * D, c.lddq, opaque(lane), T);
+  if constexpr (IN16) breg_load_pairs(op, Qg, g.ldq, lane);
+  else breg_load(op, Qg, g.ldq, lane);
+  store_rows<OUT16, IN16>(acc, c.dq, ((size_t)n * T) * c.lddq + h * D, c.lddq, opaque(lane), T);
   zero(acc);
   mm_alds_breg<true, (kSplitMask & 8) != 0>(s0, op, acc, lane);       // dK = dS^T Q
-  store_rows<OUT16>(acc, c.dk, ((size_t)n * g.kv_rows) * c.lddk + h * D, c.lddk, opaque(lane), g.kv_rows);
+  store_rows<OUT16, IN16>(acc, c.dk, ((size_t)n * g.kv_rows) * c.lddk + h * D, c.lddk, opaque(lane), g.kv_rows);
 }
 
 constexpr size_t kBwdLds = (size_t)(kHeads * kPanel + kPanel + kHeads * 64 + kDm + kHeads * 128) * sizeof(float);
 }  // namespace
 
-// out_bf16 != 0: dq / dk / dv point at bf16 tensors (library-internal: csrc/transformer.hip's bf16-storage backward)
-int ait_mha_core_bwd_ex(const float* df, const float* fc_w, const float* O, const float* gate, const float* sk_w, const float* q,
-                        int ldq, const float* k, int ldk, const float* v, int ldv, const float* P, int n_seq, int kv_rows,
+// out_bf16 != 0: dq / dk / dv point at bf16 tensors; qkv_bf16 != 0: so do q / k / v (library-internal: csrc/transformer.hip's
+// bf16-storage mode)
+int ait_mha_core_bwd_ex(const float* df, const float* fc_w, const float* O, const float* gate, const float* sk_w, const void* q,
+                        int ldq, const void* k, int ldk, const void* v, int ldv, const float* P, int n_seq, int kv_rows,
                         float scale, float p_attn, unsigned long long seed_attn, void* dq, int lddq, void* dk, int lddk, void* dv,
-                        int lddv, float* dg, int out_bf16, void* stream) {
+                        int lddv, float* dg, int out_bf16, int qkv_bf16, void* stream) {
   if (bad(n_seq, kHeads, T, D, 0, 0, p_attn)) return AIT_EINVAL;
   if (n_seq == 0) return AIT_OK;
   if (!df || !fc_w || !O || !gate || !sk_w || !q || !k || !v || !P || !dq || !dk || !dv || !dg) return AIT_EINVAL;
   if (kv_rows <= 0 || kv_rows > T) return AIT_EINVAL;
   if ((long long)n_seq * T * kDm > 0x7fffffffLL * 4) return AIT_EUNSUPPORTED;
   CoreBwdArgs c;
-  c.at = AttnArgs{q, k, v, ldq, ldk, ldv, n_seq, kHeads, 0, 0, kv_rows, scale, p_attn, seed_attn};
+  c.at = AttnArgs{static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v), ldq, ldk, ldv, n_seq,
+                  kHeads, 0, 0, kv_rows, scale, p_attn, seed_attn};
   c.df = df; c.fc_w = fc_w; c.O = O; c.gate = gate; c.sk_w = sk_w; c.P = P;
   c.dq = static_cast<float*>(dq); c.dk = static_cast<float*>(dk); c.dv = static_cast<float*>(dv);
   c.lddq = lddq; c.lddk = lddk; c.lddv = lddv; c.dg = dg;
-  const void* fn = out_bf16 ? reinterpret_cast<const void*>(mha_core_bwd_kernel<true>)
-                            : reinterpret_cast<const void*>(mha_core_bwd_kernel<false>);
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds) != hipSuccess) return AIT_ELAUNCH;
-  if (out_bf16)
-    hipLaunchKernelGGL(mha_core_bwd_kernel<true>, dim3((unsigned)n_seq), dim3(kFusedThreads), kBwdLds, ait_stream(stream), c);
-  else
-    hipLaunchKernelGGL(mha_core_bwd_kernel<false>, dim3((unsigned)n_seq), dim3(kFusedThreads), kBwdLds, ait_stream(stream), c);
+  void (*fn)(const CoreBwdArgs) = out_bf16 ? (qkv_bf16 ? mha_core_bwd_kernel<true, true> : mha_core_bwd_kernel<true, false>)
+                                           : (qkv_bf16 ? mha_core_bwd_kernel<false, true> : mha_core_bwd_kernel<false, false>);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdLds) != hipSuccess)
+    return AIT_ELAUNCH;
+  hipLaunchKernelGGL(fn, dim3((unsigned)n_seq), dim3(kFusedThreads), kBwdLds, ait_stream(stream), c);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }
@@ -292,5 +307,5 @@ AIT_API int ait_mha_core_bwd(const float* df, const float* fc_w, const float* O,
                              int kv_rows, float scale, float p_attn, unsigned long long seed_attn, float* dq, int lddq, float* dk,
                              int lddk, float* dv, int lddv, float* dg, void* stream) {
   return ait_mha_core_bwd_ex(df, fc_w, O, gate, sk_w, q, ldq, k, ldk, v, ldv, P, n_seq, kv_rows, scale, p_attn, seed_attn, dq, lddq,
-                             dk, lddk, dv, lddv, dg, 0, stream);
+                             dk, lddk, dv, lddv, dg, 0, 0, stream);
 }

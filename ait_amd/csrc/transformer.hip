@@ -158,6 +158,27 @@ inline Qkv views(const MhaBuf& m, long long n, bool cross) {
   return Qkv{m.qkv, kv, kv + D, D, 2 * D};
 }
 
+// ---- q / k / v STORED in bf16 (AIT_CTX_BF16, round 5) ------------------------------------------------------------------
+// Taken when the mode is on, the block has its pre-split-weight scratch (unused in this mode: W_qkv^T and W_qkv as bf16 take
+// 4 of its 6 bytes per value) and the rows fill the bf16 kernel's tiles.  The SAME predicate in the forward and the
+// backward of a step: the backward reads m.qkv in the format the forward wrote.  Layout inside m.qkv (f32-sized regions, the
+// bf16 tensors take the first half of theirs, the bf16 copies of the block's inputs the second):
+//   self:  qkv16 [M, 1536] | x16 [M, 512]            cross:  q16 [M, 512] | x16 [M, 512] ... kv16 [R2, 1024] | xkv16 [R2, 512]
+inline bool qkv16_on(const Run& s, const P3W& pq, long long M) {
+#ifdef AIT_LAB_NO_BF16_QKV      // lab knob: f32 q / k / v in the bf16 mode, for A/Bs
+  return false;
+#endif
+  return s.ctx && (s.ctx->flags & AIT_CTX_BF16) && pq.w.p && M >= 256;
+}
+inline unsigned short* qkv_w16(const P3W& pq) { return const_cast<unsigned short*>(pq.w.p) + (size_t)3 * D * D; }
+struct Qkv16 { unsigned short *q, *k, *v, *x, *xkv; int ldq, ldkv; };
+inline Qkv16 views16(const MhaBuf& m, long long n, long long M, int kv_rows, bool cross) {
+  unsigned short* b = reinterpret_cast<unsigned short*>(m.qkv);
+  if (!cross) return Qkv16{b, b + D, b + 2 * D, b + (size_t)M * 3 * D, nullptr, 3 * D, 3 * D};
+  unsigned short* kv = reinterpret_cast<unsigned short*>(m.qkv + (size_t)n * T * D);
+  return Qkv16{b, kv, kv + D, b + (size_t)M * D, kv + (size_t)n * kv_rows * 2 * D, D, 2 * D};
+}
+
 // one MultiHeadAttention block (SubLayers.py:68-102 with the selective heads of :22-39):
 //   xq [n*64, 512] queries (and residual); keys/values from xkv [n*kv_rows, 512] (xkv == xq: self).
 // p_fc: dropout rate behind fc (SubLayers.py:64,97), p_attn: on the probabilities (Modules.py:14,24);
@@ -169,6 +190,30 @@ int mha_block(const float* xq, const float* xkv, int n, int kv_rows, int mask_mo
   // a pair, equal for all of its proposals): the query projection and the residual are taken per pair
   const int M = (n / q_rep) * T;
   const bool cross = xkv != xq;
+  const bool train = m.mean != nullptr;
+  if (qkv16_on(s, pq, M)) {
+    // bf16 storage of q / k / v (AIT_CTX_BF16): the block's input(s) and W_qkv are converted once -- the copies of the inputs
+    // stay in the second half of m.qkv for the weight gradient of the backward --, the projection runs on the bf16-operand
+    // kernel with a bf16 result, and the attention kernel widens what it loads
+    const long long R2 = (long long)n * kv_rows;
+    unsigned short* w16 = qkv_w16(pq);
+    AIT_TRY(ait_f32_to_bf16(w.w_qkv, 3 * D, D, D, w16, D, 0, s.stream));
+    const Qkv16 v = views16(m, n, M, kv_rows, cross);
+    AIT_TRY(ait_f32_to_bf16(xq, M, D, D, v.x, D, 0, s.stream));
+    if (!cross) {
+      AIT_TRY(ait_gemm_bf16s(M, 3 * D, D, v.x, D, w16, D, nullptr, 0, v.q, 3 * D, nullptr, nullptr, nullptr, 0, 0, s.ctx, s.stream));
+    } else {
+      AIT_TRY(ait_f32_to_bf16(xkv, R2, D, D, v.xkv, D, 0, s.stream));
+      AIT_TRY(ait_gemm_bf16s(M, D, D, v.x, D, w16, D, nullptr, 0, v.q, D, nullptr, nullptr, nullptr, 0, 0, s.ctx, s.stream));
+      AIT_TRY(ait_gemm_bf16s((int)R2, 2 * D, D, v.xkv, D, w16 + (size_t)D * D, D, nullptr, 0, v.k, 2 * D, nullptr, nullptr, nullptr,
+                             0, 0, s.ctx, s.stream));
+    }
+    return ait_mha_core_fwd_ex(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, n, kv_rows, mask_mode, n_valid, 0.125f, p_attn,
+                               ait_dropout_seed(seed, 0), w.sk_w, w.sk_b, w.fc_w, xq, w.ln_g, w.ln_b, kEps, p_fc,
+                               ait_dropout_seed(seed, 1), out_rows, q_rep, train ? m.P : nullptr, train ? m.O : nullptr,
+                               train ? m.u : nullptr, train ? m.gate : nullptr, train ? m.s : nullptr, train ? m.f : nullptr, y,
+                               m.mean, m.rstd, 1, s.stream);
+  }
   if (!cross) {
     AIT_TRY(linear(xq, M, D, w.w_qkv, 3 * D, nullptr, false, m.qkv, s, pq.w));
   } else {
@@ -180,7 +225,6 @@ int mha_block(const float* xq, const float* xkv, int n, int kv_rows, int mask_mo
   // sequence resident (csrc/mha_fused.hip).  Training saves what the backward reads; inference writes nothing but y.
   // (out_rows < 64: only the first out_rows rows of every sequence are written, compacted -- the encoder, whose padded
   // rows are never read again)
-  const bool train = m.mean != nullptr;
   return ait_mha_core_fwd(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, n, kv_rows, mask_mode, n_valid, 0.125f, p_attn,
                           ait_dropout_seed(seed, 0), w.sk_w, w.sk_b, w.fc_w, xq, w.ln_g, w.ln_b, kEps, p_fc,
                           ait_dropout_seed(seed, 1), out_rows, q_rep, train ? m.P : nullptr, train ? m.O : nullptr,
@@ -215,13 +259,22 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
                      ait_dropout_seed(seed, 1), t.df, t.dres, g.ln_g, g.ln_b, nullptr, s.stream));
   AIT_TRY(wgrad(t.df, M, D, m.u, DK, g.fc_w, s));                            // d fc_w += df^T u
   const Qkv v = views(m, n, cross);
+  // (the forward of this step stored q / k / v -- and bf16 copies of the block's inputs -- in bf16: same predicate)
+  const bool in16 = qkv16_on(s, pq, M);
+  const Qkv16 v16 = views16(m, n, M, kv_rows, cross);
   // fc's input gradient, the selective heads and the attention tiles backwards: one kernel per sequence
   // (csrc/mha_fused_bwd.hip; du and dO stay on the chip), or -- lab builds, for A/Bs -- the three launches it replaces
   auto attn_back = [&](void* dq_, int lddq, void* dk_, int lddk, void* dv_, int lddv, int out16) -> int {
 #ifndef AIT_LAB_NO_FUSED_BWD
-    AIT_TRY(ait_mha_core_bwd_ex(t.df, w.fc_w, m.O, m.gate, w.sk_w, v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, n, kv_rows, 0.125f,
-                                p_attn, ait_dropout_seed(seed, 0), dq_, lddq, dk_, lddk, dv_, lddv, t.dg, out16, s.stream));
+    if (in16)
+      AIT_TRY(ait_mha_core_bwd_ex(t.df, w.fc_w, m.O, m.gate, w.sk_w, v16.q, v16.ldq, v16.k, v16.ldkv, v16.v, v16.ldkv, m.P, n,
+                                  kv_rows, 0.125f, p_attn, ait_dropout_seed(seed, 0), dq_, lddq, dk_, lddk, dv_, lddv, t.dg, out16, 1,
+                                  s.stream));
+    else
+      AIT_TRY(ait_mha_core_bwd_ex(t.df, w.fc_w, m.O, m.gate, w.sk_w, v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, n, kv_rows, 0.125f,
+                                  p_attn, ait_dropout_seed(seed, 0), dq_, lddq, dk_, lddk, dv_, lddv, t.dg, out16, 0, s.stream));
 #else
+    if (in16) return AIT_EUNSUPPORTED;      // (the three launches read f32 q / k / v: build with -DAIT_LAB_NO_BF16_QKV too)
     AIT_TRY(dgrad(t.df, M, D, w.fc_w, DK, nullptr, false, t.du, s));            // du = df fc_w
     AIT_TRY(ait_sh_bwd(t.du, m.O, m.gate, w.sk_w, n, H, T, DK, t.dO, t.dg, s.stream));
     AIT_TRY(ait_attn_bwd_ex(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
@@ -239,15 +292,20 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
   {
     const long long R2 = (long long)n * kv_rows;
     int sp = 0, sp2 = 0;
+    size_t part_bytes = 0;
 #ifndef AIT_LAB_NO_BF16_ATTN      // lab knob: the f32-storage projection backward in the bf16 mode, for A/Bs
     if (s.ctx && (s.ctx->flags & AIT_CTX_BF16) && pq.w.p && M >= 256) {
 #else
     if (false) {
 #endif
-      if (!cross) sp = bf16_tn_split(3 * D, D, M, (size_t)M * 2 * D * 2);
+      // (scratch for the K-ranges' partial tiles: t.dqkv behind its bf16 tensors -- with the inputs' bf16 copies left in m.qkv
+      // by the forward, its whole second half)
+      if (!cross) part_bytes = in16 ? (size_t)M * 3 * D * 2 : (size_t)M * 2 * D * 2;
+      else part_bytes = in16 ? ((size_t)M * D + (size_t)R2 * 2 * D) * 2 : (size_t)R2 * 2 * D;
+      if (!cross) sp = bf16_tn_split(3 * D, D, M, part_bytes);
       else {
-        sp = bf16_tn_split(D, D, M, (size_t)R2 * 2 * D);
-        sp2 = bf16_tn_split(2 * D, D, R2, (size_t)R2 * 2 * D);
+        sp = bf16_tn_split(D, D, M, part_bytes);
+        sp2 = bf16_tn_split(2 * D, D, R2, part_bytes);
       }
     }
     if (sp && (!cross || sp2)) {
@@ -255,32 +313,30 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
       unsigned short* g16 = reinterpret_cast<unsigned short*>(t.dqkv);          // the gradients, bf16, in the first half of t.dqkv
       AIT_TRY(ait_f32_to_bf16(w.w_qkv, 3 * D, D, D, wt16, 3 * D, 1, s.stream));
       if (!cross) {
-        unsigned short* x16 = g16 + (size_t)M * 3 * D;                          // [M, D] in the second half
+        unsigned short* x16 = in16 ? v16.x : g16 + (size_t)M * 3 * D;            // [M, D]: the forward's copy, or made here
+        void* part = in16 ? g16 + (size_t)M * 3 * D : x16 + (size_t)M * D;
         AIT_TRY(attn_back(g16, 3 * D, g16 + D, 3 * D, g16 + 2 * D, 3 * D, 1));
-        AIT_TRY(ait_f32_to_bf16(xq, M, D, D, x16, D, 0, s.stream));
+        if (!in16) AIT_TRY(ait_f32_to_bf16(xq, M, D, D, x16, D, 0, s.stream));
         AIT_TRY(ait_gemm_bf16s(M, D, 3 * D, g16, 3 * D, wt16, 3 * D, dxq, D, nullptr, 0, nullptr, t.dres, nullptr, D, 0, s.ctx,
                                s.stream));                                                                   // dx = dqkv W_qkv + dres
-        // (scratch for the K-ranges' partial tiles: what is left of t.dqkv's second half behind x16)
-        if (g.w_qkv)
-          AIT_TRY(ait_gemm_bf16s_tn(3 * D, D, M, g16, 3 * D, x16, D, g.w_qkv, D, sp, x16 + (size_t)M * D, (size_t)M * 2 * D * 2,
-                                    s.ctx, s.stream));
+        if (g.w_qkv) AIT_TRY(ait_gemm_bf16s_tn(3 * D, D, M, g16, 3 * D, x16, D, g.w_qkv, D, sp, part, part_bytes, s.ctx, s.stream));
         return AIT_OK;
       }
       unsigned short* dq16 = g16;                                               // [M, D]
       unsigned short* dkv16 = dq16 + (size_t)M * D;                             // [R2, 2D]
-      unsigned short* x16 = dkv16 + (size_t)R2 * 2 * D;                         // [M, D]
-      unsigned short* xkv16 = x16 + (size_t)M * D;                              // [R2, D]
+      unsigned short* x16 = in16 ? v16.x : dkv16 + (size_t)R2 * 2 * D;          // [M, D]
+      unsigned short* xkv16 = in16 ? v16.xkv : x16 + (size_t)M * D;             // [R2, D]
+      void* part = in16 ? dkv16 + (size_t)R2 * 2 * D : xkv16 + (size_t)R2 * D;
       AIT_TRY(attn_back(dq16, D, dkv16, 2 * D, dkv16 + D, 2 * D, 1));
-      AIT_TRY(ait_f32_to_bf16(xq, M, D, D, x16, D, 0, s.stream));
-      AIT_TRY(ait_f32_to_bf16(xkv, R2, D, D, xkv16, D, 0, s.stream));
+      if (!in16) {
+        AIT_TRY(ait_f32_to_bf16(xq, M, D, D, x16, D, 0, s.stream));
+        AIT_TRY(ait_f32_to_bf16(xkv, R2, D, D, xkv16, D, 0, s.stream));
+      }
       AIT_TRY(ait_gemm_bf16s(M, D, D, dq16, D, wt16, 3 * D, dxq, D, nullptr, 0, nullptr, t.dres, nullptr, D, 0, s.ctx, s.stream));
       if (dxkv)
         AIT_TRY(ait_gemm_bf16s((int)R2, D, 2 * D, dkv16, 2 * D, wt16 + D, 3 * D, dxkv, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0,
                                s.ctx, s.stream));
       if (g.w_qkv) {
-        // (scratch for the partial tiles: the R2 * 2D bytes of t.dqkv behind the four bf16 tensors)
-        void* part = xkv16 + (size_t)R2 * D;
-        const size_t part_bytes = (size_t)R2 * 2 * D;
         AIT_TRY(ait_gemm_bf16s_tn(D, D, M, dq16, D, x16, D, g.w_qkv, D, sp, part, part_bytes, s.ctx, s.stream));
         AIT_TRY(ait_gemm_bf16s_tn(2 * D, D, (int)R2, dkv16, 2 * D, xkv16, D, g.w_qkv + (size_t)D * D, D, sp2, part, part_bytes,
                                   s.ctx, s.stream));

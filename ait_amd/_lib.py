@@ -97,6 +97,7 @@ SIGNATURES = {
     "ait_ffn_bwd_workspace_bytes": (_sz, [_ll]),
     "ait_ffn_bwd": (_i, [_vp, _vp, _ll, _vp, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
     "ait_transformer_saved_bytes": (_sz, [_i, _i, _i]),
+    "ait_transformer_io_bf16_ok": (_i, [_i, _i, _i]),
     "ait_transformer_fwd_train": (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _vp, _vp]),
     "ait_transformer_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "ait_transformer_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp,
@@ -227,6 +228,7 @@ _ACTIVE_PROBE = None
 USE_SCHED_WS = True  # test hook: False = launch without scheduler scratch (static work lists, whole tiles)
 CTX_NATIVE_F32 = 1   # ait_launch_ctx::flags
 CTX_BF16 = 2
+CTX_IO_BF16 = 4
 NATIVE_F32 = False   # ops.set_matmul_dtype("f32_native"): dense products on v_mfma_f32_32x32x2_f32 (default: bf16 3-way split)
 BF16_PRODUCTS = False   # ops.set_matmul_dtype("bf16"): operands rounded to bf16 in registers, one MFMA per block
 

@@ -722,6 +722,29 @@ inline bool carve_eval(Bump& b, AitBufs& a, long long bp, long long bs, int ns) 
          a.d1 && a.d2;
 }
 
+// ---- dec_trans with a bf16 result / a bf16 output gradient (AIT_CTX_BF16 | AIT_CTX_IO_BF16) -----------------------------
+// The consumer of the operator's output in the bf16 configuration is a bf16 convolution stack (the proposal tail on MIOpen):
+// `out` leaves as bf16 [M, 1024] and `d_out` arrives as bf16, d3's bf16 copy (the product's left operand, and the right
+// operand of the weight gradient) lives in what the bf16-storage feed-forward leaves unused of its h buffer, the weight and
+// its transpose in the pre-split scratch.  Taken when the decoder's feed-forward runs in bf16 storage (the h buffer is laid
+// out that way) and the rows suit the weight-gradient kernel.
+struct Io16 {
+  bool on = false;
+  unsigned short *d3, *w, *wt;      // [M, D], [C2, D], [D, C2]
+};
+inline Io16 io16_plan(long long M, const Run& s, const AitBufs& a) {
+  Io16 o;
+  if (!s.ctx || !(s.ctx->flags & AIT_CTX_IO_BF16)) return o;
+  const Bf16Ffn f = bf16_ffn_plan(M, s, a.p_dec_w1, a.p_dec_w2);
+  if (!f.on || !a.p_dec_trans.w.p) return o;
+  if (!bf16_tn_split(C2, D, M, 0)) return o;      // (the weight gradient's rows: whole 32-row slabs per K-range)
+  o.on = true;
+  o.d3 = reinterpret_cast<unsigned short*>(a.dec_ffn.h) + (size_t)M * DI + (size_t)M * D;      // behind h16 and x16
+  o.w = const_cast<unsigned short*>(a.p_dec_trans.w.p);
+  o.wt = o.w + (size_t)C2 * D;
+  return o;
+}
+
 // block seeds of the operator's ten dropout sites (two per attention block, one per feed-forward / prologue)
 enum { kSeedEncPro = 16, kSeedEncSlf, kSeedEncFfn, kSeedDecPro, kSeedDecSlf, kSeedDecEnc, kSeedDecFfn };
 
@@ -763,6 +786,13 @@ int ait_forward(const float* x_props, const float* x_query, int bp, int bs, int 
   }
   AIT_TRY(ffn_block(a.d2, M, w->dec_ffn, a.dec_ffn, p, ait_dropout_seed(seed, kSeedDecFfn), a.d3, run, a.p_dec_w1, a.p_dec_w2));
   // dec_trans back to 2d channels per token
+  if (run.ctx && (run.ctx->flags & AIT_CTX_IO_BF16)) {
+    const Io16 io = io16_plan(M, run, a);
+    if (!io.on) return AIT_EUNSUPPORTED;
+    AIT_TRY(ait_f32_to_bf16(w->dec_trans_w, C2, D, D, io.w, D, 0, stream));
+    AIT_TRY(ait_f32_to_bf16(a.d3, M, D, D, io.d3, D, 0, stream));
+    return ait_gemm_bf16s(M, C2, D, io.d3, D, io.w, D, nullptr, 0, out, C2, w->dec_trans_b, nullptr, nullptr, 0, 0, run.ctx, stream);
+  }
   return linear(a.d3, M, D, w->dec_trans_w, C2, w->dec_trans_b, false, out, run, a.p_dec_trans.w);
 }
 
@@ -812,6 +842,15 @@ AIT_API int ait_transformer_fwd_train(const float* x_props, const float* x_query
   return ait_forward(x_props, x_query, bp, bs, n_src, w, a, p_drop, p_attn_drop, seed, out, Run{stream, ctx});
 }
 
+// 1 if ait_transformer_fwd_train / _fwd / _bwd take AIT_CTX_BF16 | AIT_CTX_IO_BF16 at this size (else they return
+// AIT_EUNSUPPORTED under that flag)
+AIT_API int ait_transformer_io_bf16_ok(int bp, int bs, int n_src) {
+  if (check_ait(bp, bs, n_src, &bp) != AIT_OK || bp == 0) return 0;
+  const long long M = (long long)bp * T;
+  if (M < 256 || M > 0x7fffffffLL / DI) return 0;
+  return bf16_tn_split(D, DI, M, (size_t)M * (DI - D) * 2) > 0 && bf16_tn_split(C2, D, M, 0) > 0;
+}
+
 AIT_API size_t ait_transformer_bwd_workspace_bytes(int bp, int bs, int n_src) {
   if (bp <= 0 || bs <= 0 || n_src <= 0 || n_src > T) return 0;
   const size_t M = (size_t)bp * T;
@@ -854,9 +893,26 @@ static int ait_backward_parts(int parts, const float* d_out, const float* x_prop
 
   if (parts & 1) {
   // dec_trans: out = d3 W^T + b
+  if (ctx && (ctx->flags & AIT_CTX_IO_BF16)) {
+    // (d_out is a bf16 tensor; the forward of this step left d3's bf16 copy behind: same plan)
+    const Io16 io = io16_plan(M, run, a);
+    if (!io.on) return AIT_EUNSUPPORTED;
+    // (K-ranges of the weight gradient: as many as the block scratch holds partial tiles for)
+    Bump bb = blk;
+    const int sp = bf16_tn_split(C2, D, M, bb.left > 4096 ? bb.left - 4096 : 0);
+    const size_t part_floats = (size_t)sp * C2 * D;
+    float* part = bb.take(part_floats);
+    if (g->dec_trans_b) AIT_TRY(ait_colsum_bf16(d_out, M, C2, C2, g->dec_trans_b, stream));
+    if (g->dec_trans_w)
+      AIT_TRY(ait_gemm_bf16s_tn(C2, D, M, d_out, C2, io.d3, D, g->dec_trans_w, D, sp, part, part ? part_floats * sizeof(float) : 0,
+                                ctx, stream));
+    AIT_TRY(ait_f32_to_bf16(w->dec_trans_w, C2, D, D, io.wt, C2, 1, stream));
+    AIT_TRY(ait_gemm_bf16s(M, D, C2, d_out, C2, io.wt, C2, ga, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, ctx, stream));   // ga = d d3
+  } else {
   if (g->dec_trans_b) AIT_TRY(ait_colsum_f32(d_out, M, C2, C2, g->dec_trans_b, stream));
   AIT_TRY(wgrad(d_out, M, C2, a.d3, D, g->dec_trans_w, run));
   AIT_TRY(dgrad(d_out, M, C2, w->dec_trans_w, D, nullptr, false, ga, run, nullptr, a.p_dec_trans.wt));      // ga = d d3
+  }
   {  // decoder feed-forward: d d3 -> d d2
     Bump bb = blk; FfnBwdWs t;
     if (!carve_ffn_ws(bb, t, M)) return AIT_EWORKSPACE;

@@ -59,6 +59,7 @@ def _side_stream(device):
 _TAIL_FUSED = True
 _HEADS_KERNEL = True          # test hook: False = the two heads as torch nn.Linear calls (vendor GEMM)
 _TRUNK_BF16 = True            # test hook: False = the C4 trunk in f32 also in the bf16 configuration (round 4's cfg5)
+_AIT_OUT_BF16 = True          # test hook: False = the AIT's output stays f32 in the bf16 configuration (cast by the tail's entry)
 _TAIL_BF16_MIOPEN = True      # test hook: False = the library's (f32-storage) tail node also in the bf16 configuration
 _TOP_NHWC = True
 _BASE_NHWC = True
@@ -760,6 +761,9 @@ class _fasterRCNN(nn.Module):
         num_props = rois.size(1)
 
         props_feat = self.RCNN_roi_align(non_img, rois.view(-1, 5))          # [bs*P, 1024, 7, 7]
+        # (bf16 configuration: the tail below computes on bf16 tensors -- the AIT hands its output over in bf16, sizes permitting)
+        tail16 = bool(_TAIL_BF16_MIOPEN and _lib.BF16_PRODUCTS and props_feat.is_cuda and (1 if _SK_FULL else self._top_stride()) == 2)
+        self.transformer.out_bf16 = tail16 and _AIT_OUT_BF16
         props_feat = self.transformer(x_props=props_feat, x_query=non_qry)   # [bs*P, 1024, 8, 8]
         # layer4 opens with stride-2 1x1 convolutions (Bottleneck.conv1 / downsample,
         # resnet_sys_transformer_sk_dilat.py:78,482-490): of the SK block's 8x8 output only the 16
@@ -769,7 +773,7 @@ class _fasterRCNN(nn.Module):
         # reference), 3/4 of the SK work not done.  AIT_SK_FULL=1 keeps the dead positions.
         sk_stride = 1 if _SK_FULL else self._top_stride()
         c_att = None
-        if _TAIL_BF16_MIOPEN and _lib.BF16_PRODUCTS and props_feat.is_cuda and sk_stride == 2:
+        if tail16:
             # the bf16 configuration (BASELINE configs[4]): the proposal tail as the module composition on MIOpen with bf16
             # tensors, like the trunk (frozen-BN passes: ait_bn_act_*_bf16) -- the library's tail node (ait_tail_*) stores
             # f32 and multiplies bf16-rounded operands at 250-430 TFLOP/s; MIOpen's bf16 convolutions are 4.6 ms/step faster

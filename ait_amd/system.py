@@ -420,7 +420,7 @@ _PART_PARAMS = (
 
 class _AitState:
     """what the three backward parts of one forward share (plain Python object: not a tensor, not saved by autograd)"""
-    __slots__ = ("fw", "ws", "W", "keep", "cfg", "shapes", "_dxq", "flags")
+    __slots__ = ("fw", "ws", "W", "keep", "cfg", "shapes", "_dxq", "flags", "out16")
 
 
 def _grads_struct(views_by_index):
@@ -469,7 +469,9 @@ def _ait_backward_part(st, part, d_out, kept, want_dxp=False, want_dxq=False):
     dxp = torch.empty_like(xp) if want_dxp else None
     dxq = torch.empty_like(xq) if want_dxq else None
     with torch.cuda.device(dev):
-        rc = L.ait_transformer_bwd_part(part, None if d_out is None else _lib.dev_ptr(d_out), _lib.dev_ptr(xp),
+        # (d_out: f32, or bf16 when the forward ran with AIT_CTX_IO_BF16 -- autograd hands the gradient in the output's dtype)
+        want = torch.bfloat16 if st.flags & _lib.CTX_IO_BF16 else torch.float32
+        rc = L.ait_transformer_bwd_part(part, None if d_out is None else _lib.dev_ptr(d_out, want), _lib.dev_ptr(xp),
                                         _lib.dev_ptr(xq), bp, bs, n_s, ctypes.byref(st.W), p, p_attn, seed,
                                         ctypes.c_void_p(saved.data_ptr()), saved.numel(),
                                         ctypes.c_void_p(st.ws.data_ptr()), st.ws.numel(),
@@ -491,12 +493,18 @@ class _AitCore(torch.autograd.Function):
         xp, xq = xp.contiguous(), xq.contiguous()
         nbytes = int(L.ait_transformer_saved_bytes(bp, bs, n_s))
         saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        out = torch.empty((bp * SEQ, xp.shape[1]), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st.flags = _lib.current_flags()      # the backward parts run in the product form of this forward
+            # bf16 configuration, a consumer that computes in bf16 (Transformer.out_bf16): the output leaves as bf16 and its
+            # gradient arrives as bf16 (AIT_CTX_IO_BF16), sizes permitting
+            if st.out16 and (st.flags & _lib.CTX_BF16) and xp.shape[1] == 1024 and L.ait_transformer_io_bf16_ok(bp, bs, n_s):
+                st.flags |= _lib.CTX_IO_BF16
+        io16 = bool(st.flags & _lib.CTX_IO_BF16)
+        out = torch.empty((bp * SEQ, xp.shape[1]), dtype=torch.bfloat16 if io16 else torch.float32, device=dev)
+        with torch.cuda.device(dev):
             rc = L.ait_transformer_fwd_train(_lib.dev_ptr(xp), _lib.dev_ptr(xq), bp, bs, n_s, ctypes.byref(st.W),
                                              float(p), float(p_attn), int(seed), ctypes.c_void_p(saved.data_ptr()),
-                                             nbytes, _lib.dev_ptr(out), _lib.launch_ctx(dev, flags=st.flags),
+                                             nbytes, _lib.dev_ptr(out, out.dtype), _lib.launch_ctx(dev, flags=st.flags),
                                              _lib.cur_stream(dev))
         _lib.check(rc, "ait_transformer_fwd_train")
         # the multi-GB activation buffer and the two inputs are the NODES' saved tensors (all three nodes save the same
@@ -537,10 +545,11 @@ class _AitStage(torch.autograd.Function):
         return (d, None, None) + tuple(grads)
 
 
-def _transformer_train(xp, xq, bp, bs, n_s, p, p_attn, seed, W, keep, params):
+def _transformer_train(xp, xq, bp, bs, n_s, p, p_attn, seed, W, keep, params, out_bf16=False):
     st = _AitState.__new__(_AitState)
     st.ws = st.fw = st._dxq = None
     st.flags = 0
+    st.out16 = bool(out_bf16)
     st.W, st.keep = W, keep                        # (keep owns the concatenated QKV matrices W points into)
     st.cfg = (bp, bs, n_s, float(p), float(p_attn), int(seed))
     st.shapes = [tuple(t.shape) for t in params]
@@ -902,6 +911,9 @@ class Transformer(nn.Module):
                                pad_idx=trg_pad_idx, dropout=dropout)
         self.dec_trans = nn.Sequential(conv2d_1x1(d_word_vec, d_word_vec * 2, bias=True))
         self.channels_last_out = False
+        # the bf16 configuration's consumer (the proposal tail on bf16 convolutions) sets this: with
+        # set_matmul_dtype("bf16"), in training, the output is a bf16 tensor (AIT_CTX_IO_BF16) -- else it is ignored
+        self.out_bf16 = False
         for p in self.parameters():
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
@@ -1023,7 +1035,8 @@ class Transformer(nn.Module):
         if len(self.encoder.layer_stack) == 1 and len(self.decoder.layer_stack) == 1 and not fine:
             # training: ait_transformer_fwd_train, and its backward as three chained autograd nodes (_transformer_train)
             W, keep = self._c_weights_cached()
-            out = _transformer_train(xp, xq, bp, bs, n_s, p, p_attn, base_seed, W, keep, self._param_list())
+            out = _transformer_train(xp, xq, bp, bs, n_s, p, p_attn, base_seed, W, keep, self._param_list(),
+                                     out_bf16=self.out_bf16 and self.channels_last_out)
             if self.channels_last_out:
                 return out.view(bp, hq, wq, c2).permute(0, 3, 1, 2)
             return out.view(bp, n_t, c2).transpose(1, 2).reshape(bp, c2, hq, wq)

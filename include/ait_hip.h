@@ -79,10 +79,18 @@ const char* ait_strerror(int code);
  *       (ait_conv_*, ait_tail_*).  Inside ait_transformer_fwd_train / ait_transformer_bwd_part the feed-forward blocks
  *       additionally STORE their 2048-wide tensors (the ReLU output h, its gradient) in bf16 and multiply bf16 operands
  *       from memory (ait_gemm_bf16s, ait_gemm_bf16s_tn; shapes permitting): the `saved` buffer of such a forward holds
- *       bf16 where an f32 forward holds f32, so THE BACKWARD MUST BE GIVEN THE FLAGS OF ITS FORWARD.
+ *       bf16 where an f32 forward holds f32, so THE BACKWARD MUST BE GIVEN THE FLAGS OF ITS FORWARD.  The same holds
+ *       for q / k / v of the attention blocks (bf16 projection results, widened by the attention kernels).
+ *       AIT_CTX_IO_BF16 (with AIT_CTX_BF16; ait_transformer_fwd / _fwd_train / _bwd / _bwd_part only): the operator's
+ *       `out` is WRITTEN as a bf16 tensor [bp*64, 1024] and `d_out` is READ as one, behind the float pointers of the
+ *       signatures -- for a consumer that computes in bf16 anyway (the proposal tail on bf16 convolutions in
+ *       BASELINE configs[4]): no f32 copy of the largest activation of the path, dec_trans and its two gradient
+ *       products on bf16 operands from memory.  Sizes permitting: ait_transformer_io_bf16_ok(bp, bs, n_src) != 0,
+ *       else AIT_EUNSUPPORTED.
  * ------------------------------------------------------------------------------------- */
 #define AIT_CTX_NATIVE_F32 1u
 #define AIT_CTX_BF16 2u
+#define AIT_CTX_IO_BF16 4u
 typedef struct {
   void* sched_ws;
   size_t sched_ws_bytes;
@@ -678,6 +686,7 @@ int ait_ffn_bwd(const float* dy, const float* x, long long rows, const ait_ffn_w
                 size_t workspace_bytes, float* dx, const ait_ffn_grads* grads, const ait_launch_ctx* ctx,
                 void* stream);
 
+int ait_transformer_io_bf16_ok(int bp, int bs, int n_src);      /* see AIT_CTX_IO_BF16 */
 size_t ait_transformer_saved_bytes(int bp, int bs, int n_src);
 int ait_transformer_fwd_train(const float* x_props, const float* x_query, int bp, int bs, int n_src,
                               const ait_transformer_weights* w, float p_drop, float p_attn_drop,

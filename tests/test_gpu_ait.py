@@ -365,6 +365,43 @@ def test_transformer_bf16_matmul_mode_vs_fp32_oracle():
     assert errs[0] > 1e-5          # the switch really changed the arithmetic
 
 
+def test_transformer_bf16_mode_with_a_bf16_output_matches_its_f32_output():
+    """AIT_CTX_IO_BF16 (Transformer.out_bf16, what the bf16 configuration's proposal tail asks for): the operator's output
+    leaves as a bf16 tensor and its gradient arrives as one; dec_trans and its two gradient products run on bf16 operands
+    from memory.  Against the same bf16-products mode with an f32 output, same weights and inputs: the output within bf16
+    rounding (relative L2 <= 3e-3: 2^-9 per element), the input gradients and dec_trans' parameter gradients within the
+    bf16 mode's own tolerance (<= 2e-2; the cotangent itself is rounded to bf16 on this path)."""
+    from ait_amd import ops
+    t = _transformer(3).eval()
+    t.channels_last_out = True
+    xp0, xq0 = seeded(311, (6, 1024, 7, 7)), seeded(312, (2, 1024, 8, 8))
+    cot = _dev(seeded(313, (6, 1024, 8, 8))).contiguous(memory_format=torch.channels_last)
+    res = {}
+    ops.set_matmul_dtype("bf16")
+    try:
+        for out16 in (False, True):
+            t.out_bf16 = out16
+            t.zero_grad(set_to_none=True)
+            A, B = _dev(xp0).requires_grad_(True), _dev(xq0).requires_grad_(True)
+            y = t(x_props=A, x_query=B)
+            assert y.dtype == (torch.bfloat16 if out16 else torch.float32) and y.shape == (6, 1024, 8, 8)
+            y.backward(cot.to(y.dtype))
+            res[out16] = (y.detach().float(), A.grad, B.grad, t.dec_trans[0].weight.grad.clone(), t.dec_trans[0].bias.grad.clone())
+    finally:
+        ops.set_matmul_dtype("f32")
+        t.out_bf16 = False
+    rel = lambda got, want: float((got - want).norm() / want.norm())
+    errs = [rel(a, b) for a, b in zip(res[True], res[False])]
+    print("bf16 output against f32 output (y, d x_props, d x_query, d dec_trans.w, d dec_trans.b):", errs)
+    assert errs[0] <= 3e-3 and all(e <= 2e-2 for e in errs[1:]), errs
+    # and in the f32 modes the switch is ignored
+    t.out_bf16 = True
+    try:
+        assert t(x_props=_dev(xp0).requires_grad_(True), x_query=_dev(xq0)).dtype == torch.float32
+    finally:
+        t.out_bf16 = False
+
+
 def test_transformer_bf16x3_mode_meets_the_fp32_tolerance():
     """Experimental split-bf16 GEMMs (3 bf16 MFMAs per fp32 product, fp32 accumulate): the AIT
     forward (the logits side north_star's tolerance is stated on) stays inside the SAME tolerance

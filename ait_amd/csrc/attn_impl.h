@@ -219,9 +219,17 @@ __device__ __forceinline__ float frag_at(const Frag& f, int j) {
 //   SPLIT = false: v_mfma_f32_32x32x2_f32, 32 MFMAs of twice the cycles per block and no vector work -- MFMA step j of
 //                  block kb multiplies k = 16 kb + j (lane half 0) and 16 kb + 8 + j (half 1): any pairing of k-values is
 //                  a valid step as long as both operands use it.
-// The forward uses the split form, the backward the f32 instruction (attn_bwd_kernel says why).
-template <bool SPLIT, class FA, class FB>
+// The forward and the fused backward (mha_fused_bwd.hip) use the split form, attn_bwd_kernel the f32 instruction (it says why).
+// PA / PB: the planes operand A / B HAS -- 3: any f32 value; 1: the values are bf16 already (the bf16-storage mode's
+// q / k / v, widened on their way in): that operand's lower planes are zero, its split is one conversion per pair, and the
+// product is EXACT in three MFMAs (one, if both operands are bf16) instead of six.
+template <bool SPLIT, int PA_ = 3, int PB_ = 3, class FA, class FB>
 __device__ __forceinline__ void mm_split(FA fa, FB fb, f32x16 (&acc)[2][2]) {
+#ifdef AIT_LAB_NO_BF16_PLANES      // lab knob: six terms whatever the operands are, for A/Bs
+  constexpr int PA = 3, PB = 3;
+#else
+  constexpr int PA = PA_, PB = PB_;
+#endif
 #pragma unroll
   for (int kb = 0; kb < 4; kb++) {
     // (fence per k-block: the loop must be fully unrolled -- static register indices -- but the scheduler must not
@@ -243,31 +251,45 @@ __device__ __forceinline__ void mm_split(FA fa, FB fb, f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       const Frag x = fa(t, kb);
-      pa[t] = ait_gemm::split8<6, true>(x.lo, x.hi);
+      pa[t] = ait_gemm::split8<PA == 1 ? 1 : 6, true>(x.lo, x.hi);
       const Frag y = fb(t, kb);
-      pb[t] = ait_gemm::split8<6, true>(y.lo, y.hi);
+      pb[t] = ait_gemm::split8<PB == 1 ? 1 : 6, true>(y.lo, y.hi);
     }
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
-      for (int b = 0; b < 2; b++) acc[a][b] = ait_gemm::mfma_split<6>(pa[a], pb[b], acc[a][b]);
+      for (int b = 0; b < 2; b++) {
+        if constexpr (PA == 3 && PB == 3) {
+          acc[a][b] = ait_gemm::mfma_split<6>(pa[a], pb[b], acc[a][b]);
+        } else if constexpr (PA == 3) {       // (smallest terms first, as the six-term form)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a].l, pb[b].h, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a].m, pb[b].h, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a].h, pb[b].h, acc[a][b], 0, 0, 0);
+        } else if constexpr (PB == 3) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a].h, pb[b].l, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a].h, pb[b].m, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a].h, pb[b].h, acc[a][b], 0, 0, 0);
+        } else {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a].h, pb[b].h, acc[a][b], 0, 0, 0);
+        }
+      }
   }
 }
 // the four operand placements the kernels use
 //   A in registers, R(k, j) = Rs[j][k]  (right operand transposed, from the panel)
-template <bool SPLIT = true>
+template <bool SPLIT = true, int PA = 3, int PB = 3>
 __device__ __forceinline__ void mm_areg_bldsT(const OpRegs& a, const float* __restrict__ Rs,
                                               f32x16 (&acc)[2][2], int lane) {
   const int li = lane & 31, lk = lane >> 5;
-  mm_split<SPLIT>([&](int t, int kb) { return a.frag(t, kb); }, [&](int t, int kb) { return frag_rows(Rs, t, kb, li, lk); }, acc);
+  mm_split<SPLIT, PA, PB>([&](int t, int kb) { return a.frag(t, kb); }, [&](int t, int kb) { return frag_rows(Rs, t, kb, li, lk); }, acc);
 }
 //   L from the panel (L(i,k) = Ls[i][k], or Ls[k][i] with LT), B in registers
-template <bool LT, bool SPLIT = true>
+template <bool LT, bool SPLIT = true, int PA = 3, int PB = 3>
 __device__ __forceinline__ void mm_alds_breg(const float* __restrict__ Ls, const OpRegs& b,
                                              f32x16 (&acc)[2][2], int lane) {
   const int li = lane & 31, lk = lane >> 5;
-  mm_split<SPLIT>([&](int t, int kb) { return LT ? frag_cols(Ls, t, kb, li, lk) : frag_rows(Ls, t, kb, li, lk); },
-           [&](int t, int kb) { return b.frag(t, kb); }, acc);
+  mm_split<SPLIT, PA, PB>([&](int t, int kb) { return LT ? frag_cols(Ls, t, kb, li, lk) : frag_rows(Ls, t, kb, li, lk); },
+                          [&](int t, int kb) { return b.frag(t, kb); }, acc);
 }
 
 __device__ __forceinline__ void zero(f32x16 (&acc)[2][2]) {

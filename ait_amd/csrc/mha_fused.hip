@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   f32x16 acc[2][2];
   zero(acc);
   STAMP(0)
-  mm_areg_bldsT(op, s0, acc, lane);       // S = Q K^T
+  mm_areg_bldsT<true, IN16 ? 1 : 3, IN16 ? 1 : 3>(op, s0, acc, lane);       // S = Q K^T
   STAMP(1)
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (IN16)      // (column-paired: O_h's columns below are acc_col_of<IN16>)
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   STAMP(2)
   acc_to_lds(acc, s0, lane);
   zero(acc);
-  mm_alds_breg<false>(s0, op, acc, lane);  // O_h = P V, kept in acc
+  mm_alds_breg<false, true, 3, IN16 ? 1 : 3>(s0, op, acc, lane);  // O_h = P V, kept in acc
   STAMP(3)
   __builtin_amdgcn_sched_barrier(0);
   if (c.O) {

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_bwd_kernel(const Co
   }
   __builtin_amdgcn_sched_barrier(0);
   zero(acc);
-  mm_areg_bldsT<(kSplitMask & 2) != 0>(op, s0, acc, lane);
+  mm_areg_bldsT<(kSplitMask & 2) != 0, 3, IN16 ? 1 : 3>(op, s0, acc, lane);
   __builtin_amdgcn_sched_barrier(0);
   // dS = P * (dP - rowsum(dP * P)) with dP = dPd * mask / (1 - p); then the 1 / sqrt(d_k) scale
   const int lane_s = opaque(lane);
@@ -263,13 +263,13 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_bwd_kernel(const Co
   else breg_load(op, Kg, g.ldk, lane, g.kv_rows);
   acc_to_lds(acc, s0, lane);
   zero(acc);
-  mm_alds_breg<false, (kSplitMask & 4) != 0>(s0, op, acc, lane);      // dQ = dS K
+  mm_alds_breg<false, (kSplitMask & 4) != 0, 3, IN16 ? 1 : 3>(s0, op, acc, lane);      // dQ = dS K
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (IN16) breg_load_pairs(op, Qg, g.ldq, lane);
   else breg_load(op, Qg, g.ldq, lane);
   store_rows<OUT16, IN16>(acc, c.dq, ((size_t)n * T) * c.lddq + h * D, c.lddq, opaque(lane), T);
   zero(acc);
-  mm_alds_breg<true, (kSplitMask & 8) != 0>(s0, op, acc, lane);       // dK = dS^T Q
+  mm_alds_breg<true, (kSplitMask & 8) != 0, 3, IN16 ? 1 : 3>(s0, op, acc, lane);       // dK = dS^T Q
   store_rows<OUT16, IN16>(acc, c.dk, ((size_t)n * g.kv_rows) * c.lddk + h * D, c.lddk, opaque(lane), g.kv_rows);
 }
 

@@ -14,6 +14,10 @@ def c(n):
     if 'naive_conv' in n or 'miopen' in n.lower() or 'gridwise' in n.lower(): return 'miopen other'
     if 'at::native' in n or 'rocprim' in n or 'at::cuda' in n: return 'torch elementwise / reduce / index'
     if 'anonymous' in n:
+        if 'gemm_bf16s_tn' in n or 'tn_reduce' in n: return 'ait_gemm bf16 storage: weight gradients (+ partial-tile reduce)'
+        if 'gemm_bf16s' in n: return 'ait_gemm bf16 storage'
+        if 'to_bf16' in n: return 'ait f32 -> bf16 conversions'
+        if 'mha_core_bwd' in n: return 'ait fused attention block, backward (fc dgrad + selective heads + tiles)'
         if 'mha_core' in n: return 'ait fused attention block (fwd: tiles + selective heads + fc + LayerNorm)'
         for k in ('roi_align', 'attn', 'bn_act', 'ln_', 'sh_', 'nms', 'sk_', 'colsum', 'rep_sum'):
             if k in n: return 'ait ' + k.strip('_')

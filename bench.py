@@ -415,9 +415,10 @@ def main():
                   "f32_native": "f32 (AIT products on v_mfma_f32_32x32x2_f32; the proposal tail's and the RPN head's convolutions "
                                 "keep the split-bf16 form)",
                   "bf16": "bf16 (BASELINE configs[4]): C4 trunk and proposal tail on MIOpen with bf16 tensors (f32 master weights, f32 accumulate, "
-                          "frozen-BN passes on bf16); AIT: every product on v_mfma_f32_32x32x16_bf16 with f32 accumulate -- feed-forward "
-                          "hidden tensors and the attention blocks' gradients STORED in bf16 (bf16 operands from memory), the other "
-                          "linears' operands rounded to bf16 in registers; f32 residual stream, LayerNorm, attention tiles, RPN, losses",
+                          "frozen-BN passes on bf16); AIT: every linear on v_mfma_f32_32x32x16_bf16 with f32 accumulate -- feed-forward "
+                          "hidden tensors, q / k / v, the attention blocks' gradients and the operator's output STORED in bf16 (bf16 "
+                          "operands from memory), the embeddings' operands rounded to bf16 in registers; f32 residual stream, LayerNorm, "
+                          "softmax and attention-tile arithmetic (on widened bf16 q / k / v), RPN, losses",
                   "bf16x3": "f32 emulated as 3 bf16 MFMAs per product (experimental; fp32 accumulate)"}[args.dtype],
         "data": "synthetic",
         "config": {"workload": conf["workload"] % {"P": args.proposals, "bs": args.bs},

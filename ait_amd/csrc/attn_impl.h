@@ -41,6 +41,11 @@ using ait_gemm::f32x16;
 using ait_gemm::Planes;
 
 constexpr int T = 64, D = 64, PITCH = 65;
+#ifdef AIT_LAB_F32_PAIRS      // lab knob: the column-paired right-operand loads (breg_load_pairs) for f32 q / k / v as well
+constexpr bool kF32Pairs = true;
+#else
+constexpr bool kF32Pairs = false;
+#endif
 constexpr int kPanel = T * PITCH;          // floats per LDS panel
 constexpr int kWaves = 4;
 constexpr int kThreads = kWaves * 64;
@@ -197,6 +202,20 @@ __device__ __forceinline__ void breg_load_pairs(OpRegs& b, const unsigned short*
       const unsigned w = *reinterpret_cast<const unsigned*>(g + (unsigned)(min(k, rows - 1) * ld + 2 * li));
       b.v[0][kb][j] = k < rows ? bf16_lo(w) : 0.f;
       b.v[1][kb][j] = k < rows ? bf16_hi(w) : 0.f;
+    }
+}
+
+// ... and the column-paired form for an f32 tensor: one 8-byte load per lane and row (columns 2 li, 2 li + 1)
+__device__ __forceinline__ void breg_load_pairs(OpRegs& b, const float* __restrict__ g, int ld, int lane, int rows = T) {
+  const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int kb = 0; kb < 4; kb++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = 16 * kb + 8 * lk + j;
+      const float2 w = *reinterpret_cast<const float2*>(g + (unsigned)(min(k, rows - 1) * ld + 2 * li));
+      b.v[0][kb][j] = k < rows ? w.x : 0.f;
+      b.v[1][kb][j] = k < rows ? w.y : 0.f;
     }
 }
 

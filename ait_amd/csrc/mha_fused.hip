@@ -76,6 +76,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   float* const sv = vec + kDm;                     // [64]     s
   float* const rstat = sv + 64;                    // [2][64]  row mean / rstd
   const AttnArgs& g = c.at;
+  constexpr bool PAIRED = IN16 || kF32Pairs;      // O_h's columns: 2 li + t (breg_load_pairs), else 32 t + li
   const int lane = threadIdx.x & 63, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform, in an SGPR)
   const int li = lane & 31, lk = lane >> 5, tid = h * 64 + lane;
   float* s0 = lds + h * kPanel;
@@ -115,6 +116,8 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (IN16)      // (column-paired: O_h's columns below are acc_col_of<IN16>)
     breg_load_pairs(op, reinterpret_cast<const unsigned short*>(g.v) + ((size_t)n * g.kv_rows) * g.ldv + h * D, g.ldv, lane, g.kv_rows);
+  else if constexpr (PAIRED)
+    breg_load_pairs(op, g.v + ((size_t)n * g.kv_rows) * g.ldv + h * D, g.ldv, lane, g.kv_rows);
   else
     breg_load(op, g.v + ((size_t)n * g.kv_rows) * g.ldv + h * D, g.ldv, lane, g.kv_rows);
   scale_mask(acc, lane, g);
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int row = acc_row(a, r, lane);
-        if constexpr (IN16) {      // columns 2 li and 2 li + 1: one 8-byte store
+        if constexpr (PAIRED) {      // columns 2 li and 2 li + 1: one 8-byte store
           *reinterpret_cast<float2*>(og + (unsigned)(row * D + 2 * li)) = make_float2(acc[a][0][r], acc[a][1][r]);
         } else {
           og[(unsigned)(row * D + li)] = acc[a][0][r];
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
 #pragma unroll
         for (int r = 0; r < 16; r++) cs += acc[a][b][r];
       cs += __shfl_xor(cs, 32, 64);
-      if (lk == 0) part[h * 64 + acc_col_of<IN16>(b, lane)] = cs;
+      if (lk == 0) part[h * 64 + acc_col_of<PAIRED>(b, lane)] = cs;
     }
     sw.store(s0, lane);
   }
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   // ---- phase C: u = sum_h gate_h * O_h through the panels, heads in fixed order ---------------------------------
   {
     float g0, g1;                                           // gates of the lane's two channels
-    if constexpr (IN16) {
+    if constexpr (PAIRED) {
       g0 = __shfl(gj, 2 * li, 64);
       g1 = __shfl(gj, 2 * li + 1, 64);
     } else {
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
       g0 = lk ? gx : gj;                                    // channels li and 32 + li
       g1 = lk ? gj : gx;
     }
-    const int c0 = acc_col_of<IN16>(0, lane), c1 = acc_col_of<IN16>(1, lane);
+    const int c0 = acc_col_of<PAIRED>(0, lane), c1 = acc_col_of<PAIRED>(1, lane);
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll

@@ -259,18 +259,19 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_bwd_kernel(const Co
       acc[a][1][r] = p1 * (d1 - dot) * g.scale;
     }
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (IN16) breg_load_pairs(op, Kg, g.ldk, lane, g.kv_rows);      // (column-paired: so are dQ's columns)
+  constexpr bool PAIRED = IN16 || kF32Pairs;
+  if constexpr (PAIRED) breg_load_pairs(op, Kg, g.ldk, lane, g.kv_rows);      // (column-paired: so are dQ's columns)
   else breg_load(op, Kg, g.ldk, lane, g.kv_rows);
   acc_to_lds(acc, s0, lane);
   zero(acc);
   mm_alds_breg<false, (kSplitMask & 4) != 0, 3, IN16 ? 1 : 3>(s0, op, acc, lane);      // dQ = dS K
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (IN16) breg_load_pairs(op, Qg, g.ldq, lane);
+  if constexpr (PAIRED) breg_load_pairs(op, Qg, g.ldq, lane);
   else breg_load(op, Qg, g.ldq, lane);
-  store_rows<OUT16, IN16>(acc, c.dq, ((size_t)n * T) * c.lddq + h * D, c.lddq, opaque(lane), T);
+  store_rows<OUT16, PAIRED>(acc, c.dq, ((size_t)n * T) * c.lddq + h * D, c.lddq, opaque(lane), T);
   zero(acc);
   mm_alds_breg<true, (kSplitMask & 8) != 0, 3, IN16 ? 1 : 3>(s0, op, acc, lane);       // dK = dS^T Q
-  store_rows<OUT16, IN16>(acc, c.dk, ((size_t)n * g.kv_rows) * c.lddk + h * D, c.lddk, opaque(lane), g.kv_rows);
+  store_rows<OUT16, PAIRED>(acc, c.dk, ((size_t)n * g.kv_rows) * c.lddk + h * D, c.lddk, opaque(lane), g.kv_rows);
 }
 
 constexpr size_t kBwdLds = (size_t)(kHeads * kPanel + kPanel + kHeads * 64 + kDm + kHeads * 128) * sizeof(float);

@@ -1,6 +1,8 @@
 """ait_mha_core_fwd against the four launches it replaces, 1200 sequences (bench shapes), ms per block."""
 import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _lab_lib  # noqa: F401  (AIT_LAB_LIB=<variant> selects a lab build of the library)
 import torch
 from ait_amd import ops
 dev = "cuda"

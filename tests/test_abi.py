@@ -46,6 +46,12 @@ def test_library_builds_and_exports_header_symbols():
     assert L.ait_abi_version() == 6
     assert L.ait_strerror(0) == b"ok"
     assert L.ait_nms_workspace_bytes(12000) >= 12000 * 188 * 8
+    # AIT_CTX_IO_BF16's size predicate (a host function): the bench configurations and the 6-proposal test size qualify,
+    # fewer than 256 token rows or an invalid batch do not
+    assert L.ait_transformer_io_bf16_ok(1200, 4, 49) == 1 and L.ait_transformer_io_bf16_ok(4096, 8, 49) == 1
+    assert L.ait_transformer_io_bf16_ok(6, 2, 49) == 1
+    assert L.ait_transformer_io_bf16_ok(2, 2, 49) == 0 and L.ait_transformer_io_bf16_ok(7, 2, 49) == 0
+    assert L.ait_transformer_io_bf16_ok(0, 2, 49) == 0 and L.ait_transformer_io_bf16_ok(6, 2, 65) == 0
 
 
 def test_code_object_is_gfx950():

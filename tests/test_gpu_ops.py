@@ -737,6 +737,14 @@ def test_round5_entry_points_check_their_arguments():
     assert set(torch.unique(m).tolist()) <= {0.0, float(np.float32(1) / np.float32(0.75))} and 0.70 < float((m != 0).float().mean()) < 0.80
     assert torch.equal(m[7:100], ops.dropout_mask(123, 12, 93, 0.25, "cuda"))            # a function of (seed, absolute index)
     assert L.ait_dropout_mask(1, 0, 10, ctypes.c_float(1.0), vp(o), st) == EINVAL
+    # the fused attention backward: nothing to do for zero sequences; NULL tensors, kv_rows outside 1..64 and p = 1 are refused
+    t = torch.zeros(64 * 1536, device="cuda")
+    f = ctypes.c_float
+    core = lambda n, kv, p, df: L.ait_mha_core_bwd(df, vp(t), vp(t), vp(t), vp(t), vp(t), 1536, vp(t), 1536, vp(t), 1536, vp(t), n, kv,
+                                                   f(0.125), f(p), 1, vp(t), 1536, vp(t), 1536, vp(t), 1536, vp(t), st)
+    assert core(0, 64, 0.0, None) == OK
+    assert core(1, 64, 0.0, None) == EINVAL and core(1, 0, 0.0, vp(t)) == EINVAL and core(1, 65, 0.0, vp(t)) == EINVAL
+    assert core(1, 64, 1.0, vp(t)) == EINVAL and core(-1, 64, 0.0, vp(t)) == EINVAL
 
 
 def test_frozen_bn_residual_relu_on_bf16_tensors_matches_float_arithmetic():

@@ -408,24 +408,51 @@ __global__ __launch_bounds__(256) void to_bf16_t_kernel(const float* __restrict_
 }
 
 // out[c] += sum_r x[r, c] over a bf16 [rows, cols] matrix (the bias gradient of a layer whose output gradient is stored
-// in bf16): a thread per column quad (8-B loads), a block a band of 128 rows, one f32 atomic per column and block
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const unsigned short* __restrict__ x, long long rows, int cols,
-                                                          long long ld, float* __restrict__ out) {
-  const long long r0 = (long long)blockIdx.x * 128;
-  const long long r1 = r0 + 128 < rows ? r0 + 128 : rows;
-  for (int c4 = threadIdx.x + blockIdx.y * blockDim.x; c4 < cols / 4; c4 += blockDim.x * gridDim.y) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const unsigned short* __restrict__ p = x + r0 * ld + 4 * c4;
+// in bf16).  A 1024-thread block sums a band of rows: thread (tx, ty) takes the V columns of group tx (V = 8: 16-B loads,
+// else 4: 8-B) on rows ty, ty + RY, ... of the band; the RY partial rows meet in LDS and row 0 adds the band's sums to `out`
+// with one f32 atomic per column.  Few, tall bands (~512 blocks): the atomics of a column all hit one address, and a
+// thousand of them in a row cost more than the read (0.29 ms for 0.54 GB with 128-row bands).
+template <int V>
+__global__ __launch_bounds__(1024) void colsum_bf16_kernel(const unsigned short* __restrict__ x, long long rows, int cols,
+                                                           long long ld, int band, int G, float* __restrict__ out) {
+  extern __shared__ float part[];      // [RY][G * V]
+  const int RY = blockDim.x / G, tx = threadIdx.x % G, ty = threadIdx.x / G;
+  const int cv = tx + blockIdx.y * G;
+  const long long r0 = (long long)blockIdx.x * band;
+  const long long r1 = r0 + band < rows ? r0 + band : rows;
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; j++) acc[j] = 0.f;
+  if (cv < cols / V) {
+    const unsigned short* __restrict__ p = x + (r0 + ty) * ld + V * cv;
+    const long long step = (long long)RY * ld;
 #pragma unroll 8
-    for (long long r = r0; r < r1; r++, p += ld) {
-      const uint2 v = *reinterpret_cast<const uint2*>(p);
-      acc.x += __uint_as_float(v.x << 16); acc.y += __uint_as_float(v.x & 0xffff0000u);
-      acc.z += __uint_as_float(v.y << 16); acc.w += __uint_as_float(v.y & 0xffff0000u);
+    for (long long r = r0 + ty; r < r1; r += RY, p += step) {
+      unsigned w[V / 2];
+      if constexpr (V == 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+      } else {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        w[0] = v.x; w[1] = v.y;
+      }
+#pragma unroll
+      for (int j = 0; j < V / 2; j++) {
+        acc[2 * j] += __uint_as_float(w[j] << 16);
+        acc[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+      }
     }
-    unsafeAtomicAdd(out + 4 * c4 + 0, acc.x);
-    unsafeAtomicAdd(out + 4 * c4 + 1, acc.y);
-    unsafeAtomicAdd(out + 4 * c4 + 2, acc.z);
-    unsafeAtomicAdd(out + 4 * c4 + 3, acc.w);
+  }
+#pragma unroll
+  for (int j = 0; j < V; j++) part[(ty * G + tx) * V + j] = acc[j];
+  __syncthreads();
+  // G * V columns of the block, summed over the RY partial rows by the first G * V threads
+  for (int c = threadIdx.x; c < G * V; c += blockDim.x) {
+    const int col = blockIdx.y * G * V + c;
+    if (col >= cols) continue;
+    float s = 0.f;
+    for (int y = 0; y < RY; y++) s += part[y * G * V + c];
+    unsafeAtomicAdd(out + col, s);
   }
 }
 
@@ -585,10 +612,26 @@ AIT_API int ait_colsum_bf16(const void* x, long long rows, int cols, long long l
   if (rows < 0 || cols < 0 || (cols & 3) || ld < cols || (ld & 3)) return AIT_EINVAL;
   if (rows == 0 || cols == 0) return AIT_OK;
   if (!x || !out || (reinterpret_cast<uintptr_t>(x) & 7)) return AIT_EINVAL;
-  const int threads = cols / 4 >= 256 ? 256 : (cols / 4 > 64 ? 128 : 64);
-  const unsigned gy = (unsigned)((cols / 4 + threads - 1) / threads);
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)((rows + 127) / 128), gy), dim3(threads), 0, ait_stream(stream),
-                     static_cast<const unsigned short*>(x), rows, cols, ld, out);
+  const bool wide = (cols % 8) == 0 && (ld % 8) == 0 && !(reinterpret_cast<uintptr_t>(x) & 15);
+  const int V = wide ? 8 : 4, groups = cols / V;
+  int G = 1;
+  while (G < groups && G < 256) G *= 2;                 // column groups per block: a power of two <= 256 (divides 1024)
+  const unsigned gy = (unsigned)((groups + G - 1) / G);
+  const int RY = 1024 / G;
+  long long want_blocks = 512 / gy > 0 ? 512 / gy : 1;
+  long long band = (rows + want_blocks - 1) / want_blocks;
+  const long long unit = (long long)RY * 8;             // whole unrolled passes of the block's RY row lanes
+  band = (band + unit - 1) / unit * unit;
+  const long long bx = (rows + band - 1) / band;
+  if (band > 0x7fffffffLL || bx > 0x7fffffffLL) return AIT_EUNSUPPORTED;
+  const dim3 grid((unsigned)bx, gy);
+  const size_t lds = (size_t)1024 * V * sizeof(float);
+  if (wide)
+    hipLaunchKernelGGL(colsum_bf16_kernel<8>, grid, dim3(1024), lds, ait_stream(stream), static_cast<const unsigned short*>(x), rows,
+                       cols, ld, (int)band, G, out);
+  else
+    hipLaunchKernelGGL(colsum_bf16_kernel<4>, grid, dim3(1024), lds, ait_stream(stream), static_cast<const unsigned short*>(x), rows,
+                       cols, ld, (int)band, G, out);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }

@@ -223,26 +223,36 @@ __global__ __launch_bounds__(kThreads) void ln_bwd_kernel(
   }
 }
 
-// out[c] += sum_r x[r*ld + c]: bias gradients (column sums over token rows).  One thread owns a
-// column quad (16-B loads, a row of the block is one coalesced segment), a block a band of rows;
-// one atomic per column per block.
-constexpr int kColsumRows = 128;
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long rows, int cols,
-                                                     long long ld, float* __restrict__ out) {
-  const long long r0 = (long long)blockIdx.x * kColsumRows;
-  const long long r1 = r0 + kColsumRows < rows ? r0 + kColsumRows : rows;
-  for (int c4 = threadIdx.x + blockIdx.y * blockDim.x; c4 < cols / 4; c4 += blockDim.x * gridDim.y) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* __restrict__ p = x + r0 * ld + 4 * c4;
+// out[c] += sum_r x[r*ld + c]: bias gradients (column sums over token rows).  A 1024-thread block sums a band of rows:
+// thread (tx, ty) takes column quad tx (16-B loads) on rows ty, ty + RY, ... of the band, the RY partial rows meet in LDS and
+// the block adds its sums to `out` with one atomic per column.  Few, tall bands (~512 blocks): a column's atomics all hit
+// ONE address, and a thousand of them in a row cost more than the read (round 5: the 128-row bands of the first version ran
+// at 1.8-3.5 TB/s, this form at 5.7-5.9; csrc/gemm_bf16s.hip's colsum_bf16_kernel is the same kernel on bf16).
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, long long rows, int cols, long long ld, int band,
+                                                      int G, float* __restrict__ out) {
+  extern __shared__ float colsum_part[];      // [RY][G * 4]
+  const int RY = blockDim.x / G, tx = threadIdx.x % G, ty = threadIdx.x / G;
+  const int c4 = tx + blockIdx.y * G;
+  const long long r0 = (long long)blockIdx.x * band;
+  const long long r1 = r0 + band < rows ? r0 + band : rows;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < cols / 4) {
+    const float* __restrict__ p = x + (r0 + ty) * ld + 4 * c4;
+    const long long step = (long long)RY * ld;
 #pragma unroll 8
-    for (long long r = r0; r < r1; r++, p += ld) {
+    for (long long r = r0 + ty; r < r1; r += RY, p += step) {
       const float4 v = *reinterpret_cast<const float4*>(p);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    unsafeAtomicAdd(out + 4 * c4 + 0, acc.x);
-    unsafeAtomicAdd(out + 4 * c4 + 1, acc.y);
-    unsafeAtomicAdd(out + 4 * c4 + 2, acc.z);
-    unsafeAtomicAdd(out + 4 * c4 + 3, acc.w);
+  }
+  *reinterpret_cast<float4*>(colsum_part + (ty * G + tx) * 4) = acc;
+  __syncthreads();
+  for (int c = threadIdx.x; c < G * 4; c += blockDim.x) {
+    const int col = blockIdx.y * G * 4 + c;
+    if (col >= cols) continue;
+    float s_ = 0.f;
+    for (int y = 0; y < RY; y++) s_ += colsum_part[y * G * 4 + c];
+    unsafeAtomicAdd(out + col, s_);
   }
 }
 
@@ -617,7 +627,9 @@ int ait_ln_bwd_ex(const float* dy, const float* a, const float* pos, const float
   RowMap m{seq_len, src_rows_per_seq, rep, dy_rows_per_seq, seq_len};
   // fewer, fatter blocks: each block issues 2*512 atomics for the affine gradients
   long long b = (rows + 63) / 64;
-  unsigned grid = (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+  // (1024 blocks are resident at a time: between one and two rounds of 64-row blocks the second round is a partial one --
+  // 1200 blocks at cfg2's 76800 rows ran 13 % slower than 1024 blocks striding over the same rows, 0.184 against 0.160 ms)
+  unsigned grid = (unsigned)(b < 1 ? 1 : b <= 1024 ? b : b < 2048 ? 1024 : 2048);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(kThreads), 0, ait_stream(stream), dy, a, pos,
                      residual, gamma, mean, rstd, rows, m, p_drop, seed, da, dres, dgamma, dbeta, dcolsum,
                      static_cast<unsigned short*>(da16));
@@ -638,10 +650,19 @@ AIT_API int ait_colsum_f32(const float* x, long long rows, int cols, long long l
   if (rows < 0 || cols < 0 || (cols & 3) || ld < cols || (ld & 3)) return AIT_EINVAL;
   if (rows == 0 || cols == 0) return AIT_OK;
   if (!x || !out || (reinterpret_cast<uintptr_t>(x) & 15)) return AIT_EINVAL;
-  const int threads = cols / 4 >= 256 ? 256 : (cols / 4 > 64 ? 128 : 64);
-  const unsigned gy = (unsigned)((cols / 4 + threads - 1) / threads);
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + kColsumRows - 1) / kColsumRows), gy), dim3(threads), 0,
-                     ait_stream(stream), x, rows, cols, ld, out);
+  const int groups = cols / 4;
+  int G = 1;
+  while (G < groups && G < 256) G *= 2;                 // column quads per block: a power of two <= 256 (divides 1024)
+  const unsigned gy = (unsigned)((groups + G - 1) / G);
+  const int RY = 1024 / G;
+  const long long want_blocks = 512 / gy > 0 ? 512 / gy : 1;
+  long long band = (rows + want_blocks - 1) / want_blocks;
+  const long long unit = (long long)RY * 8;             // whole unrolled passes of the block's RY row lanes
+  band = (band + unit - 1) / unit * unit;
+  const long long bx = (rows + band - 1) / band;
+  if (band > 0x7fffffffLL || bx > 0x7fffffffLL) return AIT_EUNSUPPORTED;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)bx, gy), dim3(1024), (size_t)1024 * 4 * sizeof(float), ait_stream(stream), x, rows,
+                     cols, ld, (int)band, G, out);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }

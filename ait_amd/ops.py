@@ -284,6 +284,18 @@ def gemm_bf16s(a16, b16, bias=None, residual=None, gate16=None, relu=False, mask
     return out32, out16
 
 
+def colsum_bf16(x16, out=None):
+    """ait_colsum_bf16: out [cols] f32 += column sums of a bf16 [rows, cols] matrix (row pitch from stride(0))"""
+    assert x16.dtype == torch.bfloat16 and x16.dim() == 2 and x16.stride(1) == 1
+    rows, cols = x16.shape
+    if out is None:
+        out = torch.zeros(cols, dtype=torch.float32, device=x16.device)
+    with torch.cuda.device(x16.device):
+        rc = _lib.lib().ait_colsum_bf16(ctypes.c_void_p(x16.data_ptr()), rows, cols, x16.stride(0), _p(out), _lib.cur_stream(x16.device))
+    _lib.check(rc, "ait_colsum_bf16")
+    return out
+
+
 def gemm_bf16s_tn(dy16, x16, out=None, split_k=None, partials=True):
     """ait_gemm_bf16s_tn: out [Mo, No] f32 (+)= dy16^T @ x16 over the R token rows, bf16 operands [R, Mo] / [R, No]"""
     assert dy16.dtype == torch.bfloat16 and x16.dtype == torch.bfloat16 and dy16.shape[0] == x16.shape[0]

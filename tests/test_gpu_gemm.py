@@ -746,6 +746,27 @@ def test_bf16_storage_gemm_against_float64(M, N, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,pitch", [(1, 4, 4), (130, 12, 12), (1000, 2048, 2048), (76800, 1024, 1024), (5000, 512, 1536),
+                                             (4097, 20, 28)])
+def test_bf16_column_sums_against_float64(rows, cols, pitch):
+    """ait_colsum_bf16 (the bias gradients of the bf16-storage mode): out += column sums of a bf16 matrix, any row count,
+    pitched rows, both load widths (16-byte when columns, pitch and base allow, else 8-byte); ACCUMULATES into out."""
+    from ait_amd import ops
+    torch.manual_seed(rows + cols)
+    buf = torch.randn(rows, pitch, device="cuda").to(torch.bfloat16)
+    x = buf[:, :cols]
+    out = torch.full((cols,), 2.0, device="cuda")
+    ops.colsum_bf16(x, out)
+    want = x.double().sum(0) + 2.0
+    scale = x.double().abs().sum(0) + 2.0
+    assert float(((out.double() - want).abs() / scale).max()) < 2e-6
+    if cols >= 8 and pitch > cols:      # a base that is only 8-byte aligned takes the narrow form
+        y = buf[:, 4:4 + (cols // 8) * 8 - 4] if (cols // 8) * 8 - 4 > 0 and ((cols // 8) * 8 - 4) % 4 == 0 else None
+        if y is not None and y.shape[1] % 4 == 0 and y.shape[1] > 0:
+            assert float(((ops.colsum_bf16(y).double() - y.double().sum(0)).abs() / (y.double().abs().sum(0) + 1e-9)).max()) < 2e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R,Mo,No,sk", [(64, 256, 128, 1), (2048, 512, 2048, 4), (4800, 2048, 512, 5), (76800, 512, 2048, 16)])
 def test_bf16_storage_weight_gradient_product_against_float64(R, Mo, No, sk):
     """ait_gemm_bf16s_tn: dW[Mo, No] += dy^T x over the token rows, bf16 operands row-major with the reduction index

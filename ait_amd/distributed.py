@@ -52,7 +52,9 @@ def collective_description(ddp):
     protocol the environment pins, if any"""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return "none"
-    desc = "DDP gradient all-reduce (sum / world), backend %s" % dist.get_backend()
+    kind = getattr(ddp, "_ait_exchange", "allreduce")
+    desc = ("DDP gradient all-reduce (sum / world)" if kind == "allreduce" else
+            "DDP buckets exchanged by reduce-scatter + all-gather (sum of 1/N shards, averaged, gathered)") + ", backend %s" % dist.get_backend()
     if dist.get_backend() == "nccl":
         desc += " = RCCL over xGMI"
     try:
@@ -66,6 +68,60 @@ def collective_description(ddp):
     return desc
 
 
+# ---- the gradient exchange of a bucket ----------------------------------------------------------------------------------
+# "allreduce" (default): DDP's own hook -- RCCL picks the algorithm.
+# "rs_ag" (opt-in: AIT_DDP_EXCHANGE=rs_ag or bench.py --exchange rs_ag): reduce-scatter + all-gather, the exchange SURVEY 8e
+# sketches for a fully connected xGMI node -- every rank sums ONE 1/N shard of the bucket (N - 1 direct peer transfers per
+# rank, no ring), averages it, and the shards are gathered back.  The same sum as the all-reduce up to the order of the
+# additions.  NEVER RUN ON RCCL HERE (no multi-GPU box in this round): its tensor logic -- padding to a multiple of N, the
+# average, the copy back -- is held against the default hook by a two-rank gloo test with the two collectives emulated
+# (tests/test_distributed_cpu.py); the two RCCL calls themselves are the untested lines.
+EXCHANGES = ("allreduce", "rs_ag")
+
+
+def _rs_future(shard, flat, group):
+    return dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group, async_op=True).get_future()
+
+
+def _ag_future(flat, shard, group):
+    return dist.all_gather_into_tensor(flat, shard, group=group, async_op=True).get_future()
+
+
+def make_exchange_hook(kind="allreduce", reduce_scatter=_rs_future, all_gather=_ag_future):
+    """a DDP comm hook (state = the process group or None) for the named exchange; the two collectives of "rs_ag" are
+    injectable (callables returning futures) so that the hook's own logic can be tested on a backend without them"""
+    if kind not in EXCHANGES:
+        raise ValueError("exchange must be one of %s" % (EXCHANGES,))
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    if kind == "allreduce":
+        return default_hooks.allreduce_hook
+
+    def hook(state, bucket):
+        group = state if state is not None else dist.group.WORLD
+        world = dist.get_world_size(group)
+        buf = bucket.buffer()
+        n = buf.numel()
+        pad = (-n) % world
+        flat = buf if pad == 0 else torch.cat([buf, buf.new_zeros(pad)])
+        shard = torch.empty(flat.numel() // world, dtype=flat.dtype, device=flat.device)
+
+        def gather(_):
+            shard.div_(world)
+            all_gather(flat, shard, group).wait()
+            if pad:
+                buf.copy_(flat[:n])
+            return buf
+        return reduce_scatter(shard, flat, group).then(gather)
+    return hook
+
+
+def exchange_from_env():
+    kind = os.environ.get("AIT_DDP_EXCHANGE", "allreduce")
+    if kind not in EXCHANGES:
+        raise ValueError("AIT_DDP_EXCHANGE must be one of %s" % (EXCHANGES,))
+    return kind
+
+
 class BucketClock:
     """When does the reducer hand its buckets to the all-reduce?  A comm hook (the default all-reduce, plus two notes per
     bucket) over a DDP-wrapped model: `start()` before backward(), `stop()` behind it, then `summary()` says when the
@@ -76,9 +132,10 @@ class BucketClock:
         of the backward this shows how much of the backward's device time was still ahead when the bucket could go
         (CUDA tensors only; needs a synchronize before summary(), which bench.py's timed region ends with)."""
 
-    def __init__(self, ddp):
+    def __init__(self, ddp, exchange="allreduce", inner=None):
         import time
-        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+        inner = inner if inner is not None else make_exchange_hook(exchange)
+        self.exchange = exchange
         self._time, self.t0, self.stamps, self.events = time, None, [], []
         self.ev0 = self.ev1 = None
         self._cuda = next(ddp.parameters()).is_cuda
@@ -90,7 +147,7 @@ class BucketClock:
                     ev = torch.cuda.Event(enable_timing=True)
                     ev.record()
                     self.events.append(ev)
-            return default_hooks.allreduce_hook(None, bucket)
+            return inner(None, bucket)
         ddp.register_comm_hook(None, hook)
 
     def start(self):

@@ -263,6 +263,8 @@ def main():
     ap.add_argument("--variant", choices=["voc", "coco"], default=None, help="override the configuration's detector variant")
     ap.add_argument("--bs", type=int, default=None, help="pairs per GPU (override; cfg2: 4, cfg3-5: 8)")
     ap.add_argument("--proposals", type=int, default=None)
+    ap.add_argument("--exchange", choices=["allreduce", "rs_ag"], default=None,
+                    help="N > 1: the gradient buckets' exchange (default: AIT_DDP_EXCHANGE or DDP's all-reduce)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ab", action="store_true", help="skip the f32_native A/B steps behind the timed region")
     ap.add_argument("--gemm-table", default=None, metavar="PATH",
@@ -304,7 +306,12 @@ def main():
     np.random.seed(3 + rank)                     # reference RNG_SEED, one stream per rank
     batch = synth_batch(args.bs, 1000 + rank, device, max_gt=50 if args.variant == "coco" else 20)
 
-    clock = D.BucketClock(ddp) if world > 1 else None      # (N > 1: when the gradient buckets reach the all-reduce)
+    # (N > 1: the buckets' exchange -- DDP's all-reduce, or with --exchange rs_ag / AIT_DDP_EXCHANGE=rs_ag reduce-scatter +
+    # all-gather -- under a clock that notes when the reducer hands each bucket over)
+    exchange = args.exchange or D.exchange_from_env()
+    clock = D.BucketClock(ddp, exchange) if world > 1 else None
+    if world > 1:
+        ddp._ait_exchange = exchange
 
     def step():
         opt.zero_grad(set_to_none=True)

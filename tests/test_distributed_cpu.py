@@ -80,6 +80,73 @@ def test_two_rank_gloo_data_parallel(tmp_path):
         assert "rank %d ok" % r in o
 
 
+RS_AG_WORKER = textwrap.dedent("""
+    import os, sys, torch, torch.nn as nn, torch.distributed as dist
+    sys.path.insert(0, %r)
+    from ait_amd import distributed as D
+    rank, local_rank, world = D.init()
+    # gloo has neither reduce_scatter_tensor nor all_gather_into_tensor: the hook's two collectives are emulated with what
+    # it has (same results); everything else -- padding to a multiple of the world size, the average, the copy back into
+    # the bucket, the future chain DDP waits on -- is the product's code
+    def rs(shard, flat, group):
+        tmp = flat.clone()
+        fut = dist.all_reduce(tmp, group=group, async_op=True).get_future()
+        return fut.then(lambda f: shard.copy_(tmp.view(world, -1)[rank]))
+    def ag(flat, shard, group):
+        parts = [torch.empty_like(shard) for _ in range(world)]
+        fut = dist.all_gather(parts, shard, group=group, async_op=True).get_future()
+        return fut.then(lambda f: flat.copy_(torch.cat(parts)))
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(7, 8); self.b = nn.Linear(8, 3)      # 56 + 8 + 24 + 3 = 91 values: an odd bucket, padded to 92
+        def forward(self, x):
+            return self.b(torch.tanh(self.a(x)))
+    grads = {}
+    for kind in ("allreduce", "rs_ag"):
+        torch.manual_seed(0)
+        net = Net()
+        ddp = D.wrap(net, local_rank, bucket_mb=1)
+        clock = D.BucketClock(ddp, kind, inner=D.make_exchange_hook(kind, rs, ag))
+        torch.manual_seed(100 + rank)
+        x = torch.randn(5, 7)
+        for _ in range(3):
+            net.zero_grad()
+            clock.start()
+            ddp(x).pow(2).sum().backward()
+        assert clock.summary()["buckets"] >= 1 and clock.exchange == kind
+        grads[kind] = torch.cat([p.grad.flatten() for p in net.parameters()])
+    assert torch.allclose(grads["rs_ag"], grads["allreduce"], rtol=1e-6, atol=1e-7), (grads["rs_ag"] - grads["allreduce"]).abs().max()
+    assert float(grads["rs_ag"].abs().max()) > 0
+    try:
+        D.make_exchange_hook("ring")
+        raise SystemExit("an unknown exchange was accepted")
+    except ValueError:
+        pass
+    D.barrier()
+    print("rank", rank, "ok")
+""")
+
+
+def test_reduce_scatter_all_gather_exchange_equals_the_all_reduce(tmp_path):
+    """the opt-in rs_ag bucket exchange (ait_amd.distributed.make_exchange_hook): same gradients as DDP's all-reduce hook on
+    two gloo ranks, with a bucket whose size is not a multiple of the world size (the two collectives emulated: see the worker)"""
+    script = tmp_path / "worker_rs_ag.py"
+    script.write_text(RS_AG_WORKER % ROOT)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
+                   AIT_DIST_BACKEND="gloo", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
+        assert "rank %d ok" % r in o
+
+
 def test_shard_slice_covers_everything():
     from ait_amd.distributed import shard_slice
     for n in (0, 1, 7, 64):

@@ -17,6 +17,7 @@ _ll, _ull = ctypes.c_longlong, ctypes.c_ulonglong
 # name -> (restype, argtypes); mirrors include/ait_hip.h one to one
 SIGNATURES = {
     "ait_abi_version": (_i, []),
+    "ait_lab_build": (_i, []),
     "ait_strerror": (ctypes.c_char_p, [_i]),
     "ait_gemm_workspace_bytes": (_sz, []),
     "ait_gemm_workspace_init": (_i, [_vp, _sz, _vp]),
@@ -71,8 +72,6 @@ SIGNATURES = {
     "ait_conv_bwd_weight_f32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp]),
     "ait_gemm_bf16": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
                            _i, ctypes.c_longlong, _vp, _vp]),
-    "ait_gemm_bf16x3": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,
-                             _i, ctypes.c_longlong, _vp, _vp]),
     "ait_mha_block_workspace_bytes": (_sz, [_i, _i]),
     "ait_mha_block_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ait_ffn_workspace_bytes": (_sz, [_ll]),

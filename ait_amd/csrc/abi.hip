@@ -5,7 +5,9 @@
 
 
 
-AIT_API int ait_abi_version(void) { return 6; }
+AIT_API int ait_abi_version(void) { return 7; }
+// 0 for the shipped library; 1 for a lab variant built with experiment knobs (csrc/lab_knobs.h)
+AIT_API int ait_lab_build(void) { return ait_lab::kLabBuild; }
 
 AIT_API const char* ait_strerror(int code) {
   switch (code) {

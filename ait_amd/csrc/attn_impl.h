@@ -41,11 +41,7 @@ using ait_gemm::f32x16;
 using ait_gemm::Planes;
 
 constexpr int T = 64, D = 64, PITCH = 65;
-#ifdef AIT_LAB_F32_PAIRS      // lab knob: the column-paired right-operand loads (breg_load_pairs) for f32 q / k / v as well
-constexpr bool kF32Pairs = true;
-#else
-constexpr bool kF32Pairs = false;
-#endif
+constexpr bool kF32Pairs = ait_lab::Knobs::f32_pairs;      // (lab: the column-paired right-operand loads for f32 q / k / v as well)
 constexpr int kPanel = T * PITCH;          // floats per LDS panel
 constexpr int kWaves = 4;
 constexpr int kThreads = kWaves * 64;
@@ -244,11 +240,7 @@ __device__ __forceinline__ float frag_at(const Frag& f, int j) {
 // product is EXACT in three MFMAs (one, if both operands are bf16) instead of six.
 template <bool SPLIT, int PA_ = 3, int PB_ = 3, class FA, class FB>
 __device__ __forceinline__ void mm_split(FA fa, FB fb, f32x16 (&acc)[2][2]) {
-#ifdef AIT_LAB_NO_BF16_PLANES      // lab knob: six terms whatever the operands are, for A/Bs
-  constexpr int PA = 3, PB = 3;
-#else
-  constexpr int PA = PA_, PB = PB_;
-#endif
+  constexpr int PA = ait_lab::Knobs::no_bf16_planes ? 3 : PA_, PB = ait_lab::Knobs::no_bf16_planes ? 3 : PB_;
 #pragma unroll
   for (int kb = 0; kb < 4; kb++) {
     // (fence per k-block: the loop must be fully unrolled -- static register indices -- but the scheduler must not

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/ait_hip.h"
+#include "lab_knobs.h"
 
 #define AIT_WAVE 64
 #define AIT_API extern "C" __attribute__((visibility("default")))

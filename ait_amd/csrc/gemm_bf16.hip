@@ -24,19 +24,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;
 constexpr int ROWB = BK * 2;                // bytes per LDS row
 
-// SPLIT = false: plain bf16 operands (cfg-5 arithmetic).
-// SPLIT = true : "bf16x3" -- every fp32 operand x is staged as hi = bf16(x) and lo = bf16(x - hi)
-//   and each product is formed as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the bf16 matrix cores with
-//   fp32 accumulation: the dropped lo*lo term and the residuals are <= ~3*2^-18 relative per
-//   product, i.e. fp32-class accuracy at 3/16 of the fp32 MFMA cost.  EXPERIMENTAL, opt-in.
-template <int BM_, int BN_, int WM_, int WN_, bool SPLIT_>
+template <int BM_, int BN_, int WM_, int WN_>
 struct BCfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
-  static constexpr bool SPLIT = SPLIT_;
   static constexpr int NT = 64 * WM * WN;
   static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static constexpr int PARTS = SPLIT ? 2 : 1;
-  static constexpr size_t LDS_BYTES = (size_t)2 * PARTS * (BM + BN) * ROWB;
+  static constexpr size_t LDS_BYTES = (size_t)2 * (BM + BN) * ROWB;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset of a 16-B chunk
@@ -45,7 +38,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset of
 
 // ---- staging: global fp32 -> registers (raw) -> bf16 -> LDS -----------------------------------
 // KCONTIG: item = (row, chunk of 8 k): 2 float4.   !KCONTIG: item = (4 rows, 4 k): 4 float4.
-template <bool KCONTIG, int ROWS, int NT, bool SPLIT>
+template <bool KCONTIG, int ROWS, int NT>
 struct Stage {
   static constexpr int ITEMS = KCONTIG ? ROWS * 4 : (ROWS / 4) * 8;
   static constexpr int PER = (ITEMS + NT - 1) / NT;
@@ -89,10 +82,7 @@ struct Stage {
     }
   }
 
-  static __device__ __forceinline__ __bf16 lo_part(float x, __bf16 hi) { return (__bf16)(x - (float)hi); }
-
-  // hi image at `lds`, lo image (SPLIT only) `lo_off` bytes further
-  __device__ __forceinline__ void store(char* __restrict__ lds, int lo_off) const {
+  __device__ __forceinline__ void store(char* __restrict__ lds) const {
 #pragma unroll
     for (int i = 0; i < PER; i++) {
       const int e = threadIdx.x + i * NT;
@@ -100,14 +90,10 @@ struct Stage {
       if (KCONTIG) {
         const int row = e >> 2, c = e & 3;
         const float f[8] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w};
-        bf16x8 o, l;
+        bf16x8 o;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-          o[q] = (__bf16)f[q];
-          if (SPLIT) l[q] = lo_part(f[q], o[q]);
-        }
+        for (int q = 0; q < 8; q++) o[q] = (__bf16)f[q];
         *reinterpret_cast<bf16x8*>(lds + lds_off(row, c)) = o;
-        if (SPLIT) *reinterpret_cast<bf16x8*>(lds + lo_off + lds_off(row, c)) = l;
       } else {
         // K-outer operand: "k-pair-major" image  word[kp][row] = (bf16 k = 2kp, bf16 k = 2kp + 1).
         // The item's 4 rows x 4 k become two rows of four consecutive words: two conflict-free
@@ -117,20 +103,15 @@ struct Stage {
         const float* f = reinterpret_cast<const float*>(&v[i][0]);   // f[q*4 + j] = (k = c8*4+q, row rq*4+j)
 #pragma unroll
         for (int h = 0; h < 2; h++) {                                 // kp = c8*2 + h  <-  k = c8*4 + 2h, +1
-          bf16x8 o, l;
+          bf16x8 o;
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             const float x0 = f[(2 * h) * 4 + j], x1 = f[(2 * h + 1) * 4 + j];
             o[2 * j] = (__bf16)x0;
             o[2 * j + 1] = (__bf16)x1;
-            if (SPLIT) {
-              l[2 * j] = lo_part(x0, o[2 * j]);
-              l[2 * j + 1] = lo_part(x1, o[2 * j + 1]);
-            }
           }
           const int off = ((c8 * 2 + h) * ROWS + rq * 4) * 4;
           *reinterpret_cast<bf16x8*>(lds + off) = o;
-          if (SPLIT) *reinterpret_cast<bf16x8*>(lds + lo_off + off) = l;
         }
       }
     }
@@ -150,11 +131,10 @@ __device__ __forceinline__ bf16x8 fetch8(const char* __restrict__ img, int row, 
 template <class C, bool AK, bool BKC, int EPI>
 __global__ __launch_bounds__(C::NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
   constexpr int BM = C::BM, BN = C::BN, TM = C::TM, TN = C::TN, WN = C::WN;
-  constexpr int A_IMG = BM * ROWB, B_IMG = BN * ROWB;            // bytes of one (hi or lo) image
-  constexpr int A_BUF = A_IMG * C::PARTS, B_BUF = B_IMG * C::PARTS;
+  constexpr int A_BUF = BM * ROWB, B_BUF = BN * ROWB;            // bytes of one operand image
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* As = lds;                          // [2 buffers][hi | lo][BM][64 B]
-  char* Bs = lds + 2 * A_BUF;              // [2 buffers][hi | lo][BN][64 B]
+  char* As = lds;                          // [2 buffers][BM][64 B]
+  char* Bs = lds + 2 * A_BUF;              // [2 buffers][BN][64 B]
 
   const int tiles_n = (g.N + BN - 1) / BN;
   const int tiles_m = (g.M + BM - 1) / BM;
@@ -195,12 +175,12 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-  Stage<AK, BM, C::NT, C::SPLIT> sa;
-  Stage<BKC, BN, C::NT, C::SPLIT> sb;
+  Stage<AK, BM, C::NT> sa;
+  Stage<BKC, BN, C::NT> sb;
   sa.load(g.A, g.lda, m0, g.M, kbeg, kend);
   sb.load(g.B, g.ldb, n0, g.N, kbeg, kend);
-  sa.store(As, A_IMG);
-  sb.store(Bs, B_IMG);
+  sa.store(As);
+  sb.store(Bs);
   __syncthreads();
 
   int cur = 0;
@@ -214,31 +194,20 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_bf16_kernel(const GemmArgs g) {
     const char* bs = Bs + cur * B_BUF;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
-      bf16x8 av[TM], bv[TN], al[TM], bl[TN];
+      bf16x8 av[TM], bv[TN];
 #pragma unroll
-      for (int a = 0; a < TM; a++) {
-        av[a] = fetch8<AK, BM>(as, wm + a * 32 + li, ks, lk);
-        if (C::SPLIT) al[a] = fetch8<AK, BM>(as + A_IMG, wm + a * 32 + li, ks, lk);
-      }
+      for (int a = 0; a < TM; a++) av[a] = fetch8<AK, BM>(as, wm + a * 32 + li, ks, lk);
 #pragma unroll
-      for (int b = 0; b < TN; b++) {
-        bv[b] = fetch8<BKC, BN>(bs, wn + b * 32 + li, ks, lk);
-        if (C::SPLIT) bl[b] = fetch8<BKC, BN>(bs + B_IMG, wn + b * 32 + li, ks, lk);
-      }
+      for (int b = 0; b < TN; b++) bv[b] = fetch8<BKC, BN>(bs, wn + b * 32 + li, ks, lk);
 #pragma unroll
       for (int a = 0; a < TM; a++)
 #pragma unroll
-        for (int b = 0; b < TN; b++) {
-          if (C::SPLIT) {   // small cross terms first, the dominant hi*hi term last
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bv[b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bl[b], acc[a][b], 0, 0, 0);
-          }
+        for (int b = 0; b < TN; b++)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv[b], acc[a][b], 0, 0, 0);
-        }
     }
     if (more) {
-      sa.store(As + (cur ^ 1) * A_BUF, A_IMG);
-      sb.store(Bs + (cur ^ 1) * B_BUF, B_IMG);
+      sa.store(As + (cur ^ 1) * A_BUF);
+      sb.store(Bs + (cur ^ 1) * B_BUF);
     }
     __syncthreads();
     cur ^= 1;
@@ -285,10 +254,9 @@ int dispatch_bf16(const GemmArgs& g, bool ak, bool bk, hipStream_t s) {
   return dispatch_layout_bf16<C, EPI_STORE>(g, ak, bk, s);
 }
 
-using Bf16Tile = BCfg<256, 128, 4, 2, false>;
-using SplitTile = BCfg<128, 128, 2, 2, true>;     // hi+lo images: 64 KB of LDS per workgroup
+using Bf16Tile = BCfg<256, 128, 4, 2>;
 
-int run_gemm(bool split3, int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
+int run_gemm(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
              int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
              const float* residual, int flags, int split_k, int c_colblk, long long c_batch_stride,
              const ait_launch_ctx* ctx, void* stream) {
@@ -299,7 +267,6 @@ int run_gemm(bool split3, int trans_a, int trans_b, int M, int N, int K, float a
   if (rc != AIT_OK) return rc;
   hipStream_t s = ait_stream(stream);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K, s, M, N, K, trans_a, trans_b, g.splits);
-  if (split3) return dispatch_bf16<SplitTile>(g, !trans_a, trans_b != 0, s);
   return dispatch_bf16<Bf16Tile>(g, !trans_a, trans_b != 0, s);
 }
 
@@ -309,14 +276,6 @@ AIT_API int ait_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, float a
                           const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                           const float* bias, const float* residual, int flags, int split_k,
                           int c_colblk, long long c_batch_stride, const ait_launch_ctx* ctx, void* stream) {
-  return run_gemm(false, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
-                  flags, split_k, c_colblk, c_batch_stride, ctx, stream);
-}
-
-AIT_API int ait_gemm_bf16x3(int trans_a, int trans_b, int M, int N, int K, float alpha,
-                            const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                            const float* bias, const float* residual, int flags, int split_k,
-                            int c_colblk, long long c_batch_stride, const ait_launch_ctx* ctx, void* stream) {
-  return run_gemm(true, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
+  return run_gemm(trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, C, ldc, bias, residual,
                   flags, split_k, c_colblk, c_batch_stride, ctx, stream);
 }

@@ -532,12 +532,7 @@ int launch_tn(const TnArgs& g, hipStream_t s) {
 
 }  // namespace
 
-// lab knob (scripts/build_variant.py): -DAIT_LAB_BF16S_SMALL_ONLY keeps every product on the 256 x 128 x 32 tile
-#ifndef AIT_LAB_BF16S_SMALL_ONLY
-constexpr bool kUseBig = true;
-#else
-constexpr bool kUseBig = false;
-#endif
+constexpr bool kUseBig = !ait_lab::Knobs::bf16s_small_only;
 
 AIT_API int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, float* C32,
                            long long ldc32, void* C16, long long ldc16, const float* bias, const float* residual,
@@ -567,10 +562,7 @@ AIT_API int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, co
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K, s, M, N, K, 0, 1, 1);
   // long reductions on the 256 x 256 x 64 tile (at least a round of them), the 512-deep products on the 256 x 128 x 32 one
   const long long big_tiles = (long long)((M + Big::BM - 1) / Big::BM) * (N / Big::BN);
-#ifndef AIT_LAB_BF16S_BIG_MINK
-#define AIT_LAB_BF16S_BIG_MINK 512       // lab knob: the shortest reduction the 256 x 256 x 64 tile takes
-#endif
-  if (kUseBig && K >= AIT_LAB_BF16S_BIG_MINK && (K % Big::BK) == 0 && (N % Big::BN) == 0 && big_tiles >= 192)
+  if (kUseBig && K >= ait_lab::Knobs::bf16s_big_min_k && (K % Big::BK) == 0 && (N % Big::BN) == 0 && big_tiles >= 192)
     return launch_epi<Big>(g, gate, s);
   return launch_epi<Small>(g, gate, s);
 }
@@ -594,11 +586,8 @@ AIT_API int ait_gemm_bf16s_tn(int Mo, int No, int R, const void* A, long long ld
   // (in range order: reproducible); without it they are added to C with f32 atomics -- a third of the product's time at 16
   // ranges (profiles/r05_bf16_storage_ffn.txt)
   const size_t need = (size_t)split_k * Mo * No * sizeof(float);
-#ifndef AIT_LAB_TN_ATOMICS      // lab knob: always the atomic form
-  const bool use_partials = split_k > 1 && partials && partials_bytes >= need && !(reinterpret_cast<uintptr_t>(partials) & 15);
-#else
-  const bool use_partials = false && need;
-#endif
+  const bool use_partials = !ait_lab::Knobs::tn_atomics && split_k > 1 && partials && partials_bytes >= need &&
+                            !(reinterpret_cast<uintptr_t>(partials) & 15);
   g.partials = use_partials ? static_cast<float*>(partials) : nullptr;
   hipStream_t s = ait_stream(stream);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * Mo * No * R, s, Mo, No, R, 1, 0, split_k);

@@ -1785,11 +1785,7 @@ int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int 
     // (the 0.62 holds for tiles of which a CU holds two or more: the lone workgroup of an under-filled round has the
     // CU to itself.  A tile that fills the CU alone -- the 256 x 256 ones, > 80 KB of LDS -- gains nothing from idle
     // neighbours: its last round costs a whole tile however few workgroups are in it)
-#ifndef AIT_LAB_OLD_LAST_ROUND
-    const double last_round = (rem * 2 <= wfull && C::LDS <= 80 * 1024) ? 0.62 : 1.0;
-#else
-    const double last_round = (rem * 2 <= wfull) ? 0.62 : 1.0;
-#endif
+    const double last_round = (rem * 2 <= wfull && (ait_lab::Knobs::old_last_round || C::LDS <= 80 * 1024)) ? 0.62 : 1.0;
     const int item_slabs = (g.splits > 1 ? g.k_per_split : g.K) / 16;
     if (EPI == EPI_ATOMIC) {
       // split-K launches (weight gradients): a piece of an item just ADDS its partial tile like a whole item does --
@@ -1800,10 +1796,8 @@ int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int 
         w = wfull;
       }
     }
-#ifndef AIT_LAB_SK_PAYS
-#define AIT_LAB_SK_PAYS 12.0      // lab knob: slab-times a stream-K cut of the last round must save
-#endif
-    const bool sk_pays = item_slabs * (last_round - (double)rem / wfull) > AIT_LAB_SK_PAYS;
+    // (12 slab-times: what a stream-K cut of the last round must save to pay for its hand-off)
+    const bool sk_pays = item_slabs * (last_round - (double)rem / wfull) > ait_lab::Knobs::sk_pays;
     if (ws.p) {
       if (ws.bytes < kCtlBytes) return AIT_EWORKSPACE;
       // ticket counters for the dynamic hand-out of whole tiles (every launch), partial tiles + flags when this

@@ -37,10 +37,7 @@ bool ait_gemm_p3b_takes(int M, int N, int K, const ait_launch_ctx* ctx) {
   if (ctx && (ctx->flags & (AIT_CTX_NATIVE_F32 | AIT_CTX_BF16))) return false;
   if (!ctx || !ctx->sched_ws) return false;         // (the 256 x 256 tile list needs the stream-K cut of its last round)
   const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
-#ifndef AIT_LAB_P3_MIN_TILES
-#define AIT_LAB_P3_MIN_TILES 128      // lab knob
-#endif
-  return M >= 512 && N >= 256 && K >= 128 && (K % 16) == 0 && tiles >= AIT_LAB_P3_MIN_TILES;
+  return M >= 512 && N >= 256 && K >= 128 && (K % 16) == 0 && tiles >= ait_lab::Knobs::p3_min_tiles;
 }
 
 int ait_gemm_f32_p3b(int M, int N, int K, float alpha, const float* A, int lda, const void* B_p3, long long ldb_values,

@@ -35,7 +35,6 @@ struct CoreArgs {
   int out_rows;
   int q_rep;       // sequence n takes its queries and its residual from sequence n / q_rep of q / residual
   float *P, *O, *u, *gate, *s, *f, *y, *mean, *rstd;
-  unsigned long long* prof;
 };
 
 // raw barrier: __syncthreads() is fence + barrier, and the fence drains vmcnt(0) -- the P / O / u / f stores still in
@@ -60,12 +59,6 @@ __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
 }
 
-#ifdef AIT_MHA_PROF
-#define STAMP(i) if (c.prof && tid == 0) { const unsigned long long t_ = clock64(); atomicAdd(c.prof + (i), t_ - t_last); t_last = t_; }
-#else
-#define STAMP(i)
-#endif
-
 // IN16: q / k / v are bf16 tensors behind the float pointers (pitches in elements either way)
 template <bool IN16>
 __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const CoreArgs c) {
@@ -87,9 +80,6 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   const int n = blockIdx.x;
   const int nq = c.q_rep > 1 ? n / c.q_rep : n;      // (inference: the decoder's query side is one sequence per PAIR)
   const long long unit = (long long)n * kHeads + h;
-#ifdef AIT_MHA_PROF
-  unsigned long long t_last = clock64();
-#endif
   // ---- phase A: the attention tile of head h (attn.hip) -----------------------------------------------------
   OpRegs op;
   if constexpr (IN16) {
@@ -110,9 +100,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   __builtin_amdgcn_sched_barrier(0);
   f32x16 acc[2][2];
   zero(acc);
-  STAMP(0)
   mm_areg_bldsT<true, IN16 ? 1 : 3, IN16 ? 1 : 3>(op, s0, acc, lane);       // S = Q K^T
-  STAMP(1)
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (IN16)      // (column-paired: O_h's columns below are acc_col_of<IN16>)
     breg_load_pairs(op, reinterpret_cast<const unsigned short*>(g.v) + ((size_t)n * g.kv_rows) * g.ldv + h * D, g.ldv, lane, g.kv_rows);
@@ -138,11 +126,9 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
     const DropBlock db(g.seed, pbase);
     for_acc(acc, lane, [&](float x, int row, int col) { return x * db.scale(row * T + col, g.p, inv_keep); });
   }
-  STAMP(2)
   acc_to_lds(acc, s0, lane);
   zero(acc);
   mm_alds_breg<false, true, 3, IN16 ? 1 : 3>(s0, op, acc, lane);  // O_h = P V, kept in acc
-  STAMP(3)
   __builtin_amdgcn_sched_barrier(0);
   if (c.O) {
     float* __restrict__ og = c.O + (size_t)unit * T * D;
@@ -192,7 +178,6 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
         op.v[t][kb][4] = hi.x; op.v[t][kb][5] = hi.y; op.v[t][kb][6] = hi.z; op.v[t][kb][7] = hi.w;
       }
   }
-  STAMP(4)
   wg_barrier();
   float gj;                                     // gate of (head h, channel `lane`)
   {
@@ -217,7 +202,6 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
     gj = exp_neg(d - mx) / sum;
     if (c.gate) c.gate[(size_t)n * kDm + tid] = gj;
   }
-  STAMP(5)
   // ---- phase C: u = sum_h gate_h * O_h through the panels, heads in fixed order ---------------------------------
   {
     float g0, g1;                                           // gates of the lane's two channels
@@ -250,12 +234,10 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
     if (c.u) c.u[((size_t)n * T + row) * D + lane] = v;
   }
   wg_barrier();
-  STAMP(6)
   // ---- phase D: f = u fc_w^T, this wave's 64 columns ---------------------------------------------------------
   zero(acc);
   mm_alds_breg<false>(U, op, acc, lane);
   __builtin_amdgcn_sched_barrier(0);
-  STAMP(7)
   const size_t row0 = (size_t)n * T;
   const int col0 = h * 64;
   if (c.f) {
@@ -267,7 +249,6 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
         for (int r = 0; r < 16; r++)
           c.f[(row0 + acc_row(a, r, lane)) * kDm + col0 + acc_col(b, lane)] = acc[a][b][r];
   }
-  STAMP(8)
   // ---- phase E: z = dropout(f) + residual ; LayerNorm over the 512 columns of every token row ------------------
   {
     const float inv_keep = c.p_fc > 0.f ? 1.f / (1.f - c.p_fc) : 1.f;
@@ -284,7 +265,6 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
           acc[a][b][r] = z + c.residual[idx - (size_t)(n - nq) * T * kDm];
         }
   }
-  STAMP(9)
   float rv[32];
 #pragma unroll
   for (int a = 0; a < 2; a++)
@@ -331,7 +311,6 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
   }
   wg_barrier();
   {
-    STAMP(10)
     const float* lg = each_time(c.ln_g);
     const float* lb = each_time(c.ln_b);
     const float g0 = lg[col0 + li], g1 = lg[col0 + 32 + li];
@@ -350,20 +329,11 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_fwd_kernel(const Co
         }
       }
   }
-  STAMP(11)
 }
 
 constexpr size_t kFusedLds = (size_t)(kHeads * kPanel + kPanel + kHeads * 64 + kDm + 64 + 128 + 64) * sizeof(float);
 
-#ifdef AIT_MHA_PROF
-unsigned long long* g_prof = nullptr;      // lab builds only (-DAIT_MHA_PROF: phase stamps, profiles/r04_mha_fused.txt)
-#else
-constexpr unsigned long long* g_prof = nullptr;
-#endif
 }  // namespace
-#ifdef AIT_MHA_PROF
-AIT_API void ait_mha_core_set_prof(unsigned long long* p) { g_prof = p; }
-#endif
 
 // qkv_bf16 != 0: q / k / v point at bf16 tensors (library-internal: csrc/transformer.hip's bf16-storage mode)
 int ait_mha_core_fwd_ex(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int n_seq, int kv_rows,
@@ -381,7 +351,7 @@ int ait_mha_core_fwd_ex(const void* q, int ldq, const void* k, int ldk, const vo
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds) != hipSuccess) return AIT_ELAUNCH;
   CoreArgs c{AttnArgs{static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v), ldq, ldk, ldv, n_seq,
                       kHeads, mask_mode, n_valid_keys, kv_rows, scale, p_attn, seed_attn},
-             sk_w, sk_b, fc_w, residual, ln_g, ln_b, eps, p_fc, seed_fc, out_rows, q_rep, P, O, u, gate, s, f, y, mean, rstd, g_prof};
+             sk_w, sk_b, fc_w, residual, ln_g, ln_b, eps, p_fc, seed_fc, out_rows, q_rep, P, O, u, gate, s, f, y, mean, rstd};
   if (qkv_bf16)
     hipLaunchKernelGGL(mha_core_fwd_kernel<true>, dim3((unsigned)n_seq), dim3(kFusedThreads), kFusedLds, ait_stream(stream), c);
   else

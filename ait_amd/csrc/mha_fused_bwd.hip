@@ -30,10 +30,7 @@ using namespace ait_attn;
 constexpr int kHeads = 8;
 constexpr int kDm = kHeads * D;
 constexpr int kFusedThreads = kHeads * 64;
-#ifndef AIT_LAB_FB_SPLIT
-#define AIT_LAB_FB_SPLIT 15     // lab knob: which of the attention tile's products run in the split form (1 dV, 2 dPd, 4 dQ, 8 dK)
-#endif
-constexpr int kSplitMask = AIT_LAB_FB_SPLIT;
+constexpr int kSplitMask = ait_lab::Knobs::fb_split;      // the attention tile's products in the split form: all four
 
 struct CoreBwdArgs {
   AttnArgs at;
@@ -118,11 +115,7 @@ __global__ __launch_bounds__(kFusedThreads, 1) void mha_core_bwd_kernel(const Co
   }
   __builtin_amdgcn_sched_barrier(0);
   zero(acc);
-#ifndef AIT_LAB_FB_DU_F32
-  mm_alds_breg<false, true>(s0, op, acc, lane);       // (split form: nothing on the vector pipe beside this product)
-#else
-  mm_alds_breg<false, false>(s0, op, acc, lane);
-#endif
+  mm_alds_breg<false, !ait_lab::Knobs::fb_du_f32>(s0, op, acc, lane);       // (split form: nothing on the vector pipe beside this product)
   __builtin_amdgcn_sched_barrier(0);
   // this head's O (64 x 64, whole rows) and its gates in flight across the head sum
   Stage so;

@@ -674,8 +674,8 @@ AIT_API int ait_roi_align_fwd(const float* feat, const float* rois, int n_rois, 
   if (!feat || !rois || !out) return AIT_EINVAL;
   // Measured on MI355X (bs=4, P=300, C=1024, scripts/bench_roi.py): the window-staged kernel
   // (0.81 ms) beats the plane-resident forward (1.05 ms, LDS-latency-bound at 8 waves/CU), so the
-  // latter is kept only as an opt-in (sampling_ratio encodes nothing; env AIT_ROI_FWD_PLANE=1).
-  static const bool fwd_plane = getenv("AIT_ROI_FWD_PLANE") != nullptr;
+  // latter is kept only for the lab (lab_knobs.h: roi_fwd_plane).
+  constexpr bool fwd_plane = ait_lab::Knobs::roi_fwd_plane;
   if (fwd_plane && plane_lds_fwd(H, W) <= 64 * 1024) {
     const unsigned blocks = (unsigned)(B * ((C + kPG - 1) / kPG));
     hipLaunchKernelGGL(roi_align_fwd_plane_kernel, dim3(blocks), dim3(kPG * 64), plane_lds_fwd(H, W),

@@ -29,20 +29,13 @@
 namespace {
 
 constexpr int kPW = 7;          // pooled width/height this file is specialised for (cfg.POOLING_SIZE)
-#ifndef AIT_ROI_CELLS           // lab knob: cells of a feature row a lane keeps in flight in the separable forward
-#define AIT_ROI_CELLS 4
-#endif
-constexpr int kCellsInFlight = AIT_ROI_CELLS;
+constexpr int kCellsInFlight = ait_lab::Knobs::roi_cells;      // cells of a feature row a lane keeps in flight in the separable forward
 // The separable two-stage forward (round 5) loads every window cell once and wins where the feature does NOT sit in L2
 // (scripts/bench_roi.py's RoIs with a random image each: 0.253 against 0.29 ms); in the detector's step the RoIs come image
 // by image, the sliced kernel's repeated loads are L1 / L2 hits, and its lack of barriers and LDS round trips wins: 0.199
-// against 0.240 ms (same-box A/B, profiles/r05_roi_align_sep.txt).  The sliced kernel ships; -DAIT_ROI_FWD_SEPARABLE
-// (scripts/build_variant.py) builds the other one for the lab.
-#ifdef AIT_ROI_FWD_SEPARABLE
-constexpr bool kFwdSeparable = true;
-#else
-constexpr bool kFwdSeparable = false;
-#endif
+// against 0.240 ms (same-box A/B, profiles/r05_roi_align_sep.txt).  The sliced kernel ships; the lab knob roi_fwd_separable
+// (lab_knobs.h, scripts/build_variant.py) builds the other one.
+constexpr bool kFwdSeparable = ait_lab::Knobs::roi_fwd_separable;
 constexpr int kThreads = 256;
 
 struct Geom {

@@ -231,11 +231,7 @@ inline int dgrad(const float* dy, long long M, int N_out, const float* w, int K_
   // (the residual + gate epilogue reads two more tensors per output: on these short reductions the 256 x 256 tile's
   // epilogue then weighs more than the pre-split planes save -- 35 % against 39 % of the matrix pipe -- so it stays on
   // the 256 x 128 tile)
-#ifdef AIT_LAB_TAIL_RESG_P3      // lab knob: the residual + gate epilogue on the 256 x 256 tile as well
-  const bool both_ok = true;
-#else
-  const bool both_ok = false;
-#endif
+  constexpr bool both_ok = ait_lab::Knobs::tail_resg_p3;
   if (p3t.p && (both_ok || !(residual && mask)) && ait_gemm_p3b_takes((int)M, K_in, N_out, r.ctx)) {      // B = planes of W'^T: rows K_in, reduction over N_out
     const bool both = residual && mask;
     return ait_gemm_f32_p3b((int)M, K_in, N_out, 1.f, dy, N_out, p3t.p, p3t.ld, dx, K_in, nullptr, both ? residual : (mask ? mask : residual),

@@ -165,9 +165,7 @@ inline Qkv views(const MhaBuf& m, long long n, bool cross) {
 // bf16 tensors take the first half of theirs, the bf16 copies of the block's inputs the second):
 //   self:  qkv16 [M, 1536] | x16 [M, 512]            cross:  q16 [M, 512] | x16 [M, 512] ... kv16 [R2, 1024] | xkv16 [R2, 512]
 inline bool qkv16_on(const Run& s, const P3W& pq, long long M) {
-#ifdef AIT_LAB_NO_BF16_QKV      // lab knob: f32 q / k / v in the bf16 mode, for A/Bs
-  return false;
-#endif
+  if (ait_lab::Knobs::no_bf16_qkv) return false;
   return s.ctx && (s.ctx->flags & AIT_CTX_BF16) && pq.w.p && M >= 256;
 }
 inline unsigned short* qkv_w16(const P3W& pq) { return const_cast<unsigned short*>(pq.w.p) + (size_t)3 * D * D; }
@@ -263,9 +261,8 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
   const bool in16 = qkv16_on(s, pq, M);
   const Qkv16 v16 = views16(m, n, M, kv_rows, cross);
   // fc's input gradient, the selective heads and the attention tiles backwards: one kernel per sequence
-  // (csrc/mha_fused_bwd.hip; du and dO stay on the chip), or -- lab builds, for A/Bs -- the three launches it replaces
+  // (csrc/mha_fused_bwd.hip; du and dO stay on the chip)
   auto attn_back = [&](void* dq_, int lddq, void* dk_, int lddk, void* dv_, int lddv, int out16) -> int {
-#ifndef AIT_LAB_NO_FUSED_BWD
     if (in16)
       AIT_TRY(ait_mha_core_bwd_ex(t.df, w.fc_w, m.O, m.gate, w.sk_w, v16.q, v16.ldq, v16.k, v16.ldkv, v16.v, v16.ldkv, m.P, n,
                                   kv_rows, 0.125f, p_attn, ait_dropout_seed(seed, 0), dq_, lddq, dk_, lddk, dv_, lddv, t.dg, out16, 1,
@@ -273,13 +270,6 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
     else
       AIT_TRY(ait_mha_core_bwd_ex(t.df, w.fc_w, m.O, m.gate, w.sk_w, v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, n, kv_rows, 0.125f,
                                   p_attn, ait_dropout_seed(seed, 0), dq_, lddq, dk_, lddk, dv_, lddv, t.dg, out16, 0, s.stream));
-#else
-    if (in16) return AIT_EUNSUPPORTED;      // (the three launches read f32 q / k / v: build with -DAIT_LAB_NO_BF16_QKV too)
-    AIT_TRY(dgrad(t.df, M, D, w.fc_w, DK, nullptr, false, t.du, s));            // du = df fc_w
-    AIT_TRY(ait_sh_bwd(t.du, m.O, m.gate, w.sk_w, n, H, T, DK, t.dO, t.dg, s.stream));
-    AIT_TRY(ait_attn_bwd_ex(v.q, v.ldq, v.k, v.ldkv, v.v, v.ldkv, m.P, t.dO, n, H, T, DK, kv_rows, 0.125f, p_attn,
-                            ait_dropout_seed(seed, 0), dq_, lddq, dk_, lddk, dv_, lddv, out16, s.stream));
-#endif
     AIT_TRY(wgrad(t.dg, n, D, m.s, DK, g.sk_w, s));                            // d sk_w += dg^T s
     if (g.sk_b) AIT_TRY(ait_colsum_f32(t.dg, n, D, D, g.sk_b, s.stream));
     return AIT_OK;
@@ -293,11 +283,7 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
     const long long R2 = (long long)n * kv_rows;
     int sp = 0, sp2 = 0;
     size_t part_bytes = 0;
-#ifndef AIT_LAB_NO_BF16_ATTN      // lab knob: the f32-storage projection backward in the bf16 mode, for A/Bs
-    if (s.ctx && (s.ctx->flags & AIT_CTX_BF16) && pq.w.p && M >= 256) {
-#else
-    if (false) {
-#endif
+    if (!ait_lab::Knobs::no_bf16_attn && s.ctx && (s.ctx->flags & AIT_CTX_BF16) && pq.w.p && M >= 256) {
       // (scratch for the K-ranges' partial tiles: t.dqkv behind its bf16 tensors -- with the inputs' bf16 copies left in m.qkv
       // by the forward, its whole second half)
       if (!cross) part_bytes = in16 ? (size_t)M * 3 * D * 2 : (size_t)M * 2 * D * 2;
@@ -375,9 +361,7 @@ struct Bf16Ffn {
 };
 inline Bf16Ffn bf16_ffn_plan(long long rows, const Run& s, const P3W& p1, const P3W& p2) {
   Bf16Ffn b;
-#ifdef AIT_LAB_NO_BF16_FFN      // lab knob (scripts/build_variant.py): the f32-storage feed-forward in the bf16 mode, for A/Bs
-  return b;
-#endif
+  if (ait_lab::Knobs::no_bf16_ffn) return b;
   if (!s.ctx || !(s.ctx->flags & AIT_CTX_BF16) || !p1.w.p || !p2.w.p || rows < 256 || rows > 0x7fffffffLL / DI) return b;
   b.split = bf16_tn_split(D, DI, rows, (size_t)rows * (DI - D) * 2);      // (both weight gradients: 16 tiles of 256 x 256)
   b.on = b.split > 0;

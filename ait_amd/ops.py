@@ -40,10 +40,9 @@ def set_matmul_dtype(dtype):
     "f32_native": the same kernels on v_mfma_f32_32x32x2_f32 (the A/B for the above).
     "bf16": the same kernels with every operand value rounded to bf16 in registers, one MFMA per block, f32
     accumulate, f32 tensors in memory (torch.autocast semantics; BASELINE configs[4]) -- NOT f32 accuracy.
-    "bf16_lds" / "bf16x3": the round-1 bf16 kernel (operands converted on their way into LDS; x3: hi + lo, three
-    products)."""
+    "bf16_lds": the round-1 bf16 kernel (operands converted on their way into LDS)."""
     global MATMUL_DTYPE
-    if dtype not in ("f32", "f32_native", "bf16", "bf16_lds", "bf16x3"):
+    if dtype not in ("f32", "f32_native", "bf16", "bf16_lds"):
         raise ValueError(dtype)
     _lib.NATIVE_F32 = dtype == "f32_native"
     _lib.BF16_PRODUCTS = dtype == "bf16"
@@ -54,7 +53,7 @@ def _gemm_fn(exact=False):
     L = _lib.lib()
     if exact:
         return L.ait_gemm_f32
-    return {"f32": L.ait_gemm_f32, "bf16": L.ait_gemm_bf16, "bf16x3": L.ait_gemm_bf16x3}[MATMUL_DTYPE]
+    return {"f32": L.ait_gemm_f32, "bf16": L.ait_gemm_bf16}[MATMUL_DTYPE]
 
 
 def gemm(a, b, trans_a=False, trans_b=True, out=None, bias=None, residual=None, relu=False,

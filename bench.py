@@ -204,52 +204,108 @@ def pmc_traffic_per_launch(kernel_prefix="gemm_f32_"):
             "source": "profiles/%s + profiles/%s" % (out["fetch"][1], out["write"][1])}
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, deadline_s=None, grace_s=10.0):
     """`python bench.py --gpus N` outside a torch.distributed.run environment: this parent starts N fresh child
     processes of this same script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torchrun would:
     the reference's `python trainval_net_voc.py --mGPUs`, trainval_net_voc.py:83,321-326, is one command too),
     relays rank 0's JSON line and returns non-zero if any rank fails.  The parent never initialises the GPU
-    (torch.cuda.device_count() only) and nothing is exec'ed."""
+    (torch.cuda.device_count() only) and nothing is exec'ed.
+
+    It cannot hang: when a rank fails the others get SIGTERM and, `grace_s` later, SIGKILL (a rank stuck inside an
+    RCCL collective or a kernel does not act on SIGTERM); the whole job has a deadline (AIT_BENCH_DEADLINE_S, default
+    3600 s) behind which everything is killed and the exit code is 124.  The rendezvous port is picked by binding port 0
+    and closing it, so another process can take it before rank 0 listens: a job whose rank 0 dies of EADDRINUSE is
+    started again on a new port (three tries)."""
     import socket
     import subprocess
+    import tempfile
     have = torch.cuda.device_count()
     gloo = os.environ.get("AIT_DIST_BACKEND") == "gloo"          # test hook: N ranks share the GPUs there are
     if have < n and not gloo:
         sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible\n" % (n, have))
         return 2
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    import tempfile
-    procs = []
-    with tempfile.TemporaryFile(mode="w+") as out0:
-        for r in range(n):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-            if gloo:
-                env.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
-        # a rank that dies leaves the others inside a collective: stop them (by their exact PIDs) instead of waiting
-        # for the collective's timeout
-        failed = None
-        while any(p.poll() is None for p in procs):
-            bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
-            if bad and failed is None:
-                failed = bad[0]
-                time.sleep(2.0)
-                for p in procs:
-                    if p.poll() is None:
-                        p.terminate()
+    deadline_s = float(os.environ.get("AIT_BENCH_DEADLINE_S", "3600")) if deadline_s is None else deadline_s
+    t_end = time.monotonic() + deadline_s
+
+    def stop(procs):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + grace_s
+        while any(p.poll() is None for p in procs) and time.monotonic() < t_kill:
             time.sleep(0.05)
-        codes = [p.wait() for p in procs]
-        out0.seek(0)
-        sys.stdout.write(out0.read())
-        sys.stdout.flush()
-    if any(codes):
-        sys.stderr.write("bench.py: rank exit codes %r%s\n" % (codes, "" if failed is None else " (rank %d failed first)" % failed))
-        return 1
-    return 0
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+
+    for attempt in range(3):
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        procs, errs = [], []
+        with tempfile.TemporaryFile(mode="w+") as out0:
+            for r in range(n):
+                # (HSA_ENABLE_IPC_MODE_LEGACY: see ait_amd/distributed.py init())
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                if gloo:
+                    env.setdefault("GLOO_SOCKET_IFNAME", "lo")
+                errs.append(tempfile.TemporaryFile(mode="w+"))
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                              stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=errs[-1]))
+            # a rank that dies leaves the others inside a collective: stop them (by their exact PIDs) instead of
+            # waiting for the collective's timeout
+            failed, timed_out = None, False
+            while any(p.poll() is None for p in procs):
+                bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+                if bad:
+                    failed = bad[0]
+                    time.sleep(min(2.0, grace_s))       # let the others fail by themselves and say why
+                    stop(procs)
+                    break
+                if time.monotonic() > t_end:
+                    timed_out = True
+                    stop(procs)
+                    break
+                time.sleep(0.05)
+            codes = [p.wait() for p in procs]
+            texts = []
+            for e in errs:
+                e.seek(0)
+                texts.append(e.read())
+                e.close()
+            in_use = any(k in texts[0] for k in ("EADDRINUSE", "Address already in use", "address already in use"))
+            if codes[0] != 0 and in_use and attempt < 2 and not timed_out:
+                sys.stderr.write("bench.py: port %d was taken before rank 0 could listen: starting the ranks again\n" % port)
+                continue
+            for t in texts:
+                sys.stderr.write(t)
+            out0.seek(0)
+            sys.stdout.write(out0.read() if not (any(codes) or timed_out) else "")
+            sys.stdout.flush()
+        if timed_out:
+            sys.stderr.write("bench.py: the %d ranks did not finish within %.0f s: killed\n" % (n, deadline_s))
+            return 124
+        if any(codes):
+            sys.stderr.write("bench.py: rank exit codes %r%s\n" % (codes, "" if failed is None else " (rank %d failed first)" % failed))
+            return 1
+        return 0
+    return 1
+
+
+def cpu_model():
+    """the host CPU's model string (core count AND CPU model printed beside the CPU baseline)"""
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.lower().startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def main():
@@ -263,13 +319,17 @@ def main():
     ap.add_argument("--variant", choices=["voc", "coco"], default=None, help="override the configuration's detector variant")
     ap.add_argument("--bs", type=int, default=None, help="pairs per GPU (override; cfg2: 4, cfg3-5: 8)")
     ap.add_argument("--proposals", type=int, default=None)
-    ap.add_argument("--exchange", choices=["allreduce", "rs_ag"], default=None,
-                    help="N > 1: the gradient buckets' exchange (default: AIT_DDP_EXCHANGE or DDP's all-reduce)")
+    ap.add_argument("--exchange", choices=["allreduce", "rs_ag"], default="allreduce",
+                    help="N > 1: the gradient buckets' exchange (default DDP's all-reduce; rs_ag is experimental and is "
+                         "selected by this argument only)")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="--gpus 1 only: build a real one-rank process group (RCCL) and the DDP wrapper anyway "
+                         "(same as AIT_FORCE_DDP=1): runs the N > 1 code path on a one-GPU box; not the headline mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ab", action="store_true", help="skip the f32_native A/B steps behind the timed region")
     ap.add_argument("--gemm-table", default=None, metavar="PATH",
                     help="also write the timed region's GEMM launches grouped by shape (launches/step, ms/step, TFLOP/s)")
-    ap.add_argument("--dtype", choices=["f32", "f32_native", "bf16", "bf16x3"], default=None,
+    ap.add_argument("--dtype", choices=["f32", "f32_native", "bf16"], default=None,
                     help="matmul arithmetic of the AIT GEMMs.  f32 is the headline / parity "
                          "configuration; bf16 is the BASELINE cfg-5 arithmetic (operands rounded to bf16, "
                          "fp32 accumulate) and is reported as such, never as the headline number")
@@ -284,6 +344,12 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     from ait_amd import distributed as D
+    if args.force_ddp:
+        os.environ["AIT_FORCE_DDP"] = "1"
+    # a rank of an N > 1 job: next to its GPU's NUMA cores, BEFORE anything initialises the GPU (sysfs only).  N = 1 stays
+    # unbound: its CPU baseline is timed on all the box's cores
+    affinity = D.bind_rank_to_gpu_numa(D.env_world()[1], int(os.environ.get("LOCAL_WORLD_SIZE", "1"))) \
+        if D.env_world()[2] > 1 else {"bound": False, "why": "one rank"}
     from ait_amd import _lib, ops, tuning
     rank, local_rank, world = D.init()
     # MIOpen solver picks for the torch-side convolutions: the committed find-db holds the shapes of cfg2 .. cfg5 as
@@ -306,11 +372,11 @@ def main():
     np.random.seed(3 + rank)                     # reference RNG_SEED, one stream per rank
     batch = synth_batch(args.bs, 1000 + rank, device, max_gt=50 if args.variant == "coco" else 20)
 
-    # (N > 1: the buckets' exchange -- DDP's all-reduce, or with --exchange rs_ag / AIT_DDP_EXCHANGE=rs_ag reduce-scatter +
+    # (N > 1: the buckets' exchange -- DDP's all-reduce, or with --exchange rs_ag reduce-scatter +
     # all-gather -- under a clock that notes when the reducer hands each bucket over)
-    exchange = args.exchange or D.exchange_from_env()
-    clock = D.BucketClock(ddp, exchange) if world > 1 else None
-    if world > 1:
+    exchange = args.exchange
+    clock = D.BucketClock(ddp, exchange) if D.active() else None
+    if D.active():
         ddp._ait_exchange = exchange
 
     def step():
@@ -330,20 +396,38 @@ def main():
     # live roofline measurement: the library brackets every GEMM / RoIAlign launch of the timed region with
     # HIP events on its launch stream (include/ait_hip.h "Measurement"), wherever the launch comes from
     probe = _lib.Probe(1024 * max(1, args.steps))
+    # every step between two HIP events on the step's stream; the line reports their MEDIAN as ms_per_step and
+    # the wall-clock mean of the whole region (what `value` is computed from, per the bench contract) beside it
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if os.environ.get("AIT_BENCH_NO_PROBE") == "1":       # diagnostic: what the event brackets cost the step
-        for _ in range(args.steps):
+    with probe:
+        for i in range(args.steps):
+            marks[i].record()
             step()
-    else:
-        with probe:
-            for _ in range(args.steps):
-                step()
+        marks[args.steps].record()
     torch.cuda.synchronize()
     D.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, device)
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    med = lambda v: 0.5 * (v[(len(v) - 1) // 2] + v[len(v) // 2])
+    step_stats = {"median": D.max_over_ranks(med(step_ms), device), "mean": sum(step_ms) / len(step_ms),
+                  "min": step_ms[0], "max": step_ms[-1],
+                  "clock": "HIP events on the step's stream, one pair per step%s" % ("; median = max over ranks of the per-rank medians" if world > 1 else "")}
+
+    # what the library's event brackets around every GEMM / RoIAlign launch cost the timed region: the same steps once
+    # more WITHOUT the probe, outside the timed region (every rank runs them: the steps hold collectives)
+    n_np = max(1, min(args.steps, 10))
+    D.barrier()
+    torch.cuda.synchronize()
+    tn = time.perf_counter()
+    for _ in range(n_np):
+        step()
+    torch.cuda.synchronize()
+    D.barrier()
+    noprobe_ms = D.max_over_ranks(time.perf_counter() - tn, device) / n_np * 1e3
 
     # A/B beside the headline, OUTSIDE its timed region (every rank runs it: the steps hold collectives): the same step
     # with the AIT's products on the instruction that multiplies f32 operands (v_mfma_f32_32x32x2_f32)
@@ -394,7 +478,7 @@ def main():
     # dense MFMA peak for the arithmetic: fp32, bf16, or bf16 / 3 MFMAs per product
     # (f32: the bf16 pipe's dense peak over the SIX MFMAs an f32 block product costs on it -- the ceiling of the split
     # form; the f32 instruction's own peak is reported beside it)
-    peak = {"f32": 2500.0 / 6, "f32_native": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 3}[args.dtype]
+    peak = {"f32": 2500.0 / 6, "f32_native": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0}[args.dtype]
     is_f32 = args.dtype in ("f32", "f32_native")
     pmc = pmc_traffic_per_launch() if is_f32 else None
     # algorithmic bytes of the same launches: each operand read once, the output written once
@@ -415,7 +499,12 @@ def main():
     value = pairs / elapsed
     line = {
         "metric": METRIC, "value": value, "unit": "pairs/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "steps": args.steps, "warmup": args.warmup,
+        # the median of the event-timed steps; `value` = pairs / wall-clock of the whole region (mean)
+        "ms_per_step": step_stats["median"], "ms_per_step_mean": 1e3 * elapsed / args.steps, "step_ms": step_stats,
+        "probe_overhead_ms_per_step": 1e3 * elapsed / args.steps - noprobe_ms,
+        "probe_overhead_is": "wall-clock mean of the timed region (every GEMM / RoIAlign launch bracketed by two HIP events "
+                             "for the roofline) minus the mean of %d further steps without the brackets, run right after it" % n_np,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32 (operands, results, accumulation and storage f32; products: every operand value split exactly into "
                          "three bf16 values (round to nearest), six v_mfma_f32_32x32x16_bf16 per block, dropped terms <= 2^-23 |a b|)",
@@ -425,8 +514,7 @@ def main():
                           "frozen-BN passes on bf16); AIT: every linear on v_mfma_f32_32x32x16_bf16 with f32 accumulate -- feed-forward "
                           "hidden tensors, q / k / v, the attention blocks' gradients and the operator's output STORED in bf16 (bf16 "
                           "operands from memory), the embeddings' operands rounded to bf16 in registers; f32 residual stream, LayerNorm, "
-                          "softmax and attention-tile arithmetic (on widened bf16 q / k / v), RPN, losses",
-                  "bf16x3": "f32 emulated as 3 bf16 MFMAs per product (experimental; fp32 accumulate)"}[args.dtype],
+                          "softmax and attention-tile arithmetic (on widened bf16 q / k / v), RPN, losses"}[args.dtype],
         "data": "synthetic",
         "config": {"workload": conf["workload"] % {"P": args.proposals, "bs": args.bs},
                    "name": args.config,
@@ -434,7 +522,7 @@ def main():
                               else "coco (non-local co-attention, 12 anchors, 50 gt boxes)",
                    "backbone": "ResNet%d" % conf["layers"],
                    "pairs_per_gpu": args.bs, "global_batch": world * args.bs,
-                   "collective": "none" if world == 1 else D.collective_description(ddp),
+                   "collective": D.collective_description(ddp), "host_affinity": affinity,
                    "gradient_buckets": clock.summary() if clock is not None else None,
                    "proposals": args.proposals, "target": "600x1000", "query": "128x128",
                    "parallelism": "dp%d" % world, "miopen_find_db": bool(tuned)},
@@ -443,13 +531,11 @@ def main():
                                "six v_mfma_f32_32x32x16_bf16 (f32 accumulate) per 32x32x16 block = f32-equivalent products "
                                "(few-tile launches: gemm_f32_kernel on v_mfma_f32_32x32x2_f32)" if args.dtype == "f32"
                                else "gemm_f32_stream_kernel / gemm_f32_kernel (v_mfma_f32_32x32x2_f32)" if args.dtype == "f32_native"
-                               else "the AIT's products: gemm_bf16s_kernel / gemm_bf16s_tn_kernel (bf16 operands stored in memory) and gemm_f32_stream_kernel with KNOB_BF16 (f32 operands rounded to bf16 in registers), one v_mfma_f32_32x32x16_bf16 per block" if args.dtype == "bf16"
-                               else "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16%s)" % (", 3 per product" if args.dtype == "bf16x3" else ""),
+                               else "the AIT's products: gemm_bf16s_kernel / gemm_bf16s_tn_kernel (bf16 operands stored in memory) and gemm_f32_stream_kernel with KNOB_BF16 (f32 operands rounded to bf16 in registers), one v_mfma_f32_32x32x16_bf16 per block",
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak,
                      "peak_is": {"f32": "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per f32 block product",
-                                 "f32_native": "v_mfma_f32_32x32x2_f32 dense peak", "bf16": "dense bf16 MFMA",
-                                 "bf16x3": "dense bf16 MFMA / 3"}[args.dtype],
+                                 "f32_native": "v_mfma_f32_32x32x2_f32 dense peak", "bf16": "dense bf16 MFMA"}[args.dtype],
                      "f32_instruction_peak": PEAK_F32_MFMA_TFLOPS,
                      "achieved_over_f32_instruction_peak": achieved / PEAK_F32_MFMA_TFLOPS if is_f32 else None,
                      # PMC counters cannot be read from inside this process: `traffic` (HBM bytes per launch of the dominant
@@ -498,6 +584,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         # (the CPU port is timed on the headline workload's pair: VOC variant, ResNet50)
         line["cpu_baseline"] = cpu_baseline(args.proposals)
+        line["cpu_baseline"]["cpu_model"] = cpu_model()
     print(json.dumps(line), flush=True)
 
 

@@ -34,6 +34,8 @@ extern "C" {
 
 /* ABI version; bumped on any signature change. */
 int ait_abi_version(void);
+/* 0 for the shipped library; 1 for a lab variant compiled with experiment knobs (csrc/lab_knobs.h) -- never shipped */
+int ait_lab_build(void);
 const char* ait_strerror(int code);
 
 /* ---------------------------------------------------------------------------------------
@@ -417,16 +419,6 @@ int ait_colsum_bf16(const void* x, long long rows, int cols, long long ld, float
  * the input-gradient products) and the activations whose producer is not one of this library's bf16-emitting kernels. */
 int ait_f32_to_bf16(const float* src, long long rows, int cols, long long ld_src, void* dst, long long ld_dst,
                     int transpose, void* stream);
-
-/* EXPERIMENTAL "bf16x3" variant: every fp32 operand is split into hi = bf16(x), lo = bf16(x - hi)
- * and each product is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the bf16 matrix cores with fp32
- * accumulation (<= ~3*2^-18 relative per product): fp32-class accuracy at 3/16 of the fp32 MFMA
- * cost.  Opt-in only (ait_amd.ops.set_matmul_dtype("bf16x3")); the default and the headline
- * metric use the exact ait_gemm_f32. */
-int ait_gemm_bf16x3(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* A,
-                    int lda, const float* B, int ldb, float* C, int ldc, const float* bias,
-                    const float* residual, int flags, int split_k, int c_colblk,
-                    long long c_batch_stride, const ait_launch_ctx* ctx, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Row kernels (d_model = 512 only; other widths return AIT_EUNSUPPORTED).

@@ -43,7 +43,11 @@ def test_library_builds_and_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), "libait_hip.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names, (sorted(_lib.SIGNATURES), names)
-    assert L.ait_abi_version() == 6
+    assert L.ait_abi_version() == 7
+    # the shipped library is the product build: no experiment knob is set (csrc/lab_knobs.h), and ait_amd/build.py has no
+    # way to set one
+    assert L.ait_lab_build() == 0
+    assert not any("AIT_LAB" in f for f in build.COMMON + [x for v in build.PER_FILE.values() for x in v])
     assert L.ait_strerror(0) == b"ok"
     assert L.ait_nms_workspace_bytes(12000) >= 12000 * 188 * 8
     # AIT_CTX_IO_BF16's size predicate (a host function): the bench configurations and the 6-proposal test size qualify,
@@ -52,6 +56,28 @@ def test_library_builds_and_exports_header_symbols():
     assert L.ait_transformer_io_bf16_ok(6, 2, 49) == 1
     assert L.ait_transformer_io_bf16_ok(2, 2, 49) == 0 and L.ait_transformer_io_bf16_ok(7, 2, 49) == 0
     assert L.ait_transformer_io_bf16_ok(0, 2, 49) == 0 and L.ait_transformer_io_bf16_ok(6, 2, 65) == 0
+
+
+def test_shipped_sources_hold_no_experiment_switches():
+    """every build-time experiment knob lives in csrc/lab_knobs.h (one #ifdef, on AIT_LAB_KNOBS); the kernels' sources have
+    no AIT_LAB_* / AIT_ROI_* conditionals, read no environment and the object cache holds no variant objects"""
+    csrc = os.path.join(ROOT, "ait_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(csrc, f)).read()
+        assert "getenv" not in text, f
+        for m in re.finditer(r"^\s*#\s*(if|ifdef|ifndef|elif)\b(.*)$", text, flags=re.M):
+            cond = m.group(2)
+            if f == "lab_knobs.h":
+                assert cond.strip() == "AIT_LAB_KNOBS", (f, cond)
+            else:
+                assert "AIT_" not in cond, (f, m.group(0))
+    objs = os.path.join(csrc, "_obj")
+    if os.path.isdir(objs):
+        srcs = {s[:-4] for s in build.sources()}
+        extra = [o for o in os.listdir(objs) if o.endswith(".o") and o[:-2] not in srcs]
+        assert not extra, "variant / stale objects in the object cache: %r" % extra
 
 
 def test_code_object_is_gfx950():

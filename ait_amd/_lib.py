@@ -97,12 +97,12 @@ SIGNATURES = {
     "ait_ffn_bwd": (_i, [_vp, _vp, _ll, _vp, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
     "ait_transformer_saved_bytes": (_sz, [_i, _i, _i]),
     "ait_transformer_io_bf16_ok": (_i, [_i, _i, _i]),
-    "ait_transformer_fwd_train": (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _vp, _vp]),
+    "ait_transformer_fwd_train": (_i, [_vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _vp, _vp, _vp]),
     "ait_transformer_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
-    "ait_transformer_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp,
+    "ait_transformer_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, ctypes.c_uint, _vp, _sz, _vp, _vp,
                                  _vp, _vp, _vp]),
-    "ait_transformer_bwd_part": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, _vp, _sz, _vp, _vp,
-                                 _vp, _vp, _vp]),
+    "ait_transformer_bwd_part": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, ctypes.c_uint, _vp, _sz,
+                                      _vp, _vp, _vp, _vp, _vp]),
     "ait_tail_saved_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ait_tail_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "ait_tail_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

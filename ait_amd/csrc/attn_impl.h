@@ -43,6 +43,11 @@ using ait_gemm::Planes;
 constexpr int T = 64, D = 64, PITCH = 65;
 constexpr bool kF32Pairs = ait_lab::Knobs::f32_pairs;      // (lab: the column-paired right-operand loads for f32 q / k / v as well)
 constexpr int kPanel = T * PITCH;          // floats per LDS panel
+// a [rows, 8 heads x 64] tensor as the fused kernels address it: at least 512 columns per row, the pitch a whole number of
+// 16-byte vectors (4 f32 / 8 bf16), the base 16-byte aligned
+inline bool rows_ok(const void* p, int ld, int is_bf16) {
+  return ld >= 8 * D && (ld % (is_bf16 ? 8 : 4)) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
 constexpr int kWaves = 4;
 constexpr int kThreads = kWaves * 64;
 

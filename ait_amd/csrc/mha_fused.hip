@@ -346,6 +346,8 @@ int ait_mha_core_fwd_ex(const void* q, int ldq, const void* k, int ldk, const vo
   if (!q || !k || !v || !sk_w || !sk_b || !fc_w || !residual || !ln_g || !ln_b || !y) return AIT_EINVAL;
   if (kv_rows <= 0 || kv_rows > T || out_rows <= 0 || out_rows > T || q_rep < 1) return AIT_EINVAL;
   if ((long long)n_seq * T * kDm > 0x7fffffffLL * 4) return AIT_EUNSUPPORTED;
+  if (!ait_attn::rows_ok(q, ldq, qkv_bf16) || !ait_attn::rows_ok(k, ldk, qkv_bf16) || !ait_attn::rows_ok(v, ldv, qkv_bf16))
+    return AIT_EUNSUPPORTED;      // (512 columns per row, pitches in whole 16-byte vectors, aligned bases)
   const void* fn = qkv_bf16 ? reinterpret_cast<const void*>(mha_core_fwd_kernel<true>)
                             : reinterpret_cast<const void*>(mha_core_fwd_kernel<false>);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds) != hipSuccess) return AIT_ELAUNCH;

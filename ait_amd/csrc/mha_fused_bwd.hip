@@ -281,6 +281,14 @@ int ait_mha_core_bwd_ex(const float* df, const float* fc_w, const float* O, cons
   if (!df || !fc_w || !O || !gate || !sk_w || !q || !k || !v || !P || !dq || !dk || !dv || !dg) return AIT_EINVAL;
   if (kv_rows <= 0 || kv_rows > T) return AIT_EINVAL;
   if ((long long)n_seq * T * kDm > 0x7fffffffLL * 4) return AIT_EUNSUPPORTED;
+  // the kernels' 16-byte (paired: 8-byte) loads and stores: rows of at least the eight heads' 512 columns, pitches in whole
+  // vectors (4 f32 / 8 bf16), 16-byte aligned bases -- a strided view that breaks one of these is refused, not faulted on
+  if (!ait_attn::rows_ok(q, ldq, qkv_bf16) || !ait_attn::rows_ok(k, ldk, qkv_bf16) || !ait_attn::rows_ok(v, ldv, qkv_bf16) ||
+      !ait_attn::rows_ok(dq, lddq, out_bf16) || !ait_attn::rows_ok(dk, lddk, out_bf16) || !ait_attn::rows_ok(dv, lddv, out_bf16))
+    return AIT_EUNSUPPORTED;
+  for (const void* p : {(const void*)df, (const void*)fc_w, (const void*)O, (const void*)gate, (const void*)sk_w, (const void*)P,
+                        (const void*)dg})
+    if (reinterpret_cast<uintptr_t>(p) & 15) return AIT_EUNSUPPORTED;
   CoreBwdArgs c;
   c.at = AttnArgs{static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v), ldq, ldk, ldv, n_seq,
                   kHeads, 0, 0, kv_rows, scale, p_attn, seed_attn};

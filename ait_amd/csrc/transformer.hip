@@ -729,6 +729,25 @@ inline Io16 io16_plan(long long M, const Run& s, const AitBufs& a) {
   return o;
 }
 
+// ---- the storage format of a training forward's `saved` buffer ---------------------------------------------------------
+// Which blocks stored what as bf16 is decided by the call's ctx flags and sizes (qkv16_on, bf16_ffn_plan, io16_plan above).
+// The backward re-derives those decisions from ITS ctx; nothing in device memory could tell it (reading a header back would
+// cost a device-to-host round trip per step).  So the forward REPORTS its decisions as one word, the caller hands that word
+// to the backward, and a backward whose own derivation differs -- other flags, another ctx -- returns AIT_EINVAL instead of
+// reading bf16 bytes as f32.  One function, called with the same arguments by both.
+constexpr unsigned kFmtMagic = 0xA1700000u;
+inline unsigned saved_format(const Run& run, const AitBufs& a, int bp, int n_src) {
+  const long long M = (long long)bp * T, Mc = (long long)bp * n_src;
+  unsigned f = kFmtMagic;
+  if (qkv16_on(run, a.p_enc_qkv, M)) f |= AIT_SAVED_ENC_QKV16;
+  if (qkv16_on(run, a.p_dec_qkv, M)) f |= AIT_SAVED_DEC_QKV16;
+  if (qkv16_on(run, a.p_x_qkv, M)) f |= AIT_SAVED_X_QKV16;
+  if (bf16_ffn_plan(Mc, run, a.p_enc_w1, a.p_enc_w2).on && a.p_enc_w1.wt.p) f |= AIT_SAVED_ENC_FFN16;
+  if (bf16_ffn_plan(M, run, a.p_dec_w1, a.p_dec_w2).on && a.p_dec_w1.wt.p) f |= AIT_SAVED_DEC_FFN16;
+  if (io16_plan(M, run, a).on) f |= AIT_SAVED_IO16;
+  return f;
+}
+
 // block seeds of the operator's ten dropout sites (two per attention block, one per feed-forward / prologue)
 enum { kSeedEncPro = 16, kSeedEncSlf, kSeedEncFfn, kSeedDecPro, kSeedDecSlf, kSeedDecEnc, kSeedDecFfn };
 
@@ -813,16 +832,18 @@ AIT_API size_t ait_transformer_saved_bytes(int bp, int bs, int n_src) {
 
 AIT_API int ait_transformer_fwd_train(const float* x_props, const float* x_query, int bp, int bs, int n_src,
                                       const ait_transformer_weights* w, float p_drop, float p_attn_drop,
-                                      unsigned long long seed, void* saved, size_t saved_bytes, float* out,
-                                      const ait_launch_ctx* ctx, void* stream) {
+                                      unsigned long long seed, void* saved, size_t saved_bytes,
+                                      unsigned* saved_format_out, float* out, const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY(check_ait(bp, bs, n_src, w));
-  if (bad_p(p_drop) || bad_p(p_attn_drop)) return AIT_EINVAL;
+  if (bad_p(p_drop) || bad_p(p_attn_drop) || !saved_format_out) return AIT_EINVAL;
+  *saved_format_out = kFmtMagic;
   if (bp == 0) return AIT_OK;
   if (!x_props || !x_query || !out || !saved) return AIT_EINVAL;
   if (saved_bytes < ait_transformer_saved_bytes(bp, bs, n_src)) return AIT_EWORKSPACE;
   Bump b{static_cast<char*>(saved), saved_bytes};
   AitBufs a;
   if (!carve_train(b, a, bp, bs, n_src)) return AIT_EWORKSPACE;
+  *saved_format_out = saved_format(Run{stream, ctx}, a, bp, n_src);
   return ait_forward(x_props, x_query, bp, bs, n_src, w, a, p_drop, p_attn_drop, seed, out, Run{stream, ctx});
 }
 
@@ -851,11 +872,12 @@ AIT_API size_t ait_transformer_bwd_workspace_bytes(int bp, int bs, int n_src) {
 // every call the same workspace.
 static int ait_backward_parts(int parts, const float* d_out, const float* x_props, const float* x_query, int bp, int bs,
                               int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
-                              unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
-                              size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                              unsigned long long seed, const void* saved, size_t saved_bytes, unsigned saved_fmt,
+                              void* workspace, size_t workspace_bytes, float* d_x_props, float* d_x_query,
                               const ait_transformer_grads* g, const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY(check_ait(bp, bs, n_src, w));
   if (bad_p(p_drop) || bad_p(p_attn_drop) || !g) return AIT_EINVAL;
+  if ((saved_fmt & 0xFFF00000u) != kFmtMagic) return AIT_EINVAL;      // not a word ait_transformer_fwd_train reported
   if (bp == 0) return AIT_OK;
   if (((parts & 1) && !d_out) || !x_props || !x_query || !saved || !workspace) return AIT_EINVAL;
   if (saved_bytes < ait_transformer_saved_bytes(bp, bs, n_src)) return AIT_EWORKSPACE;
@@ -866,6 +888,8 @@ static int ait_backward_parts(int parts, const float* d_out, const float* x_prop
   Bump bs_{static_cast<char*>(const_cast<void*>(saved)), saved_bytes};
   AitBufs a;
   if (!carve_train(bs_, a, bp, bs, n_src)) return AIT_EWORKSPACE;
+  // the forward stored its tensors in the format it reported; this call would read them in the format ITS ctx implies
+  if (saved_format(run, a, bp, n_src) != saved_fmt) return AIT_EINVAL;
   Bump b{static_cast<char*>(workspace), workspace_bytes};
   float* ga = b.take((size_t)M * D);
   float* gb = b.take((size_t)M * D);
@@ -950,19 +974,20 @@ static int ait_backward_parts(int parts, const float* d_out, const float* x_prop
 
 AIT_API int ait_transformer_bwd(const float* d_out, const float* x_props, const float* x_query, int bp, int bs,
                                 int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
-                                unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
-                                size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                                unsigned long long seed, const void* saved, size_t saved_bytes, unsigned saved_format,
+                                void* workspace, size_t workspace_bytes, float* d_x_props, float* d_x_query,
                                 const ait_transformer_grads* g, const ait_launch_ctx* ctx, void* stream) {
   return ait_backward_parts(7, d_out, x_props, x_query, bp, bs, n_src, w, p_drop, p_attn_drop, seed, saved, saved_bytes,
-                            workspace, workspace_bytes, d_x_props, d_x_query, g, ctx, stream);
+                            saved_format, workspace, workspace_bytes, d_x_props, d_x_query, g, ctx, stream);
 }
 
 AIT_API int ait_transformer_bwd_part(int part, const float* d_out, const float* x_props, const float* x_query, int bp,
                                      int bs, int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
-                                     unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
-                                     size_t workspace_bytes, float* d_x_props, float* d_x_query,
-                                     const ait_transformer_grads* g, const ait_launch_ctx* ctx, void* stream) {
+                                     unsigned long long seed, const void* saved, size_t saved_bytes,
+                                     unsigned saved_format, void* workspace, size_t workspace_bytes, float* d_x_props,
+                                     float* d_x_query, const ait_transformer_grads* g, const ait_launch_ctx* ctx,
+                                     void* stream) {
   if (part < 0 || part > 2) return AIT_EINVAL;
   return ait_backward_parts(1 << part, d_out, x_props, x_query, bp, bs, n_src, w, p_drop, p_attn_drop, seed, saved,
-                            saved_bytes, workspace, workspace_bytes, d_x_props, d_x_query, g, ctx, stream);
+                            saved_bytes, saved_format, workspace, workspace_bytes, d_x_props, d_x_query, g, ctx, stream);
 }

@@ -417,6 +417,21 @@ def _channels_last_weight(p):
     return p
 
 
+def _only_plain_forward_hooks(mod):
+    """True if every hook on `mod` is a plain forward hook (module, args, output) on the module itself -- the only kind the
+    fused heads path can call by hand.  Forward pre-hooks, hooks registered with with_kwargs / always_call, backward
+    (pre-)hooks, and hooks of any kind on a child module need torch's own dispatch."""
+    def none(m, names):
+        return not any(getattr(m, n, None) for n in names)
+    if not none(mod, ("_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks", "_forward_hooks_with_kwargs",
+                      "_forward_hooks_always_called")):
+        return False
+    for child in mod.modules():
+        if child is not mod and not none(child, ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks")):
+            return False
+    return True
+
+
 class _HeadsFn(torch.autograd.Function):
     """(pooled proposal features [R, F], pooled query features [bs, F]) -> (bbox_pred [R, n_bbox], score [R, 2]) through
     ait_heads_fwd / ait_heads_bwd: RCNN_bbox_pred and the two Linears of RCNN_cls_score on the concatenation the
@@ -791,8 +806,11 @@ class _fasterRCNN(nn.Module):
             props_feat = self._head_to_tail(props_feat, subsampled=sk_stride != 1)   # [bs*P, 2048]
             query_feat = self._head_to_tail(query_feat, subsampled=sk_stride != 1)   # [bs, 2048]
 
+        # (hooks the fused path cannot honour -- pre-hooks, kwargs / always-call hooks, backward hooks, any hook on a child
+        # of RCNN_cls_score -- send the two heads through their modules, where torch dispatches them)
+        hooks_plain = _only_plain_forward_hooks(self.RCNN_bbox_pred) and _only_plain_forward_hooks(self.RCNN_cls_score)
         if (props_feat.is_cuda and props_feat.dtype == torch.float32 and _HEADS_KERNEL and self.RCNN_bbox_pred.out_features <= 8
-                and props_feat.shape[1] in (256, 512, 1024, 2048, 4096)):
+                and props_feat.shape[1] in (256, 512, 1024, 2048, 4096) and hooks_plain):
             # both heads in the library (csrc/heads.hip): no [bs*P, 4096] concatenation, no vendor GEMM under the logits
             bbox_pred, score = _HeadsFn.apply(props_feat, query_feat, self.RCNN_bbox_pred.weight, self.RCNN_bbox_pred.bias,
                                               self.RCNN_cls_score[0].weight, self.RCNN_cls_score[0].bias,
@@ -808,7 +826,7 @@ class _fasterRCNN(nn.Module):
                         else:
                             score = r
         else:
-            if props_feat.is_cuda and _HEADS_KERNEL:
+            if props_feat.is_cuda and _HEADS_KERNEL and hooks_plain:
                 ops.note_fallback("heads", props_feat)
             bbox_pred = self.RCNN_bbox_pred(props_feat)
             stack_feat = torch.cat((props_feat.view(bs, num_props, -1),

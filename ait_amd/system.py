@@ -420,7 +420,7 @@ _PART_PARAMS = (
 
 class _AitState:
     """what the three backward parts of one forward share (plain Python object: not a tensor, not saved by autograd)"""
-    __slots__ = ("fw", "ws", "W", "keep", "cfg", "shapes", "_dxq", "flags", "out16")
+    __slots__ = ("fw", "ws", "W", "keep", "cfg", "shapes", "_dxq", "flags", "out16", "fmt")
 
 
 def _grads_struct(views_by_index):
@@ -473,7 +473,7 @@ def _ait_backward_part(st, part, d_out, kept, want_dxp=False, want_dxq=False):
         want = torch.bfloat16 if st.flags & _lib.CTX_IO_BF16 else torch.float32
         rc = L.ait_transformer_bwd_part(part, None if d_out is None else _lib.dev_ptr(d_out, want), _lib.dev_ptr(xp),
                                         _lib.dev_ptr(xq), bp, bs, n_s, ctypes.byref(st.W), p, p_attn, seed,
-                                        ctypes.c_void_p(saved.data_ptr()), saved.numel(),
+                                        ctypes.c_void_p(saved.data_ptr()), saved.numel(), st.fmt,
                                         ctypes.c_void_p(st.ws.data_ptr()), st.ws.numel(),
                                         None if dxp is None else _lib.dev_ptr(dxp),
                                         None if dxq is None else _lib.dev_ptr(dxq), ctypes.byref(G),
@@ -501,12 +501,14 @@ class _AitCore(torch.autograd.Function):
                 st.flags |= _lib.CTX_IO_BF16
         io16 = bool(st.flags & _lib.CTX_IO_BF16)
         out = torch.empty((bp * SEQ, xp.shape[1]), dtype=torch.bfloat16 if io16 else torch.float32, device=dev)
+        fmt = ctypes.c_uint(0)
         with torch.cuda.device(dev):
             rc = L.ait_transformer_fwd_train(_lib.dev_ptr(xp), _lib.dev_ptr(xq), bp, bs, n_s, ctypes.byref(st.W),
                                              float(p), float(p_attn), int(seed), ctypes.c_void_p(saved.data_ptr()),
-                                             nbytes, _lib.dev_ptr(out, out.dtype), _lib.launch_ctx(dev, flags=st.flags),
-                                             _lib.cur_stream(dev))
+                                             nbytes, ctypes.byref(fmt), _lib.dev_ptr(out, out.dtype),
+                                             _lib.launch_ctx(dev, flags=st.flags), _lib.cur_stream(dev))
         _lib.check(rc, "ait_transformer_fwd_train")
+        st.fmt = fmt.value       # what the forward stored in which format: the backward parts must be handed this word
         # the multi-GB activation buffer and the two inputs are the NODES' saved tensors (all three nodes save the same
         # storages): autograd frees them when the graph is freed -- not when the Python state object dies -- and an
         # in-place change of x_props / x_query between forward and backward is detected

@@ -204,7 +204,7 @@ def pmc_traffic_per_launch(kernel_prefix="gemm_f32_"):
             "source": "profiles/%s + profiles/%s" % (out["fetch"][1], out["write"][1])}
 
 
-def spawn_ranks(n, argv, deadline_s=None, grace_s=10.0):
+def spawn_ranks(n, argv, deadline_s=None, grace_s=10.0, script=None):
     """`python bench.py --gpus N` outside a torch.distributed.run environment: this parent starts N fresh child
     processes of this same script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torchrun would:
     the reference's `python trainval_net_voc.py --mGPUs`, trainval_net_voc.py:83,321-326, is one command too),
@@ -254,7 +254,7 @@ def spawn_ranks(n, argv, deadline_s=None, grace_s=10.0):
                 if gloo:
                     env.setdefault("GLOO_SOCKET_IFNAME", "lo")
                 errs.append(tempfile.TemporaryFile(mode="w+"))
-                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env,
                                               stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=errs[-1]))
             # a rank that dies leaves the others inside a collective: stop them (by their exact PIDs) instead of
             # waiting for the collective's timeout

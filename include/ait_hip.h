@@ -680,15 +680,27 @@ int ait_ffn_bwd(const float* dy, const float* x, long long rows, const ait_ffn_w
 
 int ait_transformer_io_bf16_ok(int bp, int bs, int n_src);      /* see AIT_CTX_IO_BF16 */
 size_t ait_transformer_saved_bytes(int bp, int bs, int n_src);
+/* The STORAGE FORMAT of `saved` (ABI v7).  Under AIT_CTX_BF16 / AIT_CTX_IO_BF16 the training forward stores some of its
+ * activations as bf16 -- which ones depends on the flags and on the sizes.  It reports its decisions in *saved_format
+ * (required, host memory; written before any launch): a magic in the top 12 bits plus the AIT_SAVED_* bits below.  The
+ * caller hands that word to the backward of the SAME step; a backward whose own ctx implies another format (flags changed
+ * between the two calls, another ctx) returns AIT_EINVAL instead of reading bf16 bytes as f32 or the reverse.  A word that
+ * did not come from ait_transformer_fwd_train (wrong magic) is AIT_EINVAL too. */
+#define AIT_SAVED_ENC_QKV16 1u     /* encoder self-attention: q / k / v and the block's input copy stored as bf16 */
+#define AIT_SAVED_DEC_QKV16 2u     /* decoder self-attention: likewise */
+#define AIT_SAVED_X_QKV16 4u       /* decoder cross-attention: likewise */
+#define AIT_SAVED_ENC_FFN16 8u     /* encoder feed-forward: hidden tensor, input copy and weight copies stored as bf16 */
+#define AIT_SAVED_DEC_FFN16 16u    /* decoder feed-forward: likewise */
+#define AIT_SAVED_IO16 32u         /* dec_trans: bf16 copy of its input kept, `out` / `d_out` are bf16 tensors */
 int ait_transformer_fwd_train(const float* x_props, const float* x_query, int bp, int bs, int n_src,
                               const ait_transformer_weights* w, float p_drop, float p_attn_drop,
-                              unsigned long long seed, void* saved, size_t saved_bytes, float* out,
-                              const ait_launch_ctx* ctx, void* stream);
+                              unsigned long long seed, void* saved, size_t saved_bytes, unsigned* saved_format,
+                              float* out, const ait_launch_ctx* ctx, void* stream);
 size_t ait_transformer_bwd_workspace_bytes(int bp, int bs, int n_src);
 int ait_transformer_bwd(const float* d_out, const float* x_props, const float* x_query, int bp, int bs,
                         int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
-                        unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
-                        size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                        unsigned long long seed, const void* saved, size_t saved_bytes, unsigned saved_format,
+                        void* workspace, size_t workspace_bytes, float* d_x_props, float* d_x_query,
                         const ait_transformer_grads* grads, const ait_launch_ctx* ctx, void* stream);
 /* The same backward in THREE calls, for a data-parallel caller that wants the parameter gradients in bursts it can
  * hand to the gradient all-reduce while the rest of the backward still runs (trainval_net_voc.py:321-326,391-395:
@@ -699,8 +711,8 @@ int ait_transformer_bwd(const float* d_out, const float* x_props, const float* x
  * a part only touches the `grads` members of its own layers (the others may be NULL). */
 int ait_transformer_bwd_part(int part, const float* d_out, const float* x_props, const float* x_query, int bp, int bs,
                              int n_src, const ait_transformer_weights* w, float p_drop, float p_attn_drop,
-                             unsigned long long seed, const void* saved, size_t saved_bytes, void* workspace,
-                             size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                             unsigned long long seed, const void* saved, size_t saved_bytes, unsigned saved_format,
+                             void* workspace, size_t workspace_bytes, float* d_x_props, float* d_x_query,
                              const ait_transformer_grads* grads, const ait_launch_ctx* ctx, void* stream);
 
 /* ---------------------------------------------------------------------------------------

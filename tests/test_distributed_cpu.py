@@ -107,7 +107,8 @@ RS_AG_WORKER = textwrap.dedent("""
         torch.manual_seed(0)
         net = Net()
         ddp = D.wrap(net, local_rank, bucket_mb=1)
-        clock = D.BucketClock(ddp, kind, inner=D.make_exchange_hook(kind, rs, ag))
+        inner = D.make_exchange_hook(kind, rs, ag)
+        clock = D.BucketClock(ddp, kind, inner=inner)
         torch.manual_seed(100 + rank)
         x = torch.randn(5, 7)
         for _ in range(3):
@@ -115,6 +116,8 @@ RS_AG_WORKER = textwrap.dedent("""
             clock.start()
             ddp(x).pow(2).sum().backward()
         assert clock.summary()["buckets"] >= 1 and clock.exchange == kind
+        if kind == "rs_ag":                     # one padded copy + one shard per bucket, allocated once
+            assert len(inner.cache) >= 1 and all(b[1] is not None and b[1].numel() == 92 and b[2].numel() == 46 for b in inner.cache.values())
         grads[kind] = torch.cat([p.grad.flatten() for p in net.parameters()])
     assert torch.allclose(grads["rs_ag"], grads["allreduce"], rtol=1e-6, atol=1e-7), (grads["rs_ag"] - grads["allreduce"]).abs().max()
     assert float(grads["rs_ag"].abs().max()) > 0
@@ -175,3 +178,96 @@ def test_bench_gpus_n_spawns_ranks_and_refuses_a_mismatch():
     assert r.returncode == 1 and "rank exit codes" in r.stderr and "{" not in r.stdout
     r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_spawn_ranks_cannot_hang(tmp_path, monkeypatch):
+    """bench.spawn_ranks: a rank that ignores SIGTERM after another one failed is killed after the grace period; a job
+    that never finishes is killed at its deadline (exit code 124); neither returns a JSON line"""
+    import importlib
+    import time
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    monkeypatch.setenv("AIT_DIST_BACKEND", "gloo")
+    stubborn = tmp_path / "stubborn.py"
+    stubborn.write_text(textwrap.dedent("""
+        import os, signal, sys, time
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)          # like a rank stuck inside a collective
+        if os.environ["RANK"] == "1" and sys.argv[1] == "fail":
+            sys.exit(3)
+        print('{"not": "a result"}', flush=True)
+        time.sleep(600)
+    """))
+    t0 = time.monotonic()
+    assert bench.spawn_ranks(2, ["fail"], deadline_s=120, grace_s=1.0, script=str(stubborn)) == 1
+    assert time.monotonic() - t0 < 30
+    t0 = time.monotonic()
+    assert bench.spawn_ranks(2, ["sleep"], deadline_s=2.0, grace_s=1.0, script=str(stubborn)) == 124
+    assert time.monotonic() - t0 < 30
+
+
+def test_spawn_ranks_retries_when_the_port_was_taken(tmp_path, monkeypatch, capfd):
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    monkeypatch.setenv("AIT_DIST_BACKEND", "gloo")
+    flag = tmp_path / "second_try"
+    script = tmp_path / "once_busy.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        flag = %r
+        if not os.path.exists(flag):
+            if os.environ["RANK"] == "0":
+                open(flag, "w").close()
+                sys.stderr.write("RuntimeError: The server socket has failed to listen ... EADDRINUSE: address already in use\\n")
+                sys.exit(1)
+            import time; time.sleep(30)
+        if os.environ["RANK"] == "0":
+            print('{"ok": %%s}' %% os.environ["MASTER_PORT"])
+    """ % str(flag)))
+    assert bench.spawn_ranks(2, [], deadline_s=60, grace_s=1.0, script=str(script)) == 0
+    out = capfd.readouterr()
+    assert '{"ok": ' in out.out and "starting the ranks again" in out.err
+
+
+def _fake_sysfs(root, gpus):
+    """gpus: list of (domain, bus, numa_node, cpulist); KFD node 0 is the CPU"""
+    top = root / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    (top / "0").mkdir(parents=True)
+    (top / "0" / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\n")
+    for i, (dom, bus, node, cpus) in enumerate(gpus):
+        d = top / str(i + 1)
+        d.mkdir()
+        d.joinpath("properties").write_text("cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain %d\n" % (bus << 8, dom))
+        p = root / "bus" / "pci" / "devices" / ("%04x:%02x:00.0" % (dom, bus))
+        p.mkdir(parents=True)
+        p.joinpath("numa_node").write_text("%d\n" % node)
+        p.joinpath("local_cpulist").write_text(cpus + "\n")
+
+
+def test_rank_binding_follows_the_gpus_numa_node(tmp_path, monkeypatch):
+    """ait_amd.distributed.bind_rank_to_gpu_numa: sysfs only (KFD topology -> PCI function -> numa_node / local_cpulist);
+    ranks sharing a node split its cores; visible-device lists are honoured; a silent sysfs leaves the process alone"""
+    import os as _os
+    from ait_amd import distributed as D
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    _fake_sysfs(tmp_path, [(0, 0x05, 0, "0-3"), (0, 0x15, 0, "0-3"), (0, 0x85, 1, "4-7"), (0, 0x95, 1, "4-7")])
+    monkeypatch.setattr(_os, "sched_getaffinity", lambda pid: set(range(8)))
+    assert D.gpu_numa_cpus(2, str(tmp_path)) == (1, {4, 5, 6, 7})
+    got = []
+    r = D.bind_rank_to_gpu_numa(3, 4, str(tmp_path), setaffinity=got.append)
+    assert r["bound"] and r["numa_node"] == 1 and r["ranks_on_node"] == 2 and got == [{6, 7}]
+    got = []
+    r = D.bind_rank_to_gpu_numa(0, 1, str(tmp_path), setaffinity=got.append)
+    assert r["bound"] and got == [{0, 1, 2, 3}]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,3")
+    assert D.gpu_numa_cpus(0, str(tmp_path)) == (1, {4, 5, 6, 7})
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-abcdef")
+    assert D.gpu_numa_cpus(0, str(tmp_path)) == (None, None)
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    got = []
+    r = D.bind_rank_to_gpu_numa(0, 1, str(tmp_path / "nothing_here"), setaffinity=got.append)
+    assert not r["bound"] and got == []
+    monkeypatch.setattr(_os, "sched_getaffinity", lambda pid: {0, 1})          # a cgroup that excludes the GPU's node
+    r = D.bind_rank_to_gpu_numa(2, 4, str(tmp_path), setaffinity=got.append)
+    assert not r["bound"] and got == []

@@ -407,6 +407,64 @@ def test_transformer_bf16_mode_with_a_bf16_output_matches_its_f32_output():
         t.out_bf16 = False
 
 
+def test_backward_refuses_a_saved_buffer_of_another_storage_format():
+    """ABI v7: ait_transformer_fwd_train reports which of its saved tensors it stored as bf16 (AIT_SAVED_* bits
+    behind a magic); the backward is handed that word and returns AIT_EINVAL -- instead of reading bf16 bytes as f32 -- when
+    its own ctx implies another format, or when the word did not come from the forward."""
+    import ctypes
+    from ait_amd import _lib, system
+    L = _lib.lib()
+    t = _transformer(3).train()
+    bs, P = 2, 3
+    xp, xq = _dev(seeded(401, (bs * P, 1024, 7, 7))), _dev(seeded(402, (bs, 1024, 8, 8)))
+    dev = xp.device
+    fmts = {}
+    for name, flags in (("f32", 0), ("bf16", _lib.CTX_BF16)):
+        st = system._AitState.__new__(system._AitState)
+        st.W, st.keep, _ = t._c_weights()
+        nbytes = int(L.ait_transformer_saved_bytes(bs * P, bs, 49))
+        saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty((bs * P * 64, 1024), device=dev)
+        tok = xp.permute(0, 2, 3, 1).reshape(-1, 1024).contiguous()
+        tq = xq.permute(0, 2, 3, 1).reshape(-1, 1024).contiguous()
+        fmt = ctypes.c_uint(0)
+        assert L.ait_transformer_fwd_train(_lib.dev_ptr(tok), _lib.dev_ptr(tq), bs * P, bs, 49, ctypes.byref(st.W), 0.0, 0.0, 7,
+                                           ctypes.c_void_p(saved.data_ptr()), nbytes, None, _lib.dev_ptr(out),
+                                           _lib.launch_ctx(dev, flags=flags), _lib.cur_stream(dev)) == -1      # the word is required
+        rc = L.ait_transformer_fwd_train(_lib.dev_ptr(tok), _lib.dev_ptr(tq), bs * P, bs, 49, ctypes.byref(st.W), 0.0, 0.0, 7,
+                                         ctypes.c_void_p(saved.data_ptr()), nbytes, ctypes.byref(fmt), _lib.dev_ptr(out),
+                                         _lib.launch_ctx(dev, flags=flags), _lib.cur_stream(dev))
+        assert rc == 0, rc
+        assert fmt.value >> 20 == 0xA17
+        fmts[name] = (fmt.value, saved, st, tok, tq)
+    assert fmts["f32"][0] & 0xFFFFF == 0 and fmts["bf16"][0] & 0xFFFFF != 0, [hex(v[0]) for v in fmts.values()]
+    wbytes = int(L.ait_transformer_bwd_workspace_bytes(bs * P, bs, 49))
+    ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    d_out = torch.ones((bs * P * 64, 1024), device=dev)
+
+    def bwd(which, fmt_word, flags):
+        _, saved, st, tok, tq = fmts[which]
+        flat = torch.zeros(8338944, device=dev)
+        views, o = {}, 0
+        for i, p in enumerate(t._param_list()):
+            views[i] = flat[o:o + p.numel()].view(p.shape)
+            o += p.numel()
+        G = system._grads_struct(views)
+        dxp, dxq = torch.empty_like(tok), torch.empty_like(tq)
+        return L.ait_transformer_bwd(_lib.dev_ptr(d_out), _lib.dev_ptr(tok), _lib.dev_ptr(tq), bs * P, bs, 49, ctypes.byref(st.W),
+                                     0.0, 0.0, 7, ctypes.c_void_p(saved.data_ptr()), saved.numel(), fmt_word,
+                                     ctypes.c_void_p(ws.data_ptr()), wbytes, _lib.dev_ptr(dxp), _lib.dev_ptr(dxq), ctypes.byref(G),
+                                     _lib.launch_ctx(dev, flags=flags), _lib.cur_stream(dev))
+
+    EINVAL = -1
+    assert bwd("f32", fmts["f32"][0], 0) == 0
+    assert bwd("bf16", fmts["bf16"][0], _lib.CTX_BF16) == 0
+    assert bwd("bf16", fmts["bf16"][0], 0) == EINVAL                  # the forward stored bf16, this ctx would read f32
+    assert bwd("f32", fmts["f32"][0], _lib.CTX_BF16) == EINVAL        # and the reverse
+    assert bwd("f32", 0, 0) == EINVAL and bwd("f32", 0x12345, 0) == EINVAL      # not a word the forward reported
+    torch.cuda.synchronize()
+
+
 def test_transformer_full_size_is_batch_invariant_and_linear_in_the_cotangent():
     """BASELINE cfg2 size (4 pairs x 300 proposals = 1200 sequences) -- beyond what the CPU oracle
     finishes in seconds, so checked through size-independent properties: every proposal's output

@@ -230,23 +230,46 @@ def test_cfg2_full_size_ait_output_vs_oracle():
     names = list(params)                       # (the module's parameter order; the state_dict's differs)
     assert sorted(names) == sorted(k for k in sdr if "pos_table" not in k)
     want_p = [torch.zeros_like(sdr[n]) for n in names]
-    want_xp, want_xq = [], []
+    want_xp, want_xq, margin_seq = [], [], []
     for b in range(bs):
         a = xp[b * P:(b + 1) * P].clone().requires_grad_(True)
         q = xq[b:b + 1].clone().requires_grad_(True)
-        yb = ait_ref.transformer_forward(sdr, a, q)
+        yb, inter = ait_ref.transformer_forward(sdr, a, q, return_intermediates=True)
+        margin_seq.append(inter["relu_margin_seq"])
         gb = torch.autograd.grad(yb, [a, q] + [sdr[n] for n in names], cot[b * P:(b + 1) * P])
         want_xp.append(gb[0]); want_xq.append(gb[1])
         for acc, g_ in zip(want_p, gb[2:]):
             acc += g_
     wants = [torch.cat(want_xp), torch.cat(want_xq)] + want_p
+    # ---- WHERE the out-of-band elements are.  d x_props is per sequence: a sequence all of whose
+    # 2 x 64 x 2048 feed-forward pre-activations sit further from zero than the products' rounding (the oracle's
+    # relu_margin_seq >= TAU) takes the same side of every ReLU here and there, and EVERY element of its gradient must be
+    # inside the band; only the sequences with a pre-activation within TAU of the kink may differ, by about one hidden unit's
+    # share.  So: (1) no out-of-band element outside those sequences, (2) inside them the error stays bounded.
+    TAU = 2e-6
+    margin_seq = torch.cat(margin_seq)
+    gx, wx = got[0].cpu().reshape(bs * P, -1), wants[0].reshape(bs * P, -1)
+    band = 1e-3 * float(wx.pow(2).mean().sqrt()) + 1e-4 * wx.abs()
+    bad_elems = ((gx - wx).abs() > band).sum(1)
+    rel_seq = (gx - wx).norm(dim=1) / wx.norm(dim=1)
+    suspect = margin_seq < TAU
+    order = torch.argsort(rel_seq, descending=True)[:24]
+    print("sequences by error: (rel, out-of-band elements, oracle relu margin)",
+          [(round(float(rel_seq[i]), 6), int(bad_elems[i]), float(margin_seq[i])) for i in order])
+    print("suspect sequences (margin < %g): %d of %d; sequences with out-of-band elements: %d; clean sequences' worst rel %.3g"
+          % (TAU, int(suspect.sum()), bs * P, int((bad_elems > 0).sum()), float(rel_seq[~suspect].max())))
+    assert int(bad_elems[~suspect].sum()) == 0, "out-of-band gradient elements in sequences no ReLU of which is near its kink"
+    assert float(rel_seq[~suspect].max()) < 1e-4
+    assert float(rel_seq[suspect].max()) < 0.2 and int((bad_elems > 0).sum()) <= 0.05 * bs * P
     for n, g_, w_ in zip(["x_props", "x_query"] + names, got, wants):
         g_ = g_.cpu()
         rel = float((g_ - w_).norm() / (w_.norm() + 1e-30))
         # (band: 1e-4 relative + 1e-3 of the tensor's RMS -- these gradients are sums over 76800 token rows)
         out = float(((g_ - w_).abs() > 1e-3 * float(w_.pow(2).mean().sqrt()) + 1e-4 * w_.abs()).float().mean())
         # (measured: rel 3e-4 .. 4e-4; about 1 % of d x_props outside the band -- the rows of the dozen sequences
-        # one of whose 3e8 ReLU pre-activations fell on the other side of zero)
+        # one of whose 3e8 ReLU pre-activations fell on the other side of zero: located above.  d x_query and the
+        # parameter gradients SUM over sequences, so a flipped one touches every element a little)
+        print("cfg2-size gradient", n, "rel", rel, "out-of-band share", out)
         assert rel < 1e-3 and out < 3e-2, (n, rel, out)
     pair = 2
     with torch.no_grad():

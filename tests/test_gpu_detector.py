@@ -261,6 +261,90 @@ def test_detector_train_step_gradients_vs_oracle(model):
         assert rel < 5e-3, (k, rel)
 
 
+WATCH18 = ["transformer.encoder.layer_stack.0.slf_attn.w_qs.weight", "transformer.dec_trans.0.bias",
+           "RCNN_cls_score.1.weight", "coattention.img_trans.0.weight", "RCNN_rpn.RPN_Conv.bias",
+           "RCNN_base.backbone.layer3.5.conv3.weight", "transformer.enc_emb.0.weight",
+           "RCNN_top.0.0.conv1.weight", "RCNN_top.0.0.conv2.weight", "RCNN_top.0.0.conv3.weight",
+           "RCNN_top.0.2.conv1.weight", "RCNN_top.0.2.conv2.weight", "RCNN_top.0.2.conv3.weight",
+           "RCNN_top.0.0.downsample.0.weight",
+           "sk.sk_props.convs.0.0.weight", "sk.sk_props.convs.0.0.bias",
+           "sk.sk_props.convs.1.0.weight", "sk.sk_props.convs.1.0.bias"]
+
+
+def test_detector_headline_size_eval_logits_vs_oracle(model):
+    """The headline shape -- one 600x1000 target, one 128x128 query, 300 proposals (BASELINE configs[1] per pair) -- in
+    eval(): EVERY one of the 300 similarity logits (faster_rcnn_sys_transformer_sk_dilat.py:277-290) within 1e-4 relative
+    (+2e-6) of the CPU oracle's, on the oracle's own proposals injected behind the proposal layer (the cfg1 test's recipe:
+    no dependence on a GPU-vs-CPU exp() ulp in the box decode); cls_prob and bbox_pred with them."""
+    from ait_amd import ops
+    from ait_amd.config import cfg
+    cfg.TEST.RPN_POST_NMS_TOP_N = 300
+    cfgd = D.default_config()
+    cfgd["TEST"]["RPN_POST_NMS_TOP_N"] = 300
+    sd = D.make_detector_state_dict(9, D.reference_shapes())
+    ins = D.synth_inputs(1, 2201)
+    with torch.no_grad():
+        want, aux = D.detector_forward(sd, cfgd, *ins, False)
+    assert tuple(want[0].shape) == (1, 300, 5) and tuple(aux["score"].shape) == (300, 2)
+    model.eval()
+    feats = {}
+    h = model.RCNN_cls_score.register_forward_hook(lambda m, i, o: feats.__setitem__("score", o))
+    ops.reset_fallbacks()
+    try:
+        with torch.no_grad(), _reference_proposals(model, want[0].numpy()):
+            got = model(*[t.cuda() for t in ins])
+    finally:
+        h.remove()
+    assert ops.fallback_count() == 0, dict(ops.FALLBACKS)
+    assert np.array_equal(got[0].cpu().numpy(), want[0].numpy())
+    score, ref = feats["score"].cpu().numpy(), aux["score"].numpy()
+    err = np.abs(score - ref) / (1e-4 * np.abs(ref) + 2e-6)
+    print("P=300 logits: worst error / tolerance", float(err.max()), "logit range", float(ref.min()), float(ref.max()))
+    np.testing.assert_allclose(score, ref, rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(got[1].cpu().numpy(), want[1].numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got[2].cpu().numpy(), want[2].numpy(), rtol=1e-3, atol=2e-6)
+
+
+def test_detector_headline_size_train_step_vs_oracle(model):
+    """The same pair in train() (TRAIN.BATCH_SIZE = 300 sampled RoIs, dropout off): the sampled RoIs and labels identical,
+    the five losses within 2e-4, and the gradients of the 18 watched parameters (AIT, heads, co-attention, RPN, trunk,
+    every convolution of layer4's first and last bottleneck, both SK branches) within 1e-3 relative L2 of the oracle's
+    backward -- the step the timed region runs, at its size (faster_rcnn_sys_transformer_sk_dilat.py:277-314)."""
+    from ait_amd.config import cfg
+    cfg.TRAIN.BATCH_SIZE = 300
+    cfgd = D.default_config()
+    cfgd["TRAIN"]["BATCH_SIZE"] = 300
+    sd = {k: v.clone() for k, v in D.make_detector_state_dict(9, D.reference_shapes()).items()}
+    watch = [k for k in WATCH18 if k in sd]
+    assert len(watch) == 18, watch
+    for k in watch:
+        sd[k].requires_grad_(True)
+    ins = D.synth_inputs(1, 2201)
+    np.random.seed(3)
+    out, aux = D.detector_forward(sd, cfgd, *ins, True)
+    assert tuple(out[0].shape) == (1, 300, 5)
+    (out[3] + out[4] + out[5] + out[6] + out[7]).backward()
+    model.train()
+    with _dropout_off(model), _reference_proposals(model, aux["rpn_rois"].numpy()):
+        model.zero_grad(set_to_none=True)
+        np.random.seed(3)
+        res = model(*[t.cuda() for t in ins])
+        (res[3] + res[4] + res[5] + res[6] + res[7]).backward()
+    np.testing.assert_allclose(res[0].cpu().numpy(), out[0].numpy(), rtol=0, atol=1e-4)
+    assert np.array_equal(res[8].cpu().numpy(), out[8].numpy())
+    for i in range(3, 8):
+        assert abs(float(res[i]) - float(out[i])) <= 2e-4 * abs(float(out[i])) + 2e-6, (i, float(res[i]), float(out[i]))
+    np.testing.assert_allclose(res[1].detach().cpu().numpy(), out[1].detach().numpy(), rtol=1e-4, atol=1e-6)
+    params = dict(model.named_parameters())
+    rels = {}
+    for k in watch:
+        pk = k if k in params else "RCNN_base.backbone.layer4." + k[len("RCNN_top.0."):]
+        got, want = params[pk].grad.cpu(), sd[k].grad
+        rels[k] = float((got - want).norm() / (want.norm() + 1e-12))
+    print("P=300 train step, relative L2 of the watched gradients:", {k: round(v, 6) for k, v in rels.items()})
+    assert max(rels.values()) < 1e-3, rels
+
+
 def test_detector_coco_variant(golden):
     """COCO variant (faster_rcnn_coatt_transformer_sk.py): non-local co-attention, A = 12."""
     from ait_amd import config

@@ -158,3 +158,160 @@ def test_bench_gpus_2_starts_its_own_two_ranks():
     assert 0 <= dev["first_ready_ms"] <= dev["last_ready_ms"] <= dev["backward_end_ms"] + 1e-3
     assert dev["first_ready_ms"] < 0.6 * dev["backward_end_ms"], dev
     assert line["value"] > 0 and line["roofline"]["achieved"] > 0
+
+
+# ---- the same code on RCCL ------------------------------------------------------------------------------------------
+# The box of the GPU tests has ONE GPU and RCCL refuses two ranks on one device, so the N > 1 tests above run over gloo.
+# AIT_FORCE_DDP=1 makes ait_amd.distributed build its process group and its DDP wrapper at WORLD_SIZE 1 too: then
+# init_process_group, DDP's reducer, both bucket hooks, reduce_scatter_tensor / all_gather_into_tensor, the barrier and the
+# max-over-ranks all-reduce execute on a real `nccl` (= RCCL) group.  The same worker runs with two real ranks where the
+# box has two GPUs.
+RCCL_WORKER = textwrap.dedent("""
+    import faulthandler, os, sys
+    faulthandler.dump_traceback_later(200, exit=True)
+    sys.path.insert(0, %r)
+    kind = sys.argv[1]
+    import numpy as np, torch, torch.distributed as dist
+    from ait_amd import distributed as D, _lib
+    from ait_amd.config import cfg_from_list
+    from ait_amd.faster_rcnn import resnet
+    from oracle import detector_ref as R          # (synthetic inputs only)
+    rank, local_rank, world = D.init()
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and D.active() and dist.get_world_size() == world
+    _lib.lib()
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    cfg_from_list(['TRAIN.BATCH_SIZE', 32])
+    torch.manual_seed(1234)
+    m = resnet(('__background__', 'fg'), 50, pretrained=False, class_agnostic=True, num_K=3)
+    m.create_architecture()
+    m = m.to(dev).train()
+    for mod in m.modules():
+        if hasattr(mod, "p") and isinstance(mod.p, float):
+            mod.p = 0.0
+    ins = [t.to(dev) for t in R.synth_inputs(1, 500 + rank, im_hw=(320, 480))]
+    watch = ["transformer.encoder.layer_stack.0.slf_attn.w_qs.weight", "transformer.dec_trans.0.bias",
+             "transformer.enc_emb.0.weight", "RCNN_cls_score.1.weight", "RCNN_bbox_pred.weight",
+             "coattention.img_trans.0.weight", "RCNN_rpn.RPN_Conv.bias", "RCNN_base.backbone.layer4.2.conv3.weight",
+             "RCNN_base.backbone.layer3.5.conv3.weight", "sk.sk_props.convs.1.0.weight"]
+    params = dict(m.named_parameters())
+    clock = None
+
+    def step(model):
+        m.zero_grad(set_to_none=True)
+        np.random.seed(3 + rank)
+        out = model(*ins)
+        cost = out[3] + out[4] + out[5] + out[6] + out[7]
+        if clock is not None:
+            clock.start()
+        cost.backward()
+        if clock is not None:
+            clock.stop()
+        return {k: params[k].grad.detach().clone() for k in watch}
+
+    alone = step(m)                                # this rank's own gradient, no exchange
+    ddp = D.wrap(m, local_rank, bucket_mb=8)
+    assert ddp is not m and type(ddp).__name__ == "DistributedDataParallel"
+    calls = {"rs": 0, "ag": 0}
+    def rs(shard, flat, group):
+        calls["rs"] += 1
+        return D._rs_future(shard, flat, group)    # dist.reduce_scatter_tensor on RCCL
+    def ag(flat, shard, group):
+        calls["ag"] += 1
+        return D._ag_future(flat, shard, group)    # dist.all_gather_into_tensor on RCCL
+    inner = D.make_exchange_hook(kind, rs, ag)
+    clock = D.BucketClock(ddp, kind, inner=inner)
+    ddp._ait_exchange = kind
+    ptrs = None
+    for it in range(4):                            # static_graph settles (and rebuilds its buckets) in the first iterations
+        got = step(ddp)
+        if kind == "rs_ag" and it >= 2:
+            now = sorted((i, b[2].data_ptr()) for i, b in inner.cache.items())
+            assert ptrs is None or ptrs == now, "the exchange's shard buffers were allocated again"
+            ptrs = now
+    torch.cuda.synchronize()
+    s = clock.summary()
+    print("rank", rank, kind, "buckets", s, "collective calls", calls, flush=True)
+    assert s["buckets"] >= 4
+    assert 0 <= s["device"]["first_ready_ms"] <= s["device"]["last_ready_ms"] <= s["device"]["backward_end_ms"] + 1e-3
+    if kind == "rs_ag":
+        assert calls["rs"] == calls["ag"] and calls["rs"] >= s["buckets"], calls
+        assert len(inner.cache) >= s["buckets"]
+    desc = D.collective_description(ddp)
+    assert "backend nccl" in desc and "RCCL" in desc and ("reduce-scatter" in desc) == (kind == "rs_ag"), desc
+    assert params["RCNN_base.backbone.fc.weight"].grad is None
+    for k in watch:
+        mine = [torch.zeros_like(alone[k]) for _ in range(world)]
+        dist.all_gather(mine, alone[k])            # (RCCL)
+        mean = sum(mine) / world
+        rel = float((got[k] - mean).norm() / (mean.norm() + 1e-20))
+        print("rank", rank, k, "rel", rel, flush=True)
+        # (split-K weight-gradient kernels sum with atomics: two runs of one step differ by ~1e-4 relative)
+        assert rel < 1e-3, (k, rel)
+        assert float(mean.norm()) > 0
+    assert D.max_over_ranks(1.0 + rank, dev) == float(world)
+    D.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def _run_rccl_ranks(tmp_path, kind, world):
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % ROOT)
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = {k: v for k, v in os.environ.items() if k != "AIT_DIST_BACKEND"}
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", AIT_FORCE_DDP="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), kind], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append(p.communicate()[0])
+    report = "\n".join("---- rank %d (exit %s) ----\n%s" % (r, p.returncode, o[-4000:]) for r, (p, o) in enumerate(zip(procs, outs)))
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, report)
+        assert "rank %d ok" % r in o
+
+
+@pytest.mark.parametrize("kind", ["allreduce", "rs_ag"])
+def test_one_rank_rccl_group_runs_ddp_and_both_bucket_exchanges(tmp_path, kind):
+    """trainval_net_voc.py:321-326,391-395's replacement on RCCL itself: a world-size-1 `nccl` process group, the real
+    detector under DDP, the default all-reduce hook and the reduce-scatter + all-gather hook (their RCCL calls counted);
+    gradients equal the unwrapped model's."""
+    _run_rccl_ranks(tmp_path, kind, 1)
+
+
+@pytest.mark.parametrize("kind", ["allreduce", "rs_ag"])
+def test_two_ranks_on_two_gpus_over_rccl(tmp_path, kind):
+    """the same worker as two real RCCL ranks, one per GPU, where the box has two (the driver's GPU-test box has one: skipped
+    there): gradients equal the mean of the per-rank gradients under both exchanges"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_rccl_ranks(tmp_path, kind, 2)
+
+
+def test_bench_force_ddp_reports_an_rccl_collective():
+    """`bench.py --gpus 1 --force-ddp` in a fresh child: the bench's own N > 1 code (wrap, bucket clock, barrier, max over
+    ranks) on a one-rank RCCL group; the line says so."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "AIT_DIST_BACKEND", "AIT_FORCE_DDP")}
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-ab", "--force-ddp"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and "backend nccl" in line["config"]["collective"] and "WORLD SIZE 1" in line["config"]["collective"]
+    assert line["config"]["gradient_buckets"]["buckets"] >= 4
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and line["step_ms"]["min"] <= line["ms_per_step"] <= line["step_ms"]["max"]

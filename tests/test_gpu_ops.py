@@ -745,6 +745,16 @@ def test_round5_entry_points_check_their_arguments():
     assert core(0, 64, 0.0, None) == OK
     assert core(1, 64, 0.0, None) == EINVAL and core(1, 0, 0.0, vp(t)) == EINVAL and core(1, 65, 0.0, vp(t)) == EINVAL
     assert core(1, 64, 1.0, vp(t)) == EINVAL and core(-1, 64, 0.0, vp(t)) == EINVAL
+    # ... and so are rows narrower than the eight heads' 512 columns, pitches that are not whole 16-byte vectors and
+    # misaligned bases, on the inputs and on the outputs (EUNSUPPORTED, not a fault)
+    core2 = lambda q, ldq, dq, lddq: L.ait_mha_core_bwd(vp(t), vp(t), vp(t), vp(t), vp(t), q, ldq, vp(t), 1536, vp(t), 1536, vp(t), 1, 64,
+                                                        f(0.125), f(0.0), 1, dq, lddq, vp(t), 1536, vp(t), 1536, vp(t), st)
+    off = ctypes.c_void_p(t.data_ptr() + 4)
+    assert core2(vp(t), 1536, vp(t), 1536) == OK
+    assert core2(vp(t), 256, vp(t), 1536) == EUNSUPPORTED and core2(vp(t), 1538, vp(t), 1536) == EUNSUPPORTED
+    assert core2(off, 1536, vp(t), 1536) == EUNSUPPORTED
+    assert core2(vp(t), 1536, vp(t), 510) == EUNSUPPORTED and core2(vp(t), 1536, vp(t), 1537) == EUNSUPPORTED
+    assert core2(vp(t), 1536, off, 1536) == EUNSUPPORTED
 
 
 def test_frozen_bn_residual_relu_on_bf16_tensors_matches_float_arithmetic():

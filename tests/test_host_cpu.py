@@ -193,3 +193,27 @@ def test_three_way_bf16_split_is_exact_and_six_terms_reach_f32_accuracy():
     _, m_n, l_n = split(pos, rne_bf16)
     assert (m_t >= 0).all() and (l_t >= 0).all() and float(m_t.mean()) > 1e-3
     assert abs(float(m_n.astype(f).mean())) < 2e-5 and 0.4 < float((m_n > 0).mean()) < 0.6 and 0.4 < float((l_n > 0).mean()) < 0.6
+
+
+def test_fused_heads_path_defers_to_torch_for_hooks_it_cannot_call():
+    """ait_amd.faster_rcnn._only_plain_forward_hooks: the fused heads kernel calls plain forward hooks on the
+    two head modules by hand; anything else -- pre-hooks, kwargs / always-call hooks, backward hooks, a hook on a child of
+    RCNN_cls_score -- must send the heads through their modules"""
+    import torch.nn as nn
+    from ait_amd.faster_rcnn import _only_plain_forward_hooks as plain
+    mk = lambda: nn.Sequential(nn.Linear(4, 3), nn.Linear(3, 2))
+    m = mk()
+    assert plain(m)
+    h = m.register_forward_hook(lambda mod, a, o: None)
+    assert plain(m)
+    h.remove()
+    for reg in (lambda m: m.register_forward_pre_hook(lambda mod, a: None),
+                lambda m: m.register_forward_hook(lambda mod, a, k, o: None, with_kwargs=True),
+                lambda m: m.register_forward_hook(lambda mod, a, o: None, always_call=True),
+                lambda m: m.register_full_backward_hook(lambda mod, gi, go: None),
+                lambda m: m[1].register_forward_hook(lambda mod, a, o: None)):
+        m = mk()
+        h = reg(m)
+        assert not plain(m)
+        h.remove()
+        assert plain(m)

@@ -417,17 +417,25 @@ def main():
                   "min": step_ms[0], "max": step_ms[-1],
                   "clock": "HIP events on the step's stream, one pair per step%s" % ("; median = max over ranks of the per-rank medians" if world > 1 else "")}
 
-    # what the library's event brackets around every GEMM / RoIAlign launch cost the timed region: the same steps once
-    # more WITHOUT the probe, outside the timed region (every rank runs them: the steps hold collectives)
-    n_np = max(1, min(args.steps, 10))
+    # what the library's event brackets around every GEMM / RoIAlign launch cost the timed region: further steps outside it,
+    # ALTERNATING with and without the brackets (the chip's clock drifts over seconds, so two back-to-back blocks of steps
+    # would measure the drift), each between two events; the difference of the two medians (every rank runs them: the steps
+    # hold collectives)
+    n_np = max(2, min(args.steps, 10))
+    probe2 = _lib.Probe(1024 * n_np)
+    marks2 = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_np + 1)]
     D.barrier()
-    torch.cuda.synchronize()
-    tn = time.perf_counter()
-    for _ in range(n_np):
-        step()
+    with probe2:
+        for i in range(2 * n_np):
+            _lib._ACTIVE_PROBE = probe2 if i % 2 == 0 else None
+            marks2[i].record()
+            step()
+        marks2[2 * n_np].record()
     torch.cuda.synchronize()
     D.barrier()
-    noprobe_ms = D.max_over_ranks(time.perf_counter() - tn, device) / n_np * 1e3
+    t_on = sorted(marks2[i].elapsed_time(marks2[i + 1]) for i in range(0, 2 * n_np, 2))
+    t_off = sorted(marks2[i].elapsed_time(marks2[i + 1]) for i in range(1, 2 * n_np, 2))
+    probe_overhead_ms = med(t_on) - med(t_off)
 
     # A/B beside the headline, OUTSIDE its timed region (every rank runs it: the steps hold collectives): the same step
     # with the AIT's products on the instruction that multiplies f32 operands (v_mfma_f32_32x32x2_f32)
@@ -502,9 +510,10 @@ def main():
         "steps": args.steps, "warmup": args.warmup,
         # the median of the event-timed steps; `value` = pairs / wall-clock of the whole region (mean)
         "ms_per_step": step_stats["median"], "ms_per_step_mean": 1e3 * elapsed / args.steps, "step_ms": step_stats,
-        "probe_overhead_ms_per_step": 1e3 * elapsed / args.steps - noprobe_ms,
-        "probe_overhead_is": "wall-clock mean of the timed region (every GEMM / RoIAlign launch bracketed by two HIP events "
-                             "for the roofline) minus the mean of %d further steps without the brackets, run right after it" % n_np,
+        "probe_overhead_ms_per_step": probe_overhead_ms,
+        "probe_overhead_is": "median of %d event-timed steps WITH the library's two HIP events around every GEMM / RoIAlign launch (as in "
+                             "the timed region: they feed `roofline`) minus the median of %d steps without them, alternating, run "
+                             "right after the timed region" % (n_np, n_np),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32 (operands, results, accumulation and storage f32; products: every operand value split exactly into "
                          "three bf16 values (round to nearest), six v_mfma_f32_32x32x16_bf16 per block, dropped terms <= 2^-23 |a b|)",

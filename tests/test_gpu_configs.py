@@ -246,7 +246,9 @@ def test_cfg2_full_size_ait_output_vs_oracle():
     # relu_margin_seq >= TAU) takes the same side of every ReLU here and there, and EVERY element of its gradient must be
     # inside the band; only the sequences with a pre-activation within TAU of the kink may differ, by about one hidden unit's
     # share.  So: (1) no out-of-band element outside those sequences, (2) inside them the error stays bounded.
-    TAU = 2e-6
+    # (measured: 52 sequences of 1200 hold out-of-band elements, every one with a margin <= 5.9e-7 and a relative error
+    # <= 5e-3; the other sequences agree to 2e-6 relative.)
+    TAU = 1e-6
     margin_seq = torch.cat(margin_seq)
     gx, wx = got[0].cpu().reshape(bs * P, -1), wants[0].reshape(bs * P, -1)
     band = 1e-3 * float(wx.pow(2).mean().sqrt()) + 1e-4 * wx.abs()
@@ -259,8 +261,8 @@ def test_cfg2_full_size_ait_output_vs_oracle():
     print("suspect sequences (margin < %g): %d of %d; sequences with out-of-band elements: %d; clean sequences' worst rel %.3g"
           % (TAU, int(suspect.sum()), bs * P, int((bad_elems > 0).sum()), float(rel_seq[~suspect].max())))
     assert int(bad_elems[~suspect].sum()) == 0, "out-of-band gradient elements in sequences no ReLU of which is near its kink"
-    assert float(rel_seq[~suspect].max()) < 1e-4
-    assert float(rel_seq[suspect].max()) < 0.2 and int((bad_elems > 0).sum()) <= 0.05 * bs * P
+    assert float(rel_seq[~suspect].max()) < 1e-5
+    assert float(rel_seq[suspect].max()) < 2e-2 and int((bad_elems > 0).sum()) <= 0.08 * bs * P
     for n, g_, w_ in zip(["x_props", "x_query"] + names, got, wants):
         g_ = g_.cpu()
         rel = float((g_ - w_).norm() / (w_.norm() + 1e-30))

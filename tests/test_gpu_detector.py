@@ -342,7 +342,8 @@ def test_detector_headline_size_train_step_vs_oracle(model):
         got, want = params[pk].grad.cpu(), sd[k].grad
         rels[k] = float((got - want).norm() / (want.norm() + 1e-12))
     print("P=300 train step, relative L2 of the watched gradients:", {k: round(v, 6) for k, v in rels.items()})
-    assert max(rels.values()) < 1e-3, rels
+    # (VERDICT r5 asked for <= 1e-3; measured <= 3.4e-5 -- at P = 300 no ReLU of this pair sits within rounding of its kink)
+    assert max(rels.values()) < 2e-4, rels
 
 
 def test_detector_coco_variant(golden):

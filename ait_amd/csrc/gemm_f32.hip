@@ -60,17 +60,12 @@ using Tile128 = Cfg<128, 128, 16, 2, 2, 2, MODE_DB>;
 using TileN64 = Cfg<256, 64, 16, 4, 1, 2, MODE_DB>;
 using TileN64D = Cfg<256, 64, 16, 4, 1, 2, MODE_DLDS, 3, KNOB_SPLIT | KNOB_RNE>;      // the same 256x64 outputs on the persistent split tile (four waves of 64x64)
 using Tile64 = Cfg<64, 64, 16, 2, 2, 2, MODE_DB>;
-//   Tile64K    the same 64x64 outputs with K-slabs of 64: a few-tile product is a chain of global-load round trips (one per
-//              slab, overlapped with ONE slab's eight MFMAs per wave), so a slab four times as deep makes the chain a quarter
-//              as long.  Same products in the same order as Tile64: bit-identical results.
-using Tile64K = Cfg<64, 64, 64, 2, 2, 2, MODE_DB>;
-// few-tile launches: which of the two (lab knob small_bk; reductions shorter than one deep slab stay on Tile64)
-template <class... A>
-inline int dispatch_few(const GemmArgs& g, bool ak, bool bk, hipStream_t s) {
-  const int kr = g.splits > 1 ? g.k_per_split : g.K;
-  if (ait_lab::Knobs::small_bk == 64 && kr >= 64) return dispatch<Tile64K>(g, ak, bk, s);
-  return dispatch<Tile64>(g, ak, bk, s);
-}
+//   (lab, round 6: the same 64x64 outputs with K-slabs of 64 -- a quarter of the global-load round trips -- measured no
+//   faster: 33-35 us for 256x512x1024 either way, profiles/r06_gemm_tail_experiments.txt.  The few-tile launches are bound
+//   by one wave's serial MFMA chain, not by the slab round trips.)
+//   Tile128S   128x128 split tile, four waves of 64x64, four-slot ring, up to two workgroups per CU: products of a few
+//              hundred 256x128 tiles (lab knob mid_tile)
+using Tile128S = Cfg<128, 128, 16, 2, 2, 2, MODE_DLDS, 4, KNOB_SPLIT | KNOB_RNE>;
 //   TileCoop   256x256, eight waves of 64x128, one workgroup per CU, every operand value split ONCE per workgroup into an LDS
 //              plane image (KNOB_COOP): 88 vector instructions per 48 MFMAs against 264.  The weight-gradient products (both
 //              operands are activations, K-outer: nothing to pre-split): 203-204 TF/s against 185 for Tile256D on the
@@ -131,6 +126,11 @@ int ait_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, float alpha, 
   if (direct && ait_gemm_coop_takes(trans_a, trans_b, M, N, K, flags, ctx) &&
       (long long)((M + 255) / 256) * ((N + 255) / 256) * g.splits >= 128)
     return launch<TileCoop, false, false, EPI_ATOMIC>(g, ait_stream(stream), ws);
+  if constexpr (ait_lab::Knobs::mid_tile != 0) {      // lab: products of fewer than 512 256x128 tiles on the 128x128 split tile
+    const long long t128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * g.splits;
+    if (direct && M >= 512 && tiles256 < 512 && t128 >= 128 && !(ctx && (ctx->flags & (AIT_CTX_NATIVE_F32 | AIT_CTX_BF16))))
+      return dispatch<Tile128S>(g, !trans_a, trans_b != 0, ait_stream(stream), ait_lab::Knobs::mid_tile == 2 ? ws : SchedWs());
+  }
   if (M >= 512 && (tiles256 >= 512 || few_tiles_sk)) {
     if (direct) {
       if (ctx && (ctx->flags & AIT_CTX_BF16)) return dispatch<Tile256B>(g, !trans_a, trans_b != 0, ait_stream(stream), ws);
@@ -140,7 +140,7 @@ int ait_gemm_f32_ex(int trans_a, int trans_b, int M, int N, int K, float alpha, 
     return dispatch<Tile256>(g, !trans_a, trans_b != 0, ait_stream(stream));
   }
   const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * g.splits;
-  if (tiles128 < 128) return dispatch_few(g, !trans_a, trans_b != 0, ait_stream(stream));
+  if (tiles128 < 128) return dispatch<Tile64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   return dispatch<Tile128>(g, !trans_a, trans_b != 0, ait_stream(stream));
 }
 
@@ -197,6 +197,6 @@ AIT_API int ait_gemm_f32_batched(int trans_a, int trans_b, int M, int N, int K, 
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K * batch * batch2, ait_stream(stream), M, N, K,
                       trans_a, trans_b, batch * batch2);
   const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch * batch2 * g.splits;
-  if (tiles128 < 128) return dispatch_few(g, !trans_a, trans_b != 0, ait_stream(stream));
+  if (tiles128 < 128) return dispatch<Tile64>(g, !trans_a, trans_b != 0, ait_stream(stream));
   return dispatch<Tile128>(g, !trans_a, trans_b != 0, ait_stream(stream));
 }

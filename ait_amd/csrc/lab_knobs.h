@@ -40,8 +40,9 @@ struct Product {
   // attn_impl.h: column-paired right-operand loads for f32 q / k / v as well; six MFMA terms whatever the operands are
   static constexpr bool f32_pairs = false;
   static constexpr bool no_bf16_planes = false;
-  // gemm_f32.hip: K-slab depth of the 64 x 64 few-tile launches (16: Tile64, 64: Tile64K)
-  static constexpr int small_bk = 64;
+  // gemm_f32.hip: products of fewer than 512 256x128 tiles on the 128x128 split tile (0 off, 1 static work list, 2 with the
+  // scheduler scratch: tickets + stream-K)
+  static constexpr int mid_tile = 0;
   // gemm_f32_impl.h: round 4's last-round cost model; slab-times a stream-K cut of the last round must save
   static constexpr bool old_last_round = false;
   static constexpr double sk_pays = 12.0;

@@ -14,11 +14,12 @@ from ait_amd import ops  # noqa: E402
 SHAPES = [
     (19328, 2048, 512, 0, 1, 1, 1), (19328, 2048, 512, 0, 0, 1, 1), (76800, 512, 512, 0, 1, 1, 1), (76800, 1024, 512, 0, 1, 1, 1),
     (76800, 1024, 320, 0, 0, 1, 1), (58800, 1024, 512, 0, 1, 1, 1),
-    (512, 64, 76800, 1, 0, 127, 1), (512, 512, 76800, 1, 0, 64, 1),
+    (512, 64, 76800, 1, 0, 127, 1), (512, 64, 76800, 1, 0, 64, 1), (512, 64, 76800, 1, 0, 253, 1), (512, 512, 76800, 1, 0, 64, 1),
     (512, 1024, 19328, 1, 0, 8, 1), (19328, 1024, 512, 0, 1, 1, 1), (19328, 512, 1024, 0, 1, 1, 1),
     (9576, 512, 1024, 0, 0, 1, 1), (9576, 512, 1024, 0, 1, 1, 1), (9576, 1024, 512, 0, 0, 1, 1), (9576, 1024, 512, 0, 1, 1, 1),
     (9576, 512, 512, 0, 0, 1, 1), (9576, 512, 512, 0, 1, 1, 1), (9576, 512, 9216, 0, 1, 1, 1),
-    (512, 1024, 9576, 1, 0, 32, 1), (1024, 512, 9576, 1, 0, 32, 1), (512, 512, 9576, 1, 0, 32, 1), (64, 512, 9576, 1, 0, 8, 1),
+    (512, 1024, 9576, 1, 0, 32, 1), (512, 1024, 9576, 1, 0, 8, 1), (512, 1024, 9576, 1, 0, 16, 1), (512, 1024, 9576, 1, 0, 64, 1),
+    (1024, 512, 9576, 1, 0, 32, 1), (512, 512, 9576, 1, 0, 32, 1), (512, 512, 9576, 1, 0, 16, 1), (512, 512, 9576, 1, 0, 64, 1), (64, 512, 9576, 1, 0, 8, 1),
     (512, 64, 9576, 1, 0, 32, 1), (9576, 64, 512, 0, 0, 1, 1), (9576, 64, 512, 0, 1, 1, 1), (9576, 512, 64, 0, 0, 1, 1), (9576, 512, 64, 0, 1, 1, 1),
     (256, 1024, 320, 0, 0, 1, 1), (256, 512, 1024, 0, 0, 1, 1), (256, 512, 1024, 0, 1, 1, 1), (256, 1024, 512, 0, 0, 1, 1),
     (256, 1024, 512, 0, 1, 1, 1), (256, 512, 512, 0, 0, 1, 1), (256, 512, 512, 0, 1, 1, 1), (256, 64, 512, 0, 0, 1, 1), (256, 512, 64, 0, 1, 1, 1),

@@ -47,9 +47,9 @@ SIGNATURES = {
                                    ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                    ctypes.POINTER(ctypes.c_float), _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ait_bn_act_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp, _vp]),
-    "ait_bn_act_bwd": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _vp, _vp, _vp]),
+    "ait_bn_act_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _i, _vp, _vp, _vp]),
     "ait_bn_act_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp]),
-    "ait_bn_act_bwd_bf16": (_i, [_vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp]),
+    "ait_bn_act_bwd_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp]),
     "ait_sk_sqsum_fwd": (_i, [_vp, _vp, _ll, _vp, _vp]),
     "ait_sk_sqsum_bwd": (_i, [_vp, _vp, _vp, _ll, _vp, _vp, _vp]),
     "ait_gemm_f32": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i,

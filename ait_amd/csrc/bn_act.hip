@@ -6,7 +6,9 @@
 // shift = beta - mean*scale.  The bottleneck tail "bn3(conv3) ; out += residual ; relu"
 // (:99-111) and "bn ; relu" (:88-96) are HBM-bound elementwise chains that the reference runs as
 // 2-3 separate passes; here each is ONE read-modify-write pass (16 B per lane), forward and
-// backward (dx = dy * [y>0] * scale[c], dres = dy * [y>0]).
+// backward (dx = dy * [y>0] * scale[c], dres = dy * [y>0]).  The backward takes the incoming gradient as up to TWO addends
+// (dy + dy2): a bottleneck's output feeds the next block's convolution path AND its shortcut, and summing the two gradients
+// while this pass streams them replaces a separate add kernel (three tensor passes) by one more read.
 #include "common.h"
 
 namespace {
@@ -63,13 +65,17 @@ __global__ __launch_bounds__(kThreads) void bn_act_fwd_kernel(
 
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void bn_act_bwd_kernel(
-    const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ dy, const float* __restrict__ dy2, const float* __restrict__ y, const float* __restrict__ scale,
     int relu, long long total, int C, int HW, float* __restrict__ dx, float* __restrict__ dres) {
   const long long stride = (long long)gridDim.x * kThreads * 4;
   for (long long i = ((long long)blockIdx.x * kThreads + threadIdx.x) * 4; i < total; i += stride) {
     if (MODE != 0) {
       const float4 g4 = *reinterpret_cast<const float4*>(dy + i);
       float g[4] = {g4.x, g4.y, g4.z, g4.w};
+      if (dy2) {
+        const float4 h4 = *reinterpret_cast<const float4*>(dy2 + i);
+        g[0] += h4.x; g[1] += h4.y; g[2] += h4.z; g[3] += h4.w;
+      }
       if (relu) {
         const float4 o = *reinterpret_cast<const float4*>(y + i);
         g[0] = o.x > 0.f ? g[0] : 0.f;
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(kThreads) void bn_act_bwd_kernel(
       for (int k = 0; k < 4; k++) {
         const long long j = i + k;
         if (j >= total) break;
-        float g = dy[j];
+        float g = dy[j] + (dy2 ? dy2[j] : 0.f);
         if (relu && !(y[j] > 0.f)) g = 0.f;
         if (dres) dres[j] = g;
         dx[j] = g * scale[(int)((j / HW) % C)];
@@ -138,7 +144,8 @@ __global__ __launch_bounds__(kThreads) void bn_act_fwd16_kernel(const unsigned s
     *reinterpret_cast<uint4*>(y + i) = pack8(v);
   }
 }
-__global__ __launch_bounds__(kThreads) void bn_act_bwd16_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ y,
+__global__ __launch_bounds__(kThreads) void bn_act_bwd16_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ dy2,
+                                                                const unsigned short* __restrict__ y,
                                                                 const float* __restrict__ scale, int relu, long long total, int C,
                                                                 unsigned short* __restrict__ dx, unsigned short* __restrict__ dres) {
   const long long stride = (long long)gridDim.x * kThreads * 8;
@@ -146,12 +153,17 @@ __global__ __launch_bounds__(kThreads) void bn_act_bwd16_kernel(const unsigned s
     float g[8], o[8], s[8];
     const uint4 graw = *reinterpret_cast<const uint4*>(dy + i);
     unpack8(graw, g);
+    if (dy2) {      // (the sum of the two bf16 addends is formed in f32 and rounded ONCE, into dres / dx below)
+      unpack8(*reinterpret_cast<const uint4*>(dy2 + i), o);
+#pragma unroll
+      for (int k = 0; k < 8; k++) g[k] += o[k];
+    }
     if (relu) {
       unpack8(*reinterpret_cast<const uint4*>(y + i), o);
 #pragma unroll
       for (int k = 0; k < 8; k++) g[k] = o[k] > 0.f ? g[k] : 0.f;
     }
-    if (dres) *reinterpret_cast<uint4*>(dres + i) = pack8(g);       // (a masked copy of bf16 values: exact)
+    if (dres) *reinterpret_cast<uint4*>(dres + i) = pack8(g);       // (one addend: a masked copy of bf16 values, exact)
     const int c = (int)(i % C);
     *reinterpret_cast<float4*>(s) = *reinterpret_cast<const float4*>(scale + c);
     *reinterpret_cast<float4*>(s + 4) = *reinterpret_cast<const float4*>(scale + c + 4);
@@ -191,22 +203,22 @@ AIT_API int ait_bn_act_fwd(const float* x, const float* scale, const float* shif
   return AIT_OK;
 }
 
-AIT_API int ait_bn_act_bwd(const float* dy, const float* y, const float* scale, int relu,
+AIT_API int ait_bn_act_bwd(const float* dy, const float* dy2, const float* y, const float* scale, int relu,
                            long long n, int C, int HW, float* dx, float* dres, void* stream) {
   if (n < 0 || C <= 0 || HW <= 0) return AIT_EINVAL;
   const long long total = n * C * HW;
   if (total == 0) return AIT_OK;
   if (!dy || !scale || !dx || (relu && !y)) return AIT_EINVAL;
-  const bool al = aligned16(dy) && aligned16(dx) && (!relu || aligned16(y)) && (!dres || aligned16(dres));
+  const bool al = aligned16(dy) && aligned16(dx) && (!relu || aligned16(y)) && (!dres || aligned16(dres)) && (!dy2 || aligned16(dy2));
   if (al && HW % 4 == 0)
     hipLaunchKernelGGL(bn_act_bwd_kernel<1>, dim3(grid_for(total)), dim3(kThreads), 0,
-                       ait_stream(stream), dy, y, scale, relu, total, C, HW, dx, dres);
+                       ait_stream(stream), dy, dy2, y, scale, relu, total, C, HW, dx, dres);
   else if (al && HW == 1 && C % 4 == 0 && aligned16(scale))
     hipLaunchKernelGGL(bn_act_bwd_kernel<2>, dim3(grid_for(total)), dim3(kThreads), 0,
-                       ait_stream(stream), dy, y, scale, relu, total, C, HW, dx, dres);
+                       ait_stream(stream), dy, dy2, y, scale, relu, total, C, HW, dx, dres);
   else
     hipLaunchKernelGGL(bn_act_bwd_kernel<0>, dim3(grid_for(total)), dim3(kThreads), 0,
-                       ait_stream(stream), dy, y, scale, relu, total, C, HW, dx, dres);
+                       ait_stream(stream), dy, dy2, y, scale, relu, total, C, HW, dx, dres);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }
@@ -227,17 +239,17 @@ AIT_API int ait_bn_act_fwd_bf16(const void* x, const float* scale, const float* 
   return AIT_OK;
 }
 
-AIT_API int ait_bn_act_bwd_bf16(const void* dy, const void* y, const float* scale, int relu, long long rows, int C, void* dx,
-                                void* dres, void* stream) {
+AIT_API int ait_bn_act_bwd_bf16(const void* dy, const void* dy2, const void* y, const float* scale, int relu, long long rows, int C,
+                                void* dx, void* dres, void* stream) {
   if (rows < 0 || C <= 0) return AIT_EINVAL;
   const long long total = rows * C;
   if (total == 0) return AIT_OK;
   if (!dy || !scale || !dx || (relu && !y)) return AIT_EINVAL;
-  if ((C % 8) || !aligned16(dy) || !aligned16(dx) || (relu && !aligned16(y)) || (dres && !aligned16(dres)) || !aligned16(scale))
+  if ((C % 8) || !aligned16(dy) || (dy2 && !aligned16(dy2)) || !aligned16(dx) || (relu && !aligned16(y)) || (dres && !aligned16(dres)) || !aligned16(scale))
     return AIT_EUNSUPPORTED;
   long long b = (total / 8 + kThreads - 1) / kThreads;
   hipLaunchKernelGGL(bn_act_bwd16_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(kThreads), 0, ait_stream(stream),
-                     static_cast<const unsigned short*>(dy), static_cast<const unsigned short*>(y), scale, relu, total, C,
+                     static_cast<const unsigned short*>(dy), static_cast<const unsigned short*>(dy2), static_cast<const unsigned short*>(y), scale, relu, total, C,
                      static_cast<unsigned short*>(dx), static_cast<unsigned short*>(dres));
   AIT_CHECK_LAUNCH();
   return AIT_OK;

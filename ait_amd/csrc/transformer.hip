@@ -84,8 +84,18 @@ inline int dgrad(const float* dy, int M, int N_out, const float* w, int K_in, co
 // whole rounds with at least 256 tokens per split (the heuristic ait_amd/system.py used in round 1).
 inline int wgrad_splits(int M_out, int N_out, long long K, bool coop) {
   long long tiles, slots;
-  if (coop) { tiles = (long long)((M_out + 255) / 256) * ((N_out + 255) / 256); slots = 256; }      // the 256 x 256 tile, one per CU
-  else if (M_out >= 512) { tiles = (long long)((M_out + 255) / 256) * ((N_out + 127) / 128); slots = 512; }
+  if (coop) {
+    // the 256 x 256 tile, one per CU.  Its atomic launches cut an under-filled round evenly over the workgroups (stream-K
+    // pieces ADD their partial tiles), so "whole rounds" is not what decides: every K-range costs each output element one
+    // more atomic add, and the fewest ranges the tile takes (tiles x ranges >= 128: ait_gemm_coop_takes' caller) win --
+    // 1536 x 512 x 76800 (the self-attention blocks' W_qkv gradient): 16 ranges 630 us, 32 640, 40 636, 64 (round 5's
+    // choice: three whole rounds) 701; the 4- / 8- / 16-tile gradients measure the same for every admissible count
+    // (profiles/r06_gemm_tail_experiments.txt)
+    tiles = (long long)((M_out + 255) / 256) * ((N_out + 255) / 256);
+    int sp = 8;
+    while (sp < 64 && tiles * sp < 128 && K / (sp + 8) >= 256) sp += 8;
+    return sp;
+  } else if (M_out >= 512) { tiles = (long long)((M_out + 255) / 256) * ((N_out + 127) / 128); slots = 512; }
   else { tiles = (long long)((M_out + 127) / 128) * ((N_out + 127) / 128); slots = 1024; }
   int best = 8;
   double best_eff = -1.0;

@@ -62,6 +62,7 @@ _TRUNK_BF16 = True            # test hook: False = the C4 trunk in f32 also in t
 _AIT_OUT_BF16 = True          # test hook: False = the AIT's output stays f32 in the bf16 configuration (cast by the tail's entry)
 _TAIL_BF16_MIOPEN = True      # test hook: False = the library's (f32-storage) tail node also in the bf16 configuration
 _TOP_NHWC = True
+_PAIR_GRADS = True            # test hook: False = a bottleneck's two input gradients summed by autograd (an add kernel each)
 _BASE_NHWC = True
 _ROI_NHWC = True
 
@@ -338,6 +339,39 @@ class _BnAct(torch.autograd.Function):
         return dx, None, None, dres, None
 
 
+def _alias(y):
+    """a second tensor object over y's storage that autograd does not know as a view of y"""
+    return torch.empty(0, dtype=y.dtype, device=y.device).set_(y.untyped_storage(), y.storage_offset(), y.size(), y.stride())
+
+
+class _BnActPair(torch.autograd.Function):
+    """_BnAct whose result is handed out TWICE -- two tensor objects over ONE storage: the first for the next block's
+    convolution path, the second for its shortcut (resnet_sys_transformer_sk_dilat.py:89-107).  Autograd then hands the
+    gradients of the two uses back SEPARATELY instead of adding them in front of this node (an add kernel per bottleneck:
+    two reads and a write of the block's widest tensor, 91 launches a step), and the backward pass sums them while it streams
+    them (ait_bn_act_bwd's second addend).  Same arithmetic: g = g_main + g_skip in f32, once."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, relu, bf16):
+        y = (ops.bn_act_fwd_bf16 if bf16 else ops.bn_act_fwd)(x, scale, shift, residual, relu)
+        ctx.save_for_backward(y if relu else None, scale)
+        ctx.relu, ctx.bf16 = relu, bf16
+        ctx.has_res = residual is not None
+        ctx.fmt = _fmt(x)
+        ctx.set_materialize_grads(False)          # an unused output's gradient arrives as None, not as a tensor of zeros
+        return y, _alias(y)
+
+    @staticmethod
+    def backward(ctx, g_main, g_skip):
+        y, scale = ctx.saved_tensors
+        gs = [g.contiguous(memory_format=ctx.fmt) for g in (g_main, g_skip) if g is not None]
+        if not gs:
+            return None, None, None, None, None, None
+        bwd = ops.bn_act_bwd_bf16 if ctx.bf16 else ops.bn_act_bwd
+        dx, dres = bwd(gs[0], y, scale, ctx.relu, ctx.has_res and ctx.needs_input_grad[3], dy2=gs[1] if len(gs) > 1 else None)
+        return dx, None, None, dres, None, None
+
+
 def _bn_frozen(bn):
     return (not bn.training) and not bn.weight.requires_grad and not bn.bias.requires_grad
 
@@ -376,34 +410,40 @@ class _BnAct16(torch.autograd.Function):
         return dx, None, None, dres, None
 
 
-def bn_act(x, bn, residual=None, relu=True):
+def bn_act(x, bn, residual=None, relu=True, pair=False):
     """relu(bn(x) + residual) for a FROZEN BatchNorm2d in eval mode (the only state the reference
-    ever runs its BatchNorms in); anything else goes through torch."""
+    ever runs its BatchNorms in); anything else goes through torch.  pair=True: the result as TWO tensors over one storage
+    (_BnActPair: for a consumer that reads it on two paths), or the same tensor twice where that node does not apply."""
     if _bn_frozen(bn) and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 8 == 0:
         scale, shift, _ = _bn_affine(bn)
         x = x.contiguous(memory_format=torch.channels_last)
         if residual is not None:
             residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        if pair:
+            return _BnActPair.apply(x, scale, shift, residual, relu, True)
         return _BnAct16.apply(x, scale, shift, residual, relu)
     if not (_bn_frozen(bn) and x.is_cuda and x.dtype == torch.float32):
         y = bn(x)
         if residual is not None:
             y = y + residual
-        return F.relu(y) if relu else y
+        y = F.relu(y) if relu else y
+        return (y, y) if pair else y
     scale, shift, _ = _bn_affine(bn)
     fmt = _fmt(x)
     x = x.contiguous(memory_format=fmt)
     if residual is not None:
         residual = residual.contiguous(memory_format=fmt)
+    if pair:
+        return _BnActPair.apply(x, scale, shift, residual, relu, False)
     return _BnAct.apply(x, scale, shift, residual, relu)
 
 
-def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, stride1=False):
+def conv1x1_bn_act(x, conv, bn, residual=None, relu=True, stride1=False, pair=False):
     """relu(bn(conv(x)) + residual) for a bias-free 1x1 convolution.  `stride1`: run the convolution at stride 1
     whatever conv.stride says (the input is already subsampled).  The convolution is PyTorch-ROCm's (the C4 trunk,
     SURVEY 2), the frozen BN / residual / ReLU one HIP pass."""
     y = F.conv2d(x, conv.weight, None, (1, 1)) if stride1 else conv(x)
-    return bn_act(y, bn, residual=residual, relu=relu)
+    return bn_act(y, bn, residual=residual, relu=relu, pair=pair)
 
 
 # ------------------------------------------------------------------------------------------
@@ -547,25 +587,28 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x, subsampled=False, out_stride=1):
+    def forward(self, x, subsampled=False, out_stride=1, pair=False):
         """subsampled=True: `x` already holds only the positions this block's stride-s 1x1
         convolutions read (x[:, :, ::s, ::s]), so they run at stride 1.
         out_stride=s: the caller guarantees that this block's output is read ONLY by stride-s 1x1
         convolutions (the first block of the next stage); the block then produces just those
         positions -- conv2 runs at stride s (same 3x3 sums at the kept positions), conv3, the
-        frozen BN, the residual and the ReLU are position-wise."""
+        frozen BN, the residual and the ReLU are position-wise.
+        x may be a PAIR (x_main, x_skip) of tensors over one storage (the previous block's pair=True result): the
+        convolution path reads the first, the shortcut the second; pair=True returns this block's result as such a pair."""
+        x, x_skip = x if isinstance(x, tuple) else (x, x)
         out = conv1x1_bn_act(x, self.conv1, self.bn1, stride1=subsampled)
         if out_stride == 1:
             out = bn_act(self.conv2(out), self.bn2)
         else:
             out = bn_act(F.conv2d(out, self.conv2.weight, None, out_stride, self.conv2.padding), self.bn2)
         if self.downsample is None:
-            identity = x if out_stride == 1 else _Subsample.apply(x, out_stride)
+            identity = x_skip if out_stride == 1 else _Subsample.apply(x_skip, out_stride)
         elif out_stride != 1:
             raise ValueError("out_stride needs an identity shortcut")
         else:
-            identity = conv1x1_bn_act(x, self.downsample[0], self.downsample[1], relu=False, stride1=subsampled)
-        return conv1x1_bn_act(out, self.conv3, self.bn3, residual=identity)
+            identity = conv1x1_bn_act(x_skip, self.downsample[0], self.downsample[1], relu=False, stride1=subsampled)
+        return conv1x1_bn_act(out, self.conv3, self.bn3, residual=identity, pair=pair)
 
 
 def _c4_size(h, w):
@@ -593,14 +636,22 @@ def run_stages(stages, x):
     positions that are (see Bottleneck.forward).  Same values and gradients as the plain
     composition; AIT_SK_FULL=1 restores it."""
     subsampled = False
-    for k, stage in enumerate(stages):
+    blocks = [(k, i, blk) for k, stage in enumerate(stages) for i, blk in enumerate(stage)]
+    for n, (k, i, blk) in enumerate(blocks):
+        stage = stages[k]
         nxt = stages[k + 1] if k + 1 < len(stages) else None
         skip = (not _SK_FULL) and nxt is not None and _opens_with_stride2_1x1(nxt) \
             and isinstance(stage[-1], Bottleneck) and stage[-1].downsample is None and len(stage) > 1
-        for i, blk in enumerate(stage):
-            x = blk(x, subsampled=(subsampled and i == 0), out_stride=2 if (skip and i == len(stage) - 1) else 1)
-        subsampled = skip
-    return x
+        # a block whose result the NEXT bottleneck reads on two paths (convolution + shortcut) hands it out as a pair
+        # (_BnActPair): the two gradients come back separately and are summed inside the frozen-BN backward pass
+        pair = _PAIR_GRADS and n + 1 < len(blocks) and isinstance(blk, Bottleneck) and isinstance(blocks[n + 1][2], Bottleneck)
+        kw = {"pair": True} if pair else {}
+        if isinstance(x, tuple) and not isinstance(blk, Bottleneck):
+            x = x[0]
+        x = blk(x, subsampled=(subsampled and i == 0), out_stride=2 if (skip and i == len(stage) - 1) else 1, **kw)
+        if i == len(stage) - 1:
+            subsampled = skip
+    return x[0] if isinstance(x, tuple) else x
 
 
 class ResNet(nn.Module):

@@ -590,13 +590,14 @@ def bn_act_fwd(x, scale, shift, residual, relu):
     return y
 
 
-def bn_act_bwd(dy, y, scale, relu, need_dres):
+def bn_act_bwd(dy, y, scale, relu, need_dres, dy2=None):
+    """dx, dres of ait_bn_act_fwd for the gradient dy (+ dy2: a second addend, summed in the same pass)"""
     n, C, HW = _bn_dims(dy)
     dx = torch.empty_like(dy)
     dres = torch.empty_like(dy) if need_dres else None
-    _same_format(dy, y, dx, dres)
+    _same_format(dy, y, dx, dres, dy2)
     with torch.cuda.device(dy.device):
-        rc = _lib.lib().ait_bn_act_bwd(_pd(dy), _pd(y), _p(scale), int(relu), n, C, HW, _pd(dx), _pd(dres),
+        rc = _lib.lib().ait_bn_act_bwd(_pd(dy), _pd(dy2), _pd(y), _p(scale), int(relu), n, C, HW, _pd(dx), _pd(dres),
                                        _lib.cur_stream(dy.device))
     _lib.check(rc, "ait_bn_act_bwd")
     return dx, dres
@@ -624,14 +625,16 @@ def bn_act_fwd_bf16(x, scale, shift, residual, relu):
     return y
 
 
-def bn_act_bwd_bf16(dy, y, scale, relu, need_dres):
+def bn_act_bwd_bf16(dy, y, scale, relu, need_dres, dy2=None):
     rows, C = _cl_rows(dy)
+    if dy2 is not None:
+        _cl_rows(dy2)
     dx = torch.empty_like(dy)
     dres = torch.empty_like(dy) if need_dres else None
-    _same_format(dy, y, dx, dres)
+    _same_format(dy, y, dx, dres, dy2)
     vp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
     with torch.cuda.device(dy.device):
-        rc = _lib.lib().ait_bn_act_bwd_bf16(vp(dy), vp(y), _p(scale), int(relu), rows, C, vp(dx), vp(dres),
+        rc = _lib.lib().ait_bn_act_bwd_bf16(vp(dy), vp(dy2), vp(y), _p(scale), int(relu), rows, C, vp(dx), vp(dres),
                                             _lib.cur_stream(dy.device))
     _lib.check(rc, "ait_bn_act_bwd_bf16")
     return dx, dres

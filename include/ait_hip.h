@@ -795,12 +795,14 @@ int ait_heads_bwd(const float* d_bbox, const float* d_score, const float* props,
  * kept in eval mode during training, :435-441,457-480):
  *   y  = [relu]( x*scale[c] + shift[c] [+ residual] )      scale = gamma/sqrt(var+eps),
  *                                                          shift = beta - mean*scale
- *   dx = dy*[y>0]*scale[c],  dres = dy*[y>0]               (the BN parameters get no gradient)
- * residual / dres may be NULL.
+ *   dx = g*[y>0]*scale[c],  dres = g*[y>0],  g = dy + dy2  (the BN parameters get no gradient)
+ * residual / dres / dy2 may be NULL.  dy2: the gradient arrives as two addends -- the block's output fed the next block's
+ * convolution path and its shortcut (resnet_sys_transformer_sk_dilat.py:89-107) -- and is summed in this pass instead of
+ * by an add kernel in front of it.
  * ------------------------------------------------------------------------------------- */
 int ait_bn_act_fwd(const float* x, const float* scale, const float* shift, const float* residual,
                    int relu, long long n, int C, int HW, float* y, void* stream);
-int ait_bn_act_bwd(const float* dy, const float* y, const float* scale, int relu, long long n,
+int ait_bn_act_bwd(const float* dy, const float* dy2, const float* y, const float* scale, int relu, long long n,
                    int C, int HW, float* dx, float* dres, void* stream);
 
 /* The same pass over bf16 tensors in channels-last memory ([rows, C] rows of C channels, C % 8 == 0; scale / shift f32):
@@ -808,8 +810,8 @@ int ait_bn_act_bwd(const float* dy, const float* y, const float* scale, int relu
  * frozen-BN / residual / ReLU pass between them).  f32 arithmetic, nearest-even rounding on the way out. */
 int ait_bn_act_fwd_bf16(const void* x, const float* scale, const float* shift, const void* residual, int relu,
                         long long rows, int C, void* y, void* stream);
-int ait_bn_act_bwd_bf16(const void* dy, const void* y, const float* scale, int relu, long long rows, int C, void* dx,
-                        void* dres, void* stream);
+int ait_bn_act_bwd_bf16(const void* dy, const void* dy2, const void* y, const float* scale, int relu, long long rows, int C,
+                        void* dx, void* dres, void* stream);
 
 /* SKBlock tail as the reference executes it (blocks_sys_transformer_sk_dilat.py:966-981: two
  * conv+ReLU branches, `v = f * f`, summed): y = relu(a)^2 + relu(b)^2 over n fp32 elements

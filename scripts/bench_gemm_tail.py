@@ -46,6 +46,13 @@ def timeit(fn, n=30, w=5):
     return ms[len(ms) // 2]
 
 
+# the AIT's weight gradients: K-range counts around the product's choice (AIT_TAIL_WGRAD=1 selects this list)
+WGRAD = [(1536, 512, 76800, 1, 0, sp, 1) for sp in (64, 16, 20, 21, 24, 32, 40, 42)] + \
+        [(512, 512, 76800, 1, 0, sp, 1) for sp in (64, 32, 56, 63)] + [(1024, 512, 76800, 1, 0, sp, 1) for sp in (32, 16, 24, 31)] + \
+        [(2048, 512, 76800, 1, 0, sp, 1) for sp in (16, 8, 15)] + [(512, 2048, 58800, 1, 0, sp, 1) for sp in (16, 15)] + \
+        [(512, 4608, 19328, 1, 0, sp, 1) for sp in (8, 7, 14)]
+if os.environ.get("AIT_TAIL_WGRAD") == "1":
+    SHAPES = WGRAD
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 tot = 0.0
 for m, n, k, ta, tb, sk, batch in SHAPES:

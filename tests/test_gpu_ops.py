@@ -203,6 +203,63 @@ def test_frozen_bn_residual_relu_matches_torch():
                     assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
 
 
+def test_bottleneck_gradients_summed_inside_the_frozen_bn_backward():
+    """The pair form of a bottleneck's closing pass (faster_rcnn._BnActPair, ait_bn_act_bwd's second addend): the block's
+    result goes to the next block as two tensors over one storage, the two gradients come back separately and are summed
+    inside the backward pass.  (1) the kernel: dx / dres for g = dy + dy2 equal those of the pre-summed gradient bit for bit,
+    f32 and bf16, both memory formats; (2) a stack of bottlenecks (resnet_sys_transformer_sk_dilat.py:89-107) through
+    run_stages: outputs identical and every parameter / input gradient equal to the plain composition's, with no add
+    kernel's worth of difference -- the sums are the same two-operand f32 additions."""
+    import ait_amd.faster_rcnn as fr
+    from ait_amd import ops
+    torch.manual_seed(3)
+    for shape, fmt in (((2, 16, 6, 4), torch.contiguous_format), ((2, 16, 5, 3), torch.channels_last), ((1, 5, 7, 9), torch.contiguous_format)):
+        y = torch.randn(shape, device="cuda").contiguous(memory_format=fmt)
+        g1, g2 = (torch.randn(shape, device="cuda").contiguous(memory_format=fmt) for _ in range(2))
+        sc = torch.rand(shape[1], device="cuda") + 0.5
+        for relu in (True, False):
+            a = ops.bn_act_bwd(g1 + g2, y, sc, relu, True)
+            b = ops.bn_act_bwd(g1, y, sc, relu, True, dy2=g2)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    y = torch.randn(2, 16, 5, 3, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    g1, g2 = (torch.randn(2, 16, 5, 3, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(2))
+    sc = torch.rand(16, device="cuda") + 0.5
+    b = ops.bn_act_bwd_bf16(g1, y, sc, True, True, dy2=g2)
+    want = ((g1.float() + g2.float()) * (y.float() > 0))
+    assert torch.equal(b[1], want.to(torch.bfloat16)) and torch.equal(b[0], (want * sc.view(1, -1, 1, 1)).to(torch.bfloat16))
+    # (2) three stages of bottlenecks, with a stride-2 stage boundary (the dead-position subsampling path) in the middle
+    net = fr.ResNet(fr.Bottleneck, [2, 3, 2, 1]).cuda().eval()          # eval(): every BatchNorm frozen, as the detector's
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            for p in m.parameters():
+                p.requires_grad = False
+            with torch.no_grad():
+                m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.6, 1.4); m.weight.uniform_(0.7, 1.3); m.bias.uniform_(-0.2, 0.2)
+    stages = [net.layer1, net.layer2, net.layer3]
+    x0 = torch.randn(2, 64, 24, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+    cot = None
+    res = {}
+    for mode in (True, False):
+        fr._PAIR_GRADS = mode
+        try:
+            net.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            out = fr.run_stages(stages, x)
+            cot = torch.randn_like(out) if cot is None else cot
+            out.backward(cot)
+            res[mode] = (out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        finally:
+            fr._PAIR_GRADS = True
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    # (the forward is the same kernels either way; MIOpen may pick another solver on its second call of a shape)
+    assert rel(res[True][0], res[False][0]) < 1e-6
+    # (MIOpen's split-K weight-gradient kernels sum with atomics: two runs of ONE configuration differ in the last bits)
+    assert rel(res[True][1], res[False][1]) < 1e-5
+    assert set(res[True][2]) == set(res[False][2]) and len(res[True][2]) >= 20
+    for k in res[True][2]:
+        assert rel(res[True][2][k], res[False][2][k]) < 1e-5, k
+
+
 def test_roi_align_channels_last_fuzz_vs_oracle():
     """Seeded fuzz of the channels-last RoIAlign pair against the C oracle: odd feature sizes, C not a
     multiple of the workgroup's channel span, RoIs from sub-pixel to larger than the image, explicit

@@ -27,6 +27,13 @@ ARCH = "gfx950"
 # values, always the same four accumulator registers (scripts/gemm_lab diffmap with LAB_SELF=1: a kernel against a
 # second launch of itself; ROCm 7.2, gfx950).  Without packing every kernel is reproducible launch to launch;
 # MI355X_MICROARCH.md lists packed f32 arithmetic beside MFMAs as an anti-lever anyway.
+# Round 6 looked for the cause at ISA level (profiles/r06_packed_f32_hazard.txt).  The vectorised epilogue is
+#     v_mov_b32 v116, v142 ; s_waitcnt vmcnt(1) ; v_mov_b32 v117, v138 ; v_pk_fma_f32 v[114:115], s[44:45], v[96:97], v[116:117] op_sel:[0,0,1]
+# (v138: a bias value just loaded; v[96:97]: accumulators).  REFUTED: a VALU -> packed-VALU forwarding hazard on the half
+# taken through op_sel -- scripts/pk_hazard.hip repeats exactly that pair back to back 6e9 times per launch with a stale
+# value in the register: not one wrong lane, with or without wait states.  What the symptom still fits (the LAST lane
+# quarter of a register that is the destination of an in-flight load holding its previous content): the load's return
+# against the counted s_waitcnt among the epilogue's stores -- not proven; the flag stays, it costs nothing measurable.
 COMMON = ["-O3", "-fno-slp-vectorize", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-I", INCLUDE,
           "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # integer/geometry kernels must reproduce the reference's fp32 operation sequence exactly

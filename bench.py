@@ -327,6 +327,9 @@ def main():
                          "(same as AIT_FORCE_DDP=1): runs the N > 1 code path on a one-GPU box; not the headline mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ab", action="store_true", help="skip the f32_native A/B steps behind the timed region")
+    ap.add_argument("--no-probe-pass", action="store_true",
+                    help="skip the probe-overhead steps behind the timed region (profiling runs: the trace then holds warm-up + "
+                         "timed steps only); probe_overhead_ms_per_step is null")
     ap.add_argument("--gemm-table", default=None, metavar="PATH",
                     help="also write the timed region's GEMM launches grouped by shape (launches/step, ms/step, TFLOP/s)")
     ap.add_argument("--dtype", choices=["f32", "f32_native", "bf16"], default=None,
@@ -421,8 +424,8 @@ def main():
     # ALTERNATING with and without the brackets (the chip's clock drifts over seconds, so two back-to-back blocks of steps
     # would measure the drift), each between two events; the difference of the two medians (every rank runs them: the steps
     # hold collectives)
-    n_np = max(2, min(args.steps, 10))
-    probe2 = _lib.Probe(1024 * n_np)
+    n_np = 0 if args.no_probe_pass else max(2, min(args.steps, 10))
+    probe2 = _lib.Probe(1024 * max(1, n_np))
     marks2 = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_np + 1)]
     D.barrier()
     with probe2:
@@ -435,7 +438,7 @@ def main():
     D.barrier()
     t_on = sorted(marks2[i].elapsed_time(marks2[i + 1]) for i in range(0, 2 * n_np, 2))
     t_off = sorted(marks2[i].elapsed_time(marks2[i + 1]) for i in range(1, 2 * n_np, 2))
-    probe_overhead_ms = med(t_on) - med(t_off)
+    probe_overhead_ms = (med(t_on) - med(t_off)) if n_np else None
 
     # A/B beside the headline, OUTSIDE its timed region (every rank runs it: the steps hold collectives): the same step
     # with the AIT's products on the instruction that multiplies f32 operands (v_mfma_f32_32x32x2_f32)

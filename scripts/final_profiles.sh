@@ -11,7 +11,7 @@ python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-ab --gemm-table "$o
 python bench.py --config cfg5 --steps 10 --warmup 3 --no-cpu-baseline --no-ab --gemm-table "$out/${tag}_cfg5_gemm_by_shape.txt" > "$out/${tag}_cfg5_bench_line.json" 2>> "$out/bench.err"
 python bench.py --config cfg3 --steps 10 --warmup 3 --no-cpu-baseline --no-ab > "$out/${tag}_cfg3_bench_line.json" 2>> "$out/bench.err"
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/trace5" --output-format csv -- python3 "$root/bench.py" --config cfg5 --steps 6 --warmup 3 --no-cpu-baseline --no-ab > /dev/null 2> "$root/$out/trace5.err"
+timeout 900 rocprofv3 --kernel-trace --stats -d "$root/$out/trace5" --output-format csv -- python3 "$root/bench.py" --config cfg5 --steps 6 --warmup 3 --no-cpu-baseline --no-ab --no-probe-pass > /dev/null 2> "$root/$out/trace5.err"
 cd "$root"
 python3 scripts/trace_stats.py "$out/trace5" 3 6 "$out/${tag}_cfg5_timed_region_kernel_stats.csv" > /dev/null 2>&1
 python3 scripts/trace_categories.py "$out/${tag}_cfg5_timed_region_kernel_stats.csv" 6 > "$out/${tag}_cfg5_categories.txt" 2>&1

@@ -150,9 +150,18 @@ int wgrad_dispatch(const GemmArgs& g, hipStream_t s, const SchedWs& ws, bool gro
 }
 }  // namespace
 
-AIT_API int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_conv_geom* q, int cin, int cout,
-                             const float* bias, const float* residual, int flags, float* y, int ldy,
-                             const float* zeros, size_t zeros_floats, const ait_launch_ctx* ctx, void* stream) {
+// position-major rows (ConvGeom::pm_maps; csrc/tail.hip): power-of-two maps, stride 1, dense, fewer than 2^24 rows
+static int set_pm(ConvGeom& c, const ait_conv_geom* q, int pm, bool general, long long rows) {
+  if (!pm) return AIT_OK;
+  if (general || q->stride != 1 || q->groups > 1 || q->in_h != q->out_h || q->in_w != q->out_w || rows >= (1ll << 24)) return AIT_EUNSUPPORTED;
+  c.pm_maps = q->n;
+  c.inv_pm = 1.0f / (float)q->n;
+  return AIT_OK;
+}
+
+int ait_conv_fwd_f32_pm(const float* x, int ldx, const float* w, const ait_conv_geom* q, int cin, int cout,
+                        const float* bias, const float* residual, int flags, float* y, int ldy,
+                        const float* zeros, size_t zeros_floats, int pm, const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY_RC(check_geom(q, cin, cout));
   const int hw = log2_exact(q->out_h * q->out_w), ws = log2_exact(q->out_w);
   const bool general = hw < 0 || ws < 0;
@@ -170,9 +179,15 @@ AIT_API int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_
                        16, g));
   g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
   if (general) set_general_rows(g.conv, q->out_h, q->out_w, rows);
+  AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows));
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), (int)rows, cout,
                       taps * cing, 0, 1, 1);
   return conv_dispatch<CONV_A, true, true>(g, ait_stream(stream), ctx);
+}
+AIT_API int ait_conv_fwd_f32(const float* x, int ldx, const float* w, const ait_conv_geom* q, int cin, int cout,
+                             const float* bias, const float* residual, int flags, float* y, int ldy,
+                             const float* zeros, size_t zeros_floats, const ait_launch_ctx* ctx, void* stream) {
+  return ait_conv_fwd_f32_pm(x, ldx, w, q, cin, cout, bias, residual, flags, y, ldy, zeros, zeros_floats, 0, ctx, stream);
 }
 
 // Data gradient of a STRIDE-2 convolution by parity class of the input positions, ONE launch (ConvGeom, gemm_f32_impl.h):
@@ -233,9 +248,9 @@ int ait_conv_bwd_data_s2(const float* dy, int lddy, const float* w, const ait_co
   return parity_dispatch<SplitFam>(g, s, ws, small, G > 1, big);
 }
 
-AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, const ait_conv_geom* q, int cin, int cout,
-                                  const float* residual, int flags, float* dx, int lddx, const float* zeros,
-                                  size_t zeros_floats, const ait_launch_ctx* ctx, void* stream) {
+int ait_conv_bwd_data_f32_pm(const float* dy, int lddy, const float* w, const ait_conv_geom* q, int cin, int cout,
+                             const float* residual, int flags, float* dx, int lddx, const float* zeros,
+                             size_t zeros_floats, int pm, const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY_RC(check_geom(q, cin, cout));
   const int hw = log2_exact(q->in_h * q->in_w), ws = log2_exact(q->in_w);
   const bool general = hw < 0 || ws < 0;
@@ -258,14 +273,20 @@ AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, con
   g.conv = make_geom(hw, ws, q->out_h, q->out_w, q->kw, 1, -1, q->pad, log2_exact(q->stride), coutg, (long long)cing, zeros,
                      G > 1 ? coutg : 0, cing);
   if (general) set_general_rows(g.conv, q->in_h, q->in_w, rows);
+  AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows));
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cin * taps * coutg, ait_stream(stream), (int)rows, cin,
                       taps * coutg, 0, 0, 1);
   return conv_dispatch<CONV_A, true, false>(g, ait_stream(stream), ctx);
 }
+AIT_API int ait_conv_bwd_data_f32(const float* dy, int lddy, const float* w, const ait_conv_geom* q, int cin, int cout,
+                                  const float* residual, int flags, float* dx, int lddx, const float* zeros,
+                                  size_t zeros_floats, const ait_launch_ctx* ctx, void* stream) {
+  return ait_conv_bwd_data_f32_pm(dy, lddy, w, q, cin, cout, residual, flags, dx, lddx, zeros, zeros_floats, 0, ctx, stream);
+}
 
-AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, int ldx, const ait_conv_geom* q, int cin,
-                                    int cout, float* dw, int split_k, const float* zeros, size_t zeros_floats,
-                                    const ait_launch_ctx* ctx, void* stream) {
+int ait_conv_bwd_weight_f32_pm(const float* dy, int lddy, const float* x, int ldx, const ait_conv_geom* q, int cin,
+                               int cout, float* dw, int split_k, const float* zeros, size_t zeros_floats, int pm,
+                               const ait_launch_ctx* ctx, void* stream) {
   AIT_TRY_RC(check_geom(q, cin, cout));
   const int hw = log2_exact(q->out_h * q->out_w), ws = log2_exact(q->out_w);
   const long long rows = (long long)q->n * q->out_h * q->out_w;
@@ -282,8 +303,14 @@ AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, i
                        nullptr, AIT_GEMM_ATOMIC, split_k < 1 ? 1 : split_k, 0, 0, 16, g));
   g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
   if (general) set_general_rows(g.conv, q->out_h, q->out_w, rows);
+  AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows));
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), cout, taps * cing,
                       (int)rows, 1, 0, g.splits);
   if (bf16_products(ctx)) return wgrad_dispatch<Bf16Fam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1, false);
   return wgrad_dispatch<SplitFam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1, sp_coop);
+}
+AIT_API int ait_conv_bwd_weight_f32(const float* dy, int lddy, const float* x, int ldx, const ait_conv_geom* q, int cin,
+                                    int cout, float* dw, int split_k, const float* zeros, size_t zeros_floats,
+                                    const ait_launch_ctx* ctx, void* stream) {
+  return ait_conv_bwd_weight_f32_pm(dy, lddy, x, ldx, q, cin, cout, dw, split_k, zeros, zeros_floats, 0, ctx, stream);
 }

@@ -48,6 +48,12 @@ struct ConvGeom {
   // of them per group (a tile never straddles two), and the gathered operand's channels of that group start
   // a_group floats further per group
   int a_group, n_group;
+  // ---- POSITION-MAJOR rows (pm_maps > 0; csrc/tail.hip's layer4, maps of 2^rows_hw_shift positions): GEMM row
+  // r = position * pm_maps + map instead of map * positions + position, in the gathered tensor as well.  The rows of ONE
+  // window position are then a contiguous block of pm_maps rows: a tap that falls outside the map for a position is
+  // outside for a whole block (the weight gradient skips such blocks, below).
+  int pm_maps;
+  float inv_pm;
   // ---- the data gradient of a STRIDE-2 convolution by parity class (py, px) of the input positions (ROWMAP kernels):
   // a class holds the positions (2ya + py, 2xa + px); only the window taps ty = (py + pad) mod 2 (+ 2 ...) reach it
   // (1, 2, 2 or 4 of a 3x3 window's 9), the source position of class tap (t'y, t'x) is (ya + cy - t'y, xa + cx - t'x),
@@ -105,9 +111,18 @@ __device__ __forceinline__ int div_small(int n, int d, float inv, int& rem) {
   return q;
 }
 
+// position-major rows: (map, y, x) of row r, and the source row of position (sy, sx)
+__device__ __forceinline__ void pm_decode(const ConvGeom& c, int r, int& map, int& y, int& x) {
+  const int p = div_small(r, c.pm_maps, c.inv_pm, map);
+  y = p >> c.rows_w_shift;
+  x = p & ((1 << c.rows_w_shift) - 1);
+}
+
 __device__ __forceinline__ int conv_src_row(const ConvGeom& c, int r, int tap) {
   int img, y, x;
-  if (c.rows_hw_shift >= 0) {
+  if (c.pm_maps > 0) {
+    pm_decode(c, r, img, y, x);
+  } else if (c.rows_hw_shift >= 0) {
     img = r >> c.rows_hw_shift;
     const int rem = r & ((1 << c.rows_hw_shift) - 1);
     y = rem >> c.rows_w_shift;
@@ -122,13 +137,16 @@ __device__ __forceinline__ int conv_src_row(const ConvGeom& c, int r, int tap) {
   const int ny = y * c.a + c.c + ty * c.b, nx = x * c.a + c.c + tx * c.b;
   const int sy = ny >> c.div_shift, sx = nx >> c.div_shift;
   const bool ok = ny >= 0 && nx >= 0 && ((ny | nx) & ((1 << c.div_shift) - 1)) == 0 && sy < c.src_h && sx < c.src_w;
+  if (c.pm_maps > 0) return ok ? (sy * c.src_w + sx) * c.pm_maps + img : -1;
   return ok ? (img * c.src_h + sy) * c.src_w + sx : -1;
 }
 // the same with the tap already decomposed (ty, tx): the weight gradient's tap is fixed per column tile, and tap / kw is
 // a ~35-instruction runtime division the transfers of every slab would repeat
 __device__ __forceinline__ int conv_src_row_t(const ConvGeom& c, int r, int ty, int tx) {
   int img, y, x;
-  if (c.rows_hw_shift >= 0) {
+  if (c.pm_maps > 0) {
+    pm_decode(c, r, img, y, x);
+  } else if (c.rows_hw_shift >= 0) {
     img = r >> c.rows_hw_shift;
     const int rem = r & ((1 << c.rows_hw_shift) - 1);
     y = rem >> c.rows_w_shift;
@@ -142,6 +160,7 @@ __device__ __forceinline__ int conv_src_row_t(const ConvGeom& c, int r, int ty, 
   const int ny = y * c.a + c.c + ty * c.b, nx = x * c.a + c.c + tx * c.b;
   const int sy = ny >> c.div_shift, sx = nx >> c.div_shift;
   const bool ok = ny >= 0 && nx >= 0 && ((ny | nx) & ((1 << c.div_shift) - 1)) == 0 && sy < c.src_h && sx < c.src_w;
+  if (c.pm_maps > 0) return ok ? (sy * c.src_w + sx) * c.pm_maps + img : -1;
   return ok ? (img * c.src_h + sy) * c.src_w + sx : -1;
 }
 

@@ -25,6 +25,18 @@ int ait_conv_bwd_data_s2(const float* dy, int lddy, const float* w, const ait_co
                          const float* w1, int cin, int cout, const float* residual, int flags, float* dx, int lddx,
                          const float* zeros, const ait_launch_ctx* ctx, void* stream);
 
+// the three convolution entries with POSITION-MAJOR rows (pm != 0: GEMM row = position * q->n + map in every activation
+// tensor; gemm_f32_impl.h ConvGeom::pm_maps): csrc/tail.hip's layer4.  pm == 0: the public entries exactly.
+int ait_conv_fwd_f32_pm(const float* x, int ldx, const float* w, const ait_conv_geom* q, int cin, int cout, const float* bias,
+                        const float* residual, int flags, float* y, int ldy, const float* zeros, size_t zeros_floats, int pm,
+                        const ait_launch_ctx* ctx, void* stream);
+int ait_conv_bwd_data_f32_pm(const float* dy, int lddy, const float* w, const ait_conv_geom* q, int cin, int cout,
+                             const float* residual, int flags, float* dx, int lddx, const float* zeros, size_t zeros_floats,
+                             int pm, const ait_launch_ctx* ctx, void* stream);
+int ait_conv_bwd_weight_f32_pm(const float* dy, int lddy, const float* x, int ldx, const ait_conv_geom* q, int cin, int cout,
+                               float* dw, int split_k, const float* zeros, size_t zeros_floats, int pm,
+                               const ait_launch_ctx* ctx, void* stream);
+
 // ait_attn_bwd with the three gradients written as bf16 (out_bf16 != 0; pitches in elements) -- csrc/attn_bwd.hip
 int ait_attn_bwd_ex(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* P, const float* dO,
                     int n_seq, int H, int T, int d, int kv_rows, float scale, float p_drop, unsigned long long seed, void* dq,

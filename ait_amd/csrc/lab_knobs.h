@@ -40,6 +40,8 @@ struct Product {
   // attn_impl.h: column-paired right-operand loads for f32 q / k / v as well; six MFMA terms whatever the operands are
   static constexpr bool f32_pairs = false;
   static constexpr bool no_bf16_planes = false;
+  // tail.hip: layer4's activations in position-major row order (false: map-major, round 5's)
+  static constexpr bool l4_pm = true;
   // gemm_f32.hip: products of fewer than 512 256x128 tiles on the 128x128 split tile (0 off, 1 static work list, 2 with the
   // scheduler scratch: tickets + stream-K)
   static constexpr int mid_tile = 0;

@@ -304,8 +304,24 @@ int ait_conv_bwd_weight_f32_pm(const float* dy, int lddy, const float* x, int ld
   g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
   if (general) set_general_rows(g.conv, q->out_h, q->out_w, rows);
   AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows));
-  AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), cout, taps * cing,
-                      (int)rows, 1, 0, g.splits);
+  // position-major rows, a window that hangs over the map's edge: the reduction over position blocks, the (position, tap)
+  // pairs that multiply nothing but zeros left out (ConvGeom::pm_wgrad).  Items are q->n rows long (rounded up to whole
+  // slabs: the rows past a block read zeros); `splits` > 1 only says "several items per output tile" to the kernel.
+  double flops = 2.0 * rows * cout * taps * cing;
+  int probe_k = (int)rows;
+  if (pm && ait_lab::Knobs::l4_pm_wgrad && !bf16_products(ctx) && q->pad > 0 && taps > 1 && (cing % 256) == 0 && cout >= 256 && (cout & 3) == 0 &&
+      q->n >= 64) {
+    g.conv.pm_wgrad = 1;
+    g.conv.pm_kh = q->kh;
+    g.splits = 2;
+    g.k_per_split = (q->n + 15) / 16 * 16;
+    const int pairs = WorkMap::pm_pairs(g.conv);
+    flops = 2.0 * (double)q->n * pairs * cout * cing;
+    probe_k = (int)((long long)q->n * pairs / taps);          // (the executed reduction length per output column, on average)
+    AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, flops, ait_stream(stream), cout, taps * cing, probe_k, 1, 0, pairs);
+    return conv_launch<TileCoop, CONV_B, false, false>(g, ait_stream(stream), sched_ws_of(ctx));
+  }
+  AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, flops, ait_stream(stream), cout, taps * cing, probe_k, 1, 0, g.splits);
   if (bf16_products(ctx)) return wgrad_dispatch<Bf16Fam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1, false);
   return wgrad_dispatch<SplitFam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1, sp_coop);
 }

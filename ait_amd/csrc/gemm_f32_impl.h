@@ -54,6 +54,11 @@ struct ConvGeom {
   // outside for a whole block (the weight gradient skips such blocks, below).
   int pm_maps;
   float inv_pm;
+  // ... and the WEIGHT GRADIENT over position blocks (pm_wgrad != 0, CONV_B, stride 1): the reduction of a column tile (its
+  // tap fixed) runs over the rows of ONE position at a time, and only over positions the tap reaches -- the work items are
+  // the valid (position, tap) pairs x the tiles of a tap, every one pm_maps rows long (WorkMap below); 100 of the 144
+  // pairs of a 3x3 window on 4 x 4 maps.  pm_kh = window rows.
+  int pm_wgrad, pm_kh;
   // ---- the data gradient of a STRIDE-2 convolution by parity class (py, px) of the input positions (ROWMAP kernels):
   // a class holds the positions (2ya + py, 2xa + px); only the window taps ty = (py + pad) mod 2 (+ 2 ...) reach it
   // (1, 2, 2 or 4 of a 3x3 window's 9), the source position of class tap (t'y, t'x) is (ya + cy - t'y, xa + cx - t'x),
@@ -624,10 +629,34 @@ __device__ __forceinline__ void mfma_group(f32x16 (&acc)[TM][TN], const float4 (
 //                the 16-row slabs that the co-running tiles walk in step are served from that L2.
 struct WorkMap {
   int tiles_m, tiles_n, tiles, items, chunk;
+  // position-block weight gradient (ConvGeom::pm_wgrad): taps of the window that reach output position q along one axis
+  // (n positions, window k, padding pad, stride 1): [lo, lo + cnt)
+  __host__ __device__ static void pm_taps(int q, int n, int k, int pad, int& lo, int& cnt) {
+    lo = pad - q > 0 ? pad - q : 0;
+    const int hi = (n - 1 + pad - q) < (k - 1) ? (n - 1 + pad - q) : (k - 1);
+    cnt = hi >= lo ? hi - lo + 1 : 0;
+  }
+  __host__ __device__ static int pm_pairs(const ConvGeom& c) {       // valid (position, tap) pairs of one map
+    int tot = 0;
+    for (int y = 0; y < c.src_h; y++)
+      for (int x = 0; x < c.src_w; x++) {
+        int l, ny, nx;
+        pm_taps(y, c.src_h, c.pm_kh, -c.c, l, ny);
+        pm_taps(x, c.src_w, c.kw, -c.c, l, nx);
+        tot += ny * nx;
+      }
+    return tot;
+  }
   __host__ __device__ void init(const GemmArgs& g, int BM, int BN) {
     tiles_n = (g.N + BN - 1) / BN;
     tiles_m = (g.M + BM - 1) / BM;
     tiles = tiles_m * tiles_n;
+    if (g.conv.pm_wgrad) {
+      // (tiles of ONE tap) x (valid pairs), position-major: neighbouring items reduce over the same block of rows
+      items = tiles_m * (g.conv.seg / BN) * pm_pairs(g.conv);
+      chunk = (items + AIT_NXCD - 1) / AIT_NXCD;
+      return;
+    }
     items = tiles * g.splits;
     chunk = (g.splits == 1) ? (tiles + AIT_NXCD - 1) / AIT_NXCD
                             : ((g.splits + AIT_NXCD - 1) / AIT_NXCD) * tiles;
@@ -635,6 +664,26 @@ struct WorkMap {
   // item id -> tile origin and K range
   __device__ __forceinline__ void decode(const GemmArgs& g, int id, int BM, int BN, int& m0, int& n0,
                                          int& kbeg, int& kend) const {
+    if (g.conv.pm_wgrad) {
+      const ConvGeom& c = g.conv;
+      const int tpt = c.seg / BN, per = tiles_m * tpt;
+      int j = id / per;
+      const int t = id - j * per;
+      int p = 0, ylo = 0, ny = 0, xlo = 0, nx = 0;
+      for (;; p++) {                                  // (at most src_h * src_w steps; scalar)
+        pm_taps(p >> c.rows_w_shift, c.src_h, c.pm_kh, -c.c, ylo, ny);
+        pm_taps(p & ((1 << c.rows_w_shift) - 1), c.src_w, c.kw, -c.c, xlo, nx);
+        if (j < ny * nx) break;
+        j -= ny * nx;
+      }
+      const int jy = j / nx, tap = (ylo + jy) * c.kw + xlo + (j - jy * nx);
+      const int tm = t / tpt;
+      m0 = tm * BM;
+      n0 = (tap * tpt + (t - tm * tpt)) * BN;
+      kbeg = p * c.pm_maps;
+      kend = kbeg + c.pm_maps;
+      return;
+    }
     int split = 0, t = id;
     if (g.splits > 1) { split = id / tiles; t = id - split * tiles; }
     const int tm = t / tiles_n;
@@ -818,6 +867,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   int l_n0 = 0, l_m0 = 0;           // origin of the load cursor's tile (CONV kernels)
   int l_kin = 0;                    // CONV_A: reduction index within the current tap (retap() sets it; no per-slab modulo)
   int l_ty = 0, l_tx = 0, l_ch0 = 0;   // CONV_B: the column tile's tap (row, column of the window) and first source channel (+ group offset)
+  int l_blk_end = 0x7fffffff;          // CONV_B over position blocks: first row behind the item's block (a piece of an item ends on a slab, not on the block)
   int arow[LA];                     // CONV_A: this lane's (clamped) GEMM row per A transfer
   bool l_valid = true;
   // CONV_A: operand pointers at reduction index l_k = tap * seg + kin
@@ -876,6 +926,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     l_n0 = n0;
     if constexpr (GRP || ROWMAP || CONV == CONV_B) l_m0 = m0;
     if constexpr (CONV == CONV_B) {
+      if (g.conv.pm_wgrad) l_blk_end = (l_k / g.conv.pm_maps + 1) * g.conv.pm_maps;
       const int tap = n0 / g.conv.seg;
       l_ty = tap / g.conv.kw;
       l_tx = tap - l_ty * g.conv.kw;
@@ -970,7 +1021,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           // column tile) pairs with GEMM row k; nothing to pair with -> the row of zeros
           // (tap, channel offset and group of the column / row tile: l_ty, l_tx, l_ch0 -- set once per tile in set_tile)
           const int e = q * 256 + lane * 4;
-          const int src = conv_src_row_t(g.conv, l_k + e / BN, l_ty, l_tx);
+          // (position blocks: rows past the item's block belong to the next position -- they read the row of zeros)
+          const int kr_b = l_k + e / BN;
+          const int src = (g.conv.pm_wgrad && kr_b >= l_blk_end) ? -1 : conv_src_row_t(g.conv, kr_b, l_ty, l_tx);
           glds16_at((src >= 0 ? g.B + (size_t)src * g.ldb + l_ch0 : g.conv.zero) + e % BN, dst);
         } else {
           glds16_at(pb[piece - LA], dst);
@@ -1809,7 +1862,7 @@ int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int 
     if (EPI == EPI_ATOMIC) {
       // split-K launches (weight gradients): a piece of an item just ADDS its partial tile like a whole item does --
       // no scratch, no hand-off; costs one more atomic epilogue (~4 slab-times) per cut.  Needs equal splits.
-      const bool equal = g.K % 16 == 0 && (g.splits == 1 || (g.k_per_split % 16 == 0 && g.K == g.splits * g.k_per_split));
+      const bool equal = g.conv.pm_wgrad || (g.K % 16 == 0 && (g.splits == 1 || (g.k_per_split % 16 == 0 && g.K == g.splits * g.k_per_split)));
       if (equal && rem > 0 && item_slabs * (last_round - (double)rem / wfull) > 6.0) {
         gl.sk_on = 1;
         w = wfull;

@@ -42,6 +42,8 @@ struct Product {
   static constexpr bool no_bf16_planes = false;
   // tail.hip: layer4's activations in position-major row order (false: map-major, round 5's)
   static constexpr bool l4_pm = true;
+  // conv_f32.hip: the 3x3 weight gradient of position-major maps over position blocks, out-of-map (position, tap) pairs skipped
+  static constexpr bool l4_pm_wgrad = true;
   // gemm_f32.hip: products of fewer than 512 256x128 tiles on the 128x128 split tile (0 off, 1 static work list, 2 with the
   // scheduler scratch: tickets + stream-K)
   static constexpr int mid_tile = 0;

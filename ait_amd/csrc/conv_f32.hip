@@ -159,6 +159,32 @@ static int set_pm(ConvGeom& c, const ait_conv_geom* q, int pm, bool general, lon
   return AIT_OK;
 }
 
+// Tap skipping for the forward / data gradient of position-major 4 x 4 maps (ConvGeom::pm_skip): on, if the launch is what
+// the kernel's two-group cut handles -- the 256 x 256 tile, every XCD's chunk of the tile list = the tiles of two whole
+// positions and no longer than the workgroups of an XCD (32), a dense 3x3-like window with padding, the split product form,
+// the partial-tile scratch in the launch context.  Returns the executed (position, tap) pairs per map, 0 = off.
+static int set_pm_skip(GemmArgs& g, const ait_conv_geom* q, int pm, int seg, const ait_launch_ctx* ctx) {
+  if (!pm || !ait_lab::Knobs::l4_pm_skip || bf16_products(ctx)) return 0;
+  if (q->in_h != 4 || q->in_w != 4 || q->kh * q->kw < 2 || q->pad < 1 || q->groups > 1 || (seg % 16)) return 0;
+  const SchedWs ws = sched_ws_of(ctx);
+  const int tiles_n = (g.N + 255) / 256, tpr = (q->n + 255) / 256, tpp = tpr * tiles_n;
+  const int items = 16 * tpp, chunk = items / AIT_NXCD;
+  if (g.N % 256 || g.M < 4096 || (items % AIT_NXCD) || chunk != 2 * tpp || chunk > 32) return 0;
+  if (!ws.p || ws.bytes < kCtlBytes + (size_t)256 * 256 * 256 * sizeof(float)) return 0;
+  g.conv.pm_skip = 1;
+  g.conv.pm_kh = q->kh;
+  // corners beside interiors, edges beside edges: 13 / 12 taps per XCD (position pairs in launch order)
+  g.conv.pm_order = 0xedb87421af9c6350ull;
+  int pairs = 0;
+  for (int p = 0; p < 16; p++) {
+    int l, ny, nx;
+    WorkMap::pm_axis(p >> 2, 4, q->kh, g.conv.b, g.conv.c, l, ny);
+    WorkMap::pm_axis(p & 3, 4, q->kw, g.conv.b, g.conv.c, l, nx);
+    pairs += ny * nx;
+  }
+  return pairs;
+}
+
 int ait_conv_fwd_f32_pm(const float* x, int ldx, const float* w, const ait_conv_geom* q, int cin, int cout,
                         const float* bias, const float* residual, int flags, float* y, int ldy,
                         const float* zeros, size_t zeros_floats, int pm, const ait_launch_ctx* ctx, void* stream) {
@@ -180,6 +206,12 @@ int ait_conv_fwd_f32_pm(const float* x, int ldx, const float* w, const ait_conv_
   g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
   if (general) set_general_rows(g.conv, q->out_h, q->out_w, rows);
   AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows));
+  if (const int pairs = set_pm_skip(g, q, pm, cing, ctx)) {
+    // (executed work: the taps that reach the map -- the skipped ones multiply rows of zeros)
+    AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * q->n * pairs * cout * cing, ait_stream(stream), (int)rows, cout,
+                        pairs * cing / 16, 0, 1, 1);
+    return conv_launch<TileCoop, CONV_A, true, true>(g, ait_stream(stream), sched_ws_of(ctx));
+  }
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), (int)rows, cout,
                       taps * cing, 0, 1, 1);
   return conv_dispatch<CONV_A, true, true>(g, ait_stream(stream), ctx);
@@ -274,6 +306,11 @@ int ait_conv_bwd_data_f32_pm(const float* dy, int lddy, const float* w, const ai
                      G > 1 ? coutg : 0, cing);
   if (general) set_general_rows(g.conv, q->in_h, q->in_w, rows);
   AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows));
+  if (const int pairs = set_pm_skip(g, q, pm, coutg, ctx)) {
+    AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * q->n * pairs * cin * coutg, ait_stream(stream), (int)rows, cin,
+                        pairs * coutg / 16, 0, 0, 1);
+    return conv_launch<TileCoop, CONV_A, true, false>(g, ait_stream(stream), sched_ws_of(ctx));
+  }
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cin * taps * coutg, ait_stream(stream), (int)rows, cin,
                       taps * coutg, 0, 0, 1);
   return conv_dispatch<CONV_A, true, false>(g, ait_stream(stream), ctx);

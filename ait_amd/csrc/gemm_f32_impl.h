@@ -59,6 +59,14 @@ struct ConvGeom {
   // the valid (position, tap) pairs x the tiles of a tap, every one pm_maps rows long (WorkMap below); 100 of the 144
   // pairs of a 3x3 window on 4 x 4 maps.  pm_kh = window rows.
   int pm_wgrad, pm_kh;
+  // ... and the FORWARD / DATA GRADIENT with the out-of-map taps left out (pm_skip != 0, CONV_A, stride 1, b = +-1): a row
+  // tile lies inside ONE position's block of rows (the last tile of a block is ragged: m0 = position * pm_maps + t * BM, rows
+  // past the block masked), its reduction runs over the ntaps(position) taps that reach the map, in window order -- 4, 6 or
+  // 9 of a 3x3 window's taps on 4 x 4 maps.  Items therefore differ in length; the stream-K cut handles an XCD's chunk as up
+  // to two groups of equal-length items (kernel).  pm_order: the positions in launch order, a nibble each -- an order in which
+  // every XCD's share of the tile list carries about the same number of taps.
+  int pm_skip;
+  unsigned long long pm_order;
   // ---- the data gradient of a STRIDE-2 convolution by parity class (py, px) of the input positions (ROWMAP kernels):
   // a class holds the positions (2ya + py, 2xa + px); only the window taps ty = (py + pad) mod 2 (+ 2 ...) reach it
   // (1, 2, 2 or 4 of a 3x3 window's 9), the source position of class tap (t'y, t'x) is (ya + cy - t'y, xa + cx - t'x),
@@ -657,13 +665,53 @@ struct WorkMap {
       chunk = (items + AIT_NXCD - 1) / AIT_NXCD;
       return;
     }
+    if (g.conv.pm_skip) {
+      // every position's block in its own row tiles
+      const int tpr = (g.conv.pm_maps + BM - 1) / BM;
+      tiles_m = tpr << g.conv.rows_hw_shift;
+      tiles = tiles_m * tiles_n;
+      items = tiles;
+      chunk = (items + AIT_NXCD - 1) / AIT_NXCD;
+      return;
+    }
     items = tiles * g.splits;
     chunk = (g.splits == 1) ? (tiles + AIT_NXCD - 1) / AIT_NXCD
                             : ((g.splits + AIT_NXCD - 1) / AIT_NXCD) * tiles;
   }
+  // taps along one axis that reach the map from position q of n: source coordinate q + c + b * t (b = +1 forward, -1 data
+  // gradient), window k: [lo, lo + cnt)
+  __host__ __device__ static void pm_axis(int q, int n, int k, int b, int c, int& lo, int& cnt) {
+    int l = b > 0 ? -c - q : q + c - (n - 1), h = b > 0 ? n - 1 - c - q : q + c;
+    if (l < 0) l = 0;
+    if (h > k - 1) h = k - 1;
+    lo = l;
+    cnt = h >= l ? h - l + 1 : 0;
+  }
+  struct PmTile { int p, ylo, ny, xlo, nx, m_end; };
+  // tap skipping: the position of tile-list entry `id` (through pm_order), its tap window, the end of its block of rows
+  __host__ __device__ PmTile pm_tile(const GemmArgs& g, int id, int BM) const {
+    const ConvGeom& c = g.conv;
+    const int tpr = (c.pm_maps + BM - 1) / BM, tpp = tpr * tiles_n;
+    PmTile t;
+    t.p = (int)((c.pm_order >> (4 * (id / tpp))) & 15ull);
+    pm_axis(t.p >> c.rows_w_shift, c.src_h, c.pm_kh, c.b, c.c, t.ylo, t.ny);
+    pm_axis(t.p & ((1 << c.rows_w_shift) - 1), c.src_w, c.kw, c.b, c.c, t.xlo, t.nx);
+    t.m_end = (t.p + 1) * c.pm_maps;
+    return t;
+  }
   // item id -> tile origin and K range
   __device__ __forceinline__ void decode(const GemmArgs& g, int id, int BM, int BN, int& m0, int& n0,
                                          int& kbeg, int& kend) const {
+    if (g.conv.pm_skip) {
+      const int tpr = (g.conv.pm_maps + BM - 1) / BM, tpp = tpr * tiles_n;
+      const PmTile t = pm_tile(g, id, BM);
+      const int r = id - (id / tpp) * tpp, tr = r / tiles_n;
+      m0 = t.p * g.conv.pm_maps + tr * BM;
+      n0 = (r - tr * tiles_n) * BN;
+      kbeg = 0;
+      kend = t.ny * t.nx * g.conv.seg;
+      return;
+    }
     if (g.conv.pm_wgrad) {
       const ConvGeom& c = g.conv;
       const int tpt = c.seg / BN, per = tiles_m * tpt;
@@ -765,13 +813,38 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // slabs per item: the whole reduction, or one K-split of it (split-K launches combine with atomics: their pieces
   // need no hand-off at all -- every piece simply adds its partial tile; launch() enables the list only when all
   // splits have the same length)
-  const int ns = (g.splits > 1 ? g.k_per_split : g.K) / BK;
+  int ns = (g.splits > 1 ? g.k_per_split : g.K) / BK;
+  // Tap skipping (ConvGeom::pm_skip) makes the items of a chunk differ in length -- by position, and a chunk holds the tiles
+  // of whole positions in order, so its items form runs of equal length.  The cut treats (up to) TWO such runs as two
+  // independent groups side by side: group `grp` = items [g_i0, g_i0 + sk_r) of the chunk, each g-local `ns` slabs long, cut
+  // over the workgroups [g_j0, g_j0 + g_W) in proportion to the groups' work.  Inside a group everything is the uniform
+  // scheme above with (j - g_j0, g_W) for (j, W).  (One group, all of W: every other launch.)
+  int g_i0 = 0, g_j0 = 0, g_W = W;
   if (g.sk_on) {
     sk_r = lim % W;
+    if constexpr (CONV == CONV_A) {
+      if (g.conv.pm_skip) {
+        auto len_of = [&](int i) -> int { const WorkMap::PmTile t = wmap.pm_tile(g, base + i, BM); return t.ny * t.nx * (g.conv.seg / BK); };
+        sk_r = lim;                                  // (launch() made sure that lim <= W: no whole items beside the cut)
+        const int L0 = len_of(0);
+        int na = 1;
+        while (na < lim && len_of(na) == L0) na++;
+        ns = L0;
+        if (na < lim) {
+          const int L1 = len_of(na);
+          const long long wa = (long long)na * L0, wb = (long long)(lim - na) * L1;
+          int Wa = (int)(((long long)W * wa + (wa + wb) / 2) / (wa + wb));
+          Wa = max(1, min(W - 1, Wa));
+          if (j < Wa) { sk_r = na; g_W = Wa; }
+          else { g_i0 = na; sk_r = lim - na; g_j0 = Wa; g_W = W - Wa; ns = L1; }
+        }
+      }
+    }
+    const int jl = j - g_j0;
     sk_total = sk_r * ns;
-    sk_w = max(1, min(W, sk_total / SK_MIN));
-    if (sk_r > 0 && j < sk_w) {
-      const int lo = (int)((long long)j * sk_total / sk_w), hi = (int)((long long)(j + 1) * sk_total / sk_w);
+    sk_w = max(1, min(g_W, sk_total / SK_MIN));
+    if (sk_r > 0 && jl < sk_w) {
+      const int lo = (int)((long long)jl * sk_total / sk_w), hi = (int)((long long)(jl + 1) * sk_total / sk_w);
       skA_tile = lo / ns;
       const int e0 = min(hi, (skA_tile + 1) * ns);
       skA_kb = (lo - skA_tile * ns) * BK;
@@ -780,6 +853,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       if (hi > e0) { skB_ke = (hi - e0) * BK; n_sk = 2; }
     }
   }
+  const int sk_all = (CONV == CONV_A && g.conv.pm_skip && g.sk_on) ? lim : sk_r;      // items of the chunk that are cut, all groups
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -794,7 +868,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   // vmcnt(0) wait covers it), so no wave ever waits for the counter.  The last workgroup of an XCD to exit
   // zeroes its two counters.
   const bool dyn = g.sched != nullptr;
-  const int lim_dp = lim - sk_r;                                   // whole items of this XCD
+  const int lim_dp = lim - sk_all;                                 // whole items of this XCD
   int* idq = reinterpret_cast<int*>(lds + NSR * (SA + SB) + (kCoop ? 2 * 24 * (BM + BN) : 0));         // [8] ticket ring
   unsigned* ticket = g.sched + xcd * 32;
   int n_fetched = 0;            // tickets in the ring so far (identical in every wave)
@@ -819,11 +893,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   auto get_item = [&](int it, int& m0, int& n0, int& kb, int& ke) __attribute__((always_inline)) -> bool {
     int id;
     const bool pieceB = n_sk == 2 && it == 0;        // (two pieces: the non-owned head of the next tile goes first)
-    if (it < n_sk) id = skA_tile + (pieceB ? 1 : 0);
+    if (it < n_sk) id = g_i0 + skA_tile + (pieceB ? 1 : 0);
     else {
       id = dp_id(it - n_sk);
       if (id < 0) return false;
-      id += sk_r;
+      id += sk_all;
     }
     wmap.decode(g, base + id, BM, BN, m0, n0, kb, ke);
     if constexpr (ROWMAP) { kb = 0; ke = pick_class(g.conv, (m0 >> g.conv.bm_shift) & 3).k_end; }     // (never with stream-K pieces)
@@ -872,8 +946,26 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   bool l_valid = true;
   // CONV_A: operand pointers at reduction index l_k = tap * seg + kin
   auto retap = [&]() __attribute__((always_inline)) {
-    const int tap = l_k / g.conv.seg, kin = l_k - tap * g.conv.seg;
+    int tap = l_k / g.conv.seg;
+    const int kin = l_k - tap * g.conv.seg;
     l_kin = kin;
+    // tap skipping (ConvGeom::pm_skip): the reduction index counts only the taps that reach the map from the tile's position;
+    // their sources lie a constant number of rows away (position-major rows), inside the map by construction
+    bool pmk = false;
+    int pm_shift = 0;
+    if constexpr (CONV == CONV_A && !ROWMAP && !GRP) {
+      if (g.conv.pm_skip) {
+        const ConvGeom& c = g.conv;
+        const int p = l_m0 / c.pm_maps;
+        int ylo, ny, xlo, nx;
+        WorkMap::pm_axis(p >> c.rows_w_shift, c.src_h, c.pm_kh, c.b, c.c, ylo, ny);
+        WorkMap::pm_axis(p & ((1 << c.rows_w_shift) - 1), c.src_w, c.kw, c.b, c.c, xlo, nx);
+        const int jy = tap / nx, ty = ylo + jy, tx = xlo + (tap - jy * nx);
+        tap = ty * c.kw + tx;
+        pm_shift = ((c.c + c.b * ty) * c.src_w + (c.c + c.b * tx)) * c.pm_maps;
+        pmk = true;
+      }
+    }
     int grp = 0, gch = 0;                          // GRP: the tile's group, its first channel in the gathered operand
     if constexpr (GRP) { grp = l_n0 / g.conv.n_group; gch = grp * g.conv.a_group; }
     const int col0 = GRP ? l_n0 - grp * g.conv.n_group : l_n0;
@@ -908,8 +1000,17 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     for (int i = 0; i < LA; i++) {
       const int row = (wave + i * NW) * 16 + (lane >> 2);
       const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-      const int src = conv_src_row(g.conv, arow[i], tap);
+      const int src = pmk ? arow[i] + pm_shift : conv_src_row(g.conv, arow[i], tap);
       pa[i] = (src >= 0 ? g.A + (size_t)src * g.lda + gch : g.conv.zero) + kin + chunk * 4;
+    }
+    if (BKC && pmk) {
+      // K-contiguous weights [co][tap][ci]: the next tap in work is not the next in memory
+#pragma unroll
+      for (int i = 0; i < LB; i++) {
+        const int row = (wave + i * NW) * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        pb[i] = g.B + (size_t)min(l_n0 + row, g.N - 1) * g.ldb + tap * g.conv.seg + kin + chunk * 4;
+      }
     }
     if (!BKC) {
       // K-outer weights [co][tap][ci]: rows = output channels (of the tile's group), columns within the tap
@@ -924,7 +1025,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     int m0, n0;
     if (!get_item(it, m0, n0, l_k, l_kend)) { l_valid = false; return; }
     l_n0 = n0;
-    if constexpr (GRP || ROWMAP || CONV == CONV_B) l_m0 = m0;
+    if constexpr (GRP || ROWMAP || CONV != CONV_NONE) l_m0 = m0;
     if constexpr (CONV == CONV_B) {
       if (g.conv.pm_wgrad) l_blk_end = (l_k / g.conv.pm_maps + 1) * g.conv.pm_maps;
       const int tap = n0 / g.conv.seg;
@@ -947,7 +1048,11 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           int cls_, rr_;
           parity_row(g.conv, min(m0 + row, g.M - 1), cls_, rr_);
           arow[i] = rr_;
-        } else if (CONV == CONV_A) arow[i] = min(m0 + row, g.M - 1);
+        } else if (CONV == CONV_A) {
+          // (tap skipping: the tile ends with its position's block of rows)
+          const int m_lim = g.conv.pm_skip ? min(g.M, (m0 / g.conv.pm_maps + 1) * g.conv.pm_maps) : g.M;
+          arow[i] = min(m0 + row, m_lim - 1);
+        }
         else pa[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + l_k + chunk * 4;
       } else {
         const int e = q * 256 + lane * 4;            // element of the [16][BM] image
@@ -1510,10 +1615,15 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     }
     if constexpr (Probe::on) { c_loop += __builtin_amdgcn_s_memtime() - c0; n_tile++; }
     bool finish = true;          // this workgroup writes the tile
-    if (EPI != EPI_ATOMIC && item < n_sk && (kbeg != 0 || kend != g.K)) {
+    // (the item's whole reduction: g.K, or with tap skipping its position's taps)
+    int k_full = g.K;
+    if constexpr (CONV == CONV_A) {
+      if (g.conv.pm_skip) { int a_, b_, c_; wmap.decode(g, base + g_i0 + skA_tile + ((n_sk == 2 && item == 0) ? 1 : 0), BM, BN, a_, b_, c_, k_full); }
+    }
+    if (EPI != EPI_ATOMIC && item < n_sk && (kbeg != 0 || kend != k_full)) {
       // Inter-workgroup hand-off in the write-through form: every byte of a partial tile is stored sc1
       // and read with sc1 loads (per-XCD L2s are not coherent), the flag is an agent-scope word.
-      if (kend != g.K) {                           // does not end its tile: publish
+      if (kend != k_full) {                        // does not end its tile: publish
         finish = false;
         __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(
             g.sk_ws + (size_t)blockIdx.x * (BM * BN), 0, BM * BN * 4, 0x00020000);
@@ -1534,9 +1644,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           __hip_atomic_store(g.sk_flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else {                                     // ends its tile: gather the runs before it, in workgroup order
         const int tile_start = skA_tile * ns;      // (an owned stream-K piece is always piece A)
-        for (int jj = j - 1; jj >= 0; jj--) {
+        for (int jj = j - g_j0 - 1; jj >= 0; jj--) {      // (runs of this workgroup's group)
           if ((int)((long long)(jj + 1) * sk_total / sk_w) <= tile_start) break;      // run jj ends before this tile
-          const int peer = jj * AIT_NXCD + xcd;
+          const int peer = (g_j0 + jj) * AIT_NXCD + xcd;
           if (threadIdx.x == 0) {
             while (__hip_atomic_load(g.sk_flags + peer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
               __builtin_amdgcn_s_sleep(2);
@@ -1566,7 +1676,18 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
         }
       }
     }
-    if (finish) epilogue<C::TM, C::TN, EPI, ROWMAP>(acc, g, m0, n0, wm, wn, li, lk);
+    if (finish) {
+      bool done = false;
+      if constexpr (CONV == CONV_A && !ROWMAP && !GRP) {
+        if (g.conv.pm_skip) {       // a tile ends with its position's block of rows: the rows behind it are another position's
+          GemmArgs ge = g;
+          ge.M = min(g.M, (m0 / g.conv.pm_maps + 1) * g.conv.pm_maps);
+          epilogue<C::TM, C::TN, EPI, ROWMAP>(acc, ge, m0, n0, wm, wn, li, lk);
+          done = true;
+        }
+      }
+      if (!done) epilogue<C::TM, C::TN, EPI, ROWMAP>(acc, g, m0, n0, wm, wn, li, lk);
+    }
     // (the operand quads are dead across the epilogue -- its address arithmetic needs the registers --
     // and are fetched again from the next tile's first slab, complete in LDS since the last barrier)
     __builtin_amdgcn_sched_barrier(0);
@@ -1870,6 +1991,18 @@ int launch(const GemmArgs& g, hipStream_t s, const SchedWs& ws = SchedWs(), int 
     }
     // (12 slab-times: what a stream-K cut of the last round must save to pay for its hand-off)
     const bool sk_pays = item_slabs * (last_round - (double)rem / wfull) > ait_lab::Knobs::sk_pays;
+    if (g.conv.pm_skip) {
+      // tap skipping: every item is cut (the kernel's two-group scheme); the caller checked pm_skip_fits()
+      if (!ws.p || wmap.chunk > wfull || ws.bytes < kCtlBytes + (size_t)wfull * AIT_NXCD * C::BM * C::BN * sizeof(float))
+        return AIT_EWORKSPACE;
+      gl.sk_on = 1;
+      gl.sk_ws = ws.partials();
+      gl.sk_flags = ws.flags();
+      blocks = (unsigned)(wfull * AIT_NXCD);
+      hipLaunchKernelGGL((gemm_f32_stream_kernel<C, AK, BKC, EPI, Probe, CONV, GRP, ROWMAP>), dim3(blocks), dim3(C::NT), C::LDS, s, gl);
+      AIT_CHECK_LAUNCH();
+      return AIT_OK;
+    }
     if (ws.p) {
       if (ws.bytes < kCtlBytes) return AIT_EWORKSPACE;
       // ticket counters for the dynamic hand-out of whole tiles (every launch), partial tiles + flags when this

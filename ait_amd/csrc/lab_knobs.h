@@ -44,6 +44,8 @@ struct Product {
   static constexpr bool l4_pm = true;
   // conv_f32.hip: the 3x3 weight gradient of position-major maps over position blocks, out-of-map (position, tap) pairs skipped
   static constexpr bool l4_pm_wgrad = true;
+  // conv_f32.hip: the 3x3 forward / data gradient of position-major maps with the out-of-map taps skipped (two-group stream-K cut)
+  static constexpr bool l4_pm_skip = true;
   // gemm_f32.hip: products of fewer than 512 256x128 tiles on the 128x128 split tile (0 off, 1 static work list, 2 with the
   // scheduler scratch: tickets + stream-K)
   static constexpr int mid_tile = 0;

@@ -151,9 +151,13 @@ int wgrad_dispatch(const GemmArgs& g, hipStream_t s, const SchedWs& ws, bool gro
 }  // namespace
 
 // position-major rows (ConvGeom::pm_maps; csrc/tail.hip): power-of-two maps, stride 1, dense, fewer than 2^24 rows
-static int set_pm(ConvGeom& c, const ait_conv_geom* q, int pm, bool general, long long rows) {
+// (launches over position-major rows run on the cooperative 256 x 256 tile's kernels -- the only ones that carry the
+// position-major decode -- in the split product form: the callers below)
+static int set_pm(ConvGeom& c, const ait_conv_geom* q, int pm, bool general, long long rows, const ait_launch_ctx* ctx) {
   if (!pm) return AIT_OK;
-  if (general || q->stride != 1 || q->groups > 1 || q->in_h != q->out_h || q->in_w != q->out_w || rows >= (1ll << 24)) return AIT_EUNSUPPORTED;
+  if (general || q->stride != 1 || q->groups > 1 || q->in_h != q->out_h || q->in_w != q->out_w || rows >= (1ll << 24) ||
+      bf16_products(ctx) || (ctx && (ctx->flags & AIT_CTX_NATIVE_F32)))
+    return AIT_EUNSUPPORTED;
   c.pm_maps = q->n;
   c.inv_pm = 1.0f / (float)q->n;
   return AIT_OK;
@@ -205,11 +209,12 @@ int ait_conv_fwd_f32_pm(const float* x, int ldx, const float* w, const ait_conv_
                        16, g));
   g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
   if (general) set_general_rows(g.conv, q->out_h, q->out_w, rows);
-  AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows));
-  if (const int pairs = set_pm_skip(g, q, pm, cing, ctx)) {
+  AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows, ctx));
+  if (pm) {
     // (executed work: the taps that reach the map -- the skipped ones multiply rows of zeros)
-    AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * q->n * pairs * cout * cing, ait_stream(stream), (int)rows, cout,
-                        pairs * cing / 16, 0, 1, 1);
+    const int pairs = set_pm_skip(g, q, pm, cing, ctx);
+    AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, pairs ? 2.0 * q->n * pairs * cout * cing : 2.0 * rows * cout * taps * cing,
+                        ait_stream(stream), (int)rows, cout, pairs ? pairs * cing / 16 : taps * cing, 0, 1, 1);
     return conv_launch<TileCoop, CONV_A, true, true>(g, ait_stream(stream), sched_ws_of(ctx));
   }
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), (int)rows, cout,
@@ -305,10 +310,11 @@ int ait_conv_bwd_data_f32_pm(const float* dy, int lddy, const float* w, const ai
   g.conv = make_geom(hw, ws, q->out_h, q->out_w, q->kw, 1, -1, q->pad, log2_exact(q->stride), coutg, (long long)cing, zeros,
                      G > 1 ? coutg : 0, cing);
   if (general) set_general_rows(g.conv, q->in_h, q->in_w, rows);
-  AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows));
-  if (const int pairs = set_pm_skip(g, q, pm, coutg, ctx)) {
-    AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * q->n * pairs * cin * coutg, ait_stream(stream), (int)rows, cin,
-                        pairs * coutg / 16, 0, 0, 1);
+  AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows, ctx));
+  if (pm) {
+    const int pairs = set_pm_skip(g, q, pm, coutg, ctx);
+    AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, pairs ? 2.0 * q->n * pairs * cin * coutg : 2.0 * rows * cin * taps * coutg,
+                        ait_stream(stream), (int)rows, cin, pairs ? pairs * coutg / 16 : taps * coutg, 0, 0, 1);
     return conv_launch<TileCoop, CONV_A, true, false>(g, ait_stream(stream), sched_ws_of(ctx));
   }
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cin * taps * coutg, ait_stream(stream), (int)rows, cin,
@@ -340,7 +346,7 @@ int ait_conv_bwd_weight_f32_pm(const float* dy, int lddy, const float* x, int ld
                        nullptr, AIT_GEMM_ATOMIC, split_k < 1 ? 1 : split_k, 0, 0, 16, g));
   g.conv = make_geom(hw, ws, q->in_h, q->in_w, q->kw, q->stride, 1, -q->pad, 0, cing, 0, zeros, G > 1 ? cing : 0, cout / G);
   if (general) set_general_rows(g.conv, q->out_h, q->out_w, rows);
-  AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows));
+  AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows, ctx));
   // position-major rows, a window that hangs over the map's edge: the reduction over position blocks, the (position, tap)
   // pairs that multiply nothing but zeros left out (ConvGeom::pm_wgrad).  Items are q->n rows long (rounded up to whole
   // slabs: the rows past a block read zeros); `splits` > 1 only says "several items per output tile" to the kernel.
@@ -359,6 +365,7 @@ int ait_conv_bwd_weight_f32_pm(const float* dy, int lddy, const float* x, int ld
     return conv_launch<TileCoop, CONV_B, false, false>(g, ait_stream(stream), sched_ws_of(ctx));
   }
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, flops, ait_stream(stream), cout, taps * cing, probe_k, 1, 0, g.splits);
+  if (pm) return conv_launch<TileCoop, CONV_B, false, false>(g, ait_stream(stream), sched_ws_of(ctx));      // (position-major rows: see set_pm)
   if (bf16_products(ctx)) return wgrad_dispatch<Bf16Fam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1, false);
   return wgrad_dispatch<SplitFam>(g, ait_stream(stream), sched_ws_of(ctx), G > 1, sp_coop);
 }

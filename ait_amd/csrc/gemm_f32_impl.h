@@ -131,9 +131,12 @@ __device__ __forceinline__ void pm_decode(const ConvGeom& c, int r, int& map, in
   x = p & ((1 << c.rows_w_shift) - 1);
 }
 
+// (PM: only the kernels of the 256 x 256 cooperative tile carry the position-major decode -- every launch over
+// position-major rows runs on it; in the 256 x 128 kernels its registers cost ~800 bytes of scratch per lane)
+template <bool PM = false>
 __device__ __forceinline__ int conv_src_row(const ConvGeom& c, int r, int tap) {
   int img, y, x;
-  if (c.pm_maps > 0) {
+  if (PM && c.pm_maps > 0) {
     pm_decode(c, r, img, y, x);
   } else if (c.rows_hw_shift >= 0) {
     img = r >> c.rows_hw_shift;
@@ -150,14 +153,15 @@ __device__ __forceinline__ int conv_src_row(const ConvGeom& c, int r, int tap) {
   const int ny = y * c.a + c.c + ty * c.b, nx = x * c.a + c.c + tx * c.b;
   const int sy = ny >> c.div_shift, sx = nx >> c.div_shift;
   const bool ok = ny >= 0 && nx >= 0 && ((ny | nx) & ((1 << c.div_shift) - 1)) == 0 && sy < c.src_h && sx < c.src_w;
-  if (c.pm_maps > 0) return ok ? (sy * c.src_w + sx) * c.pm_maps + img : -1;
+  if (PM && c.pm_maps > 0) return ok ? (sy * c.src_w + sx) * c.pm_maps + img : -1;
   return ok ? (img * c.src_h + sy) * c.src_w + sx : -1;
 }
 // the same with the tap already decomposed (ty, tx): the weight gradient's tap is fixed per column tile, and tap / kw is
 // a ~35-instruction runtime division the transfers of every slab would repeat
+template <bool PM = false>
 __device__ __forceinline__ int conv_src_row_t(const ConvGeom& c, int r, int ty, int tx) {
   int img, y, x;
-  if (c.pm_maps > 0) {
+  if (PM && c.pm_maps > 0) {
     pm_decode(c, r, img, y, x);
   } else if (c.rows_hw_shift >= 0) {
     img = r >> c.rows_hw_shift;
@@ -173,7 +177,7 @@ __device__ __forceinline__ int conv_src_row_t(const ConvGeom& c, int r, int ty, 
   const int ny = y * c.a + c.c + ty * c.b, nx = x * c.a + c.c + tx * c.b;
   const int sy = ny >> c.div_shift, sx = nx >> c.div_shift;
   const bool ok = ny >= 0 && nx >= 0 && ((ny | nx) & ((1 << c.div_shift) - 1)) == 0 && sy < c.src_h && sx < c.src_w;
-  if (c.pm_maps > 0) return ok ? (sy * c.src_w + sx) * c.pm_maps + img : -1;
+  if (PM && c.pm_maps > 0) return ok ? (sy * c.src_w + sx) * c.pm_maps + img : -1;
   return ok ? (img * c.src_h + sy) * c.src_w + sx : -1;
 }
 
@@ -410,10 +414,13 @@ enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_AUX = 2, EPI_RES = 3, EPI_RESG = 4 /* 
 //               blocks before each half tile's stores (small / rare launches).
 template <int TM, int TN, int EPI, bool ROWMAP = false>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& g, int m0, int n0,
-                                         int wm, int wn, int li, int lk) {
+                                         int wm, int wn, int li, int lk, int m_lim = -1) {
+  // rows of the result that exist for THIS tile: g.M, or less for a tile that ends inside the matrix (tap skipping:
+  // ConvGeom::pm_skip -- a scalar, not a copy of the argument struct, which would go to scratch memory)
+  const int gM = m_lim >= 0 ? m_lim : g.M;
   const bool relu = (g.flags & AIT_GEMM_RELU) != 0;
   const unsigned ldc = (unsigned)g.ldc;
-  const bool interior = (m0 + wm + TM * 32 <= g.M) && (n0 + wn + TN * 32 <= g.N);   // wave-uniform
+  const bool interior = (m0 + wm + TM * 32 <= gM) && (n0 + wn + TN * 32 <= g.N);   // wave-uniform
   // Element offset of the first column of the row that holds accumulator register r of an MFMA tile whose first row
   // (for this lane) is `rb`: tile_off(rb) + reg_off(r).  Plain: rows rb + (r&3) + 8*(r>>2).  ROWMAP (parity-class
   // data gradient on 4 x 4 class grids): rb is a multiple of 4 with y = lane half, so register r sits at x = r & 3,
@@ -473,7 +480,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
     // never has one: its row count is a multiple of the tile)
     auto off_of = [&](int i, int r, bool clamp) -> unsigned {
       if constexpr (ROWMAP) return cb[i % TN] + tile_off(m0 + wm + (i / TN) * 32 + 4 * lk) + reg_off(r);
-      else return cb[i % TN] + (unsigned)(clamp ? min(row_of(i, r), g.M - 1) : row_of(i, r)) * ldc;
+      else return cb[i % TN] + (unsigned)(clamp ? min(row_of(i, r), gM - 1) : row_of(i, r)) * ldc;
     };
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -500,7 +507,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
         if constexpr (gated) v = gt[r] > 0.f ? v : 0.f;
         if (relu) v = fmaxf(v, 0.f);
         const int row = row_of(i, r);
-        if (interior || (cok[b] && row < g.M)) { g.C[off_of(i, r, false)] = v; cs[b] += v; }
+        if (interior || (cok[b] && row < gM)) { g.C[off_of(i, r, false)] = v; cs[b] += v; }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -525,7 +532,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
       if (EPI == EPI_ATOMIC) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          if (interior || (cok[b] && rbase + AIT_ROW(r) < g.M))
+          if (interior || (cok[b] && rbase + AIT_ROW(r) < gM))
             unsafeAtomicAdd(g.C + (obase + (unsigned)AIT_ROW(r) * ldc), g.alpha * acc[a][b][r]);
         }
       } else {
@@ -540,10 +547,10 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
             // serves small / rare launches only.)
             unsigned off[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) off[q] = cb[b] + (unsigned)min(rbase + AIT_ROW(h * 8 + q), g.M - 1) * ldc;
+            for (int q = 0; q < 8; q++) off[q] = cb[b] + (unsigned)min(rbase + AIT_ROW(h * 8 + q), gM - 1) * ldc;
             if (g.bias && (g.flags & AIT_GEMM_BIAS_ROW)) {
 #pragma unroll
-              for (int q = 0; q < 8; q++) v[q] += g.bias[min(rbase + AIT_ROW(h * 8 + q), g.M - 1)];
+              for (int q = 0; q < 8; q++) v[q] += g.bias[min(rbase + AIT_ROW(h * 8 + q), gM - 1)];
             }
             if (g.residual) {
               float x[8];
@@ -583,7 +590,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[TM][TN], const GemmArgs& 
           } else {
 #pragma unroll
             for (int q = 0; q < 8; q++)
-              if (cok[b] && rbase + AIT_ROW(h * 8 + q) < g.M) {
+              if (cok[b] && rbase + AIT_ROW(h * 8 + q) < gM) {
                 g.C[obase + (unsigned)AIT_ROW(h * 8 + q) * ldc] = v[q];
                 cs[b] += v[q];
               }
@@ -699,10 +706,11 @@ struct WorkMap {
     t.m_end = (t.p + 1) * c.pm_maps;
     return t;
   }
-  // item id -> tile origin and K range
+  // item id -> tile origin and K range (PM: the kernels that serve position-major launches, see conv_src_row)
+  template <bool PM = false>
   __device__ __forceinline__ void decode(const GemmArgs& g, int id, int BM, int BN, int& m0, int& n0,
                                          int& kbeg, int& kend) const {
-    if (g.conv.pm_skip) {
+    if (PM && g.conv.pm_skip) {
       const int tpr = (g.conv.pm_maps + BM - 1) / BM, tpp = tpr * tiles_n;
       const PmTile t = pm_tile(g, id, BM);
       const int r = id - (id / tpp) * tpp, tr = r / tiles_n;
@@ -712,7 +720,7 @@ struct WorkMap {
       kend = t.ny * t.nx * g.conv.seg;
       return;
     }
-    if (g.conv.pm_wgrad) {
+    if (PM && g.conv.pm_wgrad) {
       const ConvGeom& c = g.conv;
       const int tpt = c.seg / BN, per = tiles_m * tpt;
       int j = id / per;
@@ -822,7 +830,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   int g_i0 = 0, g_j0 = 0, g_W = W;
   if (g.sk_on) {
     sk_r = lim % W;
-    if constexpr (CONV == CONV_A) {
+    if constexpr (CONV == CONV_A && kCoop) {
       if (g.conv.pm_skip) {
         auto len_of = [&](int i) -> int { const WorkMap::PmTile t = wmap.pm_tile(g, base + i, BM); return t.ny * t.nx * (g.conv.seg / BK); };
         sk_r = lim;                                  // (launch() made sure that lim <= W: no whole items beside the cut)
@@ -853,7 +861,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       if (hi > e0) { skB_ke = (hi - e0) * BK; n_sk = 2; }
     }
   }
-  const int sk_all = (CONV == CONV_A && g.conv.pm_skip && g.sk_on) ? lim : sk_r;      // items of the chunk that are cut, all groups
+  const int sk_all = (CONV == CONV_A && kCoop && g.conv.pm_skip && g.sk_on) ? lim : sk_r;      // items of the chunk that are cut, all groups
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -899,7 +907,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       if (id < 0) return false;
       id += sk_all;
     }
-    wmap.decode(g, base + id, BM, BN, m0, n0, kb, ke);
+    wmap.template decode<kCoop>(g, base + id, BM, BN, m0, n0, kb, ke);
     if constexpr (ROWMAP) { kb = 0; ke = pick_class(g.conv, (m0 >> g.conv.bm_shift) & 3).k_end; }     // (never with stream-K pieces)
     if (it < n_sk) {                      // a piece: its sub-range of the item's K range
       ke = kb + (pieceB ? skB_ke : skA_ke);
@@ -953,7 +961,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     // their sources lie a constant number of rows away (position-major rows), inside the map by construction
     bool pmk = false;
     int pm_shift = 0;
-    if constexpr (CONV == CONV_A && !ROWMAP && !GRP) {
+    if constexpr (CONV == CONV_A && !ROWMAP && !GRP && kCoop) {
       if (g.conv.pm_skip) {
         const ConvGeom& c = g.conv;
         const int p = l_m0 / c.pm_maps;
@@ -1000,7 +1008,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     for (int i = 0; i < LA; i++) {
       const int row = (wave + i * NW) * 16 + (lane >> 2);
       const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-      const int src = pmk ? arow[i] + pm_shift : conv_src_row(g.conv, arow[i], tap);
+      const int src = pmk ? arow[i] + pm_shift : conv_src_row<kCoop>(g.conv, arow[i], tap);
       pa[i] = (src >= 0 ? g.A + (size_t)src * g.lda + gch : g.conv.zero) + kin + chunk * 4;
     }
     if (BKC && pmk) {
@@ -1025,9 +1033,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     int m0, n0;
     if (!get_item(it, m0, n0, l_k, l_kend)) { l_valid = false; return; }
     l_n0 = n0;
-    if constexpr (GRP || ROWMAP || CONV != CONV_NONE) l_m0 = m0;
+    if constexpr (GRP || ROWMAP || CONV == CONV_B || (CONV == CONV_A && kCoop)) l_m0 = m0;
     if constexpr (CONV == CONV_B) {
-      if (g.conv.pm_wgrad) l_blk_end = (l_k / g.conv.pm_maps + 1) * g.conv.pm_maps;
+      if constexpr (kCoop) { if (g.conv.pm_wgrad) l_blk_end = (l_k / g.conv.pm_maps + 1) * g.conv.pm_maps; }
       const int tap = n0 / g.conv.seg;
       l_ty = tap / g.conv.kw;
       l_tx = tap - l_ty * g.conv.kw;
@@ -1050,7 +1058,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           arow[i] = rr_;
         } else if (CONV == CONV_A) {
           // (tap skipping: the tile ends with its position's block of rows)
-          const int m_lim = g.conv.pm_skip ? min(g.M, (m0 / g.conv.pm_maps + 1) * g.conv.pm_maps) : g.M;
+          int m_lim = g.M;
+          if constexpr (kCoop) { if (g.conv.pm_skip) m_lim = min(g.M, (m0 / g.conv.pm_maps + 1) * g.conv.pm_maps); }
           arow[i] = min(m0 + row, m_lim - 1);
         }
         else pa[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + l_k + chunk * 4;
@@ -1128,7 +1137,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           const int e = q * 256 + lane * 4;
           // (position blocks: rows past the item's block belong to the next position -- they read the row of zeros)
           const int kr_b = l_k + e / BN;
-          const int src = (g.conv.pm_wgrad && kr_b >= l_blk_end) ? -1 : conv_src_row_t(g.conv, kr_b, l_ty, l_tx);
+          const int src = (kCoop && g.conv.pm_wgrad && kr_b >= l_blk_end) ? -1 : conv_src_row_t<kCoop>(g.conv, kr_b, l_ty, l_tx);
           glds16_at((src >= 0 ? g.B + (size_t)src * g.ldb + l_ch0 : g.conv.zero) + e % BN, dst);
         } else {
           glds16_at(pb[piece - LA], dst);
@@ -1617,8 +1626,8 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     bool finish = true;          // this workgroup writes the tile
     // (the item's whole reduction: g.K, or with tap skipping its position's taps)
     int k_full = g.K;
-    if constexpr (CONV == CONV_A) {
-      if (g.conv.pm_skip) { int a_, b_, c_; wmap.decode(g, base + g_i0 + skA_tile + ((n_sk == 2 && item == 0) ? 1 : 0), BM, BN, a_, b_, c_, k_full); }
+    if constexpr (CONV == CONV_A && kCoop) {
+      if (g.conv.pm_skip) { int a_, b_, c_; wmap.template decode<true>(g, base + g_i0 + skA_tile + ((n_sk == 2 && item == 0) ? 1 : 0), BM, BN, a_, b_, c_, k_full); }
     }
     if (EPI != EPI_ATOMIC && item < n_sk && (kbeg != 0 || kend != k_full)) {
       // Inter-workgroup hand-off in the write-through form: every byte of a partial tile is stored sc1
@@ -1677,16 +1686,12 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
       }
     }
     if (finish) {
-      bool done = false;
-      if constexpr (CONV == CONV_A && !ROWMAP && !GRP) {
-        if (g.conv.pm_skip) {       // a tile ends with its position's block of rows: the rows behind it are another position's
-          GemmArgs ge = g;
-          ge.M = min(g.M, (m0 / g.conv.pm_maps + 1) * g.conv.pm_maps);
-          epilogue<C::TM, C::TN, EPI, ROWMAP>(acc, ge, m0, n0, wm, wn, li, lk);
-          done = true;
-        }
+      int m_lim = -1;
+      if constexpr (CONV == CONV_A && !ROWMAP && !GRP && kCoop) {
+        // (tap skipping: a tile ends with its position's block of rows -- the rows behind it are another position's)
+        if (g.conv.pm_skip) m_lim = min(g.M, (m0 / g.conv.pm_maps + 1) * g.conv.pm_maps);
       }
-      if (!done) epilogue<C::TM, C::TN, EPI, ROWMAP>(acc, g, m0, n0, wm, wn, li, lk);
+      epilogue<C::TM, C::TN, EPI, ROWMAP>(acc, g, m0, n0, wm, wn, li, lk, m_lim);
     }
     // (the operand quads are dead across the epilogue -- its address arithmetic needs the registers --
     // and are fetched again from the next tile's first slab, complete in LDS since the last barrier)

@@ -92,13 +92,16 @@ int scale_rows(const ScaleBatch& b, hipStream_t s) {
 // Why: on a 4 x 4 map a 3x3 window hangs over the edge for 12 of the 16 positions -- 31 % of all (position, tap) pairs
 // multiply a row of zeros -- and in this order the rows of one position are ONE contiguous block, so that whole blocks of
 // the weight gradient's reduction can be skipped (conv_f32.hip).  map-major (the lab knob's other value): row = m * 16 + p.
+// (per call: the position-major gather exists in the split-product kernels only -- a call in the bf16 or the f32-instruction
+// product form keeps the map-major order)
 constexpr bool kPM = ait_lab::Knobs::l4_pm;
-__host__ __device__ __forceinline__ long long l4_row(int m, int p, int n_maps_pad) {
-  return kPM ? (long long)p * n_maps_pad + m : (long long)m * kPos + p;
+inline bool l4_pm_on(const ait_launch_ctx* ctx) { return kPM && !(ctx && (ctx->flags & (AIT_CTX_BF16 | AIT_CTX_NATIVE_F32))); }
+__host__ __device__ __forceinline__ long long l4_row(int m, int p, int n_maps_pad, int pm) {
+  return pm ? (long long)p * n_maps_pad + m : (long long)m * kPos + p;
 }
 
 // pooled[i][c] = mean of the 16 rows of map i (mean(3).mean(2) of the reference as one reduction over equal groups)
-__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ o, int n_maps, int n_maps_pad, int C,
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ o, int n_maps, int n_maps_pad, int pm, int C,
                                                        float* __restrict__ pooled) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)n_maps * (C / 4)) return;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int p = 0; p < kPos; p++) {
-    const float4 v = reinterpret_cast<const float4*>(o + (size_t)l4_row(m, p, n_maps_pad) * C)[c4];
+    const float4 v = reinterpret_cast<const float4*>(o + (size_t)l4_row(m, p, n_maps_pad, pm) * C)[c4];
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }
   const float k = 1.f / kPos;
@@ -114,11 +117,11 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
 }
 // g[r][c] = dpooled[r / 16][c] / 16 where o[r][c] > 0 (the ReLU that closes layer4), 0 elsewhere and on padding maps
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ o,
-                                                       long long rows, int n_maps, int n_maps_pad, int C, float* __restrict__ g) {
+                                                       long long rows, int n_maps, int n_maps_pad, int pm, int C, float* __restrict__ g) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= rows * (C / 4)) return;
   const long long r = i / (C / 4);
-  const int c4 = (int)(i - r * (C / 4)), m = kPM ? (int)(r % n_maps_pad) : (int)(r / kPos);
+  const int c4 = (int)(i - r * (C / 4)), m = pm ? (int)(r % n_maps_pad) : (int)(r / kPos);
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (m < n_maps) {
     const float4 d = reinterpret_cast<const float4*>(dpooled + (size_t)m * C)[c4];
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
 // order: a / b hold n maps of 16 rows (map-major, as the SK convolutions write them), y row l4_row(map0 + m, p).
 // n_zero more maps behind them are zero-filled (the padding maps, by the call that writes the last real ones).
 __global__ __launch_bounds__(256) void sqsum_l4_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, int n_zero,
-                                                           int map0, int n_maps_pad, int C, float* __restrict__ y) {
+                                                           int map0, int n_maps_pad, int pm, int C, float* __restrict__ y) {
   const long long n4 = (long long)(n + n_zero) * kPos * (C / 4);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const long long r = i / (C / 4);
@@ -147,17 +150,17 @@ __global__ __launch_bounds__(256) void sqsum_l4_fwd_kernel(const float* __restri
       u = fmaxf(x.z, 0.f); v = fmaxf(z.z, 0.f); o.z = u * u + v * v;
       u = fmaxf(x.w, 0.f); v = fmaxf(z.w, 0.f); o.w = u * u + v * v;
     }
-    reinterpret_cast<float4*>(y + (size_t)l4_row(map0 + m, p, n_maps_pad) * C)[c4] = o;
+    reinterpret_cast<float4*>(y + (size_t)l4_row(map0 + m, p, n_maps_pad, pm) * C)[c4] = o;
   }
 }
 __global__ __launch_bounds__(256) void sqsum_l4_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ a,
-                                                           const float* __restrict__ b, int n, int map0, int n_maps_pad, int C,
+                                                           const float* __restrict__ b, int n, int map0, int n_maps_pad, int pm, int C,
                                                            float* __restrict__ da, float* __restrict__ db) {
   const long long n4 = (long long)n * kPos * (C / 4);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const long long r = i / (C / 4);
     const int c4 = (int)(i - r * (C / 4)), m = (int)(r / kPos), p = (int)(r - (long long)m * kPos);
-    const float4 g = reinterpret_cast<const float4*>(dy + (size_t)l4_row(map0 + m, p, n_maps_pad) * C)[c4];
+    const float4 g = reinterpret_cast<const float4*>(dy + (size_t)l4_row(map0 + m, p, n_maps_pad, pm) * C)[c4];
     const float4 x = reinterpret_cast<const float4*>(a)[i], z = reinterpret_cast<const float4*>(b)[i];
     reinterpret_cast<float4*>(da)[i] = make_float4(2.f * fmaxf(x.x, 0.f) * g.x, 2.f * fmaxf(x.y, 0.f) * g.y,
                                                    2.f * fmaxf(x.z, 0.f) * g.z, 2.f * fmaxf(x.w, 0.f) * g.w);
@@ -330,7 +333,7 @@ int sk_forward(const float* x, int n, int n_zero, int map0, const Dims& d, const
   }
   if (n + n_zero == 0) return AIT_OK;
   hipLaunchKernelGGL(sqsum_l4_fwd_kernel, dim3(l4_grid((long long)(n + n_zero) * kPos * (d.C / 4))), dim3(256), 0, ait_stream(r.stream),
-                     f1, f3, n, n_zero, map0, d.n_maps_pad, d.C, xtop);
+                     f1, f3, n, n_zero, map0, d.n_maps_pad, (int)l4_pm_on(r.ctx), d.C, xtop);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }
@@ -398,7 +401,7 @@ AIT_API int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int
     const int cin = k == 0 ? C : E;
     AIT_TRY(linear(xin, d.R, cin, s.wf[k].w1, P, bw.bn1_shift, nullptr, true, s.a1[k], run, s.p3[k].w1.w));
     AIT_TRY(ait_conv_fwd_f32_pm(s.a1[k], P, s.wf[k].w2, &g3, P, P, bw.bn2_shift, nullptr, AIT_GEMM_RELU, s.a2[k], P, s.zeros, kZeros,
-                                kPM, ctx, stream));
+                                (int)l4_pm_on(ctx), ctx, stream));
     const float* idn = xin;
     if (k == 0) {
       // the projection shortcut; parked in the buffer of the NEXT block's output (free until then), or in the pooled
@@ -414,7 +417,7 @@ AIT_API int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int
   {
     const long long n4 = (long long)d.n_maps * (E / 4);
     hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, hs, s.o[d.n_blocks - 1], d.n_maps,
-                       d.n_maps_pad, E, pooled);
+                       d.n_maps_pad, (int)l4_pm_on(ctx), E, pooled);
     AIT_CHECK_LAUNCH();
   }
   return AIT_OK;
@@ -462,7 +465,7 @@ AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const floa
   {
     const long long n4 = d.R * (E / 4);
     hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, hs, d_pooled, s.o[d.n_blocks - 1], d.R,
-                       d.n_maps, d.n_maps_pad, E, ga);
+                       d.n_maps, d.n_maps_pad, (int)l4_pm_on(ctx), E, ga);
     AIT_CHECK_LAUNCH();
   }
   const ait_conv_geom g3 = l4_geom(d.n_maps_pad);
@@ -473,8 +476,8 @@ AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const floa
     const float* xin = k == 0 ? s.xtop : s.o[k - 1];
     AIT_TRY(wgrad(gout, d.R, E, s.a2[k], P, dwf[k].w3, run));                                     // d W3' += g^T a2
     AIT_TRY(dgrad(gout, d.R, E, s.wf[k].w3, P, nullptr, s.a2[k], g2, run, s.p3[k].w3.wt));                      // g2 = (g W3') [a2 > 0]
-    AIT_TRY(ait_conv_bwd_weight_f32_pm(g2, P, s.a1[k], P, &g3, P, P, dwf[k].w2, 8, s.zeros, kZeros, kPM, ctx, stream));
-    AIT_TRY(ait_conv_bwd_data_f32_pm(g2, P, s.wf[k].w2, &g3, P, P, s.a1[k], AIT_GEMM_MASK_POS, g1, P, s.zeros, kZeros, kPM, ctx, stream));
+    AIT_TRY(ait_conv_bwd_weight_f32_pm(g2, P, s.a1[k], P, &g3, P, P, dwf[k].w2, 8, s.zeros, kZeros, (int)l4_pm_on(ctx), ctx, stream));
+    AIT_TRY(ait_conv_bwd_data_f32_pm(g2, P, s.wf[k].w2, &g3, P, P, s.a1[k], AIT_GEMM_MASK_POS, g1, P, s.zeros, kZeros, (int)l4_pm_on(ctx), ctx, stream));
     AIT_TRY(wgrad(g1, d.R, P, xin, cin, dwf[k].w1, run));                                         // d W1' += g1^T x_in
     if (k > 0) {
       // gradient at the previous block's output: conv1's data gradient + the identity shortcut's, behind that block's ReLU
@@ -506,12 +509,12 @@ AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const floa
   // (f1p | f1q and f3p | f3q are separate buffers: two passes each)
   if (bp > 0) {
     hipLaunchKernelGGL(sqsum_l4_bwd_kernel, dim3(l4_grid((long long)bp * kPos * (C / 4))), dim3(256), 0, hs, dxt, s.f1p, s.f3p, bp, 0,
-                       d.n_maps_pad, C, df1, df3);
+                       d.n_maps_pad, (int)l4_pm_on(ctx), C, df1, df3);
     AIT_CHECK_LAUNCH();
   }
   if (bs > 0) {
     hipLaunchKernelGGL(sqsum_l4_bwd_kernel, dim3(l4_grid((long long)bs * kPos * (C / 4))), dim3(256), 0, hs, dxt, s.f1q, s.f3q, bs, bp,
-                       d.n_maps_pad, C, df1 + (size_t)d.Rp * C, df3 + (size_t)d.Rp * C);
+                       d.n_maps_pad, (int)l4_pm_on(ctx), C, df1 + (size_t)d.Rp * C, df3 + (size_t)d.Rp * C);
     AIT_CHECK_LAUNCH();
   }
   (void)Rsk;

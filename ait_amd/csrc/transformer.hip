@@ -91,10 +91,14 @@ inline int wgrad_splits(int M_out, int N_out, long long K, bool coop) {
     // 1536 x 512 x 76800 (the self-attention blocks' W_qkv gradient): 16 ranges 630 us, 32 640, 40 636, 64 (round 5's
     // choice: three whole rounds) 701; the 4- / 8- / 16-tile gradients measure the same for every admissible count
     // (profiles/r06_gemm_tail_experiments.txt)
+    // ... PROVIDED the ranges are equal (K a multiple of 16 x ranges): the kernel cuts an under-filled round only then.  The
+    // encoder's 58800 rows (1200 x 49) are not: 16 tiles x 8 ranges left half the chip idle (1.05 ms against 0.62 with the 16
+    // ranges of the whole-rounds rule) -- those keep the rule below.
     tiles = (long long)((M_out + 255) / 256) * ((N_out + 255) / 256);
     int sp = 8;
     while (sp < 64 && tiles * sp < 128 && K / (sp + 8) >= 256) sp += 8;
-    return sp;
+    if (K % ((long long)sp * 16) == 0) return sp;
+    slots = 256;
   } else if (M_out >= 512) { tiles = (long long)((M_out + 255) / 256) * ((N_out + 127) / 128); slots = 512; }
   else { tiles = (long long)((M_out + 127) / 128) * ((N_out + 127) / 128); slots = 1024; }
   int best = 8;

@@ -86,3 +86,44 @@ def test_code_object_is_gfx950():
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
     blob = open(build.LIB, "rb").read()
     assert b"gfx950" in blob or "gfx950" in out
+
+
+def _kernel_scratch(obj):
+    """{mangled kernel name: private_segment_fixed_size} of the gfx950 code object inside a built host object"""
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        subprocess.check_call([llvm + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(d, "copy.o")])
+        subprocess.check_call([llvm + "clang-offload-bundler", "--type=o", "--unbundle", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        notes = subprocess.run([llvm + "llvm-readelf", "--notes", co], stdout=subprocess.PIPE, text=True).stdout
+    out, name = {}, None
+    for line in notes.splitlines():
+        m = re.search(r"\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", line)
+        if m and name:
+            out[name] = int(m.group(1))
+    return out
+
+
+def test_hot_gemm_kernels_do_not_spill():
+    """Round 6 lost 0.45 ms/step for a while without any test noticing: a position-major branch in the convolution gather
+    pushed the 256 x 128 implicit-GEMM kernels (the RPN's 3x3, the SK blocks' grouped 3x3) from 84 to ~900 bytes of scratch
+    per lane.  The persistent kernels of the 256-row tiles live at the edge of the register file by design; this reads the
+    scratch size of every kernel out of the BUILT objects (no compile here) and holds the 256 x 128 / 256 x 256 / 256 x 64
+    product tiles to the 128 bytes they have always fitted in (the small parity-class tiles of the query side: 640)."""
+    build.build()
+    seen = 0
+    for src in ("gemm_f32", "gemm_p3", "conv_f32"):
+        for k, scratch in _kernel_scratch(os.path.join(build.OBJ, src + ".o")).items():
+            m = re.search(r"gemm_f32_stream_kernelINS_3CfgILi(\d+)ELi(\d+)E", k)
+            if not m:
+                continue
+            seen += 1
+            limit = 128 if int(m.group(1)) == 256 else 640
+            assert scratch <= limit, "%s: %d bytes of scratch per lane (limit %d)" % (k, scratch, limit)
+    assert seen >= 40

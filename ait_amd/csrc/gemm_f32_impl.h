@@ -949,6 +949,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
   int l_n0 = 0, l_m0 = 0;           // origin of the load cursor's tile (CONV kernels)
   int l_kin = 0;                    // CONV_A: reduction index within the current tap (retap() sets it; no per-slab modulo)
   int l_ty = 0, l_tx = 0, l_ch0 = 0;   // CONV_B: the column tile's tap (row, column of the window) and first source channel (+ group offset)
+  int l_pm_shift = 0;                  // ... and the source rows' constant offset for the item's tap
   int l_blk_end = 0x7fffffff;          // CONV_B over position blocks: first row behind the item's block (a piece of an item ends on a slab, not on the block)
   int arow[LA];                     // CONV_A: this lane's (clamped) GEMM row per A transfer
   bool l_valid = true;
@@ -1035,10 +1036,17 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
     l_n0 = n0;
     if constexpr (GRP || ROWMAP || CONV == CONV_B || (CONV == CONV_A && kCoop)) l_m0 = m0;
     if constexpr (CONV == CONV_B) {
-      if constexpr (kCoop) { if (g.conv.pm_wgrad) l_blk_end = (l_k / g.conv.pm_maps + 1) * g.conv.pm_maps; }
       const int tap = n0 / g.conv.seg;
       l_ty = tap / g.conv.kw;
       l_tx = tap - l_ty * g.conv.kw;
+      if constexpr (kCoop) {
+        if (g.conv.pm_wgrad) {
+          // position blocks: the tap reaches the map from every row of the item's block, its sources lie a constant number
+          // of rows away -- no decode, no bounds test per transfer
+          l_blk_end = (l_k / g.conv.pm_maps + 1) * g.conv.pm_maps;
+          l_pm_shift = ((g.conv.c + g.conv.b * l_ty) * g.conv.src_w + (g.conv.c + g.conv.b * l_tx)) * g.conv.pm_maps;
+        }
+      }
       l_ch0 = n0 - tap * g.conv.seg + (GRP ? (m0 / g.conv.n_group) * g.conv.a_group : 0);
     }
 #pragma unroll
@@ -1137,7 +1145,9 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_stream_kernel(const G
           const int e = q * 256 + lane * 4;
           // (position blocks: rows past the item's block belong to the next position -- they read the row of zeros)
           const int kr_b = l_k + e / BN;
-          const int src = (kCoop && g.conv.pm_wgrad && kr_b >= l_blk_end) ? -1 : conv_src_row_t<kCoop>(g.conv, kr_b, l_ty, l_tx);
+          int src;
+          if (kCoop && g.conv.pm_wgrad) src = kr_b < l_blk_end ? kr_b + l_pm_shift : -1;
+          else src = conv_src_row_t<kCoop>(g.conv, kr_b, l_ty, l_tx);
           glds16_at((src >= 0 ? g.B + (size_t)src * g.ldb + l_ch0 : g.conv.zero) + e % BN, dst);
         } else {
           glds16_at(pb[piece - LA], dst);

@@ -104,9 +104,9 @@ SIGNATURES = {
     "ait_transformer_bwd_part": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _ull, _vp, _sz, ctypes.c_uint, _vp, _sz,
                                       _vp, _vp, _vp, _vp, _vp]),
     "ait_tail_saved_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "ait_tail_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "ait_tail_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "ait_tail_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "ait_tail_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "ait_tail_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, ctypes.c_uint, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "ait_heads_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ait_heads_bwd_workspace_bytes": (_sz, [_i, _i]),
     "ait_heads_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz] + [_vp] * 8 + [_vp]),

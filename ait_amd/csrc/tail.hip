@@ -346,13 +346,17 @@ AIT_API size_t ait_tail_saved_bytes(int bp, int bs, int channels, int planes, in
   return saved_floats(d) * sizeof(float) + 64 * 256;
 }
 
+constexpr unsigned kTailFmtMagic = 0xA1800000u;
+inline unsigned tail_format(const ait_launch_ctx* ctx) { return kTailFmtMagic | (l4_pm_on(ctx) ? AIT_TAIL_SAVED_PM : 0u); }
+
 AIT_API int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int bs, int channels, int planes,
-                         int n_blocks, const ait_tail_weights* w, void* saved, size_t saved_bytes, float* pooled,
-                         const ait_launch_ctx* ctx, void* stream) {
+                         int n_blocks, const ait_tail_weights* w, void* saved, size_t saved_bytes, unsigned* saved_format,
+                         float* pooled, const ait_launch_ctx* ctx, void* stream) {
   Dims d;
   AIT_TRY(make_dims(bp, bs, channels, planes, n_blocks, d));
   AIT_TRY(check_weights(w, d));
-  if ((bp > 0 && !x_props) || (bs > 0 && !x_query) || !saved || !pooled) return AIT_EINVAL;
+  if ((bp > 0 && !x_props) || (bs > 0 && !x_query) || !saved || !pooled || !saved_format) return AIT_EINVAL;
+  *saved_format = tail_format(ctx);
   if (saved_bytes < ait_tail_saved_bytes(bp, bs, channels, planes, n_blocks)) return AIT_EWORKSPACE;
   Bump b{static_cast<char*>(saved), saved_bytes};
   Saved s;
@@ -433,11 +437,13 @@ AIT_API size_t ait_tail_bwd_workspace_bytes(int bp, int bs, int channels, int pl
 
 AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const float* x_query, int bp, int bs, int channels,
                          int planes, int n_blocks, const ait_tail_weights* w, const void* saved, size_t saved_bytes,
-                         void* workspace, size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                         unsigned saved_format, void* workspace, size_t workspace_bytes, float* d_x_props, float* d_x_query,
                          const ait_tail_grads* grads, const ait_launch_ctx* ctx, void* stream) {
   Dims d;
   AIT_TRY(make_dims(bp, bs, channels, planes, n_blocks, d));
   AIT_TRY(check_weights(w, d));
+  // the forward laid `saved` out in the row order it reported; this call would read it in the order ITS ctx implies
+  if (saved_format != tail_format(ctx)) return AIT_EINVAL;
   if (!d_pooled || (bp > 0 && !x_props) || (bs > 0 && !x_query) || !saved || !workspace || !grads) return AIT_EINVAL;
   if (saved_bytes < ait_tail_saved_bytes(bp, bs, channels, planes, n_blocks)) return AIT_EWORKSPACE;
   if (workspace_bytes < ait_tail_bwd_workspace_bytes(bp, bs, channels, planes, n_blocks)) return AIT_EWORKSPACE;

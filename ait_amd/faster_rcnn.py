@@ -509,11 +509,14 @@ class _TailFn(torch.autograd.Function):
             raise _lib.AitHipError("ait_tail: unsupported shape (bp=%d bs=%d C=%d planes=%d)" % (bp, bs, C, planes))
         saved = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         pooled = torch.empty((bp + bs, 4 * planes), dtype=torch.float32, device=dev)
+        fmt = ctypes.c_uint(0)
         with torch.cuda.device(dev):
+            ctx.flags = _lib.current_flags()      # (the backward runs in the product form of this forward: the layout of `saved`)
             rc = L.ait_tail_fwd(_lib.dev_ptr(xp), _lib.dev_ptr(xq), bp, bs, C, planes, n_blocks, ctypes.byref(W),
-                                ctypes.c_void_p(saved.data_ptr()), nbytes, _lib.dev_ptr(pooled), _lib.launch_ctx(dev),
-                                _lib.cur_stream(dev))
+                                ctypes.c_void_p(saved.data_ptr()), nbytes, ctypes.byref(fmt), _lib.dev_ptr(pooled),
+                                _lib.launch_ctx(dev, flags=ctx.flags), _lib.cur_stream(dev))
         _lib.check(rc, "ait_tail_fwd")
+        ctx.fmt = fmt.value
         ctx.save_for_backward(xp, xq, saved)
         ctx.W, ctx.keep = W, keep
         ctx.cfg = (bp, bs, C, planes, n_blocks)
@@ -561,10 +564,10 @@ class _TailFn(torch.autograd.Function):
         ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             rc = L.ait_tail_bwd(_lib.dev_ptr(d_pooled), _lib.dev_ptr(xp), _lib.dev_ptr(xq), bp, bs, C, planes, n_blocks,
-                                ctypes.byref(ctx.W), ctypes.c_void_p(saved.data_ptr()), saved.numel(),
+                                ctypes.byref(ctx.W), ctypes.c_void_p(saved.data_ptr()), saved.numel(), ctx.fmt,
                                 ctypes.c_void_p(ws.data_ptr()), wbytes,
                                 None if dxp is None else _lib.dev_ptr(dxp), None if dxq is None else _lib.dev_ptr(dxq),
-                                ctypes.byref(G), _lib.launch_ctx(dev), _lib.cur_stream(dev))
+                                ctypes.byref(G), _lib.launch_ctx(dev, flags=ctx.flags), _lib.cur_stream(dev))
         _lib.check(rc, "ait_tail_bwd")
         return (dxp, dxq, None, None, None, None, None, None, None) + tuple(views)
 

@@ -758,13 +758,19 @@ typedef struct {
   ait_bottleneck_grads block[4];
 } ait_tail_grads;
 size_t ait_tail_saved_bytes(int bp, int bs, int channels, int planes, int n_blocks);
+/* saved_format (ABI v7; as ait_transformer_fwd_train's): the LAYOUT of `saved` depends on the call's product form -- layer4's
+ * activations are kept in position-major row order (row = position * maps + map: its 3x3 convolutions then skip the window's
+ * out-of-map taps) in the split product form, map-major under AIT_CTX_BF16 / AIT_CTX_NATIVE_F32.  The forward reports what it
+ * wrote (a magic in the top 12 bits + AIT_TAIL_SAVED_PM; host memory, required), the backward is handed that word and returns
+ * AIT_EINVAL if its own ctx implies the other order or the word is not one the forward reported. */
+#define AIT_TAIL_SAVED_PM 1u
 int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int bs, int channels, int planes, int n_blocks,
-                 const ait_tail_weights* w, void* saved, size_t saved_bytes, float* pooled, const ait_launch_ctx* ctx,
-                 void* stream);
+                 const ait_tail_weights* w, void* saved, size_t saved_bytes, unsigned* saved_format, float* pooled,
+                 const ait_launch_ctx* ctx, void* stream);
 size_t ait_tail_bwd_workspace_bytes(int bp, int bs, int channels, int planes, int n_blocks);
 int ait_tail_bwd(const float* d_pooled, const float* x_props, const float* x_query, int bp, int bs, int channels,
                  int planes, int n_blocks, const ait_tail_weights* w, const void* saved, size_t saved_bytes,
-                 void* workspace, size_t workspace_bytes, float* d_x_props, float* d_x_query,
+                 unsigned saved_format, void* workspace, size_t workspace_bytes, float* d_x_props, float* d_x_query,
                  const ait_tail_grads* grads, const ait_launch_ctx* ctx, void* stream);
 
 /* ---------------------------------------------------------------------------------------

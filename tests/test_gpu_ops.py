@@ -592,6 +592,55 @@ def test_proposal_tail_node_matches_the_module_composition(monkeypatch, bp, bs):
         assert rel(a, b) < tol, (lab, rel(a, b))
 
 
+def test_tail_backward_is_held_to_its_forwards_layout(monkeypatch):
+    """ABI v7: layer4's saved activations are position-major in the split product form and map-major otherwise.  (1) The
+    autograd node runs its backward in the product form of ITS forward whatever the global switch says by then: gradients
+    equal those of an undisturbed step.  (2) The C entry refuses (AIT_EINVAL) a layout word that is not the one the forward
+    reported -- the other row order, or no word of the forward's at all -- instead of reading the buffer in the wrong order."""
+    import ait_amd.faster_rcnn as fr
+    from ait_amd import _lib, ops
+    torch.manual_seed(11)
+    m = fr.resnet(('__background__', 'fg'), 50, pretrained=False, class_agnostic=True, num_K=3)
+    m.create_architecture()
+    m = m.cuda().train()
+    bp, bs = 37, 2
+    x0 = torch.randn(bp, 1024, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+    q0 = torch.randn(bs, 1024, 8, 8, device="cuda")
+    cot = torch.randn(bp + bs, 2048, device="cuda")
+    L = _lib.lib()
+    real = L.ait_tail_bwd
+    seen = []
+
+    def spy(*a):
+        word = a[11]
+        seen.append(word)
+        assert word >> 20 == 0xA18 and (word & 1) == 1            # position-major: the f32 split form
+        assert real(*(a[:11] + (word ^ 1,) + a[12:])) == -1       # the other row order
+        assert real(*(a[:11] + (0x12345,) + a[12:])) == -1        # not a word of the forward's
+        return real(*a)
+
+    grads = {}
+    for switch in (False, True):
+        m.zero_grad(set_to_none=True)
+        x, q = x0.clone().requires_grad_(True), q0.clone().requires_grad_(True)
+        assert m._tail_on_library(x, q, 2)
+        yp, yq = m._tail(x, q)
+        try:
+            if switch:
+                ops.set_matmul_dtype("f32_native")                  # between forward and backward
+                monkeypatch.setattr(L, "ait_tail_bwd", spy, raising=False)
+            (torch.cat([yp, yq]) * cot).sum().backward()
+        finally:
+            ops.set_matmul_dtype("f32")
+            if switch:
+                monkeypatch.undo()
+        grads[switch] = [x.grad.clone(), q.grad.clone(), m.sk.sk_props.convs[1][0].weight.grad.clone(),
+                         m.RCNN_top[0][1].conv2.weight.grad.clone()]
+    assert len(seen) == 1
+    for a, b in zip(grads[True], grads[False]):
+        assert float((a - b).norm() / (b.norm() + 1e-30)) < 1e-4     # (atomics in the weight gradients: not bit-equal)
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout,k,pad", [(4, 38, 63, 1024, 512, 3, 1), (1, 20, 30, 256, 128, 3, 1), (2, 19, 31, 128, 256, 3, 1),
                                                    (3, 7, 5, 128, 64, 1, 0), (2, 38, 63, 256, 256, 3, 1)])
 def test_implicit_gemm_convolutions_on_maps_of_any_size(n, h, w, cin, cout, k, pad):

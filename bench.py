@@ -351,8 +351,11 @@ def main():
         os.environ["AIT_FORCE_DDP"] = "1"
     # a rank of an N > 1 job: next to its GPU's NUMA cores, BEFORE anything initialises the GPU (sysfs only).  N = 1 stays
     # unbound: its CPU baseline is timed on all the box's cores
-    affinity = D.bind_rank_to_gpu_numa(D.env_world()[1], int(os.environ.get("LOCAL_WORLD_SIZE", "1"))) \
-        if D.env_world()[2] > 1 else {"bound": False, "why": "one rank"}
+    try:
+        affinity = D.bind_rank_to_gpu_numa(D.env_world()[1], int(os.environ.get("LOCAL_WORLD_SIZE", "1"))) \
+            if D.env_world()[2] > 1 else {"bound": False, "why": "one rank"}
+    except Exception as e:              # (placement is an optimisation: never a reason not to run)
+        affinity = {"bound": False, "why": "bind_rank_to_gpu_numa raised %r" % (e,)}
     from ait_amd import _lib, ops, tuning
     rank, local_rank, world = D.init()
     # MIOpen solver picks for the torch-side convolutions: the committed find-db holds the shapes of cfg2 .. cfg5 as

@@ -166,16 +166,22 @@ static int set_pm(ConvGeom& c, const ait_conv_geom* q, int pm, bool general, lon
 // Tap skipping for the forward / data gradient of position-major 4 x 4 maps (ConvGeom::pm_skip): on, if the launch is what
 // the kernel's two-group cut handles -- the 256 x 256 tile, every XCD's chunk of the tile list = the tiles of two whole
 // positions and no longer than the workgroups of an XCD (32), a dense 3x3-like window with padding, the split product form,
-// the partial-tile scratch in the launch context.  Returns the executed (position, tap) pairs per map, 0 = off.
-static int set_pm_skip(GemmArgs& g, const ait_conv_geom* q, int pm, int seg, const ait_launch_ctx* ctx) {
+// the partial-tile scratch in the launch context.  More maps than that (8 pairs of 300 proposals: 10 row tiles per position)
+// go in several launches, each over a slice of every position's row tiles (ConvGeom::pm_t0 / pm_tcnt; pm_launches says how
+// many).  Returns the executed (position, tap) pairs per map, 0 = off.
+static int set_pm_skip(GemmArgs& g, const ait_conv_geom* q, int pm, int seg, const ait_launch_ctx* ctx, int& pm_launches) {
+  pm_launches = 1;
   if (!pm || !ait_lab::Knobs::l4_pm_skip || bf16_products(ctx)) return 0;
   if (q->in_h != 4 || q->in_w != 4 || q->kh * q->kw < 2 || q->pad < 1 || q->groups > 1 || (seg % 16)) return 0;
   const SchedWs ws = sched_ws_of(ctx);
-  const int tiles_n = (g.N + 255) / 256, tpr = (q->n + 255) / 256, tpp = tpr * tiles_n;
-  const int items = 16 * tpp, chunk = items / AIT_NXCD;
-  if (g.N % 256 || g.M < 4096 || (items % AIT_NXCD) || chunk != 2 * tpp || chunk > 32) return 0;
+  const int tiles_n = (g.N + 255) / 256, tpr = (q->n + 255) / 256;
+  if (g.N % 256 || g.M < 4096 || tiles_n > 16) return 0;
+  const int per = 16 / tiles_n;                          // row tiles per position a launch can take: 2 positions x per x tiles_n <= 32
+  pm_launches = (tpr + per - 1) / per;
   if (!ws.p || ws.bytes < kCtlBytes + (size_t)256 * 256 * 256 * sizeof(float)) return 0;
   g.conv.pm_skip = 1;
+  g.conv.pm_t0 = 0;
+  g.conv.pm_tcnt = (tpr + pm_launches - 1) / pm_launches;
   g.conv.pm_kh = q->kh;
   // corners beside interiors, edges beside edges: 13 / 12 taps per XCD (position pairs in launch order)
   g.conv.pm_order = 0xedb87421af9c6350ull;
@@ -187,6 +193,21 @@ static int set_pm_skip(GemmArgs& g, const ait_conv_geom* q, int pm, int seg, con
     pairs += ny * nx;
   }
   return pairs;
+}
+
+// the forward / data gradient over position-major rows on the cooperative tile: one launch, or (tap skipping over more maps
+// than one launch cuts) one per slice of every position's row tiles -- the slices are disjoint sets of output rows
+template <bool BKC>
+static int pm_launch_slices(GemmArgs& g, const ait_conv_geom* q, int n_launch, hipStream_t s, const SchedWs& ws) {
+  if (!g.conv.pm_skip || n_launch <= 1) return conv_launch<TileCoop, CONV_A, true, BKC>(g, s, ws);
+  const int tpr = (q->n + 255) / 256, per = g.conv.pm_tcnt;
+  for (int t0 = 0; t0 < tpr; t0 += per) {
+    g.conv.pm_t0 = t0;
+    g.conv.pm_tcnt = t0 + per <= tpr ? per : tpr - t0;
+    const int rc = conv_launch<TileCoop, CONV_A, true, BKC>(g, s, ws);
+    if (rc != AIT_OK) return rc;
+  }
+  return AIT_OK;
 }
 
 int ait_conv_fwd_f32_pm(const float* x, int ldx, const float* w, const ait_conv_geom* q, int cin, int cout,
@@ -212,10 +233,11 @@ int ait_conv_fwd_f32_pm(const float* x, int ldx, const float* w, const ait_conv_
   AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows, ctx));
   if (pm) {
     // (executed work: the taps that reach the map -- the skipped ones multiply rows of zeros)
-    const int pairs = set_pm_skip(g, q, pm, cing, ctx);
+    int n_launch = 1;
+    const int pairs = set_pm_skip(g, q, pm, cing, ctx, n_launch);
     AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, pairs ? 2.0 * q->n * pairs * cout * cing : 2.0 * rows * cout * taps * cing,
                         ait_stream(stream), (int)rows, cout, pairs ? pairs * cing / 16 : taps * cing, 0, 1, 1);
-    return conv_launch<TileCoop, CONV_A, true, true>(g, ait_stream(stream), sched_ws_of(ctx));
+    return pm_launch_slices<true>(g, q, pairs ? n_launch : 1, ait_stream(stream), sched_ws_of(ctx));
   }
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cout * taps * cing, ait_stream(stream), (int)rows, cout,
                       taps * cing, 0, 1, 1);
@@ -312,10 +334,11 @@ int ait_conv_bwd_data_f32_pm(const float* dy, int lddy, const float* w, const ai
   if (general) set_general_rows(g.conv, q->in_h, q->in_w, rows);
   AIT_TRY_RC(set_pm(g.conv, q, pm, general, rows, ctx));
   if (pm) {
-    const int pairs = set_pm_skip(g, q, pm, coutg, ctx);
+    int n_launch = 1;
+    const int pairs = set_pm_skip(g, q, pm, coutg, ctx, n_launch);
     AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, pairs ? 2.0 * q->n * pairs * cin * coutg : 2.0 * rows * cin * taps * coutg,
                         ait_stream(stream), (int)rows, cin, pairs ? pairs * coutg / 16 : taps * coutg, 0, 0, 1);
-    return conv_launch<TileCoop, CONV_A, true, false>(g, ait_stream(stream), sched_ws_of(ctx));
+    return pm_launch_slices<false>(g, q, pairs ? n_launch : 1, ait_stream(stream), sched_ws_of(ctx));
   }
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * rows * cin * taps * coutg, ait_stream(stream), (int)rows, cin,
                       taps * coutg, 0, 0, 1);

@@ -65,7 +65,10 @@ struct ConvGeom {
   // 9 of a 3x3 window's taps on 4 x 4 maps.  Items therefore differ in length; the stream-K cut handles an XCD's chunk as up
   // to two groups of equal-length items (kernel).  pm_order: the positions in launch order, a nibble each -- an order in which
   // every XCD's share of the tile list carries about the same number of taps.
+  // A launch covers the row tiles pm_t0 .. pm_t0 + pm_tcnt - 1 of EVERY position's block (all of them, or -- more maps than
+  // an XCD's workgroups can cut in one go -- a slice per launch, csrc/conv_f32.hip).
   int pm_skip;
+  int pm_t0, pm_tcnt;
   unsigned long long pm_order;
   // ---- the data gradient of a STRIDE-2 convolution by parity class (py, px) of the input positions (ROWMAP kernels):
   // a class holds the positions (2ya + py, 2xa + px); only the window taps ty = (py + pad) mod 2 (+ 2 ...) reach it
@@ -673,9 +676,8 @@ struct WorkMap {
       return;
     }
     if (g.conv.pm_skip) {
-      // every position's block in its own row tiles
-      const int tpr = (g.conv.pm_maps + BM - 1) / BM;
-      tiles_m = tpr << g.conv.rows_hw_shift;
+      // every position's block in its own row tiles (this launch's slice of them)
+      tiles_m = g.conv.pm_tcnt << g.conv.rows_hw_shift;
       tiles = tiles_m * tiles_n;
       items = tiles;
       chunk = (items + AIT_NXCD - 1) / AIT_NXCD;
@@ -698,7 +700,7 @@ struct WorkMap {
   // tap skipping: the position of tile-list entry `id` (through pm_order), its tap window, the end of its block of rows
   __host__ __device__ PmTile pm_tile(const GemmArgs& g, int id, int BM) const {
     const ConvGeom& c = g.conv;
-    const int tpr = (c.pm_maps + BM - 1) / BM, tpp = tpr * tiles_n;
+    const int tpp = c.pm_tcnt * tiles_n;
     PmTile t;
     t.p = (int)((c.pm_order >> (4 * (id / tpp))) & 15ull);
     pm_axis(t.p >> c.rows_w_shift, c.src_h, c.pm_kh, c.b, c.c, t.ylo, t.ny);
@@ -711,10 +713,10 @@ struct WorkMap {
   __device__ __forceinline__ void decode(const GemmArgs& g, int id, int BM, int BN, int& m0, int& n0,
                                          int& kbeg, int& kend) const {
     if (PM && g.conv.pm_skip) {
-      const int tpr = (g.conv.pm_maps + BM - 1) / BM, tpp = tpr * tiles_n;
+      const int tpp = g.conv.pm_tcnt * tiles_n;
       const PmTile t = pm_tile(g, id, BM);
       const int r = id - (id / tpp) * tpp, tr = r / tiles_n;
-      m0 = t.p * g.conv.pm_maps + tr * BM;
+      m0 = t.p * g.conv.pm_maps + (g.conv.pm_t0 + tr) * BM;
       n0 = (r - tr * tiles_n) * BN;
       kbeg = 0;
       kend = t.ny * t.nx * g.conv.seg;

@@ -536,7 +536,9 @@ def test_box_kernel_edge_cases():
 
 # (300, 4): one pair's worth; (37, 2): below every fast path's threshold; (1200, 4): the headline size -- layer4's 3x3 convolutions
 # with the out-of-map taps skipped, one launch; (2400, 8): BASELINE configs[2] / [3] per GPU -- the same in two slices
-@pytest.mark.parametrize("bp,bs", [(300, 4), (37, 2), (1200, 4), (2400, 8)])
+# (513, 3): 520 maps -- the third row tile of every position holds 8 real rows; (255, 1): exactly one row tile per position, every
+# tile cut over five or more workgroups
+@pytest.mark.parametrize("bp,bs", [(300, 4), (37, 2), (1200, 4), (2400, 8), (513, 3), (255, 1)])
 def test_proposal_tail_node_matches_the_module_composition(monkeypatch, bp, bs):
     """ait_tail_fwd / ait_tail_bwd (both SK blocks + layer4 + the mean over positions as ONE autograd node: grouped
     implicit GEMMs at stride 2, per-parity data gradients, frozen BN folded into the weights, every ReLU mask and

@@ -177,8 +177,13 @@ static int set_pm_skip(GemmArgs& g, const ait_conv_geom* q, int pm, int seg, con
   const int tiles_n = (g.N + 255) / 256, tpr = (q->n + 255) / 256;
   if (g.N % 256 || g.M < 4096 || tiles_n > 16) return 0;
   const int per = 16 / tiles_n;                          // row tiles per position a launch can take: 2 positions x per x tiles_n <= 32
-  pm_launches = (tpr + per - 1) / per;
   if (!ws.p || ws.bytes < kCtlBytes + (size_t)256 * 256 * 256 * sizeof(float)) return 0;
+  // (32 = the workgroups of an XCD on the 256-CU part, one cooperative tile per CU: a device with fewer resident workgroups keeps
+  // every tap -- same results, no launch that could not be cut)
+  if (stream_slots<TileCoop>(reinterpret_cast<const void*>(
+          gemm_f32_stream_kernel<TileCoop, true, true, EPI_STORE, NoProbe, CONV_A, false, false>)) / AIT_NXCD < 32)
+    return 0;
+  pm_launches = (tpr + per - 1) / per;
   g.conv.pm_skip = 1;
   g.conv.pm_t0 = 0;
   g.conv.pm_tcnt = (tpr + pm_launches - 1) / pm_launches;

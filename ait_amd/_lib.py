@@ -58,6 +58,9 @@ SIGNATURES = {
     "ait_gemm_bf16s_tn": (_i, [_i, _i, _i, _vp, _ll, _vp, _ll, _vp, _ll, _i, _vp, _sz, _vp, _vp]),
     "ait_colsum_bf16": (_i, [_vp, _ll, _i, _ll, _vp, _vp]),
     "ait_f32_to_bf16": (_i, [_vp, _ll, _i, _ll, _vp, _ll, _i, _vp]),
+    "ait_conv_fwd_bf16s": (_i, [_vp, _ll, _vp, _vp, _i, _i, _vp, _vp, _vp, _ll, _i, _vp, _ll, _vp, _ll, _vp, _sz, _vp, _vp]),
+    "ait_conv_bwd_weight_bf16s": (_i, [_vp, _ll, _vp, _ll, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "ait_conv_weight_to_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ait_p3_bytes": (_sz, [_ll, _ll]),
     "ait_p3_split": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "ait_gemm_f32_p3": (_i, [_i, _i, _i, _f, _vp, _i, _vp, _ll, _vp, _i, _vp, _vp, _i, _i, _ll, _vp, _vp]),

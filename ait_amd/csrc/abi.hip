@@ -5,7 +5,7 @@
 
 
 
-AIT_API int ait_abi_version(void) { return 7; }
+AIT_API int ait_abi_version(void) { return 8; }
 // 0 for the shipped library; 1 for a lab variant built with experiment knobs (csrc/lab_knobs.h)
 AIT_API int ait_lab_build(void) { return ait_lab::kLabBuild; }
 

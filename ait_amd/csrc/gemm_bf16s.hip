@@ -19,8 +19,10 @@
 // (global_load_lds_dwordx4, 16 rows x 64 B per instruction), 16-B chunk c of row r stored at chunk position
 // c ^ ((r >> 2) & 3): the ds_read_b128 of 32 consecutive rows is bank-conflict-free.
 #include "common.h"
+#include "gemm_internal.h"
 
 namespace {
+using ait_bf16s::Conv;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -60,13 +62,23 @@ struct Args {
   float* C32;
   unsigned short* C16;
   const float* bias;
-  const float* residual;      // added (EPI_RES) or read as the gate (EPI_GATE: value kept where residual > 0)
-  const unsigned short* gate16;   // EPI_GATE with a bf16 gate tensor (the stored ReLU output) instead of `residual`
+  const float* residual;      // added (EPI_RES / EPI_RESGATE) or read as the gate (EPI_GATE: value kept where residual > 0)
+  const unsigned short* res16;    // ... the addend as a bf16 tensor instead (pitch ldr)
+  const unsigned short* gate16;   // EPI_GATE / EPI_RESGATE: a bf16 gate tensor (the stored ReLU output; pitch ldg)
   int M, N, K;
-  long long lda, ldb, ldc32, ldc16, ldr;
+  long long lda, ldb, ldc32, ldc16, ldr, ldg;
   int relu;
+  Conv cv;                    // CONV kernels: A is a channels-last map, the reduction runs over (tap, channel)
 };
-enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_GATE = 2 };
+enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_GATE = 2, EPI_RESGATE = 3 };
+
+// The source of one operand row of a stride-1 "same" convolution (gemm_internal.h ait_bf16s::Conv): GEMM row `row` is position
+// (y, x) of a map, the slab lies inside window tap (dy, dx) -- scalars of the slab -- and reads the row of the neighbouring
+// position, or a row of zeros where the window hangs over the map's edge.
+__device__ __forceinline__ long long conv_row(const Conv& cv, int row, int dy, int dx) {
+  const int p = row & cv.hw_mask, sy = (p >> cv.w_shift) + dy, sx = (p & cv.w_mask) + dx;
+  return ((unsigned)sy < (unsigned)cv.H && (unsigned)sx < (unsigned)cv.W) ? (long long)(row + dy * cv.W + dx) : -1ll;
+}
 
 __device__ __forceinline__ void glds16(const void* src, unsigned dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "m0", "memory");
@@ -91,7 +103,7 @@ __device__ __forceinline__ void wait_vm() {
 template <int CH>
 __device__ __forceinline__ int swz(int r) { return CH == 4 ? (r >> 2) & 3 : r & 7; }
 
-template <class T, int EPI>
+template <class T, int EPI, bool CONV>
 __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {      // (two waves per SIMD: <= 256 VGPRs)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NS = T::NS, ROWB = T::ROWB, CH = T::CH, RG = T::RG, STAGE = T::STAGE;
@@ -118,6 +130,13 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {   
     int m0, n0;
     tile_origin(s / slabs, m0, n0);
     const int k0 = (s % slabs) * BK;
+    int tap_dy = 0, tap_dx = 0, tap_c0 = 0;                          // CONV: the slab's window tap and first channel
+    if constexpr (CONV) {
+      const int tap = k0 >> g.cv.cin_shift;
+      tap_c0 = k0 & ((1 << g.cv.cin_shift) - 1);
+      tap_dy = tap / g.cv.kw - g.cv.pad;
+      tap_dx = tap % g.cv.kw - g.cv.pad;
+    }
 #pragma unroll
     for (int i = 0; i < T::LPW; i++) {
       const int q = wave + i * T::NW;
@@ -125,7 +144,12 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {   
       if (q < BM / RG) {
         int row = m0 + q * RG + rr;
         row = row < g.M ? row : g.M - 1;                             // (rows past M: any finite data, never stored)
-        glds16(g.A + (size_t)row * g.lda + k0 + cfetch * 8, dst);
+        if constexpr (CONV) {
+          const long long src = conv_row(g.cv, row, tap_dy, tap_dx);
+          glds16(src >= 0 ? g.A + (size_t)src * g.lda + tap_c0 + cfetch * 8 : g.cv.zeros + cfetch * 8, dst);
+        } else {
+          glds16(g.A + (size_t)row * g.lda + k0 + cfetch * 8, dst);
+        }
       } else {
         const int row = n0 + (q - BM / RG) * RG + rr;
         glds16(g.B + (size_t)row * g.ldb + k0 + cfetch * 8, dst);
@@ -193,13 +217,19 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {   
               v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
             }
             if (ok) {
-              if constexpr (EPI == EPI_RES) {
-                const float4 rv = *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col);
-                v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+              if constexpr (EPI == EPI_RES || EPI == EPI_RESGATE) {
+                if (g.res16) {
+                  const uint2 rv = *reinterpret_cast<const uint2*>(g.res16 + (size_t)row * g.ldr + col);
+                  v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
+                  v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
+                } else {
+                  const float4 rv = *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col);
+                  v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
               }
-              if constexpr (EPI == EPI_GATE) {
-                if (g.gate16) {
-                  const uint2 gv = *reinterpret_cast<const uint2*>(g.gate16 + (size_t)row * g.ldr + col);
+              if constexpr (EPI == EPI_GATE || EPI == EPI_RESGATE) {
+                if (EPI == EPI_RESGATE || g.gate16) {
+                  const uint2 gv = *reinterpret_cast<const uint2*>(g.gate16 + (size_t)row * g.ldg + col);
                   // (a bf16 value is positive iff its 16 bits, read as a signed short, are > 0: +0 is 0, negatives and -0 < 0)
                   v.x = (short)(gv.x & 0xffffu) > 0 ? v.x : 0.f; v.y = (short)(gv.x >> 16) > 0 ? v.y : 0.f;
                   v.z = (short)(gv.y & 0xffffu) > 0 ? v.z : 0.f; v.w = (short)(gv.y >> 16) > 0 ? v.w : 0.f;
@@ -239,6 +269,7 @@ struct TnArgs {
   float* partials;              // PARTIAL: [splits][Mo][No] scratch, every element written once (no atomics); reduced afterwards
   int Mo, No, R, splits, k_per_split;
   long long lda, ldb, ldc;
+  Conv cv;                      // CONV: B is a channels-last map gathered per window tap, No = taps * cin (column = (tap, channel))
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off_lo, int off_hi) {
@@ -250,7 +281,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base, int off_lo,
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <class T, bool PARTIAL>
+template <class T, bool PARTIAL, bool CONV>
 __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NS = T::NS, STAGE = T::STAGE;
@@ -280,6 +311,13 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g)
     int m0, n0, k0;
     item_of(s / slabs, m0, n0, k0);
     k0 += (s % slabs) * BK;
+    int tap_dy = 0, tap_dx = 0, tap_c0 = 0;                    // CONV: the tile's columns lie inside one window tap
+    if constexpr (CONV) {
+      const int tap = n0 >> g.cv.cin_shift;
+      tap_c0 = n0 & ((1 << g.cv.cin_shift) - 1);
+      tap_dy = tap / g.cv.kw - g.cv.pad;
+      tap_dx = tap % g.cv.kw - g.cv.pad;
+    }
 #pragma unroll
     for (int i = 0; i < T::LPW; i++) {
       const int q = wave + i * T::NW;
@@ -289,7 +327,13 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g)
         glds16(g.A + (size_t)(k0 + row) * g.lda + m0 + (pos ^ (4 * (row & 3))) * 8, dst);
       } else {
         const int row = (q - GA) * (64 / LPRB) + lane / LPRB, pos = lane % LPRB;
-        glds16(g.B + (size_t)(k0 + row) * g.ldb + n0 + (pos ^ (4 * (row & 3))) * 8, dst);
+        const int chunk = pos ^ (4 * (row & 3));
+        if constexpr (CONV) {
+          const long long src = conv_row(g.cv, k0 + row, tap_dy, tap_dx);
+          glds16(src >= 0 ? g.B + (size_t)src * g.ldb + tap_c0 + chunk * 8 : g.cv.zeros + chunk * 8, dst);
+        } else {
+          glds16(g.B + (size_t)(k0 + row) * g.ldb + n0 + chunk * 8, dst);
+        }
       }
     }
   };
@@ -473,9 +517,9 @@ inline int slots_of(const void* kern, int& memo) {
   return memo;
 }
 
-template <class T, int EPI>
+template <class T, int EPI, bool CONV>
 int launch(const Args& g, hipStream_t s) {
-  const void* kern = reinterpret_cast<const void*>(gemm_bf16s_kernel<T, EPI>);
+  const void* kern = reinterpret_cast<const void*>(gemm_bf16s_kernel<T, EPI, CONV>);
   static int memo = 0;
   const int slots = slots_of<T>(kern, memo);
   if (slots <= 0) return AIT_ELAUNCH;
@@ -484,15 +528,16 @@ int launch(const Args& g, hipStream_t s) {
   int w = slots / AIT_NXCD;
   if (w > per) w = per;
   if (w < 1) w = 1;
-  hipLaunchKernelGGL((gemm_bf16s_kernel<T, EPI>), dim3(w * AIT_NXCD), dim3(T::NT), T::LDS, s, g);
+  hipLaunchKernelGGL((gemm_bf16s_kernel<T, EPI, CONV>), dim3(w * AIT_NXCD), dim3(T::NT), T::LDS, s, g);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }
-template <class T>
+template <class T, bool CONV>
 int launch_epi(const Args& g, bool gate, hipStream_t s) {
-  if (gate) return launch<T, EPI_GATE>(g, s);
-  if (g.residual) return launch<T, EPI_RES>(g, s);
-  return launch<T, EPI_PLAIN>(g, s);
+  const bool res = g.residual || g.res16;
+  if (gate) return res && g.gate16 ? launch<T, EPI_RESGATE, CONV>(g, s) : launch<T, EPI_GATE, CONV>(g, s);
+  if (res) return launch<T, EPI_RES, CONV>(g, s);
+  return launch<T, EPI_PLAIN, CONV>(g, s);
 }
 // C[m, n] += sum over the K-ranges of partials[s][m][n]  (16-B loads; in range order: reproducible)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partials, int splits, int Mo, int No,
@@ -511,15 +556,15 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   }
 }
 
-template <class T, bool PARTIAL>
+template <class T, bool PARTIAL, bool CONV>
 int launch_tn(const TnArgs& g, hipStream_t s) {
-  const void* kern = reinterpret_cast<const void*>(gemm_bf16s_tn_kernel<T, PARTIAL>);
+  const void* kern = reinterpret_cast<const void*>(gemm_bf16s_tn_kernel<T, PARTIAL, CONV>);
   static int memo = 0;
   const int slots = slots_of<T>(kern, memo);
   if (slots <= 0) return AIT_ELAUNCH;
   const long long items = (long long)(g.Mo / T::BM) * (g.No / T::BN) * g.splits;
   const int grid = (int)(items < slots ? items : slots);
-  hipLaunchKernelGGL((gemm_bf16s_tn_kernel<T, PARTIAL>), dim3(grid), dim3(T::NT), T::LDS, s, g);
+  hipLaunchKernelGGL((gemm_bf16s_tn_kernel<T, PARTIAL, CONV>), dim3(grid), dim3(T::NT), T::LDS, s, g);
   AIT_CHECK_LAUNCH();
   if (PARTIAL) {
     const long long want = ((long long)g.Mo * (g.No / 4) + 255) / 256;
@@ -534,67 +579,221 @@ int launch_tn(const TnArgs& g, hipStream_t s) {
 
 constexpr bool kUseBig = !ait_lab::Knobs::bf16s_small_only;
 
-AIT_API int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, float* C32,
-                           long long ldc32, void* C16, long long ldc16, const float* bias, const float* residual,
-                           const void* gate16, long long ldr, int flags, const ait_launch_ctx* ctx, void* stream) {
+namespace {
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+
+// the window geometry the CONV kernels serve, from the public description (include/ait_hip.h ait_conv_geom)
+int make_conv(const ait_conv_geom* q, int cin, const void* zeros, size_t zeros_bytes, Conv& cv, long long& rows, int& taps) {
+  if (!q || !zeros) return AIT_EINVAL;
+  if (q->n < 0 || q->in_h <= 0 || q->in_w <= 0 || q->kh <= 0 || q->kw <= 0 || cin <= 0) return AIT_EINVAL;
+  const int hw = q->in_h * q->in_w;
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  if (q->groups > 1 || q->stride != 1 || q->out_h != q->in_h || q->out_w != q->in_w || q->kh != q->kw || !(q->kh & 1) ||
+      q->pad != q->kh / 2 || !pow2(q->in_w) || !pow2(hw) || !pow2(cin) || cin < 64 || zeros_bytes < 512 || !al16(zeros))
+    return AIT_EUNSUPPORTED;
+  cv.on = 1;
+  cv.hw_mask = hw - 1;
+  cv.w_shift = __builtin_ctz((unsigned)q->in_w);
+  cv.w_mask = q->in_w - 1;
+  cv.H = q->in_h; cv.W = q->in_w; cv.kw = q->kw; cv.pad = q->pad;
+  cv.cin_shift = __builtin_ctz((unsigned)cin);
+  cv.zeros = static_cast<const unsigned short*>(zeros);
+  rows = (long long)q->n * hw;
+  taps = q->kh * q->kw;
+  return AIT_OK;
+}
+}  // namespace
+
+int ait_bf16s::gemm(const Gemm& p, const ait_launch_ctx* ctx, void* stream) {
+  const int M = p.M, N = p.N, K = p.K;
   if (M < 0 || N < 0 || K < 0) return AIT_EINVAL;
   if (M == 0 || N == 0) return AIT_OK;
-  if (!A || !B || (!C32 && !C16)) return AIT_EINVAL;
-  if (K == 0 || (K % Small::BK) || (N % Small::BN) || (lda % 8) || (ldb % 8) || lda < K || ldb < K ||
-      (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) ||
-      (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
+  if (!p.A || !p.B || (!p.C32 && !p.C16)) return AIT_EINVAL;
+  const long long lda_min = p.cv.on ? (1ll << p.cv.cin_shift) : K;
+  if (K == 0 || (K % Small::BK) || (N % Small::BN) || (p.lda % 8) || (p.ldb % 8) || p.lda < lda_min || p.ldb < K || !al16(p.A) ||
+      !al16(p.B) || (p.bias && !al16(p.bias)))
     return AIT_EUNSUPPORTED;
-  if ((C32 && ((ldc32 % 4) || ldc32 < N || (reinterpret_cast<uintptr_t>(C32) & 15))) ||
-      (C16 && ((ldc16 % 4) || ldc16 < N || (reinterpret_cast<uintptr_t>(C16) & 7))))
+  if ((p.C32 && ((p.ldc32 % 4) || p.ldc32 < N || !al16(p.C32))) || (p.C16 && ((p.ldc16 % 4) || p.ldc16 < N || !al8(p.C16))))
     return AIT_EUNSUPPORTED;
-  if (flags & ~(AIT_GEMM_RELU | AIT_GEMM_MASK_POS)) return AIT_EUNSUPPORTED;
-  const bool gate = (flags & AIT_GEMM_MASK_POS) != 0;
-  if (gate && !residual && !gate16) return AIT_EINVAL;
-  if (!gate && gate16) return AIT_EINVAL;
-  if ((residual || gate16) && ((ldr % 4) || ldr < N)) return AIT_EUNSUPPORTED;
+  if (p.gate && !p.res32 && !p.gate16) return AIT_EINVAL;
+  if ((!p.gate && p.gate16) || (p.res32 && p.res16)) return AIT_EINVAL;
+  if (p.gate && p.res16 && !p.gate16) return AIT_EINVAL;      // (an f32 tensor alone IS the gate; an addend and a gate need gate16)
+  if ((p.res32 || p.res16) && ((p.ldr % 4) || p.ldr < N || (p.res32 ? !al16(p.res32) : !al8(p.res16)))) return AIT_EUNSUPPORTED;
+  if (p.gate16 && ((p.ldg % 4) || p.ldg < N || !al8(p.gate16))) return AIT_EUNSUPPORTED;
   Args g;
-  g.A = static_cast<const unsigned short*>(A); g.B = static_cast<const unsigned short*>(B);
-  g.C32 = C32; g.C16 = static_cast<unsigned short*>(C16);
-  g.bias = bias; g.residual = residual; g.gate16 = static_cast<const unsigned short*>(gate16);
-  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc32 = ldc32; g.ldc16 = ldc16; g.ldr = ldr;
-  g.relu = (flags & AIT_GEMM_RELU) ? 1 : 0;
+  g.A = static_cast<const unsigned short*>(p.A); g.B = static_cast<const unsigned short*>(p.B);
+  g.C32 = p.C32; g.C16 = static_cast<unsigned short*>(p.C16);
+  g.bias = p.bias; g.residual = p.res32; g.res16 = static_cast<const unsigned short*>(p.res16);
+  g.gate16 = static_cast<const unsigned short*>(p.gate16);
+  g.M = M; g.N = N; g.K = K; g.lda = p.lda; g.ldb = p.ldb; g.ldc32 = p.ldc32; g.ldc16 = p.ldc16; g.ldr = p.ldr;
+  g.ldg = p.gate16 ? p.ldg : p.ldr;
+  g.relu = p.relu ? 1 : 0;
+  g.cv = p.cv;
   hipStream_t s = ait_stream(stream);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K, s, M, N, K, 0, 1, 1);
   // long reductions on the 256 x 256 x 64 tile (at least a round of them), the 512-deep products on the 256 x 128 x 32 one
   const long long big_tiles = (long long)((M + Big::BM - 1) / Big::BM) * (N / Big::BN);
-  if (kUseBig && K >= ait_lab::Knobs::bf16s_big_min_k && (K % Big::BK) == 0 && (N % Big::BN) == 0 && big_tiles >= 192)
-    return launch_epi<Big>(g, gate, s);
-  return launch_epi<Small>(g, gate, s);
+  const bool big = kUseBig && K >= ait_lab::Knobs::bf16s_big_min_k && (K % Big::BK) == 0 && (N % Big::BN) == 0 && big_tiles >= 192;
+  if (p.cv.on) return big ? launch_epi<Big, true>(g, p.gate, s) : launch_epi<Small, true>(g, p.gate, s);
+  return big ? launch_epi<Big, false>(g, p.gate, s) : launch_epi<Small, false>(g, p.gate, s);
+}
+
+AIT_API int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, float* C32,
+                           long long ldc32, void* C16, long long ldc16, const float* bias, const float* residual,
+                           const void* gate16, long long ldr, int flags, const ait_launch_ctx* ctx, void* stream) {
+  if (flags & ~(AIT_GEMM_RELU | AIT_GEMM_MASK_POS)) return AIT_EUNSUPPORTED;
+  ait_bf16s::Gemm p{};
+  p.A = A; p.B = B; p.C32 = C32; p.C16 = C16; p.bias = bias;
+  p.gate = (flags & AIT_GEMM_MASK_POS) != 0;
+  // (this entry's gate is ONE tensor: gate16 if given, else `residual`; an addend and a gate together are library-internal)
+  if (p.gate && gate16) p.gate16 = gate16; else p.res32 = residual;
+  if (!p.gate && gate16) return AIT_EINVAL;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc32 = ldc32; p.ldc16 = ldc16; p.ldr = ldr; p.ldg = ldr;
+  p.relu = (flags & AIT_GEMM_RELU) != 0;
+  return ait_bf16s::gemm(p, ctx, stream);
+}
+
+int ait_bf16s::wgrad(const Wgrad& p, const ait_launch_ctx* ctx, void* stream) {
+  const int Mo = p.Mo, No = p.No, R = p.R;
+  if (Mo < 0 || No < 0 || R < 0) return AIT_EINVAL;
+  if (Mo == 0 || No == 0 || R == 0) return AIT_OK;
+  if (!p.A || !p.B || !p.C) return AIT_EINVAL;
+  const long long ldb_min = p.cv.on ? (1ll << p.cv.cin_shift) : No;
+  if ((Mo % Small::BM) || (No % Small::BN) || (p.lda % 8) || (p.ldb % 8) || p.lda < Mo || p.ldb < ldb_min || (p.ldc % 4) ||
+      p.ldc < No || !al16(p.A) || !al16(p.B) || !al16(p.C))
+    return AIT_EUNSUPPORTED;
+  int split_k = p.split_k < 1 ? 1 : p.split_k;
+  if ((R % split_k) || ((R / split_k) % Small::BK)) return AIT_EUNSUPPORTED;      // whole 32-row slabs per split
+  TnArgs g;
+  g.A = static_cast<const unsigned short*>(p.A); g.B = static_cast<const unsigned short*>(p.B); g.C = p.C;
+  g.Mo = Mo; g.No = No; g.R = R; g.splits = split_k; g.k_per_split = R / split_k;
+  g.lda = p.lda; g.ldb = p.ldb; g.ldc = p.ldc;
+  g.cv = p.cv;
+  // with scratch for one partial tile set per K-range the ranges are stored once and added by a second small launch
+  // (in range order: reproducible); without it they are added to C with f32 atomics -- a third of the product's time at 16
+  // ranges (profiles/r05_bf16_storage_ffn.txt)
+  const size_t need = (size_t)split_k * Mo * No * sizeof(float);
+  const bool use_partials = !ait_lab::Knobs::tn_atomics && split_k > 1 && p.partials && p.partials_bytes >= need && al16(p.partials);
+  g.partials = use_partials ? static_cast<float*>(p.partials) : nullptr;
+  hipStream_t s = ait_stream(stream);
+  AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * Mo * No * R, s, Mo, No, R, 1, 0, split_k);
+  // (CONV: a tile's columns lie inside one tap -- cin is a power of two >= 64, so 128- and 256-wide tiles need cin >= that)
+  const bool fits_big = !p.cv.on || (1 << p.cv.cin_shift) >= Big::BN;
+  if (p.cv.on && (1 << p.cv.cin_shift) < Small::BN) return AIT_EUNSUPPORTED;
+  const bool big = kUseBig && fits_big && (No % Big::BN) == 0 && (g.k_per_split % Big::BK) == 0 &&
+                   (long long)(Mo / Big::BM) * (No / Big::BN) * split_k >= 192;
+  if (p.cv.on) {
+    if (use_partials) return big ? launch_tn<Big, true, true>(g, s) : launch_tn<Small, true, true>(g, s);
+    return big ? launch_tn<Big, false, true>(g, s) : launch_tn<Small, false, true>(g, s);
+  }
+  if (use_partials) return big ? launch_tn<Big, true, false>(g, s) : launch_tn<Small, true, false>(g, s);
+  return big ? launch_tn<Big, false, false>(g, s) : launch_tn<Small, false, false>(g, s);
 }
 
 AIT_API int ait_gemm_bf16s_tn(int Mo, int No, int R, const void* A, long long lda, const void* B, long long ldb, float* C,
                               long long ldc, int split_k, void* partials, size_t partials_bytes, const ait_launch_ctx* ctx,
                               void* stream) {
-  if (Mo < 0 || No < 0 || R < 0) return AIT_EINVAL;
-  if (Mo == 0 || No == 0 || R == 0) return AIT_OK;
-  if (!A || !B || !C) return AIT_EINVAL;
-  if ((Mo % Small::BM) || (No % Small::BN) || (lda % 8) || (ldb % 8) || lda < Mo || ldb < No || (ldc % 4) || ldc < No ||
-      (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(B) & 15) || (reinterpret_cast<uintptr_t>(C) & 15))
-    return AIT_EUNSUPPORTED;
-  if (split_k < 1) split_k = 1;
-  if ((R % split_k) || ((R / split_k) % Small::BK)) return AIT_EUNSUPPORTED;      // whole 32-row slabs per split
-  TnArgs g;
-  g.A = static_cast<const unsigned short*>(A); g.B = static_cast<const unsigned short*>(B); g.C = C;
-  g.Mo = Mo; g.No = No; g.R = R; g.splits = split_k; g.k_per_split = R / split_k;
-  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-  // with scratch for one partial tile set per K-range the ranges are stored once and added by a second small launch
-  // (in range order: reproducible); without it they are added to C with f32 atomics -- a third of the product's time at 16
-  // ranges (profiles/r05_bf16_storage_ffn.txt)
-  const size_t need = (size_t)split_k * Mo * No * sizeof(float);
-  const bool use_partials = !ait_lab::Knobs::tn_atomics && split_k > 1 && partials && partials_bytes >= need &&
-                            !(reinterpret_cast<uintptr_t>(partials) & 15);
-  g.partials = use_partials ? static_cast<float*>(partials) : nullptr;
-  hipStream_t s = ait_stream(stream);
-  AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * Mo * No * R, s, Mo, No, R, 1, 0, split_k);
-  const bool big = kUseBig && (No % Big::BN) == 0 && (g.k_per_split % Big::BK) == 0 &&
-                   (long long)(Mo / Big::BM) * (No / Big::BN) * split_k >= 192;
-  if (use_partials) return big ? launch_tn<Big, true>(g, s) : launch_tn<Small, true>(g, s);
-  return big ? launch_tn<Big, false>(g, s) : launch_tn<Small, false>(g, s);
+  ait_bf16s::Wgrad p{};
+  p.A = A; p.B = B; p.C = C; p.Mo = Mo; p.No = No; p.R = R; p.split_k = split_k; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.partials = partials; p.partials_bytes = partials_bytes;
+  return ait_bf16s::wgrad(p, ctx, stream);
+}
+
+// ---- convolutions over bf16 channels-last maps (include/ait_hip.h "bf16-storage convolutions") --------------------------------
+AIT_API int ait_conv_fwd_bf16s(const void* x, long long ldx, const void* w, const ait_conv_geom* geom, int cin, int cout,
+                               const float* bias, const void* res16, const void* gate16, long long ldr, int flags, float* y32,
+                               long long ldy32, void* y16, long long ldy16, const void* zeros, size_t zeros_bytes,
+                               const ait_launch_ctx* ctx, void* stream) {
+  if (flags & ~(AIT_GEMM_RELU | AIT_GEMM_MASK_POS)) return AIT_EUNSUPPORTED;
+  ait_bf16s::Gemm p{};
+  long long rows = 0;
+  int taps = 0;
+  AIT_TRY_RC(make_conv(geom, cin, zeros, zeros_bytes, p.cv, rows, taps));
+  if (rows > 0x7fffffffLL) return AIT_EUNSUPPORTED;
+  p.A = x; p.B = w; p.C32 = y32; p.C16 = y16; p.bias = bias; p.res16 = res16;
+  p.gate = (flags & AIT_GEMM_MASK_POS) != 0;
+  p.gate16 = gate16;
+  p.M = (int)rows; p.N = cout; p.K = taps * cin;
+  p.lda = ldx; p.ldb = (long long)taps * cin; p.ldc32 = ldy32; p.ldc16 = ldy16; p.ldr = ldr; p.ldg = ldr;
+  p.relu = (flags & AIT_GEMM_RELU) != 0;
+  return ait_bf16s::gemm(p, ctx, stream);
+}
+
+AIT_API int ait_conv_bwd_weight_bf16s(const void* dy, long long lddy, const void* x, long long ldx, const ait_conv_geom* geom,
+                                      int cin, int cout, float* dw, int split_k, const void* zeros, size_t zeros_bytes,
+                                      void* partials, size_t partials_bytes, const ait_launch_ctx* ctx, void* stream) {
+  ait_bf16s::Wgrad p{};
+  long long rows = 0;
+  int taps = 0;
+  AIT_TRY_RC(make_conv(geom, cin, zeros, zeros_bytes, p.cv, rows, taps));
+  if (rows > 0x7fffffffLL) return AIT_EUNSUPPORTED;
+  p.A = dy; p.B = x; p.C = dw; p.Mo = cout; p.No = taps * cin; p.R = (int)rows; p.split_k = split_k;
+  p.lda = lddy; p.ldb = ldx; p.ldc = (long long)taps * cin;
+  p.partials = partials; p.partials_bytes = partials_bytes;
+  return ait_bf16s::wgrad(p, ctx, stream);
+}
+
+// ---- weights: f32 [n_out][taps][cin] (x scale[n_out]) -> bf16, as they lie (the forward's B operand) and / or as the
+// data gradient's B operand [cin][taps][n_out] with the window flipped (tap t of the gradient = tap taps - 1 - t of the forward)
+namespace {
+struct WJob { const float* src; const float* scale; unsigned short* dst; int n_out, taps, cin, flipped; };
+struct WJobs { WJob j[24]; int n; };
+__global__ __launch_bounds__(256) void fold_bf16_kernel(const WJobs jobs) {
+  __shared__ float tile[64][65];
+  const WJob j = jobs.j[blockIdx.y];
+  const long long cols = (long long)j.taps * j.cin;
+  if (!j.flipped) {
+    const long long n4 = (long long)j.n_out * (cols / 4);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+      const float sc = j.scale ? j.scale[i / (cols / 4)] : 1.f;
+      const float4 v = reinterpret_cast<const float4*>(j.src)[i];
+      reinterpret_cast<uint2*>(j.dst)[i] = make_uint2(pack2(v.x * sc, v.y * sc), pack2(v.z * sc, v.w * sc));
+    }
+    return;
+  }
+  const int ot = j.n_out / 64, ct = j.cin / 64, tiles = j.taps * ot * ct;
+  const long long ld_dst = (long long)j.taps * j.n_out;
+  for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int tap = t / (ot * ct), rem = t - tap * (ot * ct), o0 = (rem / ct) * 64, c0 = (rem % ct) * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      tile[r][c] = j.src[(long long)(o0 + r) * cols + (long long)tap * j.cin + c0 + c] * (j.scale ? j.scale[o0 + r] : 1.f);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+      const int c = i >> 5, r = (i & 31) * 2;
+      *reinterpret_cast<unsigned*>(j.dst + (long long)(c0 + c) * ld_dst + (long long)(j.taps - 1 - tap) * j.n_out + o0 + r) =
+          pack2(tile[r][c], tile[r + 1][c]);
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
+int ait_bf16s::fold_weights(const WeightJob* jobs, int n, void* stream) {
+  if (n < 0 || n > 24) return AIT_EINVAL;
+  if (n == 0) return AIT_OK;
+  WJobs b;
+  b.n = n;
+  for (int i = 0; i < n; i++) {
+    const WeightJob& w = jobs[i];
+    if (!w.src || !w.dst || w.n_out <= 0 || w.taps <= 0 || w.cin <= 0) return AIT_EINVAL;
+    if ((w.n_out % 64) || (w.cin % 64) || !al16(w.src) || !al16(w.dst)) return AIT_EUNSUPPORTED;
+    b.j[i] = WJob{w.src, w.scale, static_cast<unsigned short*>(w.dst), w.n_out, w.taps, w.cin, w.flipped};
+  }
+  hipLaunchKernelGGL(fold_bf16_kernel, dim3(256, (unsigned)n), dim3(256), 0, ait_stream(stream), b);
+  AIT_CHECK_LAUNCH();
+  return AIT_OK;
+}
+
+AIT_API int ait_conv_weight_to_bf16(const float* w, const float* row_scale, int cout, int taps, int cin, void* w16,
+                                    void* w16_dgrad, void* stream) {
+  ait_bf16s::WeightJob jobs[2];
+  int n = 0;
+  if (w16) jobs[n++] = ait_bf16s::WeightJob{w, row_scale, w16, cout, taps, cin, 0};
+  if (w16_dgrad) jobs[n++] = ait_bf16s::WeightJob{w, row_scale, w16_dgrad, cout, taps, cin, 1};
+  return ait_bf16s::fold_weights(jobs, n, stream);
 }
 
 AIT_API int ait_colsum_bf16(const void* x, long long rows, int cols, long long ld, float* out, void* stream) {

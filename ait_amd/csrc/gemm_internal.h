@@ -61,3 +61,44 @@ int ait_ln_bwd_ex(const float* dy, const float* a, const float* pos, const float
                   const float* mean, const float* rstd, long long rows, int d, int seq_len, int src_rows_per_seq, int rep,
                   int dy_rows_per_seq, float p_drop, unsigned long long seed, float* da, float* dres, float* dgamma,
                   float* dbeta, float* dcolsum, void* da16, void* stream);
+
+// ---- bf16-STORAGE products (csrc/gemm_bf16s.hip) with what only the library's composites use: a bf16 addend, an addend AND
+// a gate, and operands gathered through a convolution window (csrc/tail.hip's layer4 in the bf16 configuration) -------------
+namespace ait_bf16s {
+// A stride-1 "same" convolution (odd square window, pad = k / 2) over maps of H x W positions, H * W and W powers of two,
+// rows (map, y, x) of a channels-last tensor with cin (a power of two >= 64) channels: the reduction index of the product is
+// (tap, channel), a K-slab lies inside one tap and reads the rows of the neighbouring position -- or `zeros` (>= 512 bytes)
+// where the window hangs over the edge.
+struct Conv {
+  int on;
+  int hw_mask, w_shift, w_mask, H, W, kw, pad, cin_shift;
+  const unsigned short* zeros;
+};
+// C[M, N] = A[M, K] . B[N, K]^T (+ bias) (+ res32 | res16) (kept where the gate > 0: gate16, or res32 when that is the only
+// tensor given) (ReLU) -> C32 and / or C16.  cv.on: A is the map [M, cin] (pitch lda), K = taps * cin, B = [N][taps][cin].
+struct Gemm {
+  const void* A; const void* B;
+  float* C32; void* C16;
+  const float* bias; const float* res32; const void* res16; const void* gate16;
+  int M, N, K;
+  long long lda, ldb, ldc32, ldc16, ldr, ldg;
+  bool relu, gate;
+  Conv cv;
+};
+int gemm(const Gemm& p, const ait_launch_ctx* ctx, void* stream);
+// C[Mo, No] (f32) += A[R, Mo]^T . B[R, No] over K-ranges of the rows.  cv.on: B is the map [R, cin] (pitch ldb), No = taps * cin,
+// column (tap, channel) of row r reads the map row of r's neighbour under that tap (the convolution's weight gradient).
+struct Wgrad {
+  const void* A; const void* B;
+  float* C;
+  int Mo, No, R, split_k;
+  long long lda, ldb, ldc;
+  void* partials; size_t partials_bytes;
+  Conv cv;
+};
+int wgrad(const Wgrad& p, const ait_launch_ctx* ctx, void* stream);
+// f32 weights [n_out][taps][cin] (x scale[n_out], may be NULL) -> bf16: as they lie, or (flipped) as the data gradient's
+// operand [cin][taps][n_out] with the window mirrored; up to 24 matrices in one launch
+struct WeightJob { const float* src; const float* scale; void* dst; int n_out, taps, cin, flipped; };
+int fold_weights(const WeightJob* jobs, int n, void* stream);
+}  // namespace ait_bf16s

@@ -731,3 +731,55 @@ def conv_bwd_weight(dy, x, geom, kh, kw, split_k=8):
                                                 _lib.launch_ctx(dy.device), _lib.cur_stream(dy.device))
     _lib.check(rc, "ait_conv_bwd_weight_f32")
     return dw
+
+
+# ------------------------------------------------------------------------------------------
+# ... and over bf16 channels-last maps (ait_conv_*_bf16s: the bf16 configuration's layer4)
+# ------------------------------------------------------------------------------------------
+def conv_weight_to_bf16(w, row_scale=None, dgrad=False):
+    """w f32 [cout, kh, kw, cin] (x row_scale[cout]) -> bf16 [cout, kh*kw*cin]; dgrad=True: the data gradient's operand
+    [cin, kh*kw*cout] with the window mirrored (ait_conv_weight_to_bf16)"""
+    cout, kh, kw, cin = w.shape
+    taps = kh * kw
+    out = torch.empty((cin, taps * cout) if dgrad else (cout, taps * cin), dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _lib.lib().ait_conv_weight_to_bf16(_lib.dev_ptr(w), _p(row_scale), cout, taps, cin,
+                                                None if dgrad else ctypes.c_void_p(out.data_ptr()),
+                                                ctypes.c_void_p(out.data_ptr()) if dgrad else None, _lib.cur_stream(w.device))
+    _lib.check(rc, "ait_conv_weight_to_bf16")
+    return out
+
+
+def conv_fwd_bf16s(x16, w16, geom, cin, cout, bias=None, res16=None, gate16=None, relu=False, out_f32=False):
+    """x16 bf16 [rows, cin] rows of a channels-last map, w16 bf16 [cout, taps*cin] -> y [rows, cout] (bf16, or f32 with
+    out_f32); + bias, + res16, kept where gate16 > 0, ReLU.  The data gradient: the same call with conv_weight_to_bf16(...,
+    dgrad=True) and cin / cout swapped."""
+    rows = geom.n * geom.out_h * geom.out_w
+    y = torch.empty((rows, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x16.device)
+    z = _zeros(x16.device)
+    ldr = (res16 if res16 is not None else gate16).stride(0) if (res16 is not None or gate16 is not None) else 0
+    if res16 is not None and gate16 is not None and res16.stride(0) != gate16.stride(0):
+        raise _lib.AitHipError("conv_fwd_bf16s: res16 and gate16 share one pitch")
+    vp = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    flags = (_lib.GEMM_RELU if relu else 0) | (_lib.GEMM_MASK_POS if gate16 is not None else 0)
+    with torch.cuda.device(x16.device):
+        rc = _lib.lib().ait_conv_fwd_bf16s(vp(x16), x16.stride(0), vp(w16), ctypes.byref(geom), cin, cout, _p(bias), vp(res16),
+                                           vp(gate16), ldr, flags, _p(y) if out_f32 else None, cout,
+                                           None if out_f32 else vp(y), cout, _p(z), z.numel() * 4,
+                                           _lib.launch_ctx(x16.device), _lib.cur_stream(x16.device))
+    _lib.check(rc, "ait_conv_fwd_bf16s")
+    return y
+
+
+def conv_bwd_weight_bf16s(dy16, x16, geom, kh, kw, split_k=8, partials=False):
+    cout, cin = dy16.shape[1], x16.shape[1]
+    dw = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=dy16.device)
+    z = _zeros(dy16.device)
+    ws = torch.empty(int(split_k) * dw.numel(), dtype=torch.float32, device=dy16.device) if (partials and split_k > 1) else None
+    with torch.cuda.device(dy16.device):
+        rc = _lib.lib().ait_conv_bwd_weight_bf16s(ctypes.c_void_p(dy16.data_ptr()), dy16.stride(0), ctypes.c_void_p(x16.data_ptr()),
+                                                  x16.stride(0), ctypes.byref(geom), cin, cout, _p(dw), int(split_k), _p(z),
+                                                  z.numel() * 4, _p(ws), 0 if ws is None else ws.numel() * 4,
+                                                  _lib.launch_ctx(dy16.device), _lib.cur_stream(dy16.device))
+    _lib.check(rc, "ait_conv_bwd_weight_bf16s")
+    return dw

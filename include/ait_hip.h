@@ -420,6 +420,32 @@ int ait_colsum_bf16(const void* x, long long rows, int cols, long long ld, float
 int ait_f32_to_bf16(const float* src, long long rows, int cols, long long ld_src, void* dst, long long ld_dst,
                     int transpose, void* stream);
 
+/* bf16-storage CONVOLUTIONS (ABI v8): the 3x3 convolutions of RCNN_top = ResNet layer4 behind the AIT in the bf16 configuration
+ * (BASELINE configs[4]; lib/model/faster_rcnn/resnet_sys_transformer_sk_dilat.py:85-111 Bottleneck.conv2, :482-491) as implicit
+ * GEMMs of ait_gemm_bf16s / ait_gemm_bf16s_tn: no im2col buffer, the operand rows gathered through the window by the LDS-DMA
+ * loads (a tap outside the map reads `zeros`: a caller-owned, 16-byte aligned device buffer of >= 512 zero bytes).
+ * Geometry (else AIT_EUNSUPPORTED): stride 1, odd square window with pad = k / 2 (out = in), in_w and in_h * in_w powers of two,
+ * groups <= 1, cin a power of two >= 64 (>= 128 for the weight gradient), cout % 128 == 0 (% 256 for the weight gradient).
+ *   x   bf16 [n * in_h * in_w, cin] rows (map, y, x) of a channels-last map, pitch ldx (elements, % 8)
+ *   w   bf16 [cout][kh][kw][cin]: ait_conv_weight_to_bf16's `w16` of the f32 parameter (channels-last memory of a PyTorch weight)
+ *   y   = conv(x, w) (+ bias[cout] f32) (+ res16: bf16 [rows, cout], pitch ldr) (kept where gate16 > 0 with AIT_GEMM_MASK_POS:
+ *         bf16 [rows, cout], pitch ldr) (ReLU with AIT_GEMM_RELU) -> y32 (f32, pitch ldy32) and / or y16 (bf16, pitch ldy16)
+ *   The DATA GRADIENT is the same call on the output gradient with the roles of cin / cout swapped and `w16_dgrad` as the weight:
+ *         dx = ait_conv_fwd_bf16s(dy, ..., w16_dgrad, geom, cout, cin, ...)  (w16_dgrad = [cin][taps, window mirrored][cout]).
+ *   dw  f32 [cout][kh][kw][cin] += dy^T (*) x over split_k equal ranges of whole 32-row slabs of the rows (zero dw first);
+ *         partials as in ait_gemm_bf16s_tn.
+ * ait_conv_weight_to_bf16: w f32 [cout][taps][cin] (x row_scale[cout] if given: a frozen BatchNorm's scale folded in) ->
+ *   w16 (as it lies) and / or w16_dgrad; either may be NULL.  cout, cin % 64 == 0. */
+int ait_conv_fwd_bf16s(const void* x, long long ldx, const void* w, const ait_conv_geom* geom, int cin, int cout,
+                       const float* bias, const void* res16, const void* gate16, long long ldr, int flags, float* y32,
+                       long long ldy32, void* y16, long long ldy16, const void* zeros, size_t zeros_bytes,
+                       const ait_launch_ctx* ctx, void* stream);
+int ait_conv_bwd_weight_bf16s(const void* dy, long long lddy, const void* x, long long ldx, const ait_conv_geom* geom,
+                              int cin, int cout, float* dw, int split_k, const void* zeros, size_t zeros_bytes,
+                              void* partials, size_t partials_bytes, const ait_launch_ctx* ctx, void* stream);
+int ait_conv_weight_to_bf16(const float* w, const float* row_scale, int cout, int taps, int cin, void* w16,
+                            void* w16_dgrad, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Row kernels (d_model = 512 only; other widths return AIT_EUNSUPPORTED).
  *

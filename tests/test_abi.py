@@ -43,7 +43,7 @@ def test_library_builds_and_exports_header_symbols():
     for n in names:
         assert hasattr(L, n), "libait_hip.so does not export %s" % n
     assert sorted(_lib.SIGNATURES) == names, (sorted(_lib.SIGNATURES), names)
-    assert L.ait_abi_version() == 7
+    assert L.ait_abi_version() == 8
     # the shipped library is the product build: no experiment knob is set (csrc/lab_knobs.h), and ait_amd/build.py has no
     # way to set one
     assert L.ait_lab_build() == 0

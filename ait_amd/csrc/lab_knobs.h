@@ -46,6 +46,8 @@ struct Product {
   static constexpr bool l4_pm_wgrad = true;
   // conv_f32.hip: the 3x3 forward / data gradient of position-major maps with the out-of-map taps skipped (two-group stream-K cut)
   static constexpr bool l4_pm_skip = true;
+  // tail.hip: layer4 on bf16 storage under AIT_CTX_BF16 (false: f32 tensors, operands rounded in registers -- round 5's)
+  static constexpr bool tail_bf16s = true;
   // gemm_f32.hip: products of fewer than 512 256x128 tiles on the 128x128 split tile (0 off, 1 static work list, 2 with the
   // scheduler scratch: tickets + stream-K)
   static constexpr int mid_tile = 0;

@@ -173,6 +173,79 @@ inline unsigned l4_grid(long long n4) {
   return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+// ---- layer4 on bf16 STORAGE (the bf16 configuration, BASELINE configs[4]: cfgs/res101.yml) ----------------------------------
+// Under AIT_CTX_BF16 every activation and gradient of layer4 -- its input (the SK blocks' result), a1 / a2 / o of every
+// bottleneck, the four gradient buffers -- is HELD in bf16 (map-major rows, padded to a multiple of 1024 so that the weight
+// gradients cut into 16 equal ranges of whole 64-row slabs) and the folded weights are converted once per call, both
+// orientations: the products run on gemm_bf16s.hip's kernels (bf16 operands from memory, 2-byte results), the 3x3 convolutions
+// through their window gather.  Same buffers: every bf16 tensor lives in the first half of the f32 tensor it replaces.  The SK
+// blocks keep their f32 tensors (their products round to bf16 in registers): their closing pass writes layer4's input in
+// bf16, and the last two data-gradient products of layer4 write the gradient they hand back in f32.
+constexpr bool kTail16 = ait_lab::Knobs::tail_bf16s;
+typedef unsigned short bf16_t;
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {         // v_cvt_pk_bf16_f32, nearest even
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 t;
+  t[0] = (__bf16)a;
+  t[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ float4 ld_bf16x4(const bf16_t* p) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st_bf16x4(bf16_t* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+}
+__global__ __launch_bounds__(256) void pool_fwd16_kernel(const bf16_t* __restrict__ o, int n_maps, int C, float* __restrict__ pooled) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)n_maps * (C / 4)) return;
+  const int m = (int)(i / (C / 4)), c4 = (int)(i - (long long)m * (C / 4));
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int p = 0; p < kPos; p++) {
+    const float4 v = ld_bf16x4(o + ((size_t)m * kPos + p) * C + 4 * c4);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  const float k = 1.f / kPos;
+  reinterpret_cast<float4*>(pooled + (size_t)m * C)[c4] = make_float4(acc.x * k, acc.y * k, acc.z * k, acc.w * k);
+}
+__global__ __launch_bounds__(256) void pool_bwd16_kernel(const float* __restrict__ dpooled, const bf16_t* __restrict__ o, long long rows,
+                                                         int n_maps, int C, bf16_t* __restrict__ g) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * (C / 4)) return;
+  const long long r = i / (C / 4);
+  const int c4 = (int)(i - r * (C / 4)), m = (int)(r / kPos);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m < n_maps) {
+    const float4 d = reinterpret_cast<const float4*>(dpooled + (size_t)m * C)[c4];
+    const float4 y = ld_bf16x4(o + (size_t)r * C + 4 * c4);
+    const float k = 1.f / kPos;
+    v = make_float4(y.x > 0.f ? d.x * k : 0.f, y.y > 0.f ? d.y * k : 0.f, y.z > 0.f ? d.z * k : 0.f, y.w > 0.f ? d.w * k : 0.f);
+  }
+  st_bf16x4(g + (size_t)r * C + 4 * c4, v);
+}
+// sqsum_l4_fwd_kernel with its result in bf16, map-major
+__global__ __launch_bounds__(256) void sqsum_l4_fwd16_kernel(const float* __restrict__ a, const float* __restrict__ b, int n, int n_zero,
+                                                             int map0, int C, bf16_t* __restrict__ y) {
+  const long long n4 = (long long)(n + n_zero) * kPos * (C / 4);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const long long r = i / (C / 4);
+    const int c4 = (int)(i - r * (C / 4));
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < (long long)n * kPos) {
+      const float4 x = reinterpret_cast<const float4*>(a)[i], z = reinterpret_cast<const float4*>(b)[i];
+      float u, v;
+      u = fmaxf(x.x, 0.f); v = fmaxf(z.x, 0.f); o.x = u * u + v * v;
+      u = fmaxf(x.y, 0.f); v = fmaxf(z.y, 0.f); o.y = u * u + v * v;
+      u = fmaxf(x.z, 0.f); v = fmaxf(z.z, 0.f); o.z = u * u + v * v;
+      u = fmaxf(x.w, 0.f); v = fmaxf(z.w, 0.f); o.w = u * u + v * v;
+    }
+    st_bf16x4(y + ((size_t)map0 * kPos + r) * C + 4 * c4, o);
+  }
+}
+
 // ---- geometry and buffers ------------------------------------------------------------------------------------
 struct Dims {
   int bp, bs, C, P, E;          // C = SK / layer4 input channels, P = planes, E = 4 * planes
@@ -325,17 +398,65 @@ int check_weights(const ait_tail_weights* w, const Dims& d) {
 // one SKBlock at stride 2: f1 = relu(conv1x1_g8(x) + b1), f3 = relu(conv3x3_g8(x) + b3), y = f1^2 + f3^2 written into
 // layer4's input at maps map0 .. map0 + n - 1 (+ n_zero zero-filled maps behind them)
 int sk_forward(const float* x, int n, int n_zero, int map0, const Dims& d, const ait_sk_weights& w, float* f1, float* f3, float* xtop,
-               const float* zeros, const Run& r) {
+               const float* zeros, const Run& r, bool out16 = false) {
   if (n > 0) {
     const ait_conv_geom g1 = sk_geom(n, 1), g3 = sk_geom(n, 3);
     AIT_TRY(ait_conv_fwd_f32(x, d.C, w.w1, &g1, d.C, d.C, w.b1, nullptr, AIT_GEMM_RELU, f1, d.C, zeros, kZeros, r.ctx, r.stream));
     AIT_TRY(ait_conv_fwd_f32(x, d.C, w.w3, &g3, d.C, d.C, w.b3, nullptr, AIT_GEMM_RELU, f3, d.C, zeros, kZeros, r.ctx, r.stream));
   }
   if (n + n_zero == 0) return AIT_OK;
-  hipLaunchKernelGGL(sqsum_l4_fwd_kernel, dim3(l4_grid((long long)(n + n_zero) * kPos * (d.C / 4))), dim3(256), 0, ait_stream(r.stream),
-                     f1, f3, n, n_zero, map0, d.n_maps_pad, (int)l4_pm_on(r.ctx), d.C, xtop);
+  if (out16)
+    hipLaunchKernelGGL(sqsum_l4_fwd16_kernel, dim3(l4_grid((long long)(n + n_zero) * kPos * (d.C / 4))), dim3(256), 0,
+                       ait_stream(r.stream), f1, f3, n, n_zero, map0, d.C, reinterpret_cast<bf16_t*>(xtop));
+  else
+    hipLaunchKernelGGL(sqsum_l4_fwd_kernel, dim3(l4_grid((long long)(n + n_zero) * kPos * (d.C / 4))), dim3(256), 0, ait_stream(r.stream),
+                       f1, f3, n, n_zero, map0, d.n_maps_pad, (int)l4_pm_on(r.ctx), d.C, xtop);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
+}
+
+// ---- layer4 on bf16 storage: when, its row count, its views of the buffers ---------------------------------------------
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+inline bool tail16_on(const ait_launch_ctx* ctx, const Dims& d) {
+  // (at least 1024 real rows: the 1024-row padding then fits the f32 buffers it lives in; the convolution gather wants a
+  // power-of-two channel count)
+  return kTail16 && ctx && (ctx->flags & AIT_CTX_BF16) && !(ctx->flags & AIT_CTX_NATIVE_F32) && d.Rp + d.Rq >= 1024 &&
+         pow2(d.P) && d.P >= 256;
+}
+inline long long rows16(const Dims& d) { return (long long)align_up((size_t)(d.Rp + d.Rq), 1024); }
+struct W16 { bf16_t *w1, *w1t, *w2, *w2d, *w3, *w3t, *wd, *wdt; };
+inline W16 weights16(const BlockW& f, const Dims& d, int k) {
+  const size_t cin = k == 0 ? d.C : d.E, P = d.P, E = d.E;
+  W16 w;
+  w.w1 = reinterpret_cast<bf16_t*>(f.w1); w.w1t = w.w1 + P * cin;
+  w.w2 = reinterpret_cast<bf16_t*>(f.w2); w.w2d = w.w2 + P * 9 * P;
+  w.w3 = reinterpret_cast<bf16_t*>(f.w3); w.w3t = w.w3 + E * P;
+  w.wd = reinterpret_cast<bf16_t*>(f.wd); w.wdt = f.wd ? w.wd + E * cin : nullptr;
+  return w;
+}
+inline ait_bf16s::Conv l4_conv16(const float* zeros, int channels) {
+  return ait_bf16s::Conv{1, kPos - 1, 2, 3, 4, 4, 3, 1, __builtin_ctz((unsigned)channels), reinterpret_cast<const unsigned short*>(zeros)};
+}
+// y16 [M, N] = relu?(x16 [M, K] W16[N, K]^T + bias (+ res16)) (kept where gate16 > 0), or the same into y32; conv: through the 3x3 window
+inline int mm16(const bf16_t* x, long long M, int K, const bf16_t* w, int N, const float* bias, const bf16_t* res16, const float* res32,
+                const bf16_t* gate16, bool relu, bf16_t* y16, float* y32, const Run& r, const ait_bf16s::Conv* cv = nullptr) {
+  ait_bf16s::Gemm p{};
+  p.A = x; p.B = w; p.C16 = y16; p.C32 = y32; p.bias = bias; p.res16 = res16; p.res32 = res32; p.gate16 = gate16;
+  p.gate = gate16 != nullptr;
+  p.M = (int)M; p.N = N; p.K = K;
+  p.lda = cv ? (1 << cv->cin_shift) : K; p.ldb = K; p.ldc16 = N; p.ldc32 = N; p.ldr = N; p.ldg = N;
+  p.relu = relu;
+  if (cv) p.cv = *cv;
+  return ait_bf16s::gemm(p, r.ctx, r.stream);
+}
+// dW [N_out, cols] (f32) += dy16 [R, N_out]^T x16 [R, .] over 16 equal ranges of the rows
+inline int wg16(const bf16_t* dy, long long R, int N_out, const bf16_t* x, int K_in, float* dw, const Run& r,
+                const ait_bf16s::Conv* cv = nullptr) {
+  ait_bf16s::Wgrad p{};
+  p.A = dy; p.B = x; p.C = dw; p.Mo = N_out; p.No = cv ? 9 * K_in : K_in; p.R = (int)R; p.split_k = 16;
+  p.lda = N_out; p.ldb = K_in; p.ldc = p.No;
+  if (cv) p.cv = *cv;
+  return ait_bf16s::wgrad(p, r.ctx, r.stream);
 }
 
 }  // namespace
@@ -347,7 +468,9 @@ AIT_API size_t ait_tail_saved_bytes(int bp, int bs, int channels, int planes, in
 }
 
 constexpr unsigned kTailFmtMagic = 0xA1800000u;
-inline unsigned tail_format(const ait_launch_ctx* ctx) { return kTailFmtMagic | (l4_pm_on(ctx) ? AIT_TAIL_SAVED_PM : 0u); }
+inline unsigned tail_format(const ait_launch_ctx* ctx, const Dims& d) {
+  return kTailFmtMagic | (l4_pm_on(ctx) ? AIT_TAIL_SAVED_PM : 0u) | (tail16_on(ctx, d) ? AIT_TAIL_SAVED_BF16 : 0u);
+}
 
 AIT_API int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int bs, int channels, int planes,
                          int n_blocks, const ait_tail_weights* w, void* saved, size_t saved_bytes, unsigned* saved_format,
@@ -356,7 +479,7 @@ AIT_API int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int
   AIT_TRY(make_dims(bp, bs, channels, planes, n_blocks, d));
   AIT_TRY(check_weights(w, d));
   if ((bp > 0 && !x_props) || (bs > 0 && !x_query) || !saved || !pooled || !saved_format) return AIT_EINVAL;
-  *saved_format = tail_format(ctx);
+  *saved_format = tail_format(ctx, d);
   if (saved_bytes < ait_tail_saved_bytes(bp, bs, channels, planes, n_blocks)) return AIT_EWORKSPACE;
   Bump b{static_cast<char*>(saved), saved_bytes};
   Saved s;
@@ -365,6 +488,56 @@ AIT_API int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int
   const Run run{stream, ctx};
   const int C = d.C, P = d.P, E = d.E;
   if (hipMemsetAsync(s.zeros, 0, kZeros * sizeof(float), hs) != hipSuccess) return AIT_ELAUNCH;
+  if (tail16_on(ctx, d)) {
+    // ---- layer4 on bf16 storage: folded weights -> bf16 (both orientations), the SK blocks' result in bf16, bf16 products
+    const long long R16 = rows16(d);
+    const int npad16 = (int)(R16 / kPos);
+    for (int k = 0; k < d.n_blocks; k++) {
+      const ait_bottleneck_weights& bw = w->block[k];
+      const int cin = k == 0 ? C : E;
+      const W16 w16 = weights16(s.wf[k], d, k);
+      ait_bf16s::WeightJob jobs[8];
+      int n = 0;
+      jobs[n++] = ait_bf16s::WeightJob{bw.conv1, bw.bn1_scale, w16.w1, P, 1, cin, 0};
+      jobs[n++] = ait_bf16s::WeightJob{bw.conv1, bw.bn1_scale, w16.w1t, P, 1, cin, 1};
+      jobs[n++] = ait_bf16s::WeightJob{bw.conv2, bw.bn2_scale, w16.w2, P, 9, P, 0};
+      jobs[n++] = ait_bf16s::WeightJob{bw.conv2, bw.bn2_scale, w16.w2d, P, 9, P, 1};
+      jobs[n++] = ait_bf16s::WeightJob{bw.conv3, bw.bn3_scale, w16.w3, E, 1, P, 0};
+      jobs[n++] = ait_bf16s::WeightJob{bw.conv3, bw.bn3_scale, w16.w3t, E, 1, P, 1};
+      if (k == 0) {
+        jobs[n++] = ait_bf16s::WeightJob{bw.down, bw.bnd_scale, w16.wd, E, 1, cin, 0};
+        jobs[n++] = ait_bf16s::WeightJob{bw.down, bw.bnd_scale, w16.wdt, E, 1, cin, 1};
+      }
+      AIT_TRY(ait_bf16s::fold_weights(jobs, n, stream));
+    }
+    AIT_TRY(sk_forward(x_props, bp, 0, 0, d, w->sk_props, s.f1p, s.f3p, s.xtop, s.zeros, run, true));
+    AIT_TRY(sk_forward(x_query, bs, npad16 - d.n_maps, bp, d, w->sk_query, s.f1q, s.f3q, s.xtop, s.zeros, run, true));
+    const ait_bf16s::Conv cv = l4_conv16(s.zeros, P);
+    const bf16_t* xin = reinterpret_cast<const bf16_t*>(s.xtop);
+    for (int k = 0; k < d.n_blocks; k++) {
+      const ait_bottleneck_weights& bw = w->block[k];
+      const int cin = k == 0 ? C : E;
+      const W16 w16 = weights16(s.wf[k], d, k);
+      bf16_t* a1 = reinterpret_cast<bf16_t*>(s.a1[k]);
+      bf16_t* a2 = reinterpret_cast<bf16_t*>(s.a2[k]);
+      bf16_t* o = reinterpret_cast<bf16_t*>(s.o[k]);
+      AIT_TRY(mm16(xin, R16, cin, w16.w1, P, bw.bn1_shift, nullptr, nullptr, nullptr, true, a1, nullptr, run));
+      AIT_TRY(mm16(a1, R16, 9 * P, w16.w2, P, bw.bn2_shift, nullptr, nullptr, nullptr, true, a2, nullptr, run, &cv));
+      const bf16_t* idn = xin;
+      if (k == 0) {
+        bf16_t* park = reinterpret_cast<bf16_t*>(s.o[1]);       // (free until block 1 writes its output; n_blocks >= 2)
+        AIT_TRY(mm16(xin, R16, cin, w16.wd, E, bw.bnd_shift, nullptr, nullptr, nullptr, false, park, nullptr, run));
+        idn = park;
+      }
+      AIT_TRY(mm16(a2, R16, P, w16.w3, E, bw.bn3_shift, idn, nullptr, nullptr, true, o, nullptr, run));
+      xin = o;
+    }
+    const long long n4 = (long long)d.n_maps * (E / 4);
+    hipLaunchKernelGGL(pool_fwd16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, hs,
+                       reinterpret_cast<const bf16_t*>(s.o[d.n_blocks - 1]), d.n_maps, E, pooled);
+    AIT_CHECK_LAUNCH();
+    return AIT_OK;
+  }
   // ---- frozen-BN scales into the weight rows (resnet_sys_transformer_sk_dilat.py:435-441,474-480: every BatchNorm of
   // RCNN_top is frozen and in eval mode): y = bn(conv(x)) = x (diag(scale) W)^T + shift
   {
@@ -443,7 +616,7 @@ AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const floa
   AIT_TRY(make_dims(bp, bs, channels, planes, n_blocks, d));
   AIT_TRY(check_weights(w, d));
   // the forward laid `saved` out in the row order it reported; this call would read it in the order ITS ctx implies
-  if (saved_format != tail_format(ctx)) return AIT_EINVAL;
+  if (saved_format != tail_format(ctx, d)) return AIT_EINVAL;
   if (!d_pooled || (bp > 0 && !x_props) || (bs > 0 && !x_query) || !saved || !workspace || !grads) return AIT_EINVAL;
   if (saved_bytes < ait_tail_saved_bytes(bp, bs, channels, planes, n_blocks)) return AIT_EWORKSPACE;
   if (workspace_bytes < ait_tail_bwd_workspace_bytes(bp, bs, channels, planes, n_blocks)) return AIT_EWORKSPACE;
@@ -467,8 +640,45 @@ AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const floa
   const Run run{stream, ctx};
   if (hipMemsetAsync(dwf_base, 0, dwf_bytes, hs) != hipSuccess) return AIT_ELAUNCH;
 
+  const bool t16 = tail16_on(ctx, d);
+  if (t16) {
+    const long long R16 = rows16(d);
+    bf16_t* gout = reinterpret_cast<bf16_t*>(ga);
+    bf16_t* gnext = reinterpret_cast<bf16_t*>(gb);
+    bf16_t* g2h = reinterpret_cast<bf16_t*>(g2);
+    bf16_t* g1h = reinterpret_cast<bf16_t*>(g1);
+    {
+      const long long n4 = R16 * (E / 4);
+      hipLaunchKernelGGL(pool_bwd16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, hs, d_pooled,
+                         reinterpret_cast<const bf16_t*>(s.o[d.n_blocks - 1]), R16, d.n_maps, E, gout);
+      AIT_CHECK_LAUNCH();
+    }
+    const ait_bf16s::Conv cv = l4_conv16(s.zeros, P);
+    for (int k = d.n_blocks - 1; k >= 0; k--) {
+      const int cin = k == 0 ? C : E;
+      const W16 w16 = weights16(s.wf[k], d, k);
+      const bf16_t* xin = reinterpret_cast<const bf16_t*>(k == 0 ? s.xtop : s.o[k - 1]);
+      const bf16_t* a1 = reinterpret_cast<const bf16_t*>(s.a1[k]);
+      const bf16_t* a2 = reinterpret_cast<const bf16_t*>(s.a2[k]);
+      AIT_TRY(wg16(gout, R16, E, a2, P, dwf[k].w3, run));                                                   // d W3' += g^T a2
+      AIT_TRY(mm16(gout, R16, E, w16.w3t, P, nullptr, nullptr, nullptr, a2, false, g2h, nullptr, run));     // g2 = (g W3') [a2 > 0]
+      AIT_TRY(wg16(g2h, R16, P, a1, P, dwf[k].w2, run, &cv));
+      AIT_TRY(mm16(g2h, R16, 9 * P, w16.w2d, P, nullptr, nullptr, nullptr, a1, false, g1h, nullptr, run, &cv));
+      AIT_TRY(wg16(g1h, R16, P, xin, cin, dwf[k].w1, run));                                                 // d W1' += g1^T x_in
+      if (k > 0) {
+        // conv1's data gradient + the identity shortcut's, behind the previous block's ReLU
+        AIT_TRY(mm16(g1h, R16, P, w16.w1t, cin, nullptr, gout, nullptr, xin, false, gnext, nullptr, run));
+        bf16_t* t = gout; gout = gnext; gnext = t;
+      } else {
+        AIT_TRY(wg16(gout, R16, E, xin, cin, dwf[k].wd, run));                                              // projection shortcut
+        // (the gradient handed to the SK blocks in f32, rows of real maps only: dxt has d.R rows)
+        AIT_TRY(mm16(gout, d.R, E, w16.wdt, cin, nullptr, nullptr, nullptr, nullptr, false, nullptr, dxt, run));
+        AIT_TRY(mm16(g1h, d.R, P, w16.w1t, cin, nullptr, nullptr, dxt, nullptr, false, nullptr, dxt, run));  // (+=, in place)
+      }
+    }
+  }
   // gradient at layer4's output, behind its closing ReLU
-  {
+  if (!t16) {
     const long long n4 = d.R * (E / 4);
     hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, hs, d_pooled, s.o[d.n_blocks - 1], d.R,
                        d.n_maps, d.n_maps_pad, (int)l4_pm_on(ctx), E, ga);
@@ -477,7 +687,7 @@ AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const floa
   const ait_conv_geom g3 = l4_geom(d.n_maps_pad);
   float* gout = ga;        // gradient at this block's output (masked)
   float* gnext = gb;       // where the gradient at the block's input goes
-  for (int k = d.n_blocks - 1; k >= 0; k--) {
+  for (int k = t16 ? -1 : d.n_blocks - 1; k >= 0; k--) {
     const int cin = k == 0 ? C : E;
     const float* xin = k == 0 ? s.xtop : s.o[k - 1];
     AIT_TRY(wgrad(gout, d.R, E, s.a2[k], P, dwf[k].w3, run));                                     // d W3' += g^T a2

@@ -787,9 +787,15 @@ size_t ait_tail_saved_bytes(int bp, int bs, int channels, int planes, int n_bloc
 /* saved_format (ABI v7; as ait_transformer_fwd_train's): the LAYOUT of `saved` depends on the call's product form -- layer4's
  * activations are kept in position-major row order (row = position * maps + map: its 3x3 convolutions then skip the window's
  * out-of-map taps) in the split product form, map-major under AIT_CTX_BF16 / AIT_CTX_NATIVE_F32.  The forward reports what it
- * wrote (a magic in the top 12 bits + AIT_TAIL_SAVED_PM; host memory, required), the backward is handed that word and returns
+ * wrote (a magic in the top 12 bits + AIT_TAIL_SAVED_PM / AIT_TAIL_SAVED_BF16; host memory, required), the backward is handed that word and returns
  * AIT_EINVAL if its own ctx implies the other order or the word is not one the forward reported. */
 #define AIT_TAIL_SAVED_PM 1u
+/* ... and (ABI v8) whether layer4's tensors are held in bf16: under AIT_CTX_BF16, from 1024 rows (64 maps) and for planes a
+ * power of two >= 256, every activation and gradient of layer4 is STORED in bf16 (map-major rows padded to a multiple of 1024,
+ * inside the same `saved` / `workspace` sizes) and its products read bf16 operands from memory (ait_gemm_bf16s / _tn, the 3x3
+ * convolutions through ait_conv_*_bf16s' window gather; folded weights converted once per call).  The SK blocks keep f32 tensors
+ * (operands rounded in registers).  Smaller calls under AIT_CTX_BF16: f32 tensors, operands rounded in registers. */
+#define AIT_TAIL_SAVED_BF16 2u
 int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int bs, int channels, int planes, int n_blocks,
                  const ait_tail_weights* w, void* saved, size_t saved_bytes, unsigned* saved_format, float* pooled,
                  const ait_launch_ctx* ctx, void* stream);

@@ -646,6 +646,115 @@ def test_tail_backward_is_held_to_its_forwards_layout(monkeypatch):
         assert float((a - b).norm() / (b.norm() + 1e-30)) < 1e-4     # (atomics in the weight gradients: not bit-equal)
 
 
+def _tail_bf16_emulation(m, dp, x, q):
+    """The proposal tail in float64 on the host, rounded to bf16 (straight-through for autograd) exactly where the library's
+    bf16-storage form rounds: the SK blocks' operands, their result, the folded weights, every activation of layer4."""
+    import torch.nn.functional as F
+    import ait_amd.faster_rcnn as fr
+
+    def r(t):
+        return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
+
+    def sk(prefix, blk, x):
+        fs = []
+        for i in range(2):
+            conv = blk.convs[i][0]
+            w, b = dp["%s.convs.%d.0.weight" % (prefix, i)], dp["%s.convs.%d.0.bias" % (prefix, i)]
+            fs.append(F.relu(F.conv2d(r(x), r(w), b, 2, conv.padding, 1, 8)))
+        return r(fs[0] ** 2 + fs[1] ** 2)
+    xt = torch.cat([sk("sk.sk_props", m.sk.sk_props, x), sk("sk.sk_query", m.sk.sk_query, q)])
+    for k, b in enumerate(m.RCNN_top[0]):
+        def fold(name, bn):
+            scale, shift, _ = fr._bn_affine(bn)
+            w = dp["RCNN_base.backbone.layer4.%d.%s.weight" % (k, name)]
+            return r(w * scale.cpu().double()[:, None, None, None]), shift.cpu().double()[None, :, None, None]
+        w1, s1 = fold("conv1", b.bn1)
+        a1 = r(F.relu(F.conv2d(xt, w1) + s1))
+        w2, s2 = fold("conv2", b.bn2)
+        a2 = r(F.relu(F.conv2d(a1, w2, padding=1) + s2))
+        idn = xt
+        if k == 0:
+            wd, sd = fold("downsample.0", b.downsample[1])
+            idn = r(F.conv2d(xt, wd) + sd)
+        w3, s3 = fold("conv3", b.bn3)
+        xt = r(F.relu(F.conv2d(a2, w3) + s3 + idn))
+    return xt.mean((2, 3))
+
+
+@pytest.mark.parametrize("bp,bs,positive", [(100, 4, True), (100, 4, False), (300, 5, True)])
+def test_proposal_tail_on_bf16_storage(monkeypatch, bp, bs, positive):
+    """ABI v8: under AIT_CTX_BF16, from 1024 rows, ait_tail_* keeps layer4's activations and gradients in bf16 and runs its
+    products -- the 3x3 convolutions through the window gather -- on the bf16-storage kernels.  Against a float64 host
+    emulation that rounds to bf16 at the same points (_tail_bf16_emulation; gradients by autograd, un-rounded).
+    positive: frozen statistics and biases that keep every pre-activation above zero -- no ReLU masks, so none can flip:
+    pooled features to 2e-4 and all 22 gradients to 8e-3 in relative L2 (what is left is the bf16 rounding of the stored
+    GRADIENTS: measured 1.6e-3 .. 2.9e-3).  Otherwise (random statistics: half of every mask is zero) the two chains
+    decorrelate at the level of one bf16 ulp per element within a few layers -- a perturbation d of a value flips its rounding
+    with probability d / 2^-8 -- and every flipped mask bit moves a gradient: pooled 4e-3, gradients 0.15 (measured 9e-4 /
+    1.2e-2 at the last convolution .. 6.1e-2 at the inputs; the f32-tensor form of the same call measures 1.3e-3 / 9.9e-2).
+    The forward must report the bf16 layout."""
+    import ait_amd.faster_rcnn as fr
+    from ait_amd import _lib, ops
+    torch.manual_seed(7)
+    m = fr.resnet(('__background__', 'fg'), 50, pretrained=False, class_agnostic=True, num_K=3)
+    m.create_architecture()
+    for mod in m.RCNN_top.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.1)
+            if positive:
+                mod.weight.data.mul_(0.002)
+                mod.running_mean.zero_()
+                mod.bias.data.fill_(1.0)
+    if positive:
+        for blk in (m.sk.sk_props, m.sk.sk_query):
+            for c in blk.convs:
+                c[0].bias.data.fill_(8.0)
+    m = m.cuda().train()
+    x0 = torch.randn(bp, 1024, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+    q0 = torch.randn(bs, 1024, 8, 8, device="cuda")
+    cot = torch.randn(bp + bs, 2048, device="cuda")
+    names = [n for n, _ in m.named_parameters()
+             if n.startswith(("sk.sk_props.convs", "sk.sk_query.convs", "RCNN_base.backbone.layer4.", "RCNN_top."))
+             and "bn" not in n and "downsample.1" not in n]
+    assert len(names) == 18
+    L = _lib.lib()
+    real = L.ait_tail_bwd
+    words = []
+
+    def spy(*a):
+        words.append(a[11])
+        return real(*a)
+
+    x, q = x0.clone().requires_grad_(True), q0.clone().requires_grad_(True)
+    ops.set_matmul_dtype("bf16")
+    try:
+        assert m._tail_on_library(x, q, 2)
+        yp, yq = m._tail(x, q)
+        monkeypatch.setattr(L, "ait_tail_bwd", spy, raising=False)
+        (torch.cat([yp, yq]) * cot).sum().backward()
+    finally:
+        monkeypatch.undo()
+        ops.set_matmul_dtype("f32")
+    assert len(words) == 1 and words[0] >> 20 == 0xA18 and (words[0] & 3) == 2, [hex(w) for w in words]    # bf16, map-major
+    params = dict(m.named_parameters())
+    got = [torch.cat([yp, yq]).detach(), x.grad, q.grad] + [params[n].grad for n in names]
+    dp = {n: params[n].detach().cpu().double().requires_grad_(True) for n in names}
+    xe, qe = x0.cpu().double().requires_grad_(True), q0.cpu().double().requires_grad_(True)
+    ye = _tail_bf16_emulation(m, dp, xe, qe)
+    (ye * cot.cpu().double()).sum().backward()
+    want = [ye.detach(), xe.grad, qe.grad] + [dp[n].grad for n in names]
+    rel = lambda a, b: float((a.double().cpu() - b).norm() / (b.norm() + 1e-30))
+    for lab, a, b in zip(["pooled", "d_x_props", "d_x_query"] + names, got, want):
+        assert bool(torch.isfinite(a).all()), lab
+        tol = (2e-4 if positive else 4e-3) if lab == "pooled" else (8e-3 if positive else 0.15)
+        assert rel(a, b) < tol, (lab, rel(a, b))
+    if positive:
+        assert bool((yp > 0).all())                        # (the configuration did what it is for)
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout,k,pad", [(4, 38, 63, 1024, 512, 3, 1), (1, 20, 30, 256, 128, 3, 1), (2, 19, 31, 128, 256, 3, 1),
                                                    (3, 7, 5, 128, 64, 1, 0), (2, 38, 63, 256, 256, 3, 1)])
 def test_implicit_gemm_convolutions_on_maps_of_any_size(n, h, w, cin, cout, k, pad):

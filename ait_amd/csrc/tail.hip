@@ -450,11 +450,15 @@ inline int mm16(const bf16_t* x, long long M, int K, const bf16_t* w, int N, con
   return ait_bf16s::gemm(p, r.ctx, r.stream);
 }
 // dW [N_out, cols] (f32) += dy16 [R, N_out]^T x16 [R, .] over 16 equal ranges of the rows
-inline int wg16(const bf16_t* dy, long long R, int N_out, const bf16_t* x, int K_in, float* dw, const Run& r,
+// (scratch: room for the ranges' partial tiles -- stored once and added in range order instead of f32 atomics, which cost these
+// 4160-row ranges three times the product itself; too small: atomics)
+struct Scratch { void* p; size_t bytes; };
+inline int wg16(const bf16_t* dy, long long R, int N_out, const bf16_t* x, int K_in, float* dw, const Run& r, const Scratch& scratch,
                 const ait_bf16s::Conv* cv = nullptr) {
   ait_bf16s::Wgrad p{};
   p.A = dy; p.B = x; p.C = dw; p.Mo = N_out; p.No = cv ? 9 * K_in : K_in; p.R = (int)R; p.split_k = 16;
   p.lda = N_out; p.ldb = K_in; p.ldc = p.No;
+  p.partials = scratch.p; p.partials_bytes = scratch.bytes;
   if (cv) p.cv = *cv;
   return ait_bf16s::wgrad(p, r.ctx, r.stream);
 }
@@ -654,23 +658,24 @@ AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const floa
       AIT_CHECK_LAUNCH();
     }
     const ait_bf16s::Conv cv = l4_conv16(s.zeros, P);
+    const Scratch scr{dxt, (size_t)d.R * C * sizeof(float)};       // (dxt is written by the last two products only)
     for (int k = d.n_blocks - 1; k >= 0; k--) {
       const int cin = k == 0 ? C : E;
       const W16 w16 = weights16(s.wf[k], d, k);
       const bf16_t* xin = reinterpret_cast<const bf16_t*>(k == 0 ? s.xtop : s.o[k - 1]);
       const bf16_t* a1 = reinterpret_cast<const bf16_t*>(s.a1[k]);
       const bf16_t* a2 = reinterpret_cast<const bf16_t*>(s.a2[k]);
-      AIT_TRY(wg16(gout, R16, E, a2, P, dwf[k].w3, run));                                                   // d W3' += g^T a2
+      AIT_TRY(wg16(gout, R16, E, a2, P, dwf[k].w3, run, scr));                                              // d W3' += g^T a2
       AIT_TRY(mm16(gout, R16, E, w16.w3t, P, nullptr, nullptr, nullptr, a2, false, g2h, nullptr, run));     // g2 = (g W3') [a2 > 0]
-      AIT_TRY(wg16(g2h, R16, P, a1, P, dwf[k].w2, run, &cv));
+      AIT_TRY(wg16(g2h, R16, P, a1, P, dwf[k].w2, run, scr, &cv));
       AIT_TRY(mm16(g2h, R16, 9 * P, w16.w2d, P, nullptr, nullptr, nullptr, a1, false, g1h, nullptr, run, &cv));
-      AIT_TRY(wg16(g1h, R16, P, xin, cin, dwf[k].w1, run));                                                 // d W1' += g1^T x_in
+      AIT_TRY(wg16(g1h, R16, P, xin, cin, dwf[k].w1, run, scr));                                            // d W1' += g1^T x_in
       if (k > 0) {
         // conv1's data gradient + the identity shortcut's, behind the previous block's ReLU
         AIT_TRY(mm16(g1h, R16, P, w16.w1t, cin, nullptr, gout, nullptr, xin, false, gnext, nullptr, run));
         bf16_t* t = gout; gout = gnext; gnext = t;
       } else {
-        AIT_TRY(wg16(gout, R16, E, xin, cin, dwf[k].wd, run));                                              // projection shortcut
+        AIT_TRY(wg16(gout, R16, E, xin, cin, dwf[k].wd, run, scr));                                         // projection shortcut
         // (the gradient handed to the SK blocks in f32, rows of real maps only: dxt has d.R rows)
         AIT_TRY(mm16(gout, d.R, E, w16.wdt, cin, nullptr, nullptr, nullptr, nullptr, false, nullptr, dxt, run));
         AIT_TRY(mm16(g1h, d.R, P, w16.w1t, cin, nullptr, nullptr, dxt, nullptr, false, nullptr, dxt, run));  // (+=, in place)

@@ -60,7 +60,8 @@ _TAIL_FUSED = True
 _HEADS_KERNEL = True          # test hook: False = the two heads as torch nn.Linear calls (vendor GEMM)
 _TRUNK_BF16 = True            # test hook: False = the C4 trunk in f32 also in the bf16 configuration (round 4's cfg5)
 _AIT_OUT_BF16 = True          # test hook: False = the AIT's output stays f32 in the bf16 configuration (cast by the tail's entry)
-_TAIL_BF16_MIOPEN = True      # test hook: False = the library's (f32-storage) tail node also in the bf16 configuration
+_TAIL_BF16_MIOPEN = False     # test hook / A-B (scripts/ab_cfg5_tail.py): True = the bf16 configuration's proposal tail as the module
+                              # composition on MIOpen's bf16 convolutions (round 5) instead of the library's bf16-storage node
 _TOP_NHWC = True
 _PAIR_GRADS = True            # test hook: False = a bottleneck's two input gradients summed by autograd (an add kernel each)
 _BASE_NHWC = True
@@ -830,7 +831,7 @@ class _fasterRCNN(nn.Module):
         num_props = rois.size(1)
 
         props_feat = self.RCNN_roi_align(non_img, rois.view(-1, 5))          # [bs*P, 1024, 7, 7]
-        # (bf16 configuration: the tail below computes on bf16 tensors -- the AIT hands its output over in bf16, sizes permitting)
+        # (A/B hook only: the MIOpen tail computes on bf16 tensors -- the AIT then hands its output over in bf16, sizes permitting)
         tail16 = bool(_TAIL_BF16_MIOPEN and _lib.BF16_PRODUCTS and props_feat.is_cuda and (1 if _SK_FULL else self._top_stride()) == 2)
         self.transformer.out_bf16 = tail16 and _AIT_OUT_BF16
         props_feat = self.transformer(x_props=props_feat, x_query=non_qry)   # [bs*P, 1024, 8, 8]
@@ -843,10 +844,9 @@ class _fasterRCNN(nn.Module):
         sk_stride = 1 if _SK_FULL else self._top_stride()
         c_att = None
         if tail16:
-            # the bf16 configuration (BASELINE configs[4]): the proposal tail as the module composition on MIOpen with bf16
-            # tensors, like the trunk (frozen-BN passes: ait_bn_act_*_bf16) -- the library's tail node (ait_tail_*) stores
-            # f32 and multiplies bf16-rounded operands at 250-430 TFLOP/s; MIOpen's bf16 convolutions are 4.6 ms/step faster
-            # at cfg5 (77.0 -> 72.5 ms, profiles/r05_trunk_bf16.txt).  The f32 configurations keep the library's node.
+            # (A/B hook _TAIL_BF16_MIOPEN: the bf16 configuration's proposal tail as the module composition on MIOpen with bf16
+            # tensors, like the trunk -- round 5's path.  The product path is the branch below: ait_tail_* keeps layer4 on bf16
+            # storage under AIT_CTX_BF16, csrc/tail.hip, at the same step time: profiles/r06_cfg5_tail_on_library.txt)
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 xp = props_feat.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
                 xq = non_qry.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)

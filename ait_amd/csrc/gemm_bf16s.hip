@@ -267,7 +267,7 @@ struct TnArgs {
   const unsigned short* B;      // [R, No] (pitch ldb)
   float* C;                     // [Mo, No] (pitch ldc), accumulated
   float* partials;              // PARTIAL: [splits][Mo][No] scratch, every element written once (no atomics); reduced afterwards
-  int Mo, No, R, splits, k_per_split;
+  int Mo, No, R, splits;        // the R / BK slabs of the reduction are cut into `splits` ranges that differ by at most one slab
   long long lda, ldb, ldc;
   Conv cv;                      // CONV: B is a channels-last map gathered per window tap, No = taps * cin (column = (tap, channel))
 };
@@ -294,23 +294,44 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g)
   const int wm = (wave / T::WN) * 128, wn = (wave % T::WN) * 64;
   const int li = lane & 31, lk = lane >> 5;
   const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
-  const int slabs = g.k_per_split / BK;
-  // this workgroup's items: i = blockIdx.x, + gridDim.x, ...  (item = split-major: the tiles of one split are neighbours,
-  // so concurrently running workgroups read the same token rows: one pass of the operands through L2)
-  const int mine = (int)blockIdx.x < items ? (items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int slabs_all = g.R / BK, slabs_lo = slabs_all / g.splits, slabs_rem = slabs_all % g.splits;
+  // this workgroup's items.  The item list is split-major (the tiles of one K-range are neighbours: they read the same token
+  // rows) and every XCD owns a contiguous chunk of it, dealt round-robin to its workgroups (blocks b and b + 8 share an L2):
+  // the tiles that run side by side on an XCD share their A column slices and B column slices of ONE range in that L2.  Dealt
+  // over all workgroups instead (the other branch: round 5) the eight tiles of a 1024 x 512 gradient's range sit on eight
+  // different XCDs and every operand slice comes from memory once per tile.
+  constexpr bool kChunks = ait_lab::Knobs::tn_xcd_chunks;
+  const int per = (items + AIT_NXCD - 1) / AIT_NXCD, wg_per_xcd = (int)gridDim.x / AIT_NXCD;
+  const int xcd = (int)blockIdx.x % AIT_NXCD, j = (int)blockIdx.x / AIT_NXCD;
+  const int chunk_end = min(per, items - xcd * per);
+  const int mine = kChunks ? (j < chunk_end ? (chunk_end - j + wg_per_xcd - 1) / wg_per_xcd : 0)
+                           : ((int)blockIdx.x < items ? (items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0);
   if (mine <= 0) return;
-  const int total = mine * slabs;
-  auto item_of = [&](int i, int& m0, int& n0, int& k0) __attribute__((always_inline)) {
-    const int it = (int)blockIdx.x + i * (int)gridDim.x;
+  // item i of this workgroup: its tile, its K-range (first row k0, `cnt` slabs: the first slabs_rem ranges hold one more)
+  auto item_of = [&](int i, int& m0, int& n0, int& k0, int& cnt) __attribute__((always_inline)) -> int {
+    const int it = kChunks ? xcd * per + j + i * wg_per_xcd : (int)blockIdx.x + i * (int)gridDim.x;
     const int split = it / tiles, t = it % tiles;
     m0 = (t / tiles_n) * BM;
     n0 = (t % tiles_n) * BN;
-    k0 = split * g.k_per_split;
+    k0 = (split * slabs_lo + min(split, slabs_rem)) * BK;
+    cnt = slabs_lo + (split < slabs_rem ? 1 : 0);
+    return split;
   };
-  auto issue = [&](int s, int stage) __attribute__((always_inline)) {
-    int m0, n0, k0;
-    item_of(s / slabs, m0, n0, k0);
-    k0 += (s % slabs) * BK;
+  int total = 0;
+  for (int i = 0; i < mine; i++) {
+    int m0, n0, k0, cnt;
+    item_of(i, m0, n0, k0, cnt);
+    total += cnt;
+  }
+  // the loader walks the items' slabs in order: (item, slab within it) of the NEXT slab to request
+  int iss_item = 0, iss_slab = 0, iss_m0, iss_n0, iss_k0, iss_cnt;
+  item_of(0, iss_m0, iss_n0, iss_k0, iss_cnt);
+  auto issue = [&](int stage) __attribute__((always_inline)) {
+    const int m0 = iss_m0, n0 = iss_n0, k0 = iss_k0 + iss_slab * BK;
+    if (++iss_slab == iss_cnt) {
+      iss_slab = 0;
+      if (++iss_item < mine) item_of(iss_item, iss_m0, iss_n0, iss_k0, iss_cnt);
+    }
     int tap_dy = 0, tap_dx = 0, tap_c0 = 0;                    // CONV: the tile's columns lie inside one window tap
     if constexpr (CONV) {
       const int tap = n0 >> g.cv.cin_shift;
@@ -361,13 +382,15 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g)
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 #pragma unroll
   for (int i = 0; i < NS - 1; i++)
-    if (i < total) issue(i, i);
+    if (i < total) issue(i);
   int done = 0, ti = 0, stage = 0;
+  int cur_m0, cur_n0, cur_k0, cur_cnt;
+  int cur_split = item_of(0, cur_m0, cur_n0, cur_k0, cur_cnt);
   for (int s = 0; s < total; s++) {
     if (s + NS - 1 > total) wait_vm<0>();
     else wait_vm<(NS - 2) * T::LPW>();
     __builtin_amdgcn_s_barrier();
-    if (s + NS - 1 < total) issue(s + NS - 1, (stage + NS - 1) % NS);
+    if (s + NS - 1 < total) issue((stage + NS - 1) % NS);
     const unsigned char* sa = lds + stage * STAGE;
     const unsigned char* sb = sa + SLAB_A;
 #pragma unroll
@@ -383,9 +406,8 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g)
         for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
-    if (++done == slabs) {
-      int m0, n0, k0;
-      item_of(ti, m0, n0, k0);
+    if (++done == cur_cnt) {
+      const int m0 = cur_m0, n0 = cur_n0;
 #pragma unroll
       for (int a = 0; a < 4; a++) {
         const int row = m0 + wm + a * 32 + li;
@@ -395,7 +417,7 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g)
           for (int q = 0; q < 4; q++) {
             const int col = n0 + wn + b * 32 + 8 * q + 4 * lk;
             if constexpr (PARTIAL) {      // this K-range's tile, stored once (16-B stores); tn_reduce_kernel adds the ranges
-              float* dst = g.partials + ((size_t)(k0 / g.k_per_split) * g.Mo + row) * g.No + col;
+              float* dst = g.partials + ((size_t)cur_split * g.Mo + row) * g.No + col;
               *reinterpret_cast<float4*>(dst) =
                   make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
             } else {
@@ -408,7 +430,7 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g)
           }
       }
       done = 0;
-      ti++;
+      if (++ti < mine) cur_split = item_of(ti, cur_m0, cur_n0, cur_k0, cur_cnt);
       wait_vm<0>();       // (the atomics count like stores and may overtake the loads already requested: wait for everything once)
     }
   }
@@ -563,7 +585,14 @@ int launch_tn(const TnArgs& g, hipStream_t s) {
   const int slots = slots_of<T>(kern, memo);
   if (slots <= 0) return AIT_ELAUNCH;
   const long long items = (long long)(g.Mo / T::BM) * (g.No / T::BN) * g.splits;
-  const int grid = (int)(items < slots ? items : slots);
+  int grid = (int)(items < slots ? items : slots);
+  if (ait_lab::Knobs::tn_xcd_chunks) {      // whole XCD sets of workgroups, no more per XCD than its chunk of the items
+    const long long per = (items + AIT_NXCD - 1) / AIT_NXCD;
+    long long w = slots / AIT_NXCD;
+    if (w > per) w = per;
+    if (w < 1) w = 1;
+    grid = (int)w * AIT_NXCD;
+  }
   hipLaunchKernelGGL((gemm_bf16s_tn_kernel<T, PARTIAL, CONV>), dim3(grid), dim3(T::NT), T::LDS, s, g);
   AIT_CHECK_LAUNCH();
   if (PARTIAL) {
@@ -664,10 +693,11 @@ int ait_bf16s::wgrad(const Wgrad& p, const ait_launch_ctx* ctx, void* stream) {
       p.ldc < No || !al16(p.A) || !al16(p.B) || !al16(p.C))
     return AIT_EUNSUPPORTED;
   int split_k = p.split_k < 1 ? 1 : p.split_k;
-  if ((R % split_k) || ((R / split_k) % Small::BK)) return AIT_EUNSUPPORTED;      // whole 32-row slabs per split
+  // whole 32-row slabs, at least one per range; the ranges need not be equal (they differ by at most one slab)
+  if ((R % Small::BK) || R / Small::BK < split_k) return AIT_EUNSUPPORTED;
   TnArgs g;
   g.A = static_cast<const unsigned short*>(p.A); g.B = static_cast<const unsigned short*>(p.B); g.C = p.C;
-  g.Mo = Mo; g.No = No; g.R = R; g.splits = split_k; g.k_per_split = R / split_k;
+  g.Mo = Mo; g.No = No; g.R = R; g.splits = split_k;
   g.lda = p.lda; g.ldb = p.ldb; g.ldc = p.ldc;
   g.cv = p.cv;
   // with scratch for one partial tile set per K-range the ranges are stored once and added by a second small launch
@@ -681,7 +711,7 @@ int ait_bf16s::wgrad(const Wgrad& p, const ait_launch_ctx* ctx, void* stream) {
   // (CONV: a tile's columns lie inside one tap -- cin is a power of two >= 64, so 128- and 256-wide tiles need cin >= that)
   const bool fits_big = !p.cv.on || (1 << p.cv.cin_shift) >= Big::BN;
   if (p.cv.on && (1 << p.cv.cin_shift) < Small::BN) return AIT_EUNSUPPORTED;
-  const bool big = kUseBig && fits_big && (No % Big::BN) == 0 && (g.k_per_split % Big::BK) == 0 &&
+  const bool big = kUseBig && fits_big && (No % Big::BN) == 0 && (R % Big::BK) == 0 && R / Big::BK >= split_k &&
                    (long long)(Mo / Big::BM) * (No / Big::BN) * split_k >= 192;
   if (p.cv.on) {
     if (use_partials) return big ? launch_tn<Big, true, true>(g, s) : launch_tn<Small, true, true>(g, s);

@@ -19,6 +19,8 @@ struct Product {
   static constexpr int bf16s_big_min_k = 512;
   // gemm_bf16s.hip: weight gradients always through f32 atomics (never the stored K-range partials)
   static constexpr bool tn_atomics = false;
+  // gemm_bf16s.hip: the weight-gradient kernel's items in one contiguous chunk per XCD (false: dealt over all workgroups)
+  static constexpr bool tn_xcd_chunks = true;
   // gemm_p3.hip: the fewest 256 x 256 tiles the pre-split-weight kernel takes
   static constexpr int p3_min_tiles = 128;
   // mha_fused_bwd.hip: which of the attention tile's backward products run in the split form (1 dV, 2 dPd, 4 dQ, 8 dK)

@@ -175,8 +175,8 @@ inline unsigned l4_grid(long long n4) {
 
 // ---- layer4 on bf16 STORAGE (the bf16 configuration, BASELINE configs[4]: cfgs/res101.yml) ----------------------------------
 // Under AIT_CTX_BF16 every activation and gradient of layer4 -- its input (the SK blocks' result), a1 / a2 / o of every
-// bottleneck, the four gradient buffers -- is HELD in bf16 (map-major rows, padded to a multiple of 1024 so that the weight
-// gradients cut into 16 equal ranges of whole 64-row slabs) and the folded weights are converted once per call, both
+// bottleneck, the four gradient buffers -- is HELD in bf16 (map-major rows, padded to a multiple of 256: whole row tiles and
+// whole 64-row slabs of the weight gradients' reduction) and the folded weights are converted once per call, both
 // orientations: the products run on gemm_bf16s.hip's kernels (bf16 operands from memory, 2-byte results), the 3x3 convolutions
 // through their window gather.  Same buffers: every bf16 tensor lives in the first half of the f32 tensor it replaces.  The SK
 // blocks keep their f32 tensors (their products round to bf16 in registers): their closing pass writes layer4's input in
@@ -418,12 +418,12 @@ int sk_forward(const float* x, int n, int n_zero, int map0, const Dims& d, const
 // ---- layer4 on bf16 storage: when, its row count, its views of the buffers ---------------------------------------------
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 inline bool tail16_on(const ait_launch_ctx* ctx, const Dims& d) {
-  // (at least 1024 real rows: the 1024-row padding then fits the f32 buffers it lives in; the convolution gather wants a
-  // power-of-two channel count)
+  // (from 1024 rows -- below that the launches are latency-bound either way and the f32 form keeps its position-major
+  // tricks; the convolution gather wants a power-of-two channel count)
   return kTail16 && ctx && (ctx->flags & AIT_CTX_BF16) && !(ctx->flags & AIT_CTX_NATIVE_F32) && d.Rp + d.Rq >= 1024 &&
          pow2(d.P) && d.P >= 256;
 }
-inline long long rows16(const Dims& d) { return (long long)align_up((size_t)(d.Rp + d.Rq), 1024); }
+inline long long rows16(const Dims& d) { return (long long)align_up((size_t)(d.Rp + d.Rq), 256); }
 struct W16 { bf16_t *w1, *w1t, *w2, *w2d, *w3, *w3t, *wd, *wdt; };
 inline W16 weights16(const BlockW& f, const Dims& d, int k) {
   const size_t cin = k == 0 ? d.C : d.E, P = d.P, E = d.E;
@@ -456,7 +456,14 @@ struct Scratch { void* p; size_t bytes; };
 inline int wg16(const bf16_t* dy, long long R, int N_out, const bf16_t* x, int K_in, float* dw, const Run& r, const Scratch& scratch,
                 const ait_bf16s::Conv* cv = nullptr) {
   ait_bf16s::Wgrad p{};
-  p.A = dy; p.B = x; p.C = dw; p.Mo = N_out; p.No = cv ? 9 * K_in : K_in; p.R = (int)R; p.split_k = 16;
+  p.A = dy; p.B = x; p.C = dw; p.Mo = N_out; p.No = cv ? 9 * K_in : K_in; p.R = (int)R;
+  // K-ranges: as many as make tiles x ranges ONE round of the 256 workgroup slots of the 256 x 256 tile (7 for the 36 tiles
+  // of the 3x3 gradient, 16 / 32 / 8 for the 1x1 ones); the kernel takes ranges that differ by a slab
+  const int tiles = (p.Mo / 256) * (p.No / 256);
+  int sp = tiles > 0 ? 256 / tiles : 1;
+  sp = sp < 1 ? 1 : (sp > 64 ? 64 : sp);
+  if (sp > R / 64) sp = (int)(R / 64) > 0 ? (int)(R / 64) : 1;
+  p.split_k = sp;
   p.lda = N_out; p.ldb = K_in; p.ldc = p.No;
   p.partials = scratch.p; p.partials_bytes = scratch.bytes;
   if (cv) p.cv = *cv;

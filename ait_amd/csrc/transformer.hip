@@ -129,6 +129,13 @@ inline int wgrad(const float* dy, long long M, int N_out, const float* x, int K_
 inline int bf16_tn_split(int Mo, int No, long long R, size_t scratch_bytes) {
   const long long tiles = (long long)(Mo / 256) * (No % 256 == 0 ? No / 256 : No / 128);
   if (tiles <= 0 || R <= 0) return 0;
+  // ONE round of the 256 x 256 tile's 256 slots where that is possible (the kernel takes ranges that differ by one 64-row slab:
+  // 21 ranges for the 12 tiles of W_qkv's gradient instead of 32 -- a round and a half)
+  if (No % 256 == 0 && R % 64 == 0) {
+    int sp = (int)(256 / tiles);
+    sp = sp < 1 ? 1 : (sp > 64 ? 64 : sp);
+    if (R / 64 >= sp && (sp == 1 || R / sp >= 512) && (sp <= 16 || (size_t)sp * Mo * No * sizeof(float) <= scratch_bytes)) return sp;
+  }
   int want = 1;
   while (want < 64 && tiles * want < 256) want *= 2;
   for (int sp = want; sp >= 1; sp /= 2) {

@@ -404,9 +404,10 @@ int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, const void
                    const void* gate16, long long ldr, int flags, const ait_launch_ctx* ctx, void* stream);
 /* ... and the weight-gradient product of that mode: C[Mo, No] (f32, pitch ldc) += sum over the R token rows of
  * A[r, m] * B[r, n], A = bf16 [R, Mo] (the output gradient), B = bf16 [R, No] (the layer's input), both row-major with
- * the REDUCTION index outermost (pitches in elements, multiples of 8).  Mo % 256 == 0, No % 128 == 0; the rows are cut into
- * split_k equal ranges of whole 32-row slabs (R % split_k == 0, (R / split_k) % 32 == 0: pad the operands with zero rows)
- * whose partial tiles are ADDED to C -- zero C for a plain gradient (SubLayers.py:181-183's weights).  `partials`
+ * the REDUCTION index outermost (pitches in elements, multiples of 8).  Mo % 256 == 0, No % 128 == 0; the rows are whole 32-row
+ * slabs (R % 32 == 0: pad the operands with zero rows), cut into split_k ranges of slabs that differ by at most one slab (ABI v8;
+ * before: equal ranges only) -- at most one range per slab -- whose partial tiles are ADDED to C: zero C for a plain gradient
+ * (SubLayers.py:181-183's weights).  `partials`
  * (optional, caller-owned, split_k * Mo * No floats, 16-byte aligned): the ranges' tiles are stored there once and added to
  * C in range order by a second small launch (bit-reproducible); NULL or too small: f32 atomics (order-dependent rounding). */
 int ait_gemm_bf16s_tn(int Mo, int No, int R, const void* A, long long lda, const void* B, long long ldb, float* C,
@@ -791,7 +792,7 @@ size_t ait_tail_saved_bytes(int bp, int bs, int channels, int planes, int n_bloc
  * AIT_EINVAL if its own ctx implies the other order or the word is not one the forward reported. */
 #define AIT_TAIL_SAVED_PM 1u
 /* ... and (ABI v8) whether layer4's tensors are held in bf16: under AIT_CTX_BF16, from 1024 rows (64 maps) and for planes a
- * power of two >= 256, every activation and gradient of layer4 is STORED in bf16 (map-major rows padded to a multiple of 1024,
+ * power of two >= 256, every activation and gradient of layer4 is STORED in bf16 (map-major rows padded to a multiple of 256,
  * inside the same `saved` / `workspace` sizes) and its products read bf16 operands from memory (ait_gemm_bf16s / _tn, the 3x3
  * convolutions through ait_conv_*_bf16s' window gather; folded weights converted once per call).  The SK blocks keep f32 tensors
  * (operands rounded in registers).  Smaller calls under AIT_CTX_BF16: f32 tensors, operands rounded in registers. */

@@ -932,7 +932,9 @@ def test_round5_entry_points_check_their_arguments():
     c32 = torch.zeros(256, 256, device="cuda")
     # weight-gradient product: rows must split into whole 32-row slabs; outputs in whole 256 x 128 tiles
     big = torch.zeros(96, 256, device="cuda", dtype=torch.bfloat16)
-    assert L.ait_gemm_bf16s_tn(256, 256, 96, vp(big), 256, vp(big), 256, vp(c32), 256, 2, None, 0, None, st) == EUNSUPPORTED
+    assert L.ait_gemm_bf16s_tn(256, 256, 80, vp(big), 256, vp(big), 256, vp(c32), 256, 1, None, 0, None, st) == EUNSUPPORTED   # not whole slabs
+    assert L.ait_gemm_bf16s_tn(256, 256, 96, vp(big), 256, vp(big), 256, vp(c32), 256, 4, None, 0, None, st) == EUNSUPPORTED   # 3 slabs, 4 ranges
+    assert L.ait_gemm_bf16s_tn(256, 256, 96, vp(big), 256, vp(big), 256, vp(c32), 256, 2, None, 0, None, st) == OK             # ranges of 2 + 1 slabs
     assert L.ait_gemm_bf16s_tn(200, 256, 96, vp(big), 256, vp(big), 256, vp(c32), 256, 1, None, 0, None, st) == EUNSUPPORTED
     assert L.ait_gemm_bf16s_tn(256, 256, 96, vp(big), 256, vp(big), 256, vp(c32), 256, 1, None, 0, None, st) == OK
     # NT product: N in whole 128-column tiles, K in whole 32-deep slabs, at least one result

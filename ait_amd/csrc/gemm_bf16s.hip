@@ -28,6 +28,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // Tile families (every wave owns 128 x 64 outputs = 4 x 2 MFMA blocks, 128 accumulator registers):
@@ -69,6 +70,11 @@ struct Args {
   long long lda, ldb, ldc32, ldc16, ldr, ldg;
   int relu;
   Conv cv;                    // CONV kernels: A is a channels-last map, the reduction runs over (tap, channel)
+  // CUT kernels (the last, under-filled round of tiles cut along K): pieces per leftover tile, scratch for one partial tile per
+  // workgroup, one arrival counter per leftover tile (zero between launches)
+  int cut_parts;
+  float* cut_ws;
+  unsigned* cut_cnt;
 };
 enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_GATE = 2, EPI_RESGATE = 3 };
 
@@ -103,33 +109,62 @@ __device__ __forceinline__ void wait_vm() {
 template <int CH>
 __device__ __forceinline__ int swz(int r) { return CH == 4 ? (r >> 2) & 3 : r & 7; }
 
-template <class T, int EPI, bool CONV>
+// CUT: the launch's tiles are `full` whole rounds of the grid plus L <= grid / 2 leftover tiles.  Whole tiles run as ever; each
+// leftover tile is cut along K into cut_parts pieces, one per workgroup (piece ids dealt so that the pieces of a tile sit on one
+// XCD): a workgroup stores its piece's partial tile write-through into its slot of cut_ws, counts itself in on the tile's
+// arrival counter, and the LAST to arrive -- whoever that is -- adds all pieces in piece order (its own read back like the
+// others: one order, bit-reproducible), runs the epilogue and zeroes the counter.  Nobody waits for anybody.
+template <class T, int EPI, bool CONV, bool CUT>
 __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {      // (two waves per SIMD: <= 256 VGPRs)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NS = T::NS, ROWB = T::ROWB, CH = T::CH, RG = T::RG, STAGE = T::STAGE;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tiles_n = g.N / BN, tiles_m = (g.M + BM - 1) / BM, tiles = tiles_m * tiles_n;
-  const int per = (tiles + AIT_NXCD - 1) / AIT_NXCD, wg_per_xcd = gridDim.x / AIT_NXCD;
+  const int wg_per_xcd = gridDim.x / AIT_NXCD;
   const int xcd = blockIdx.x % AIT_NXCD, j = blockIdx.x / AIT_NXCD;
-  const int chunk_end = min(per, tiles - xcd * per);
-  const int mine = j < chunk_end ? (chunk_end - j + wg_per_xcd - 1) / wg_per_xcd : 0;
-  if (mine <= 0) return;
+  const int slabs = g.K / BK;
+  int per, mine, total;
+  int pc_tile = -1, pc_s0 = 0, pc_cnt = 0, pc_id = 0, pc_lt = 0;      // CUT: this workgroup's piece of a leftover tile
+  if constexpr (CUT) {
+    const int full = (tiles / (int)gridDim.x) * (int)gridDim.x, left = tiles - full;
+    per = full / AIT_NXCD;
+    mine = full / (int)gridDim.x;
+    pc_id = xcd * wg_per_xcd + j;
+    if (pc_id < left * g.cut_parts) {
+      pc_lt = pc_id / g.cut_parts;
+      const int part = pc_id - pc_lt * g.cut_parts;
+      pc_tile = full + pc_lt;
+      pc_s0 = part * slabs / g.cut_parts;
+      pc_cnt = (part + 1) * slabs / g.cut_parts - pc_s0;
+    }
+    total = mine * slabs + pc_cnt;
+    if (total <= 0) return;
+  } else {
+    per = (tiles + AIT_NXCD - 1) / AIT_NXCD;
+    const int chunk_end = min(per, tiles - xcd * per);
+    mine = j < chunk_end ? (chunk_end - j + wg_per_xcd - 1) / wg_per_xcd : 0;
+    if (mine <= 0) return;
+    total = mine * slabs;
+  }
   const int wm = (wave / T::WN) * 128, wn = (wave % T::WN) * 64;
   const int li = lane & 31, lk = lane >> 5;
-  const int slabs = g.K / BK, total = mine * slabs;
   const int rr = lane / CH, pos = lane % CH;                          // row within a granule, chunk POSITION in LDS
   const int cfetch = pos ^ swz<CH>(rr);                               // the 16-B chunk of the row that lands there
   const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
   auto tile_origin = [&](int i, int& m0, int& n0) __attribute__((always_inline)) {
-    const int t = xcd * per + j + i * wg_per_xcd;
+    const int t = (CUT && i >= mine) ? pc_tile : xcd * per + j + i * wg_per_xcd;
     m0 = (t / tiles_n) * BM;
     n0 = (t % tiles_n) * BN;
   };
   // loader: granule q of a slab is RG operand rows (A's BM / RG granules first, then B's); wave w takes q = w, w + NW, ...
   auto issue = [&](int s, int stage) __attribute__((always_inline)) {
     int m0, n0;
-    tile_origin(s / slabs, m0, n0);
-    const int k0 = (s % slabs) * BK;
+    int unit = s / slabs, ks = s - unit * slabs;
+    if constexpr (CUT) {
+      if (s >= mine * slabs) { unit = mine; ks = pc_s0 + s - mine * slabs; }
+    }
+    tile_origin(unit, m0, n0);
+    const int k0 = ks * BK;
     int tap_dy = 0, tap_dx = 0, tap_c0 = 0;                          // CONV: the slab's window tap and first channel
     if constexpr (CONV) {
       const int tap = k0 >> g.cv.cin_shift;
@@ -199,7 +234,65 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {   
         for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
-    if (++done == slabs) {
+    bool tile_done = ++done == slabs;
+    bool finish = true;
+    if constexpr (CUT) {
+      if (ti == mine) {
+        tile_done = done == pc_cnt;
+        if (tile_done) {                     // the piece is this workgroup's last unit: publish it, count in, maybe finish the tile
+          constexpr int NQ = 4 * 2 * 4;
+          {
+            __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(g.cut_ws + (size_t)pc_id * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+              for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                  u32x4 v;
+                  v.x = __float_as_uint(acc[a][b][4 * q]); v.y = __float_as_uint(acc[a][b][4 * q + 1]);
+                  v.z = __float_as_uint(acc[a][b][4 * q + 2]); v.w = __float_as_uint(acc[a][b][4 * q + 3]);
+                  __builtin_amdgcn_raw_buffer_store_b128(v, ws, (int)threadIdx.x * 16, ((a * 2 + b) * 4 + q) * T::NT * 16, 16);
+                }
+          }
+          wait_vm<0>();                      // every storing wave drains (per-XCD L2s are not coherent: sc1 stores, sc1 loads)
+          __builtin_amdgcn_s_barrier();
+          unsigned* flag = reinterpret_cast<unsigned*>(lds);
+          if (threadIdx.x == 0)
+            *flag = __hip_atomic_fetch_add(g.cut_cnt + pc_lt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __syncthreads();
+          finish = (int)*flag == g.cut_parts - 1;
+          if (finish) {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+              for (int b = 0; b < 2; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+            for (int p = 0; p < g.cut_parts; p++) {
+              __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(
+                  g.cut_ws + (size_t)(pc_lt * g.cut_parts + p) * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+              for (int q0 = 0; q0 < NQ; q0 += 16) {
+                u32x4 t[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                  t[i] = __builtin_amdgcn_raw_buffer_load_b128(ws, (int)threadIdx.x * 16, (q0 + i) * T::NT * 16, 16);
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                  const int idx = q0 + i, ab = idx >> 2, q = idx & 3;
+                  f32x16& d = acc[ab / 2][ab % 2];
+                  d[4 * q] += __uint_as_float(t[i].x); d[4 * q + 1] += __uint_as_float(t[i].y);
+                  d[4 * q + 2] += __uint_as_float(t[i].z); d[4 * q + 3] += __uint_as_float(t[i].w);
+                }
+              }
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(g.cut_cnt + pc_lt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
+    if (tile_done && finish) {
       int m0, n0;
       tile_origin(ti, m0, n0);
 #pragma unroll
@@ -539,27 +632,59 @@ inline int slots_of(const void* kern, int& memo) {
   return memo;
 }
 
+// The last round's cut (CUT kernels; the 256 x 256 tile only -- one workgroup per CU; lab knob bf16s_cut, OFF in the product):
+// when the tiles are whole rounds of the grid plus at most half a round, and the caller's scheduler scratch
+// (ait_launch_ctx::sched_ws, the one the f32 kernel's stream-K uses: launches ordered on one stream) holds a partial tile per
+// workgroup.  4096 x 16 + 8 x 16 rows of cfg5's layer4 are 256.5 row tiles: every 512-column product runs a third round for two
+// tiles.  Measured: 389 us with the cut against 364 for exactly two rounds (the model: pieces 27 us + six gathers 30 us + the
+// epilogue) -- and in the step no faster than without it (same-box A/B 30.5 vs 30.5 ms of products): the lone tiles of a third
+// round have the memory system to themselves and finish in ~0.6 of a tile-time.
 template <class T, int EPI, bool CONV>
-int launch(const Args& g, hipStream_t s) {
-  const void* kern = reinterpret_cast<const void*>(gemm_bf16s_kernel<T, EPI, CONV>);
+int launch(Args g, const ait_launch_ctx* ctx, hipStream_t s) {
+  const void* kern = reinterpret_cast<const void*>(gemm_bf16s_kernel<T, EPI, CONV, false>);
   static int memo = 0;
   const int slots = slots_of<T>(kern, memo);
   if (slots <= 0) return AIT_ELAUNCH;
   const int tiles = ((g.M + T::BM - 1) / T::BM) * (g.N / T::BN);
+  if constexpr (T::BN == 256) {
+    if (ait_lab::Knobs::bf16s_cut && ctx && ctx->sched_ws && (slots % AIT_NXCD) == 0 && tiles > slots) {
+      const int left = tiles % slots, slabs = g.K / T::BK;
+      // pieces per leftover tile: a piece costs its slabs (~2.2 us each), the finishing workgroup ~5 us per piece it gathers (two
+      // dependent round trips of write-through data) -- the sum is least near sqrt(0.44 slabs): 6 pieces for 72 slabs, 4 for 32
+      int parts = left > 0 ? slots / left : 0;
+      int best = 2;
+      while ((best + 1) * (best + 1) * 100 <= 44 * slabs + 100 * best) best++;      // (best^2 ~ 0.44 slabs, rounded)
+      if (parts > best) parts = best;
+      if (parts > slabs / 2) parts = slabs / 2;
+      const size_t need = ait_ws::kCtlBytes + (size_t)slots * T::BM * T::BN * sizeof(float);
+      if (parts >= 2 && left <= 256 && ctx->sched_ws_bytes >= need) {
+        const void* kcut = reinterpret_cast<const void*>(gemm_bf16s_kernel<T, EPI, CONV, true>);
+        static int memo_cut = 0;
+        if (slots_of<T>(kcut, memo_cut) == slots) {
+          g.cut_parts = parts;
+          g.cut_ws = reinterpret_cast<float*>(static_cast<char*>(ctx->sched_ws) + ait_ws::kCtlBytes);
+          g.cut_cnt = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->sched_ws) + ait_ws::kBf16CutCounters);
+          hipLaunchKernelGGL((gemm_bf16s_kernel<T, EPI, CONV, true>), dim3(slots), dim3(T::NT), T::LDS, s, g);
+          AIT_CHECK_LAUNCH();
+          return AIT_OK;
+        }
+      }
+    }
+  }
   const int per = (tiles + AIT_NXCD - 1) / AIT_NXCD;
   int w = slots / AIT_NXCD;
   if (w > per) w = per;
   if (w < 1) w = 1;
-  hipLaunchKernelGGL((gemm_bf16s_kernel<T, EPI, CONV>), dim3(w * AIT_NXCD), dim3(T::NT), T::LDS, s, g);
+  hipLaunchKernelGGL((gemm_bf16s_kernel<T, EPI, CONV, false>), dim3(w * AIT_NXCD), dim3(T::NT), T::LDS, s, g);
   AIT_CHECK_LAUNCH();
   return AIT_OK;
 }
 template <class T, bool CONV>
-int launch_epi(const Args& g, bool gate, hipStream_t s) {
+int launch_epi(const Args& g, bool gate, const ait_launch_ctx* ctx, hipStream_t s) {
   const bool res = g.residual || g.res16;
-  if (gate) return res && g.gate16 ? launch<T, EPI_RESGATE, CONV>(g, s) : launch<T, EPI_GATE, CONV>(g, s);
-  if (res) return launch<T, EPI_RES, CONV>(g, s);
-  return launch<T, EPI_PLAIN, CONV>(g, s);
+  if (gate) return res && g.gate16 ? launch<T, EPI_RESGATE, CONV>(g, ctx, s) : launch<T, EPI_GATE, CONV>(g, ctx, s);
+  if (res) return launch<T, EPI_RES, CONV>(g, ctx, s);
+  return launch<T, EPI_PLAIN, CONV>(g, ctx, s);
 }
 // C[m, n] += sum over the K-ranges of partials[s][m][n]  (16-B loads; in range order: reproducible)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partials, int splits, int Mo, int No,
@@ -659,13 +784,14 @@ int ait_bf16s::gemm(const Gemm& p, const ait_launch_ctx* ctx, void* stream) {
   g.ldg = p.gate16 ? p.ldg : p.ldr;
   g.relu = p.relu ? 1 : 0;
   g.cv = p.cv;
+  g.cut_parts = 0; g.cut_ws = nullptr; g.cut_cnt = nullptr;
   hipStream_t s = ait_stream(stream);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K, s, M, N, K, 0, 1, 1);
   // long reductions on the 256 x 256 x 64 tile (at least a round of them), the 512-deep products on the 256 x 128 x 32 one
   const long long big_tiles = (long long)((M + Big::BM - 1) / Big::BM) * (N / Big::BN);
   const bool big = kUseBig && K >= ait_lab::Knobs::bf16s_big_min_k && (K % Big::BK) == 0 && (N % Big::BN) == 0 && big_tiles >= 192;
-  if (p.cv.on) return big ? launch_epi<Big, true>(g, p.gate, s) : launch_epi<Small, true>(g, p.gate, s);
-  return big ? launch_epi<Big, false>(g, p.gate, s) : launch_epi<Small, false>(g, p.gate, s);
+  if (p.cv.on) return big ? launch_epi<Big, true>(g, p.gate, ctx, s) : launch_epi<Small, true>(g, p.gate, ctx, s);
+  return big ? launch_epi<Big, false>(g, p.gate, ctx, s) : launch_epi<Small, false>(g, p.gate, ctx, s);
 }
 
 AIT_API int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, float* C32,

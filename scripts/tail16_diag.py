@@ -2,7 +2,8 @@
 import sys
 import torch
 import torch.nn.functional as F
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ait_amd.faster_rcnn as fr
 from ait_amd import ops
 

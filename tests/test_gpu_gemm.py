@@ -686,8 +686,12 @@ def test_every_epilogue_and_tile_family_the_step_launches_is_reproducible():
 
 
 @pytest.mark.gpu
+# (12290 ..., 50000 ...: the 256 x 256 x 64 tile; the last three: its under-filled last round cut along K -- 257 row tiles x 2
+# column tiles = two rounds of 256 + 2 tiles in 4 pieces each; 258 x 8 = eight rounds + 16 tiles in 2 pieces, ragged rows; 291 x 4 =
+# four rounds + 140 tiles: more than half a round, no cut)
 @pytest.mark.parametrize("M,N,K", [(256, 128, 32), (1000, 256, 64), (4097, 512, 512), (19200, 2048, 512), (777, 1536, 2048),
-                                   (12290, 1024, 1024), (50000, 512, 2048)])       # (the last two: the 256 x 256 x 64 tile)
+                                   (12290, 1024, 1024), (50000, 512, 2048), (65792, 512, 1024), (65900, 2048, 512),
+                                   (74400, 1024, 512)])
 def test_bf16_storage_gemm_against_float64(M, N, K):
     """ait_gemm_bf16s (csrc/gemm_bf16s.hip): bf16 operands stored in memory, f32 accumulate; against the float64 product of
     the SAME bf16 values (the only error left is the f32 accumulation), every epilogue: bias, ReLU, residual, the two
@@ -704,6 +708,8 @@ def test_bf16_storage_gemm_against_float64(M, N, K):
     y32, y16 = ops.gemm_bf16s(a16, b16, out32=guard[:M], want16=True)
     assert float(((y32.double() - ref).abs() / mag).max()) < 2e-6 and bool((guard[M:] == 7.0).all())
     assert torch.equal(y16, y32.to(torch.bfloat16))
+    again, _ = ops.gemm_bf16s(a16, b16)
+    assert torch.equal(again, y32)                                           # (also where a tile's pieces meet: fixed order)
     y, _ = ops.gemm_bf16s(a16, b16, bias=bias, relu=True)
     assert float(((y.double() - (ref + bias.double()).clamp_min(0)).abs() / (mag + 1)).max()) < 2e-6
     y, _ = ops.gemm_bf16s(a16, b16, bias=bias, residual=res)
@@ -714,7 +720,10 @@ def test_bf16_storage_gemm_against_float64(M, N, K):
     _, y = ops.gemm_bf16s(a16, b16, gate16=g16, mask_pos=True, want32=False, want16=True)
     want = (ref * (g16.float() > 0)).float().to(torch.bfloat16)
     assert float((y.float() - want.float()).abs().max()) <= 2.0 ** -7 * float(want.float().abs().max())
-    assert bool(((y.float() == 0) == ((g16.float() <= 0) | (want.float() == 0))).all())
+    # (zero exactly where the gate is shut; a sum whose float64 value is ~1e-9 of its terms may also be an exact 0 in f32 -- a
+    # handful of elements among 1e8)
+    assert int(((y.float() == 0) != ((g16.float() <= 0) | (want.float() == 0))).sum()) <= 4
+    assert bool((y.float()[g16.float() <= 0] == 0).all())
 
 
 @pytest.mark.gpu
@@ -766,6 +775,7 @@ def test_bf16_storage_weight_gradient_product_against_float64(R, Mo, No, sk):
 @pytest.mark.parametrize("n,hw,k,cin,cout", [(8, 4, 3, 512, 512),       # layer4's 3x3 on 4x4 maps (256 x 128 x 32 tile: one row tile)
                                               (520, 4, 3, 512, 512),     # ... several row tiles per workgroup
                                               (3100, 4, 3, 512, 512),    # ... enough of them for the 256 x 256 x 64 tile
+                                              (4112, 4, 3, 512, 512),    # ... 257 row tiles: the last round's two tiles cut into 18 pieces
                                               (37, 8, 3, 128, 256),      # ragged row count, 8x8 maps
                                               (16, 4, 1, 256, 128),      # a 1x1 window is the plain product
                                               (6, 8, 5, 64, 128)])       # 5x5 window, 64-channel taps

@@ -424,12 +424,6 @@ inline bool tail16_on(const ait_launch_ctx* ctx, const Dims& d) {
          pow2(d.P) && d.P >= 256;
 }
 inline long long rows16(const Dims& d) { return (long long)align_up((size_t)(d.Rp + d.Rq), 256); }
-// rows of a product's first launch (mm16): none -- one launch per product.  (Measured at cfg5, 4096 proposal + 8 query maps =
-// 256.5 row tiles: the proposals' 256 tiles alone are whole rounds of the persistent kernel's workgroups -- the 4608-deep
-// convolutions run at 967 instead of 679 TFLOP/s, every 512-column product loses its third round of two tiles, -1.6 ms -- but
-// the query maps' twenty products on their own are serial K loops on one or two workgroups, 33-163 us each, +1.6 ms: a wash.
-// What would collect the 1.6 ms is a stream-K cut of the bf16 kernel's last round, as the f32 kernel has; not built.)
-inline long long head16(const Dims&) { return 0; }
 struct W16 { bf16_t *w1, *w1t, *w2, *w2d, *w3, *w3t, *wd, *wdt; };
 inline W16 weights16(const BlockW& f, const Dims& d, int k) {
   const size_t cin = k == 0 ? d.C : d.E, P = d.P, E = d.E;
@@ -445,17 +439,11 @@ inline ait_bf16s::Conv l4_conv16(const float* zeros, int channels) {
 }
 // y16 [M, N] = relu?(x16 [M, K] W16[N, K]^T + bias (+ res16)) (kept where gate16 > 0), or the same into y32; conv: through the 3x3 window
 inline int mm16(const bf16_t* x, long long M, int K, const bf16_t* w, int N, const float* bias, const bf16_t* res16, const float* res32,
-                const bf16_t* gate16, bool relu, bf16_t* y16, float* y32, const Run& r, const ait_bf16s::Conv* cv = nullptr,
-                long long head = 0) {
-  // `head` rows first, the rest in a second launch: the proposals' 4096 x 16 rows are exactly 256 row tiles -- whole rounds of
-  // the persistent kernel's 256 workgroups -- and the handful of query maps behind them would add a THIRD round of two tiles
-  // to every 512-column product (a third of its time); on their own they are one small launch.  (Rows are whole maps.)
-  if (head > 0 && head < M) {
-    const long long lda = cv ? (1ll << cv->cin_shift) : K;
-    AIT_TRY(mm16(x, head, K, w, N, bias, res16, res32, gate16, relu, y16, y32, r, cv));
-    return mm16(x + head * lda, M - head, K, w, N, bias, res16 ? res16 + head * N : nullptr, res32 ? res32 + head * N : nullptr,
-                gate16 ? gate16 + head * N : nullptr, relu, y16 ? y16 + head * N : nullptr, y32 ? y32 + head * N : nullptr, r, cv);
-  }
+                const bf16_t* gate16, bool relu, bf16_t* y16, float* y32, const Run& r, const ait_bf16s::Conv* cv = nullptr) {
+  // (One launch per product.  Measured at cfg5 -- 4096 proposal + 8 query maps = 256.5 row tiles, a third round of two tiles
+  // for every 512-column product: the proposals' rows launched alone run the 4608-deep convolutions at 967 instead of 679
+  // TFLOP/s, -1.6 ms, but the query maps' twenty products on their own are serial K loops on one or two workgroups, 33-163 us
+  // each, +1.6 ms; and a K-cut of the last round inside the kernel, gemm_bf16s.hip's lab knob, gains nothing either.)
   ait_bf16s::Gemm p{};
   p.A = x; p.B = w; p.C16 = y16; p.C32 = y32; p.bias = bias; p.res16 = res16; p.res32 = res32; p.gate16 = gate16;
   p.gate = gate16 != nullptr;
@@ -540,7 +528,6 @@ AIT_API int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int
     AIT_TRY(sk_forward(x_props, bp, 0, 0, d, w->sk_props, s.f1p, s.f3p, s.xtop, s.zeros, run, true));
     AIT_TRY(sk_forward(x_query, bs, npad16 - d.n_maps, bp, d, w->sk_query, s.f1q, s.f3q, s.xtop, s.zeros, run, true));
     const ait_bf16s::Conv cv = l4_conv16(s.zeros, P);
-    const long long head = head16(d);
     const bf16_t* xin = reinterpret_cast<const bf16_t*>(s.xtop);
     for (int k = 0; k < d.n_blocks; k++) {
       const ait_bottleneck_weights& bw = w->block[k];
@@ -549,15 +536,15 @@ AIT_API int ait_tail_fwd(const float* x_props, const float* x_query, int bp, int
       bf16_t* a1 = reinterpret_cast<bf16_t*>(s.a1[k]);
       bf16_t* a2 = reinterpret_cast<bf16_t*>(s.a2[k]);
       bf16_t* o = reinterpret_cast<bf16_t*>(s.o[k]);
-      AIT_TRY(mm16(xin, R16, cin, w16.w1, P, bw.bn1_shift, nullptr, nullptr, nullptr, true, a1, nullptr, run, nullptr, head));
-      AIT_TRY(mm16(a1, R16, 9 * P, w16.w2, P, bw.bn2_shift, nullptr, nullptr, nullptr, true, a2, nullptr, run, &cv, head));
+      AIT_TRY(mm16(xin, R16, cin, w16.w1, P, bw.bn1_shift, nullptr, nullptr, nullptr, true, a1, nullptr, run));
+      AIT_TRY(mm16(a1, R16, 9 * P, w16.w2, P, bw.bn2_shift, nullptr, nullptr, nullptr, true, a2, nullptr, run, &cv));
       const bf16_t* idn = xin;
       if (k == 0) {
         bf16_t* park = reinterpret_cast<bf16_t*>(s.o[1]);       // (free until block 1 writes its output; n_blocks >= 2)
-        AIT_TRY(mm16(xin, R16, cin, w16.wd, E, bw.bnd_shift, nullptr, nullptr, nullptr, false, park, nullptr, run, nullptr, head));
+        AIT_TRY(mm16(xin, R16, cin, w16.wd, E, bw.bnd_shift, nullptr, nullptr, nullptr, false, park, nullptr, run));
         idn = park;
       }
-      AIT_TRY(mm16(a2, R16, P, w16.w3, E, bw.bn3_shift, idn, nullptr, nullptr, true, o, nullptr, run, nullptr, head));
+      AIT_TRY(mm16(a2, R16, P, w16.w3, E, bw.bn3_shift, idn, nullptr, nullptr, true, o, nullptr, run));
       xin = o;
     }
     const long long n4 = (long long)d.n_maps * (E / 4);
@@ -683,7 +670,6 @@ AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const floa
     }
     const ait_bf16s::Conv cv = l4_conv16(s.zeros, P);
     const Scratch scr{dxt, (size_t)d.R * C * sizeof(float)};       // (dxt is written by the last two products only)
-    const long long head = head16(d);
     for (int k = d.n_blocks - 1; k >= 0; k--) {
       const int cin = k == 0 ? C : E;
       const W16 w16 = weights16(s.wf[k], d, k);
@@ -691,19 +677,19 @@ AIT_API int ait_tail_bwd(const float* d_pooled, const float* x_props, const floa
       const bf16_t* a1 = reinterpret_cast<const bf16_t*>(s.a1[k]);
       const bf16_t* a2 = reinterpret_cast<const bf16_t*>(s.a2[k]);
       AIT_TRY(wg16(gout, R16, E, a2, P, dwf[k].w3, run, scr));                                              // d W3' += g^T a2
-      AIT_TRY(mm16(gout, R16, E, w16.w3t, P, nullptr, nullptr, nullptr, a2, false, g2h, nullptr, run, nullptr, head));     // g2 = (g W3') [a2 > 0]
+      AIT_TRY(mm16(gout, R16, E, w16.w3t, P, nullptr, nullptr, nullptr, a2, false, g2h, nullptr, run));     // g2 = (g W3') [a2 > 0]
       AIT_TRY(wg16(g2h, R16, P, a1, P, dwf[k].w2, run, scr, &cv));
-      AIT_TRY(mm16(g2h, R16, 9 * P, w16.w2d, P, nullptr, nullptr, nullptr, a1, false, g1h, nullptr, run, &cv, head));
+      AIT_TRY(mm16(g2h, R16, 9 * P, w16.w2d, P, nullptr, nullptr, nullptr, a1, false, g1h, nullptr, run, &cv));
       AIT_TRY(wg16(g1h, R16, P, xin, cin, dwf[k].w1, run, scr));                                            // d W1' += g1^T x_in
       if (k > 0) {
         // conv1's data gradient + the identity shortcut's, behind the previous block's ReLU
-        AIT_TRY(mm16(g1h, R16, P, w16.w1t, cin, nullptr, gout, nullptr, xin, false, gnext, nullptr, run, nullptr, head));
+        AIT_TRY(mm16(g1h, R16, P, w16.w1t, cin, nullptr, gout, nullptr, xin, false, gnext, nullptr, run));
         bf16_t* t = gout; gout = gnext; gnext = t;
       } else {
         AIT_TRY(wg16(gout, R16, E, xin, cin, dwf[k].wd, run, scr));                                         // projection shortcut
         // (the gradient handed to the SK blocks in f32, rows of real maps only: dxt has d.R rows)
-        AIT_TRY(mm16(gout, d.R, E, w16.wdt, cin, nullptr, nullptr, nullptr, nullptr, false, nullptr, dxt, run, nullptr, head));
-        AIT_TRY(mm16(g1h, d.R, P, w16.w1t, cin, nullptr, nullptr, dxt, nullptr, false, nullptr, dxt, run, nullptr, head));  // (+=, in place)
+        AIT_TRY(mm16(gout, d.R, E, w16.wdt, cin, nullptr, nullptr, nullptr, nullptr, false, nullptr, dxt, run));
+        AIT_TRY(mm16(g1h, d.R, P, w16.w1t, cin, nullptr, nullptr, dxt, nullptr, false, nullptr, dxt, run));  // (+=, in place)
       }
     }
   }

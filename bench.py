@@ -525,10 +525,12 @@ def main():
                          "three bf16 values (round to nearest), six v_mfma_f32_32x32x16_bf16 per block, dropped terms <= 2^-23 |a b|)",
                   "f32_native": "f32 (AIT products on v_mfma_f32_32x32x2_f32; the proposal tail's and the RPN head's convolutions "
                                 "keep the split-bf16 form)",
-                  "bf16": "bf16 (BASELINE configs[4]): C4 trunk and proposal tail on MIOpen with bf16 tensors (f32 master weights, f32 accumulate, "
+                  "bf16": "bf16 (BASELINE configs[4]): C4 trunk on MIOpen with bf16 tensors (f32 master weights, f32 accumulate, "
                           "frozen-BN passes on bf16); AIT: every linear on v_mfma_f32_32x32x16_bf16 with f32 accumulate -- feed-forward "
-                          "hidden tensors, q / k / v, the attention blocks' gradients and the operator's output STORED in bf16 (bf16 "
-                          "operands from memory), the embeddings' operands rounded to bf16 in registers; f32 residual stream, LayerNorm, "
+                          "hidden tensors, q / k / v and the attention blocks' gradients STORED in bf16 (bf16 operands from memory), the "
+                          "embeddings' operands rounded to bf16 in registers; proposal tail in the library (ait_tail_*): layer4's "
+                          "activations and gradients STORED in bf16, its 1x1 / 3x3 convolutions on the bf16-storage kernels (folded "
+                          "bf16 weight copies per call), the SK blocks' operands rounded in registers; f32 residual stream, LayerNorm, "
                           "softmax and attention-tile arithmetic (on widened bf16 q / k / v), RPN, losses"}[args.dtype],
         "data": "synthetic",
         "config": {"workload": conf["workload"] % {"P": args.proposals, "bs": args.bs},

@@ -5,6 +5,8 @@ import collections
 import torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab_lib  # noqa: F401  (AIT_LAB_LIB=<name>: a lab build of the library)
 import ait_amd.faster_rcnn as fr
 from ait_amd import ops, _lib
 

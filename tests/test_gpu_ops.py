@@ -757,35 +757,39 @@ def test_proposal_tail_on_bf16_storage(monkeypatch, bp, bs, positive):
 
 def test_bf16_tail_rows_do_not_depend_on_the_maps_around_them():
     """A map's pooled feature and input gradient depend on that map alone, and an output element's sum runs over the reduction
-    in the same order wherever its row tile lies and however many row tiles there are: the bf16-storage tail on 2048 + 3 maps
-    against 2047 + 3 on the same inputs (another row count, another padding, the query maps in another tile): pooled features
-    bit for bit, input gradients to f32 rounding."""
+    in the same order wherever its row tile lies and however many row tiles there are: the bf16-storage tail at BASELINE
+    configs[4]'s size -- 4096 + 8 maps, 257 row tiles of the 256 x 256 x 64 tile: two whole rounds and two tiles -- against
+    2047 + 8 on the first 2047 proposals (another row count, another padding, another tile for every query map): pooled
+    features bit for bit, input gradients to f32 rounding."""
     import ait_amd.faster_rcnn as fr
     from ait_amd import ops
     torch.manual_seed(13)
     m = fr.resnet(('__background__', 'fg'), 50, pretrained=False, class_agnostic=True, num_K=3)
     m.create_architecture()
     m = m.cuda().train()
-    x0 = torch.randn(2048, 1024, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
-    q0 = torch.randn(3, 1024, 8, 8, device="cuda")
-    cot = torch.randn(2048 + 3, 2048, device="cuda")
+    n_big, n_small, nq = 4096, 2047, 8
+    x0 = torch.randn(n_big, 1024, 8, 8, device="cuda").contiguous(memory_format=torch.channels_last)
+    q0 = torch.randn(nq, 1024, 8, 8, device="cuda")
+    cot = torch.randn(n_big + nq, 2048, device="cuda")
     out = {}
     ops.set_matmul_dtype("bf16")
     try:
-        for bp in (2048, 2047):
+        for bp in (n_big, n_small):
             m.zero_grad(set_to_none=True)
             x, q = x0[:bp].clone().requires_grad_(True), q0.clone().requires_grad_(True)
             yp, yq = m._tail(x, q)
-            ((yp * cot[:bp]).sum() + (yq * cot[2048:]).sum()).backward()
+            ((yp * cot[:bp]).sum() + (yq * cot[n_big:]).sum()).backward()
             out[bp] = (yp.detach(), yq.detach(), x.grad.clone())
+            del x, q, yp, yq
     finally:
         ops.set_matmul_dtype("f32")
-    assert torch.equal(out[2048][0][:2047], out[2047][0]) and torch.equal(out[2048][1], out[2047][1])
+    assert torch.equal(out[n_big][0][:n_small], out[n_small][0]) and torch.equal(out[n_big][1], out[n_small][1])
     # (the input gradient leaves through the SK blocks' f32 products, whose stream-K cut of the last round of tiles -- and with
     # it the order of a few partial sums -- follows the number of rows: to f32 rounding, not to the bit)
-    a, b = out[2048][2][:2047], out[2047][2]
+    a, b = out[n_big][2][:n_small], out[n_small][2]
     assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), float((a - b).abs().max() / b.abs().max())
-    assert float(out[2048][0][2047].abs().sum()) > 0 and float(out[2048][2][2047].abs().sum()) > 0
+    assert float(out[n_big][0][n_small:].abs().sum()) > 0 and float(out[n_big][2][n_small:].abs().sum()) > 0
+    assert bool(torch.isfinite(out[n_big][0]).all()) and bool(torch.isfinite(out[n_big][2]).all())
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout,k,pad", [(4, 38, 63, 1024, 512, 3, 1), (1, 20, 30, 256, 128, 3, 1), (2, 19, 31, 128, 256, 3, 1),

@@ -70,11 +70,9 @@ struct Args {
   long long lda, ldb, ldc32, ldc16, ldr, ldg;
   int relu;
   Conv cv;                    // CONV kernels: A is a channels-last map, the reduction runs over (tap, channel)
-  // CUT kernels (the last, under-filled round of tiles cut along K): pieces per leftover tile, scratch for one partial tile per
-  // workgroup, one arrival counter per leftover tile (zero between launches)
+  // CUT launches (the last, under-filled round of tiles cut along K): pieces per leftover tile, scratch for a partial tile per piece
   int cut_parts;
   float* cut_ws;
-  unsigned* cut_cnt;
 };
 enum { EPI_PLAIN = 0, EPI_RES = 1, EPI_GATE = 2, EPI_RESGATE = 3 };
 
@@ -109,11 +107,71 @@ __device__ __forceinline__ void wait_vm() {
 template <int CH>
 __device__ __forceinline__ int swz(int r) { return CH == 4 ? (r >> 2) & 3 : r & 7; }
 
-// CUT: the launch's tiles are `full` whole rounds of the grid plus L <= grid / 2 leftover tiles.  Whole tiles run as ever; each
-// leftover tile is cut along K into cut_parts pieces, one per workgroup (piece ids dealt so that the pieces of a tile sit on one
-// XCD): a workgroup stores its piece's partial tile write-through into its slot of cut_ws, counts itself in on the tile's
-// arrival counter, and the LAST to arrive -- whoever that is -- adds all pieces in piece order (its own read back like the
-// others: one order, bit-reproducible), runs the epilogue and zeroes the counter.  Nobody waits for anybody.
+// what the epilogue does to four consecutive columns of one output row (after the bias): + addend, gate, ReLU, stores
+template <int EPI>
+__device__ __forceinline__ void epi_apply(const Args& g, int row, int col, float4 v) {
+  if constexpr (EPI == EPI_RES || EPI == EPI_RESGATE) {
+    if (g.res16) {
+      const uint2 rv = *reinterpret_cast<const uint2*>(g.res16 + (size_t)row * g.ldr + col);
+      v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
+      v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
+    } else {
+      const float4 rv = *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col);
+      v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+    }
+  }
+  if constexpr (EPI == EPI_GATE || EPI == EPI_RESGATE) {
+    if (EPI == EPI_RESGATE || g.gate16) {
+      const uint2 gv = *reinterpret_cast<const uint2*>(g.gate16 + (size_t)row * g.ldg + col);
+      // (a bf16 value is positive iff its 16 bits, read as a signed short, are > 0: +0 is 0, negatives and -0 < 0)
+      v.x = (short)(gv.x & 0xffffu) > 0 ? v.x : 0.f; v.y = (short)(gv.x >> 16) > 0 ? v.y : 0.f;
+      v.z = (short)(gv.y & 0xffffu) > 0 ? v.z : 0.f; v.w = (short)(gv.y >> 16) > 0 ? v.w : 0.f;
+    } else {
+      const float4 rv = *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col);
+      v.x = rv.x > 0.f ? v.x : 0.f; v.y = rv.y > 0.f ? v.y : 0.f;
+      v.z = rv.z > 0.f ? v.z : 0.f; v.w = rv.w > 0.f ? v.w : 0.f;
+    }
+  }
+  if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+  if (g.C32) *reinterpret_cast<float4*>(g.C32 + (size_t)row * g.ldc32 + col) = v;
+  if (g.C16) *reinterpret_cast<uint2*>(g.C16 + (size_t)row * g.ldc16 + col) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+}
+
+// (CUT launches, below) the finishing launch: block (leftover tile lt, band): BM / cut_parts rows of the tile summed over its
+// cut_parts pieces in piece order (bit-reproducible), bias, epilogue.  All loads of an element are independent: one round trip.
+template <class T, int EPI>
+__global__ __launch_bounds__(256) void cut_finish_kernel(const Args g, int tile0) {
+  constexpr int BM = T::BM, BN = T::BN;
+  const int tiles_n = g.N / BN;
+  const int lt = (int)blockIdx.x / g.cut_parts, part = (int)blockIdx.x - lt * g.cut_parts;
+  const int t = tile0 + lt, m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+  const int band_rows = BM / g.cut_parts, band0 = part * band_rows;
+  const float* ws = g.cut_ws + (size_t)lt * g.cut_parts * (BM * BN);
+  for (int e = threadIdx.x; e < band_rows * (BN / 4); e += 256) {
+    const int r = e / (BN / 4), c4 = e - r * (BN / 4);
+    const int row = m0 + band0 + r, col = n0 + 4 * c4;
+    if (row >= g.M) continue;
+    float4 t4[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+      if (p < g.cut_parts) t4[p] = *reinterpret_cast<const float4*>(ws + ((size_t)(p * BM + band0 + r) * BN + 4 * c4));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+      if (p < g.cut_parts) { v.x += t4[p].x; v.y += t4[p].y; v.z += t4[p].z; v.w += t4[p].w; }
+    if (g.bias) {
+      const float4 bb = *reinterpret_cast<const float4*>(g.bias + col);
+      v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+    }
+    epi_apply<EPI>(g, row, col, v);
+  }
+}
+
+// CUT: the launch's tiles are `full` whole rounds of the grid plus L <= grid / 2 leftover tiles -- which would be a last round of
+// L serial K loops with the rest of the chip idle.  Each leftover tile is cut along K into cut_parts (2 / 4 / 8) pieces, one per
+// workgroup, computed FIRST: the workgroup stores its piece's partial tile (row-major, plain f32) into its slot of cut_ws and
+// goes on to its whole tiles.  The pieces are summed and finished by a second, tiny launch behind this one (cut_finish_kernel):
+// no flag, no counter, nobody waits inside the kernel.
 template <class T, int EPI, bool CONV, bool CUT>
 __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {      // (two waves per SIMD: <= 256 VGPRs)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -124,18 +182,17 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {   
   const int xcd = blockIdx.x % AIT_NXCD, j = blockIdx.x / AIT_NXCD;
   const int slabs = g.K / BK;
   int per, mine, total;
-  int pc_tile = -1, pc_s0 = 0, pc_cnt = 0, pc_id = 0, pc_lt = 0;      // CUT: this workgroup's piece of a leftover tile
+  int pc_tile = -1, pc_s0 = 0, pc_cnt = 0, pc_id = 0;      // CUT: this workgroup's piece of a leftover tile
   if constexpr (CUT) {
     const int full = (tiles / (int)gridDim.x) * (int)gridDim.x, left = tiles - full;
     per = full / AIT_NXCD;
     mine = full / (int)gridDim.x;
-    pc_id = xcd * wg_per_xcd + j;
+    pc_id = xcd * wg_per_xcd + j;                                      // (the pieces of a tile on one XCD: they share its operand rows)
     if (pc_id < left * g.cut_parts) {
-      pc_lt = pc_id / g.cut_parts;
-      const int part = pc_id - pc_lt * g.cut_parts;
+      const int pc_lt = pc_id / g.cut_parts, pc_part = pc_id - pc_lt * g.cut_parts;
       pc_tile = full + pc_lt;
-      pc_s0 = part * slabs / g.cut_parts;
-      pc_cnt = (part + 1) * slabs / g.cut_parts - pc_s0;
+      pc_s0 = pc_part * slabs / g.cut_parts;
+      pc_cnt = (pc_part + 1) * slabs / g.cut_parts - pc_s0;
     }
     total = mine * slabs + pc_cnt;
     if (total <= 0) return;
@@ -151,19 +208,18 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {   
   const int rr = lane / CH, pos = lane % CH;                          // row within a granule, chunk POSITION in LDS
   const int cfetch = pos ^ swz<CH>(rr);                               // the 16-B chunk of the row that lands there
   const unsigned lds_base = (unsigned)(size_t)(lds_void*)lds;
-  auto tile_origin = [&](int i, int& m0, int& n0) __attribute__((always_inline)) {
-    const int t = (CUT && i >= mine) ? pc_tile : xcd * per + j + i * wg_per_xcd;
+  auto origin_of = [&](int t, int& m0, int& n0) __attribute__((always_inline)) {
     m0 = (t / tiles_n) * BM;
     n0 = (t % tiles_n) * BN;
   };
+  auto tile_origin = [&](int i, int& m0, int& n0) __attribute__((always_inline)) { origin_of(xcd * per + j + i * wg_per_xcd, m0, n0); };
   // loader: granule q of a slab is RG operand rows (A's BM / RG granules first, then B's); wave w takes q = w, w + NW, ...
   auto issue = [&](int s, int stage) __attribute__((always_inline)) {
     int m0, n0;
-    int unit = s / slabs, ks = s - unit * slabs;
-    if constexpr (CUT) {
-      if (s >= mine * slabs) { unit = mine; ks = pc_s0 + s - mine * slabs; }
-    }
-    tile_origin(unit, m0, n0);
+    const int sf = CUT ? s - pc_cnt : s, unit = sf / slabs;           // (CUT: the piece's slabs come first)
+    const bool piece = CUT && s < pc_cnt;
+    const int ks = piece ? pc_s0 + s : sf - unit * slabs;
+    origin_of(piece ? pc_tile : xcd * per + j + unit * wg_per_xcd, m0, n0);
     const int k0 = ks * BK;
     int tap_dy = 0, tap_dx = 0, tap_c0 = 0;                          // CONV: the slab's window tap and first channel
     if constexpr (CONV) {
@@ -201,7 +257,8 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {   
 #pragma unroll
   for (int i = 0; i < NS - 1; i++)
     if (i < total) issue(i, i);
-  int done = 0, ti = 0, stage = 0;
+  int done = 0, stage = 0;
+  int ti = (CUT && pc_cnt > 0) ? -1 : 0;                             // (unit -1: the piece)
   bool stores_pending = false;
   for (int s = 0; s < total; s++) {
     // slab s must have landed: everything but the loads of the NS - 2 slabs behind it (loads complete in order; the stores
@@ -234,65 +291,31 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {   
         for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
     }
     stage = stage + 1 == NS ? 0 : stage + 1;
-    bool tile_done = ++done == slabs;
-    bool finish = true;
+    ++done;
     if constexpr (CUT) {
-      if (ti == mine) {
-        tile_done = done == pc_cnt;
-        if (tile_done) {                     // the piece is this workgroup's last unit: publish it, count in, maybe finish the tile
-          constexpr int NQ = 4 * 2 * 4;
-          {
-            __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(g.cut_ws + (size_t)pc_id * (BM * BN), 0, BM * BN * 4, 0x00020000);
+      if (ti < 0 && done == pc_cnt) {        // the piece: store its partial tile (row-major), on to the whole tiles
+        // (buffer stores: one lane offset, the 32 block offsets as scalars -- plain 64-bit addresses cost the loop registers)
+        __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(g.cut_ws + (size_t)pc_id * (BM * BN), 0, BM * BN * 4, 0x00020000);
+        const int voff = ((wm + li) * BN + wn + 4 * lk) * 4;
 #pragma unroll
-            for (int a = 0; a < 4; a++)
+        for (int a = 0; a < 4; a++)
 #pragma unroll
-              for (int b = 0; b < 2; b++)
+          for (int b = 0; b < 2; b++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                  u32x4 v;
-                  v.x = __float_as_uint(acc[a][b][4 * q]); v.y = __float_as_uint(acc[a][b][4 * q + 1]);
-                  v.z = __float_as_uint(acc[a][b][4 * q + 2]); v.w = __float_as_uint(acc[a][b][4 * q + 3]);
-                  __builtin_amdgcn_raw_buffer_store_b128(v, ws, (int)threadIdx.x * 16, ((a * 2 + b) * 4 + q) * T::NT * 16, 16);
-                }
-          }
-          wait_vm<0>();                      // every storing wave drains (per-XCD L2s are not coherent: sc1 stores, sc1 loads)
-          __builtin_amdgcn_s_barrier();
-          unsigned* flag = reinterpret_cast<unsigned*>(lds);
-          if (threadIdx.x == 0)
-            *flag = __hip_atomic_fetch_add(g.cut_cnt + pc_lt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __syncthreads();
-          finish = (int)*flag == g.cut_parts - 1;
-          if (finish) {
+            for (int q = 0; q < 4; q++) {
+              u32x4 v;
+              v.x = __float_as_uint(acc[a][b][4 * q]); v.y = __float_as_uint(acc[a][b][4 * q + 1]);
+              v.z = __float_as_uint(acc[a][b][4 * q + 2]); v.w = __float_as_uint(acc[a][b][4 * q + 3]);
+              __builtin_amdgcn_raw_buffer_store_b128(v, ws, voff, (a * 32 * BN + b * 32 + 8 * q) * 4, 0);
 #pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-              for (int b = 0; b < 2; b++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
-            for (int p = 0; p < g.cut_parts; p++) {
-              __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(
-                  g.cut_ws + (size_t)(pc_lt * g.cut_parts + p) * (BM * BN), 0, BM * BN * 4, 0x00020000);
-#pragma unroll
-              for (int q0 = 0; q0 < NQ; q0 += 16) {
-                u32x4 t[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++)
-                  t[i] = __builtin_amdgcn_raw_buffer_load_b128(ws, (int)threadIdx.x * 16, (q0 + i) * T::NT * 16, 16);
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                  const int idx = q0 + i, ab = idx >> 2, q = idx & 3;
-                  f32x16& d = acc[ab / 2][ab % 2];
-                  d[4 * q] += __uint_as_float(t[i].x); d[4 * q + 1] += __uint_as_float(t[i].y);
-                  d[4 * q + 2] += __uint_as_float(t[i].z); d[4 * q + 3] += __uint_as_float(t[i].w);
-                }
-              }
+              for (int r = 0; r < 4; r++) acc[a][b][4 * q + r] = 0.f;
             }
-            if (threadIdx.x == 0) __hip_atomic_store(g.cut_cnt + pc_lt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
+        done = 0;
+        ti = 0;
+        stores_pending = true;
       }
     }
-    if (tile_done && finish) {
+    if ((!CUT || ti >= 0) && done == slabs) {
       int m0, n0;
       tile_origin(ti, m0, n0);
 #pragma unroll
@@ -309,33 +332,7 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {   
               const float4 bb = *reinterpret_cast<const float4*>(g.bias + col);
               v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
             }
-            if (ok) {
-              if constexpr (EPI == EPI_RES || EPI == EPI_RESGATE) {
-                if (g.res16) {
-                  const uint2 rv = *reinterpret_cast<const uint2*>(g.res16 + (size_t)row * g.ldr + col);
-                  v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
-                  v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
-                } else {
-                  const float4 rv = *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col);
-                  v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                }
-              }
-              if constexpr (EPI == EPI_GATE || EPI == EPI_RESGATE) {
-                if (EPI == EPI_RESGATE || g.gate16) {
-                  const uint2 gv = *reinterpret_cast<const uint2*>(g.gate16 + (size_t)row * g.ldg + col);
-                  // (a bf16 value is positive iff its 16 bits, read as a signed short, are > 0: +0 is 0, negatives and -0 < 0)
-                  v.x = (short)(gv.x & 0xffffu) > 0 ? v.x : 0.f; v.y = (short)(gv.x >> 16) > 0 ? v.y : 0.f;
-                  v.z = (short)(gv.y & 0xffffu) > 0 ? v.z : 0.f; v.w = (short)(gv.y >> 16) > 0 ? v.w : 0.f;
-                } else {
-                  const float4 rv = *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col);
-                  v.x = rv.x > 0.f ? v.x : 0.f; v.y = rv.y > 0.f ? v.y : 0.f;
-                  v.z = rv.z > 0.f ? v.z : 0.f; v.w = rv.w > 0.f ? v.w : 0.f;
-                }
-              }
-              if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-              if (g.C32) *reinterpret_cast<float4*>(g.C32 + (size_t)row * g.ldc32 + col) = v;
-              if (g.C16) *reinterpret_cast<uint2*>(g.C16 + (size_t)row * g.ldc16 + col) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
-            }
+            if (ok) epi_apply<EPI>(g, row, col, v);
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[a][b][4 * q + r] = 0.f;
           }
@@ -632,13 +629,10 @@ inline int slots_of(const void* kern, int& memo) {
   return memo;
 }
 
-// The last round's cut (CUT kernels; the 256 x 256 tile only -- one workgroup per CU; lab knob bf16s_cut, OFF in the product):
-// when the tiles are whole rounds of the grid plus at most half a round, and the caller's scheduler scratch
-// (ait_launch_ctx::sched_ws, the one the f32 kernel's stream-K uses: launches ordered on one stream) holds a partial tile per
-// workgroup.  4096 x 16 + 8 x 16 rows of cfg5's layer4 are 256.5 row tiles: every 512-column product runs a third round for two
-// tiles.  Measured: 389 us with the cut against 364 for exactly two rounds (the model: pieces 27 us + six gathers 30 us + the
-// epilogue) -- and in the step no faster than without it (same-box A/B 30.5 vs 30.5 ms of products): the lone tiles of a third
-// round have the memory system to themselves and finish in ~0.6 of a tile-time.
+// The last round's cut (CUT kernels + cut_finish_kernel; the 256 x 256 tile only -- one workgroup per CU): when the tiles are
+// whole rounds of the grid plus at most half a round, and the caller's scheduler scratch (ait_launch_ctx::sched_ws, the one the
+// f32 kernel's stream-K uses: launches ordered on one stream) holds a partial tile per piece.  4096 x 16 + 8 x 16 rows of cfg5's
+// layer4 are 256.5 row tiles: without the cut every 512-column product runs a third round for two tiles.
 template <class T, int EPI, bool CONV>
 int launch(Args g, const ait_launch_ctx* ctx, hipStream_t s) {
   const void* kern = reinterpret_cast<const void*>(gemm_bf16s_kernel<T, EPI, CONV, false>);
@@ -647,24 +641,24 @@ int launch(Args g, const ait_launch_ctx* ctx, hipStream_t s) {
   if (slots <= 0) return AIT_ELAUNCH;
   const int tiles = ((g.M + T::BM - 1) / T::BM) * (g.N / T::BN);
   if constexpr (T::BN == 256) {
-    if (ait_lab::Knobs::bf16s_cut && ctx && ctx->sched_ws && (slots % AIT_NXCD) == 0 && tiles > slots) {
+    // (long reductions only: at 72 slabs -- layer4's 3x3 convolutions -- the cut turns 453 us into 370, two whole rounds take 374;
+    // at 32 slabs it wins 7 us with two leftover tiles and loses 47 with 32, at 8 slabs it loses: the pieces and the finishing
+    // launch cost about what a lone short tile does)
+    if (ait_lab::Knobs::bf16s_cut && ctx && ctx->sched_ws && (slots % AIT_NXCD) == 0 && tiles > slots && g.K / T::BK >= 64) {
       const int left = tiles % slots, slabs = g.K / T::BK;
-      // pieces per leftover tile: a piece costs its slabs (~2.2 us each), the finishing workgroup ~5 us per piece it gathers (two
-      // dependent round trips of write-through data) -- the sum is least near sqrt(0.44 slabs): 6 pieces for 72 slabs, 4 for 32
-      int parts = left > 0 ? slots / left : 0;
-      int best = 2;
-      while ((best + 1) * (best + 1) * 100 <= 44 * slabs + 100 * best) best++;      // (best^2 ~ 0.44 slabs, rounded)
-      if (parts > best) parts = best;
-      if (parts > slabs / 2) parts = slabs / 2;
+      // pieces per leftover tile: 8 / 4 / 2 (bands of whole rows), at least two slabs each, no more pieces than workgroups
+      int parts = 8;
+      while (parts > 1 && (left <= 0 || parts * left > slots || slabs / parts < 2)) parts >>= 1;
       const size_t need = ait_ws::kCtlBytes + (size_t)slots * T::BM * T::BN * sizeof(float);
-      if (parts >= 2 && left <= 256 && ctx->sched_ws_bytes >= need) {
+      if (parts >= 2 && left > 0 && left <= 256 && ctx->sched_ws_bytes >= need) {
         const void* kcut = reinterpret_cast<const void*>(gemm_bf16s_kernel<T, EPI, CONV, true>);
         static int memo_cut = 0;
         if (slots_of<T>(kcut, memo_cut) == slots) {
           g.cut_parts = parts;
           g.cut_ws = reinterpret_cast<float*>(static_cast<char*>(ctx->sched_ws) + ait_ws::kCtlBytes);
-          g.cut_cnt = reinterpret_cast<unsigned*>(static_cast<char*>(ctx->sched_ws) + ait_ws::kBf16CutCounters);
           hipLaunchKernelGGL((gemm_bf16s_kernel<T, EPI, CONV, true>), dim3(slots), dim3(T::NT), T::LDS, s, g);
+          AIT_CHECK_LAUNCH();
+          hipLaunchKernelGGL((cut_finish_kernel<T, EPI>), dim3(left * parts), dim3(256), 0, s, g, tiles - left);
           AIT_CHECK_LAUNCH();
           return AIT_OK;
         }
@@ -784,7 +778,7 @@ int ait_bf16s::gemm(const Gemm& p, const ait_launch_ctx* ctx, void* stream) {
   g.ldg = p.gate16 ? p.ldg : p.ldr;
   g.relu = p.relu ? 1 : 0;
   g.cv = p.cv;
-  g.cut_parts = 0; g.cut_ws = nullptr; g.cut_cnt = nullptr;
+  g.cut_parts = 0; g.cut_ws = nullptr;
   hipStream_t s = ait_stream(stream);
   AitProbeScope probe(ait_probe_of(ctx), AIT_PROBE_GEMM, 2.0 * M * N * K, s, M, N, K, 0, 1, 1);
   // long reductions on the 256 x 256 x 64 tile (at least a round of them), the 512-deep products on the 256 x 128 x 32 one

@@ -15,6 +15,7 @@
 // file; they live in the history at 81edb57 and their results in DESIGN.md section 3.1.)
 #pragma once
 #include "common.h"
+#include "gemm_internal.h"
 #include "split_planes.h"
 #include <atomic>
 
@@ -1926,8 +1927,7 @@ __global__ __launch_bounds__(C::NT, C::MINW) void gemm_f32_kernel(const GemmArgs
 constexpr size_t kSchedBytes = AIT_NXCD * 32 * sizeof(unsigned);      // 1 KiB
 constexpr int kMaxSlots = 2048;                                       // workgroups of one persistent launch
 constexpr size_t kCtlBytes = 16384;                                   // >= kSchedBytes + kMaxSlots * 4
-// (gemm_internal.h ait_ws: the bf16-storage kernel keeps 256 arrival counters at byte 12288 of the control words)
-static_assert(kCtlBytes == 16384 && kSchedBytes + kMaxSlots * 4 <= 12288, "control words: f32 flags below the bf16 kernel's counters");
+static_assert(kCtlBytes == ait_ws::kCtlBytes, "gemm_internal.h ait_ws: the bf16 kernel's partial tiles start behind the control words too");
 struct SchedWs {
   void* p = nullptr;
   size_t bytes = 0;

@@ -62,11 +62,10 @@ int ait_ln_bwd_ex(const float* dy, const float* a, const float* pos, const float
                   int dy_rows_per_seq, float p_drop, unsigned long long seed, float* da, float* dres, float* dgamma,
                   float* dbeta, float* dcolsum, void* da16, void* stream);
 
-// the caller's scheduler scratch (ait_launch_ctx::sched_ws; layout: csrc/gemm_f32_impl.h): [0, kCtlBytes) control words -- the f32
-// kernel's tickets and flags below kBf16CutCounters, the bf16 kernel's arrival counters (256 words) from there -- then partial tiles
+// the caller's scheduler scratch (ait_launch_ctx::sched_ws; layout: csrc/gemm_f32_impl.h): [0, kCtlBytes) the f32 kernel's control
+// words, then room for partial tiles -- which the bf16 kernel's last-round cut borrows too (launches ordered on one stream)
 namespace ait_ws {
 constexpr size_t kCtlBytes = 16384;
-constexpr size_t kBf16CutCounters = 12288;
 }
 
 // ---- bf16-STORAGE products (csrc/gemm_bf16s.hip) with what only the library's composites use: a bf16 addend, an addend AND

@@ -19,11 +19,8 @@ struct Product {
   static constexpr int bf16s_big_min_k = 512;
   // gemm_bf16s.hip: weight gradients always through f32 atomics (never the stored K-range partials)
   static constexpr bool tn_atomics = false;
-  // gemm_bf16s.hip: the 256 x 256 tile's under-filled last round of tiles cut along K over the idle workgroups (correct and
-  // bit-reproducible, tests/test_gpu_gemm.py runs it in a lab build only; no gain in the step -- the two lone tiles of a third
-  // round run latency-bound at ~0.6 of a tile-time, the cut's pieces + the gathering workgroup's round trips cost about the same:
-  // profiles/r06_cfg5_tail_on_library.txt)
-  static constexpr bool bf16s_cut = false;
+  // gemm_bf16s.hip: the 256 x 256 tile's under-filled last round of tiles cut along K (pieces first, a finishing launch behind)
+  static constexpr bool bf16s_cut = true;
   // gemm_bf16s.hip: the weight-gradient kernel's items in one contiguous chunk per XCD (false: dealt over all workgroups)
   static constexpr bool tn_xcd_chunks = true;
   // gemm_p3.hip: the fewest 256 x 256 tiles the pre-split-weight kernel takes

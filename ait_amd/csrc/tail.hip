@@ -440,10 +440,10 @@ inline ait_bf16s::Conv l4_conv16(const float* zeros, int channels) {
 // y16 [M, N] = relu?(x16 [M, K] W16[N, K]^T + bias (+ res16)) (kept where gate16 > 0), or the same into y32; conv: through the 3x3 window
 inline int mm16(const bf16_t* x, long long M, int K, const bf16_t* w, int N, const float* bias, const bf16_t* res16, const float* res32,
                 const bf16_t* gate16, bool relu, bf16_t* y16, float* y32, const Run& r, const ait_bf16s::Conv* cv = nullptr) {
-  // (One launch per product.  Measured at cfg5 -- 4096 proposal + 8 query maps = 256.5 row tiles, a third round of two tiles
-  // for every 512-column product: the proposals' rows launched alone run the 4608-deep convolutions at 967 instead of 679
-  // TFLOP/s, -1.6 ms, but the query maps' twenty products on their own are serial K loops on one or two workgroups, 33-163 us
-  // each, +1.6 ms; and a K-cut of the last round inside the kernel, gemm_bf16s.hip's lab knob, gains nothing either.)
+  // (One launch per product.  At cfg5 -- 4096 proposal + 8 query maps = 256.5 row tiles -- every 512-column product would run
+  // a third round for two tiles: the 4608-deep convolutions get that round cut along K inside gemm_bf16s.hip (453 -> 370 us, two
+  // whole rounds: 374); the shorter reductions keep it -- launching the proposals' rows alone instead collects 1.6 ms on the big
+  // launches and gives it back on the query maps' twenty small ones, serial K loops on one or two workgroups, 33-163 us each.)
   ait_bf16s::Gemm p{};
   p.A = x; p.B = w; p.C16 = y16; p.C32 = y32; p.bias = bias; p.res16 = res16; p.res32 = res32; p.gate16 = gate16;
   p.gate = gate16 != nullptr;

@@ -686,12 +686,13 @@ def test_every_epilogue_and_tile_family_the_step_launches_is_reproducible():
 
 
 @pytest.mark.gpu
-# (12290 ..., 50000 ...: the 256 x 256 x 64 tile; the last three: thin last rounds of it -- 257 row tiles x 2 column tiles = two
-# rounds of 256 + 2 tiles; 258 x 8 = eight rounds + 16 tiles, ragged rows; 291 x 4 = four rounds + 140 tiles.  In a lab build with
-# bf16s_cut = true the first two run the K-cut of the last round: pieces gathered in a fixed order, hence the reproducibility check)
+# (12290 ..., 50000 ...: the 256 x 256 x 64 tile; then thin last rounds of it -- 257 row tiles x 2 column tiles = two rounds of
+# 256 + 2 tiles; 258 x 8 = eight rounds + 16 tiles, ragged rows; 291 x 4 = four rounds + 140 tiles -- and, the last two, long
+# reductions with such a round: the K-cut (pieces first, a finishing launch that adds them in piece order: hence the
+# reproducibility check), 2 leftover tiles in 8 pieces each and 28 leftover tiles in 8, ragged rows)
 @pytest.mark.parametrize("M,N,K", [(256, 128, 32), (1000, 256, 64), (4097, 512, 512), (19200, 2048, 512), (777, 1536, 2048),
                                    (12290, 1024, 1024), (50000, 512, 2048), (65792, 512, 1024), (65900, 2048, 512),
-                                   (74400, 1024, 512)])
+                                   (74400, 1024, 512), (65792, 512, 4096), (34500, 1024, 4608)])
 def test_bf16_storage_gemm_against_float64(M, N, K):
     """ait_gemm_bf16s (csrc/gemm_bf16s.hip): bf16 operands stored in memory, f32 accumulate; against the float64 product of
     the SAME bf16 values (the only error left is the f32 accumulation), every epilogue: bias, ReLU, residual, the two
@@ -775,7 +776,7 @@ def test_bf16_storage_weight_gradient_product_against_float64(R, Mo, No, sk):
 @pytest.mark.parametrize("n,hw,k,cin,cout", [(8, 4, 3, 512, 512),       # layer4's 3x3 on 4x4 maps (256 x 128 x 32 tile: one row tile)
                                               (520, 4, 3, 512, 512),     # ... several row tiles per workgroup
                                               (3100, 4, 3, 512, 512),    # ... enough of them for the 256 x 256 x 64 tile
-                                              (4112, 4, 3, 512, 512),    # ... 257 row tiles: a third round of two tiles (cut along K in a lab build)
+                                              (4112, 4, 3, 512, 512),    # ... 257 row tiles: the third round's two tiles cut along K, 8 pieces each
                                               (37, 8, 3, 128, 256),      # ragged row count, 8x8 maps
                                               (16, 4, 1, 256, 128),      # a 1x1 window is the plain product
                                               (6, 8, 5, 64, 128)])       # 5x5 window, 64-channel taps

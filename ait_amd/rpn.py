@@ -722,7 +722,9 @@ class _Heads1x1(torch.autograd.Function):
         dy[:, :n1] = d1
         dy[:, n1:n1 + n2] = d2
         dx = ops.gemm(dy, W, trans_b=False) if ctx.needs_input_grad[0] else None
-        dW = ops.gemm(dy, xm, trans_a=True, trans_b=False, split_k=8 if xm.shape[0] >= 2048 else 1)
+        # (16 K-ranges: 22 us against 39 with 8 at 9576 rows, 42 against 77 at 19152; 32 and more lose again --
+        # profiles/r06_gemm_tail_experiments.txt)
+        dW = ops.gemm(dy, xm, trans_a=True, trans_b=False, split_k=16 if xm.shape[0] >= 2048 else 1)
         db = ops.colsum(dy)
         return dx, dW[:n1].reshape(s1), db[:n1], dW[n1:n1 + n2].reshape(s2), db[n1:n1 + n2]
 

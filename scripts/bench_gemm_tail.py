@@ -51,8 +51,12 @@ WGRAD = [(1536, 512, 76800, 1, 0, sp, 1) for sp in (64, 16, 20, 21, 24, 32, 40, 
         [(512, 512, 76800, 1, 0, sp, 1) for sp in (64, 32, 56, 63)] + [(1024, 512, 76800, 1, 0, sp, 1) for sp in (32, 16, 24, 31)] + \
         [(2048, 512, 76800, 1, 0, sp, 1) for sp in (16, 8, 15)] + [(512, 2048, 58800, 1, 0, sp, 1) for sp in (16, 15)] + \
         [(512, 4608, 19328, 1, 0, sp, 1) for sp in (8, 7, 14)]
+# the RPN heads' weight gradient (64 / 128 rows): K-range counts (AIT_TAIL_WGRAD=2)
+RPNW = [(64, 512, 9576, 1, 0, sp, 1) for sp in (8, 16, 32, 40, 64)] + [(128, 512, 19152, 1, 0, sp, 1) for sp in (8, 16, 32, 64, 72)]
 if os.environ.get("AIT_TAIL_WGRAD") == "1":
     SHAPES = WGRAD
+if os.environ.get("AIT_TAIL_WGRAD") == "2":
+    SHAPES = RPNW
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 tot = 0.0
 for m, n, k, ta, tb, sk, batch in SHAPES:

@@ -398,7 +398,11 @@ int ait_gemm_bf16(int trans_a, int trans_b, int M, int N, int K, float alpha, co
  * [M, N] tensor, pitch ldr: the STORED ReLU output of the forward) if given, else `residual`; then ReLU with AIT_GEMM_RELU.
  * The result is written as f32 into C32 (pitch ldc32) and / or rounded to bf16 (nearest even) into C16 (pitch ldc16):
  * either may be NULL, not both.  The linears of the AIT in the bf16-storage mode: Models.py:246-247,278,
- * SubLayers.py:77-79,97,181-183 and their input gradients (B = the transposed weight copy). */
+ * SubLayers.py:77-79,97,181-183 and their input gradients (B = the transposed weight copy).
+ * With ctx->sched_ws (the scheduler scratch of ait_launch_ctx; launches ordered on one stream) a reduction of K >= 4096 whose
+ * 256 x 256 tiles leave a last round of at most half the chip's workgroups has those leftover tiles cut along K into 8 / 4 / 2
+ * pieces, summed in piece order by a second small launch (ABI v8; also ait_conv_fwd_bf16s): the same products, another --
+ * fixed, reproducible -- summation order for those tiles than without the scratch. */
 int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, float* C32,
                    long long ldc32, void* C16, long long ldc16, const float* bias, const float* residual,
                    const void* gate16, long long ldr, int flags, const ait_launch_ctx* ctx, void* stream);

@@ -56,6 +56,8 @@ struct TileCfg {
 };
 using Small = TileCfg<256, 128, 32, 3, 2, 2>;
 using Big = TileCfg<256, 256, 64, 2, 2, 4>;
+// (weight gradients of 64-column outputs -- d fc_w = df^T u of the attention blocks: two waves, 20-KB stages)
+using Narrow = TileCfg<256, 64, 32, 3, 2, 1>;
 
 struct Args {
   const unsigned short* A;
@@ -100,6 +102,7 @@ __device__ __forceinline__ void wait_vm() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else static_assert(N == 0, "add the immediate");
 }
 // position swizzle of a K-contiguous slab row: chunk c of row r is stored at c ^ swz(r) (conflict-free ds_read_b128 of 32
@@ -379,6 +382,9 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g)
   constexpr int SLAB_A = BK * ROWA;
   constexpr int GA = SLAB_A / 1024;                            // granules of the A slab (the B slab's follow)
   constexpr int LPRA = ROWA / 16, LPRB = ROWB_ / 16;           // lanes (16-B chunks) per slab row
+  // chunk swizzle of slab row k: position = chunk ^ (SW (k & 3)) -- 4 for rows of 16 chunks and more, 2 for the 8-chunk rows of
+  // the 64-column tile (the swizzled position must stay inside the row)
+  constexpr int SWA = LPRA >= 16 ? 4 : 2, SWB = LPRB >= 16 ? 4 : 2;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tiles_n = g.No / BN, tiles = (g.Mo / BM) * tiles_n, items = tiles * g.splits;
   const int wm = (wave / T::WN) * 128, wn = (wave % T::WN) * 64;
@@ -435,10 +441,10 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g)
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE + q * 1024);
       if (q < GA) {
         const int row = q * (64 / LPRA) + lane / LPRA, pos = lane % LPRA;
-        glds16(g.A + (size_t)(k0 + row) * g.lda + m0 + (pos ^ (4 * (row & 3))) * 8, dst);
+        glds16(g.A + (size_t)(k0 + row) * g.lda + m0 + (pos ^ (SWA * (row & 3))) * 8, dst);
       } else {
         const int row = (q - GA) * (64 / LPRB) + lane / LPRB, pos = lane % LPRB;
-        const int chunk = pos ^ (4 * (row & 3));
+        const int chunk = pos ^ (SWB * (row & 3));
         if constexpr (CONV) {
           const long long src = conv_row(g.cv, k0 + row, tap_dy, tap_dx);
           glds16(src >= 0 ? g.B + (size_t)src * g.ldb + tap_c0 + chunk * 8 : g.cv.zeros + chunk * 8, dst);
@@ -456,12 +462,12 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_tn_kernel(const TnArgs g)
 #pragma unroll
   for (int a = 0; a < 4; a++) {
     const int c = (wm + 32 * a) / 8 + 2 * (gq & 1) + (tp >> 1);
-    offA[a] = krow * ROWA + ((c ^ (4 * tq)) << 4) + 8 * (tp & 1);
+    offA[a] = krow * ROWA + ((c ^ (SWA * tq)) << 4) + 8 * (tp & 1);
   }
 #pragma unroll
   for (int b = 0; b < 2; b++) {
     const int c = (wn + 32 * b) / 8 + 2 * (gq & 1) + (tp >> 1);
-    offB[b] = krow * ROWB_ + ((c ^ (4 * tq)) << 4) + 8 * (tp & 1);
+    offB[b] = krow * ROWB_ + ((c ^ (SWB * tq)) << 4) + 8 * (tp & 1);
   }
   f32x16 acc[4][2];
 #pragma unroll
@@ -809,7 +815,8 @@ int ait_bf16s::wgrad(const Wgrad& p, const ait_launch_ctx* ctx, void* stream) {
   if (Mo == 0 || No == 0 || R == 0) return AIT_OK;
   if (!p.A || !p.B || !p.C) return AIT_EINVAL;
   const long long ldb_min = p.cv.on ? (1ll << p.cv.cin_shift) : No;
-  if ((Mo % Small::BM) || (No % Small::BN) || (p.lda % 8) || (p.ldb % 8) || p.lda < Mo || p.ldb < ldb_min || (p.ldc % 4) ||
+  const bool narrow = No == Narrow::BN && !p.cv.on;              // one 64-column tile wide: d fc_w of the attention blocks
+  if ((Mo % Small::BM) || ((No % Small::BN) && !narrow) || (p.lda % 8) || (p.ldb % 8) || p.lda < Mo || p.ldb < ldb_min || (p.ldc % 4) ||
       p.ldc < No || !al16(p.A) || !al16(p.B) || !al16(p.C))
     return AIT_EUNSUPPORTED;
   int split_k = p.split_k < 1 ? 1 : p.split_k;
@@ -833,6 +840,7 @@ int ait_bf16s::wgrad(const Wgrad& p, const ait_launch_ctx* ctx, void* stream) {
   if (p.cv.on && (1 << p.cv.cin_shift) < Small::BN) return AIT_EUNSUPPORTED;
   const bool big = kUseBig && fits_big && (No % Big::BN) == 0 && (R % Big::BK) == 0 && R / Big::BK >= split_k &&
                    (long long)(Mo / Big::BM) * (No / Big::BN) * split_k >= 192;
+  if (narrow) return use_partials ? launch_tn<Narrow, true, false>(g, s) : launch_tn<Narrow, false, false>(g, s);
   if (p.cv.on) {
     if (use_partials) return big ? launch_tn<Big, true, true>(g, s) : launch_tn<Small, true, true>(g, s);
     return big ? launch_tn<Big, false, true>(g, s) : launch_tn<Small, false, true>(g, s);

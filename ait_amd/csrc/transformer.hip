@@ -274,9 +274,25 @@ int mha_block_bwd(const float* dy, int dy_rows, const float* xq, const float* xk
   const int M = n * T;
   const bool cross = xkv != xq;
   // closing LayerNorm + dropout + residual: df (at fc's output), dres (the residual branch)
-  AIT_TRY(ait_ln_bwd(dy, m.f, nullptr, xq, w.ln_g, m.mean, m.rstd, M, D, T, T, 1, dy_rows, p_fc,
-                     ait_dropout_seed(seed, 1), t.df, t.dres, g.ln_g, g.ln_b, nullptr, s.stream));
-  AIT_TRY(wgrad(t.df, M, D, m.u, DK, g.fc_w, s));                            // d fc_w += df^T u
+  // (bf16 configuration: df also as bf16 and a bf16 copy of u -- into the du / dO scratch nothing else uses since the fused
+  // backward kernel -- for d fc_w on the bf16 weight-gradient kernel's 64-column tile: the f32 product spends 0.26 ms per
+  // block on splitting 512 x M values for 64 columns of matrix work, 66 TFLOP/s)
+  const bool fcw16 = ait_lab::Knobs::fcw_bf16 && g.fc_w && s.ctx && (s.ctx->flags & AIT_CTX_BF16) &&
+                     !(s.ctx->flags & AIT_CTX_NATIVE_F32) && M >= 4096 && (M % 32) == 0;
+  AIT_TRY(ait_ln_bwd_ex(dy, m.f, nullptr, xq, w.ln_g, m.mean, m.rstd, M, D, T, T, 1, dy_rows, p_fc, ait_dropout_seed(seed, 1), t.df,
+                        t.dres, g.ln_g, g.ln_b, nullptr, fcw16 ? static_cast<void*>(t.dO) : nullptr, s.stream));
+  if (fcw16) {
+    AIT_TRY(ait_f32_to_bf16(m.u, M, DK, DK, t.du, DK, 0, s.stream));
+    ait_bf16s::Wgrad p{};
+    p.A = t.dO; p.B = t.du; p.C = g.fc_w; p.Mo = D; p.No = DK; p.R = M;
+    p.lda = D; p.ldb = DK; p.ldc = DK;
+    p.split_k = M / 32 < 128 ? M / 32 : 128;                                 // 2 tiles x 128 ranges: a round of the narrow tile's slots
+    p.partials = reinterpret_cast<char*>(t.dO) + (size_t)M * D * 2;          // (the other half of dO)
+    p.partials_bytes = (size_t)M * D * 2;
+    AIT_TRY(ait_bf16s::wgrad(p, s.ctx, s.stream));                           // d fc_w += df^T u
+  } else {
+    AIT_TRY(wgrad(t.df, M, D, m.u, DK, g.fc_w, s));                          // d fc_w += df^T u
+  }
   const Qkv v = views(m, n, cross);
   // (the forward of this step stored q / k / v -- and bf16 copies of the block's inputs -- in bf16: same predicate)
   const bool in16 = qkv16_on(s, pq, M);

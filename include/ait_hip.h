@@ -408,7 +408,8 @@ int ait_gemm_bf16s(int M, int N, int K, const void* A, long long lda, const void
                    const void* gate16, long long ldr, int flags, const ait_launch_ctx* ctx, void* stream);
 /* ... and the weight-gradient product of that mode: C[Mo, No] (f32, pitch ldc) += sum over the R token rows of
  * A[r, m] * B[r, n], A = bf16 [R, Mo] (the output gradient), B = bf16 [R, No] (the layer's input), both row-major with
- * the REDUCTION index outermost (pitches in elements, multiples of 8).  Mo % 256 == 0, No % 128 == 0; the rows are whole 32-row
+ * the REDUCTION index outermost (pitches in elements, multiples of 8).  Mo % 256 == 0, No % 128 == 0 or (ABI v8) No == 64 -- d fc_w =
+ * df^T u of the attention blocks, SubLayers.py:97, on a 256 x 64 tile --; the rows are whole 32-row
  * slabs (R % 32 == 0: pad the operands with zero rows), cut into split_k ranges of slabs that differ by at most one slab (ABI v8;
  * before: equal ranges only) -- at most one range per slab -- whose partial tiles are ADDED to C: zero C for a plain gradient
  * (SubLayers.py:181-183's weights).  `partials`

@@ -752,7 +752,8 @@ def test_bf16_column_sums_against_float64(rows, cols, pitch):
 # (4800, ..., 7): 150 slabs of 32 rows in ranges of 22 and 21; (66560, ..., 7): 1040 slabs of 64 in ranges of 149 and 148 -- one
 # round of the 256 x 256 tile for the 36 tiles of layer4's 3x3 gradient
 @pytest.mark.parametrize("R,Mo,No,sk", [(64, 256, 128, 1), (2048, 512, 2048, 4), (4800, 2048, 512, 5), (76800, 512, 2048, 16),
-                                        (4800, 512, 512, 7), (66560, 512, 4608, 7), (2080, 256, 256, 65)])
+                                        (4800, 512, 512, 7), (66560, 512, 4608, 7), (2080, 256, 256, 65),
+                                        (76800, 512, 64, 128), (4800, 256, 64, 5)])      # (the 256 x 64 tile: d fc_w = df^T u)
 def test_bf16_storage_weight_gradient_product_against_float64(R, Mo, No, sk):
     """ait_gemm_bf16s_tn: dW[Mo, No] += dy^T x over the token rows, bf16 operands row-major with the reduction index
     outermost (the transposing LDS read ds_read_b64_tr_b16 builds the MFMA operands); split-K partials added with f32

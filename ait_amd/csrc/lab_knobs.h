@@ -41,6 +41,8 @@ struct Product {
   static constexpr bool no_bf16_qkv = false;
   static constexpr bool no_bf16_attn = false;
   static constexpr bool no_bf16_ffn = false;
+  // transformer.hip, the bf16 configuration: dec_trans and its gradients on bf16 operands also with f32 `out` / `d_out`
+  static constexpr bool dec_trans_bf16 = true;
   // transformer.hip, the bf16 configuration: d fc_w of the attention blocks on the bf16 weight-gradient kernel (false: the f32 product)
   static constexpr bool fcw_bf16 = true;
   // attn_impl.h: column-paired right-operand loads for f32 q / k / v as well; six MFMA terms whatever the operands are

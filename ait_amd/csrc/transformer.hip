@@ -749,13 +749,18 @@ inline bool carve_eval(Bump& b, AitBufs& a, long long bp, long long bs, int ns) 
 // operand of the weight gradient) lives in what the bf16-storage feed-forward leaves unused of its h buffer, the weight and
 // its transpose in the pre-split scratch.  Taken when the decoder's feed-forward runs in bf16 storage (the h buffer is laid
 // out that way) and the rows suit the weight-gradient kernel.
+// Round 6: the same three products on bf16 operands ALSO when the consumer wants f32 (the proposal tail in the library: its SK
+// blocks read f32) -- `out` then leaves the bf16 product as f32 and the backward converts `d_out` once (a pass over 1.5 GB that
+// the two gradient products and the column sum repay twice over: -0.8 ms at cfg5).  io = false: that form.
 struct Io16 {
-  bool on = false;
+  bool on = false, io = false;      // io: `out` / `d_out` are bf16 tensors (AIT_CTX_IO_BF16)
   unsigned short *d3, *w, *wt;      // [M, D], [C2, D], [D, C2]
 };
 inline Io16 io16_plan(long long M, const Run& s, const AitBufs& a) {
   Io16 o;
-  if (!s.ctx || !(s.ctx->flags & AIT_CTX_IO_BF16)) return o;
+  if (!s.ctx || !(s.ctx->flags & AIT_CTX_BF16)) return o;
+  o.io = (s.ctx->flags & AIT_CTX_IO_BF16) != 0;
+  if (!o.io && !ait_lab::Knobs::dec_trans_bf16) return o;
   const Bf16Ffn f = bf16_ffn_plan(M, s, a.p_dec_w1, a.p_dec_w2);
   if (!f.on || !a.p_dec_trans.w.p) return o;
   if (!bf16_tn_split(C2, D, M, 0)) return o;      // (the weight gradient's rows: whole 32-row slabs per K-range)
@@ -781,7 +786,8 @@ inline unsigned saved_format(const Run& run, const AitBufs& a, int bp, int n_src
   if (qkv16_on(run, a.p_x_qkv, M)) f |= AIT_SAVED_X_QKV16;
   if (bf16_ffn_plan(Mc, run, a.p_enc_w1, a.p_enc_w2).on && a.p_enc_w1.wt.p) f |= AIT_SAVED_ENC_FFN16;
   if (bf16_ffn_plan(M, run, a.p_dec_w1, a.p_dec_w2).on && a.p_dec_w1.wt.p) f |= AIT_SAVED_DEC_FFN16;
-  if (io16_plan(M, run, a).on) f |= AIT_SAVED_IO16;
+  const Io16 io = io16_plan(M, run, a);
+  if (io.on) f |= io.io ? AIT_SAVED_IO16 : AIT_SAVED_DT16;
   return f;
 }
 
@@ -826,12 +832,13 @@ int ait_forward(const float* x_props, const float* x_query, int bp, int bs, int 
   }
   AIT_TRY(ffn_block(a.d2, M, w->dec_ffn, a.dec_ffn, p, ait_dropout_seed(seed, kSeedDecFfn), a.d3, run, a.p_dec_w1, a.p_dec_w2));
   // dec_trans back to 2d channels per token
-  if (run.ctx && (run.ctx->flags & AIT_CTX_IO_BF16)) {
-    const Io16 io = io16_plan(M, run, a);
-    if (!io.on) return AIT_EUNSUPPORTED;
+  const Io16 io = io16_plan(M, run, a);
+  if (run.ctx && (run.ctx->flags & AIT_CTX_IO_BF16) && !io.on) return AIT_EUNSUPPORTED;
+  if (io.on) {
     AIT_TRY(ait_f32_to_bf16(w->dec_trans_w, C2, D, D, io.w, D, 0, stream));
     AIT_TRY(ait_f32_to_bf16(a.d3, M, D, D, io.d3, D, 0, stream));
-    return ait_gemm_bf16s(M, C2, D, io.d3, D, io.w, D, nullptr, 0, out, C2, w->dec_trans_b, nullptr, nullptr, 0, 0, run.ctx, stream);
+    return ait_gemm_bf16s(M, C2, D, io.d3, D, io.w, D, io.io ? nullptr : out, C2, io.io ? out : nullptr, C2, w->dec_trans_b, nullptr,
+                          nullptr, 0, 0, run.ctx, stream);
   }
   return linear(a.d3, M, D, w->dec_trans_w, C2, w->dec_trans_b, false, out, run, a.p_dec_trans.w);
 }
@@ -938,21 +945,28 @@ static int ait_backward_parts(int parts, const float* d_out, const float* x_prop
 
   if (parts & 1) {
   // dec_trans: out = d3 W^T + b
-  if (ctx && (ctx->flags & AIT_CTX_IO_BF16)) {
-    // (d_out is a bf16 tensor; the forward of this step left d3's bf16 copy behind: same plan)
-    const Io16 io = io16_plan(M, run, a);
-    if (!io.on) return AIT_EUNSUPPORTED;
-    // (K-ranges of the weight gradient: as many as the block scratch holds partial tiles for)
+  const Io16 io = io16_plan(M, run, a);
+  if (ctx && (ctx->flags & AIT_CTX_IO_BF16) && !io.on) return AIT_EUNSUPPORTED;
+  if (io.on) {
+    // (the forward of this step left d3's bf16 copy behind: same plan.  d_out: a bf16 tensor, or f32 and converted here once)
     Bump bb = blk;
+    const void* d_out16 = d_out;
+    if (!io.io) {
+      float* cv = bb.take((size_t)M * C2 / 2);
+      if (!cv) return AIT_EWORKSPACE;
+      AIT_TRY(ait_f32_to_bf16(d_out, M, C2, C2, cv, C2, 0, stream));
+      d_out16 = cv;
+    }
+    // (K-ranges of the weight gradient: as many as the block scratch holds partial tiles for)
     const int sp = bf16_tn_split(C2, D, M, bb.left > 4096 ? bb.left - 4096 : 0);
     const size_t part_floats = (size_t)sp * C2 * D;
     float* part = bb.take(part_floats);
-    if (g->dec_trans_b) AIT_TRY(ait_colsum_bf16(d_out, M, C2, C2, g->dec_trans_b, stream));
+    if (g->dec_trans_b) AIT_TRY(ait_colsum_bf16(d_out16, M, C2, C2, g->dec_trans_b, stream));
     if (g->dec_trans_w)
-      AIT_TRY(ait_gemm_bf16s_tn(C2, D, M, d_out, C2, io.d3, D, g->dec_trans_w, D, sp, part, part ? part_floats * sizeof(float) : 0,
+      AIT_TRY(ait_gemm_bf16s_tn(C2, D, M, d_out16, C2, io.d3, D, g->dec_trans_w, D, sp, part, part ? part_floats * sizeof(float) : 0,
                                 ctx, stream));
     AIT_TRY(ait_f32_to_bf16(w->dec_trans_w, C2, D, D, io.wt, C2, 1, stream));
-    AIT_TRY(ait_gemm_bf16s(M, D, C2, d_out, C2, io.wt, C2, ga, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, ctx, stream));   // ga = d d3
+    AIT_TRY(ait_gemm_bf16s(M, D, C2, d_out16, C2, io.wt, C2, ga, D, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, ctx, stream));   // ga = d d3
   } else {
   if (g->dec_trans_b) AIT_TRY(ait_colsum_f32(d_out, M, C2, C2, g->dec_trans_b, stream));
   AIT_TRY(wgrad(d_out, M, C2, a.d3, D, g->dec_trans_w, run));

@@ -724,6 +724,7 @@ size_t ait_transformer_saved_bytes(int bp, int bs, int n_src);
 #define AIT_SAVED_ENC_FFN16 8u     /* encoder feed-forward: hidden tensor, input copy and weight copies stored as bf16 */
 #define AIT_SAVED_DEC_FFN16 16u    /* decoder feed-forward: likewise */
 #define AIT_SAVED_IO16 32u         /* dec_trans: bf16 copy of its input kept, `out` / `d_out` are bf16 tensors */
+#define AIT_SAVED_DT16 64u         /* (ABI v8) dec_trans: bf16 copy of its input kept, its products on bf16 operands; `out` / `d_out` f32 */
 int ait_transformer_fwd_train(const float* x_props, const float* x_query, int bp, int bs, int n_src,
                               const ait_transformer_weights* w, float p_drop, float p_attn_drop,
                               unsigned long long seed, void* saved, size_t saved_bytes, unsigned* saved_format,

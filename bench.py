@@ -602,6 +602,12 @@ def main():
         # (the CPU port is timed on the headline workload's pair: VOC variant, ResNet50)
         line["cpu_baseline"] = cpu_baseline(args.proposals)
         line["cpu_baseline"]["cpu_model"] = cpu_model()
+    # (RCCL writes its version banner through C stdio, which flushes at exit -- behind this line unless flushed first)
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(line), flush=True)
 
 

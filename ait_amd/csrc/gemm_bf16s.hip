@@ -110,29 +110,44 @@ __device__ __forceinline__ void wait_vm() {
 template <int CH>
 __device__ __forceinline__ int swz(int r) { return CH == 4 ? (r >> 2) & 3 : r & 7; }
 
-// what the epilogue does to four consecutive columns of one output row (after the bias): + addend, gate, ReLU, stores
+// The epilogue of four consecutive columns of one output row in TWO steps: epi_load fetches what it adds / gates with, epi_store
+// applies it (+ addend, gate, ReLU) and stores.  Two steps because the callers issue the loads of a whole group of outputs
+// first and the stores behind them: written as load-use-store per output, every load waits for the store in front of it (the
+// compiler cannot rule out that they alias: s_waitcnt vmcnt(0) on both sides, 64 dependent round trips per tile -- the
+// 512-deep products with an addend ran at 13-16 % MfmaUtil, profiles/r06_cfg5_bf16s_mfma_util.txt).
+struct EpiIn { uint2 r16; float4 r32; uint2 g16; float4 g32; };
 template <int EPI>
-__device__ __forceinline__ void epi_apply(const Args& g, int row, int col, float4 v) {
+__device__ __forceinline__ EpiIn epi_load(const Args& g, int row, int col) {
+  EpiIn in;      // (only what epi_store<EPI> reads under the same conditions is loaded; no zero fill: writes into registers a load
+                 // of the other branch targets would put a wait between the loads)
+  if constexpr (EPI == EPI_RES || EPI == EPI_RESGATE) {
+    if (g.res16) in.r16 = *reinterpret_cast<const uint2*>(g.res16 + (size_t)row * g.ldr + col);
+    else in.r32 = *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col);
+  }
+  if constexpr (EPI == EPI_GATE || EPI == EPI_RESGATE) {
+    if (EPI == EPI_RESGATE || g.gate16) in.g16 = *reinterpret_cast<const uint2*>(g.gate16 + (size_t)row * g.ldg + col);
+    else in.g32 = *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col);
+  }
+  return in;
+}
+template <int EPI>
+__device__ __forceinline__ void epi_store(const Args& g, int row, int col, float4 v, const EpiIn& in) {
   if constexpr (EPI == EPI_RES || EPI == EPI_RESGATE) {
     if (g.res16) {
-      const uint2 rv = *reinterpret_cast<const uint2*>(g.res16 + (size_t)row * g.ldr + col);
-      v.x += __uint_as_float(rv.x << 16); v.y += __uint_as_float(rv.x & 0xffff0000u);
-      v.z += __uint_as_float(rv.y << 16); v.w += __uint_as_float(rv.y & 0xffff0000u);
+      v.x += __uint_as_float(in.r16.x << 16); v.y += __uint_as_float(in.r16.x & 0xffff0000u);
+      v.z += __uint_as_float(in.r16.y << 16); v.w += __uint_as_float(in.r16.y & 0xffff0000u);
     } else {
-      const float4 rv = *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col);
-      v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      v.x += in.r32.x; v.y += in.r32.y; v.z += in.r32.z; v.w += in.r32.w;
     }
   }
   if constexpr (EPI == EPI_GATE || EPI == EPI_RESGATE) {
     if (EPI == EPI_RESGATE || g.gate16) {
-      const uint2 gv = *reinterpret_cast<const uint2*>(g.gate16 + (size_t)row * g.ldg + col);
       // (a bf16 value is positive iff its 16 bits, read as a signed short, are > 0: +0 is 0, negatives and -0 < 0)
-      v.x = (short)(gv.x & 0xffffu) > 0 ? v.x : 0.f; v.y = (short)(gv.x >> 16) > 0 ? v.y : 0.f;
-      v.z = (short)(gv.y & 0xffffu) > 0 ? v.z : 0.f; v.w = (short)(gv.y >> 16) > 0 ? v.w : 0.f;
+      v.x = (short)(in.g16.x & 0xffffu) > 0 ? v.x : 0.f; v.y = (short)(in.g16.x >> 16) > 0 ? v.y : 0.f;
+      v.z = (short)(in.g16.y & 0xffffu) > 0 ? v.z : 0.f; v.w = (short)(in.g16.y >> 16) > 0 ? v.w : 0.f;
     } else {
-      const float4 rv = *reinterpret_cast<const float4*>(g.residual + (size_t)row * g.ldr + col);
-      v.x = rv.x > 0.f ? v.x : 0.f; v.y = rv.y > 0.f ? v.y : 0.f;
-      v.z = rv.z > 0.f ? v.z : 0.f; v.w = rv.w > 0.f ? v.w : 0.f;
+      v.x = in.g32.x > 0.f ? v.x : 0.f; v.y = in.g32.y > 0.f ? v.y : 0.f;
+      v.z = in.g32.z > 0.f ? v.z : 0.f; v.w = in.g32.w > 0.f ? v.w : 0.f;
     }
   }
   if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(256) void cut_finish_kernel(const Args g, int tile0
       const float4 bb = *reinterpret_cast<const float4*>(g.bias + col);
       v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
     }
-    epi_apply<EPI>(g, row, col, v);
+    epi_store<EPI>(g, row, col, v, epi_load<EPI>(g, row, col));
   }
 }
 
@@ -325,17 +340,25 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {   
       for (int a = 0; a < 4; a++) {
         const int row = m0 + wm + a * 32 + li;
         const bool ok = row < g.M;
+        // the eight outputs of this row block: every load first (bias, addend, gate), then the arithmetic and the stores
+        float4 bb[2][4];
+        EpiIn in[2][4];
 #pragma unroll
         for (int b = 0; b < 2; b++)
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             const int col = n0 + wn + b * 32 + 8 * q + 4 * lk;
-            float4 v = make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
-            if (g.bias) {
-              const float4 bb = *reinterpret_cast<const float4*>(g.bias + col);
-              v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-            }
-            if (ok) epi_apply<EPI>(g, row, col, v);
+            bb[b][q] = g.bias ? *reinterpret_cast<const float4*>(g.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) in[b][q] = epi_load<EPI>(g, row, col);
+          }
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int col = n0 + wn + b * 32 + 8 * q + 4 * lk;
+            float4 v = make_float4(acc[a][b][4 * q] + bb[b][q].x, acc[a][b][4 * q + 1] + bb[b][q].y, acc[a][b][4 * q + 2] + bb[b][q].z,
+                                   acc[a][b][4 * q + 3] + bb[b][q].w);
+            if (ok) epi_store<EPI>(g, row, col, v, in[b][q]);
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[a][b][4 * q + r] = 0.f;
           }

@@ -127,3 +127,12 @@ def test_hot_gemm_kernels_do_not_spill():
             limit = 128 if int(m.group(1)) == 256 else 640
             assert scratch <= limit, "%s: %d bytes of scratch per lane (limit %d)" % (k, scratch, limit)
     assert seen >= 40
+    # ... and the bf16-storage kernels (csrc/gemm_bf16s.hip): two waves per SIMD, 128 accumulator registers -- every
+    # instantiation has fitted without scratch so far (a software-pipelined epilogue that did not: 150-316 bytes, and a
+    # last-round cut with plain 64-bit store addresses: 116-176, were both caught by reading this number)
+    seen16 = 0
+    for k, scratch in _kernel_scratch(os.path.join(build.OBJ, "gemm_bf16s.o")).items():
+        if "gemm_bf16s_kernel" in k or "gemm_bf16s_tn_kernel" in k:
+            seen16 += 1
+            assert scratch == 0, "%s: %d bytes of scratch per lane" % (k, scratch)
+    assert seen16 >= 30

@@ -340,7 +340,10 @@ __global__ __launch_bounds__(T::NT, 2) void gemm_bf16s_kernel(const Args g) {   
       for (int a = 0; a < 4; a++) {
         const int row = m0 + wm + a * 32 + li;
         const bool ok = row < g.M;
-        // the eight outputs of this row block: every load first (bias, addend, gate), then the arithmetic and the stores
+        // the eight outputs of this row block: every load first (bias, addend, gate), then the arithmetic and the stores.
+        // (Measured and NOT done: the bias once per tile in front of this loop -- 32 more registers live across all four
+        // blocks, no scratch reported, yet every product 1.4-1.7x slower: the allocator pays for them in the main loop;
+        // block a + 1's loads in front of block a's stores -- spills as long as the addend / gate types are run-time choices.)
         float4 bb[2][4];
         EpiIn in[2][4];
 #pragma unroll
